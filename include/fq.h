@@ -1,0 +1,130 @@
+/* fq.h -- C ABI of libfq_hip.so: the MI355X (gfx950) implementation of the pytorch-quantity hot path.
+ *
+ * The reference (lswzjuer/pytorch-quantity) is pure Python and has no FFI; this header is the
+ * boundary a maintainer would bind from the reference's Python modules with ctypes (the binding is
+ * shown in INTEGRATION.md and is what pytorch-quantity_amd/quantity/common/quantity/_native.py does).
+ * Every entry point names the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - Every function returns 0 (FQ_OK) or a negative fq_status; nothing throws.
+ *   - Pointers are DEVICE pointers (hipMalloc'ed / torch.cuda tensors' data_ptr()) unless the
+ *     parameter is documented "host".  The caller owns every buffer.
+ *   - All device work is enqueued on the passed hipStream_t (as void*; NULL = the null stream) and is
+ *     asynchronous; there is no hidden global state, so calls are thread-safe per stream and
+ *     capturable into a hipGraph.  No function allocates device memory.
+ *   - "row" = one histogram row.  Parity mode uses one row per hooked tensor (the reference's
+ *     calibrator is per tensor: distribution_collector.py:40-42); row = tensor x channel is the
+ *     same kernels with more rows.
+ */
+#ifndef FQ_H
+#define FQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQ_VERSION 100            /* 0.1.0 */
+#define FQ_BINS 2048              /* INTERVAL_NUM, tools/configs.yml:24 */
+#define FQ_KL_TARGET_BINS 128     /* quantizer.py:98 target_bin */
+#define FQ_KL_CANDIDATES 1920     /* thresholds 128..2047, quantizer.py:103 */
+#define FQ_MAX_SEGS 1024          /* per call */
+
+typedef void* fq_stream_t;        /* hipStream_t */
+
+typedef enum fq_status {
+    FQ_OK = 0,
+    FQ_ERR_INVALID_ARG = -1,
+    FQ_ERR_HIP = -2,              /* a HIP runtime call failed; fq_last_hip_error() has the code */
+    FQ_ERR_WORKSPACE = -3,        /* workspace too small */
+    FQ_ERR_UNSUPPORTED = -4
+} fq_status;
+
+/* One contiguous run of fp32 values that is accumulated into histogram row `row`.
+ * A tensor is one segment; several segments may share a row (multi-batch, merged groups). */
+typedef struct fq_seg {
+    const float* ptr;             /* device, 4-byte aligned (16-byte alignment is faster, not required) */
+    uint64_t n;                   /* elements; 0 allowed */
+    int32_t row;                  /* >= 0 */
+    int32_t reserved;             /* must be 0 */
+} fq_seg;
+
+int fq_version(void);
+const char* fq_status_string(int status);
+int fq_last_hip_error(void);      /* thread-local hipError_t of the last FQ_ERR_HIP */
+
+/* ---- calibration: abs-max, 2048-bin histogram -------------------------------------------- */
+
+/* distribution_collector.py:70-78 (refresh_max_val): for every segment,
+ *   max_inout[row] = max(max_inout[row], max |x|).
+ * max_inout is fp32[rows] on the device, zero-initialised by the caller before the first batch
+ * (the reference's running max starts at 0).  NaNs are ignored.  `segs` is a HOST array. */
+int fq_absmax_seg(const fq_seg* segs, int nseg, float* max_inout, fq_stream_t stream);
+
+/* distribution_collector.py:127-135 (_add_to_distribution) + :115-118 (accumulate):
+ *   for x != 0:  hist[row][ min( (int32) fl32(|x| / interval[row]), 2047 ) ] += 1
+ * with a correctly rounded fp32 divide.  interval is fp32[rows] on the device (computed by the
+ * caller exactly as distribution_collector.py:61, merged as pytorch_quantizer.py:396-411).
+ * hist is int64[rows][2048] on the device, accumulated into (caller zeroes it once).
+ * Deliberate deviation: the reference accumulates in int32 and wraps past 2^31-1 per bin; int64
+ * never wraps.  Quotients >= 2048 (pass 2 seeing larger values than pass 1), +inf and NaN land in
+ * bin 2047 (the reference raises IndexError for the last two). */
+int fq_hist2048_seg(const fq_seg* segs, int nseg, const float* interval, int64_t* hist,
+                    fq_stream_t stream);
+
+/* ---- calibration: KL threshold sweep ------------------------------------------------------ */
+
+size_t fq_kl_workspace_bytes(int rows);
+
+/* quantizer.py:95-96 (normalize_distribution) + :98-167 (threshold_distribution) + :169-174
+ * (compute_kl_divergence) for `rows` histograms at once:
+ *   thr_out[r] = the threshold bin t* in [128, 2047] minimising KL(P[:t] || expand(quantize(P,t)))
+ * in float64 with NumPy's pairwise summation order; first strict minimum wins.
+ * hist: int64[rows][2048] device (merged groups are summed by the caller beforehand; the
+ * reference's float64 merged form holds the same integers).  thr_out: int32[rows] device.
+ * kl_curve_out: NULL or float64[rows][1920] device, receives KL(t) for t = 128..2047.
+ * workspace: device scratch of fq_kl_workspace_bytes(rows). */
+int fq_kl_threshold(const int64_t* hist, int rows, int32_t* thr_out, double* kl_curve_out,
+                    void* workspace, size_t workspace_bytes, fq_stream_t stream);
+
+/* HOST helper (no device work): quantizer.py:86-90
+ *   thr_val = fl32((t + 0.5) * interval);  bits = 7 - ceil(log(thr_val) / log(2))
+ * evaluated with the host libm in float64 exactly as CPython's math.log(x, 2) does.
+ * All pointers are host pointers. */
+int fq_bits_from_threshold(const int32_t* thr, const float* interval, int rows,
+                           int32_t* bits_out, float* thr_val_out);
+
+/* HOST helper: pytorch_quantizer.py:651-653  bits = 7 - ceil(log(absmax)/log(2)). absmax > 0. */
+int fq_bits_from_absmax(const float* absmax, int n, int32_t* bits_out);
+
+/* ---- element-wise quantisation ops (new_quantity_op.py) ------------------------------------ */
+/* bitwidth is 8 or 16 (QUANTIZE_BIT, new_quantity_op.py:8): clamp range [-128,127] / [-32768,32767].
+ * In-place (y == x) is allowed for all of them. */
+
+/* QuanDequan.forward, new_quantity_op.py:246-257: clamp(rint(x * 2^bit)) / 2^bit */
+int fq_quandequan_f32(const float* x, float* y, size_t n, int bit, int bitwidth, fq_stream_t stream);
+/* Quantity.forward, :52-58: clamp(rint(x * 2^ib)) (round half to even) */
+int fq_quantity_f32(const float* x, float* y, size_t n, int ib, int bitwidth, fq_stream_t stream);
+/* DeQuantity.forward, :66-68: x / 2^ob */
+int fq_dequantity_f32(const float* x, float* y, size_t n, int ob, fq_stream_t stream);
+/* Sp.forward, :76-91: clamp(x) */
+int fq_sp_f32(const float* x, float* y, size_t n, int bitwidth, fq_stream_t stream);
+/* RightShift.forward, :17-44: v = x / 2^rs; clamp(trunc(v + (v > 0 ? 0.5 : -0.5))) (half away) */
+int fq_rightshift_f32(const float* x, float* y, size_t n, int rs, int bitwidth, fq_stream_t stream);
+/* NewAdd.forward, :171-174: clamp(a + b) */
+int fq_add_sat_f32(const float* a, const float* b, float* y, size_t n, int bitwidth,
+                   fq_stream_t stream);
+/* NewConv2d / NewLinear tail fused, :127-132: for acc[outer][C][inner]
+ *   y = clamp( RightShift(acc, rs) + qbias[c] ) / 2^ob      (qbias fp32[C], integer valued) */
+int fq_recon_epilogue_f32(const float* acc, const float* qbias, float* y, size_t outer, size_t C,
+                          size_t inner, int rs, int ob, int bitwidth, fq_stream_t stream);
+/* weight quantiser, pytorch_quantizer.py:656-657,:663: (int32) clip(around(w * 2^bit), -128, 127) */
+int fq_quantize_param_i32(const float* w, int32_t* q, size_t n, int bit, fq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FQ_H */

@@ -1,0 +1,150 @@
+"""Seeded input generators shared by the golden-capture script (make_golden_kernels.py) and by the
+tests that replay the same inputs through the oracle and through the HIP path.
+
+Every generator is pure numpy with a fixed PCG64 seed, so the inputs regenerate bit-identically
+wherever numpy is the same major version; the fixtures also carry a sha256 of each input so a
+silent generator drift is caught instead of producing a bogus parity failure.
+"""
+import hashlib
+
+import numpy as np
+
+BINS = 2048
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+# --------------------------------------------------------------------------------------------
+# G1: activation-like tensors for abs-max / interval / 2048-bin histogram
+#   each case = list of batches for pass 1 (max) and list of batches for pass 2 (histogram);
+#   normally the same list (the reference runs the same images twice).
+# --------------------------------------------------------------------------------------------
+
+def g1_cases():
+    c = {}
+
+    def normal(seed, n, scale=1.0):
+        return (_rng(seed).standard_normal(n, dtype=np.float32) * np.float32(scale)).astype(np.float32)
+
+    c["normal_1000"] = dict(p1=[normal(1, 1000)])
+    c["normal_100352"] = dict(p1=[normal(2, 100352)])
+    c["normal_802816"] = dict(p1=[normal(3, 802816, 3.7)])
+    c["normal_3batch"] = dict(p1=[normal(4, 100352), normal(5, 100352, 1.3), normal(6, 100352, 0.7)])
+    lap = _rng(7).laplace(0.0, 1.0, 100352).astype(np.float32)
+    c["laplace_100352"] = dict(p1=[lap])
+    c["relu_sparse"] = dict(p1=[np.maximum(normal(8, 100352), 0).astype(np.float32)])
+    c["all_zero"] = dict(p1=[np.zeros(1000, dtype=np.float32)])
+    o = normal(9, 50000, 0.01)
+    o[12345] = np.float32(1000.0)
+    c["single_outlier"] = dict(p1=[o])
+    c["n1"] = dict(p1=[np.array([-2.5], dtype=np.float32)])
+    c["n1_zero"] = dict(p1=[np.array([0.0], dtype=np.float32)])
+    c["tiny_values"] = dict(p1=[normal(10, 4096, 1e-10)])           # 1e-12 term of the interval matters
+    c["negative_only"] = dict(p1=[-np.abs(normal(11, 30000))])
+    c["ragged_1023"] = dict(p1=[normal(12, 1023, 5.0)])
+    c["ragged_4099"] = dict(p1=[normal(13, 4099, 0.3)])
+    # pass 2 sees larger values than pass 1 did (shuffle=True loader quirk): clamp to the last bin
+    c["pass2_exceeds"] = dict(p1=[normal(14, 20000)], p2=[normal(15, 20000, 2.0)])
+    # integers on exact bin edges: max = 2048 -> interval = 1 + 1e-12 -> fl32 = 1.0
+    e = np.arange(0, 2049, dtype=np.float32)
+    c["exact_edges"] = dict(p1=[e])
+    # uniform in (0, 1): every bin populated
+    c["uniform"] = dict(p1=[_rng(16).random(300000, dtype=np.float32)])
+    for k, v in c.items():
+        v.setdefault("p2", v["p1"])
+    return c
+
+
+# --------------------------------------------------------------------------------------------
+# G2: histograms for the KL threshold sweep.  dtype int32 = as the collector returns them;
+#     float64 = the merged-group form (np.zeros(2048) += int32 hists).
+# --------------------------------------------------------------------------------------------
+
+def g2_cases():
+    h = {}
+    j = np.arange(BINS, dtype=np.float64)
+    r = _rng(100)
+
+    def poisson(lam, seed):
+        return _rng(seed).poisson(lam).astype(np.int32)
+
+    h["gauss_s300"] = poisson(2e4 * np.exp(-0.5 * (j / 300.0) ** 2), 101)
+    h["gauss_s80"] = poisson(5e4 * np.exp(-0.5 * (j / 80.0) ** 2), 102)
+    h["gauss_s700"] = poisson(3e3 * np.exp(-0.5 * (j / 700.0) ** 2), 103)
+    h["laplace_b60"] = poisson(1e5 * np.exp(-j / 60.0), 104)
+    h["laplace_b250"] = poisson(2e4 * np.exp(-j / 250.0), 105)
+    h["heavy_tail"] = poisson(1e5 / (1.0 + (j / 20.0) ** 2), 106)
+    spike = np.zeros(BINS, dtype=np.int32)
+    spike[37] = 1000
+    h["spike_low"] = spike
+    spike2 = np.zeros(BINS, dtype=np.int32)
+    spike2[1500] = 77
+    h["spike_high"] = spike2
+    two = np.zeros(BINS, dtype=np.int32)
+    two[5] = 900
+    two[2047] = 3
+    h["spike_plus_lastbin"] = two
+    h["uniform_const"] = np.full(BINS, 123, dtype=np.int32)
+    h["uniform_noise"] = poisson(np.full(BINS, 150.0), 107)
+    h["empty"] = np.zeros(BINS, dtype=np.int32)
+    big = poisson(3e3 * np.exp(-0.5 * (j / 200.0) ** 2), 108).astype(np.int64) * 40000  # counts > 2^24
+    h["big_counts"] = np.minimum(big, 2**31 - 1).astype(np.int32)
+    sp = np.zeros(BINS, dtype=np.int32)
+    idx = r.choice(BINS, 90, replace=False)
+    sp[idx] = r.integers(1, 50, 90)
+    h["sparse_random"] = sp
+    first = np.zeros(BINS, dtype=np.int32)
+    first[:128] = poisson(np.full(128, 400.0), 109)
+    h["first128_only"] = first
+    lastheavy = poisson(2e4 * np.exp(-0.5 * (j / 150.0) ** 2), 110)
+    lastheavy[2047] = 50000
+    h["lastbin_heavy"] = lastheavy
+    h["relu_like"] = poisson(8e4 * np.exp(-j / 35.0) + 30.0 * np.exp(-0.5 * ((j - 900) / 200.0) ** 2), 111)
+    h["bimodal"] = poisson(4e3 * np.exp(-0.5 * ((j - 200) / 60.0) ** 2)
+                           + 2e3 * np.exp(-0.5 * ((j - 1200) / 150.0) ** 2), 112)
+    ones = np.ones(BINS, dtype=np.int32)
+    h["all_ones"] = ones
+    few = np.zeros(BINS, dtype=np.int32)
+    few[[0, 1, 2, 130, 131, 700]] = [5, 1, 1, 2, 1, 1]
+    h["few_samples"] = few
+    # merged-group (float64) forms
+    h["merged_f64_a"] = (h["gauss_s300"].astype(np.float64) + h["laplace_b60"].astype(np.float64))
+    h["merged_f64_b"] = (h["gauss_s80"].astype(np.float64) + h["heavy_tail"].astype(np.float64)
+                         + h["uniform_noise"].astype(np.float64))
+    h["merged_f64_big"] = h["big_counts"].astype(np.float64) * 3.0   # > 2^31 per bin, still integer valued
+    return h
+
+
+def g2_intervals():
+    """One fp32 interval per G2 case (only used for bits / threshold_value)."""
+    r = _rng(200)
+    names = list(g2_cases().keys())
+    iv = {}
+    for i, n in enumerate(names):
+        m = np.float32(np.exp(r.uniform(-4.0, 6.0)))
+        iv[n] = np.float32(1) * m / 2048 + 1e-12    # same expression shape as the reference
+        assert isinstance(iv[n], np.float32)
+    # exact powers of two for (t+0.5)*interval are unreachable (t+0.5 is odd/2), keep as is
+    return iv
+
+
+# --------------------------------------------------------------------------------------------
+# G5: element-wise op vectors (ties, negatives, saturation, negative shifts)
+# --------------------------------------------------------------------------------------------
+
+def g5_inputs():
+    r = _rng(300)
+    base = np.array([0.0, -0.0, 0.5, -0.5, 1.5, -1.5, 2.5, -2.5, 0.49999997, -0.49999997,
+                     126.5, 127.5, 128.5, -127.5, -128.5, -129.5, 1e-8, -1e-8, 300.0, -300.0,
+                     3.0, -3.0, 1.0, -1.0, 0.25, -0.25, 0.75, -0.75, 63.5, -63.5,
+                     32767.5, -32768.5, 40000.0, -40000.0], dtype=np.float32)
+    rnd = (r.standard_normal(2000, dtype=np.float32) * np.float32(40.0)).astype(np.float32)
+    ints = r.integers(-70000, 70000, 1000).astype(np.float32)      # integer-valued accumulators
+    halves = (r.integers(-600, 600, 500).astype(np.float32) + np.float32(0.5))
+    return np.concatenate([base, rnd, ints, halves]).astype(np.float32)
