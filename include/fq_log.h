@@ -12,7 +12,7 @@
  *
  * Contract: x finite and > 0 (normal or subnormal).  The KL sweep only ever calls it with
  * a/(b+1e-12)+1e-12 where a > 0, b > 0, so zero / negative / inf / nan never occur; for
- * completeness: x <= 0 or nan returns nan, +inf returns +inf.
+ * completeness, as np.log: x < 0 or nan returns nan, +-0 returns -inf, +inf returns +inf.
  *
  * Compile with -ffp-contract=off (both compilers): every fma below is explicit.
  */
@@ -105,7 +105,13 @@ FQ_LOG_FN double fq_log(double x) {
     uint64_t ux;
     memcpy(&ux, &x, 8);
     if (ux == 0x7ff0000000000000ULL) return x;                       /* +inf */
-    if ((ux >> 63) || ux == 0 || (ux & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL) {
+    if ((ux << 1) == 0) {                                            /* log(+-0) = -inf, as np.log */
+        uint64_t ni = 0xfff0000000000000ULL;
+        double r;
+        memcpy(&r, &ni, 8);
+        return r;
+    }
+    if ((ux >> 63) || (ux & 0x7fffffffffffffffULL) > 0x7ff0000000000000ULL) {
         uint64_t qn = 0x7ff8000000000000ULL;
         double r;
         memcpy(&r, &qn, 8);

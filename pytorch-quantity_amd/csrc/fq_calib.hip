@@ -1,0 +1,232 @@
+// fq_calib.hip -- calibration statistics for gfx950: segmented abs-max and 2048-bin histogram.
+//
+// Replaces the reference's per-element Python loop and per-call multiprocessing.Pool
+// (quantity/common/quantity/distribution_collector.py:70-78 and :80-142).  One launch covers every
+// hooked tensor of a forward pass ("segments"): blockIdx -> (segment, tile) through a prefix table
+// that travels in the kernel-argument block, so there is no per-tensor launch and no table memcpy.
+//
+// Both kernels are HBM-bound streaming reads (4 B per element, algorithmic bytes = 4 * elements):
+//   * 16-byte loads, 4 in flight per lane; tiles sized so that one launch has ~8 workgroups per CU.
+//   * histogram bins live in LDS (8 KB per workgroup, ds_add_u32); a workgroup flushes only its
+//     non-zero bins to the int64 global rows with 64-bit atomics (T*2048 counters, L2-resident).
+//   * abs-max keeps a per-lane running max, reduces across the wave with DPP shuffles, across waves
+//     through LDS, and publishes with one 32-bit atomic max on the (non-negative) float's bits.
+#include "fq_common.h"
+
+namespace fq {
+
+thread_local int g_last_hip_error = 0;
+
+constexpr int kSegChunk = 96;          // segments per launch (kernarg block stays < 4 KB)
+constexpr int kBlock = 256;            // 4 waves
+constexpr uint32_t kMinTile = 4096;    // elements
+constexpr uint32_t kMaxTile = 1u << 22;
+
+struct SegTable {
+    const float* ptr[kSegChunk];
+    uint64_t n[kSegChunk];
+    uint32_t tile_begin[kSegChunk + 1];   // exclusive prefix of tiles per segment
+    int32_t row[kSegChunk];
+    uint32_t tile_elems;                  // multiple of 4
+    int32_t nseg;
+};
+
+// blockIdx.x -> segment index (largest s with tile_begin[s] <= b). Uniform per workgroup.
+__device__ __forceinline__ int find_seg(const SegTable& t, uint32_t b) {
+    int lo = 0, hi = t.nseg - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (t.tile_begin[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+struct TileView {
+    const float* p;      // first element of this tile
+    uint64_t cnt;        // elements in this tile
+    int row;
+};
+
+__device__ __forceinline__ TileView tile_of(const SegTable& t) {
+    const uint32_t b = blockIdx.x;
+    const int s = find_seg(t, b);
+    const uint64_t off = (uint64_t)(b - t.tile_begin[s]) * t.tile_elems;
+    const uint64_t rem = t.n[s] - off;
+    TileView v;
+    v.p = t.ptr[s] + off;
+    v.cnt = rem < t.tile_elems ? rem : t.tile_elems;
+    v.row = t.row[s];
+    return v;
+}
+
+// Visit every element of the tile: scalar head until 16-B aligned, float4 body with 4 loads in
+// flight per lane, scalar tail.
+template <typename F>
+__device__ __forceinline__ void for_each_in_tile(const TileView& tv, F&& f) {
+    const int tid = threadIdx.x;
+    const float* p = tv.p;
+    uint64_t cnt = tv.cnt;
+    const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(p) & 15u) >> 2);
+    uint32_t head = mis ? 4u - mis : 0u;
+    if (head > cnt) head = (uint32_t)cnt;
+    if ((uint32_t)tid < head) f(p[tid]);
+    p += head;
+    cnt -= head;
+    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(p);
+    const uint64_t nvec = cnt >> 2;
+    uint64_t i = tid;
+    for (; i + 3 * kBlock < nvec; i += 4 * kBlock) {
+        const float4 a = v4[i];
+        const float4 b = v4[i + kBlock];
+        const float4 c = v4[i + 2 * kBlock];
+        const float4 d = v4[i + 3 * kBlock];
+        f(a.x); f(a.y); f(a.z); f(a.w);
+        f(b.x); f(b.y); f(b.z); f(b.w);
+        f(c.x); f(c.y); f(c.z); f(c.w);
+        f(d.x); f(d.y); f(d.z); f(d.w);
+    }
+    for (; i < nvec; i += kBlock) {
+        const float4 a = v4[i];
+        f(a.x); f(a.y); f(a.z); f(a.w);
+    }
+    const uint32_t tail = (uint32_t)(cnt & 3u);
+    if ((uint32_t)tid < tail) f(p[(nvec << 2) + tid]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// abs-max  (distribution_collector.py:70-78)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void absmax_seg_kernel(const SegTable tab, float* __restrict__ max_inout) {
+    __shared__ float s_wave[kBlock / kWave];
+    const TileView tv = tile_of(tab);
+    float m = 0.0f;
+    for_each_in_tile(tv, [&](float v) { m = fmaxf(m, fabsf(v)); });   // fmaxf drops NaN
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) s_wave[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
+        // m >= 0, so the IEEE bit pattern orders like an unsigned integer
+        atomicMax(reinterpret_cast<unsigned int*>(max_inout + tv.row), __float_as_uint(m));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2048-bin histogram of |x|, x != 0  (distribution_collector.py:127-135)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void hist2048_seg_kernel(const SegTable tab,
+                                                              const float* __restrict__ interval,
+                                                              unsigned long long* __restrict__ hist) {
+    __shared__ unsigned int s_bins[FQ_BINS];
+    for (int b = threadIdx.x; b < FQ_BINS; b += kBlock) s_bins[b] = 0u;
+    const TileView tv = tile_of(tab);
+    const float iv = interval[tv.row];
+    __syncthreads();
+    for_each_in_tile(tv, [&](float v) {
+        if (v != 0.0f) {
+            const float q = fabsf(v) / iv;              // IEEE correctly rounded fp32 divide
+            const int idx = (q < 2048.0f) ? (int)q : (FQ_BINS - 1);   // >= 2048, inf, nan -> last bin
+            atomicAdd(&s_bins[idx], 1u);                // ds_add_u32
+        }
+    });
+    __syncthreads();
+    unsigned long long* __restrict__ dst = hist + (size_t)tv.row * FQ_BINS;
+    for (int b = threadIdx.x; b < FQ_BINS; b += kBlock) {
+        const unsigned int c = s_bins[b];
+        if (c) atomicAdd(dst + b, (unsigned long long)c);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side: tiling and chunked launches
+// ---------------------------------------------------------------------------------------------
+static uint32_t pick_tile_elems(const fq_seg* segs, int nseg) {
+    uint64_t total = 0;
+    for (int i = 0; i < nseg; ++i) total += segs[i].n;
+    // aim for ~8 workgroups per CU over the whole call
+    uint64_t want = total / (uint64_t)(kCUs * 8);
+    uint32_t tile = kMinTile;
+    while (tile < want && tile < kMaxTile) tile <<= 1;
+    return tile;
+}
+
+static int validate(const fq_seg* segs, int nseg) {
+    if (nseg < 0 || nseg > FQ_MAX_SEGS) return FQ_ERR_INVALID_ARG;
+    if (nseg > 0 && segs == nullptr) return FQ_ERR_INVALID_ARG;
+    for (int i = 0; i < nseg; ++i) {
+        if (segs[i].row < 0 || segs[i].reserved != 0) return FQ_ERR_INVALID_ARG;
+        if (segs[i].n != 0 && segs[i].ptr == nullptr) return FQ_ERR_INVALID_ARG;
+        if (reinterpret_cast<uintptr_t>(segs[i].ptr) & 3u) return FQ_ERR_INVALID_ARG;
+    }
+    return FQ_OK;
+}
+
+template <typename Launch>
+static int for_each_chunk(const fq_seg* segs, int nseg, Launch&& launch) {
+    const uint32_t tile = pick_tile_elems(segs, nseg);
+    int i = 0;
+    while (i < nseg) {
+        SegTable tab;
+        tab.tile_elems = tile;
+        int k = 0;
+        uint64_t tiles = 0;
+        while (i < nseg && k < kSegChunk) {
+            const fq_seg& s = segs[i++];
+            if (s.n == 0) continue;
+            const uint64_t nt = (s.n + tile - 1) / tile;
+            if (tiles + nt > 0x7fffffffULL) { --i; break; }     // grid limit: start a new launch
+            tab.ptr[k] = s.ptr;
+            tab.n[k] = s.n;
+            tab.row[k] = s.row;
+            tab.tile_begin[k] = (uint32_t)tiles;
+            tiles += nt;
+            ++k;
+        }
+        if (k == 0) {
+            if (i < nseg && segs[i].n != 0) return FQ_ERR_INVALID_ARG;   // single segment over the grid limit
+            continue;
+        }
+        tab.tile_begin[k] = (uint32_t)tiles;
+        tab.nseg = k;
+        for (int j = k + 1; j <= kSegChunk; ++j) tab.tile_begin[j] = (uint32_t)tiles;
+        for (int j = k; j < kSegChunk; ++j) { tab.ptr[j] = nullptr; tab.n[j] = 0; tab.row[j] = 0; }
+        int rc = launch(tab, (uint32_t)tiles);
+        if (rc != FQ_OK) return rc;
+    }
+    return FQ_OK;
+}
+
+}  // namespace fq
+
+extern "C" int fq_absmax_seg(const fq_seg* segs, int nseg, float* max_inout, fq_stream_t stream) {
+    using namespace fq;
+    int rc = validate(segs, nseg);
+    if (rc != FQ_OK) return rc;
+    if (nseg == 0) return FQ_OK;
+    if (max_inout == nullptr) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    return for_each_chunk(segs, nseg, [&](const SegTable& tab, uint32_t tiles) -> int {
+        hipLaunchKernelGGL(absmax_seg_kernel, dim3(tiles), dim3(kBlock), 0, st, tab, max_inout);
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    });
+}
+
+extern "C" int fq_hist2048_seg(const fq_seg* segs, int nseg, const float* interval, int64_t* hist,
+                               fq_stream_t stream) {
+    using namespace fq;
+    int rc = validate(segs, nseg);
+    if (rc != FQ_OK) return rc;
+    if (nseg == 0) return FQ_OK;
+    if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    return for_each_chunk(segs, nseg, [&](const SegTable& tab, uint32_t tiles) -> int {
+        hipLaunchKernelGGL(hist2048_seg_kernel, dim3(tiles), dim3(kBlock), 0, st, tab, interval,
+                           reinterpret_cast<unsigned long long*>(hist));
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    });
+}

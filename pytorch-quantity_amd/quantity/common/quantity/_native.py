@@ -1,0 +1,247 @@
+"""ctypes binding of libfq_hip.so (include/fq.h) for torch.cuda tensors.
+
+This is the only place the Python drop-in modules touch native code.  There is deliberately no CPU
+fallback: if the HIP library is missing or a tensor is not on the GPU, the call raises.
+PyTorch is used here for device memory and the current HIP stream only.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+BINS = 2048
+KL_CANDIDATES = 1920
+
+_PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libfq_hip.so")
+
+
+class FqError(RuntimeError):
+    pass
+
+
+class _Seg(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("n", ctypes.c_uint64), ("row", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libfq_hip.so or fail loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise FqError(
+            "libfq_hip.so not found at %s. Build it with `make -C pytorch-quantity_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.fq_version.restype = ci
+    L.fq_status_string.restype = ctypes.c_char_p
+    L.fq_status_string.argtypes = [ci]
+    L.fq_last_hip_error.restype = ci
+    L.fq_absmax_seg.restype = ci
+    L.fq_absmax_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp]
+    L.fq_hist2048_seg.restype = ci
+    L.fq_hist2048_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp, vp]
+    L.fq_kl_workspace_bytes.restype = sz
+    L.fq_kl_workspace_bytes.argtypes = [ci]
+    L.fq_kl_threshold.restype = ci
+    L.fq_kl_threshold.argtypes = [vp, ci, vp, vp, vp, sz, vp]
+    L.fq_bits_from_threshold.restype = ci
+    L.fq_bits_from_threshold.argtypes = [vp, vp, ci, vp, vp]
+    L.fq_bits_from_absmax.restype = ci
+    L.fq_bits_from_absmax.argtypes = [vp, ci, vp]
+    for name in ("fq_quandequan_f32", "fq_quantity_f32", "fq_rightshift_f32"):
+        getattr(L, name).restype = ci
+        getattr(L, name).argtypes = [vp, vp, sz, ci, ci, vp]
+    L.fq_dequantity_f32.restype = ci
+    L.fq_dequantity_f32.argtypes = [vp, vp, sz, ci, vp]
+    L.fq_sp_f32.restype = ci
+    L.fq_sp_f32.argtypes = [vp, vp, sz, ci, vp]
+    L.fq_add_sat_f32.restype = ci
+    L.fq_add_sat_f32.argtypes = [vp, vp, vp, sz, ci, vp]
+    L.fq_recon_epilogue_f32.restype = ci
+    L.fq_recon_epilogue_f32.argtypes = [vp, vp, vp, sz, sz, sz, ci, ci, ci, vp]
+    L.fq_quantize_param_i32.restype = ci
+    L.fq_quantize_param_i32.argtypes = [vp, vp, sz, ci, vp]
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc != 0:
+        L = lib()
+        raise FqError("%s failed: %s (hip error %d)" % (what, L.fq_status_string(rc).decode(), L.fq_last_hip_error()))
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _need_cuda(t, dtype, what):
+    if not isinstance(t, torch.Tensor) or t.device.type != "cuda":
+        raise FqError("%s: expected a torch.cuda tensor (the MI355X path has no CPU fallback)" % what)
+    if t.dtype != dtype:
+        raise FqError("%s: expected dtype %s, got %s" % (what, dtype, t.dtype))
+
+
+def dense_view(t):
+    """A tensor whose storage is one dense run (any permutation of a contiguous layout, e.g.
+    channels_last) can be histogrammed in storage order; anything else is made contiguous."""
+    if t.is_contiguous():
+        return t
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return t
+    return t.contiguous()
+
+
+def _seg_array(tensors, rows):
+    n = len(tensors)
+    arr = (_Seg * max(n, 1))()
+    keep = []
+    for i, (t, r) in enumerate(zip(tensors, rows)):
+        _need_cuda(t, torch.float32, "segment %d" % i)
+        d = dense_view(t)
+        keep.append(d)
+        arr[i].ptr = d.data_ptr()
+        arr[i].n = d.numel()
+        arr[i].row = int(r)
+        arr[i].reserved = 0
+    return arr, keep
+
+
+def absmax_seg(tensors, rows, max_inout):
+    """max_inout[row] = max(max_inout[row], max|x|) for every (tensor, row).  fq_absmax_seg."""
+    if not tensors:
+        return
+    _need_cuda(max_inout, torch.float32, "max_inout")
+    arr, keep = _seg_array(tensors, rows)
+    assert max(int(r) for r in rows) < max_inout.numel()
+    _check(lib().fq_absmax_seg(arr, len(tensors), max_inout.data_ptr(), _stream(max_inout)), "fq_absmax_seg")
+    return keep
+
+
+def hist2048_seg(tensors, rows, interval, hist):
+    """hist[row] += 2048-bin histogram of |x|/interval[row], x != 0.  fq_hist2048_seg."""
+    if not tensors:
+        return
+    _need_cuda(interval, torch.float32, "interval")
+    _need_cuda(hist, torch.int64, "hist")
+    assert hist.is_contiguous() and hist.shape[-1] == BINS
+    assert max(int(r) for r in rows) < hist.numel() // BINS and interval.numel() >= hist.numel() // BINS
+    arr, keep = _seg_array(tensors, rows)
+    _check(lib().fq_hist2048_seg(arr, len(tensors), interval.data_ptr(), hist.data_ptr(), _stream(hist)),
+           "fq_hist2048_seg")
+    return keep
+
+
+def kl_threshold(hist, want_curve=False):
+    """Threshold bin per row (int32 cuda tensor); optionally the [rows,1920] float64 KL curves."""
+    _need_cuda(hist, torch.int64, "hist")
+    assert hist.is_contiguous() and hist.dim() == 2 and hist.shape[1] == BINS
+    rows = hist.shape[0]
+    thr = torch.empty(rows, dtype=torch.int32, device=hist.device)
+    if rows == 0:
+        return (thr, torch.empty(0, KL_CANDIDATES, dtype=torch.float64, device=hist.device)) if want_curve else thr
+    wsb = lib().fq_kl_workspace_bytes(rows)
+    ws = torch.empty(wsb // 8, dtype=torch.float64, device=hist.device)
+    curve = torch.empty(rows, KL_CANDIDATES, dtype=torch.float64, device=hist.device) if want_curve else None
+    _check(lib().fq_kl_threshold(hist.data_ptr(), rows, thr.data_ptr(), curve.data_ptr() if want_curve else None,
+                                 ws.data_ptr(), wsb, _stream(hist)), "fq_kl_threshold")
+    return (thr, curve) if want_curve else thr
+
+
+def bits_from_threshold(thr, interval):
+    """Host helper: (bits int32[], threshold_value float32[]) from threshold bins and fp32 intervals."""
+    thr = np.ascontiguousarray(thr, dtype=np.int32)
+    interval = np.ascontiguousarray(interval, dtype=np.float32)
+    bits = np.empty(thr.shape, dtype=np.int32)
+    tv = np.empty(thr.shape, dtype=np.float32)
+    _check(lib().fq_bits_from_threshold(thr.ctypes.data, interval.ctypes.data, thr.size, bits.ctypes.data,
+                                        tv.ctypes.data), "fq_bits_from_threshold")
+    return bits, tv
+
+
+def bits_from_absmax(absmax):
+    absmax = np.ascontiguousarray(absmax, dtype=np.float32)
+    bits = np.empty(absmax.shape, dtype=np.int32)
+    _check(lib().fq_bits_from_absmax(absmax.ctypes.data, absmax.size, bits.ctypes.data), "fq_bits_from_absmax")
+    return bits
+
+
+def _out_like(x, out):
+    if out is None:
+        return torch.empty_like(x, memory_format=torch.contiguous_format)
+    _need_cuda(out, torch.float32, "out")
+    assert out.is_contiguous() and out.numel() == x.numel()
+    return out
+
+
+def _unary(fn_name, x, ints, out):
+    _need_cuda(x, torch.float32, fn_name)
+    xc = x if x.is_contiguous() else x.contiguous()
+    y = _out_like(xc, out)
+    _check(getattr(lib(), fn_name)(xc.data_ptr(), y.data_ptr(), xc.numel(), *ints, _stream(xc)), fn_name)
+    return y.view(x.shape) if y.shape != x.shape else y
+
+
+def quandequan(x, bit, bitwidth=8, out=None):
+    return _unary("fq_quandequan_f32", x, (int(bit), int(bitwidth)), out)
+
+
+def quantity(x, ib, bitwidth=8, out=None):
+    return _unary("fq_quantity_f32", x, (int(ib), int(bitwidth)), out)
+
+
+def dequantity(x, ob, out=None):
+    return _unary("fq_dequantity_f32", x, (int(ob),), out)
+
+
+def sp(x, bitwidth=8, out=None):
+    return _unary("fq_sp_f32", x, (int(bitwidth),), out)
+
+
+def rightshift(x, rs, bitwidth=8, out=None):
+    return _unary("fq_rightshift_f32", x, (int(rs), int(bitwidth)), out)
+
+
+def add_sat(a, b, bitwidth=8, out=None):
+    _need_cuda(a, torch.float32, "fq_add_sat_f32")
+    _need_cuda(b, torch.float32, "fq_add_sat_f32")
+    if a.shape != b.shape:
+        a, b = torch.broadcast_tensors(a, b)
+    ac = a.contiguous()
+    bc = b.contiguous()
+    y = _out_like(ac, out)
+    _check(lib().fq_add_sat_f32(ac.data_ptr(), bc.data_ptr(), y.data_ptr(), ac.numel(), int(bitwidth), _stream(ac)),
+           "fq_add_sat_f32")
+    return y
+
+
+def recon_epilogue(acc, qbias, rs, ob, bitwidth=8, out=None):
+    """acc: [N, C, ...] fp32 (conv/linear accumulator), qbias: fp32[C] integer valued."""
+    _need_cuda(acc, torch.float32, "fq_recon_epilogue_f32")
+    _need_cuda(qbias, torch.float32, "fq_recon_epilogue_f32")
+    ac = acc.contiguous()
+    C = ac.shape[1]
+    assert qbias.numel() == C
+    outer = ac.shape[0]
+    inner = ac.numel() // (outer * C) if ac.numel() else 0
+    y = _out_like(ac, out)
+    _check(lib().fq_recon_epilogue_f32(ac.data_ptr(), qbias.contiguous().data_ptr(), y.data_ptr(), outer, C, inner,
+                                       int(rs), int(ob), int(bitwidth), _stream(ac)), "fq_recon_epilogue_f32")
+    return y
+
+
+def quantize_param_i32(w, bit):
+    _need_cuda(w, torch.float32, "fq_quantize_param_i32")
+    wc = w.contiguous()
+    q = torch.empty(wc.shape, dtype=torch.int32, device=w.device)
+    _check(lib().fq_quantize_param_i32(wc.data_ptr(), q.data_ptr(), wc.numel(), int(bit), _stream(wc)),
+           "fq_quantize_param_i32")
+    return q

@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""Kernel-level microbenchmark (GPU box): achieved algorithmic GB/s of the calibration and
+fake-quant kernels on R50-shaped segment lists.  Not the contract bench (that is bench.py)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity"))
+from common.quantity import _native as nat  # noqa: E402
+
+
+def timeit(fn, iters=20, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in ev)
+    return ts[len(ts) // 2], ts[0]
+
+
+def r50_like_segments(batch, dist="normal"):
+    # cared-tensor sizes of a fabu ResNet-50 @224 (elements per image)
+    sizes = [150528, 802816] + [200704, 200704, 802816, 802816, 802816] + [200704, 200704, 802816, 802816] * 2 \
+        + [401408, 100352, 401408, 401408, 401408] + [100352, 100352, 401408, 401408] * 3 \
+        + [200704, 50176, 200704, 200704, 200704] + [50176, 50176, 200704, 200704] * 5 \
+        + [100352, 25088, 100352, 100352, 100352] + [25088, 25088, 100352, 100352] * 2 + [1000]
+    segs = []
+    for i, s in enumerate(sizes):
+        n = s * batch
+        if dist == "normal":
+            t = torch.randn(n, device="cuda") * (1.0 + (i % 5))
+        elif dist == "outlier":
+            t = torch.randn(n, device="cuda")
+            t[0] = 60.0
+        else:
+            t = torch.relu(torch.randn(n, device="cuda"))
+        segs.append(t)
+    return segs
+
+
+def main():
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    print("fq version", nat.lib().fq_version(), "device", torch.cuda.get_device_name(0))
+    for dist in ("normal", "outlier", "relu"):
+        segs = r50_like_segments(batch, dist)
+        rows = list(range(len(segs)))
+        nel = sum(s.numel() for s in segs)
+        mx = torch.zeros(len(segs), device="cuda")
+        ms, best = timeit(lambda: nat.absmax_seg(segs, rows, mx))
+        print("[%s] absmax_seg  : %d segs %.1f Melem  med %.3f ms  (%.0f GB/s, best %.0f)" %
+              (dist, len(segs), nel / 1e6, ms, nel * 4 / ms / 1e6, nel * 4 / best / 1e6))
+        iv = (mx / 2048 + 1e-12).float()
+        hist = torch.zeros(len(segs), 2048, dtype=torch.int64, device="cuda")
+        ms, best = timeit(lambda: nat.hist2048_seg(segs, rows, iv, hist))
+        print("[%s] hist2048_seg: med %.3f ms  (%.0f GB/s, best %.0f)" % (dist, ms, nel * 4 / ms / 1e6, nel * 4 / best / 1e6))
+        if dist == "normal":
+            t0 = time.perf_counter()
+            thr = nat.kl_threshold(hist)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ms, best = timeit(lambda: nat.kl_threshold(hist), iters=5, warmup=1)
+            print("kl_threshold rows=%d: first %.1f ms, med %.2f ms; thr[:8]=%s" %
+                  (len(segs), (t1 - t0) * 1e3, ms, thr[:8].tolist()))
+        del segs
+    x = torch.randn(64 * 802816, device="cuda")
+    y = torch.empty_like(x)
+    ms, best = timeit(lambda: nat.quandequan(x, 4, out=y))
+    print("quandequan   : %.1f Melem med %.3f ms (%.0f GB/s rd+wr, best %.0f)" %
+          (x.numel() / 1e6, ms, x.numel() * 8 / ms / 1e6, x.numel() * 8 / best / 1e6))
+    ms, best = timeit(lambda: nat.add_sat(x, y, out=y))
+    print("add_sat      : med %.3f ms (%.0f GB/s 2rd+wr)" % (ms, x.numel() * 12 / ms / 1e6))
+    ms, best = timeit(lambda: torch.clamp(torch.round(x * 16), -128, 127) / 16)
+    print("torch 4-op quandequan reference: med %.3f ms" % ms)
+    ms, best = timeit(lambda: y.copy_(x))
+    print("torch copy   : med %.3f ms (%.0f GB/s rd+wr)" % (ms, x.numel() * 8 / ms / 1e6))
+
+
+if __name__ == "__main__":
+    main()

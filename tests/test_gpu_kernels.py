@@ -1,0 +1,279 @@
+"""Parity of the HIP kernels (through the C ABI, via common.quantity._native) against the CPU oracle
+and the committed golden vectors.  Needs a real MI355X:  pytest -m gpu"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from common.quantity import _native
+    _native.lib()
+    return _native
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+# ---------------------------------------------------------------- G1 goldens through the HIP path
+@pytest.mark.parametrize("name", list(cases.g1_cases().keys()))
+def test_g1_golden_absmax_hist(nat, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, "g1_hist.npz"))
+    case = cases.g1_cases()[name]
+    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    for b in case["p1"]:
+        nat.absmax_seg([_dev(b)], [0], mx)
+    m = mx.cpu().numpy()[0]
+    assert np.float32(g[name + "/max"]) == m
+    # interval exactly as the host code computes it (numpy fp32, reference expression shape)
+    iv = np.float32(1) * np.float32(m) / 2048 + 1e-12 if m != 0 else np.float32(1e-12)
+    assert np.float32(g[name + "/interval"]) == np.float32(iv)
+    hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+    ivd = _dev(np.array([iv], dtype=np.float32))
+    for b in case["p2"]:
+        nat.hist2048_seg([_dev(b)], [0], ivd, hist)
+    np.testing.assert_array_equal(hist.cpu().numpy()[0], g[name + "/hist"].astype(np.int64))
+
+
+# ---------------------------------------------------------------- segmented launches vs oracle
+def _random_segments(rng, nseg, nrows, max_n):
+    segs, rows = [], []
+    for i in range(nseg):
+        n = int(rng.integers(0, max_n)) if i % 7 else int(rng.integers(0, 5))
+        kind = i % 4
+        if kind == 0:
+            x = rng.standard_normal(n, dtype=np.float32) * np.float32(np.exp(rng.uniform(-3, 3)))
+        elif kind == 1:
+            x = np.maximum(rng.standard_normal(n, dtype=np.float32), 0)
+        elif kind == 2:
+            x = rng.laplace(0, 1, n).astype(np.float32)
+        else:
+            x = (rng.random(n, dtype=np.float32) - np.float32(0.5))
+        segs.append(x.astype(np.float32))
+        rows.append(int(rng.integers(0, nrows)))
+    return segs, rows
+
+
+@pytest.mark.parametrize("seed,nseg,nrows,max_n", [(0, 5, 3, 5000), (1, 71, 71, 200000), (2, 139, 40, 60000),
+                                                   (3, 230, 230, 3000)])
+def test_segmented_absmax_hist_vs_oracle(nat, oracle, seed, nseg, nrows, max_n):
+    rng = np.random.default_rng(seed)
+    segs, rows = _random_segments(rng, nseg, nrows, max_n)
+    dsegs = [_dev(s) for s in segs]
+    mx = torch.zeros(nrows, dtype=torch.float32, device="cuda")
+    nat.absmax_seg(dsegs, rows, mx)
+    ref_m = np.zeros(nrows, dtype=np.float32)
+    for s, r in zip(segs, rows):
+        ref_m[r] = oracle.absmax(s, ref_m[r])
+    np.testing.assert_array_equal(mx.cpu().numpy(), ref_m)
+    iv = np.array([oracle.interval(m) for m in ref_m], dtype=np.float32)
+    hist = torch.zeros(nrows, 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_seg(dsegs, rows, _dev(iv), hist)
+    nat.hist2048_seg(dsegs, rows, _dev(iv), hist)          # accumulate twice
+    ref_h = np.zeros((nrows, 2048), dtype=np.int64)
+    for s, r in zip(segs, rows):
+        oracle.hist2048(s, iv[r], ref_h[r])
+    np.testing.assert_array_equal(hist.cpu().numpy(), 2 * ref_h)
+
+
+def test_unaligned_and_strided_inputs(nat, oracle):
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal(100003, dtype=np.float32)
+    d = _dev(base)
+    views = [d[1:], d[2:50001], d[3:7], d[5:5], d[7:100000]]
+    hosts = [base[1:], base[2:50001], base[3:7], base[5:5], base[7:100000]]
+    rows = [0, 1, 2, 3, 1]
+    mx = torch.zeros(4, dtype=torch.float32, device="cuda")
+    nat.absmax_seg(views, rows, mx)
+    ref_m = np.zeros(4, dtype=np.float32)
+    for s, r in zip(hosts, rows):
+        ref_m[r] = oracle.absmax(s, ref_m[r])
+    np.testing.assert_array_equal(mx.cpu().numpy(), ref_m)
+    iv = np.array([oracle.interval(m) for m in ref_m], dtype=np.float32)
+    hist = torch.zeros(4, 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_seg(views, rows, _dev(iv), hist)
+    ref_h = np.zeros((4, 2048), dtype=np.int64)
+    for s, r in zip(hosts, rows):
+        oracle.hist2048(s, iv[r], ref_h[r])
+    np.testing.assert_array_equal(hist.cpu().numpy(), ref_h)
+    # channels_last tensors are dense: histogram in storage order equals histogram of the values
+    x = torch.randn(4, 8, 5, 7, device="cuda").to(memory_format=torch.channels_last)
+    h2 = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+    m2 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    nat.absmax_seg([x], [0], m2)
+    iv2 = np.array([oracle.interval(m2.cpu().numpy()[0])], dtype=np.float32)
+    nat.hist2048_seg([x], [0], _dev(iv2), h2)
+    np.testing.assert_array_equal(h2.cpu().numpy()[0], oracle.hist2048(x.cpu().numpy().ravel(), iv2[0]))
+
+
+def test_special_values(nat, oracle):
+    x = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, 2047.9999, 2048.0, 5000.0, 1e-30, -1e-30, 0.99999994],
+                 dtype=np.float32)
+    iv = np.array([1.0], dtype=np.float32)
+    hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_seg([_dev(x)], [0], _dev(iv), hist)
+    np.testing.assert_array_equal(hist.cpu().numpy()[0], oracle.hist2048(x, iv[0]))
+    mx = torch.zeros(1, dtype=torch.float32, device="cuda")
+    nat.absmax_seg([_dev(np.array([np.nan, -3.0, 2.0, np.nan], dtype=np.float32))], [0], mx)
+    assert mx.item() == 3.0
+
+
+def test_full_size_properties(nat):
+    """BASELINE-size segments (802816 x 32 elements): size-independent invariants."""
+    torch.manual_seed(0)
+    a = torch.randn(802816 * 32, device="cuda")
+    b = torch.randn(802816 * 8, device="cuda") * 3
+    mx = torch.zeros(2, dtype=torch.float32, device="cuda")
+    nat.absmax_seg([a, b], [0, 1], mx)
+    assert mx[0].item() == a.abs().max().item() and mx[1].item() == b.abs().max().item()
+    nat.absmax_seg([a, b], [0, 1], mx)                      # idempotent
+    assert mx[0].item() == a.abs().max().item()
+    iv = (mx / 2048 + 1e-12).float()
+    h = torch.zeros(2, 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_seg([a, b], [0, 1], iv, h)
+    assert h[0].sum().item() == int((a != 0).sum().item())
+    assert h[1].sum().item() == int((b != 0).sum().item())
+    # linearity: histogram of the concatenation under one interval = sum of the parts
+    iv3 = torch.stack([iv[1], iv[1], iv[1]])
+    hp = torch.zeros(3, 2048, dtype=torch.int64, device="cuda")
+    half = b.numel() // 2 + 3
+    nat.hist2048_seg([b[:half], b[half:], b], [0, 0, 1], iv3, hp)
+    assert torch.equal(hp[0], hp[1])
+    # cross-check against torch's own binning of the correctly rounded quotient
+    q = (b.abs() / iv[1])
+    idx = torch.clamp(q.to(torch.int64), max=2047)[b != 0]
+    ref = torch.bincount(idx, minlength=2048)
+    assert torch.equal(hp[1], ref)
+
+
+# ---------------------------------------------------------------- KL sweep
+G2_NAMES = list(cases.g2_cases().keys())
+
+
+def test_kl_threshold_golden_and_oracle(nat, oracle, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g2_kl.npz"))
+    hs = cases.g2_cases()
+    H = np.stack([np.asarray(hs[n]).astype(np.int64) for n in G2_NAMES])
+    thr, curve = nat.kl_threshold(_dev(H), want_curve=True)
+    thr = thr.cpu().numpy()
+    curve = curve.cpu().numpy()
+    for i, n in enumerate(G2_NAMES):
+        assert thr[i] == int(g[n + "/thr"]), n
+        p = oracle.normalize(hs[n])
+        t_or, c_or = oracle.kl_threshold(p, want_curve=True, use_fq_log=True)
+        assert t_or == thr[i]
+        # same source log (include/fq_log.h) on both sides: the KL curve must match bit for bit
+        np.testing.assert_array_equal(np.isnan(curve[i]), np.isnan(c_or), err_msg=n)
+        f = ~np.isnan(c_or)
+        np.testing.assert_array_equal(curve[i][f].view(np.uint64), c_or[f].view(np.uint64), err_msg=n)
+    iv = np.array([g[n + "/interval"] for n in G2_NAMES], dtype=np.float32)
+    bits, tv = nat.bits_from_threshold(thr, iv)
+    for i, n in enumerate(G2_NAMES):
+        assert bits[i] == int(g[n + "/bits"]) and tv[i] == np.float32(g[n + "/thr_val"]), n
+
+
+def test_kl_threshold_random_rows_vs_oracle(nat, oracle):
+    rng = np.random.default_rng(7)
+    rows = []
+    j = np.arange(2048)
+    for k in range(24):
+        s = np.exp(rng.uniform(np.log(20), np.log(900)))
+        lam = np.exp(rng.uniform(2, 12)) * np.exp(-0.5 * (j / s) ** 2) + (rng.random() < 0.3) * rng.uniform(0, 3)
+        h = rng.poisson(lam).astype(np.int64)
+        if k % 5 == 0:
+            h[rng.integers(0, 2048, 40)] = 0
+        rows.append(h)
+    H = np.stack(rows)
+    thr, curve = nat.kl_threshold(_dev(H), want_curve=True)
+    thr = thr.cpu().numpy()
+    curve = curve.cpu().numpy()
+    for i in range(len(rows)):
+        p = oracle.normalize(H[i])
+        t_libm = oracle.kl_threshold(p)                      # numpy-faithful log
+        t_fq, c_fq = oracle.kl_threshold(p, want_curve=True, use_fq_log=True)
+        assert thr[i] == t_fq == t_libm
+        f = ~np.isnan(c_fq)
+        np.testing.assert_array_equal(curve[i][f].view(np.uint64), c_fq[f].view(np.uint64))
+
+
+# ---------------------------------------------------------------- element-wise ops
+def test_g5_ops_golden(nat, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_ops.npz"))
+    x = _dev(g["x"])
+    for key in g.files:
+        parts = key.split("/")
+        if parts[0] == "quantity":
+            if int(parts[1]) < -120:
+                continue
+            got = nat.quantity(x, int(parts[1]))
+        elif parts[0] == "dequantity":
+            got = nat.dequantity(x, int(parts[1]))
+        elif parts[0] == "quandequan":
+            got = nat.quandequan(x, int(parts[2]), int(parts[1]))
+        elif parts[0] == "rightshift":
+            got = nat.rightshift(x, int(parts[2]), int(parts[1]))
+        elif parts[0] == "sp":
+            got = nat.sp(x, int(parts[1]))
+        elif parts[0] == "newadd":
+            got = nat.add_sat(x, torch.flip(x, dims=[0]))
+        else:
+            continue
+        np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32), g[key].view(np.uint32), err_msg=key)
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 4, 5, 1023, 4099, 1 << 20])
+def test_ops_vs_oracle_sizes(nat, oracle, n):
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n, dtype=np.float32) * np.float32(50)).astype(np.float32)
+    y = (rng.standard_normal(n, dtype=np.float32) * np.float32(90)).astype(np.float32)
+    dx, dy = _dev(x), _dev(y)
+    for bw in (8, 16):
+        for bit in (-2, 0, 4, 9):
+            np.testing.assert_array_equal(nat.quandequan(dx, bit, bw).cpu().numpy(), oracle.quandequan(x, bit, bw))
+            np.testing.assert_array_equal(nat.quantity(dx, bit, bw).cpu().numpy(), oracle.quantity(x, bit, bw))
+            np.testing.assert_array_equal(nat.rightshift(dx, bit, bw).cpu().numpy(), oracle.rightshift(x, bit, bw))
+        np.testing.assert_array_equal(nat.sp(dx, bw).cpu().numpy(), oracle.sp(x, bw))
+        np.testing.assert_array_equal(nat.add_sat(dx, dy, bw).cpu().numpy(), oracle.add_sat(x, y, bw))
+    np.testing.assert_array_equal(nat.dequantity(dx, 5).cpu().numpy(), oracle.dequantity(x, 5))
+    if n >= 4:       # unaligned views
+        np.testing.assert_array_equal(nat.quandequan(dx[1:], 3).cpu().numpy(), oracle.quandequan(x[1:], 3))
+    # in place
+    z = dx.clone()
+    nat.quandequan(z, 3, out=z)
+    np.testing.assert_array_equal(z.cpu().numpy(), oracle.quandequan(x, 3))
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 3), (3, 8, 4, 4), (4, 10), (1, 1, 1, 1), (2, 64, 56, 56)])
+def test_recon_epilogue_vs_oracle(nat, oracle, shape):
+    rng = np.random.default_rng(sum(shape))
+    acc = rng.integers(-60000, 60000, size=shape).astype(np.float32)
+    qb = rng.integers(-128, 128, size=shape[1]).astype(np.float32)
+    for rs, ob in ((0, 0), (5, 3), (9, 6), (-1, 2), (12, 7)):
+        got = nat.recon_epilogue(_dev(acc), _dev(qb), rs, ob).cpu().numpy()
+        np.testing.assert_array_equal(got, oracle.recon_epilogue(acc, qb, rs, ob))
+
+
+def test_quantize_param_vs_oracle(nat, oracle):
+    rng = np.random.default_rng(11)
+    w = (rng.standard_normal(100001, dtype=np.float32) * np.float32(0.3)).astype(np.float32)
+    for bit in (0, 5, 8, 12):
+        np.testing.assert_array_equal(nat.quantize_param_i32(_dev(w), bit).cpu().numpy(),
+                                      oracle.quantize_param_i32(w, bit))
+
+
+def test_full_size_quandequan_properties(nat):
+    x = torch.randn(32 * 802816, device="cuda") * 4
+    y = nat.quandequan(x, 4)
+    assert torch.equal(nat.quandequan(y, 4), y)                       # idempotent
+    ref = torch.clamp(torch.round(x * 16), -128, 127) / 16            # torch's own fp32 ops
+    assert torch.equal(y, ref)
+    assert y.abs().max().item() <= 8.0
