@@ -1,0 +1,333 @@
+#!/usr/bin/env python3
+"""Headline benchmark: KL calibration throughput of a fabu ResNet-50 @224^2 on MI355X
+(BASELINE.json metric "calibration images/sec + int8-sim images/sec", config[1] at N=1).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one calibration batch taken through the whole hot path: forward -> segmented abs-max
+(pass 1), forward -> 2048-bin histograms (pass 2); the timed region is ONE complete
+Quantity.activation_quantize() over K batches per GPU: both passes, the MAX / SUM all-reduces, the
+KL threshold sweep for all 71 tensors and the feat.table write.  Inputs are synthetic fp32 images
+generated on the device BEFORE the timed region.  value = images processed by all ranks / wall time
+(max over ranks, bracketed by barrier + synchronize).  Weak scaling: K batches per GPU.
+
+The JSON line also carries
+  roofline     : the dominant hand-written kernel (hist2048_seg), algorithmic bytes (4 B x elements
+                 per launch) / its mean launch duration measured with HIP events on the launch stream;
+  cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded
+                 sample on this box's host cores, scaled to the same workload (rank 0, N=1 only);
+  int8_sim_images_per_s / fakequant_images_per_s : ReconModel / ReconTest forward throughput.
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+QUANTITY = os.path.join(ROOT, "pytorch-quantity_amd", "quantity")
+sys.path.insert(0, QUANTITY)
+sys.path.insert(0, ROOT)
+
+R50_CARED_ELEMS_PER_IMAGE = 16784872        # image + 53 conv + fc + 16 Eltwise outputs @224^2
+HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+class DeviceBatches(object):
+    """Sequence of (images, None) pairs indexed by GLOBAL batch index; only this rank's batches
+    (i % world == rank) exist, pre-generated in HBM from generator seed 1234 + i."""
+
+    def __init__(self, total, batch, hw, rank, world, device):
+        self._items = {}
+        self._total = total
+        for i in range(rank, total, world):
+            g = torch.Generator(device=device).manual_seed(1234 + i)
+            self._items[i] = torch.randn(batch, 3, hw, hw, generator=g, device=device)
+
+    def __len__(self):
+        return self._total
+
+    def __getitem__(self, i):
+        return self._items[i], None
+
+    def owned(self):
+        return list(self._items.values())
+
+
+def make_workdir(max_cali_img_num, input_shape, gpu):
+    import yaml
+    tmp = tempfile.mkdtemp(prefix="fq_bench_")
+    os.makedirs(os.path.join(tmp, "tools"))
+    os.makedirs(os.path.join(tmp, "test"))
+    with open(os.path.join(QUANTITY, "tools", "configs.yml")) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg["SETTINGS"]["MAX_CALI_IMG_NUM"] = max_cali_img_num
+    with open(os.path.join(tmp, "tools", "configs.yml"), "w") as fh:
+        yaml.safe_dump(cfg, fh)
+    with open(os.path.join(QUANTITY, "test", "user_configs.yml")) as fh:
+        ucfg = yaml.safe_load(fh)
+    ucfg["MODEL"]["INPUT_SHAPE"] = input_shape
+    ucfg["SETTINGS"]["DEVICE"] = "gpu"
+    ucfg["SETTINGS"]["GPU"] = gpu
+    with open(os.path.join(tmp, "test", "user_configs.yml"), "w") as fh:
+        yaml.safe_dump(ucfg, fh)
+    os.chdir(os.path.join(tmp, "test"))
+    return tmp
+
+
+def build_model(name, hw, device):
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_fabu import ResNet50, ResNet101
+    torch.manual_seed(0)
+    model = (ResNet50 if name == "r50" else ResNet101)(input_size=hw)
+    g = torch.Generator().manual_seed(0)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    model.eval()
+    model = merge_bn(model)
+    return model.to(device)
+
+
+class KernelTimer(object):
+    """Wraps a _native entry point and brackets every call with HIP events on the launch stream
+    (torch's current stream is the stream the C ABI is handed)."""
+
+    def __init__(self, native, name):
+        self.native, self.name = native, name
+        self.orig = getattr(native, name)
+        self.events = []
+        self.elems = []
+        self.enabled = False
+
+    def __enter__(self):
+        def wrapped(tensors, rows, *rest):
+            if not self.enabled:
+                return self.orig(tensors, rows, *rest)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            r = self.orig(tensors, rows, *rest)
+            b.record()
+            self.events.append((a, b))
+            self.elems.append(sum(int(t.numel()) for t in tensors))
+            return r
+        setattr(self.native, self.name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        setattr(self.native, self.name, self.orig)
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = [a.elapsed_time(b) for a, b in self.events]
+        return {"launches": len(ms), "mean_ms": float(np.mean(ms)), "bytes_per_launch": 4.0 * float(np.mean(self.elems))}
+
+
+def cpu_baseline(model_cpu_ctor, sample_images, hw, n_images_full, q, log):
+    """Bounded CPU run of the same workload: torch-CPU forward (what the reference does) + the CPU
+    oracle for abs-max / histogram / KL, scaled to the full image count.  Reported, not a target."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import fq_oracle as orc
+    orc.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    model = model_cpu_ctor()
+    names = ["image"] + list(q.net_info.keys())
+    feats, hooks = {}, []
+    state = {"n": 0}
+    cared = set(q.net_info.keys())
+
+    def hook(m, i, o):
+        if state["n"] == 0:
+            feats.clear()
+            feats["image"] = i[0]
+        state["n"] += 1
+        k = "%s_%i" % (type(m).__name__, state["n"])
+        if k in cared:
+            feats[k] = o
+        if state["n"] >= q.layers_num:
+            state["n"] = 0
+
+    for m in model.modules():
+        if type(m).__name__ in q._all_op_type:
+            hooks.append(m.register_forward_hook(hook))
+    x = torch.randn(sample_images, 3, hw, hw, generator=torch.Generator().manual_seed(1234))
+    pool = ThreadPoolExecutor(cores)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        model(x)                                                     # pass 1 forward
+    arrs = {n: feats[n].numpy().ravel() for n in names}
+    maxs = dict(zip(names, pool.map(lambda n: orc.absmax(arrs[n]), names)))
+    ivs = {n: orc.interval(maxs[n]) for n in names}
+    with torch.no_grad():
+        model(x)                                                     # pass 2 forward
+    arrs = {n: feats[n].numpy().ravel() for n in names}
+    hists = dict(zip(names, pool.map(lambda n: orc.hist2048(arrs[n], ivs[n]), names)))
+    t_img = (time.perf_counter() - t0) / sample_images
+    t1 = time.perf_counter()
+    list(pool.map(lambda n: orc.kl_threshold(orc.normalize(hists[n])), names))
+    t_kl = time.perf_counter() - t1
+    for h in hooks:
+        h.remove()
+    value = n_images_full / (n_images_full * t_img + t_kl)
+    log("cpu_baseline: %.3f s/image (2 forwards + absmax + hist), KL %.2f s for %d tensors" % (t_img, t_kl, len(names)))
+    return {"value": round(value, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d images through torch-CPU forward x2 + oracle absmax/hist2048, + oracle KL sweep of all %d "
+                      "tensors once; scaled to %d images" % (sample_images, len(names), n_images_full)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--model", default="r50", choices=["r50", "r101"])
+    ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-recon", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    def log(*a):
+        if rank == 0:
+            print(*a, file=sys.stderr, flush=True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    torch.backends.cudnn.benchmark = True
+    from common.quantity import _native
+    from tools import Quantity, Reconstruction
+    _native.lib()
+
+    K, W, B, HW = args.steps, args.warmup, args.batch, args.image
+    shape = "1,3,%d,%d" % (HW, HW)
+    model = build_model(args.model, HW, device)
+    devnull = open(os.devnull, "w")
+    real_stdout = sys.stdout
+    sys.stdout = devnull                                   # the drop-in prints like the reference does
+
+    # ---- warmup: W batches per GPU through the same path (MIOpen algo search, RCCL init, code load)
+    if W > 0:
+        make_workdir(W * world - 1, shape, local_rank)
+        warm = DeviceBatches(W * world, B, HW, rank, world, device)
+        Quantity(model).activation_quantize(warm)
+        del warm
+    barrier()
+
+    # ---- timed: K batches per GPU
+    make_workdir(K * world - 1, shape, local_rank)
+    data = DeviceBatches(K * world, B, HW, rank, world, device)
+    q = Quantity(model)
+    with KernelTimer(_native, "hist2048_seg") as kt_hist, KernelTimer(_native, "absmax_seg") as kt_max:
+        kt_hist.enabled = kt_max.enabled = True
+        barrier()
+        t0 = time.perf_counter()
+        q.activation_quantize(data)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    images = K * world * B
+    value = images / elapsed
+    hist_s, max_s = kt_hist.summary(), kt_max.summary()
+    timings = dict(q.timings)
+    feat_table = open("./workdir/feat.table").read() if rank == 0 else ""
+
+    result = {
+        "metric": "calibration images/sec, ResNet-50 224^2 KL calibration (2 passes + KL sweep + feat.table)",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "fabu ResNet-%s per-tensor KL calibration, %d synthetic 3x%dx%d images per GPU "
+                               "(batch %d x %d steps), 71 histogram rows x 2048 bins" %
+                               ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K),
+                   "batch": B, "images_total": images, "parallelism": "dp%d" % world},
+        "phases_s": {k: round(v, 4) for k, v in timings.items()},
+    }
+    if hist_s:
+        ach = hist_s["bytes_per_launch"] / (hist_s["mean_ms"] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": "hist2048_seg_kernel", "achieved": round(ach, 1),
+                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                              "traffic": None, "launches": hist_s["launches"],
+                              "mean_launch_ms": round(hist_s["mean_ms"], 4),
+                              "algorithmic_bytes_per_launch": hist_s["bytes_per_launch"]}
+        if max_s:
+            ach2 = max_s["bytes_per_launch"] / (max_s["mean_ms"] * 1e-3) / 1e9
+            result["roofline_absmax"] = {"kernel": "absmax_seg_kernel", "achieved": round(ach2, 1), "unit": "GB/s",
+                                         "frac": round(ach2 / HBM_PEAK_GBS, 4), "mean_launch_ms": round(max_s["mean_ms"], 4)}
+
+    # ---- int8-sim / fake-quant forward throughput (BASELINE config[2]); replicas only, no collective
+    if not args.no_recon:
+        try:
+            q.weight_quantize()
+            barrier()
+            batches = data.owned()[:min(K, 8)]
+
+            def fwd_rate(net):
+                with torch.no_grad():
+                    net(batches[0])
+                    barrier()
+                    t0 = time.perf_counter()
+                    for xb in batches:
+                        net(xb)
+                    barrier()
+                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+                if world > 1:
+                    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+                return len(batches) * B * world / float(dt.item())
+
+            result["float_forward_images_per_s"] = round(fwd_rate(model), 1)
+            rec = Reconstruction(build_model(args.model, HW, device))
+            info = rec.get_quantity_information()
+            result["fakequant_images_per_s"] = round(fwd_rate(rec.ReconTest(info, "./workdir/recontest.pth")), 1)
+            rec2 = Reconstruction(build_model(args.model, HW, device))
+            info2 = rec2.get_quantity_information()
+            result["int8_sim_images_per_s"] = round(fwd_rate(rec2.ReconModel(info2, "./workdir/recon.pth")), 1)
+        except Exception as e:  # the headline number above stands on its own
+            result["recon_error"] = repr(e)
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            result["cpu_baseline"] = cpu_baseline(lambda: build_model(args.model, HW, torch.device("cpu")),
+                                                  4, HW, images, q, log)
+        except Exception as e:
+            result["cpu_baseline"] = {"error": repr(e)}
+
+    sys.stdout = real_stdout
+    if rank == 0:
+        log("feat.table head:", feat_table.split("\n")[:4])
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

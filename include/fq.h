@@ -124,6 +124,13 @@ int fq_recon_epilogue_f32(const float* acc, const float* qbias, float* y, size_t
 /* weight quantiser, pytorch_quantizer.py:656-657,:663: (int32) clip(around(w * 2^bit), -128, 127) */
 int fq_quantize_param_i32(const float* w, int32_t* q, size_t n, int bit, fq_stream_t stream);
 
+/* ---- output files ------------------------------------------------------------------------------ */
+
+/* HOST helper: write an int32 array as nested JSON lists, byte-identical to Python's
+ * json.dump(arr.tolist(), fh, indent=indent) -- the format of weight/<param>.json, bias/<param>.json,
+ * new_weight/, new_bias/ (pytorch_quantizer.py:663-669, rewriter.py:57-59).  data/shape are host. */
+int fq_json_dump_i32(const char* path, const int32_t* data, int ndim, const int64_t* shape, int indent);
+
 #ifdef __cplusplus
 }
 #endif

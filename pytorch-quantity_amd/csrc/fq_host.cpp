@@ -45,3 +45,81 @@ extern "C" int fq_bits_from_absmax(const float* absmax, int n, int32_t* bits_out
     }
     return FQ_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Quantised-parameter JSON writer: byte-identical to Python's json.dump(nested_lists, fh, indent=N)
+// (reference pytorch_quantizer.py:663-669, rewriter.py:57-59), written straight from the int32
+// array.  HOST pointers.  Returns FQ_ERR_INVALID_ARG if the file cannot be opened / written.
+// ---------------------------------------------------------------------------------------------
+#include <cstdio>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct JsonWriter {
+    std::string buf;
+    FILE* fh;
+    bool ok = true;
+    int indent;
+    const int32_t* data;
+    const int64_t* shape;
+    int ndim;
+    std::vector<std::string> pads;
+
+    void flush() {
+        if (!buf.empty()) {
+            if (fwrite(buf.data(), 1, buf.size(), fh) != buf.size()) ok = false;
+            buf.clear();
+        }
+    }
+    static inline void put_int(std::string& s, int32_t v) {
+        char tmp[12];
+        int n = 0;
+        uint32_t u = v < 0 ? (uint32_t)(-(int64_t)v) : (uint32_t)v;
+        do { tmp[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+        if (v < 0) s.push_back('-');
+        while (n) s.push_back(tmp[--n]);
+    }
+    // emits the list at nesting depth `level` starting at flat element offset `off`; returns elements consumed
+    int64_t emit(int level, int64_t off) {
+        const int64_t n = shape[level];
+        if (n == 0) { buf += "[]"; return 0; }
+        int64_t stride = 1;
+        for (int d = level + 1; d < ndim; ++d) stride *= shape[d];
+        buf += "[\n";
+        const std::string& pad = pads[level + 1];
+        for (int64_t i = 0; i < n; ++i) {
+            buf += pad;
+            if (level == ndim - 1) put_int(buf, data[off + i]);
+            else emit(level + 1, off + i * stride);
+            if (i + 1 < n) buf += ",\n";
+            if (buf.size() > (1u << 22)) flush();
+        }
+        buf += "\n";
+        buf += pads[level];
+        buf += "]";
+        return n * stride;
+    }
+};
+
+}  // namespace
+
+extern "C" int fq_json_dump_i32(const char* path, const int32_t* data, int ndim, const int64_t* shape, int indent) {
+    if (!path || ndim < 0 || ndim > 16 || indent < 0 || indent > 64) return FQ_ERR_INVALID_ARG;
+    if (ndim > 0 && !shape) return FQ_ERR_INVALID_ARG;
+    int64_t total = 1;
+    for (int d = 0; d < ndim; ++d) { if (shape[d] < 0) return FQ_ERR_INVALID_ARG; total *= shape[d]; }
+    if (total > 0 && !data) return FQ_ERR_INVALID_ARG;
+    FILE* fh = fopen(path, "wb");
+    if (!fh) return FQ_ERR_INVALID_ARG;
+    JsonWriter w;
+    w.fh = fh; w.indent = indent; w.data = data; w.shape = shape; w.ndim = ndim;
+    for (int d = 0; d <= ndim + 1; ++d) w.pads.emplace_back((size_t)(indent * d), ' ');
+    w.buf.reserve(1u << 23);
+    if (ndim == 0) JsonWriter::put_int(w.buf, data[0]);
+    else w.emit(0, 0);
+    w.flush();
+    const bool ok = w.ok && fclose(fh) == 0;
+    return ok ? FQ_OK : FQ_ERR_INVALID_ARG;
+}

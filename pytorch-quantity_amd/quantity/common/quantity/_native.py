@@ -69,6 +69,8 @@ def lib():
     L.fq_recon_epilogue_f32.argtypes = [vp, vp, vp, sz, sz, sz, ci, ci, ci, vp]
     L.fq_quantize_param_i32.restype = ci
     L.fq_quantize_param_i32.argtypes = [vp, vp, sz, ci, vp]
+    L.fq_json_dump_i32.restype = ci
+    L.fq_json_dump_i32.argtypes = [ctypes.c_char_p, vp, ci, vp, ci]
     _lib = L
     return L
 
@@ -245,3 +247,14 @@ def quantize_param_i32(w, bit):
     _check(lib().fq_quantize_param_i32(wc.data_ptr(), q.data_ptr(), wc.numel(), int(bit), _stream(wc)),
            "fq_quantize_param_i32")
     return q
+
+
+def json_dump_i32(array, path, indent=4):
+    """Write a host int array as nested JSON lists, byte-identical to json.dump(a.tolist(), indent=4)."""
+    a = np.asarray(array)
+    nd = a.ndim
+    a = np.ascontiguousarray(a, dtype=np.int32).reshape(a.shape)     # ascontiguousarray promotes 0-d to 1-d
+    assert a.ndim == nd
+    shape = np.array(a.shape, dtype=np.int64)
+    _check(lib().fq_json_dump_i32(os.fsencode(path), a.ctypes.data, a.ndim, shape.ctypes.data if a.ndim else None,
+                                  int(indent)), "fq_json_dump_i32(%s)" % path)

@@ -1,0 +1,163 @@
+"""Running abs-max and 2048-bin |x| histograms of named tensors, accumulated over calibration
+batches -- on the GPU, state resident in HBM.
+
+Drop-in for reference quantity/common/quantity/distribution_collector.py
+(DistributionCollector :7, refresh_max_val :70-78, distribution_intervals :52-63,
+add_to_distributions :80-119, _add_to_distribution :127-135): same constructor, methods and
+properties.  What changed underneath:
+
+  * tensors stay on the device: one segmented HIP launch (fq_absmax_seg / fq_hist2048_seg) covers
+    every tensor of a batch; the reference copies each tensor to the host, forks a
+    multiprocessing.Pool per call and walks the elements in a Python loop.
+  * state is `fp32[T]` maxima and `int64[T][2048]` histograms in HBM (the reference keeps int32
+    NumPy arrays and wraps past 2^31-1 per bin); they are only downloaded when a property is read.
+  * `worker_num` is accepted and ignored (there is no process pool).
+
+NumPy arrays are accepted too (they are uploaded); there is no CPU compute path.
+"""
+import numpy as np
+import torch
+
+from . import _native
+
+__all__ = ["DistributionCollector"]
+
+
+def _as_device_f32(t, device):
+    if isinstance(t, torch.Tensor):
+        if t.device.type != "cuda":
+            t = t.to(device)
+        return t.detach() if t.dtype == torch.float32 else t.detach().float()
+    a = np.ascontiguousarray(np.asarray(t), dtype=np.float32)
+    return torch.from_numpy(a).to(device)
+
+
+class DistributionCollector(object):
+
+    def __init__(self, tensor_list, interval_num=2048, statistic=1, worker_num=1, debug=False, device=None):
+        if interval_num != _native.BINS:
+            raise ValueError("the MI355X histogram kernel is built for INTERVAL_NUM = 2048, got %r" % interval_num)
+        self._tensor_list = list(tensor_list)
+        self._row = {name: i for i, name in enumerate(self._tensor_list)}
+        self._interval_num = interval_num
+        self._statistic = statistic
+        self._worker_num = worker_num
+        self._debug = debug
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        T = len(self._tensor_list)
+        self._max_dev = torch.zeros(T, dtype=torch.float32, device=self._device)
+        self._hist_dev = torch.zeros(T, interval_num, dtype=torch.int64, device=self._device)
+        self._interval_dev = None
+        self._interval_key = None
+        self._max_vals_refreshed_flag = False
+        self._added_to_distributions_flag = False
+        self._keepalive = None
+
+    # ------------------------------------------------------------------ device-side accessors
+    @property
+    def device(self):
+        return self._device
+
+    @property
+    def max_device(self):
+        """fp32[T] running abs-max on the device (row order = tensor_list order)."""
+        return self._max_dev
+
+    @property
+    def hist_device(self):
+        """int64[T, 2048] histograms on the device."""
+        return self._hist_dev
+
+    def row_of(self, name):
+        return self._row[name]
+
+    # ------------------------------------------------------------------ reference API
+    @property
+    def max_vals(self):
+        assert self._max_vals_refreshed_flag, "Please use refresh_max_val() first."
+        host = self._max_dev.cpu().numpy()
+        # the reference's running max starts as the Python int 0 and only becomes np.float32 once a
+        # positive maximum is seen (distribution_collector.py:42,:78)
+        return {n: (host[i] if host[i] > 0 else 0) for i, n in enumerate(self._tensor_list)}
+
+    @property
+    def distribution_intervals(self):
+        """Bin width per tensor: statistic * max / 2048 + 1e-12, evaluated with NumPy scalars so the
+        types and roundings are the reference's (np.float32 throughout; the Python float 1e-12 for
+        a tensor that never left zero).  As in the reference the returned dict is kept (and may be
+        edited by the caller, e.g. merge groups) and is what add_to_distributions() bins with."""
+        assert self._max_vals_refreshed_flag, "Please use refresh_max_val() first."
+        mv = self.max_vals
+        intervals = {}
+        for name in self._tensor_list:
+            intervals[name] = self._statistic * mv[name] / self._interval_num + 1e-12
+        self._distribution_intervals = intervals
+        return intervals
+
+    @property
+    def distributions(self):
+        assert self._added_to_distributions_flag, "Please use add_to_distributions() first."
+        host = self._hist_dev.cpu().numpy()
+        narrow = host.max(initial=0) <= np.iinfo(np.int32).max
+        return {n: (host[i].astype(np.int32) if narrow else host[i].copy()) for i, n in enumerate(self._tensor_list)}
+
+    def refresh_max_val(self, tensors):
+        """Fold one batch into the running abs-max of every tensor in tensor_list."""
+        self._max_vals_refreshed_flag = True
+        segs = [_as_device_f32(tensors[n], self._device) for n in self._tensor_list]
+        rows = list(range(len(segs)))
+        self._keepalive = _native.absmax_seg(segs, rows, self._max_dev)
+
+    def add_to_distributions(self, tensors):
+        """Add one batch to every tensor's histogram, binning with the current intervals."""
+        if self._debug and self._added_to_distributions_flag:
+            return
+        self._added_to_distributions_flag = True
+        if not hasattr(self, "_distribution_intervals"):
+            print("interval:", self.distribution_intervals)
+        self._sync_intervals()
+        segs = [_as_device_f32(tensors[n], self._device) for n in self._tensor_list]
+        rows = list(range(len(segs)))
+        self._keepalive = _native.hist2048_seg(segs, rows, self._interval_dev, self._hist_dev)
+
+    # ------------------------------------------------------------------ beyond the reference API
+    def all_reduce_max(self):
+        """Data-parallel calibration: combine the per-rank maxima (one MAX all-reduce of fp32[T],
+        RCCL over xGMI when the process group is 'nccl')."""
+        import torch.distributed as dist
+        dist.all_reduce(self._max_dev, op=dist.ReduceOp.MAX)
+
+    def all_reduce_hist(self):
+        """Combine the per-rank histograms: one SUM all-reduce of the flat int64[T*2048] buffer."""
+        import torch.distributed as dist
+        dist.all_reduce(self._hist_dev, op=dist.ReduceOp.SUM)
+
+    def merged_distributions(self, groups):
+        """int64[T, 2048] device tensor in tensor_list order in which every group (a list of tensor
+        names) holds the sum of its members' histograms (reference pytorch_quantizer.py:432-445,
+        applied group after group)."""
+        assert self._added_to_distributions_flag, "Please use add_to_distributions() first."
+        merged = self._hist_dev.clone()
+        for group in groups:
+            idx = torch.tensor([self._row[n] for n in group], dtype=torch.long, device=self._device)
+            merged[idx] = merged[idx].sum(dim=0, keepdim=True)
+        return merged
+
+    def quantize_param(self, tensor, bit):
+        """clip(rint(w * 2^bit), -128, 127) as an int32 ndarray of the tensor's shape
+        (reference pytorch_quantizer.py:656-657,:663)."""
+        t = _as_device_f32(tensor, self._device)
+        return _native.quantize_param_i32(t, bit).cpu().numpy()
+
+    # ------------------------------------------------------------------ internals
+    def _sync_intervals(self):
+        vals = [np.float32(self._distribution_intervals[n]) for n in self._tensor_list]
+        key = tuple(v.tobytes() for v in vals)
+        if key != self._interval_key:
+            host = np.array(vals, dtype=np.float32)
+            self._interval_dev = torch.from_numpy(host).to(self._device)
+            self._interval_key = key
+
+    def set_intervals(self, intervals):
+        """Install an interval dict (name -> scalar) without going through the property."""
+        self._distribution_intervals = intervals

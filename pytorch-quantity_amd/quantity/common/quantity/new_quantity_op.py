@@ -1,0 +1,296 @@
+"""The quantize-op ``nn.Module`` API: integer-simulation conv/linear (NewConv2d / NewLinear),
+fake-quant (QuanDequan, TestConv / TestLinear) and the element-wise pieces they are made of.
+
+Drop-in for reference quantity/common/quantity/new_quantity_op.py: same class names, constructor
+signatures, attribute names and `quantize_infor` keys (weight_bit, bias_bit, input_bit, output_bit),
+so models pickled by `tools.Reconstruction` load against this module path.
+
+What runs underneath is different: every forward is a hand-written HIP kernel reached through the
+C ABI (include/fq.h).  The reference composes each op from 3-7 torch element-wise calls; here each
+op is one pass, and NewConv2d / NewLinear fuse RightShift -> BiasAdd -> Sp -> DeQuantity into the
+epilogue of the contraction.  Forward passes require CUDA (ROCm) tensors: there is no CPU path.
+
+Reference lines: RightShift :11-44, Quantity :48-58, DeQuantity :61-68, Sp :71-91, BiasAdd :95-101,
+NewConv2d :104-163, NewAdd :166-174, NewLinear :177-236, QuanDequan :239-257, TestConv :259-355,
+TestLinear :358-452.
+"""
+import os
+
+import torch
+from torch import nn
+
+from . import _native
+
+QUANTIZE_BIT = 8
+
+# TestConv / TestLinear can dump weights as text and 2048-bin PNG histograms the way the reference
+# constructor always does (174 s for ResNet-18).  Off unless asked for.
+DUMP_VISUALIZATION = os.environ.get("FQ_DUMP_VISUALIZATION", "0") not in ("", "0", "false", "False")
+
+__all__ = ["RightShift", "Sp", "BiasAdd", "NewConv2d", "NewAdd", "NewLinear", "QuanDequan", "TestConv",
+           "TestLinear", "Quantity", "DeQuantity", "QUANTIZE_BIT"]
+
+
+def _check_width(bits):
+    assert bits == 8 or bits == 16, "Not support bit width."
+
+
+class RightShift(nn.Module):
+    """x / 2^rs, rounded half away from zero, saturated to `bits` wide integers (kept as fp32)."""
+
+    def __init__(self, bits, rs):
+        super(RightShift, self).__init__()
+        self.rs = rs
+        self.Bit_width = bits
+
+    def forward(self, x):
+        _check_width(self.Bit_width)
+        return _native.rightshift(x, self.rs, self.Bit_width)
+
+
+class Quantity(nn.Module):
+    """clamp(round_half_even(x * 2^ib)) to the QUANTIZE_BIT range."""
+
+    def __init__(self, ib):
+        super(Quantity, self).__init__()
+        self.ib = ib
+
+    def forward(self, x):
+        return _native.quantity(x, self.ib, 8 if QUANTIZE_BIT == 8 else 16)
+
+
+class DeQuantity(nn.Module):
+    """x / 2^ob."""
+
+    def __init__(self, ob):
+        super(DeQuantity, self).__init__()
+        self.ob = ob
+
+    def forward(self, x):
+        return _native.dequantity(x, self.ob)
+
+
+class Sp(nn.Module):
+    """Saturating truncation to the int8 / int16 range."""
+
+    def __init__(self, bits):
+        super(Sp, self).__init__()
+        self.bitwidth = bits
+
+    def forward(self, x):
+        _check_width(self.bitwidth)
+        return _native.sp(x, self.bitwidth)
+
+
+class BiasAdd(nn.Module):
+
+    def __init__(self):
+        super(BiasAdd, self).__init__()
+
+    def forward(self, x, y):
+        return torch.add(x, y)
+
+
+def _quantize_params(layer, weight_bit, bias_bit, out_count, weight_16bit_range=False):
+    """Integer-valued fp32 weights / bias of a conv or linear layer (reference :135-163, :208-236).
+    One-time parameter preparation, done with torch ops on whatever device the layer lives on."""
+    assert layer.weight is not None, "The layer weight can`t be None"
+    w = layer.weight.data
+    b = layer.bias.data if layer.bias is not None else torch.zeros(out_count, device=w.device, dtype=w.dtype)
+    qw = torch.round(torch.mul(w, pow(2, weight_bit)))
+    qb = torch.round(torch.mul(b, pow(2, bias_bit)))
+    if QUANTIZE_BIT == 8:
+        qw = qw.clamp(-128, 127)
+        qb = qb.clamp(-128, 127)
+    else:
+        qw = qw.clamp(-32768, 32767) if weight_16bit_range else qw.clamp(-128, 127)
+        qb = qb.clamp(-32768.0, 32767.0)
+    return qw, qb
+
+
+class _IntegerSimLayer(nn.Module):
+    """Shared body of NewConv2d / NewLinear: Quantity -> integer contraction -> fused tail."""
+
+    def _setup(self, layer, quantize_infor, out_count, wide_weights):
+        self.weight_bit = quantize_infor["weight_bit"]
+        self.bias_bit = quantize_infor["bias_bit"]
+        self.input_bit = quantize_infor["input_bit"]
+        self.output_bit = quantize_infor["output_bit"]
+        self.rs_bit = self.weight_bit + self.input_bit - self.output_bit
+        self.Quan = Quantity(self.input_bit)
+        self.RightShift = RightShift(QUANTIZE_BIT, self.rs_bit)
+        self.BiasAdd = BiasAdd()
+        self.Sp = Sp(QUANTIZE_BIT)
+        self.DeQuan = DeQuantity(self.output_bit)
+        # as in the reference, .weight / .bias keep the layer's ORIGINAL float parameters
+        self.weight = layer.weight
+        self.bias = layer.bias
+        qw, qb = _quantize_params(layer, self.weight_bit, self.bias_bit, out_count, wide_weights)
+        # the contraction carries no bias; the quantised bias is added after the shift
+        layer.weight = nn.Parameter(qw)
+        layer.bias = nn.Parameter(torch.zeros(out_count, device=qw.device, dtype=qw.dtype))
+        # the reference keeps this as a plain attribute, so .cuda() leaves it behind (its ReconModel
+        # is CPU-only in practice); a buffer moves with the module and is pickled the same way
+        # (non-persistent: state_dict keys stay the reference's)
+        self.register_buffer("quantized_bias", qb, persistent=False)
+
+    def _tail(self, acc):
+        return _native.recon_epilogue(acc, self.quantized_bias, self.rs_bit, self.output_bit,
+                                      8 if QUANTIZE_BIT == 8 else 16, out=acc)
+
+
+class NewConv2d(_IntegerSimLayer):
+    """Integer simulation of a convolution: int8 activations x int8 weights accumulated exactly,
+    shifted right by weight_bit + input_bit - output_bit, bias added, saturated, de-quantised."""
+
+    def __init__(self, conv_module, quantize_infor):
+        super(NewConv2d, self).__init__()
+        self.Conv = conv_module
+        self._setup(conv_module, quantize_infor, conv_module.out_channels, False)
+
+    def forward(self, input):
+        q = self.Quan(input)
+        acc = self.Conv(q)          # integer-valued fp32 in, exact below 2^24 per partial sum
+        return self._tail(acc)
+
+
+class NewLinear(_IntegerSimLayer):
+
+    def __init__(self, linear_module, quantize_infor):
+        super(NewLinear, self).__init__()
+        self.Linear = linear_module
+        self._setup(linear_module, quantize_infor, linear_module.out_features, True)
+
+    def forward(self, input):
+        q = self.Quan(input)
+        acc = self.Linear(q)
+        return self._tail(acc)
+
+
+class NewAdd(nn.Module):
+    """Residual add followed by the int8 saturation (applied to de-quantised values, as in the
+    reference, where it is in effect a clamp to [-128, 127])."""
+
+    def __init__(self):
+        super(NewAdd, self).__init__()
+        self.Sp = Sp(QUANTIZE_BIT)
+
+    def forward(self, x, y):
+        return _native.add_sat(x, y, self.Sp.bitwidth)
+
+
+class QuanDequan(nn.Module):
+    """Fake quantisation: clamp(round_half_even(x * 2^bit)) / 2^bit in one fused pass."""
+
+    def __init__(self, Bitwidth, bit):
+        super(QuanDequan, self).__init__()
+        self.bitwidth = Bitwidth
+        self.bit = bit
+
+    def forward(self, quantized_x, out=None):
+        return _native.quandequan(quantized_x, self.bit, 8 if self.bitwidth == 8 else 16, out=out)
+
+
+def _fake_quant_param(t, bit, bitwidth):
+    """One-time fake quantisation of a parameter tensor at construction (reference :305-309), with
+    torch ops on whatever device the parameter lives on.  Not a forward path."""
+    s = pow(2, bit)
+    r = torch.round(torch.mul(t, s))
+    r = r.clamp(-128, 127) if bitwidth == 8 else r.clamp(-32768.0, 32767.0)
+    return torch.div(r, s)
+
+
+class _FakeQuantLayer(nn.Module):
+    """Shared body of TestConv / TestLinear: weights and bias fake-quantised once, output
+    fake-quantised on every forward."""
+
+    def _setup(self, name, layer, quantize_infor, new_model_path, out_count):
+        self.name = name
+        self.path = os.path.join(os.path.dirname(new_model_path), "quantity_results")
+        if not os.path.exists(self.path):
+            os.makedirs(self.path)
+        self.weight_bit = quantize_infor["weight_bit"]
+        self.bias_bit = quantize_infor["bias_bit"]
+        self.input_bit = quantize_infor["input_bit"]
+        self.output_bit = quantize_infor["output_bit"]
+        self.weight_qdp = QuanDequan(QUANTIZE_BIT, self.weight_bit)
+        self.bias_qdp = QuanDequan(QUANTIZE_BIT, self.bias_bit)
+        self.output_qdp = QuanDequan(QUANTIZE_BIT, self.output_bit)
+        self._layer_ref = layer
+        self.feature_extract(out_count)
+
+    def feature_extract(self, out_count=None):
+        layer = self._layer_ref
+        assert layer.weight is not None, "The layer weight can`t be None"
+        w = layer.weight.data
+        if layer.bias is None:
+            # (the reference dereferences a missing attribute here; a zero bias is what it meant)
+            b = torch.zeros(out_count, device=w.device, dtype=w.dtype)
+        else:
+            b = layer.bias.data
+        self.weight = layer.weight          # originals, as in the reference
+        self.bias = layer.bias
+        w_q = _fake_quant_param(w, self.weight_qdp.bit, self.weight_qdp.bitwidth)
+        b_q = _fake_quant_param(b, self.bias_qdp.bit, self.bias_qdp.bitwidth)
+        layer.weight = nn.Parameter(w_q)
+        layer.bias = nn.Parameter(b_q)
+        if DUMP_VISUALIZATION:
+            self._dump(w, b, w_q, b_q)
+
+    def _dump(self, w, b, w_q, b_q):
+        stem = os.path.join(self.path, self.name.replace(".", "_"))
+
+        def as_text(t):
+            return "  ".join(str(v) for v in t.detach().cpu().numpy().flatten())
+
+        with open(stem + "_weight.txt", "a") as fh:
+            fh.write(as_text(w) + "\n\n\n\n")
+            fh.write(as_text(w_q) + "\n\n\n\n")
+        with open(stem + "_bias.txt", "a") as fh:
+            fh.write(as_text(b) + "\n\n\n\n")
+            fh.write(as_text(b_q) + "\n\n\n\n")
+        self.plot_hist(w.cpu().numpy(), 2048, stem + "_weight_o.png", title="weight")
+        self.plot_hist(b.cpu().numpy(), 2048, stem + "_bias_o.png", title="bias")
+        self.plot_hist(w_q.cpu().numpy(), 2048, stem + "_weight_q.png", title="weight")
+        self.plot_hist(b_q.cpu().numpy(), 2048, stem + "_bias_q.png", title="bias")
+
+    def plot_hist(self, ndarray, bins, save_path, title):
+        if save_path is None:
+            raise NotImplementedError("the path is not exists")
+        import matplotlib
+        matplotlib.use("Agg")
+        import matplotlib.pyplot as plt
+        fig = plt.figure()
+        plt.grid()
+        plt.title(title)
+        plt.xlabel("bins")
+        plt.ylabel("counter/frequency")
+        plt.hist(ndarray.flatten(), bins, density=True, histtype="bar", facecolor="blue")
+        fig.savefig(save_path, bbox_inches="tight")
+        plt.close(fig)
+
+
+class TestConv(_FakeQuantLayer):
+    __test__ = False        # not a pytest class
+
+    def __init__(self, name, module, quantize_infor, new_model_path):
+        super(TestConv, self).__init__()
+        self.Conv = module
+        self._setup(name, module, quantize_infor, new_model_path, module.out_channels)
+
+    def forward(self, x):
+        out = self.Conv(x)
+        return self.output_qdp(out, out=out if out.is_contiguous() else None)
+
+
+class TestLinear(_FakeQuantLayer):
+    __test__ = False
+
+    def __init__(self, name, module, quantize_infor, new_model_path):
+        super(TestLinear, self).__init__()
+        self.linear = module
+        self._setup(name, module, quantize_infor, new_model_path, module.out_features)
+
+    def forward(self, x):
+        out = self.linear(x)
+        return self.output_qdp(out, out=out if out.is_contiguous() else None)

@@ -1,0 +1,89 @@
+"""KL-divergence threshold search: histogram -> threshold bin -> fractional bit count.
+
+Drop-in for reference quantity/common/quantity/quantizer.py (Quantizer :7, quantize :43-75,
+quantize_worker :77-93, normalize_distribution :95-96, threshold_distribution :98-167,
+compute_kl_divergence :169-174): same constructor, quantize(), .bits and .threshold_value.
+
+All rows go through one fq_kl_threshold call (1920 candidate thresholds x rows as independent
+workgroups, float64 in the reference's operation order).  Only the last scalar step -- threshold bin
+to bits, which the reference does with math.log -- runs on the host, with the same CPython/NumPy
+scalar arithmetic, so exact powers of two round the way they do in the reference.
+`worker_num` is accepted and ignored.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _native
+
+__all__ = ["Quantizer"]
+
+
+def _rows_to_device(distributions, names, device):
+    """Stack per-tensor histograms (NumPy int32 / merged float64, or device int64) into int64[T,2048]."""
+    if isinstance(distributions, torch.Tensor):
+        assert distributions.dtype == torch.int64 and distributions.shape == (len(names), _native.BINS)
+        return distributions.contiguous()
+    rows = []
+    for n in names:
+        h = distributions[n]
+        if isinstance(h, torch.Tensor):
+            rows.append(h.to(device=device, dtype=torch.int64))
+            continue
+        h = np.asarray(h)
+        if h.dtype.kind == "f":
+            hi = h.astype(np.int64)
+            if not np.array_equal(hi.astype(h.dtype), h):
+                raise ValueError("histogram %r holds non-integer counts" % n)
+            h = hi
+        rows.append(torch.from_numpy(np.ascontiguousarray(h, dtype=np.int64)).to(device))
+    return torch.stack(rows).contiguous() if rows else torch.zeros(0, _native.BINS, dtype=torch.int64, device=device)
+
+
+class Quantizer(object):
+
+    def __init__(self, tensor_list, worker_num=1, debug=False, device=None):
+        self._tensor_list = list(tensor_list)
+        self._worker_num = worker_num
+        self._debug = debug
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._bits = {}
+        self._threshold_value = {}
+        self._threshold_bin = {}
+        self._quantized_flag = False
+
+    @property
+    def bits(self):
+        assert self._quantized_flag, "Please use quantize() first."
+        return self._bits
+
+    @property
+    def threshold_value(self):
+        assert self._quantized_flag, "Please use quantize() first."
+        return self._threshold_value
+
+    @property
+    def threshold_bins(self):
+        """The raw threshold bin t* in [128, 2047] per tensor (not exposed by the reference)."""
+        assert self._quantized_flag, "Please use quantize() first."
+        return self._threshold_bin
+
+    def quantize(self, distributions, distribution_intervals):
+        """distributions: {name: 2048 counts} (or an int64[T,2048] device tensor in tensor_list
+        order); distribution_intervals: {name: bin width}."""
+        if self._debug and self._quantized_flag:
+            return
+        self._quantized_flag = True
+        hist = _rows_to_device(distributions, self._tensor_list, self._device)
+        thr = _native.kl_threshold(hist).cpu().numpy()
+        for name, t in zip(self._tensor_list, thr):
+            t = int(t)
+            # reference quantizer.py:86-90; NumPy scalar typing decides fp32 vs float64 here exactly
+            # as it does there (np.float32 interval -> fp32 product, Python float -> float64)
+            threshold_bias = (t + 0.5) * distribution_intervals[name]
+            bit = int(8 - 1 - math.ceil(math.log(threshold_bias, 2)))
+            self._threshold_bin[name] = t
+            self._threshold_value[name] = threshold_bias
+            self._bits[name] = bit
+            print("{} ".format(name), "bit:", bit)

@@ -1,0 +1,466 @@
+"""Calibration orchestrator: discover the cared tensors of a model, run the two-pass activation
+calibration (abs-max, then 2048-bin histograms, then the KL threshold sweep), write feat.table;
+quantise weights, write weight.table and the per-parameter JSON files.
+
+Drop-in for reference quantity/tools/pytorch_quantizer.py (Quantity :19, build_net_structure
+:65-197, get_cared_op_names :199-204, prune_net_info :207-249, preprocess :252-284, net_forward
+:288-296, get_merge_groups :298-341, activation_quantize :345-489, regist_hook_outfeature :491-524,
+init_dir :529-548, rewrite_weight :553-590, weight_quantize :592-677, dilation_to_zero_padding
+:679-693): same class, method names and call order, same config files (cwd-relative
+../tools/configs.yml and ./user_configs.yml), same output files byte for byte.
+
+MI355X design (what is different underneath):
+  * hooked activations never leave HBM: the hooks keep device tensors, and each pass ends in ONE
+    segmented HIP launch over all cared tensors of the batch (the reference copies every hooked
+    tensor to the host and forks a process pool per batch);
+  * graph edges come from tensor identity during one traced forward (value fingerprints, the
+    reference's `tid`, are only the fallback), so all-positive inputs to ReLU etc. need no special case;
+  * data-parallel calibration: when torch.distributed is initialised the calibration batches are
+    dealt round-robin to the ranks (one process per GPU) and the per-tensor maxima / histograms
+    are combined with one MAX and one SUM all-reduce (RCCL over xGMI); integer sums and maxima are
+    order independent, so the tables are bit-identical for any number of GPUs.  Rank 0 writes files.
+"""
+import json
+import math
+import os
+import time
+from collections import Counter, OrderedDict, defaultdict
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+from common.quantity import DistributionCollector, Quantizer, walk_dirs, merge_bn, tid  # noqa: F401
+from common.quantity import _native
+from .rewriter import BiasReWriter
+from ._jsonio import dump_int_array
+
+__all__ = ["Quantity"]
+
+
+def _load_yaml(path):
+    with open(path) as fh:
+        return yaml.safe_load(fh)
+
+
+def _dist_state():
+    """(rank, world) of the default process group, (0, 1) when not distributed."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class Quantity(object):
+
+    # the statistics engine; tests substitute oracle-backed doubles to exercise the host logic on CPU
+    collector_cls = DistributionCollector
+    quantizer_cls = Quantizer
+
+    def __init__(self, model):
+        assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
+        assert os.path.isfile("./user_configs.yml"), "../test/user_configs.yml"
+        self.config = _load_yaml("../tools/configs.yml")
+        self.user_config = _load_yaml("./user_configs.yml")
+        self.init_dir()
+
+        settings = self.config["SETTINGS"]
+        self.device = self.user_config["SETTINGS"]["DEVICE"]
+        if self.device == "gpu" and torch.cuda.is_available():
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                # under torchrun each rank already selected its own GPU
+                torch.cuda.set_device(self.user_config["SETTINGS"]["GPU"])
+        self._cared_op_type = settings["CARE_OP_TYPE"]
+        self._all_op_type = settings["ALL_OP_TYPE"]
+        self._allow_same_tid_op_type = settings["ALLOW_SAME_TID_OP_TYPE"]
+        self._merge_op_type = settings["MERGE_OP_YTPE"]
+        self._max_img_num = settings["MAX_CALI_IMG_NUM"]
+        print("max_img_num", self._max_img_num)
+        self.model = model
+        self.input_size = tuple(int(v) for v in self.user_config["MODEL"]["INPUT_SHAPE"].split(","))
+        self.layers_num = 0
+        self.name_to_param = OrderedDict()
+        self.net_info = self.build_net_structure(self.model, self.input_size, self.device)
+        self.cared_op_layer_names = self.get_cared_op_names(self.model)
+        self._DKL_weight = False
+        self.timings = {}
+
+    # ------------------------------------------------------------------------------------------
+    # graph discovery
+    # ------------------------------------------------------------------------------------------
+    def _model_device(self, model):
+        for p in model.parameters():
+            return p.device
+        return torch.device("cpu")
+
+    def build_net_structure(self, model, input_size, device="cpu"):
+        """One traced forward on random input.  Every module whose type is in ALL_OP_TYPE becomes a
+        node "<ClassName>_<ordinal>" (ordinal = 1-based execution order); its inputs are the nodes
+        that produced its input tensors.  Nodes not in CARE_OP_TYPE are then pruned, rewiring
+        through single-input chains.  Returns OrderedDict name -> {'inputs': [...], 'type': str}.
+        """
+        assert device.lower() in ("gpu", "cpu"), "Input device is not valid, please specify 'gpu' or 'cpu'"
+        trace = []            # (name, type, [input tensors], output tensor), execution order
+        handles = []
+
+        def on_forward(module, inputs, output):
+            kind = type(module).__name__
+            trace.append(("%s_%i" % (kind, len(trace) + 1), kind, [t for t in inputs if torch.is_tensor(t)], output))
+
+        for m in model.modules():
+            if type(m).__name__ in self._all_op_type:
+                handles.append(m.register_forward_hook(on_forward))
+        dev = self._model_device(model)
+        shapes = [input_size] if isinstance(input_size, tuple) else list(input_size)
+        x = [torch.rand(*s, device=dev) for s in shapes]
+        with torch.no_grad():
+            model(*x)
+        for h in handles:
+            h.remove()
+        self.layers_num = len(trace)
+
+        producer = {}          # id(tensor) -> node name; tensors are kept alive by `trace`
+        fingerprint = {}       # tid -> node name, fallback when a tensor object was re-wrapped
+        net = OrderedDict()
+        for i, (name, kind, ins, out) in enumerate(trace):
+            inputs = []
+            for t in ins:
+                src = producer.get(id(t))
+                if src is None:
+                    src = fingerprint.get(tid(t)) if t.numel() else None
+                if src is not None:
+                    inputs.append(src)
+                elif i != 0:
+                    raise AssertionError("Can't find the input tensor of {} \n {}".format(name, net))
+            if torch.is_tensor(out):
+                if id(out) in producer and kind not in self._allow_same_tid_op_type:
+                    if any(id(out) == id(t) for t in ins):
+                        raise ValueError("Same input and output id, the op {} is useful?".format(name))
+                    raise AssertionError("Some layers returned same tensor.")
+                producer[id(out)] = name           # a pass-through op becomes the newest producer
+                if out.numel():
+                    fingerprint.setdefault(tid(out), name)
+            net[name] = {"inputs": inputs, "type": kind}
+        keep = [n for n, info in net.items() if info["type"] in self._cared_op_type]
+        return self.prune_net_info(net, keep)
+
+    def get_cared_op_names(self, model):
+        return [name for name, module in model.named_modules() if type(module).__name__ in self._cared_op_type]
+
+    def prune_net_info(self, net_info, keep_node_list):
+        """Drop the nodes that are not kept; an edge into a dropped node is re-pointed at the
+        nearest kept ancestor (dropped nodes must be single-input)."""
+        dropped = set(net_info.keys()) - set(keep_node_list)
+
+        def nearest_kept(name):
+            ins = net_info[name]["inputs"]
+            assert len(ins) <= 1, (ins, name)
+            if not ins:
+                return None
+            return nearest_kept(ins[0]) if ins[0] in dropped else ins[0]
+
+        pruned = OrderedDict()
+        for name, info in net_info.items():
+            if name in dropped:
+                continue
+            inputs = [nearest_kept(s) if s in dropped else s for s in info["inputs"]]
+            pruned[name] = {"inputs": inputs, "type": info["type"]}
+        return pruned
+
+    # ------------------------------------------------------------------------------------------
+    # input side
+    # ------------------------------------------------------------------------------------------
+    def preprocess(self, image):
+        """PRE_PROCESS.IMG: 1 = the item is a (data, label) pair from a loader; 2 = path of a .npy
+        holding one image; 0 = path of an image file (needs an image decoder: not available in this
+        build, and broken in the reference: pytorch_quantizer.py:260-263)."""
+        mode = int(self.user_config["PRE_PROCESS"]["IMG"])
+        if mode == 1:
+            img, _ = image
+            return img
+        if mode == 2:
+            arr = torch.as_tensor(np.load(image))
+            return arr.view(1, *arr.shape)
+        if mode == 0:
+            raise NotImplementedError("PRE_PROCESS.IMG = 0 (image files) needs an image decoder; "
+                                      "use 1 (loader) or 2 (.npy)")
+        print("input option set wrong:", mode)
+        return None
+
+    def net_forward(self, net, image_path):
+        img = self.preprocess(image_path)
+        if self.device == "gpu" and img.device.type != "cuda":
+            img = img.cuda(non_blocking=True)
+        with torch.no_grad():
+            net(img)
+
+    # ------------------------------------------------------------------------------------------
+    # merge groups
+    # ------------------------------------------------------------------------------------------
+    def get_merge_groups(self, net):
+        """For every Eltwise / Concat node, deepest first: the cared tensors feeding it."""
+        merge_layers = [n for n, info in net.items() if info["type"] in self._merge_op_type]
+        merge_layers.reverse()
+        print("merge layers:", merge_layers)
+        seen = set()
+
+        def cared_bottoms(name):
+            if name in seen:
+                return []
+            seen.add(name)
+            found = []
+            for b in net[name]["inputs"]:
+                if net[b]["type"] in self._cared_op_type:
+                    found.append(b)
+                else:
+                    found.extend(cared_bottoms(b))
+            return found
+
+        groups = []
+        for layer in merge_layers:
+            bottoms = cared_bottoms(layer)
+            print(layer, bottoms)
+            if bottoms:
+                groups.append(bottoms)
+        return groups
+
+    def _group_has_eltwise(self, group):
+        return any(self.net_info[n]["type"] == "Eltwise" for n in group)
+
+    # ------------------------------------------------------------------------------------------
+    # activation calibration
+    # ------------------------------------------------------------------------------------------
+    def _calibration_items(self, images_files):
+        """Yield the calibration items this rank owns.  Batches 0..MAX_CALI_IMG_NUM are used
+        (i > MAX breaks: N+1 batches, pytorch_quantizer.py:381); with W ranks, batch i goes to
+        rank i % W.  Sequences are indexed so that other ranks' batches are never materialised."""
+        rank, world = _dist_state()
+        last = self._max_img_num
+        if hasattr(images_files, "__getitem__") and hasattr(images_files, "__len__"):
+            for i in range(rank, min(len(images_files), last + 1), world):
+                yield i, images_files[i]
+            return
+        for i, item in enumerate(images_files):
+            if i > last:
+                break
+            if i % world == rank:
+                yield i, item
+
+    def activation_quantize(self, images_files):
+        settings = self.config["SETTINGS"]
+        table_file = self.config["OUTPUT"]["FEAT_BIT_TABLE"]
+        rank, world = _dist_state()
+
+        merge_groups = self.get_merge_groups(self.net_info)
+        top_feat_names = ["image"] + list(self.net_info.keys())
+        collector = self.collector_cls(top_feat_names, interval_num=settings["INTERVAL_NUM"],
+                                       statistic=settings["STATISTIC"], worker_num=settings["WORKER_NUM"],
+                                       debug=False)
+        quantizer = self.quantizer_cls(top_feat_names, worker_num=settings["WORKER_NUM"], debug=False)
+        named_feats, hooks = self.regist_hook_outfeature(self.model)
+        self._collector, self._quantizer = collector, quantizer
+        t0 = time.perf_counter()
+
+        # pass 1: running abs-max of every cared tensor
+        for i, item in self._calibration_items(images_files):
+            self.net_forward(self.model, item)
+            collector.refresh_max_val(named_feats)
+        if world > 1:
+            collector.all_reduce_max()
+        distribution_intervals = collector.distribution_intervals
+        t1 = time.perf_counter()
+
+        # tensors that are added / concatenated must share one scale: the group's largest interval
+        # (groups fed by an Eltwise are tied after the KL search instead)
+        for group in merge_groups:
+            assert len(group) > 1
+            if self._group_has_eltwise(group):
+                continue
+            widest = 0
+            for name in group:
+                widest = max(widest, distribution_intervals[name])
+            for name in group:
+                distribution_intervals[name] = widest
+
+        # pass 2: histograms with the final intervals
+        print("Collect histograms of activations:")
+        for i, item in self._calibration_items(images_files):
+            self.net_forward(self.model, item)
+            collector.add_to_distributions(named_feats)
+        if world > 1:
+            collector.all_reduce_hist()
+        t2 = time.perf_counter()
+
+        # a merged group is searched on the sum of its members' histograms
+        pooled = [g for g in merge_groups if not self._group_has_eltwise(g)]
+        distributions = collector.merged_distributions(pooled)
+        quantizer.quantize(distributions, distribution_intervals)
+        bits = quantizer.bits
+
+        # eltwise_k = eltwise_{k-1} + conv: the conv takes the earlier eltwise's bit
+        for group in merge_groups:
+            assert len(group) > 1
+            elt_idx = None
+            for i, name in enumerate(group):
+                if self.net_info[name]["type"] == "Eltwise":
+                    elt_idx = i
+            if elt_idx is not None:
+                conv_idx = 1 - elt_idx
+                print("bit conv:eltwise ", bits[group[conv_idx]], bits[group[elt_idx]])
+                bits[group[conv_idx]] = bits[group[elt_idx]]
+        t3 = time.perf_counter()
+
+        lines = []
+        first_op = True
+        for i, feat_name in enumerate(top_feat_names):
+            if feat_name == "image":
+                line = "image " + str(bits["image"])
+            elif first_op:
+                line = "%s %s %s" % (self.cared_op_layer_names[i - 1], bits[feat_name], bits["image"])
+                first_op = False
+            elif len(self.net_info[feat_name]["inputs"]) > 0:
+                line = " ".join([self.cared_op_layer_names[i - 1], str(bits[feat_name])]
+                                + [str(bits[src]) for src in self.net_info[feat_name]["inputs"]])
+            else:
+                raise NotImplementedError(self.net_info[feat_name])
+            lines.append(line)
+        if rank == 0:
+            with open(table_file, "w") as fh:
+                for line in lines:
+                    fh.write(line + "\n")
+        for h in hooks:
+            h.remove()
+        named_feats.clear()
+        self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0}
+        return bits
+
+    def regist_hook_outfeature(self, model):
+        """Forward hooks that expose, after each forward, an ordered dict 'image' + one entry per
+        cared node ("<ClassName>_<ordinal>", same keys as net_info) holding the DEVICE tensors.
+        Returns (dict, hook handles)."""
+        out_feat = OrderedDict()
+        handles = []
+        cared = set(self.net_info.keys())
+        state = {"n": 0}
+        total = int(self.layers_num)
+
+        def on_forward(module, inputs, output):
+            if state["n"] == 0:
+                out_feat.clear()
+                out_feat["image"] = inputs[0].detach()
+            state["n"] += 1
+            key = "%s_%i" % (type(module).__name__, state["n"])
+            if key in cared:
+                out_feat[key] = output.detach()
+            if state["n"] >= total:
+                state["n"] = 0
+
+        for m in model.modules():
+            if type(m).__name__ in self._all_op_type:
+                handles.append(m.register_forward_hook(on_forward))
+        return out_feat, handles
+
+    # ------------------------------------------------------------------------------------------
+    # output directories
+    # ------------------------------------------------------------------------------------------
+    def init_dir(self):
+        out = self.config["OUTPUT"]
+        for key in ("WORK_DIR", "WEIGHT_DIR", "BIAS_DIR", "FINAL_WEIGHT_DIR", "FINAL_BIAS_DIR"):
+            if not os.path.exists(out[key]):
+                os.makedirs(out[key], exist_ok=True)
+
+    # ------------------------------------------------------------------------------------------
+    # weights
+    # ------------------------------------------------------------------------------------------
+    def rewrite_weight(self):
+        out = self.config["OUTPUT"]
+        rank, _ = _dist_state()
+        if rank != 0:
+            return
+        rewriter = BiasReWriter(out["WEIGHT_DIR"], out["BIAS_DIR"], out["FINAL_WEIGHT_DIR"], out["FINAL_BIAS_DIR"],
+                                out["WEIGHT_BIT_TABLE"], out["FEAT_BIT_TABLE"],
+                                max_shift_limit=self.config["SETTINGS"]["MAX_SHIFT"])
+        weight_bits, bias_bits = rewriter.get_weight_info()
+        feat_bits, infeat_bits = rewriter.get_feat_info()
+        unmatched = set(bias_bits.keys()) ^ set(feat_bits.keys())
+        if unmatched:
+            print("These layers not include params but we care about their features:", unmatched)
+        print("Align bias bit:")
+        rewriter.rewrite_bias_table(bias_bits, feat_bits)
+        rewriter.rewrite_bias_dir(bias_bits, feat_bits)
+        print("Add max shift limitation:")
+        need_flag, new_weight = rewriter.max_shift_limit_weight(feat_bits, infeat_bits, weight_bits)
+        if need_flag:
+            print("rewirte weight!!!!")
+            rewriter.rewrite_weight_table(weight_bits, new_weight)
+            rewriter.rewrite_weight_dir(weight_bits, new_weight)
+        print("Done!")
+
+    def weight_quantize(self):
+        """Max-based weight quantisation: bit = 7 - ceil(log2(absmax)), q = clip(rint(w * 2^bit)),
+        one JSON file per parameter plus weight.table; then rewrite_weight()."""
+        settings = self.config["SETTINGS"]
+        out = self.config["OUTPUT"]
+        rank, _ = _dist_state()
+
+        names, tensors = [], []
+        for name, param in self.model.named_parameters():
+            if not name.endswith("weight") and not name.endswith("bias"):
+                print("[WARNING]", " not supported param: {}".format(name))
+                continue
+            owner = self.model
+            for part in name.split(".")[:-1]:
+                owner = getattr(owner, part)
+            t = param.detach()
+            if name.endswith("weight") and isinstance(owner, nn.Conv2d):
+                if owner.dilation != (1, 1) and not settings["SUPPORT_DILATION"]:
+                    t = self.dilation_to_zero_padding(t, owner.dilation)
+            names.append(name)
+            tensors.append(t.float().contiguous())
+
+        collector = self.collector_cls(names, interval_num=settings["INTERVAL_NUM"], statistic=settings["STATISTIC"],
+                                       worker_num=settings["WORKER_NUM"])
+        quantizer = self.quantizer_cls(names, worker_num=settings["WORKER_NUM"])
+        params = dict(zip(names, tensors))
+        collector.refresh_max_val(params)
+        max_vals = collector.max_vals
+        print("max vals:", max_vals)
+
+        if self._DKL_weight:
+            collector.add_to_distributions(params)
+            quantizer.quantize(collector.merged_distributions([]), collector.distribution_intervals)
+            bits_co = dict(quantizer.bits)
+            print("threshold:", quantizer.threshold_value)
+        else:
+            bits_co = OrderedDict()
+            for name in names:
+                bits_co[name] = int(8 - 1 - math.ceil(math.log(max_vals[name], 2)))
+
+        table_lines = []
+        for name, bit in bits_co.items():
+            q = collector.quantize_param(params[name], bit)           # int32 ndarray, clip(rint(w*2^bit))
+            table_lines.append(name + " " + str(bit))
+            if rank != 0:
+                continue
+            if name.endswith("weight"):
+                dump_int_array(q, os.path.join(out["WEIGHT_DIR"], name + ".json"))
+            elif name.endswith("bias"):
+                dump_int_array(q, os.path.join(out["BIAS_DIR"], name + ".json"))
+            else:
+                raise NotImplementedError(name)
+        if rank == 0:
+            with open(out["WEIGHT_BIT_TABLE"], "w") as fh:
+                for line in table_lines:
+                    fh.write(line + "\n")
+        self.rewrite_weight()
+
+    def dilation_to_zero_padding(self, tensor, dilation):
+        """A k x k kernel with dilation 2 as the equivalent dense (2k-1) x (2k-1) kernel."""
+        t = torch.as_tensor(tensor)
+        assert t.shape[2] == t.shape[3] and tuple(dilation) == (2, 2), "Not support."
+        k = t.shape[2]
+        dense = torch.zeros(t.shape[0], t.shape[1], 2 * k - 1, 2 * k - 1, dtype=torch.float32, device=t.device)
+        dense[..., ::2, ::2] = t
+        return dense

@@ -1,0 +1,114 @@
+"""Oracle-backed stand-ins for the statistics engine (DistributionCollector / Quantizer), used ONLY by
+the CPU test-suite to exercise the host logic of tools.Quantity (graph discovery, merge groups, table
+and JSON writers, sharding + all-reduce plumbing) on a box without a GPU.
+
+TEST INFRASTRUCTURE: the product never imports this; its engine is the HIP library and nothing else.
+The doubles compute with oracle/fq_oracle.c (the CPU restatement) on host NumPy arrays and use the
+same method names the product classes expose.
+"""
+import math
+
+import numpy as np
+import torch
+
+from oracle import fq_oracle as orc
+
+BINS = 2048
+
+
+def _np(t):
+    if isinstance(t, torch.Tensor):
+        return t.detach().cpu().numpy().astype(np.float32, copy=False).ravel()
+    return np.asarray(t, dtype=np.float32).ravel()
+
+
+class OracleCollector(object):
+
+    def __init__(self, tensor_list, interval_num=2048, statistic=1, worker_num=1, debug=False):
+        assert interval_num == BINS
+        self._tensor_list = list(tensor_list)
+        self._row = {n: i for i, n in enumerate(self._tensor_list)}
+        self._statistic = statistic
+        self._interval_num = interval_num
+        T = len(self._tensor_list)
+        self._max = np.zeros(T, dtype=np.float32)
+        self._hist = np.zeros((T, BINS), dtype=np.int64)
+        self._refreshed = False
+        self._added = False
+
+    @property
+    def max_vals(self):
+        assert self._refreshed
+        return {n: (self._max[i] if self._max[i] > 0 else 0) for i, n in enumerate(self._tensor_list)}
+
+    @property
+    def distribution_intervals(self):
+        mv = self.max_vals
+        iv = {n: self._statistic * mv[n] / self._interval_num + 1e-12 for n in self._tensor_list}
+        self._distribution_intervals = iv
+        return iv
+
+    @property
+    def distributions(self):
+        assert self._added
+        return {n: self._hist[i].astype(np.int32) for i, n in enumerate(self._tensor_list)}
+
+    def refresh_max_val(self, tensors):
+        self._refreshed = True
+        for i, n in enumerate(self._tensor_list):
+            self._max[i] = orc.absmax(_np(tensors[n]), self._max[i])
+
+    def add_to_distributions(self, tensors):
+        self._added = True
+        if not hasattr(self, "_distribution_intervals"):
+            self.distribution_intervals
+        for i, n in enumerate(self._tensor_list):
+            orc.hist2048(_np(tensors[n]), np.float32(self._distribution_intervals[n]), self._hist[i])
+
+    def all_reduce_max(self):
+        import torch.distributed as dist
+        t = torch.from_numpy(self._max)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+
+    def all_reduce_hist(self):
+        import torch.distributed as dist
+        t = torch.from_numpy(self._hist)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    def merged_distributions(self, groups):
+        merged = self._hist.copy()
+        for g in groups:
+            idx = [self._row[n] for n in g]
+            merged[idx] = merged[idx].sum(axis=0, keepdims=True)
+        return {n: merged[i] for i, n in enumerate(self._tensor_list)}
+
+    def quantize_param(self, tensor, bit):
+        a = tensor.detach().cpu().numpy() if isinstance(tensor, torch.Tensor) else np.asarray(tensor)
+        return orc.quantize_param_i32(a, bit)
+
+
+class OracleQuantizer(object):
+
+    def __init__(self, tensor_list, worker_num=1, debug=False):
+        self._tensor_list = list(tensor_list)
+        self._bits, self._threshold_value, self._threshold_bin = {}, {}, {}
+
+    @property
+    def bits(self):
+        return self._bits
+
+    @property
+    def threshold_value(self):
+        return self._threshold_value
+
+    @property
+    def threshold_bins(self):
+        return self._threshold_bin
+
+    def quantize(self, distributions, distribution_intervals):
+        for n in self._tensor_list:
+            t = orc.kl_threshold(orc.normalize(np.asarray(distributions[n])))
+            tb = (t + 0.5) * distribution_intervals[n]
+            self._threshold_bin[n] = t
+            self._threshold_value[n] = tb
+            self._bits[n] = int(8 - 1 - math.ceil(math.log(tb, 2)))

@@ -148,3 +148,45 @@ def g5_inputs():
     ints = r.integers(-70000, 70000, 1000).astype(np.float32)      # integer-valued accumulators
     halves = (r.integers(-600, 600, 500).astype(np.float32) + np.float32(0.5))
     return np.concatenate([base, rnd, ints, halves]).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# End-to-end fixtures: deterministic weights / data that do not depend on module construction order
+# --------------------------------------------------------------------------------------------
+
+def seed_model(model, base_seed=0, gamma_scale=1.0):
+    """Fill every parameter and BatchNorm statistic from a generator keyed by the tensor's
+    state_dict name, so the reference's model file and ours get identical values."""
+    import zlib
+
+    import torch
+    sd = model.state_dict()
+    with torch.no_grad():
+        for key in sorted(sd.keys()):
+            t = sd[key]
+            if not t.is_floating_point():
+                continue
+            g = torch.Generator().manual_seed(base_seed * 1000003 + zlib.crc32(key.encode()))
+            if key.endswith("running_var"):
+                v = torch.rand(t.shape, generator=g) + 0.5
+            elif key.endswith("running_mean"):
+                v = torch.randn(t.shape, generator=g) * 0.1
+            elif t.dim() == 1 and key.endswith("weight"):
+                v = (torch.rand(t.shape, generator=g) + 0.5) * gamma_scale
+            elif t.dim() == 1:
+                v = torch.randn(t.shape, generator=g) * 0.1
+            else:
+                fan_in = t[0].numel()
+                v = torch.randn(t.shape, generator=g) * (2.0 / fan_in) ** 0.5
+            t.copy_(v.to(t.dtype))
+    return model
+
+
+def calib_batches(n_batches, shape, seed=1234):
+    """List of (images, labels) pairs as a DataLoader would yield them (PRE_PROCESS.IMG = 1)."""
+    import torch
+    out = []
+    for i in range(n_batches):
+        g = torch.Generator().manual_seed(seed + i)
+        out.append((torch.randn(*shape, generator=g), torch.zeros(shape[0], dtype=torch.long)))
+    return out

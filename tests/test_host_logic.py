@@ -1,0 +1,156 @@
+"""Host-side logic of the drop-in (no GPU): graph discovery, merge groups, file writers, the BN fold,
+the C-ABI symbol table.  Goldens come from the imported reference (tests/golden/make_golden_*.py)."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from workdir_util import product_workdir
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _golden(golden_dir, name):
+    with open(os.path.join(golden_dir, name)) as fh:
+        return json.load(fh)
+
+
+# ---------------------------------------------------------------- C ABI
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "fq.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = re.findall(r"\b(fq_[a-z0-9_]+)\s*\(", hdr)
+    assert len(names) >= 18
+    lib_path = os.path.join(ROOT, "pytorch-quantity_amd", "lib", "libfq_hip.so")
+    assert os.path.isfile(lib_path), "build the library first: make -C pytorch-quantity_amd/csrc"
+    lib = ctypes.CDLL(lib_path)
+    for n in names:
+        assert hasattr(lib, n), "libfq_hip.so does not export %s" % n
+    lib.fq_version.restype = ctypes.c_int
+    assert lib.fq_version() == 100
+
+
+def test_host_bits_helpers_match_python(oracle):
+    from common.quantity import _native
+    rng = np.random.default_rng(3)
+    thr = rng.integers(128, 2048, 500).astype(np.int32)
+    iv = np.exp(rng.uniform(-12, 3, 500)).astype(np.float32)
+    iv[:8] = np.float32(2.0) ** np.arange(-8, 0)
+    bits, tv = _native.bits_from_threshold(thr, iv)
+    import math
+    for t, i, b, v in zip(thr, iv, bits, tv):
+        tb = (int(t) + 0.5) * i
+        assert isinstance(tb, np.float32) and tb == v
+        assert b == int(8 - 1 - math.ceil(math.log(tb, 2)))
+        assert (b, v) == oracle.bits_from_threshold(int(t), i)
+    m = np.concatenate([np.exp(rng.uniform(-10, 8, 300)), 2.0 ** np.arange(-10, 10)]).astype(np.float32)
+    got = _native.bits_from_absmax(m)
+    for x, b in zip(m, got):
+        assert b == int(8 - 1 - math.ceil(math.log(x, 2))) == oracle.bits_from_absmax(x)
+
+
+def test_no_cpu_fallback_for_device_ops():
+    from common.quantity import _native, QuanDequan, NewAdd
+    x = torch.randn(16)
+    with pytest.raises(_native.FqError):
+        _native.quandequan(x, 3)
+    with pytest.raises(_native.FqError):
+        QuanDequan(8, 3)(x)
+    with pytest.raises(_native.FqError):
+        NewAdd()(x, x)
+    with pytest.raises(_native.FqError):
+        _native.absmax_seg([x], [0], torch.zeros(1))
+
+
+# ---------------------------------------------------------------- JSON writer
+@pytest.mark.parametrize("shape", [(), (5,), (1,), (3, 4), (2, 3, 4, 5), (4, 1, 1, 1), (2, 0), (0,), (0, 3), (3, 0, 2),
+                                   (64, 3, 7, 7), (10, 512)])
+def test_json_writer_is_byte_identical_to_json_dump(tmp_path, shape):
+    from tools import _jsonio
+    rng = np.random.default_rng(len(shape))
+    a = rng.integers(-40000, 40000, size=shape).astype(np.int32)
+    ref = json.dumps(a.tolist(), indent=4)
+    p = str(tmp_path / "x.json")
+    _jsonio.dump_int_array(a, p)
+    assert open(p).read() == ref
+    assert _jsonio.dumps_int_array(a) == ref
+
+
+# ---------------------------------------------------------------- merge_bn (G8)
+@pytest.mark.parametrize("tag", ["nobias", "bias"])
+def test_merge_bn_matches_reference(golden_dir, tag):
+    import torch.nn as nn
+    from common.quantity import merge_bn
+    g = np.load(os.path.join(golden_dir, "g8_merge_bn.npz"))
+    seq = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=(tag == "bias")), nn.BatchNorm2d(8), nn.ReLU(False))
+    sd = {k[len(tag) + 5:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + "/pre/")}
+    seq.load_state_dict(sd)
+    seq.eval()
+    merged = merge_bn(seq)
+    assert type(merged[1]).__name__ == str(g[tag + "/bn_type_after"]) == "Identity"
+    np.testing.assert_array_equal(merged[0].weight.detach().numpy(), g[tag + "/w"])
+    np.testing.assert_array_equal(merged[0].bias.detach().numpy(), g[tag + "/b"])
+    np.testing.assert_array_equal(merged(torch.from_numpy(g[tag + "/x"])).detach().numpy(), g[tag + "/y_merged"])
+
+
+# ---------------------------------------------------------------- graph discovery (G7)
+def _discover(ctor, shape, **seed_kw):
+    from common.quantity import merge_bn
+    from tools import Quantity
+    with product_workdir(input_shape=shape, device="cpu"):
+        model = merge_bn(cases.seed_model(ctor(), **seed_kw).eval())
+        q = Quantity(model)
+        return {"net_info": dict(q.net_info), "net_info_order": list(q.net_info.keys()),
+                "cared_op_layer_names": q.cared_op_layer_names, "merge_groups": q.get_merge_groups(q.net_info),
+                "layers_num": q.layers_num}
+
+
+@pytest.mark.parametrize("tag", ["r50", "r101"])
+def test_graph_discovery_matches_reference_bottleneck(golden_dir, tag):
+    from model.resnet.ResNet_fabu import ResNet50, ResNet101
+    ref = _golden(golden_dir, "g7_netinfo.json")[tag]
+    got = _discover(ResNet50 if tag == "r50" else ResNet101, "1,3,224,224", gamma_scale=0.5)
+    for key in ("net_info_order", "cared_op_layer_names", "merge_groups", "layers_num", "net_info"):
+        assert got[key] == ref[key], key
+
+
+def test_graph_discovery_survives_exploding_activations():
+    """The reference's value fingerprints collide on a deep net once activations grow (it raises
+    'Same input and output id' on ResNet-101 with unit-scale BN); identity tracking does not."""
+    from model.resnet.ResNet_fabu import ResNet101
+    got = _discover(lambda: ResNet101(input_size=64), "1,3,64,64")
+    assert len(got["net_info_order"]) == 138 and len(got["merge_groups"]) == 33
+
+
+# ---------------------------------------------------------------- rewriter (G6)
+def test_rewriter_matches_reference(golden_dir, tmp_path):
+    from tools import BiasReWriter
+    g = _golden(golden_dir, "g6_rewriter.json")
+    d = str(tmp_path)
+    for sub in ("weight", "bias", "new_weight", "new_bias"):
+        os.makedirs(os.path.join(d, sub))
+    for fname in ("feat.table", "weight.table"):
+        with open(os.path.join(d, fname), "w") as fh:
+            fh.write(g["inputs"][fname])
+    for rel, content in g["inputs"]["params"].items():
+        with open(os.path.join(d, rel), "w") as fh:
+            json.dump(content, fh, indent=4)
+    rw = BiasReWriter(os.path.join(d, "weight"), os.path.join(d, "bias"), os.path.join(d, "new_weight"),
+                      os.path.join(d, "new_bias"), os.path.join(d, "weight.table"), os.path.join(d, "feat.table"),
+                      max_shift_limit=12)
+    weight_bits, bias_bits = rw.get_weight_info()
+    feat_bits, infeat_bits = rw.get_feat_info()
+    rw.rewrite_bias_table(bias_bits, feat_bits)
+    rw.rewrite_bias_dir(bias_bits, feat_bits)
+    need, new_w = rw.max_shift_limit_weight(feat_bits, infeat_bits, weight_bits)
+    assert need == g["need_rewrite"] and new_w == g["new_weight_bits"]
+    rw.rewrite_weight_table(weight_bits, new_w)
+    rw.rewrite_weight_dir(weight_bits, new_w)
+    assert open(os.path.join(d, "weight.table")).read() == g["weight.table"]
+    for rel, text in g["files"].items():
+        assert open(os.path.join(d, rel)).read() == text, rel
