@@ -139,7 +139,7 @@ def cpu_baseline(model_cpu_ctor, sample_images, hw, n_images_full, q, log):
     from concurrent.futures import ThreadPoolExecutor
     from oracle import fq_oracle as orc
     orc.build()
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)          # beyond one socket's worth oneDNN only gets slower
     torch.set_num_threads(cores)
     model = model_cpu_ctor()
     names = ["image"] + list(q.net_info.keys())
@@ -163,6 +163,8 @@ def cpu_baseline(model_cpu_ctor, sample_images, hw, n_images_full, q, log):
             hooks.append(m.register_forward_hook(hook))
     x = torch.randn(sample_images, 3, hw, hw, generator=torch.Generator().manual_seed(1234))
     pool = ThreadPoolExecutor(cores)
+    with torch.no_grad():
+        model(x[:1])                                                 # untimed: oneDNN primitive creation
     t0 = time.perf_counter()
     with torch.no_grad():
         model(x)                                                     # pass 1 forward
@@ -244,6 +246,7 @@ def main():
     make_workdir(K * world - 1, shape, local_rank)
     data = DeviceBatches(K * world, B, HW, rank, world, device)
     q = Quantity(model)
+    q.profile_phases = True
     with KernelTimer(_native, "hist2048_seg") as kt_hist, KernelTimer(_native, "absmax_seg") as kt_max:
         kt_hist.enabled = kt_max.enabled = True
         barrier()
@@ -270,7 +273,7 @@ def main():
                                "(batch %d x %d steps), 71 histogram rows x 2048 bins" %
                                ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K),
                    "batch": B, "images_total": images, "parallelism": "dp%d" % world},
-        "phases_s": {k: round(v, 4) for k, v in timings.items()},
+        "phases_s": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
     }
     if hist_s:
         ach = hist_s["bytes_per_launch"] / (hist_s["mean_ms"] * 1e-3) / 1e9

@@ -124,6 +124,28 @@ int fq_recon_epilogue_f32(const float* acc, const float* qbias, float* y, size_t
 /* weight quantiser, pytorch_quantizer.py:656-657,:663: (int32) clip(around(w * 2^bit), -128, 127) */
 int fq_quantize_param_i32(const float* w, int32_t* q, size_t n, int bit, fq_stream_t stream);
 
+/* ---- integer contraction of NewConv2d / NewLinear on the matrix cores -------------------------- */
+
+/* Quantity.forward (new_quantity_op.py:52-58) fused with the layout change the MFMA kernel wants:
+ *   y[n][hw][c] = (int8) clamp(rint(x[n][c][hw] * 2^ib), -128, 127),  c in [C, Cpad) = 0
+ * x: fp32 [N][C][HW] (NCHW), y: int8 [N][HW][Cpad] (NHWC), Cpad >= C, Cpad % 4 == 0 (use a multiple
+ * of 16 for fq_conv2d_i8).  HW == 1 covers Linear inputs [N][F]. */
+int fq_quantize_i8_nhwc(const float* x_nchw, int8_t* y_nhwc, int N, int C, int HW, int Cpad, int ib,
+                        fq_stream_t stream);
+
+/* NewConv2d.forward / NewLinear.forward after Quantity (new_quantity_op.py:126-132, :199-204):
+ *   acc[n][k][p][q] = sum_{r,s,c} w[k][r][s][c] * x[n][p*stride-pad+r*dil][q*stride-pad+s*dil][c]   (int32, exact)
+ *   y = clamp( RightShift(acc, rs) + qbias[k] ) / 2^ob                                    (fp32 NCHW)
+ * implicit GEMM on v_mfma_i32_32x32x32_i8.  x: int8 NHWC [N][H][W][C], w: int8 [K][R][S][C], both
+ * 16-byte aligned, C % 16 == 0 (zero-pad channels; FQ_ERR_UNSUPPORTED otherwise), groups == 1.
+ * qbias: fp32[K] integer valued.  y: fp32 [N][K][P][Q].  A Linear layer is H = W = R = S = 1.
+ * The reference computes acc with an fp32 convolution, exact while |partial sums| < 2^24; in that
+ * regime the results are identical, beyond it this kernel stays exact. */
+int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw,
+                 int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
+                 int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob, int bitwidth,
+                 fq_stream_t stream);
+
 /* ---- output files ------------------------------------------------------------------------------ */
 
 /* HOST helper: write an int32 array as nested JSON lists, byte-identical to Python's

@@ -1,0 +1,297 @@
+// fq_conv_i8.hip -- the integer contraction of NewConv2d / NewLinear on the gfx950 matrix cores.
+//
+// Reference: quantity/common/quantity/new_quantity_op.py:124-133 (NewConv2d.forward) and :197-205
+// (NewLinear.forward) run Quantity -> fp32 conv over integer-valued tensors -> RightShift -> BiasAdd
+// -> Sp -> DeQuantity as 7+ separate passes.  Here:
+//
+//   quantize_i8_nhwc_kernel   x fp32 NCHW -> int8 NHWC (clamp(rint(x * 2^ib))), channels zero-padded
+//                             to a multiple of 16.  HBM bound: 4 B read + 1 B written per element.
+//   conv2d_i8_kernel          implicit GEMM  D[k_out][pixel] = sum_{r,s,c} W[k][r][s][c] * X[n][ih][iw][c]
+//                             on v_mfma_i32_32x32x32_i8 (int32 accumulation: exact, where the
+//                             reference's fp32 conv is exact only below 2^24), with the whole tail
+//                             (shift, round half away, bias, saturate, dequantise) fused into the
+//                             epilogue, written straight to fp32 NCHW.  This is the one place on
+//                             the path that is a dense contraction, hence the one MFMA kernel.
+//
+// Tiling (64-wide wavefronts): workgroup = 256 threads = 2x2 waves, tile = TK output channels x 128
+// pixels, K-step = 64 bytes of the (r, s, c) reduction axis = 2 MFMA k-sub-steps.  Pixels sit on
+// the MFMA lane index, so each accumulator register is 32 consecutive pixels of one output channel:
+// 128-byte coalesced NCHW stores with no shuffle.  Operand tiles are staged global -> registers ->
+// LDS (double buffered, 16-byte accesses); the 64-byte LDS rows are XOR-swizzled
+// (chunk ^= (row >> 2) & 3) so that ds_read_b128 fragment reads are bank-conflict free.
+#include "fq_common.h"
+
+namespace fq {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kConvBlock = 256;
+constexpr int kTP = 128;                 // pixels per workgroup tile
+
+struct ConvParams {
+    int N, H, W, C;                      // input NHWC, C % 16 == 0
+    int K, R, S;                         // weights [K][R][S][C]
+    int P, Q;                            // output spatial
+    int stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+    int M;                               // N * P * Q
+    int chunks;                          // R * S * C / 16   (16-byte units of the reduction axis)
+    int c16;                             // C / 16
+    float inv_rs, inv_ob, lo, hi;        // 2^-rs, 2^-ob, clamp range
+    int ilo, ihi;
+};
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+
+// RightShift -> BiasAdd -> Sp -> DeQuantity on one accumulator (new_quantity_op.py:127-132)
+__device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& p) {
+    const float v = (float)acc * p.inv_rs;
+    const float w = v + (v > 0.0f ? 0.5f : -0.5f);
+    int r = (int)w;
+    r = r < p.ilo ? p.ilo : (r > p.ihi ? p.ihi : r);
+    float o = (float)r + qb;
+    o = o < p.lo ? p.lo : (o > p.hi ? p.hi : o);
+    return o * p.inv_ob;
+}
+
+template <int TK>
+__global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                               const float* __restrict__ qbias, float* __restrict__ y,
+                                                               const ConvParams p) {
+    constexpr int MT = TK / 64;           // 32-row MFMA tiles per wave along k_out
+    constexpr int NT = 2;                 // 32-col MFMA tiles per wave along pixels
+    constexpr int A_LOADS = TK / 64;      // 16-byte chunks per thread per K-step for the weight tile
+    constexpr int B_LOADS = kTP / 64;
+    __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * 64];
+    __shared__ __attribute__((aligned(16))) int8_t sB[2][kTP * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_k = (wave >> 1) * (TK / 2);          // this wave's first k_out row inside the tile
+    const int wave_p = (wave & 1) * 64;                 // this wave's first pixel inside the tile
+    const int m0 = blockIdx.x * kTP;
+    const int k0 = blockIdx.y * TK;
+
+    // staging assignment: thread -> (row = tid >> 2 (+64 per load), chunk-in-step = tid & 3)
+    const int ld_row = tid >> 2, ld_chunk = tid & 3;
+    const int PQ = p.P * p.Q;
+    int b_ih0[B_LOADS], b_iw0[B_LOADS];
+    long b_base[B_LOADS];
+    bool b_ok[B_LOADS];
+#pragma unroll
+    for (int j = 0; j < B_LOADS; ++j) {
+        const int m = m0 + ld_row + 64 * j;
+        b_ok[j] = m < p.M;
+        const int mm = b_ok[j] ? m : 0;
+        const int n = mm / PQ, pq = mm - n * PQ;
+        const int op = pq / p.Q, oq = pq - op * p.Q;
+        b_ih0[j] = op * p.stride_h - p.pad_h;
+        b_iw0[j] = oq * p.stride_w - p.pad_w;
+        b_base[j] = (long)n * p.H * p.W * p.C;
+    }
+    const long wrow_bytes = (long)p.chunks * 16;
+
+    v4i ra[A_LOADS], rb[B_LOADS];
+    auto load_step = [&](int step) {
+        const int g = step * 4 + ld_chunk;              // global 16-byte chunk on the reduction axis
+        const bool live = g < p.chunks;
+        const int rs_ = live ? g / p.c16 : 0;
+        const int cc = live ? g - rs_ * p.c16 : 0;
+        const int r = rs_ / p.S, s = rs_ - r * p.S;
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j) {
+            const int k = k0 + ld_row + 64 * j;
+            v4i v = {0, 0, 0, 0};
+            if (live && k < p.K) v = *reinterpret_cast<const v4i*>(w + (long)k * wrow_bytes + (long)g * 16);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            const int ih = b_ih0[j] + r * p.dil_h, iw = b_iw0[j] + s * p.dil_w;
+            v4i v = {0, 0, 0, 0};
+            if (live && b_ok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                v = *reinterpret_cast<const v4i*>(x + b_base[j] + ((long)ih * p.W + iw) * p.C + cc * 16);
+            rb[j] = v;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j) {
+            const int row = ld_row + 64 * j;
+            *reinterpret_cast<v4i*>(&sA[buf][row * 64 + swz(row, ld_chunk) * 16]) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_LOADS; ++j) {
+            const int row = ld_row + 64 * j;
+            *reinterpret_cast<v4i*>(&sB[buf][row * 64 + swz(row, ld_chunk) * 16]) = rb[j];
+        }
+    };
+
+    v16i acc[MT][NT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+
+    const int nsteps = (p.chunks + 3) >> 2;
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < nsteps) load_step(step + 1);      // global loads in flight under the MFMAs
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int chunk = ks * 2 + (lane >> 5);       // lane l holds k = 16*(l>>5) + j of this 32-deep sub-step
+            v4i fa[MT], fb[NT];
+#pragma unroll
+            for (int a = 0; a < MT; ++a) {
+                const int row = wave_k + a * 32 + (lane & 31);
+                fa[a] = *reinterpret_cast<const v4i*>(&sA[cur][row * 64 + swz(row, chunk) * 16]);
+            }
+#pragma unroll
+            for (int b = 0; b < NT; ++b) {
+                const int row = wave_p + b * 32 + (lane & 31);
+                fb[b] = *reinterpret_cast<const v4i*>(&sB[cur][row * 64 + swz(row, chunk) * 16]);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
+        }
+        if (step + 1 < nsteps) {
+            store_step(cur ^ 1);                          // the other buffer was last read one barrier ago
+            __syncthreads();
+        }
+    }
+
+    // epilogue: D row = k_out = (r&3) + 8*(r>>2) + 4*(lane>>5), D col = pixel = lane&31
+#pragma unroll
+    for (int b = 0; b < NT; ++b) {
+        const int m = m0 + wave_p + b * 32 + (lane & 31);
+        if (m >= p.M) continue;
+        const int n = m / PQ, pq = m - n * PQ;
+        float* __restrict__ out = y + (long)n * p.K * PQ + pq;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wave_k + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (k < p.K) out[(long)k * PQ] = conv_tail(acc[a][b][r], qbias[k], p);
+            }
+        }
+    }
+}
+
+// ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
+// block = (64 hw) x (64 c) tile of one image, transposed through LDS.
+__global__ __launch_bounds__(256) void quantize_i8_nhwc_kernel(const float* __restrict__ x, int8_t* __restrict__ y, int C, int HW,
+                                                               int Cpad, float scale) {
+    __shared__ int8_t tile[64][68];                      // [c][hw], padded rows
+    const int n = blockIdx.z, hw0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const float* __restrict__ src = x + (long)n * C * HW;
+    // load: 64 hw (fast) x 4 channels per pass
+    const int j = tid & 63;
+#pragma unroll 4
+    for (int ci = tid >> 6; ci < 64; ci += 4) {
+        const int c = c0 + ci, hw = hw0 + j;
+        float v = 0.0f;
+        if (c < C && hw < HW) v = src[(long)c * HW + hw];
+        float q = rintf(v * scale);
+        q = q < -128.0f ? -128.0f : (q > 127.0f ? 127.0f : q);   // NaN -> stays NaN -> cast gives 0
+        tile[ci][j] = (int8_t)(int)q;
+    }
+    __syncthreads();
+    // store: 16 threads x 4 bytes = 64 channels of one hw position
+    int8_t* __restrict__ dst = y + (long)n * HW * Cpad;
+    const int c4 = (tid & 15) * 4;
+#pragma unroll 4
+    for (int jj = tid >> 4; jj < 64; jj += 16) {
+        const int hw = hw0 + jj, c = c0 + c4;
+        if (hw < HW && c < Cpad) {
+            const unsigned packed = (unsigned)(uint8_t)tile[c4][jj] | ((unsigned)(uint8_t)tile[c4 + 1][jj] << 8) |
+                                    ((unsigned)(uint8_t)tile[c4 + 2][jj] << 16) | ((unsigned)(uint8_t)tile[c4 + 3][jj] << 24);
+            *reinterpret_cast<unsigned*>(dst + (long)hw * Cpad + c) = packed;
+        }
+    }
+}
+
+// HW == 1 (Linear input [N][F]): layouts coincide, plain element-wise with channel padding
+__global__ __launch_bounds__(256) void quantize_i8_rows_kernel(const float* __restrict__ x, int8_t* __restrict__ y, int C, int Cpad,
+                                                               long rows, float scale) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = rows * Cpad, stride = (long)gridDim.x * 256;
+    for (; i < total; i += stride) {
+        const long rrow = i / Cpad;
+        const int c = (int)(i - rrow * Cpad);
+        float v = c < C ? x[rrow * C + c] : 0.0f;
+        float q = rintf(v * scale);
+        q = q < -128.0f ? -128.0f : (q > 127.0f ? 127.0f : q);
+        y[i] = (int8_t)(int)q;
+    }
+}
+
+}  // namespace fq
+
+using namespace fq;
+
+extern "C" int fq_quantize_i8_nhwc(const float* x_nchw, int8_t* y_nhwc, int N, int C, int HW, int Cpad, int ib,
+                                   fq_stream_t stream) {
+    if (N < 0 || C <= 0 || HW < 0 || Cpad < C || (Cpad & 3) || ib < -120 || ib > 120) return FQ_ERR_INVALID_ARG;
+    if (N == 0 || HW == 0) return FQ_OK;
+    if (!x_nchw || !y_nhwc) return FQ_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(y_nhwc) & 3u) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    const float scale = ldexpf(1.0f, ib);
+    if (HW == 1) {
+        const long total = (long)N * Cpad;
+        long g = (total + 255) / 256;
+        if (g > kCUs * 16) g = kCUs * 16;
+        hipLaunchKernelGGL(quantize_i8_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, x_nchw, y_nhwc, C, Cpad, (long)N, scale);
+    } else {
+        if (N > 65535) return FQ_ERR_UNSUPPORTED;
+        dim3 grid((HW + 63) / 64, (Cpad + 63) / 64, N);
+        hipLaunchKernelGGL(quantize_i8_nhwc_kernel, grid, dim3(256), 0, st, x_nchw, y_nhwc, C, HW, Cpad, scale);
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw, int N, int H,
+                            int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                            int dil_h, int dil_w, int rs, int ob, int bitwidth, fq_stream_t stream) {
+    if (!valid_bitwidth(bitwidth) || rs < -120 || rs > 120 || ob < -120 || ob > 120) return FQ_ERR_INVALID_ARG;
+    if (N < 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride_h <= 0 || stride_w <= 0 ||
+        pad_h < 0 || pad_w < 0 || dil_h <= 0 || dil_w <= 0)
+        return FQ_ERR_INVALID_ARG;
+    if (C % 16) return FQ_ERR_UNSUPPORTED;                // pad channels to 16 in fq_quantize_i8_nhwc
+    const int P = (H + 2 * pad_h - dil_h * (R - 1) - 1) / stride_h + 1;
+    const int Q = (W + 2 * pad_w - dil_w * (S - 1) - 1) / stride_w + 1;
+    if (P <= 0 || Q <= 0) return FQ_ERR_INVALID_ARG;
+    if (N == 0) return FQ_OK;
+    if (!x_nhwc || !w_krsc || !qbias || !y_nchw) return FQ_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w_krsc)) & 15u) return FQ_ERR_INVALID_ARG;
+    const long M = (long)N * P * Q;
+    if (M > 0x7fffffffL || (long)R * S * C / 16 > 0x7fffffffL) return FQ_ERR_UNSUPPORTED;
+    ConvParams p;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.P = P; p.Q = Q;
+    p.stride_h = stride_h; p.stride_w = stride_w; p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
+    p.M = (int)M; p.c16 = C / 16; p.chunks = R * S * p.c16;
+    p.inv_rs = ldexpf(1.0f, -rs); p.inv_ob = ldexpf(1.0f, -ob);
+    if (bitwidth == 8) { p.lo = -128.0f; p.hi = 127.0f; p.ilo = -128; p.ihi = 127; }
+    else { p.lo = -32768.0f; p.hi = 32767.0f; p.ilo = -32768; p.ihi = 32767; }
+    hipStream_t st = as_stream(stream);
+    const unsigned gx = (unsigned)((M + kTP - 1) / kTP);
+    if (K <= 64) {
+        hipLaunchKernelGGL(conv2d_i8_kernel<64>, dim3(gx, (K + 63) / 64), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
+                           y_nchw, p);
+    } else {
+        hipLaunchKernelGGL(conv2d_i8_kernel<128>, dim3(gx, (K + 127) / 128), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
+                           y_nchw, p);
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}

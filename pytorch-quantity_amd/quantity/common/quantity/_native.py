@@ -69,6 +69,10 @@ def lib():
     L.fq_recon_epilogue_f32.argtypes = [vp, vp, vp, sz, sz, sz, ci, ci, ci, vp]
     L.fq_quantize_param_i32.restype = ci
     L.fq_quantize_param_i32.argtypes = [vp, vp, sz, ci, vp]
+    L.fq_quantize_i8_nhwc.restype = ci
+    L.fq_quantize_i8_nhwc.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    L.fq_conv2d_i8.restype = ci
+    L.fq_conv2d_i8.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_json_dump_i32.restype = ci
     L.fq_json_dump_i32.argtypes = [ctypes.c_char_p, vp, ci, vp, ci]
     _lib = L
@@ -258,3 +262,55 @@ def json_dump_i32(array, path, indent=4):
     shape = np.array(a.shape, dtype=np.int64)
     _check(lib().fq_json_dump_i32(os.fsencode(path), a.ctypes.data, a.ndim, shape.ctypes.data if a.ndim else None,
                                   int(indent)), "fq_json_dump_i32(%s)" % path)
+
+
+def pad16(c):
+    return (int(c) + 15) // 16 * 16
+
+
+def quantize_i8_nhwc(x, ib, cpad=None):
+    """fp32 [N, C, *spatial] -> int8 [N, *spatial, Cpad] holding clamp(rint(x * 2^ib)); Cpad = C rounded
+    up to 16 (zero filled) unless given."""
+    _need_cuda(x, torch.float32, "fq_quantize_i8_nhwc")
+    xc = x.contiguous()
+    N, C = xc.shape[0], xc.shape[1]
+    spatial = tuple(xc.shape[2:])
+    HW = 1
+    for s in spatial:
+        HW *= s
+    cpad = pad16(C) if cpad is None else int(cpad)
+    y = torch.empty((N,) + spatial + (cpad,), dtype=torch.int8, device=x.device)
+    _check(lib().fq_quantize_i8_nhwc(xc.data_ptr(), y.data_ptr(), N, C, HW, cpad, int(ib), _stream(xc)),
+           "fq_quantize_i8_nhwc")
+    return y
+
+
+def pack_weight_krsc(w, cpad=None):
+    """Integer-valued fp32 weights [K, C, R, S] (or [K, F]) -> int8 [K, R, S, Cpad] for fq_conv2d_i8."""
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    K, C, R, S = w.shape
+    cpad = pad16(C) if cpad is None else int(cpad)
+    out = torch.zeros(K, R, S, cpad, dtype=torch.int8, device=w.device)
+    out[..., :C] = w.permute(0, 2, 3, 1).to(torch.int8)
+    return out.contiguous()
+
+
+def conv2d_i8(xq, wq, qbias, stride, padding, dilation, rs, ob, bitwidth=8):
+    """xq int8 [N,H,W,C] (or [N,C] for Linear), wq int8 [K,R,S,C]; returns fp32 [N,K,P,Q] (or [N,K])."""
+    _need_cuda(xq, torch.int8, "fq_conv2d_i8")
+    _need_cuda(wq, torch.int8, "fq_conv2d_i8")
+    _need_cuda(qbias, torch.float32, "fq_conv2d_i8")
+    linear = xq.dim() == 2
+    if linear:
+        xq = xq[:, None, None, :]
+    N, H, W, C = xq.shape
+    K, R, S, Cw = wq.shape
+    assert C == Cw and xq.is_contiguous() and wq.is_contiguous() and qbias.numel() == K
+    P = (H + 2 * padding[0] - dilation[0] * (R - 1) - 1) // stride[0] + 1
+    Q = (W + 2 * padding[1] - dilation[1] * (S - 1) - 1) // stride[1] + 1
+    y = torch.empty(N, K, P, Q, dtype=torch.float32, device=xq.device)
+    _check(lib().fq_conv2d_i8(xq.data_ptr(), wq.data_ptr(), qbias.contiguous().data_ptr(), y.data_ptr(), N, H, W, C, K, R, S,
+                              stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], int(rs), int(ob),
+                              int(bitwidth), _stream(xq)), "fq_conv2d_i8")
+    return y.view(N, K) if linear else y

@@ -109,7 +109,35 @@ def _quantize_params(layer, weight_bit, bias_bit, out_count, weight_16bit_range=
 
 
 class _IntegerSimLayer(nn.Module):
-    """Shared body of NewConv2d / NewLinear: Quantity -> integer contraction -> fused tail."""
+    """Shared body of NewConv2d / NewLinear: Quantity -> integer contraction -> fused tail.
+
+    Default forward = two HIP kernels: fq_quantize_i8_nhwc (Quantity fused with the NCHW->NHWC int8
+    repack) and fq_conv2d_i8 (int8 MFMA implicit GEMM, int32 accumulation, whole tail fused).
+    `use_int8_mfma = False` keeps the reference's structure instead (Quantity kernel -> fp32 conv on
+    integer-valued tensors -> fused tail kernel); both are exact below 2^24 per partial sum."""
+
+    use_int8_mfma = True
+
+    def _int8_ok(self, layer):
+        if not self.use_int8_mfma or QUANTIZE_BIT != 8:
+            return False
+        if isinstance(layer, nn.Conv2d):
+            return layer.groups == 1 and layer.padding_mode == "zeros" and not isinstance(layer.padding, str)
+        return isinstance(layer, nn.Linear)
+
+    def _packed_weight(self, layer):
+        w = layer.weight
+        cached = getattr(self, "_w_i8", None)
+        if cached is None or cached[0] != (w.data_ptr(), w._version, str(w.device)):
+            packed = _native.pack_weight_krsc(w.detach())
+            object.__setattr__(self, "_w_i8", ((w.data_ptr(), w._version, str(w.device)), packed))
+            cached = self._w_i8
+        return cached[1]
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state.pop("_w_i8", None)                  # derived data: rebuilt on first forward after loading
+        return state
 
     def _setup(self, layer, quantize_infor, out_count, wide_weights):
         self.weight_bit = quantize_infor["weight_bit"]
@@ -149,8 +177,14 @@ class NewConv2d(_IntegerSimLayer):
         self._setup(conv_module, quantize_infor, conv_module.out_channels, False)
 
     def forward(self, input):
+        conv = self.Conv
+        if self._int8_ok(conv):
+            wq = self._packed_weight(conv)
+            xq = _native.quantize_i8_nhwc(input, self.input_bit, wq.shape[-1])
+            return _native.conv2d_i8(xq, wq, self.quantized_bias, conv.stride, conv.padding, conv.dilation,
+                                     self.rs_bit, self.output_bit, 8)
         q = self.Quan(input)
-        acc = self.Conv(q)          # integer-valued fp32 in, exact below 2^24 per partial sum
+        acc = conv(q)               # integer-valued fp32 in, exact below 2^24 per partial sum
         return self._tail(acc)
 
 
@@ -162,8 +196,14 @@ class NewLinear(_IntegerSimLayer):
         self._setup(linear_module, quantize_infor, linear_module.out_features, True)
 
     def forward(self, input):
+        lin = self.Linear
+        if self._int8_ok(lin) and input.dim() == 2:
+            wq = self._packed_weight(lin)
+            xq = _native.quantize_i8_nhwc(input, self.input_bit, wq.shape[-1])
+            return _native.conv2d_i8(xq, wq, self.quantized_bias, (1, 1), (0, 0), (1, 1), self.rs_bit,
+                                     self.output_bit, 8)
         q = self.Quan(input)
-        acc = self.Linear(q)
+        acc = lin(q)
         return self._tail(acc)
 
 
@@ -216,11 +256,11 @@ class _FakeQuantLayer(nn.Module):
         self.weight_qdp = QuanDequan(QUANTIZE_BIT, self.weight_bit)
         self.bias_qdp = QuanDequan(QUANTIZE_BIT, self.bias_bit)
         self.output_qdp = QuanDequan(QUANTIZE_BIT, self.output_bit)
-        self._layer_ref = layer
-        self.feature_extract(out_count)
+        self.feature_extract(layer, out_count)
 
-    def feature_extract(self, out_count=None):
-        layer = self._layer_ref
+    def feature_extract(self, layer=None, out_count=None):
+        if layer is None:
+            layer = self.Conv if hasattr(self, "Conv") else self.linear
         assert layer.weight is not None, "The layer weight can`t be None"
         w = layer.weight.data
         if layer.bias is None:

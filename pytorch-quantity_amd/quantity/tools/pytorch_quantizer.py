@@ -15,6 +15,11 @@ MI355X design (what is different underneath):
     tensor to the host and forks a process pool per batch);
   * graph edges come from tensor identity during one traced forward (value fingerprints, the
     reference's `tid`, are only the fallback), so all-positive inputs to ReLU etc. need no special case;
+  * pass 2 re-uses the activations of pass 1 wherever HBM allows: the bin width needs the global
+    maximum first, so the reference runs every image through the network twice; an MI355X has
+    288 GB, so the cared activations of pass-1 batches are simply kept alive (67 MB per image for
+    ResNet-50) up to a budget (FQ_ACT_CACHE_GB, default 60 % of the free HBM) and histogrammed
+    without a second forward.  Same tensors, same integers; batches beyond the budget are recomputed;
   * data-parallel calibration: when torch.distributed is initialised the calibration batches are
     dealt round-robin to the ranks (one process per GPU) and the per-tensor maxima / histograms
     are combined with one MAX and one SUM all-reduce (RCCL over xGMI); integer sums and maxima are
@@ -57,6 +62,7 @@ class Quantity(object):
     # the statistics engine; tests substitute oracle-backed doubles to exercise the host logic on CPU
     collector_cls = DistributionCollector
     quantizer_cls = Quantizer
+    profile_phases = False      # synchronise at phase boundaries so that .timings are device times
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -226,6 +232,23 @@ class Quantity(object):
                 groups.append(bottoms)
         return groups
 
+    def _activation_cache_budget(self):
+        """Bytes of HBM that pass 1 may keep alive for pass 2 (0 disables the cache)."""
+        if self.device != "gpu" or not torch.cuda.is_available():
+            return 0
+        env = os.environ.get("FQ_ACT_CACHE_GB")
+        if env is not None:
+            return int(float(env) * (1 << 30))
+        free, total = torch.cuda.mem_get_info()
+        # measured on MI355X / ROCm 7.2: the first allocation that takes a process past ~128 GB costs
+        # ~4 s once (and ~3 ms per hipMalloc afterwards), more than the forwards it would save on
+        # a few thousand images -- so by default stay below 110 GB in use.
+        return max(0, min(int(free * 0.6), (110 << 30) - (total - free)))
+
+    def _sync(self):
+        if self.device == "gpu" and torch.cuda.is_available():
+            torch.cuda.synchronize()
+
     def _group_has_eltwise(self, group):
         return any(self.net_info[n]["type"] == "Eltwise" for n in group)
 
@@ -263,13 +286,21 @@ class Quantity(object):
         self._collector, self._quantizer = collector, quantizer
         t0 = time.perf_counter()
 
-        # pass 1: running abs-max of every cared tensor
+        # pass 1: running abs-max of every cared tensor; keep the activations while HBM allows
+        budget = self._activation_cache_budget()
+        cached, cached_ids, used = [], set(), 0
         for i, item in self._calibration_items(images_files):
             self.net_forward(self.model, item)
             collector.refresh_max_val(named_feats)
+            if budget:
+                need = sum(t.numel() * t.element_size() for t in named_feats.values())
+                if used + need <= budget:
+                    cached.append(dict(named_feats))
+                    cached_ids.add(i)
+                    used += need
         if world > 1:
             collector.all_reduce_max()
-        distribution_intervals = collector.distribution_intervals
+        distribution_intervals = collector.distribution_intervals      # (device -> host sync)
         t1 = time.perf_counter()
 
         # tensors that are added / concatenated must share one scale: the group's largest interval
@@ -286,11 +317,18 @@ class Quantity(object):
 
         # pass 2: histograms with the final intervals
         print("Collect histograms of activations:")
+        for feats in cached:
+            collector.add_to_distributions(feats)
         for i, item in self._calibration_items(images_files):
+            if i in cached_ids:
+                continue
             self.net_forward(self.model, item)
             collector.add_to_distributions(named_feats)
+        del cached
         if world > 1:
             collector.all_reduce_hist()
+        if self.profile_phases:
+            self._sync()
         t2 = time.perf_counter()
 
         # a merged group is searched on the sum of its members' histograms
@@ -333,7 +371,8 @@ class Quantity(object):
         for h in hooks:
             h.remove()
         named_feats.clear()
-        self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0}
+        self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0,
+                        "cached_batches": len(cached_ids), "cache_bytes": used}
         return bits
 
     def regist_hook_outfeature(self, model):

@@ -156,7 +156,9 @@ def g5_inputs():
 
 def seed_model(model, base_seed=0, gamma_scale=1.0):
     """Fill every parameter and BatchNorm statistic from a generator keyed by the tensor's
-    state_dict name, so the reference's model file and ours get identical values."""
+    state_dict name, so the reference's model file and ours get identical values.  NumPy's PCG64
+    streams are used (not torch.randn, whose CPU kernels are not guaranteed bit-identical across
+    CPU micro-architectures): the GPU box must regenerate exactly the weights the goldens saw."""
     import zlib
 
     import torch
@@ -166,19 +168,20 @@ def seed_model(model, base_seed=0, gamma_scale=1.0):
             t = sd[key]
             if not t.is_floating_point():
                 continue
-            g = torch.Generator().manual_seed(base_seed * 1000003 + zlib.crc32(key.encode()))
+            g = np.random.default_rng(base_seed * 1000003 + zlib.crc32(key.encode()))
+            shape = tuple(t.shape)
             if key.endswith("running_var"):
-                v = torch.rand(t.shape, generator=g) + 0.5
+                v = g.random(shape, dtype=np.float32) + np.float32(0.5)
             elif key.endswith("running_mean"):
-                v = torch.randn(t.shape, generator=g) * 0.1
+                v = g.standard_normal(shape, dtype=np.float32) * np.float32(0.1)
             elif t.dim() == 1 and key.endswith("weight"):
-                v = (torch.rand(t.shape, generator=g) + 0.5) * gamma_scale
+                v = (g.random(shape, dtype=np.float32) + np.float32(0.5)) * np.float32(gamma_scale)
             elif t.dim() == 1:
-                v = torch.randn(t.shape, generator=g) * 0.1
+                v = g.standard_normal(shape, dtype=np.float32) * np.float32(0.1)
             else:
-                fan_in = t[0].numel()
-                v = torch.randn(t.shape, generator=g) * (2.0 / fan_in) ** 0.5
-            t.copy_(v.to(t.dtype))
+                fan_in = int(np.prod(shape[1:]))
+                v = g.standard_normal(shape, dtype=np.float32) * np.float32((2.0 / fan_in) ** 0.5)
+            t.copy_(torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(t.dtype))
     return model
 
 
@@ -187,6 +190,12 @@ def calib_batches(n_batches, shape, seed=1234):
     import torch
     out = []
     for i in range(n_batches):
-        g = torch.Generator().manual_seed(seed + i)
-        out.append((torch.randn(*shape, generator=g), torch.zeros(shape[0], dtype=torch.long)))
+        g = np.random.default_rng(seed + i)
+        out.append((torch.from_numpy(g.standard_normal(tuple(shape), dtype=np.float32)),
+                    torch.zeros(shape[0], dtype=torch.long)))
     return out
+
+
+def fixed_input(shape, seed=99):
+    import torch
+    return torch.from_numpy(np.random.default_rng(seed).standard_normal(tuple(shape), dtype=np.float32))

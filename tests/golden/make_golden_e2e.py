@@ -103,8 +103,7 @@ def capture_r18(cq, tl):
         out["verbatim"]["new_bias/fc.bias.json@second"] = _read(os.path.join(wd, "new_bias", "fc.bias.json"))
 
         # G4: reconstruction on fresh, identically seeded models, tables as left by the run above
-        g = torch.Generator().manual_seed(99)
-        x = torch.randn(4, 3, 32, 32, generator=g)
+        x = cases.fixed_input((4, 3, 32, 32))
         arrays = {"x": x.numpy()}
         m_float = cases.seed_model(ResNet18()).eval()
         rec = tl.Reconstruction(m_float)

@@ -1,0 +1,76 @@
+"""Data-parallel calibration plumbing on CPU: two gloo ranks (one process each) run the drop-in
+orchestrator with the oracle-backed engine; batches are dealt round-robin, maxima are MAX-reduced
+and histograms SUM-reduced, and the resulting feat.table must be byte-identical to a single-process
+run over the same batches (integer sums and maxima are order independent) -- and to the reference's
+golden table."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import textwrap
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path[:0] = [r"{root}", r"{root}/pytorch-quantity_amd/quantity", r"{root}/tests", r"{root}/tests/golden"]
+    import torch, torch.distributed as dist
+    import cases
+    from engine_doubles import OracleCollector, OracleQuantizer
+    from workdir_util import product_workdir
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_18_fabu import ResNet18
+    from tools import Quantity
+
+    class CpuQuantity(Quantity):
+        collector_cls = OracleCollector
+        quantizer_cls = OracleQuantizer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    rank = dist.get_rank() if world > 1 else 0
+    torch.set_num_threads(2)
+    with product_workdir(device="cpu", max_cali_img_num=3) as tmp:
+        model = merge_bn(cases.seed_model(ResNet18()).eval())
+        q = CpuQuantity(model)
+        bits = q.activation_quantize(cases.calib_batches(5, (2, 3, 32, 32)))
+        if rank == 0:
+            table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
+            hs = {{k: int(v.sum()) for k, v in q._collector.distributions.items()}}
+            json.dump({{"table": table, "hist_sums": hs, "max": {{k: float(v) for k, v in q._collector.max_vals.items()}}}},
+                      open(r"{out}", "w"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+''')
+
+
+def _run(world, out):
+    script = os.path.join(tempfile.mkdtemp(prefix="fq_dist_"), "worker.py")
+    with open(script, "w") as fh:
+        fh.write(WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    if world == 1:
+        cmd = [sys.executable, script]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", "29617", script]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.load(open(out))
+
+
+@pytest.mark.timeout(1800)
+def test_two_rank_gloo_calibration_is_shard_count_invariant(tmp_path):
+    one = _run(1, str(tmp_path / "w1.json"))
+    two = _run(2, str(tmp_path / "w2.json"))
+    assert one["table"] == two["table"]
+    assert one["hist_sums"] == two["hist_sums"]
+    assert one["max"] == two["max"]
+    assert one["table"].startswith("image ")
+    # 4 batches of 2 images were used (MAX_CALI_IMG_NUM = 3 -> batches 0..3): every histogram saw them all
+    assert one["hist_sums"]["image"] == 4 * 2 * 3 * 32 * 32

@@ -1,0 +1,108 @@
+"""int8 MFMA implicit-GEMM convolution / linear with fused tail, and the fp32->int8 NHWC quantiser,
+against the exact integer oracle.   pytest -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from common.quantity import _native
+    _native.lib()
+    return _native
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("N,C,H,W,ib", [(2, 3, 7, 9, 5), (1, 64, 8, 8, 3), (3, 20, 5, 5, 0), (2, 130, 3, 4, 6),
+                                        (4, 16, 1, 1, 4), (5, 48, 1, 1, 2), (1, 3, 224, 224, 5)])
+def test_quantize_i8_nhwc(nat, oracle, N, C, H, W, ib):
+    rng = np.random.default_rng(N * 1000 + C)
+    x = (rng.standard_normal((N, C, H, W), dtype=np.float32) * np.float32(3.0)).astype(np.float32)
+    x.flat[::17] = np.float32(0.5) / np.float32(2.0 ** ib)          # ties
+    y = nat.quantize_i8_nhwc(_dev(x), ib).cpu().numpy()
+    cpad = (C + 15) // 16 * 16
+    assert y.shape == (N, H, W, cpad)
+    ref = oracle.quantity(x, ib).astype(np.int8).transpose(0, 2, 3, 1)
+    np.testing.assert_array_equal(y[..., :C], ref)
+    assert not y[..., C:].any()
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, S, stride, pad, dil
+    (2, 16, 8, 8, 64, 3, 3, 1, 1, 1),
+    (1, 64, 14, 14, 64, 1, 1, 1, 0, 1),
+    (3, 32, 9, 7, 40, 3, 3, 2, 1, 1),          # K not a tile multiple, ragged pixels
+    (2, 3, 33, 31, 64, 7, 7, 2, 3, 1),         # stem-like, C padded 3 -> 16
+    (2, 128, 7, 7, 200, 3, 3, 1, 1, 1),        # K > 128: two k tiles, second partial
+    (1, 256, 6, 6, 512, 1, 1, 2, 0, 1),
+    (2, 48, 10, 10, 96, 3, 3, 1, 2, 2),        # dilation 2
+    (5, 80, 5, 6, 130, 2, 3, 1, 0, 1),         # asymmetric kernel
+    (64, 64, 4, 4, 256, 1, 1, 1, 0, 1),        # many images, pixel tiles crossing images
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_i8_vs_integer_oracle(nat, oracle, case):
+    N, C, H, W, K, R, S, st, pd, dl = case
+    rng = np.random.default_rng(sum(case))
+    xq = rng.integers(-128, 128, size=(N, C, H, W)).astype(np.int32)
+    wq = rng.integers(-128, 128, size=(K, C, R, S)).astype(np.int32)
+    qb = rng.integers(-128, 128, size=K).astype(np.float32)
+    acc = oracle.conv2d_int(xq, wq, (st, st), (pd, pd), (dl, dl))
+    cpad = (C + 15) // 16 * 16
+    x_nhwc = np.zeros((N, H, W, cpad), dtype=np.int8)
+    x_nhwc[..., :C] = xq.transpose(0, 2, 3, 1)
+    w_dev = nat.pack_weight_krsc(_dev(wq.astype(np.float32)))
+    assert w_dev.shape == (K, R, S, cpad)
+    for rs, ob in ((8, 3), (12, 5), (0, 0), (15, -1)):
+        got = nat.conv2d_i8(_dev(x_nhwc), w_dev, _dev(qb), (st, st), (pd, pd), (dl, dl), rs, ob).cpu().numpy()
+        ref = oracle.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+        np.testing.assert_array_equal(got, ref, err_msg="rs=%d ob=%d" % (rs, ob))
+
+
+def test_linear_i8_vs_oracle(nat, oracle):
+    rng = np.random.default_rng(9)
+    for N, F, K in ((4, 512, 10), (64, 2048, 1000), (3, 400, 120), (1, 84, 10)):
+        xq = rng.integers(-128, 128, size=(N, F)).astype(np.int32)
+        wq = rng.integers(-128, 128, size=(K, F)).astype(np.int32)
+        qb = rng.integers(-128, 128, size=K).astype(np.float32)
+        acc = (xq.astype(np.int64) @ wq.astype(np.int64).T)
+        fpad = (F + 15) // 16 * 16
+        xp = np.zeros((N, fpad), dtype=np.int8)
+        xp[:, :F] = xq
+        w_dev = nat.pack_weight_krsc(_dev(wq.astype(np.float32)))
+        got = nat.conv2d_i8(_dev(xp), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), 9, 2).cpu().numpy()
+        ref = oracle.recon_epilogue(acc.astype(np.float32), qb, 9, 2)
+        np.testing.assert_array_equal(got, ref)
+
+
+def test_newconv2d_int8_path_equals_float_path(nat):
+    """Module level: the MFMA path and the fp32-conv path of NewConv2d agree exactly (|acc| < 2^24)."""
+    import torch.nn as nn
+    from common.quantity import new_quantity_op as nq
+    torch.manual_seed(3)
+    for cin, cout, k, st, pd in ((3, 64, 7, 2, 3), (64, 64, 3, 1, 1), (64, 256, 1, 1, 0), (128, 128, 3, 2, 1)):
+        conv = nn.Conv2d(cin, cout, k, stride=st, padding=pd, bias=True)
+        info = dict(weight_bit=8, bias_bit=4, input_bit=4, output_bit=4)
+        m = nq.NewConv2d(conv, info).cuda()
+        x = torch.randn(6, cin, 20, 20, device="cuda") * 2
+        with torch.no_grad():
+            m.use_int8_mfma = True
+            a = m(x)
+            m.use_int8_mfma = False
+            b = m(x)
+        assert torch.equal(a, b)
+    lin = nn.Linear(512, 10)
+    ml = nq.NewLinear(lin, dict(weight_bit=8, bias_bit=3, input_bit=3, output_bit=3)).cuda()
+    x = torch.randn(32, 512, device="cuda")
+    with torch.no_grad():
+        ml.use_int8_mfma = True
+        a = ml(x)
+        ml.use_int8_mfma = False
+        b = ml(x)
+    assert torch.equal(a, b)

@@ -1,0 +1,179 @@
+"""End-to-end parity on the GPU: the drop-in orchestrator with the real HIP engine against the
+goldens captured from the imported reference (G3 tables, G4 reconstruction logits), plus
+engine-vs-oracle equality on the activations the GPU itself produced.   pytest -m gpu"""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from workdir_util import product_workdir
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g3(golden_dir):
+    with open(os.path.join(golden_dir, "g3_r18_e2e.json")) as fh:
+        return json.load(fh)
+
+
+def _r18_gpu():
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_18_fabu import ResNet18
+    return merge_bn(cases.seed_model(ResNet18()).eval()).cuda()
+
+
+@pytest.fixture(scope="module")
+def calib(oracle):
+    """One calibration run of ResNet-18 on the GPU; keeps the collector for inspection."""
+    from tools import Quantity
+    out = {}
+    with product_workdir(device="gpu", max_cali_img_num=1) as tmp:
+        q = Quantity(_r18_gpu())
+        batches = cases.calib_batches(3, (4, 3, 32, 32))
+        out["bits"] = dict(q.activation_quantize(batches))
+        wd = os.path.join(tmp, "test", "workdir")
+        out["feat_table"] = open(os.path.join(wd, "feat.table")).read()
+        out["max"] = {k: float(v) for k, v in q._collector.max_vals.items()}
+        out["hist"] = q._collector.hist_device.cpu().numpy()
+        out["names"] = ["image"] + list(q.net_info.keys())
+        out["intervals"] = {k: np.float32(v) for k, v in q._collector._distribution_intervals.items()}
+        out["thr"] = dict(q._quantizer.threshold_bins)
+        # kernel-level exactness on real data: capture ONE set of activations per batch (MIOpen
+        # convolutions are not bitwise reproducible from call to call) and hand the very same
+        # tensors to a fresh HIP collector and to the oracle
+        from common.quantity import DistributionCollector
+        feats, hooks = q.regist_hook_outfeature(q.model)
+        captured = []
+        for b in batches[:2]:
+            q.net_forward(q.model, b)
+            captured.append({n: feats[n].clone() for n in out["names"]})
+        for h in hooks:
+            h.remove()
+        coll = DistributionCollector(out["names"])
+        ref_max = {n: np.float32(0) for n in out["names"]}
+        for c in captured:
+            coll.refresh_max_val(c)
+            for n in out["names"]:
+                ref_max[n] = oracle.absmax(c[n].cpu().numpy(), ref_max[n])
+        iv = coll.distribution_intervals
+        ref_hist = {n: np.zeros(2048, dtype=np.int64) for n in out["names"]}
+        for c in captured:
+            coll.add_to_distributions(c)
+            for n in out["names"]:
+                oracle.hist2048(c[n].cpu().numpy(), np.float32(iv[n]), ref_hist[n])
+        out["same_max"] = {k: float(v) for k, v in coll.max_vals.items()}
+        out["same_hist"] = coll.hist_device.cpu().numpy()
+        out["same_thr"] = None
+        out["ref_max"], out["ref_hist"] = ref_max, ref_hist
+        # KL on those histograms: HIP vs oracle
+        from common.quantity import _native
+        thr = _native.kl_threshold(coll.hist_device).cpu().numpy()
+        out["same_thr"] = [int(t) for t in thr]
+        out["ref_thr"] = [oracle.kl_threshold(oracle.normalize(ref_hist[n])) for n in out["names"]]
+        q.weight_quantize()
+        out["weight_table"] = open(os.path.join(wd, "weight.table")).read()
+        out["json"] = {k: open(os.path.join(wd, k)).read() for k in
+                       ("bias/fc.bias.json", "new_bias/fc.bias.json", "new_bias/conv1.0.bias.json",
+                        "weight/conv1.0.weight.json")}
+        import hashlib
+        out["files"] = {d: {f: hashlib.sha256(open(os.path.join(wd, d, f), "rb").read()).hexdigest()
+                            for f in sorted(os.listdir(os.path.join(wd, d)))}
+                        for d in ("weight", "bias", "new_weight", "new_bias")}
+    return out
+
+
+def test_engine_equals_oracle_on_gpu_activations(calib):
+    """Kernel-level exactness on real data: HIP abs-max / histogram of the GPU's own activations
+    equal the oracle's on the very same tensors, for all 30 rows."""
+    for i, n in enumerate(calib["names"]):
+        assert calib["same_max"][n] == float(calib["ref_max"][n]), n
+        np.testing.assert_array_equal(calib["same_hist"][i], calib["ref_hist"][n], err_msg=n)
+    assert calib["same_thr"] == calib["ref_thr"]
+
+
+def test_feat_table_matches_reference(calib, g3):
+    """MIOpen and oneDNN convolutions differ in the last bits, so activations are not bit-identical
+    to the reference's CPU run; the fractional bits are a coarse function of them and must agree."""
+    assert calib["feat_table"] == g3["feat_table"]
+    assert {k: int(v) for k, v in calib["bits"].items()} == g3["bits_final"]
+
+
+def test_weight_outputs_match_reference(calib, g3):
+    """Weights never pass through a convolution: weight.table and every JSON file are byte-identical."""
+    assert calib["weight_table"] == g3["weight_table_after_quantize"]
+    for d in ("weight", "bias", "new_weight", "new_bias"):
+        diff = [f for f in g3["files_after_quantize"][d] if calib["files"][d].get(f) != g3["files_after_quantize"][d][f]]
+        assert not diff, (d, diff)
+    assert calib["files"] == g3["files_after_quantize"]
+    for k, text in calib["json"].items():
+        assert text == g3["verbatim"][k], k
+
+
+def test_reconmodel_logits_match_reference(golden_dir, g3):
+    """Integer simulation: every accumulator is an exact integer below 2^24 (golden:
+    recon_max_abs_accumulator), so the GPU result must equal the reference's CPU result exactly."""
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_18_fabu import ResNet18
+    from tools import Reconstruction
+    g4 = np.load(os.path.join(golden_dir, "g4_r18_recon.npz"))
+    assert g3["recon_max_abs_accumulator"] < 2 ** 24
+    with product_workdir(device="gpu") as tmp:
+        wd = os.path.join(tmp, "test", "workdir")
+        os.makedirs(wd, exist_ok=True)
+        with open(os.path.join(wd, "feat.table"), "w") as fh:
+            fh.write(g3["feat_table"])
+        with open(os.path.join(wd, "weight.table"), "w") as fh:
+            fh.write(g3["weight_table_after_second_rewrite"])
+        model = cases.seed_model(ResNet18()).eval()
+        rec = Reconstruction(model)
+        rec.merge_bn()
+        info = rec.get_quantity_information()
+        ref_info = g3["quantity_information"]
+        assert {k: {kk: vv for kk, vv in v.items() if kk != "layer"} for k, v in info.items()} == ref_info
+        net = rec.ReconModel(info, os.path.join(wd, "recon.pth")).cuda()
+        assert sorted(net.state_dict().keys()) == g3["recon_state_dict_keys"]
+        x = torch.from_numpy(g4["x"]).cuda()
+        with torch.no_grad():
+            first = net.conv1[0](x).cpu().numpy()
+            logits = net(x).cpu().numpy()
+        np.testing.assert_array_equal(net.conv1[0].Conv.weight.detach().cpu().numpy(), g4["recon_conv1_qweight"])
+        np.testing.assert_array_equal(net.conv1[0].quantized_bias.cpu().numpy(), g4["recon_conv1_qbias"])
+        np.testing.assert_array_equal(first, g4["recon_conv1_out"])
+        np.testing.assert_array_equal(logits, g4["logits_recon"])
+        # the pickled model loads back against the drop-in module path
+        again = torch.load(os.path.join(wd, "recon.pth"), weights_only=False).cuda()
+        with torch.no_grad():
+            np.testing.assert_array_equal(again(x).cpu().numpy(), logits)
+
+
+def test_recontest_logits_match_reference(golden_dir, g3):
+    """Fake-quant model: float convolutions (MIOpen vs oneDNN rounding) followed by quantise ->
+    dequantise.  Tolerance: fp32 conv noise may move a value across a rounding tie, so an output may
+    differ by one quantisation step (2^-output_bit) on a small fraction of elements; logits within
+    2 steps of the last layer (output_bit 0 -> 2.0) and >= 99% of first-layer outputs identical."""
+    from model.resnet.ResNet_18_fabu import ResNet18
+    from tools import Reconstruction
+    g4 = np.load(os.path.join(golden_dir, "g4_r18_recon.npz"))
+    with product_workdir(device="gpu") as tmp:
+        wd = os.path.join(tmp, "test", "workdir")
+        os.makedirs(wd, exist_ok=True)
+        with open(os.path.join(wd, "feat.table"), "w") as fh:
+            fh.write(g3["feat_table"])
+        with open(os.path.join(wd, "weight.table"), "w") as fh:
+            fh.write(g3["weight_table_after_second_rewrite"])
+        rec = Reconstruction(cases.seed_model(ResNet18()).eval())
+        rec.merge_bn()
+        net = rec.ReconTest(rec.get_quantity_information(), os.path.join(wd, "recontest.pth")).cuda()
+        assert sorted(net.state_dict().keys()) == g3["recontest_state_dict_keys"]
+        x = torch.from_numpy(g4["x"]).cuda()
+        with torch.no_grad():
+            first = net.conv1[0](x).cpu().numpy()
+            logits = net(x).cpu().numpy()
+        same = np.mean(first == g4["recontest_conv1_out"])
+        assert same >= 0.99, same
+        assert np.max(np.abs(first - g4["recontest_conv1_out"])) <= 2.0 ** -3 + 1e-6     # conv1.0 output_bit = 3
+        assert np.max(np.abs(logits - g4["logits_recontest"])) <= 2.0
