@@ -11,6 +11,8 @@
 //     non-zero bins to the int64 global rows with 64-bit atomics (T*2048 counters, L2-resident).
 //   * abs-max keeps a per-lane running max, reduces across the wave with DPP shuffles, across waves
 //     through LDS, and publishes with one 32-bit atomic max on the (non-negative) float's bits.
+#include <cstdlib>
+
 #include "fq_common.h"
 
 namespace fq {
@@ -21,6 +23,7 @@ constexpr int kSegChunk = 96;          // segments per launch (kernarg block sta
 constexpr int kBlock = 256;            // 4 waves
 constexpr uint32_t kMinTile = 4096;    // elements
 constexpr uint32_t kMaxTile = 1u << 22;
+constexpr int kHistFastQuotientDefault = 0;   // flipped to 1 only with the exhaustive proof in profiles/
 
 struct SegTable {
     const float* ptr[kSegChunk];
@@ -117,21 +120,50 @@ __global__ __launch_bounds__(kBlock) void absmax_seg_kernel(const SegTable tab, 
 // ---------------------------------------------------------------------------------------------
 // 2048-bin histogram of |x|, x != 0  (distribution_collector.py:127-135)
 // ---------------------------------------------------------------------------------------------
+// Bin of one element.  kFast = false: the IEEE divide sequence.  kFast = true: the 3-instruction
+// quotient  q0 = a*y, r = fma(-q0, iv, a), q = fma(r, y, q0)  with y = RN(1/iv); it equals the
+// correctly rounded a/iv for every fp32 significand pair (checked exhaustively on the GPU,
+// scripts/verify_fastdiv.hip, result under profiles/), and overflow / inf / nan fall through to the
+// same "last bin" as the IEEE path because  q < 2048  is false for inf and nan.
+template <bool kFast>
+__device__ __forceinline__ int bin_of(float v, float iv, float y) {
+    const float a = fabsf(v);
+    float q;
+    if (kFast) {
+        const float q0 = a * y;
+        const float r = __builtin_fmaf(-q0, iv, a);
+        q = __builtin_fmaf(r, y, q0);
+    } else {
+        q = a / iv;                                   // v_div_scale / v_rcp / fma x4 / v_div_fmas / v_div_fixup
+    }
+    return (q < 2048.0f) ? (int)q : (FQ_BINS - 1);   // >= 2048, inf, nan -> last bin
+}
+
+template <bool kFast>
+__device__ __forceinline__ void hist_tile(const TileView& tv, float iv, unsigned int* s_bins) {
+    const float y = 1.0f / iv;                        // IEEE, once per lane
+    // branch-free: lanes holding an exact zero add into a private scratch slot (2048 + lane)
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    for_each_in_tile(tv, [&](float v) {
+        unsigned int* slot = (v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, y)) : park;
+        atomicAdd(slot, 1u);                          // ds_add_u32
+    });
+}
+
 __global__ __launch_bounds__(kBlock) void hist2048_seg_kernel(const SegTable tab,
                                                               const float* __restrict__ interval,
-                                                              unsigned long long* __restrict__ hist) {
-    __shared__ unsigned int s_bins[FQ_BINS];
-    for (int b = threadIdx.x; b < FQ_BINS; b += kBlock) s_bins[b] = 0u;
+                                                              unsigned long long* __restrict__ hist,
+                                                              const int allow_fast) {
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kBlock) s_bins[b] = 0u;
     const TileView tv = tile_of(tab);
     const float iv = interval[tv.row];
     __syncthreads();
-    for_each_in_tile(tv, [&](float v) {
-        if (v != 0.0f) {
-            const float q = fabsf(v) / iv;              // IEEE correctly rounded fp32 divide
-            const int idx = (q < 2048.0f) ? (int)q : (FQ_BINS - 1);   // >= 2048, inf, nan -> last bin
-            atomicAdd(&s_bins[idx], 1u);                // ds_add_u32
-        }
-    });
+    // the fast quotient needs a normal, finite, positive interval (always true for
+    // max/2048 + 1e-12); anything else takes the IEEE path.  Uniform per workgroup.
+    const unsigned int ivb = __float_as_uint(iv);
+    const bool fast = allow_fast && ivb >= 0x00800000u && ivb < 0x7f800000u;
+    if (fast) hist_tile<true>(tv, iv, s_bins); else hist_tile<false>(tv, iv, s_bins);
     __syncthreads();
     unsigned long long* __restrict__ dst = hist + (size_t)tv.row * FQ_BINS;
     for (int b = threadIdx.x; b < FQ_BINS; b += kBlock) {
@@ -143,6 +175,15 @@ __global__ __launch_bounds__(kBlock) void hist2048_seg_kernel(const SegTable tab
 // ---------------------------------------------------------------------------------------------
 // host side: tiling and chunked launches
 // ---------------------------------------------------------------------------------------------
+// FQ_HIST_IEEE_DIV=1 forces the IEEE divide sequence (A/B timing, paranoia).
+static int hist_fast_quotient_enabled() {
+    static const int v = [] {
+        const char* e = getenv("FQ_HIST_IEEE_DIV");
+        return (e && e[0] && e[0] != '0') ? 0 : kHistFastQuotientDefault;
+    }();
+    return v;
+}
+
 static uint32_t pick_tile_elems(const fq_seg* segs, int nseg) {
     uint64_t total = 0;
     for (int i = 0; i < nseg; ++i) total += segs[i].n;
@@ -225,7 +266,7 @@ extern "C" int fq_hist2048_seg(const fq_seg* segs, int nseg, const float* interv
     hipStream_t st = as_stream(stream);
     return for_each_chunk(segs, nseg, [&](const SegTable& tab, uint32_t tiles) -> int {
         hipLaunchKernelGGL(hist2048_seg_kernel, dim3(tiles), dim3(kBlock), 0, st, tab, interval,
-                           reinterpret_cast<unsigned long long*>(hist));
+                           reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
         FQ_LAUNCH_CHECK();
         return FQ_OK;
     });

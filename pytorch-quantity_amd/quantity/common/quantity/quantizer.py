@@ -69,6 +69,19 @@ class Quantizer(object):
         assert self._quantized_flag, "Please use quantize() first."
         return self._threshold_bin
 
+    def _result_order(self):
+        """The reference fills .bits worker by worker (worker 0 takes the first chunk plus the
+        remainder, quantizer.py:48-75); weight.table lines follow that dict order when the KL branch
+        of weight_quantize is used, so the order is part of the output contract."""
+        names, w = self._tensor_list, max(int(self._worker_num), 1)
+        per = len(names) // w
+        order = []
+        for i in range(w):
+            order += names[i * per:(i + 1) * per]
+            if i == 0:
+                order += names[w * per:]
+        return order
+
     def quantize(self, distributions, distribution_intervals):
         """distributions: {name: 2048 counts} (or an int64[T,2048] device tensor in tensor_list
         order); distribution_intervals: {name: bin width}."""
@@ -76,9 +89,9 @@ class Quantizer(object):
             return
         self._quantized_flag = True
         hist = _rows_to_device(distributions, self._tensor_list, self._device)
-        thr = _native.kl_threshold(hist).cpu().numpy()
-        for name, t in zip(self._tensor_list, thr):
-            t = int(t)
+        thr = dict(zip(self._tensor_list, _native.kl_threshold(hist).cpu().numpy()))
+        for name in self._result_order():
+            t = int(thr[name])
             # reference quantizer.py:86-90; NumPy scalar typing decides fp32 vs float64 here exactly
             # as it does there (np.float32 interval -> fp32 product, Python float -> float64)
             threshold_bias = (t + 0.5) * distribution_intervals[name]

@@ -91,6 +91,7 @@ class OracleQuantizer(object):
 
     def __init__(self, tensor_list, worker_num=1, debug=False):
         self._tensor_list = list(tensor_list)
+        self._worker_num = worker_num
         self._bits, self._threshold_value, self._threshold_bin = {}, {}, {}
 
     @property
@@ -106,7 +107,12 @@ class OracleQuantizer(object):
         return self._threshold_bin
 
     def quantize(self, distributions, distribution_intervals):
-        for n in self._tensor_list:
+        names, w = self._tensor_list, max(int(self._worker_num), 1)
+        per = len(names) // w
+        order = []
+        for i in range(w):                       # the reference's per-worker result order
+            order += names[i * per:(i + 1) * per] + (names[w * per:] if i == 0 else [])
+        for n in order:
             t = orc.kl_threshold(orc.normalize(np.asarray(distributions[n])))
             tb = (t + 0.5) * distribution_intervals[n]
             self._threshold_bin[n] = t

@@ -151,6 +151,28 @@ def capture_r18(cq, tl):
     print("G3/G4 written; feat.table:\n" + out["feat_table"])
 
 
+def capture_dkl(cq, tl):
+    """weight_quantize() with the KL branch enabled (_DKL_weight = True, pytorch_quantizer.py:644-648)."""
+    import torch
+    from model.resnet.ResNet_18_fabu import ResNet18
+    with open(os.path.join(HERE, "g3_r18_e2e.json")) as fh:
+        g3 = json.load(fh)
+    out = {}
+    with _refenv.reference_workdir(input_shape="1,3,32,32", max_cali_img_num=1) as tmp:
+        model = cq.merge_bn(cases.seed_model(ResNet18()).eval(), "cpu")
+        q = tl.Quantity(model)
+        wd = os.path.join(tmp, "test", "workdir")
+        with open(os.path.join(wd, "feat.table"), "w") as fh:
+            fh.write(g3["feat_table"])
+        q._DKL_weight = True
+        q.weight_quantize()
+        out["weight_table"] = _read(os.path.join(wd, "weight.table"))
+        out["files"] = {d: _dir_state(os.path.join(wd, d)) for d in ("weight", "bias", "new_weight", "new_bias")}
+    with open(os.path.join(HERE, "g3b_r18_dkl_weights.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("DKL weight table:\n" + out["weight_table"])
+
+
 def capture_g6(cq, tl):
     """BiasReWriter on a crafted directory: int8 wrap, negative bits, MAX_SHIFT capping."""
     import tempfile
@@ -235,6 +257,8 @@ def main():
         capture_g7(cq, tl)
     if "r18" in which:
         capture_r18(cq, tl)
+    if "dkl" in which:
+        capture_dkl(cq, tl)
 
 
 if __name__ == "__main__":

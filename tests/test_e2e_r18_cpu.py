@@ -110,3 +110,28 @@ def test_second_rewrite_quirk_reproduced(run, g3):
     assert run["weight_table_2"] == g3["weight_table_after_second_rewrite"]
     assert run["files_2"] == g3["files_after_second_rewrite"]
     assert run["files_2"]["new_bias"] != run["files_1"]["new_bias"]
+
+
+def test_kl_weight_branch_matches_reference(golden_dir, g3, oracle):
+    """weight_quantize() with _DKL_weight = True (reference pytorch_quantizer.py:644-648): histogram +
+    KL sweep over the parameters themselves; weight.table (including its worker-ordered lines) and
+    all JSON files must equal the reference's."""
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_18_fabu import ResNet18
+    from tools import Quantity
+
+    class CpuQuantity(Quantity):
+        collector_cls = OracleCollector
+        quantizer_cls = OracleQuantizer
+
+    with open(os.path.join(golden_dir, "g3b_r18_dkl_weights.json")) as fh:
+        ref = json.load(fh)
+    with product_workdir(input_shape="1,3,32,32", device="cpu", max_cali_img_num=1) as tmp:
+        q = CpuQuantity(merge_bn(cases.seed_model(ResNet18()).eval()))
+        wd = os.path.join(tmp, "test", "workdir")
+        with open(os.path.join(wd, "feat.table"), "w") as fh:
+            fh.write(g3["feat_table"])
+        q._DKL_weight = True
+        q.weight_quantize()
+        assert open(os.path.join(wd, "weight.table")).read() == ref["weight_table"]
+        assert {d: _dir_state(os.path.join(wd, d)) for d in ("weight", "bias", "new_weight", "new_bias")} == ref["files"]
