@@ -6,9 +6,12 @@
 // that travels in the kernel-argument block, so there is no per-tensor launch and no table memcpy.
 //
 // Both kernels are HBM-bound streaming reads (4 B per element, algorithmic bytes = 4 * elements):
-//   * 16-byte loads, 4 in flight per lane; tiles sized so that one launch has ~8 workgroups per CU.
-//   * histogram bins live in LDS (8 KB per workgroup, ds_add_u32); a workgroup flushes only its
-//     non-zero bins to the int64 global rows with 64-bit atomics (T*2048 counters, L2-resident).
+//   * 16-byte loads, 4 in flight per lane; tiles sized per kernel (abs-max: 256 threads, ~4
+//     workgroups per CU; histogram: 256 threads, ~8 per CU -- both measured optima).
+//   * histogram bins live in LDS (8 KB per workgroup shared by its 4 waves, ds_add_u32); a
+//     workgroup flushes only its non-zero bins to the int64 global rows with 64-bit atomics
+//     (T*2048 counters, L2-resident).  Bin = trunc(|x| / interval) through a 3-instruction quotient
+//     proven identical to the IEEE divide (profiles/r01_verify_fastdiv.log).
 //   * abs-max keeps a per-lane running max, reduces across the wave with DPP shuffles, across waves
 //     through LDS, and publishes with one 32-bit atomic max on the (non-negative) float's bits.
 #include <cstdlib>
@@ -20,10 +23,14 @@ namespace fq {
 thread_local int g_last_hip_error = 0;
 
 constexpr int kSegChunk = 96;          // segments per launch (kernarg block stays < 4 KB)
-constexpr int kBlock = 256;            // 4 waves
+constexpr int kBlock = 256;            // abs-max: 4 waves per workgroup, ~4 workgroups per CU
+constexpr int kHistBlock = 256;        // histogram: 4 waves per LDS histogram, ~8 workgroups per CU (measured optimum;
+                                       // 1024-thread workgroups at 2 per CU were 10 % slower)
 constexpr uint32_t kMinTile = 4096;    // elements
 constexpr uint32_t kMaxTile = 1u << 22;
-constexpr int kHistFastQuotientDefault = 0;   // flipped to 1 only with the exhaustive proof in profiles/
+constexpr int kTilesPerCUAbsmax = 4;
+constexpr int kTilesPerCUHist = 8;
+constexpr int kHistFastQuotientDefault = 1;   // exhaustive proof: profiles/r01_verify_fastdiv.log
 
 struct SegTable {
     const float* ptr[kSegChunk];
@@ -64,7 +71,7 @@ __device__ __forceinline__ TileView tile_of(const SegTable& t) {
 
 // Visit every element of the tile: scalar head until 16-B aligned, float4 body with 4 loads in
 // flight per lane, scalar tail.
-template <typename F>
+template <int kThreads, typename F>
 __device__ __forceinline__ void for_each_in_tile(const TileView& tv, F&& f) {
     const int tid = threadIdx.x;
     const float* p = tv.p;
@@ -78,17 +85,17 @@ __device__ __forceinline__ void for_each_in_tile(const TileView& tv, F&& f) {
     const float4* __restrict__ v4 = reinterpret_cast<const float4*>(p);
     const uint64_t nvec = cnt >> 2;
     uint64_t i = tid;
-    for (; i + 3 * kBlock < nvec; i += 4 * kBlock) {
+    for (; i + 3 * kThreads < nvec; i += 4 * kThreads) {
         const float4 a = v4[i];
-        const float4 b = v4[i + kBlock];
-        const float4 c = v4[i + 2 * kBlock];
-        const float4 d = v4[i + 3 * kBlock];
+        const float4 b = v4[i + kThreads];
+        const float4 c = v4[i + 2 * kThreads];
+        const float4 d = v4[i + 3 * kThreads];
         f(a.x); f(a.y); f(a.z); f(a.w);
         f(b.x); f(b.y); f(b.z); f(b.w);
         f(c.x); f(c.y); f(c.z); f(c.w);
         f(d.x); f(d.y); f(d.z); f(d.w);
     }
-    for (; i < nvec; i += kBlock) {
+    for (; i < nvec; i += kThreads) {
         const float4 a = v4[i];
         f(a.x); f(a.y); f(a.z); f(a.w);
     }
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(kBlock) void absmax_seg_kernel(const SegTable tab, 
     __shared__ float s_wave[kBlock / kWave];
     const TileView tv = tile_of(tab);
     float m = 0.0f;
-    for_each_in_tile(tv, [&](float v) { m = fmaxf(m, fabsf(v)); });   // fmaxf drops NaN
+    for_each_in_tile<kBlock>(tv, [&](float v) { m = fmaxf(m, fabsf(v)); });   // fmaxf drops NaN
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -144,18 +151,18 @@ __device__ __forceinline__ void hist_tile(const TileView& tv, float iv, unsigned
     const float y = 1.0f / iv;                        // IEEE, once per lane
     // branch-free: lanes holding an exact zero add into a private scratch slot (2048 + lane)
     unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
-    for_each_in_tile(tv, [&](float v) {
+    for_each_in_tile<kHistBlock>(tv, [&](float v) {
         unsigned int* slot = (v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, y)) : park;
         atomicAdd(slot, 1u);                          // ds_add_u32
     });
 }
 
-__global__ __launch_bounds__(kBlock) void hist2048_seg_kernel(const SegTable tab,
+__global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable tab,
                                                               const float* __restrict__ interval,
                                                               unsigned long long* __restrict__ hist,
                                                               const int allow_fast) {
     __shared__ unsigned int s_bins[FQ_BINS + kWave];
-    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kBlock) s_bins[b] = 0u;
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kHistBlock) s_bins[b] = 0u;
     const TileView tv = tile_of(tab);
     const float iv = interval[tv.row];
     __syncthreads();
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(kBlock) void hist2048_seg_kernel(const SegTable tab
     if (fast) hist_tile<true>(tv, iv, s_bins); else hist_tile<false>(tv, iv, s_bins);
     __syncthreads();
     unsigned long long* __restrict__ dst = hist + (size_t)tv.row * FQ_BINS;
-    for (int b = threadIdx.x; b < FQ_BINS; b += kBlock) {
+    for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) {
         const unsigned int c = s_bins[b];
         if (c) atomicAdd(dst + b, (unsigned long long)c);
     }
@@ -184,11 +191,16 @@ static int hist_fast_quotient_enabled() {
     return v;
 }
 
-static uint32_t pick_tile_elems(const fq_seg* segs, int nseg) {
+static uint32_t pick_tile_elems(const fq_seg* segs, int nseg, int default_per_cu) {
     uint64_t total = 0;
     for (int i = 0; i < nseg; ++i) total += segs[i].n;
-    // aim for ~8 workgroups per CU over the whole call
-    uint64_t want = total / (uint64_t)(kCUs * 8);
+    // aim for ~kTilesPerCU workgroups per CU over the whole call (FQ_TILES_PER_CU overrides: tuning knob)
+    static const int env_per_cu = [] {
+        const char* e = getenv("FQ_TILES_PER_CU");
+        return e ? atoi(e) : 0;
+    }();
+    const int per_cu = env_per_cu > 0 ? env_per_cu : default_per_cu;
+    uint64_t want = total / (uint64_t)(kCUs * per_cu);
     uint32_t tile = kMinTile;
     while (tile < want && tile < kMaxTile) tile <<= 1;
     return tile;
@@ -206,8 +218,8 @@ static int validate(const fq_seg* segs, int nseg) {
 }
 
 template <typename Launch>
-static int for_each_chunk(const fq_seg* segs, int nseg, Launch&& launch) {
-    const uint32_t tile = pick_tile_elems(segs, nseg);
+static int for_each_chunk(const fq_seg* segs, int nseg, int per_cu, Launch&& launch) {
+    const uint32_t tile = pick_tile_elems(segs, nseg, per_cu);
     int i = 0;
     while (i < nseg) {
         SegTable tab;
@@ -249,7 +261,7 @@ extern "C" int fq_absmax_seg(const fq_seg* segs, int nseg, float* max_inout, fq_
     if (nseg == 0) return FQ_OK;
     if (max_inout == nullptr) return FQ_ERR_INVALID_ARG;
     hipStream_t st = as_stream(stream);
-    return for_each_chunk(segs, nseg, [&](const SegTable& tab, uint32_t tiles) -> int {
+    return for_each_chunk(segs, nseg, kTilesPerCUAbsmax, [&](const SegTable& tab, uint32_t tiles) -> int {
         hipLaunchKernelGGL(absmax_seg_kernel, dim3(tiles), dim3(kBlock), 0, st, tab, max_inout);
         FQ_LAUNCH_CHECK();
         return FQ_OK;
@@ -264,8 +276,8 @@ extern "C" int fq_hist2048_seg(const fq_seg* segs, int nseg, const float* interv
     if (nseg == 0) return FQ_OK;
     if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
     hipStream_t st = as_stream(stream);
-    return for_each_chunk(segs, nseg, [&](const SegTable& tab, uint32_t tiles) -> int {
-        hipLaunchKernelGGL(hist2048_seg_kernel, dim3(tiles), dim3(kBlock), 0, st, tab, interval,
+    return for_each_chunk(segs, nseg, kTilesPerCUHist, [&](const SegTable& tab, uint32_t tiles) -> int {
+        hipLaunchKernelGGL(hist2048_seg_kernel, dim3(tiles), dim3(kHistBlock), 0, st, tab, interval,
                            reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
         FQ_LAUNCH_CHECK();
         return FQ_OK;

@@ -14,11 +14,11 @@
 //                             the path that is a dense contraction, hence the one MFMA kernel.
 //
 // Tiling (64-wide wavefronts): workgroup = 256 threads = 2x2 waves, tile = TK output channels x 128
-// pixels, K-step = 64 bytes of the (r, s, c) reduction axis = 2 MFMA k-sub-steps.  Pixels sit on
+// pixels, K-step = 128 bytes of the (r, s, c) reduction axis = 4 MFMA k-sub-steps.  Pixels sit on
 // the MFMA lane index, so each accumulator register is 32 consecutive pixels of one output channel:
 // 128-byte coalesced NCHW stores with no shuffle.  Operand tiles are staged global -> registers ->
-// LDS (double buffered, 16-byte accesses); the 64-byte LDS rows are XOR-swizzled
-// (chunk ^= (row >> 2) & 3) so that ds_read_b128 fragment reads are bank-conflict free.
+// LDS (double buffered, 16-byte accesses); the 128-byte LDS rows are XOR-swizzled
+// (chunk ^= (row >> 1) & 7) so that ds_read_b128 fragment reads are bank-conflict free.
 #include "fq_common.h"
 
 namespace fq {
@@ -41,7 +41,9 @@ struct ConvParams {
     int ilo, ihi;
 };
 
-__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+// 128-byte LDS rows hold 8 16-byte chunks; chunk ^= (row >> 1) & 7 makes every ds_read_b128 lane
+// group ({0-3,12-15,20-27}, ...) touch 16 distinct 16-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 // RightShift -> BiasAdd -> Sp -> DeQuantity on one accumulator (new_quantity_op.py:127-132)
 __device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& p) {
@@ -58,12 +60,13 @@ template <int TK>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                const float* __restrict__ qbias, float* __restrict__ y,
                                                                const ConvParams p) {
+    constexpr int BKB = 128;              // bytes of the reduction axis per K-step (8 chunks, 4 MFMA sub-steps)
     constexpr int MT = TK / 64;           // 32-row MFMA tiles per wave along k_out
     constexpr int NT = 2;                 // 32-col MFMA tiles per wave along pixels
-    constexpr int A_LOADS = TK / 64;      // 16-byte chunks per thread per K-step for the weight tile
-    constexpr int B_LOADS = kTP / 64;
-    __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * 64];
-    __shared__ __attribute__((aligned(16))) int8_t sB[2][kTP * 64];
+    constexpr int A_LOADS = TK / 32;      // 16-byte chunks per thread per K-step for the weight tile
+    constexpr int B_LOADS = kTP / 32;
+    __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * BKB];
+    __shared__ __attribute__((aligned(16))) int8_t sB[2][kTP * BKB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_k = (wave >> 1) * (TK / 2);          // this wave's first k_out row inside the tile
@@ -71,58 +74,65 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     const int m0 = blockIdx.x * kTP;
     const int k0 = blockIdx.y * TK;
 
-    // staging assignment: thread -> (row = tid >> 2 (+64 per load), chunk-in-step = tid & 3)
-    const int ld_row = tid >> 2, ld_chunk = tid & 3;
+    // staging assignment: thread -> (row = tid >> 3 (+32 per load), chunk-in-step = tid & 7)
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
     const int PQ = p.P * p.Q;
     int b_ih0[B_LOADS], b_iw0[B_LOADS];
     long b_base[B_LOADS];
-    bool b_ok[B_LOADS];
 #pragma unroll
     for (int j = 0; j < B_LOADS; ++j) {
-        const int m = m0 + ld_row + 64 * j;
-        b_ok[j] = m < p.M;
-        const int mm = b_ok[j] ? m : 0;
+        const int m = m0 + ld_row + 32 * j;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         const int n = mm / PQ, pq = mm - n * PQ;
         const int op = pq / p.Q, oq = pq - op * p.Q;
-        b_ih0[j] = op * p.stride_h - p.pad_h;
+        b_ih0[j] = ok ? op * p.stride_h - p.pad_h : -(1 << 28);     // out-of-range pixel: every tap misses
         b_iw0[j] = oq * p.stride_w - p.pad_w;
         b_base[j] = (long)n * p.H * p.W * p.C;
     }
     const long wrow_bytes = (long)p.chunks * 16;
+    // this thread's position (r, s, c16) on the reduction axis, advanced by 8 chunks per K-step
+    int g = ld_chunk;
+    int cc = g % p.c16, rs0 = g / p.c16;
+    int fr = rs0 / p.S, fs = rs0 - fr * p.S;
 
     v4i ra[A_LOADS], rb[B_LOADS];
-    auto load_step = [&](int step) {
-        const int g = step * 4 + ld_chunk;              // global 16-byte chunk on the reduction axis
+    auto load_step = [&]() {
         const bool live = g < p.chunks;
-        const int rs_ = live ? g / p.c16 : 0;
-        const int cc = live ? g - rs_ * p.c16 : 0;
-        const int r = rs_ / p.S, s = rs_ - r * p.S;
 #pragma unroll
         for (int j = 0; j < A_LOADS; ++j) {
-            const int k = k0 + ld_row + 64 * j;
+            const int k = k0 + ld_row + 32 * j;
             v4i v = {0, 0, 0, 0};
             if (live && k < p.K) v = *reinterpret_cast<const v4i*>(w + (long)k * wrow_bytes + (long)g * 16);
             ra[j] = v;
         }
+        const int dh = fr * p.dil_h, dw = fs * p.dil_w;
 #pragma unroll
         for (int j = 0; j < B_LOADS; ++j) {
-            const int ih = b_ih0[j] + r * p.dil_h, iw = b_iw0[j] + s * p.dil_w;
+            const int ih = b_ih0[j] + dh, iw = b_iw0[j] + dw;
             v4i v = {0, 0, 0, 0};
-            if (live && b_ok[j] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+            if (live && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
                 v = *reinterpret_cast<const v4i*>(x + b_base[j] + ((long)ih * p.W + iw) * p.C + cc * 16);
             rb[j] = v;
+        }
+        // advance to the next K-step
+        g += 8;
+        cc += 8;
+        while (cc >= p.c16) {
+            cc -= p.c16;
+            if (++fs == p.S) { fs = 0; ++fr; }
         }
     };
     auto store_step = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < A_LOADS; ++j) {
-            const int row = ld_row + 64 * j;
-            *reinterpret_cast<v4i*>(&sA[buf][row * 64 + swz(row, ld_chunk) * 16]) = ra[j];
+            const int row = ld_row + 32 * j;
+            *reinterpret_cast<v4i*>(&sA[buf][row * BKB + swz(row, ld_chunk) * 16]) = ra[j];
         }
 #pragma unroll
         for (int j = 0; j < B_LOADS; ++j) {
-            const int row = ld_row + 64 * j;
-            *reinterpret_cast<v4i*>(&sB[buf][row * 64 + swz(row, ld_chunk) * 16]) = rb[j];
+            const int row = ld_row + 32 * j;
+            *reinterpret_cast<v4i*>(&sB[buf][row * BKB + swz(row, ld_chunk) * 16]) = rb[j];
         }
     };
 
@@ -134,26 +144,26 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
 
-    const int nsteps = (p.chunks + 3) >> 2;
-    load_step(0);
+    const int nsteps = (p.chunks + 7) >> 3;
+    load_step();
     store_step(0);
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < nsteps) load_step(step + 1);      // global loads in flight under the MFMAs
+        if (step + 1 < nsteps) load_step();              // global loads in flight under the MFMAs
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int chunk = ks * 2 + (lane >> 5);       // lane l holds k = 16*(l>>5) + j of this 32-deep sub-step
+        for (int ks = 0; ks < 4; ++ks) {
+            const int chunk = ks * 2 + (lane >> 5);       // A and B fragments use the same k order
             v4i fa[MT], fb[NT];
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
                 const int row = wave_k + a * 32 + (lane & 31);
-                fa[a] = *reinterpret_cast<const v4i*>(&sA[cur][row * 64 + swz(row, chunk) * 16]);
+                fa[a] = *reinterpret_cast<const v4i*>(&sA[cur][row * BKB + swz(row, chunk) * 16]);
             }
 #pragma unroll
             for (int b = 0; b < NT; ++b) {
                 const int row = wave_p + b * 32 + (lane & 31);
-                fb[b] = *reinterpret_cast<const v4i*>(&sB[cur][row * 64 + swz(row, chunk) * 16]);
+                fb[b] = *reinterpret_cast<const v4i*>(&sB[cur][row * BKB + swz(row, chunk) * 16]);
             }
 #pragma unroll
             for (int a = 0; a < MT; ++a)

@@ -57,6 +57,11 @@ def _dist_state():
     return 0, 1
 
 
+def _dist_on():
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized()
+
+
 class Quantity(object):
 
     # the statistics engine; tests substitute oracle-backed doubles to exercise the host logic on CPU
@@ -242,8 +247,9 @@ class Quantity(object):
         free, total = torch.cuda.mem_get_info()
         # measured on MI355X / ROCm 7.2: the first allocation that takes a process past ~128 GB costs
         # ~4 s once (and ~3 ms per hipMalloc afterwards), more than the forwards it would save on
-        # a few thousand images -- so by default stay below 110 GB in use.
-        return max(0, min(int(free * 0.6), (110 << 30) - (total - free)))
+        # a few thousand images -- so by default the cache stops at 96 GB, which with the forward's
+        # own transient tensors (~14 GB for ResNet-50 at batch 128) keeps the process below that cliff.
+        return max(0, min(int(free * 0.6), (96 << 30) - (total - free)))
 
     def _sync(self):
         if self.device == "gpu" and torch.cuda.is_available():
@@ -289,16 +295,21 @@ class Quantity(object):
         # pass 1: running abs-max of every cared tensor; keep the activations while HBM allows
         budget = self._activation_cache_budget()
         cached, cached_ids, used = [], set(), 0
+        step_ms = []
         for i, item in self._calibration_items(images_files):
+            ts = time.perf_counter()
             self.net_forward(self.model, item)
             collector.refresh_max_val(named_feats)
+            if os.environ.get("FQ_DEBUG_STEP_TIMES"):
+                self._sync()
+                step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
             if budget:
                 need = sum(t.numel() * t.element_size() for t in named_feats.values())
                 if used + need <= budget:
                     cached.append(dict(named_feats))
                     cached_ids.add(i)
                     used += need
-        if world > 1:
+        if _dist_on():                      # also at world size 1: same code path, trivial cost
             collector.all_reduce_max()
         distribution_intervals = collector.distribution_intervals      # (device -> host sync)
         t1 = time.perf_counter()
@@ -325,7 +336,7 @@ class Quantity(object):
             self.net_forward(self.model, item)
             collector.add_to_distributions(named_feats)
         del cached
-        if world > 1:
+        if _dist_on():
             collector.all_reduce_hist()
         if self.profile_phases:
             self._sync()
@@ -373,6 +384,8 @@ class Quantity(object):
         named_feats.clear()
         self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0,
                         "cached_batches": len(cached_ids), "cache_bytes": used}
+        if step_ms:
+            self.timings["pass1_step_ms"] = step_ms
         return bits
 
     def regist_hook_outfeature(self, model):

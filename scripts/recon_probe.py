@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""GPU probe: ReconModel (int8-sim) / ReconTest forward of the fabu ResNet-50 only, for rocprofv3 kernel stats."""
+import os, sys, time
+os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity")); sys.path.insert(0, ROOT)
+import bench
+from tools import Quantity, Reconstruction
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+dev = torch.device("cuda")
+out = sys.stdout; sys.stdout = open(os.devnull, "w")
+model = bench.build_model("r50", 224, dev)
+bench.make_workdir(1, "1,3,224,224", 0)
+data = bench.DeviceBatches(2, B, 224, 0, 1, dev)
+q = Quantity(model); q.activation_quantize(data); q.weight_quantize()
+rec = Reconstruction(bench.build_model("r50", 224, dev))
+net = rec.ReconModel(rec.get_quantity_information(), "./workdir/recon.pth")
+sys.stdout = out
+x = data[0][0]
+with torch.no_grad():
+    for _ in range(3): net(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): net(x)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+print("ReconModel B=%d: %.3f ms/batch = %.0f img/s" % (B, dt * 1e3, B / dt))

@@ -154,3 +154,38 @@ def test_rewriter_matches_reference(golden_dir, tmp_path):
     assert open(os.path.join(d, "weight.table")).read() == g["weight.table"]
     for rel, text in g["files"].items():
         assert open(os.path.join(d, rel)).read() == text, rel
+
+
+# ---------------------------------------------------------------- input side: PRE_PROCESS.IMG = 2 (.npy files)
+def test_npy_input_mode_equals_loader_mode(tmp_path, oracle):
+    """pytorch_quantizer.py:276-280: each calibration item is the path of a .npy holding one CHW image."""
+    import yaml
+    from common.quantity import merge_bn
+    from engine_doubles import OracleCollector, OracleQuantizer
+    from model.resnet.ResNet_18_fabu import ResNet18
+    from tools import Quantity
+
+    class CpuQuantity(Quantity):
+        collector_cls = OracleCollector
+        quantizer_cls = OracleQuantizer
+
+    imgs = [cases.fixed_input((3, 32, 32), seed=500 + i) for i in range(3)]
+    tables = []
+    for mode in (1, 2):
+        with product_workdir(device="cpu", max_cali_img_num=2) as tmp:
+            ucfg_path = os.path.join(tmp, "test", "user_configs.yml")
+            ucfg = yaml.safe_load(open(ucfg_path))
+            ucfg["PRE_PROCESS"]["IMG"] = mode
+            yaml.safe_dump(ucfg, open(ucfg_path, "w"))
+            if mode == 1:
+                items = [(im[None], torch.zeros(1, dtype=torch.long)) for im in imgs]
+            else:
+                items = []
+                for i, im in enumerate(imgs):
+                    path = str(tmp_path / ("img%d.npy" % i))
+                    np.save(path, im.numpy())
+                    items.append(path)
+            q = CpuQuantity(merge_bn(cases.seed_model(ResNet18()).eval()))
+            q.activation_quantize(items)
+            tables.append(open(os.path.join(tmp, "test", "workdir", "feat.table")).read())
+    assert tables[0] == tables[1] and tables[0].startswith("image ")
