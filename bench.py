@@ -26,11 +26,6 @@ import sys
 import tempfile
 import time
 
-# Growing the caching allocator with one hipMalloc per activation costs ~30 ms/GB on this stack;
-# expandable segments (virtual-memory backed growth) cost ~0.1 ms/GB.  Must be set before torch
-# touches the GPU.  (Keeping pass-1 activations alive for pass 2 is what needs the room.)
-os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
-
 import numpy as np
 import torch
 
@@ -244,17 +239,16 @@ def main():
     if W > 0:
         make_workdir(W * world - 1, shape, local_rank)
         warm = DeviceBatches(W * world, B, HW, rank, world, device)
-        Quantity(model).activation_quantize(warm)
+        wq = Quantity(model)
+        wq.activation_quantize(warm)
         del warm
         # let the caching allocator reach its working-set size before the clock starts (a long-running
         # calibration service pays this growth once; a cold one-shot run pays ~10 ms/GB on top)
-        free, _t = torch.cuda.mem_get_info()
-        grow = min(int(free * 0.6), 110 << 30)
-        if os.environ.get("FQ_ACT_CACHE_GB") is not None:
-            grow = int(float(os.environ["FQ_ACT_CACHE_GB"]) * (1 << 30))
+        grow = wq._activation_cache_budget()
         if grow > 0:
             pool = torch.empty(grow, dtype=torch.uint8, device=device)
             del pool
+        del wq
     barrier()
 
     # ---- timed: K batches per GPU
@@ -286,8 +280,8 @@ def main():
         "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "fabu ResNet-%s per-tensor KL calibration, %d synthetic 3x%dx%d images per GPU "
-                               "(batch %d x %d steps), 71 histogram rows x 2048 bins" %
-                               ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K),
+                               "(batch %d x %d steps), %d histogram rows x 2048 bins" %
+                               ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K, len(q.net_info) + 1),
                    "batch": B, "images_total": images, "parallelism": "dp%d" % world},
         "phases_s": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
     }

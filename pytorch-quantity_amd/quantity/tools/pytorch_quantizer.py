@@ -245,11 +245,14 @@ class Quantity(object):
         if env is not None:
             return int(float(env) * (1 << 30))
         free, total = torch.cuda.mem_get_info()
+        reserved, live = torch.cuda.memory_reserved(), torch.cuda.memory_allocated()
+        pooled = reserved - live                   # held by the caching allocator, reusable by us
+        foreign = (total - free) - reserved        # other processes / the driver
         # measured on MI355X / ROCm 7.2: the first allocation that takes a process past ~128 GB costs
         # ~4 s once (and ~3 ms per hipMalloc afterwards), more than the forwards it would save on
-        # a few thousand images -- so by default the cache stops at 96 GB, which with the forward's
-        # own transient tensors (~14 GB for ResNet-50 at batch 128) keeps the process below that cliff.
-        return max(0, min(int(free * 0.6), (96 << 30) - (total - free)))
+        # a few thousand images -- so by default this process stays below 96 GB in total, which with
+        # the forward's own transient tensors (~14 GB for ResNet-50 at batch 128) is clear of that cliff.
+        return max(0, min(int((free + pooled) * 0.6), (96 << 30) - foreign - live))
 
     def _sync(self):
         if self.device == "gpu" and torch.cuda.is_available():

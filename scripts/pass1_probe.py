@@ -2,8 +2,7 @@
 """GPU probe: per-step time of pass 1 (forward + absmax [+ keep activations]) to locate allocator stalls."""
 import os, sys, time
 if len(sys.argv) > 2 and sys.argv[2] == "expand":
-    os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
-import torch
+    import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity")); sys.path.insert(0, ROOT)
 import bench

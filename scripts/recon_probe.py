@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """GPU probe: ReconModel (int8-sim) / ReconTest forward of the fabu ResNet-50 only, for rocprofv3 kernel stats."""
 import os, sys, time
-os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity")); sys.path.insert(0, ROOT)

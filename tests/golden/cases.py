@@ -199,3 +199,35 @@ def calib_batches(n_batches, shape, seed=1234):
 def fixed_input(shape, seed=99):
     import torch
     return torch.from_numpy(np.random.default_rng(seed).standard_normal(tuple(shape), dtype=np.float32))
+
+
+def tiny_concat_net():
+    """Small net with a Concat fed by two convolutions and an Eltwise fed by a Concat consumer and a
+    convolution: covers the Concat merge group (shared interval, pooled histogram)."""
+    import torch.nn as nn
+    from common.quantity import Concat, Eltwise, View
+
+    class TinyConcatNet(nn.Module):
+        def __init__(self):
+            super(TinyConcatNet, self).__init__()
+            self.stem = nn.Conv2d(3, 8, 3, padding=1)
+            self.relu0 = nn.ReLU(False)
+            self.branch_a = nn.Conv2d(8, 8, 3, padding=1)
+            self.branch_b = nn.Conv2d(8, 8, 1)
+            self.Concat = Concat()
+            self.relu1 = nn.ReLU(False)
+            self.mix = nn.Conv2d(16, 8, 3, padding=1)
+            self.skip = nn.Conv2d(8, 8, 1)
+            self.Eltwise = Eltwise()
+            self.relu2 = nn.ReLU(False)
+            self.pool = nn.AvgPool2d(8)
+            self.view = View()
+            self.fc = nn.Linear(8, 5)
+
+        def forward(self, x):
+            s = self.relu0(self.stem(x))
+            c = self.relu1(self.Concat(self.branch_a(s), self.branch_b(s)))
+            y = self.relu2(self.Eltwise(self.mix(c), self.skip(s)))
+            return self.fc(self.view(self.pool(y)))
+
+    return TinyConcatNet()

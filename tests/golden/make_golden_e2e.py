@@ -173,6 +173,34 @@ def capture_dkl(cq, tl):
     print("DKL weight table:\n" + out["weight_table"])
 
 
+def capture_small(cq, tl):
+    """End-to-end tables for two small nets: the LeNet fixture (biased convs, MaxPool, Linear chain)
+    and a net with a Concat merge group."""
+    import torch
+    from model.lenet.lenet import Cnn                      # the reference's model file
+    out = {}
+    specs = (("lenet", lambda: Cnn(1, 10), "1,1,28,28", (4, 1, 28, 28)),
+             ("concat", cases.tiny_concat_net, "1,3,8,8", (4, 3, 8, 8)))
+    for tag, ctor, shape_str, bshape in specs:
+        with _refenv.reference_workdir(input_shape=shape_str, max_cali_img_num=2) as tmp:
+            model = cases.seed_model(ctor(), base_seed=7).eval()
+            q = tl.Quantity(model)
+            rec = {"net_info": {k: v for k, v in q.net_info.items()}, "net_info_order": list(q.net_info.keys()),
+                   "cared_op_layer_names": q.cared_op_layer_names, "merge_groups": q.get_merge_groups(q.net_info)}
+            q.activation_quantize(cases.calib_batches(4, bshape, seed=4321))
+            wd = os.path.join(tmp, "test", "workdir")
+            rec["feat_table"] = _read(os.path.join(wd, "feat.table"))
+            q.weight_quantize()
+            rec["weight_table"] = _read(os.path.join(wd, "weight.table"))
+            rec["files"] = {d: {f: _read(os.path.join(wd, d, f)) for f in sorted(os.listdir(os.path.join(wd, d)))}
+                            for d in ("bias", "new_bias")}
+            rec["weight_files_sha"] = _dir_state(os.path.join(wd, "weight"))
+            out[tag] = rec
+            print("small", tag, "feat.table:", rec["feat_table"].replace("\n", " | "))
+    with open(os.path.join(HERE, "g9_small_nets.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+
+
 def capture_g6(cq, tl):
     """BiasReWriter on a crafted directory: int8 wrap, negative bits, MAX_SHIFT capping."""
     import tempfile
@@ -259,6 +287,8 @@ def main():
         capture_r18(cq, tl)
     if "dkl" in which:
         capture_dkl(cq, tl)
+    if "small" in which:
+        capture_small(cq, tl)
 
 
 if __name__ == "__main__":
