@@ -97,15 +97,18 @@ def _quantize_params(layer, weight_bit, bias_bit, out_count, weight_16bit_range=
     assert layer.weight is not None, "The layer weight can`t be None"
     w = layer.weight.data
     b = layer.bias.data if layer.bias is not None else torch.zeros(out_count, device=w.device, dtype=w.dtype)
-    qw = torch.round(torch.mul(w, pow(2, weight_bit)))
-    qb = torch.round(torch.mul(b, pow(2, bias_bit)))
-    if QUANTIZE_BIT == 8:
-        qw = qw.clamp(-128, 127)
-        qb = qb.clamp(-128, 127)
-    else:
-        qw = qw.clamp(-32768, 32767) if weight_16bit_range else qw.clamp(-128, 127)
-        qb = qb.clamp(-32768.0, 32767.0)
-    return qw, qb
+    w_width = 8 if (QUANTIZE_BIT == 8 or not weight_16bit_range) else 16
+    b_width = 8 if QUANTIZE_BIT == 8 else 16
+    return _round_clamp(w, weight_bit, w_width), _round_clamp(b, bias_bit, b_width)
+
+
+def _round_clamp(t, bit, width):
+    """clamp(round_half_even(t * 2^bit)) -- the Quantity kernel when the parameter already lives on
+    the GPU, the same torch expression the reference uses when the model is still on the host."""
+    if t.device.type == "cuda" and t.dtype == torch.float32:
+        return _native.quantity(t, bit, width)
+    r = torch.round(torch.mul(t, pow(2, bit)))
+    return r.clamp(-128, 127) if width == 8 else r.clamp(-32768.0, 32767.0)
 
 
 class _IntegerSimLayer(nn.Module):
@@ -232,8 +235,11 @@ class QuanDequan(nn.Module):
 
 
 def _fake_quant_param(t, bit, bitwidth):
-    """One-time fake quantisation of a parameter tensor at construction (reference :305-309), with
-    torch ops on whatever device the parameter lives on.  Not a forward path."""
+    """One-time fake quantisation of a parameter tensor at construction (reference :305-309): the
+    QuanDequan kernel for parameters on the GPU, the reference's torch expression for a model that
+    is still on the host (Reconstruction is usually run before .cuda()).  Not a forward path."""
+    if t.device.type == "cuda" and t.dtype == torch.float32:
+        return _native.quandequan(t, bit, 8 if bitwidth == 8 else 16)
     s = pow(2, bit)
     r = torch.round(torch.mul(t, s))
     r = r.clamp(-128, 127) if bitwidth == 8 else r.clamp(-32768.0, 32767.0)
