@@ -285,11 +285,19 @@ def main():
                    "batch": B, "images_total": images, "parallelism": "dp%d" % world},
         "phases_s": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
     }
+    traffic = None
+    try:        # HBM bytes per launch from the PMC counters of the committed profile of this same configuration
+        with open(os.path.join(ROOT, "profiles", "traffic_hist2048.json")) as fh:
+            tj = json.load(fh)
+        if (tj["batch"], tj["model"], tj["image"]) == (B, args.model, HW):
+            traffic = tj["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     if hist_s:
         ach = hist_s["bytes_per_launch"] / (hist_s["mean_ms"] * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": "hist2048_seg_kernel", "achieved": round(ach, 1),
                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                              "traffic": None, "launches": hist_s["launches"],
+                              "traffic": traffic, "launches": hist_s["launches"],
                               "mean_launch_ms": round(hist_s["mean_ms"], 4),
                               "algorithmic_bytes_per_launch": hist_s["bytes_per_launch"]}
         if max_s:

@@ -10,3 +10,17 @@ def batches(n_batches, batch, shape, seed=1234, device="cpu"):
         out.append((torch.randn(batch, *shape, generator=g, device=device),
                     torch.zeros(batch, dtype=torch.long, device=device)))
     return out
+
+
+def randomize_bn(model, seed=0):
+    """A freshly constructed net has running_mean = 0 and beta = 0, so every folded conv bias is exactly
+    0 and weight_quantize() stops at log2(0) -- as the reference does.  Stand-in statistics for demos."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+    return model

@@ -24,6 +24,8 @@ def main():
     weights = user_config["PATH"]["MODEL_PATH"]
     if os.path.isfile(weights):
         model.load_state_dict(torch.load(weights, map_location="cpu"))
+    else:
+        _synthetic.randomize_bn(model)      # no checkpoint: give BatchNorm non-trivial statistics
     model.eval()
     model = merge_bn(model)
     if user_config["SETTINGS"]["DEVICE"] == "gpu":
