@@ -13,11 +13,13 @@
 //                             epilogue, written straight to fp32 NCHW.  This is the one place on
 //                             the path that is a dense contraction, hence the one MFMA kernel.
 //
-// Tiling (64-wide wavefronts): workgroup = 256 threads = 2x2 waves, tile = TK output channels x 128
-// pixels, K-step = 128 bytes of the (r, s, c) reduction axis = 4 MFMA k-sub-steps.  Pixels sit on
-// the MFMA lane index, so each accumulator register is 32 consecutive pixels of one output channel:
-// 128-byte coalesced NCHW stores with no shuffle.  Operand tiles are staged global -> registers ->
-// LDS (double buffered, 16-byte accesses); the 128-byte LDS rows are XOR-swizzled
+// Tiling (64-wide wavefronts): workgroup = 256 threads = 4 waves side by side on the pixel axis,
+// tile = TK output channels x 128 pixels, K-step = 128 bytes of the (r, s, c) reduction axis = 4 MFMA
+// k-sub-steps.  Pixels sit on the MFMA lane index, so each accumulator register is 32 consecutive
+// pixels of one output channel (128-byte coalesced NCHW stores, no shuffle) and the activation
+// operand is loaded by each lane straight from the NHWC tensor (16 contiguous bytes = 16 channels
+// of one tap): the streamed operand never touches LDS.  Only the weight tile, shared by the four
+// waves, is staged global -> registers -> LDS (double buffered); its 128-byte rows are XOR-swizzled
 // (chunk ^= (row >> 1) & 7) so that ds_read_b128 fragment reads are bank-conflict free.
 #include "fq_common.h"
 
@@ -56,140 +58,138 @@ __device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& 
     return o * p.inv_ob;
 }
 
+// Position of a 16-byte chunk on the reduction axis: tap (r, s) and 16-channel group cc.
+struct RedPos { int cc, fs, fr; };
+__device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S) {
+    q.cc += delta;
+    while (q.cc >= c16) {
+        q.cc -= c16;
+        if (++q.fs == S) { q.fs = 0; ++q.fr; }
+    }
+}
+
+// Workgroup = 4 waves side by side along the pixel axis: wave w owns pixels [32w, 32w+32) of the
+// 128-pixel tile and ALL TK output channels (MT = TK/32 accumulator tiles).
+//   * activations (MFMA B operand) never touch LDS: lane l holds pixel (l & 31) and loads, per 32-deep
+//     sub-step, the 16 contiguous bytes (16 channels of one tap) at chunk 2*ks + (l >> 5) straight
+//     from the int8 NHWC tensor into the operand registers -- each byte is fetched once per workgroup;
+//   * weights (A operand) are shared by the 4 waves and staged through a double-buffered, XOR-swizzled
+//     LDS tile of TK rows x 128 bytes per K-step.
 template <int TK>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                const float* __restrict__ qbias, float* __restrict__ y,
                                                                const ConvParams p) {
     constexpr int BKB = 128;              // bytes of the reduction axis per K-step (8 chunks, 4 MFMA sub-steps)
-    constexpr int MT = TK / 64;           // 32-row MFMA tiles per wave along k_out
-    constexpr int NT = 2;                 // 32-col MFMA tiles per wave along pixels
+    constexpr int MT = TK / 32;           // 32-row MFMA tiles per wave along k_out
     constexpr int A_LOADS = TK / 32;      // 16-byte chunks per thread per K-step for the weight tile
-    constexpr int B_LOADS = kTP / 32;
     __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * BKB];
-    __shared__ __attribute__((aligned(16))) int8_t sB[2][kTP * BKB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wave_k = (wave >> 1) * (TK / 2);          // this wave's first k_out row inside the tile
-    const int wave_p = (wave & 1) * 64;                 // this wave's first pixel inside the tile
+    const int half = lane >> 5;
     const int m0 = blockIdx.x * kTP;
     const int k0 = blockIdx.y * TK;
-
-    // staging assignment: thread -> (row = tid >> 3 (+32 per load), chunk-in-step = tid & 7)
-    const int ld_row = tid >> 3, ld_chunk = tid & 7;
     const int PQ = p.P * p.Q;
-    int b_ih0[B_LOADS], b_iw0[B_LOADS];
-    long b_base[B_LOADS];
-#pragma unroll
-    for (int j = 0; j < B_LOADS; ++j) {
-        const int m = m0 + ld_row + 32 * j;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int n = mm / PQ, pq = mm - n * PQ;
-        const int op = pq / p.Q, oq = pq - op * p.Q;
-        b_ih0[j] = ok ? op * p.stride_h - p.pad_h : -(1 << 28);     // out-of-range pixel: every tap misses
-        b_iw0[j] = oq * p.stride_w - p.pad_w;
-        b_base[j] = (long)n * p.H * p.W * p.C;
-    }
-    const long wrow_bytes = (long)p.chunks * 16;
-    // this thread's position (r, s, c16) on the reduction axis, advanced by 8 chunks per K-step
-    int g = ld_chunk;
-    int cc = g % p.c16, rs0 = g / p.c16;
-    int fr = rs0 / p.S, fs = rs0 - fr * p.S;
 
-    v4i ra[A_LOADS], rb[B_LOADS];
+    // this lane's output pixel
+    const int m = m0 + wave * 32 + (lane & 31);
+    const bool m_ok = m < p.M;
+    int ih0, iw0, n_img = 0, pq = 0;
+    {
+        const int mm = m_ok ? m : 0;
+        n_img = mm / PQ; pq = mm - n_img * PQ;
+        const int op = pq / p.Q, oq = pq - op * p.Q;
+        ih0 = m_ok ? op * p.stride_h - p.pad_h : -(1 << 28);          // out-of-range pixel: every tap misses
+        iw0 = oq * p.stride_w - p.pad_w;
+    }
+    const int8_t* __restrict__ xin = x + (long)n_img * p.H * p.W * p.C;
+
+    // weight staging: thread -> (row = tid >> 3 (+32 per load), chunk-in-step = tid & 7)
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    const long wrow_bytes = (long)p.chunks * 16;
+    int ga = ld_chunk;                                   // this thread's weight chunk on the reduction axis
+
+    // activation chunk of sub-step 0 for this lane: g = step*8 + half; sub-step ks adds 2*ks
+    int gb = half;
+    RedPos pb;
+    pb.cc = gb % p.c16;
+    { const int rs0 = gb / p.c16; pb.fr = rs0 / p.S; pb.fs = rs0 - pb.fr * p.S; }
+
+    v4i ra[A_LOADS], rb[4];
     auto load_step = [&]() {
-        const bool live = g < p.chunks;
+        const bool a_live = ga < p.chunks;
 #pragma unroll
         for (int j = 0; j < A_LOADS; ++j) {
             const int k = k0 + ld_row + 32 * j;
             v4i v = {0, 0, 0, 0};
-            if (live && k < p.K) v = *reinterpret_cast<const v4i*>(w + (long)k * wrow_bytes + (long)g * 16);
+            if (a_live && k < p.K) v = *reinterpret_cast<const v4i*>(w + (long)k * wrow_bytes + (long)ga * 16);
             ra[j] = v;
         }
-        const int dh = fr * p.dil_h, dw = fs * p.dil_w;
+        ga += 8;
+        RedPos q = pb;
 #pragma unroll
-        for (int j = 0; j < B_LOADS; ++j) {
-            const int ih = b_ih0[j] + dh, iw = b_iw0[j] + dw;
+        for (int ks = 0; ks < 4; ++ks) {
+            const int ih = ih0 + q.fr * p.dil_h, iw = iw0 + q.fs * p.dil_w;
             v4i v = {0, 0, 0, 0};
-            if (live && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                v = *reinterpret_cast<const v4i*>(x + b_base[j] + ((long)ih * p.W + iw) * p.C + cc * 16);
-            rb[j] = v;
+            if (gb + 2 * ks < p.chunks && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                v = *reinterpret_cast<const v4i*>(xin + ((long)ih * p.W + iw) * p.C + q.cc * 16);
+            rb[ks] = v;
+            red_advance(q, 2, p.c16, p.S);
         }
-        // advance to the next K-step
-        g += 8;
-        cc += 8;
-        while (cc >= p.c16) {
-            cc -= p.c16;
-            if (++fs == p.S) { fs = 0; ++fr; }
-        }
+        pb = q;                                           // 4 x (+2) = +8: first chunk of the next K-step
+        gb += 8;
     };
-    auto store_step = [&](int buf) {
+    auto store_a = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < A_LOADS; ++j) {
             const int row = ld_row + 32 * j;
             *reinterpret_cast<v4i*>(&sA[buf][row * BKB + swz(row, ld_chunk) * 16]) = ra[j];
         }
-#pragma unroll
-        for (int j = 0; j < B_LOADS; ++j) {
-            const int row = ld_row + 32 * j;
-            *reinterpret_cast<v4i*>(&sB[buf][row * BKB + swz(row, ld_chunk) * 16]) = rb[j];
-        }
     };
 
-    v16i acc[MT][NT];
+    v16i acc[MT];
 #pragma unroll
     for (int a = 0; a < MT; ++a)
 #pragma unroll
-        for (int b = 0; b < NT; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0;
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0;
 
     const int nsteps = (p.chunks + 7) >> 3;
     load_step();
-    store_step(0);
+    store_a(0);
+    v4i fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = rb[ks];
     __syncthreads();
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < nsteps) load_step();              // global loads in flight under the MFMAs
+        if (step + 1 < nsteps) load_step();              // next step's global loads fly under the MFMAs
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int chunk = ks * 2 + (lane >> 5);       // A and B fragments use the same k order
-            v4i fa[MT], fb[NT];
+            const int chunk = ks * 2 + half;              // A and B fragments use the same k order
 #pragma unroll
             for (int a = 0; a < MT; ++a) {
-                const int row = wave_k + a * 32 + (lane & 31);
-                fa[a] = *reinterpret_cast<const v4i*>(&sA[cur][row * BKB + swz(row, chunk) * 16]);
+                const int row = a * 32 + (lane & 31);
+                const v4i fa = *reinterpret_cast<const v4i*>(&sA[cur][row * BKB + swz(row, chunk) * 16]);
+                acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[ks], acc[a], 0, 0, 0);
             }
-#pragma unroll
-            for (int b = 0; b < NT; ++b) {
-                const int row = wave_p + b * 32 + (lane & 31);
-                fb[b] = *reinterpret_cast<const v4i*>(&sB[cur][row * BKB + swz(row, chunk) * 16]);
-            }
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-#pragma unroll
-                for (int b = 0; b < NT; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[a], fb[b], acc[a][b], 0, 0, 0);
         }
         if (step + 1 < nsteps) {
-            store_step(cur ^ 1);                          // the other buffer was last read one barrier ago
+            store_a(cur ^ 1);                             // the other buffer was last read one barrier ago
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb[ks] = rb[ks];
             __syncthreads();
         }
     }
 
-    // epilogue: D row = k_out = (r&3) + 8*(r>>2) + 4*(lane>>5), D col = pixel = lane&31
-#pragma unroll
-    for (int b = 0; b < NT; ++b) {
-        const int m = m0 + wave_p + b * 32 + (lane & 31);
-        if (m >= p.M) continue;
-        const int n = m / PQ, pq = m - n * PQ;
-        float* __restrict__ out = y + (long)n * p.K * PQ + pq;
+    // epilogue: D row = k_out = (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel.  For a fixed
+    // register the 32 lanes of a half-wave write 32 consecutive pixels of one channel (128 bytes).
+    if (m_ok) {
+        float* __restrict__ out = y + (long)n_img * p.K * PQ + pq;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = k0 + wave_k + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (k < p.K) out[(long)k * PQ] = conv_tail(acc[a][b][r], qbias[k], p);
+                const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (k < p.K) out[(long)k * PQ] = conv_tail(acc[a][r], qbias[k], p);
             }
         }
     }
@@ -295,7 +295,9 @@ extern "C" int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const fl
     else { p.lo = -32768.0f; p.hi = 32767.0f; p.ilo = -32768; p.ihi = 32767; }
     hipStream_t st = as_stream(stream);
     const unsigned gx = (unsigned)((M + kTP - 1) / kTP);
-    if (K <= 64) {
+    // 64-row tiles when the output is narrow, or when 128-row tiles would not even give one workgroup per CU
+    const long wg128 = (long)gx * ((K + 127) / 128);
+    if (K <= 64 || wg128 < kCUs) {
         hipLaunchKernelGGL(conv2d_i8_kernel<64>, dim3(gx, (K + 63) / 64), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
                            y_nchw, p);
     } else {

@@ -111,6 +111,29 @@ def _round_clamp(t, bit, width):
     return r.clamp(-128, 127) if width == 8 else r.clamp(-32768.0, 32767.0)
 
 
+class _QuantizedInputCache(object):
+    """One-entry memo of fq_quantize_i8_nhwc results.  A residual block hands the SAME tensor to its
+    first conv and to its projection shortcut, both with the same input bit; the second caller reuses
+    the int8 NHWC copy instead of re-reading the fp32 tensor.  Keyed by tensor identity + version."""
+
+    def __init__(self):
+        self._key, self._ref, self._val = None, None, None
+
+    def get(self, x, ib, cpad):
+        key = (id(x), x._version, x.data_ptr(), tuple(x.shape), int(ib), int(cpad))
+        if key == self._key and self._ref is x:
+            return self._val
+        val = _native.quantize_i8_nhwc(x, ib, cpad)
+        self._key, self._ref, self._val = key, x, val
+        return val
+
+    def clear(self):
+        self._key, self._ref, self._val = None, None, None
+
+
+_xq_cache = _QuantizedInputCache()
+
+
 class _IntegerSimLayer(nn.Module):
     """Shared body of NewConv2d / NewLinear: Quantity -> integer contraction -> fused tail.
 
@@ -183,7 +206,7 @@ class NewConv2d(_IntegerSimLayer):
         conv = self.Conv
         if self._int8_ok(conv):
             wq = self._packed_weight(conv)
-            xq = _native.quantize_i8_nhwc(input, self.input_bit, wq.shape[-1])
+            xq = _xq_cache.get(input, self.input_bit, wq.shape[-1])
             return _native.conv2d_i8(xq, wq, self.quantized_bias, conv.stride, conv.padding, conv.dilation,
                                      self.rs_bit, self.output_bit, 8)
         q = self.Quan(input)
