@@ -1,0 +1,92 @@
+"""north_star target: feat.table / weight.table / quantised-weight JSON of the fabu ResNet-50 produced
+by the HIP path are byte-identical to the CPU path (the oracle-backed engine) on the same activations.
+
+The model forward runs once, on the GPU; a recording collector hands every batch's activations to the
+HIP engine and keeps host copies; a second orchestrator run replays those host copies through the
+oracle engine.  Both runs therefore see the very same tensors (MIOpen convolutions are not bitwise
+reproducible from call to call, so re-running the forward would not do).   pytest -m gpu"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from workdir_util import product_workdir
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(wd):
+    out = {"feat": open(os.path.join(wd, "feat.table")).read(), "weight": open(os.path.join(wd, "weight.table")).read()}
+    for d in ("weight", "bias", "new_weight", "new_bias"):
+        out[d] = {f: hashlib.sha256(open(os.path.join(wd, d, f), "rb").read()).hexdigest()
+                  for f in sorted(os.listdir(os.path.join(wd, d)))}
+    return out
+
+
+def test_r50_tables_hip_equals_cpu_oracle(oracle):
+    from common.quantity import DistributionCollector, merge_bn
+    from engine_doubles import OracleCollector, OracleQuantizer
+    from model.resnet.ResNet_fabu import ResNet50
+    from tools import Quantity
+
+    tape = {"max": [], "hist": []}
+
+    class RecordingCollector(DistributionCollector):
+        def refresh_max_val(self, tensors):
+            tape["max"].append({k: v.detach().cpu().numpy().copy() for k, v in tensors.items()})
+            super().refresh_max_val(tensors)
+
+        def add_to_distributions(self, tensors):
+            tape["hist"].append({k: v.detach().cpu().numpy().copy() for k, v in tensors.items()})
+            super().add_to_distributions(tensors)
+
+    class ReplayCollector(OracleCollector):
+        def refresh_max_val(self, tensors):
+            super().refresh_max_val(tape["max"].pop(0) if self._replay else tensors)
+
+        def add_to_distributions(self, tensors):
+            super().add_to_distributions(tape["hist"].pop(0) if self._replay else tensors)
+
+        _replay = True
+
+    class HipQuantity(Quantity):
+        collector_cls = RecordingCollector
+
+    class CpuQuantity(Quantity):
+        collector_cls = ReplayCollector
+        quantizer_cls = OracleQuantizer
+
+    batches = cases.calib_batches(2, (4, 3, 224, 224), seed=77)
+    model = merge_bn(cases.seed_model(ResNet50(), gamma_scale=0.7).eval()).cuda()
+
+    with product_workdir(input_shape="1,3,224,224", device="gpu", max_cali_img_num=1) as tmp:
+        q = HipQuantity(model)
+        q.activation_quantize(batches)
+        hip_hist = q._collector.hist_device.cpu().numpy()
+        hip_max = q._collector.max_device.cpu().numpy()
+        HipQuantity.collector_cls = DistributionCollector        # weights: plain HIP collector
+        q.collector_cls = DistributionCollector
+        q.weight_quantize()
+        hip = _state(os.path.join(tmp, "test", "workdir"))
+    assert len(tape["max"]) == 2 and len(tape["hist"]) == 2
+
+    with product_workdir(input_shape="1,3,224,224", device="gpu", max_cali_img_num=1) as tmp:
+        q2 = CpuQuantity(model)
+        q2.overlap_streams = False
+        q2.activation_quantize(batches)                          # forwards run, their outputs are ignored
+        cpu_hist = q2._collector._hist
+        cpu_max = q2._collector._max
+        ReplayCollector._replay = False                          # weights come straight from the parameters
+        q2.weight_quantize()
+        cpu = _state(os.path.join(tmp, "test", "workdir"))
+
+    np.testing.assert_array_equal(hip_max, cpu_max)
+    np.testing.assert_array_equal(hip_hist, cpu_hist)            # 71 rows x 2048 bins, exact
+    assert hip["feat"] == cpu["feat"]
+    assert hip["weight"] == cpu["weight"]
+    for d in ("weight", "bias", "new_weight", "new_bias"):
+        assert hip[d] == cpu[d], d
+    assert len(hip["feat"].strip().split("\n")) == 71

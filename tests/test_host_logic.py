@@ -189,3 +189,39 @@ def test_npy_input_mode_equals_loader_mode(tmp_path, oracle):
             q.activation_quantize(items)
             tables.append(open(os.path.join(tmp, "test", "workdir", "feat.table")).read())
     assert tables[0] == tables[1] and tables[0].startswith("image ")
+
+
+# ---------------------------------------------------------------- H6: dilation -> zero padded kernel
+def test_dilation_to_zero_padding():
+    """pytorch_quantizer.py:679-693: a k x k kernel with dilation 2 as a dense (2k-1) x (2k-1) kernel."""
+    from tools import Quantity
+    w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3) + 1
+    dense = Quantity.dilation_to_zero_padding(None, w, (2, 2))
+    assert dense.shape == (2, 3, 5, 5)
+    assert torch.equal(dense[..., ::2, ::2], w)
+    assert dense.sum() == w.sum() and (dense[..., 1::2, :] == 0).all() and (dense[..., :, 1::2] == 0).all()
+    x = torch.randn(1, 3, 9, 9)
+    ref = torch.nn.functional.conv2d(x, w, dilation=2)
+    got = torch.nn.functional.conv2d(x, dense)
+    assert torch.allclose(ref, got, atol=1e-4)
+    with pytest.raises(AssertionError):
+        Quantity.dilation_to_zero_padding(None, w, (3, 3))
+
+
+def test_testconv_visualization_dump_is_optional(tmp_path, monkeypatch):
+    """TestConv's constructor side effects (reference new_quantity_op.py:312-337): text dumps and PNG
+    histograms are written only when asked for; the results directory is always created."""
+    import torch.nn as nn
+    from common.quantity import new_quantity_op as nq
+    info = dict(weight_bit=7, bias_bit=4, input_bit=4, output_bit=4)
+    path = str(tmp_path / "m.pth")
+    nq.TestConv("a.b", nn.Conv2d(3, 4, 3), info, path)
+    res = tmp_path / "quantity_results"
+    assert res.is_dir() and not list(res.iterdir())
+    monkeypatch.setattr(nq, "DUMP_VISUALIZATION", True)
+    layer = nq.TestLinear("fc", nn.Linear(8, 3), info, path)
+    names = sorted(p.name for p in res.iterdir())
+    assert names == ["fc_bias.txt", "fc_bias_o.png", "fc_bias_q.png", "fc_weight.txt", "fc_weight_o.png", "fc_weight_q.png"]
+    # weights were fake-quantised at construction: multiples of 2^-7 within the int8 range
+    w = layer.linear.weight.detach() * 128
+    assert torch.equal(w, torch.round(w)) and w.abs().max() <= 128
