@@ -166,10 +166,14 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable
     const TileView tv = tile_of(tab);
     const float iv = interval[tv.row];
     __syncthreads();
-    // the fast quotient needs a normal, finite, positive interval (always true for
-    // max/2048 + 1e-12); anything else takes the IEEE path.  Uniform per workgroup.
+    // The exhaustive proof of the fast quotient covers every significand pair but assumes that no
+    // intermediate under/overflows.  For 2^-60 <= iv <= 2^60 that holds for every element that can
+    // land above bin 0 (|x| >= iv >= 2^-60 keeps the fma residual normal; quotients that overflow
+    // become inf/nan and fall into the last bin exactly like the IEEE path).  Calibration intervals
+    // are max/2048 + 1e-12, far inside that range; anything else takes the IEEE divide.  Uniform per
+    // workgroup.
     const unsigned int ivb = __float_as_uint(iv);
-    const bool fast = allow_fast && ivb >= 0x00800000u && ivb < 0x7f800000u;
+    const bool fast = allow_fast && ivb >= 0x21800000u && ivb <= 0x5d800000u;
     if (fast) hist_tile<true>(tv, iv, s_bins); else hist_tile<false>(tv, iv, s_bins);
     __syncthreads();
     unsigned long long* __restrict__ dst = hist + (size_t)tv.row * FQ_BINS;

@@ -277,3 +277,33 @@ def test_full_size_quandequan_properties(nat):
     ref = torch.clamp(torch.round(x * 16), -128, 127) / 16            # torch's own fp32 ops
     assert torch.equal(y, ref)
     assert y.abs().max().item() <= 8.0
+
+
+def test_hist_bin_edges_adversarial(nat, oracle):
+    """The histogram's 3-instruction quotient must reproduce the IEEE divide exactly at every bin edge:
+    values k*iv and their float neighbours, for awkward intervals (all-ones significand, powers of
+    two, 1e-12, subnormal-adjacent, huge)."""
+    rng = np.random.default_rng(123)
+    ivs = np.array([1.0, 0.5, 1.9999999, 1.0000001, 3.0e-3, 1e-12, 1.17549435e-38 * 4, 7.7e-7, 123.456, 3.3e30,
+                    np.float32(2.0) ** -100, 0.0023243546], dtype=np.float32)
+    ivs = np.concatenate([ivs, np.exp(rng.uniform(-20, 20, 20)).astype(np.float32)])
+    segs, rows = [], []
+    for r, iv in enumerate(ivs):
+        k = np.concatenate([np.arange(0, 2100, dtype=np.float64), rng.integers(0, 2100, 3000).astype(np.float64)])
+        base = (k * np.float64(iv)).astype(np.float32)
+        near = [base]
+        cur_up, cur_dn = base.copy(), base.copy()
+        for _ in range(3):
+            cur_up = np.nextafter(cur_up, np.float32(np.inf), dtype=np.float32)
+            cur_dn = np.nextafter(cur_dn, np.float32(-np.inf), dtype=np.float32)
+            near += [cur_up.copy(), cur_dn.copy()]
+        x = np.concatenate(near)
+        x = np.where(np.isfinite(x), x, np.float32(0)).astype(np.float32)
+        x[::2] *= np.float32(-1)
+        segs.append(x)
+        rows.append(r)
+    hist = torch.zeros(len(ivs), 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_seg([_dev(s) for s in segs], rows, _dev(ivs), hist)
+    got = hist.cpu().numpy()
+    for r, iv in enumerate(ivs):
+        np.testing.assert_array_equal(got[r], oracle.hist2048(segs[r], iv), err_msg="iv=%r" % iv)
