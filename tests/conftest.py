@@ -13,8 +13,21 @@ for p in (ROOT, QUANTITY, GOLDEN, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _ensure_native_lib():
+    """The HIP library is a build artefact (git-ignored).  hipcc cross-compiles gfx950 without a GPU, so
+    build it on demand when a fresh checkout runs the tests; the product itself never builds lazily."""
+    import subprocess
+    csrc = os.path.join(PKG, "csrc")
+    lib = os.path.join(PKG, "lib", "libfq_hip.so")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".cpp", ".h"))]
+    srcs += [os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include"))]
+    if not os.path.isfile(lib) or os.path.getmtime(lib) < max(os.path.getmtime(s) for s in srcs):
+        subprocess.check_call(["make", "-C", csrc, "-s"])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_native_lib()
 
 
 @pytest.fixture(scope="session")
