@@ -305,6 +305,27 @@ def main():
             result["roofline_absmax"] = {"kernel": "absmax_seg_kernel", "achieved": round(ach2, 1), "unit": "GB/s",
                                          "frac": round(ach2 / HBM_PEAK_GBS, 4), "mean_launch_ms": round(max_s["mean_ms"], 4)}
 
+    # ---- the fused fake-quant kernel on its own (north_star: >= 60 % of the HBM roofline)
+    try:
+        xq = data.owned()[0].new_empty(802816 * B)                       # the largest ResNet-50 activation
+        xq.normal_()
+        yq = torch.empty_like(xq)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
+        _native.quandequan(xq, 4, 8, out=yq)
+        for a, b in evs:
+            a.record()
+            _native.quandequan(xq, 4, 8, out=yq)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        ach = xq.numel() * 8 / (ms * 1e-3) / 1e9
+        result["roofline_fakequant"] = {"bound": "hbm", "kernel": "unary_vec_kernel<QuanDequanOp>", "achieved": round(ach, 1),
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                                        "mean_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": xq.numel() * 8.0}
+        del xq, yq
+    except Exception as e:
+        result["roofline_fakequant"] = {"error": repr(e)}
+
     # ---- int8-sim / fake-quant forward throughput (BASELINE config[2]); replicas only, no collective
     if not args.no_recon:
         try:
