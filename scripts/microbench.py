@@ -71,7 +71,7 @@ def main():
             print("kl_threshold rows=%d: first %.1f ms, med %.2f ms; thr[:8]=%s" %
                   (len(segs), (t1 - t0) * 1e3, ms, thr[:8].tolist()))
         del segs
-    x = torch.randn(64 * 802816, device="cuda")
+    x = torch.randn(128 * 802816, device="cuda")
     y = torch.empty_like(x)
     ms, best = timeit(lambda: nat.quandequan(x, 4, out=y))
     print("quandequan   : %.1f Melem med %.3f ms (%.0f GB/s rd+wr, best %.0f)" %
