@@ -42,12 +42,13 @@ class DeviceBatches(object):
     """Sequence of (images, None) pairs indexed by GLOBAL batch index; only this rank's batches
     (i % world == rank) exist, pre-generated in HBM from generator seed 1234 + i."""
 
-    def __init__(self, total, batch, hw, rank, world, device):
+    def __init__(self, total, batch, hw, rank, world, device, on_host=False):
         self._items = {}
         self._total = total
         for i in range(rank, total, world):
             g = torch.Generator(device=device).manual_seed(1234 + i)
-            self._items[i] = torch.randn(batch, 3, hw, hw, generator=g, device=device)
+            t = torch.randn(batch, 3, hw, hw, generator=g, device=device)
+            self._items[i] = t.cpu() if on_host else t       # --host-inputs: pageable host memory
 
     def __len__(self):
         return self._total
@@ -196,6 +197,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--model", default="r50", choices=["r50", "r101"])
     ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="hand the calibrator pageable HOST batches (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recon", action="store_true")
     args = ap.parse_args()
@@ -253,7 +256,7 @@ def main():
 
     # ---- timed: K batches per GPU
     make_workdir(K * world - 1, shape, local_rank)
-    data = DeviceBatches(K * world, B, HW, rank, world, device)
+    data = DeviceBatches(K * world, B, HW, rank, world, device, on_host=args.host_inputs)
     q = Quantity(model)
     q.profile_phases = True
     with KernelTimer(_native, "hist2048_seg") as kt_hist, KernelTimer(_native, "absmax_seg") as kt_max:
@@ -278,7 +281,7 @@ def main():
         "metric": "calibration images/sec, ResNet-50 224^2 KL calibration (2 passes + KL sweep + feat.table)",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host-resident, PCIe inclusive)" if args.host_inputs else ""),
         "config": {"workload": "fabu ResNet-%s per-tensor KL calibration, %d synthetic 3x%dx%d images per GPU "
                                "(batch %d x %d steps), %d histogram rows x 2048 bins" %
                                ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K, len(q.net_info) + 1),
@@ -307,7 +310,7 @@ def main():
 
     # ---- the fused fake-quant kernel on its own (north_star: >= 60 % of the HBM roofline)
     try:
-        xq = data.owned()[0].new_empty(802816 * B)                       # the largest ResNet-50 activation
+        xq = torch.empty(802816 * B, device=device)                      # the largest ResNet-50 activation
         xq.normal_()
         yq = torch.empty_like(xq)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
@@ -331,7 +334,7 @@ def main():
         try:
             q.weight_quantize()
             barrier()
-            batches = data.owned()[:min(K, 8)]
+            batches = [b.to(device) for b in data.owned()[:min(K, 8)]]
 
             def fwd_rate(net):
                 with torch.no_grad():
