@@ -189,8 +189,13 @@ class Quantity(object):
     # ------------------------------------------------------------------------------------------
     def preprocess(self, image):
         """PRE_PROCESS.IMG: 1 = the item is a (data, label) pair from a loader; 2 = path of a .npy
-        holding one image; 0 = path of an image file (needs an image decoder: not available in this
-        build, and broken in the reference: pytorch_quantizer.py:260-263)."""
+        holding one CHW image; 0 = path of an image file.
+
+        Mode 0 in the reference (pytorch_quantizer.py:259-271) cannot run as shipped (`slef`,
+        `image_path` NameErrors), so there is nothing to be bit-compatible with; this follows what it
+        spells out: cv2.imread (BGR, uint8) -> cv2.resize(RESIZE) -> float32 - MEAN -> CHW -> [1,3,H,W]
+        (SCALE is read and never applied there, and is not applied here).  Decoding uses Pillow;
+        the resize is half-pixel bilinear rounded back to uint8, OpenCV's INTER_LINEAR convention."""
         mode = int(self.user_config["PRE_PROCESS"]["IMG"])
         if mode == 1:
             img, _ = image
@@ -199,8 +204,19 @@ class Quantity(object):
             arr = torch.as_tensor(np.load(image))
             return arr.view(1, *arr.shape)
         if mode == 0:
-            raise NotImplementedError("PRE_PROCESS.IMG = 0 (image files) needs an image decoder; "
-                                      "use 1 (loader) or 2 (.npy)")
+            from PIL import Image
+            cfg = self.user_config["PRE_PROCESS"]["IMG_SET"]
+            mean = float(cfg["MEAN"])
+            width, height = (int(float(v)) for v in str(cfg["RESIZE"]).split(","))
+            try:
+                rgb = np.asarray(Image.open(image).convert("RGB"))
+            except (OSError, ValueError):
+                return False                                   # the reference returns False for unreadable files
+            bgr = torch.from_numpy(np.ascontiguousarray(rgb[:, :, ::-1])).permute(2, 0, 1)[None].float()
+            if bgr.shape[-2:] != (height, width):
+                bgr = torch.nn.functional.interpolate(bgr, size=(height, width), mode="bilinear", align_corners=False)
+                bgr = torch.clamp(torch.round(bgr), 0, 255)
+            return bgr - mean
         print("input option set wrong:", mode)
         return None
 

@@ -225,3 +225,31 @@ def test_testconv_visualization_dump_is_optional(tmp_path, monkeypatch):
     # weights were fake-quantised at construction: multiples of 2^-7 within the int8 range
     w = layer.linear.weight.detach() * 128
     assert torch.equal(w, torch.round(w)) and w.abs().max() <= 128
+
+
+def test_image_file_input_mode(tmp_path):
+    """PRE_PROCESS.IMG = 0: decode -> BGR -> resize -> minus MEAN -> [1,3,H,W] float32."""
+    import yaml
+    from PIL import Image
+    from tools import Quantity
+    rng = np.random.default_rng(1)
+    rgb = rng.integers(0, 256, (32, 32, 3), dtype=np.uint8)
+    p_same = str(tmp_path / "a.png")
+    Image.fromarray(rgb).save(p_same)
+    big = rng.integers(0, 256, (64, 48, 3), dtype=np.uint8)
+    p_big = str(tmp_path / "b.png")
+    Image.fromarray(big).save(p_big)
+    with product_workdir(device="cpu") as tmp:
+        ucfg_path = os.path.join(tmp, "test", "user_configs.yml")
+        ucfg = yaml.safe_load(open(ucfg_path))
+        ucfg["PRE_PROCESS"]["IMG"] = 0
+        yaml.safe_dump(ucfg, open(ucfg_path, "w"))
+        q = Quantity.__new__(Quantity)
+        q.user_config = ucfg
+        x = q.preprocess(p_same)
+        assert x.shape == (1, 3, 32, 32) and x.dtype == torch.float32
+        np.testing.assert_array_equal(x[0].numpy(), rgb[:, :, ::-1].transpose(2, 0, 1).astype(np.float32) - 128.0)
+        y = q.preprocess(p_big)
+        assert y.shape == (1, 3, 32, 32) and y.min() >= -128 and y.max() <= 127
+        assert torch.equal(y, torch.round(y))
+        assert q.preprocess(str(tmp_path / "missing.png")) is False
