@@ -26,10 +26,11 @@ def _state(wd):
     return out
 
 
-def test_r50_tables_hip_equals_cpu_oracle(oracle):
+@pytest.mark.parametrize("arch,rows,batch", [("r50", 71, 4), ("r101", 139, 2)])
+def test_bottleneck_tables_hip_equals_cpu_oracle(oracle, arch, rows, batch):
     from common.quantity import DistributionCollector, merge_bn
     from engine_doubles import OracleCollector, OracleQuantizer
-    from model.resnet.ResNet_fabu import ResNet50
+    from model.resnet.ResNet_fabu import ResNet50, ResNet101
     from tools import Quantity
 
     tape = {"max": [], "hist": []}
@@ -59,16 +60,16 @@ def test_r50_tables_hip_equals_cpu_oracle(oracle):
         collector_cls = ReplayCollector
         quantizer_cls = OracleQuantizer
 
-    batches = cases.calib_batches(2, (4, 3, 224, 224), seed=77)
-    model = merge_bn(cases.seed_model(ResNet50(), gamma_scale=0.7).eval()).cuda()
+    batches = cases.calib_batches(2, (batch, 3, 224, 224), seed=77)
+    ctor = ResNet50 if arch == "r50" else ResNet101         # r101: 139 rows = two chunked kernel launches
+    model = merge_bn(cases.seed_model(ctor(), gamma_scale=0.7 if arch == "r50" else 0.5).eval()).cuda()
 
     with product_workdir(input_shape="1,3,224,224", device="gpu", max_cali_img_num=1) as tmp:
         q = HipQuantity(model)
         q.activation_quantize(batches)
         hip_hist = q._collector.hist_device.cpu().numpy()
         hip_max = q._collector.max_device.cpu().numpy()
-        HipQuantity.collector_cls = DistributionCollector        # weights: plain HIP collector
-        q.collector_cls = DistributionCollector
+        q.collector_cls = DistributionCollector                  # weights: plain HIP collector
         q.weight_quantize()
         hip = _state(os.path.join(tmp, "test", "workdir"))
     assert len(tape["max"]) == 2 and len(tape["hist"]) == 2
@@ -81,6 +82,7 @@ def test_r50_tables_hip_equals_cpu_oracle(oracle):
         cpu_max = q2._collector._max
         ReplayCollector._replay = False                          # weights come straight from the parameters
         q2.weight_quantize()
+        ReplayCollector._replay = True
         cpu = _state(os.path.join(tmp, "test", "workdir"))
 
     np.testing.assert_array_equal(hip_max, cpu_max)
@@ -89,4 +91,4 @@ def test_r50_tables_hip_equals_cpu_oracle(oracle):
     assert hip["weight"] == cpu["weight"]
     for d in ("weight", "bias", "new_weight", "new_bias"):
         assert hip[d] == cpu[d], d
-    assert len(hip["feat"].strip().split("\n")) == 71
+    assert len(hip["feat"].strip().split("\n")) == rows
