@@ -1,0 +1,115 @@
+"""Per-channel calibration: one abs-max / 2048-bin histogram / KL threshold per (tensor, channel).
+
+EXTENSION, not part of the reference API: the reference's calibrator is per tensor
+(distribution_collector.py:40-42; feat.table holds one bit per layer), so there is nothing to be
+bit-compatible with.  The HIP kernels take a generic histogram ROW, and a row can just as well be
+(tensor, channel): this collector lays every [N, C, ...] activation out channel-major ([C, N*...], one
+contiguous run per channel) and feeds the SAME segmented kernels with row = first_row(tensor) + c.
+Arithmetic per row is exactly the per-tensor arithmetic (same interval formula, same binning, same KL
+sweep), which tests/test_gpu_per_channel.py checks against the CPU oracle channel by channel.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _native
+
+__all__ = ["ChannelCollector"]
+
+_MAX_SEGS = 1024            # FQ_MAX_SEGS per C-ABI call
+
+
+class ChannelCollector(object):
+
+    def __init__(self, channels, statistic=1, device=None):
+        """channels: ordered {tensor name: channel count C} (dimension 1 of the activation)."""
+        self._names = list(channels.keys())
+        self._channels = dict(channels)
+        self._first = {}
+        row = 0
+        for n in self._names:
+            self._first[n] = row
+            row += int(channels[n])
+        self._rows = row
+        self._statistic = statistic
+        self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._max = torch.zeros(row, dtype=torch.float32, device=self._device)
+        self._hist = torch.zeros(row, _native.BINS, dtype=torch.int64, device=self._device)
+        self._interval = None
+
+    @property
+    def rows(self):
+        return self._rows
+
+    def row_range(self, name):
+        return self._first[name], self._first[name] + self._channels[name]
+
+    def _segments(self, tensors):
+        segs, rows = [], []
+        for n in self._names:
+            t = tensors[n]
+            C = self._channels[n]
+            assert t.shape[1] == C, (n, tuple(t.shape), C)
+            cm = t.detach().transpose(0, 1).reshape(C, -1)        # channel-major copy: [C, N*H*W]
+            if not cm.is_contiguous():
+                cm = cm.contiguous()
+            for c in range(C):
+                segs.append(cm[c])
+                rows.append(self._first[n] + c)
+        return segs, rows
+
+    def _call(self, fn, tensors, *extra):
+        segs, rows = self._segments(tensors)
+        for i in range(0, len(segs), _MAX_SEGS):
+            fn(segs[i:i + _MAX_SEGS], rows[i:i + _MAX_SEGS], *extra)
+
+    def refresh_max_val(self, tensors):
+        self._call(_native.absmax_seg, tensors, self._max)
+
+    def intervals(self):
+        """fp32 bin width per row: statistic * max / 2048 + 1e-12 with NumPy fp32 scalars (the
+        reference's expression, distribution_collector.py:61); rows that never left zero get 1e-12."""
+        m = self._max.cpu().numpy()
+        iv = np.empty(self._rows, dtype=np.float32)
+        for r in range(self._rows):
+            v = m[r] if m[r] > 0 else 0
+            iv[r] = np.float32(self._statistic * v / _native.BINS + 1e-12)
+        self._interval = torch.from_numpy(iv).to(self._device)
+        return iv
+
+    def add_to_distributions(self, tensors):
+        if self._interval is None:
+            self.intervals()
+        self._call(_native.hist2048_seg, tensors, self._interval, self._hist)
+
+    def all_reduce_max(self):
+        import torch.distributed as dist
+        dist.all_reduce(self._max, op=dist.ReduceOp.MAX)
+
+    def all_reduce_hist(self):
+        import torch.distributed as dist
+        dist.all_reduce(self._hist, op=dist.ReduceOp.SUM)
+
+    @property
+    def max_device(self):
+        return self._max
+
+    @property
+    def hist_device(self):
+        return self._hist
+
+    def quantize(self):
+        """-> {tensor name: [bits per channel]} via the KL sweep (quantizer.py:86-90 per row)."""
+        iv = self._interval.cpu().numpy()
+        thr = _native.kl_threshold(self._hist).cpu().numpy()
+        bits = {}
+        for n in self._names:
+            lo, hi = self.row_range(n)
+            out = []
+            for r in range(lo, hi):
+                tb = (int(thr[r]) + 0.5) * iv[r]
+                out.append(int(8 - 1 - math.ceil(math.log(tb, 2))))
+            bits[n] = out
+        self.threshold_bins = thr
+        return bits

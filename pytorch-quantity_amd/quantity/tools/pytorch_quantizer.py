@@ -464,6 +464,46 @@ class Quantity(object):
             self.timings["pass1_step_ms"] = step_ms
         return bits
 
+    def activation_quantize_per_channel(self, images_files, table_file=None):
+        """EXTENSION (no reference counterpart): the same two-pass calibration with one histogram row per
+        (cared tensor, channel) instead of one per tensor.  Returns {module name: [bit per channel]} and
+        writes "<module name> b0 b1 ... b(C-1)" lines to ./workdir/feat_channel.table.  No merge-group
+        pooling is applied (the reference defines it for per-tensor scales only); 'image' is included."""
+        from common.quantity.channel_collector import ChannelCollector
+        rank, _world = _dist_state()
+        names = ["image"] + list(self.net_info.keys())
+        named_feats, hooks = self.regist_hook_outfeature(self.model)
+        collector = None
+        for _pass in (1, 2):
+            for i, item in self._device_items(images_files):
+                self.net_forward(self.model, item)
+                if collector is None:
+                    collector = ChannelCollector({n: int(named_feats[n].shape[1]) for n in names},
+                                                 statistic=self.config["SETTINGS"]["STATISTIC"])
+                if _pass == 1:
+                    collector.refresh_max_val(named_feats)
+                else:
+                    collector.add_to_distributions(named_feats)
+            if _dist_on():
+                collector.all_reduce_max() if _pass == 1 else collector.all_reduce_hist()
+            if _pass == 1:
+                collector.intervals()
+        bits = collector.quantize()
+        for h in hooks:
+            h.remove()
+        named_feats.clear()
+        by_module = OrderedDict()
+        by_module["image"] = bits["image"]
+        for i, feat_name in enumerate(names[1:]):
+            by_module[self.cared_op_layer_names[i]] = bits[feat_name]
+        if rank == 0:
+            path = table_file or os.path.join(self.config["OUTPUT"]["WORK_DIR"], "feat_channel.table")
+            with open(path, "w") as fh:
+                for module, b in by_module.items():
+                    fh.write(module + " " + " ".join(str(v) for v in b) + "\n")
+        self._channel_collector = collector
+        return by_module
+
     def regist_hook_outfeature(self, model):
         """Forward hooks that expose, after each forward, an ordered dict 'image' + one entry per
         cared node ("<ClassName>_<ordinal>", same keys as net_info) holding the DEVICE tensors.

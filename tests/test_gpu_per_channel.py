@@ -1,0 +1,72 @@
+"""Per-channel calibration extension: rows = (tensor, channel).  Same kernels, same per-row arithmetic;
+checked against the CPU oracle channel by channel on the activations the GPU produced.  pytest -m gpu"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from workdir_util import product_workdir
+
+pytestmark = pytest.mark.gpu
+
+
+def test_channel_collector_vs_oracle(oracle):
+    from common.quantity.channel_collector import ChannelCollector
+    rng = np.random.default_rng(5)
+    feats = [{"a": torch.from_numpy(rng.standard_normal((3, 5, 7, 6), dtype=np.float32) * np.float32(b + 1)).cuda(),
+              "b": torch.from_numpy(np.maximum(rng.standard_normal((3, 4), dtype=np.float32), 0)).cuda()}
+             for b in range(2)]
+    coll = ChannelCollector({"a": 5, "b": 4})
+    for f in feats:
+        coll.refresh_max_val(f)
+    iv = coll.intervals()
+    for f in feats:
+        coll.add_to_distributions(f)
+    bits = coll.quantize()
+    mx = coll.max_device.cpu().numpy()
+    hist = coll.hist_device.cpu().numpy()
+    for name, C in (("a", 5), ("b", 4)):
+        lo, hi = coll.row_range(name)
+        for c in range(C):
+            ref_m = np.float32(0)
+            for f in feats:
+                ref_m = oracle.absmax(f[name][:, c].cpu().numpy(), ref_m)
+            assert mx[lo + c] == ref_m
+            ref_iv = oracle.interval(ref_m)
+            assert iv[lo + c] == ref_iv
+            ref_h = np.zeros(2048, dtype=np.int64)
+            for f in feats:
+                oracle.hist2048(f[name][:, c].cpu().numpy(), ref_iv, ref_h)
+            np.testing.assert_array_equal(hist[lo + c], ref_h)
+            t = oracle.kl_threshold(oracle.normalize(ref_h))
+            assert coll.threshold_bins[lo + c] == t
+            assert bits[name][c] == oracle.bits_from_threshold(t, ref_iv)[0]
+
+
+def test_per_channel_calibration_of_a_model():
+    """Orchestrator level: per-channel table of the Concat net; pooling all channels of a tensor gives
+    back the per-tensor maxima and histogram mass of the reference-compatible path."""
+    from tools import Quantity
+    with product_workdir(input_shape="1,3,8,8", device="gpu", max_cali_img_num=2) as tmp:
+        model = cases.seed_model(cases.tiny_concat_net(), base_seed=7).eval().cuda()
+        q = Quantity(model)
+        batches = cases.calib_batches(4, (4, 3, 8, 8), seed=4321)
+        per_tensor_bits = q.activation_quantize(batches)
+        t_max = {n: float(v) for n, v in q._collector.max_vals.items()}
+        t_mass = {n: int(v.sum()) for n, v in q._collector.distributions.items()}
+        by_module = q.activation_quantize_per_channel(batches)
+        cc = q._channel_collector
+        names = ["image"] + list(q.net_info.keys())
+        for n in names:
+            lo, hi = cc.row_range(n)
+            assert float(cc.max_device[lo:hi].max()) == t_max[n]
+            assert int(cc.hist_device[lo:hi].sum()) == t_mass[n]
+        table = open(os.path.join(tmp, "test", "workdir", "feat_channel.table")).read().strip().split("\n")
+        assert len(table) == len(names) and table[0].startswith("image ")
+        assert [len(v) for v in by_module.values()] == [3, 8, 8, 8, 16, 8, 8, 8, 5]
+        # a channel never needs fewer fractional bits than its whole tensor's range allows
+        for (module, b), n in zip(by_module.items(), names):
+            assert min(b) >= per_tensor_bits[n] - 1, (module, b, per_tensor_bits[n])
