@@ -126,11 +126,13 @@ class DistributionCollector(object):
         RCCL over xGMI when the process group is 'nccl')."""
         import torch.distributed as dist
         dist.all_reduce(self._max_dev, op=dist.ReduceOp.MAX)
+        self._max_vals_refreshed_flag = True        # a rank that owned no batch still holds the global maxima
 
     def all_reduce_hist(self):
         """Combine the per-rank histograms: one SUM all-reduce of the flat int64[T*2048] buffer."""
         import torch.distributed as dist
         dist.all_reduce(self._hist_dev, op=dist.ReduceOp.SUM)
+        self._added_to_distributions_flag = True
 
     def merged_distributions(self, groups):
         """int64[T, 2048] device tensor in tensor_list order in which every group (a list of tensor

@@ -366,6 +366,16 @@ class Quantity(object):
         quantizer = self.quantizer_cls(top_feat_names, worker_num=settings["WORKER_NUM"], debug=False)
         named_feats, hooks = self.regist_hook_outfeature(self.model)
         self._collector, self._quantizer = collector, quantizer
+        try:
+            return self._calibrate(images_files, collector, quantizer, named_feats, merge_groups, top_feat_names,
+                                   table_file)
+        finally:
+            for h in hooks:                 # (the reference never removes its hooks)
+                h.remove()
+            named_feats.clear()
+
+    def _calibrate(self, images_files, collector, quantizer, named_feats, merge_groups, top_feat_names, table_file):
+        rank, world = _dist_state()
         t0 = time.perf_counter()
 
         # pass 1: running abs-max of every cared tensor; keep the activations while HBM allows
@@ -455,9 +465,6 @@ class Quantity(object):
             with open(table_file, "w") as fh:
                 for line in lines:
                     fh.write(line + "\n")
-        for h in hooks:
-            h.remove()
-        named_feats.clear()
         self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0,
                         "cached_batches": len(cached_ids), "cache_bytes": used}
         if step_ms:

@@ -69,11 +69,13 @@ class OracleCollector(object):
         import torch.distributed as dist
         t = torch.from_numpy(self._max)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        self._refreshed = True
 
     def all_reduce_hist(self):
         import torch.distributed as dist
         t = torch.from_numpy(self._hist)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        self._added = True
 
     def merged_distributions(self, groups):
         merged = self._hist.copy()

@@ -34,7 +34,7 @@ WORKER = textwrap.dedent('''
         dist.init_process_group("gloo")
     rank = dist.get_rank() if world > 1 else 0
     torch.set_num_threads(2)
-    with product_workdir(device="cpu", max_cali_img_num=3) as tmp:
+    with product_workdir(device="cpu", max_cali_img_num=int(os.environ.get("FQ_TEST_MAX_CALI", "3"))) as tmp:
         model = merge_bn(cases.seed_model(ResNet18()).eval())
         q = CpuQuantity(model)
         bits = q.activation_quantize(cases.calib_batches(5, (2, 3, 32, 32)))
@@ -49,11 +49,11 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def _run(world, out):
+def _run(world, out, max_cali=3):
     script = os.path.join(tempfile.mkdtemp(prefix="fq_dist_"), "worker.py")
     with open(script, "w") as fh:
         fh.write(WORKER.format(root=ROOT, out=out))
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", FQ_TEST_MAX_CALI=str(max_cali))
     if world == 1:
         cmd = [sys.executable, script]
     else:
@@ -74,3 +74,13 @@ def test_two_rank_gloo_calibration_is_shard_count_invariant(tmp_path):
     assert one["table"].startswith("image ")
     # 4 batches of 2 images were used (MAX_CALI_IMG_NUM = 3 -> batches 0..3): every histogram saw them all
     assert one["hist_sums"]["image"] == 4 * 2 * 3 * 32 * 32
+
+
+@pytest.mark.timeout(1800)
+def test_rank_without_batches_still_gets_global_statistics(tmp_path):
+    """One calibration batch, two ranks: rank 1 owns nothing, yet after the all-reduces every rank holds
+    the global maxima / histograms and the table equals the single-process one."""
+    one = _run(1, str(tmp_path / "w1.json"), max_cali=0)
+    two = _run(2, str(tmp_path / "w2.json"), max_cali=0)
+    assert one["table"] == two["table"]
+    assert one["hist_sums"] == two["hist_sums"] and one["hist_sums"]["image"] == 2 * 3 * 32 * 32
