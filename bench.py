@@ -192,7 +192,7 @@ def cpu_baseline(model_cpu_ctor, sample_images, hw, n_images_full, q, log):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)      # 40 x 128 = 5 120 images: BASELINE configs[1] ("5k")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--model", default="r50", choices=["r50", "r101"])

@@ -15,11 +15,11 @@ MI355X design (what is different underneath):
     tensor to the host and forks a process pool per batch);
   * graph edges come from tensor identity during one traced forward (value fingerprints, the
     reference's `tid`, are only the fallback), so all-positive inputs to ReLU etc. need no special case;
-  * pass 2 re-uses the activations of pass 1 wherever HBM allows: the bin width needs the global
-    maximum first, so the reference runs every image through the network twice; an MI355X has
-    288 GB, so the cared activations of pass-1 batches are simply kept alive (67 MB per image for
-    ResNet-50) up to a budget (FQ_ACT_CACHE_GB, default 60 % of the free HBM) and histogrammed
-    without a second forward.  Same tensors, same integers; batches beyond the budget are recomputed;
+  * pass 2 re-uses activations of pass 1 wherever HBM allows: the bin width needs the global maximum
+    first, so the reference runs every image through the network twice; an MI355X has 288 GB, so
+    pass 1 keeps cared activations alive within a budget (FQ_ACT_CACHE_GB) -- either whole batches, or
+    (usually better) the deepest suffix of EVERY batch, in which case the second forward stops at
+    the last tensor that was not kept (_plan_cache).  Same tensors, same integers;
   * data-parallel calibration: when torch.distributed is initialised the calibration batches are
     dealt round-robin to the ranks (one process per GPU) and the per-tensor maxima / histograms
     are combined with one MAX and one SUM all-reduce (RCCL over xGMI); integer sums and maxima are
@@ -55,6 +55,11 @@ def _dist_state():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+class _StopForward(Exception):
+    """Raised by the feature hook to end a forward pass early (pass 2 only needs a prefix of the net
+    when the deeper activations were kept from pass 1)."""
 
 
 def _dist_on():
@@ -225,7 +230,10 @@ class Quantity(object):
         if self.device == "gpu" and img.device.type != "cuda":
             img = img.cuda(non_blocking=True)
         with torch.no_grad():
-            net(img)
+            try:
+                net(img)
+            except _StopForward:
+                pass
 
     def _device_items(self, images_files):
         """(index, network input) for this rank's calibration items.  Host-resident batches are copied
@@ -311,6 +319,46 @@ class Quantity(object):
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
 
+    @staticmethod
+    def _ordinal(name):
+        return 0 if name == "image" else int(name.rsplit("_", 1)[1])
+
+    def _plan_cache(self, budget, n_owned, feats, cum_ms):
+        """Decide what pass 1 keeps for pass 2 inside `budget` bytes of HBM.
+
+        plan A  keep ALL cared activations of the first m batches; the other batches are recomputed in full.
+        plan B  keep, for EVERY batch, the deepest suffix of cared activations that fits; pass 2 re-runs
+                only the prefix of the network up to the last tensor that was not kept (the hook ends the
+                forward there).  Early layers hold most of the bytes, late layers most of the depth, so
+                a small cache removes a large part of the second forward for every image.
+        The cheaper one by the measured time stamps of the first forward wins.  Either way pass 2
+        histograms exactly the tensors pass 1 took the maxima of, or fresh ones from the same weights."""
+        sizes = [(n, self._ordinal(n), t.numel() * t.element_size()) for n, t in feats.items()]
+        per_batch_all = sum(b for _n, _o, b in sizes)
+        t_full = max(cum_ms.values()) if cum_ms else 1.0
+        m = min(n_owned if n_owned is not None else 1 << 30, budget // max(per_batch_all, 1))
+        plan = {"kind": "A", "whole_batches": int(m), "keep": None, "stop_after": None}
+        if n_owned is None or n_owned == 0 or not cum_ms:
+            return plan
+        cost_a = (n_owned - min(m, n_owned)) * t_full
+        room = budget // n_owned
+        keep, used = [], 0
+        for n, o, b in sorted(sizes, key=lambda e: -e[1]):       # deepest first
+            if n == "image" or used + b > room:
+                break
+            keep.append(n)
+            used += b
+        if not keep:
+            return plan
+        early = [o for n, o, _b in sizes if n not in keep and n != "image"]
+        stop_after = max(early) if early else 0
+        cost_b = n_owned * (cum_ms.get(stop_after, 0.0) if stop_after else 0.0)
+        forced = os.environ.get("FQ_CACHE_PLAN", "")           # "A" / "B": testing and A/B timing
+        if (cost_b < cost_a and forced != "A") or forced == "B":
+            plan = {"kind": "B", "whole_batches": 0, "keep": set(keep), "stop_after": stop_after,
+                    "prefix_fraction": round((cum_ms.get(stop_after, 0.0) if stop_after else 0.0) / t_full, 3)}
+        return plan
+
     def _sync(self):
         if self.device == "gpu" and torch.cuda.is_available():
             torch.cuda.synchronize()
@@ -378,23 +426,45 @@ class Quantity(object):
         rank, world = _dist_state()
         t0 = time.perf_counter()
 
-        # pass 1: running abs-max of every cared tensor; keep the activations while HBM allows
+        # pass 1: running abs-max of every cared tensor; keep activations for pass 2 while HBM allows
         budget = self._activation_cache_budget()
-        cached, cached_ids, used = [], set(), 0
+        n_owned = None
+        if hasattr(images_files, "__len__") and hasattr(images_files, "__getitem__"):
+            n_owned = len(range(rank, min(len(images_files), self._max_img_num + 1), world))
+        ctl = self._hook_ctl
+        plan = None
+        cached, cached_ids, used = {}, set(), 0
         step_ms = []
         for i, item in self._device_items(images_files):
             ts = time.perf_counter()
+            if budget and plan is None and self.device == "gpu" and torch.cuda.is_available():
+                start = torch.cuda.Event(enable_timing=True)
+                start.record()
+                ctl["events"] = []
             self.net_forward(self.model, item)
             self._on_stat_stream(collector.refresh_max_val, named_feats)
             if os.environ.get("FQ_DEBUG_STEP_TIMES"):
                 self._sync()
                 step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
-            if budget:
-                need = sum(t.numel() * t.element_size() for t in named_feats.values())
-                if used + need <= budget:
-                    cached.append(dict(named_feats))
+            if not budget:
+                continue
+            if plan is None:
+                cum_ms = {}
+                if ctl["events"]:
+                    self._sync()
+                    cum_ms = {o: start.elapsed_time(ev) for o, ev in ctl["events"]}
+                ctl["events"] = None
+                plan = self._plan_cache(budget, n_owned, named_feats, cum_ms)
+            need_all = sum(t.numel() * t.element_size() for t in named_feats.values())
+            if plan["kind"] == "A":
+                if len(cached) < plan["whole_batches"] and used + need_all <= budget:
+                    cached[i] = dict(named_feats)
                     cached_ids.add(i)
-                    used += need
+                    used += need_all
+            else:
+                kept = {n: t for n, t in named_feats.items() if n in plan["keep"]}
+                cached[i] = kept
+                used += sum(t.numel() * t.element_size() for t in kept.values())
         self._join_stat_stream()
         if _dist_on():                      # also at world size 1: same code path, trivial cost
             collector.all_reduce_max()
@@ -415,11 +485,27 @@ class Quantity(object):
 
         # pass 2: histograms with the final intervals
         print("Collect histograms of activations:")
-        for feats in cached:
-            self._on_stat_stream(collector.add_to_distributions, feats)
-        for i, item in self._device_items(self._skip(images_files, cached_ids)):
-            self.net_forward(self.model, item)
-            self._on_stat_stream(collector.add_to_distributions, named_feats)
+        if plan is not None and plan["kind"] == "B":
+            ctl["stop_after"] = plan["stop_after"] if plan["stop_after"] else None
+            try:
+                for i, item in self._device_items(images_files):
+                    if plan["stop_after"]:
+                        self.net_forward(self.model, item)              # ends at the last tensor that was not kept
+                        feats = dict(named_feats)
+                    else:
+                        feats = {"image": self.preprocess(item) if not torch.is_tensor(item) else item}
+                        if self.device == "gpu" and feats["image"].device.type != "cuda":
+                            feats["image"] = feats["image"].cuda()
+                    feats.update(cached.pop(i))
+                    self._on_stat_stream(collector.add_to_distributions, feats)
+            finally:
+                ctl["stop_after"] = None
+        else:
+            for i in sorted(cached):
+                self._on_stat_stream(collector.add_to_distributions, cached[i])
+            for i, item in self._device_items(self._skip(images_files, cached_ids)):
+                self.net_forward(self.model, item)
+                self._on_stat_stream(collector.add_to_distributions, named_feats)
         self._join_stat_stream()
         del cached
         if _dist_on():
@@ -466,7 +552,9 @@ class Quantity(object):
                 for line in lines:
                     fh.write(line + "\n")
         self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0,
-                        "cached_batches": len(cached_ids), "cache_bytes": used}
+                        "cached_batches": len(cached_ids), "cache_bytes": used,
+                        "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
+                                       if k != "keep"} if plan else None}
         if step_ms:
             self.timings["pass1_step_ms"] = step_ms
         return bits
@@ -520,6 +608,7 @@ class Quantity(object):
         cared = set(self.net_info.keys())
         state = {"n": 0}
         total = int(self.layers_num)
+        ctl = self._hook_ctl = {"stop_after": None, "events": None}
 
         def on_forward(module, inputs, output):
             if state["n"] == 0:
@@ -529,8 +618,15 @@ class Quantity(object):
             key = "%s_%i" % (type(module).__name__, state["n"])
             if key in cared:
                 out_feat[key] = output.detach()
+                if ctl["events"] is not None:                 # time stamps of one forward, for the cache plan
+                    ev = torch.cuda.Event(enable_timing=True)
+                    ev.record()
+                    ctl["events"].append((state["n"], ev))
             if state["n"] >= total:
                 state["n"] = 0
+            elif ctl["stop_after"] is not None and state["n"] >= ctl["stop_after"]:
+                state["n"] = 0
+                raise _StopForward()
 
         for m in model.modules():
             if type(m).__name__ in self._all_op_type:

@@ -177,3 +177,23 @@ def test_recontest_logits_match_reference(golden_dir, g3):
         assert same >= 0.99, same
         assert np.max(np.abs(first - g4["recontest_conv1_out"])) <= 2.0 ** -3 + 1e-6     # conv1.0 output_bit = 3
         assert np.max(np.abs(logits - g4["logits_recontest"])) <= 2.0
+
+
+@pytest.mark.parametrize("cache_gb,plan", [("0", ""), ("0.02", "A"), ("0.012", "B"), ("1", "B"), ("1", "A")])
+def test_activation_cache_plans_do_not_change_the_tables(g3, monkeypatch, cache_gb, plan):
+    """Pass 2 may histogram activations kept from pass 1 (whole batches, plan A; or the deepest suffix of
+    every batch with a truncated second forward, plan B) instead of recomputing them: the tables must not
+    depend on which plan ran."""
+    from tools import Quantity
+    monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
+    monkeypatch.setenv("FQ_CACHE_PLAN", plan)
+    with product_workdir(device="gpu", max_cali_img_num=1) as tmp:
+        q = Quantity(_r18_gpu())
+        q.activation_quantize(cases.calib_batches(3, (4, 3, 32, 32)))
+        table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
+        info = q.timings
+    assert table == g3["feat_table"]
+    if cache_gb == "0":
+        assert info["cache_bytes"] == 0
+    elif plan:
+        assert info["cache_plan"]["kind"] == plan and info["cache_bytes"] > 0
