@@ -83,12 +83,14 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     constexpr int MT = TK / 32;           // 32-row MFMA tiles per wave along k_out
     constexpr int A_LOADS = TK / 32;      // 16-byte chunks per thread per K-step for the weight tile
     __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * BKB];
+    __shared__ float sBias[TK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;
     const int m0 = blockIdx.x * kTP;
     const int k0 = blockIdx.y * TK;
     const int PQ = p.P * p.Q;
+    if (tid < TK) sBias[tid] = (k0 + tid < p.K) ? qbias[k0 + tid] : 0.0f;    // visible after the first barrier
 
     // this lane's output pixel
     const int m = m0 + wave * 32 + (lane & 31);
@@ -116,23 +118,25 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
 
     v4i ra[A_LOADS], rb[4];
     auto load_step = [&]() {
+        // branch-free: an out-of-range chunk reads a valid dummy address and is zeroed by a select,
+        // so all loads of a step issue back to back
         const bool a_live = ga < p.chunks;
+        const v4i zero = {0, 0, 0, 0};
 #pragma unroll
         for (int j = 0; j < A_LOADS; ++j) {
             const int k = k0 + ld_row + 32 * j;
-            v4i v = {0, 0, 0, 0};
-            if (a_live && k < p.K) v = *reinterpret_cast<const v4i*>(w + (long)k * wrow_bytes + (long)ga * 16);
-            ra[j] = v;
+            const bool ok = a_live && k < p.K;
+            const v4i v = *reinterpret_cast<const v4i*>(ok ? w + (long)k * wrow_bytes + (long)ga * 16 : w);
+            ra[j] = ok ? v : zero;
         }
         ga += 8;
         RedPos q = pb;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int ih = ih0 + q.fr * p.dil_h, iw = iw0 + q.fs * p.dil_w;
-            v4i v = {0, 0, 0, 0};
-            if (gb + 2 * ks < p.chunks && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                v = *reinterpret_cast<const v4i*>(xin + ((long)ih * p.W + iw) * p.C + q.cc * 16);
-            rb[ks] = v;
+            const bool ok = gb + 2 * ks < p.chunks && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const v4i v = *reinterpret_cast<const v4i*>(ok ? xin + ((long)ih * p.W + iw) * p.C + q.cc * 16 : x);
+            rb[ks] = ok ? v : zero;
             red_advance(q, 2, p.c16, p.S);
         }
         pb = q;                                           // 4 x (+2) = +8: first chunk of the next K-step
@@ -188,8 +192,8 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int k = k0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (k < p.K) out[(long)k * PQ] = conv_tail(acc[a][r], qbias[k], p);
+                const int kl = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (k0 + kl < p.K) out[(long)(k0 + kl) * PQ] = conv_tail(acc[a][r], sBias[kl], p);
             }
         }
     }
