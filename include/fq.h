@@ -133,6 +133,16 @@ int fq_quantize_param_i32(const float* w, int32_t* q, size_t n, int bit, fq_stre
 int fq_quantize_i8_nhwc(const float* x_nchw, int8_t* y_nhwc, int N, int C, int HW, int Cpad, int ib,
                         fq_stream_t stream);
 
+/* Stem variant of fq_quantize_i8_nhwc for C <= 4 inputs (e.g. 7x7 stride-2 on RGB): the kernel WIDTH is
+ * folded into the channel axis,
+ *   y[n][ih][q][s*C + c] = Quantity(x[n][c][ih][q*stride_w - pad_w + s*dil_w])   (0 outside the image
+ *   and for folded channels >= S*C),   Q = (W + 2*pad_w - dil_w*(S-1) - 1)/stride_w + 1,
+ * y: int8 [N][H][Q][Cpad2], Cpad2 >= S*C, Cpad2 % 16 == 0.  fq_conv2d_i8 is then called on y with
+ * W := Q, C := Cpad2, S := 1, stride_w := 1, pad_w := 0, dil_w := 1 and weights folded the same way
+ * ([K][R][1][Cpad2]): same integers, R*Cpad2 reduction bytes instead of R*S*16. */
+int fq_quantize_i8_unfold_w(const float* x_nchw, int8_t* y, int N, int C, int H, int W, int S,
+                            int stride_w, int pad_w, int dil_w, int Cpad2, int ib, fq_stream_t stream);
+
 /* NewConv2d.forward / NewLinear.forward after Quantity (new_quantity_op.py:126-132, :199-204):
  *   acc[n][k][p][q] = sum_{r,s,c} w[k][r][s][c] * x[n][p*stride-pad+r*dil][q*stride-pad+s*dil][c]   (int32, exact)
  *   y = clamp( RightShift(acc, rs) + qbias[k] ) / 2^ob                                    (fp32 NCHW)

@@ -200,35 +200,111 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
 }
 
 // ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
-// block = (64 hw) x (64 c) tile of one image, transposed through LDS.
+__device__ __forceinline__ unsigned q8(float v, float scale) {
+    float q = rintf(v * scale);
+    q = q < -128.0f ? -128.0f : (q > 127.0f ? 127.0f : q);          // NaN stays NaN; the cast gives 0
+    return (unsigned)(uint8_t)(int8_t)(int)q;
+}
+
+// block = (64 hw) x (64 c) tile of one image.  Each thread loads a 4(c) x 4(hw) patch with four
+// 16-byte loads along hw, quantises, and writes the patch transposed (4 dwords of 4 channels) into an
+// LDS tile [hw][c]; the tile is then read back 16 channels at a time and stored with 16-byte stores.
+// kVec = false: scalar loads for planes whose rows are not 16-byte aligned (HW % 4 != 0).
+template <bool kVec>
 __global__ __launch_bounds__(256) void quantize_i8_nhwc_kernel(const float* __restrict__ x, int8_t* __restrict__ y, int C, int HW,
                                                                int Cpad, float scale) {
-    __shared__ int8_t tile[64][68];                      // [c][hw], padded rows
+    constexpr int RS = 17;                                // LDS row stride in dwords (64 c bytes + 4 pad)
+    __shared__ unsigned tile[64 * RS];                    // [hw][c / 4]
     const int n = blockIdx.z, hw0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
     const float* __restrict__ src = x + (long)n * C * HW;
-    // load: 64 hw (fast) x 4 channels per pass
-    const int j = tid & 63;
-#pragma unroll 4
-    for (int ci = tid >> 6; ci < 64; ci += 4) {
-        const int c = c0 + ci, hw = hw0 + j;
-        float v = 0.0f;
-        if (c < C && hw < HW) v = src[(long)c * HW + hw];
-        float q = rintf(v * scale);
-        q = q < -128.0f ? -128.0f : (q > 127.0f ? 127.0f : q);   // NaN -> stays NaN -> cast gives 0
-        tile[ci][j] = (int8_t)(int)q;
+    const int hwg = tid & 15, cg = tid >> 4;              // 16 hw groups of 4, 16 channel groups of 4
+    const int hw = hw0 + 4 * hwg;
+    float v[4][4];                                        // [channel i][hw e]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + 4 * cg + i;
+        const bool c_ok = c < C;
+        if (kVec) {
+            const bool ok = c_ok && hw < HW;              // HW % 4 == 0: a group is all in or all out
+            const float4 f = *reinterpret_cast<const float4*>(ok ? src + (long)c * HW + hw : src);
+            v[i][0] = ok ? f.x : 0.0f; v[i][1] = ok ? f.y : 0.0f; v[i][2] = ok ? f.z : 0.0f; v[i][3] = ok ? f.w : 0.0f;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = (c_ok && hw + e < HW) ? src[(long)c * HW + hw + e] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const unsigned packed = q8(v[0][e], scale) | (q8(v[1][e], scale) << 8) | (q8(v[2][e], scale) << 16) |
+                                (q8(v[3][e], scale) << 24);
+        tile[(4 * hwg + e) * RS + cg] = packed;
     }
     __syncthreads();
-    // store: 16 threads x 4 bytes = 64 channels of one hw position
-    int8_t* __restrict__ dst = y + (long)n * HW * Cpad;
-    const int c4 = (tid & 15) * 4;
-#pragma unroll 4
-    for (int jj = tid >> 4; jj < 64; jj += 16) {
-        const int hw = hw0 + jj, c = c0 + c4;
-        if (hw < HW && c < Cpad) {
-            const unsigned packed = (unsigned)(uint8_t)tile[c4][jj] | ((unsigned)(uint8_t)tile[c4 + 1][jj] << 8) |
-                                    ((unsigned)(uint8_t)tile[c4 + 2][jj] << 16) | ((unsigned)(uint8_t)tile[c4 + 3][jj] << 24);
-            *reinterpret_cast<unsigned*>(dst + (long)hw * Cpad + c) = packed;
+    // store: thread -> (hw = tid >> 2, 16 channels = tid & 3)
+    const int shw = tid >> 2, cq = tid & 3;
+    const int ohw = hw0 + shw, oc = c0 + 16 * cq;
+    if (ohw < HW && oc < Cpad) {
+        const unsigned* row = &tile[shw * RS + 4 * cq];
+        int8_t* dst = y + ((long)n * HW + ohw) * Cpad + oc;
+        if (oc + 16 <= Cpad && (Cpad & 15) == 0) {
+            uint4 o; o.x = row[0]; o.y = row[1]; o.z = row[2]; o.w = row[3];
+            *reinterpret_cast<uint4*>(dst) = o;
+        } else {
+#pragma unroll
+            for (int d = 0; d < 4; ++d)
+                if (oc + 4 * d < Cpad) *reinterpret_cast<unsigned*>(dst + 4 * d) = row[d];
+        }
+    }
+}
+
+// C <= 4 (the image going into the stem convolution), Cpad == 16: one pixel per thread -- C coalesced
+// plane reads, one 16-byte store of [c0 c1 c2 c3 0 ... 0].
+__global__ __launch_bounds__(256) void quantize_i8_nhwc_smallc_kernel(const float* __restrict__ x, int8_t* __restrict__ y, int C,
+                                                                      int HW, long total_pixels, float scale) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < total_pixels; i += stride) {
+        const long n = i / HW;
+        const int hw = (int)(i - n * HW);
+        const float* __restrict__ src = x + n * C * HW + hw;
+        unsigned packed = 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) packed |= q8(src[(long)c * HW], scale) << (8 * c);
+        uint4 o; o.x = packed; o.y = 0; o.z = 0; o.w = 0;
+        *reinterpret_cast<uint4*>(y + i * 16) = o;
+    }
+}
+
+// Stem layers (C <= 4, e.g. 7x7 stride-2 on RGB): channel padding to 16 would waste 13/16 of every
+// MFMA.  Instead the kernel width is folded into the channel axis: y[n][ih][q][s*C + c] =
+// Quantity(x[n][c][ih][q*stride_w - pad_w + s*dil_w]) (zero outside the image / beyond S*C), Cpad2 bytes
+// per output column q.  The convolution then runs with S = 1, stride_w = 1, pad_w = 0 over width Q and
+// "channels" Cpad2: an R x 1 kernel with R * Cpad2 reduction bytes instead of R * S * 16.
+__global__ __launch_bounds__(256) void quantize_i8_unfold_w_kernel(const float* __restrict__ x, int8_t* __restrict__ y, int C, int H,
+                                                                   int W, int S, int stride_w, int pad_w, int dil_w, int Q,
+                                                                   int Cpad2, long total, float scale) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    for (; i < total; i += stride) {                      // i = (n*H + ih)*Q + q
+        const int q = (int)(i % Q);
+        const long nih = i / Q;
+        const int ih = (int)(nih % H);
+        const long n = nih / H;
+        const float* __restrict__ src = x + (n * C * H + ih) * (long)W;     // + c*H*W + iw
+        int8_t* dst = y + i * Cpad2;
+        const int iw0 = q * stride_w - pad_w;
+        for (int b0 = 0; b0 < Cpad2; b0 += 4) {           // one dword (4 folded channels) at a time
+            unsigned packed = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int f = b0 + e;                      // folded channel = s*C + c
+                const int s_ = f / C, c = f - s_ * C;
+                const int iw = iw0 + s_ * dil_w;
+                if (s_ < S && (unsigned)iw < (unsigned)W) packed |= q8(src[(long)c * H * W + iw], scale) << (8 * e);
+            }
+            *reinterpret_cast<unsigned*>(dst + b0) = packed;
         }
     }
 }
@@ -265,11 +341,38 @@ extern "C" int fq_quantize_i8_nhwc(const float* x_nchw, int8_t* y_nhwc, int N, i
         long g = (total + 255) / 256;
         if (g > kCUs * 16) g = kCUs * 16;
         hipLaunchKernelGGL(quantize_i8_rows_kernel, dim3((unsigned)g), dim3(256), 0, st, x_nchw, y_nhwc, C, Cpad, (long)N, scale);
+    } else if (C <= 4 && Cpad == 16 && (reinterpret_cast<uintptr_t>(y_nhwc) & 15u) == 0) {
+        const long total = (long)N * HW;
+        long g = (total + 255) / 256;
+        if (g > kCUs * 32) g = kCUs * 32;
+        hipLaunchKernelGGL(quantize_i8_nhwc_smallc_kernel, dim3((unsigned)g), dim3(256), 0, st, x_nchw, y_nhwc, C, HW, total, scale);
     } else {
         if (N > 65535) return FQ_ERR_UNSUPPORTED;
         dim3 grid((HW + 63) / 64, (Cpad + 63) / 64, N);
-        hipLaunchKernelGGL(quantize_i8_nhwc_kernel, grid, dim3(256), 0, st, x_nchw, y_nhwc, C, HW, Cpad, scale);
+        const bool vec = (HW % 4 == 0) && ((reinterpret_cast<uintptr_t>(x_nchw) & 15u) == 0);
+        if (vec)
+            hipLaunchKernelGGL(quantize_i8_nhwc_kernel<true>, grid, dim3(256), 0, st, x_nchw, y_nhwc, C, HW, Cpad, scale);
+        else
+            hipLaunchKernelGGL(quantize_i8_nhwc_kernel<false>, grid, dim3(256), 0, st, x_nchw, y_nhwc, C, HW, Cpad, scale);
     }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_quantize_i8_unfold_w(const float* x_nchw, int8_t* y, int N, int C, int H, int W, int S, int stride_w,
+                                       int pad_w, int dil_w, int Cpad2, int ib, fq_stream_t stream) {
+    if (N < 0 || C <= 0 || H <= 0 || W <= 0 || S <= 0 || stride_w <= 0 || pad_w < 0 || dil_w <= 0 || ib < -120 || ib > 120)
+        return FQ_ERR_INVALID_ARG;
+    if (Cpad2 < S * C || (Cpad2 & 15)) return FQ_ERR_INVALID_ARG;
+    const int Q = (W + 2 * pad_w - dil_w * (S - 1) - 1) / stride_w + 1;
+    if (Q <= 0) return FQ_ERR_INVALID_ARG;
+    if (N == 0) return FQ_OK;
+    if (!x_nchw || !y || (reinterpret_cast<uintptr_t>(y) & 15u)) return FQ_ERR_INVALID_ARG;
+    const long total = (long)N * H * Q;
+    long g = (total + 255) / 256;
+    if (g > kCUs * 32) g = kCUs * 32;
+    hipLaunchKernelGGL(quantize_i8_unfold_w_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x_nchw, y, C, H, W, S,
+                       stride_w, pad_w, dil_w, Q, Cpad2, total, ldexpf(1.0f, ib));
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }

@@ -71,6 +71,8 @@ def lib():
     L.fq_quantize_param_i32.argtypes = [vp, vp, sz, ci, vp]
     L.fq_quantize_i8_nhwc.restype = ci
     L.fq_quantize_i8_nhwc.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp]
+    L.fq_quantize_i8_unfold_w.restype = ci
+    L.fq_quantize_i8_unfold_w.argtypes = [vp, vp] + [ci] * 10 + [vp]
     L.fq_conv2d_i8.restype = ci
     L.fq_conv2d_i8.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_json_dump_i32.restype = ci
@@ -314,3 +316,24 @@ def conv2d_i8(xq, wq, qbias, stride, padding, dilation, rs, ob, bitwidth=8):
                               stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], int(rs), int(ob),
                               int(bitwidth), _stream(xq)), "fq_conv2d_i8")
     return y.view(N, K) if linear else y
+
+
+def quantize_i8_unfold_w(x, ib, S, stride_w, pad_w, dil_w, cpad2):
+    """Stem input: fp32 [N, C<=4, H, W] -> int8 [N, H, Q, cpad2] with the kernel width folded into the
+    channel axis (folded channel = s*C + c).  See fq_quantize_i8_unfold_w in include/fq.h."""
+    _need_cuda(x, torch.float32, "fq_quantize_i8_unfold_w")
+    xc = x.contiguous()
+    N, C, H, W = xc.shape
+    Q = (W + 2 * pad_w - dil_w * (S - 1) - 1) // stride_w + 1
+    y = torch.empty(N, H, Q, cpad2, dtype=torch.int8, device=x.device)
+    _check(lib().fq_quantize_i8_unfold_w(xc.data_ptr(), y.data_ptr(), N, C, H, W, int(S), int(stride_w), int(pad_w),
+                                         int(dil_w), int(cpad2), int(ib), _stream(xc)), "fq_quantize_i8_unfold_w")
+    return y
+
+
+def pack_weight_unfold_w(w, cpad2):
+    """Integer-valued fp32 weights [K, C, R, S] -> int8 [K, R, 1, cpad2] with folded channel s*C + c."""
+    K, C, R, S = w.shape
+    out = torch.zeros(K, R, 1, cpad2, dtype=torch.int8, device=w.device)
+    out[:, :, 0, :S * C] = w.permute(0, 2, 3, 1).reshape(K, R, S * C).to(torch.int8)
+    return out.contiguous()

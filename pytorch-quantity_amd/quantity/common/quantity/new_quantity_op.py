@@ -151,11 +151,20 @@ class _IntegerSimLayer(nn.Module):
             return layer.groups == 1 and layer.padding_mode == "zeros" and not isinstance(layer.padding, str)
         return isinstance(layer, nn.Linear)
 
+    @staticmethod
+    def _stem_fold(layer):
+        """Cpad2 if the conv is a stem-like layer (<= 4 input channels, kernel wider than 1) whose width
+        is better folded into the channel axis, else 0."""
+        if isinstance(layer, nn.Conv2d) and layer.in_channels <= 4 and layer.kernel_size[1] > 1:
+            return _native.pad16(layer.kernel_size[1] * layer.in_channels)
+        return 0
+
     def _packed_weight(self, layer):
         w = layer.weight
         cached = getattr(self, "_w_i8", None)
         if cached is None or cached[0] != (w.data_ptr(), w._version, str(w.device)):
-            packed = _native.pack_weight_krsc(w.detach())
+            fold = self._stem_fold(layer)
+            packed = _native.pack_weight_unfold_w(w.detach(), fold) if fold else _native.pack_weight_krsc(w.detach())
             object.__setattr__(self, "_w_i8", ((w.data_ptr(), w._version, str(w.device)), packed))
             cached = self._w_i8
         return cached[1]
@@ -206,6 +215,11 @@ class NewConv2d(_IntegerSimLayer):
         conv = self.Conv
         if self._int8_ok(conv):
             wq = self._packed_weight(conv)
+            if self._stem_fold(conv):
+                xq = _native.quantize_i8_unfold_w(input, self.input_bit, conv.kernel_size[1], conv.stride[1],
+                                                  conv.padding[1], conv.dilation[1], wq.shape[-1])
+                return _native.conv2d_i8(xq, wq, self.quantized_bias, (conv.stride[0], 1), (conv.padding[0], 0),
+                                         (conv.dilation[0], 1), self.rs_bit, self.output_bit, 8)
             xq = _xq_cache.get(input, self.input_bit, wq.shape[-1])
             return _native.conv2d_i8(xq, wq, self.quantized_bias, conv.stride, conv.padding, conv.dilation,
                                      self.rs_bit, self.output_bit, 8)

@@ -106,3 +106,22 @@ def test_newconv2d_int8_path_equals_float_path(nat):
         ml.use_int8_mfma = False
         b = ml(x)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("C,H,W,K,R,S,st,pd,dl", [(3, 33, 31, 64, 7, 7, 2, 3, 1), (1, 28, 28, 6, 3, 3, 1, 1, 1), (4, 16, 20, 10, 5, 3, 1, 2, 2),
+                                                   (3, 224, 224, 64, 7, 7, 2, 3, 1)])
+def test_stem_unfold_path_vs_integer_oracle(nat, oracle, C, H, W, K, R, S, st, pd, dl):
+    """Kernel width folded into the channel axis (stem layers): same integers as the plain convolution."""
+    rng = np.random.default_rng(C * 100 + H)
+    N = 2
+    x = (rng.standard_normal((N, C, H, W), dtype=np.float32) * np.float32(3)).astype(np.float32)
+    wq = rng.integers(-128, 128, size=(K, C, R, S)).astype(np.int32)
+    qb = rng.integers(-128, 128, size=K).astype(np.float32)
+    ib = 4
+    xq_ref = oracle.quantity(x, ib).astype(np.int32)
+    acc = oracle.conv2d_int(xq_ref, wq, (st, st), (pd, pd), (dl, dl))
+    cpad2 = (S * C + 15) // 16 * 16
+    xq = nat.quantize_i8_unfold_w(_dev(x), ib, S, st, pd, dl, cpad2)
+    w_dev = nat.pack_weight_unfold_w(_dev(wq.astype(np.float32)), cpad2)
+    got = nat.conv2d_i8(xq, w_dev, _dev(qb), (st, 1), (pd, 0), (dl, 1), 9, 3).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.recon_epilogue(acc.astype(np.float32), qb, 9, 3))
