@@ -48,13 +48,14 @@ struct ConvParams {
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 // RightShift -> BiasAdd -> Sp -> DeQuantity on one accumulator (new_quantity_op.py:127-132)
+// The values are integers (never NaN), so the clamps are single v_med3 instructions; v == 0 may round
+// with either sign of 0.5 (both truncate to 0), so the half is attached with a sign copy.
 __device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& p) {
     const float v = (float)acc * p.inv_rs;
-    const float w = v + (v > 0.0f ? 0.5f : -0.5f);
-    int r = (int)w;
-    r = r < p.ilo ? p.ilo : (r > p.ihi ? p.ihi : r);
-    float o = (float)r + qb;
-    o = o < p.lo ? p.lo : (o > p.hi ? p.hi : o);
+    const float w = v + __builtin_copysignf(0.5f, v);
+    int r = (int)w;                                       // truncates toward zero, saturates
+    r = min(max(r, p.ilo), p.ihi);
+    const float o = __builtin_amdgcn_fmed3f((float)r + qb, p.lo, p.hi);
     return o * p.inv_ob;
 }
 
@@ -109,6 +110,9 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
     const long wrow_bytes = (long)p.chunks * 16;
     int ga = ld_chunk;                                   // this thread's weight chunk on the reduction axis
+    const int8_t* wrow[A_LOADS];                         // row bases: 64-bit once, 32-bit offsets per step
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) wrow[j] = w + (long)(k0 + ld_row + 32 * j) * wrow_bytes;
 
     // activation chunk of sub-step 0 for this lane: g = step*8 + half; sub-step ks adds 2*ks
     int gb = half;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
         for (int j = 0; j < A_LOADS; ++j) {
             const int k = k0 + ld_row + 32 * j;
             const bool ok = a_live && k < p.K;
-            const v4i v = *reinterpret_cast<const v4i*>(ok ? w + (long)k * wrow_bytes + (long)ga * 16 : w);
+            const v4i v = *reinterpret_cast<const v4i*>(ok ? wrow[j] + (unsigned)(ga * 16) : w);
             ra[j] = ok ? v : zero;
         }
         ga += 8;
@@ -135,7 +139,8 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
         for (int ks = 0; ks < 4; ++ks) {
             const int ih = ih0 + q.fr * p.dil_h, iw = iw0 + q.fs * p.dil_w;
             const bool ok = gb + 2 * ks < p.chunks && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const v4i v = *reinterpret_cast<const v4i*>(ok ? xin + ((long)ih * p.W + iw) * p.C + q.cc * 16 : x);
+            const unsigned off = ok ? (unsigned)((ih * p.W + iw) * p.C + q.cc * 16) : 0u;    // one image < 2^31 bytes
+            const v4i v = *reinterpret_cast<const v4i*>(xin + off);
             rb[ks] = ok ? v : zero;
             red_advance(q, 2, p.c16, p.S);
         }
@@ -187,13 +192,16 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     // epilogue: D row = k_out = (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel.  For a fixed
     // register the 32 lanes of a half-wave write 32 consecutive pixels of one channel (128 bytes).
     if (m_ok) {
-        float* __restrict__ out = y + (long)n_img * p.K * PQ + pq;
+        // one 64-bit base per lane; the 16*MT rows are 32-bit element offsets from it (a K-tile of one
+        // image spans at most TK*PQ floats, far below 2^31)
+        float* __restrict__ out = y + ((long)n_img * p.K + k0 + 4 * half) * PQ + pq;
+        const int kmax = p.K - k0 - 4 * half;             // rows of this lane that exist
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int kl = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (k0 + kl < p.K) out[(long)(k0 + kl) * PQ] = conv_tail(acc[a][r], sBias[kl], p);
+                const int kl = a * 32 + (r & 3) + 8 * (r >> 2);          // compile-time constant
+                if (kl < kmax) out[(unsigned)(kl * PQ)] = conv_tail(acc[a][r], sBias[kl + 4 * half], p);
             }
         }
     }
@@ -393,6 +401,8 @@ extern "C" int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const fl
     if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w_krsc)) & 15u) return FQ_ERR_INVALID_ARG;
     const long M = (long)N * P * Q;
     if (M > 0x7fffffffL || (long)R * S * C / 16 > 0x7fffffffL) return FQ_ERR_UNSUPPORTED;
+    if ((long)H * W * C > 0x7fffffffL || (long)R * S * C > 0x7fffffffL || (long)K * P * Q > 0x1fffffffL)
+        return FQ_ERR_UNSUPPORTED;                        // 32-bit per-image / per-row offsets inside the kernel
     ConvParams p;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.P = P; p.Q = Q;
     p.stride_h = stride_h; p.stride_w = stride_w; p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
