@@ -21,6 +21,8 @@
 // of one tap): the streamed operand never touches LDS.  Only the weight tile, shared by the four
 // waves, is staged global -> registers -> LDS (double buffered); its 128-byte rows are XOR-swizzled
 // (chunk ^= (row >> 1) & 7) so that ds_read_b128 fragment reads are bank-conflict free.
+#include <cstdlib>
+
 #include "fq_common.h"
 
 namespace fq {
@@ -43,6 +45,9 @@ struct ConvParams {
     int ilo, ihi;
 };
 
+// 16 zero bytes in device memory: out-of-image taps load from here instead of being zeroed by selects
+__device__ const v4i g_zero_page = {0, 0, 0, 0};
+
 // 128-byte LDS rows hold 8 16-byte chunks; chunk ^= (row >> 1) & 7 makes every ds_read_b128 lane
 // group ({0-3,12-15,20-27}, ...) touch 16 distinct 16-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
@@ -61,11 +66,18 @@ __device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& 
 
 // Position of a 16-byte chunk on the reduction axis: tap (r, s) and 16-channel group cc.
 struct RedPos { int cc, fs, fr; };
+// delta is 2 (chunks of one lane are two apart): at most two wraps (c16 == 1), done with selects so the
+// K loop carries no divergent branch.
 __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S) {
     q.cc += delta;
-    while (q.cc >= c16) {
-        q.cc -= c16;
-        if (++q.fs == S) { q.fs = 0; ++q.fr; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const bool wrap = q.cc >= c16;
+        q.cc -= wrap ? c16 : 0;
+        const int fs1 = q.fs + (wrap ? 1 : 0);
+        const bool row = fs1 == S;
+        q.fs = row ? 0 : fs1;
+        q.fr += row ? 1 : 0;
     }
 }
 
@@ -76,7 +88,10 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
 //     from the int8 NHWC tensor into the operand registers -- each byte is fetched once per workgroup;
 //   * weights (A operand) are shared by the 4 waves and staged through a double-buffered, XOR-swizzled
 //     LDS tile of TK rows x 128 bytes per K-step.
-template <int TK>
+// kC128: C % 128 == 0 and K % TK == 0 -- every K-step then lies inside one tap and every weight row /
+// chunk exists, so the per-step index arithmetic collapses to one tap update and pointer increments
+// (the general path spends ~260 VALU instructions per K-step on it, against 16 MFMAs).
+template <int TK, bool kC128>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                const float* __restrict__ qbias, float* __restrict__ y,
                                                                const ConvParams p) {
@@ -121,7 +136,32 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     { const int rs0 = gb / p.c16; pb.fr = rs0 / p.S; pb.fs = rs0 - pb.fr * p.S; }
 
     v4i ra[A_LOADS], rb[4];
+    // fast-path state: current tap (uniform), steps left inside it, per-lane byte offset of the tap
+    int tap_r = 0, tap_s = 0, c_step = 0;
+    const int steps_per_tap = p.C >> 7;
+    const int8_t* wp[A_LOADS];
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) wp[j] = wrow[j] + ld_chunk * 16;
     auto load_step = [&]() {
+        if (kC128) {
+#pragma unroll
+            for (int j = 0; j < A_LOADS; ++j) {
+                ra[j] = *reinterpret_cast<const v4i*>(wp[j]);
+                wp[j] += BKB;
+            }
+            const int ih = ih0 + tap_r * p.dil_h, iw = iw0 + tap_s * p.dil_w;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const int8_t* src = ok ? xin + (unsigned)((ih * p.W + iw) * p.C + c_step * BKB + half * 16)
+                                   : reinterpret_cast<const int8_t*>(&g_zero_page) - 0;
+            const unsigned hop = ok ? 32u : 0u;           // chunks of one lane are 2 apart = 32 bytes
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) rb[ks] = *reinterpret_cast<const v4i*>(src + ks * hop);
+            if (++c_step == steps_per_tap) {
+                c_step = 0;
+                if (++tap_s == p.S) { tap_s = 0; ++tap_r; }
+            }
+            return;
+        }
         // branch-free: an out-of-range chunk reads a valid dummy address and is zeroed by a select,
         // so all loads of a step issue back to back
         const bool a_live = ga < p.chunks;
@@ -161,6 +201,14 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][r] = 0;
 
+    // LDS byte offsets of this lane's A fragments: row = a*32 + (lane&31); the XOR term (row>>1)&7 does
+    // not depend on a (a*16 is a multiple of 8), so the swizzled chunk offset is shared by all tiles
+    int a_off[MT], swz_off[4];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) a_off[a] = (a * 32 + (lane & 31)) * BKB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) swz_off[ks] = ((ks * 2 + half) ^ (((lane & 31) >> 1) & 7)) * 16;
+
     const int nsteps = (p.chunks + 7) >> 3;
     load_step();
     store_a(0);
@@ -171,15 +219,23 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
         if (step + 1 < nsteps) load_step();              // next step's global loads fly under the MFMAs
+        // A fragments are read one sub-step ahead into their own registers: every fragment feeds a
+        // single MFMA (each wave owns all TK rows), so without this the ds_read latency sits between
+        // every pair of MFMAs
+        v4i fa[2][MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+            fa[0][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[0]]);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int chunk = ks * 2 + half;              // A and B fragments use the same k order
+            if (ks < 3) {
 #pragma unroll
-            for (int a = 0; a < MT; ++a) {
-                const int row = a * 32 + (lane & 31);
-                const v4i fa = *reinterpret_cast<const v4i*>(&sA[cur][row * BKB + swz(row, chunk) * 16]);
-                acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[ks], acc[a], 0, 0, 0);
+                for (int a = 0; a < MT; ++a)
+                    fa[(ks + 1) & 1][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[ks + 1]]);
             }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+                acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks], acc[a], 0, 0, 0);
         }
         if (step + 1 < nsteps) {
             store_a(cur ^ 1);                             // the other buffer was last read one barrier ago
@@ -415,11 +471,19 @@ extern "C" int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const fl
     // 64-row tiles when the output is narrow, or when 128-row tiles would not even give one workgroup per CU
     const long wg128 = (long)gx * ((K + 127) / 128);
     if (K <= 64 || wg128 < kCUs) {
-        hipLaunchKernelGGL(conv2d_i8_kernel<64>, dim3(gx, (K + 63) / 64), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
-                           y_nchw, p);
+        if (C % 128 == 0 && K % 64 == 0)
+            hipLaunchKernelGGL((conv2d_i8_kernel<64, true>), dim3(gx, K / 64), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
+                               y_nchw, p);
+        else
+            hipLaunchKernelGGL((conv2d_i8_kernel<64, false>), dim3(gx, (K + 63) / 64), dim3(kConvBlock), 0, st, x_nhwc, w_krsc,
+                               qbias, y_nchw, p);
     } else {
-        hipLaunchKernelGGL(conv2d_i8_kernel<128>, dim3(gx, (K + 127) / 128), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
-                           y_nchw, p);
+        if (C % 128 == 0 && K % 128 == 0)
+            hipLaunchKernelGGL((conv2d_i8_kernel<128, true>), dim3(gx, K / 128), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
+                               y_nchw, p);
+        else
+            hipLaunchKernelGGL((conv2d_i8_kernel<128, false>), dim3(gx, (K + 127) / 128), dim3(kConvBlock), 0, st, x_nhwc, w_krsc,
+                               qbias, y_nchw, p);
     }
     FQ_LAUNCH_CHECK();
     return FQ_OK;
