@@ -25,11 +25,10 @@ MI355X design (what is different underneath):
     are combined with one MAX and one SUM all-reduce (RCCL over xGMI); integer sums and maxima are
     order independent, so the tables are bit-identical for any number of GPUs.  Rank 0 writes files.
 """
-import json
 import math
 import os
 import time
-from collections import Counter, OrderedDict, defaultdict
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -37,7 +36,6 @@ import torch.nn as nn
 import yaml
 
 from common.quantity import DistributionCollector, Quantizer, walk_dirs, merge_bn, tid  # noqa: F401
-from common.quantity import _native
 from .rewriter import BiasReWriter
 from ._jsonio import dump_int_array
 

@@ -10,7 +10,6 @@ reference casts with astype(np.int8): 128 -> -128, 200 -> -56); that wrap is rep
 because the JSON bytes are the product's output contract.
 """
 import json
-import os
 import os.path as osp
 
 import numpy as np

@@ -9,7 +9,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 import cases
 from engine_doubles import OracleCollector, OracleQuantizer

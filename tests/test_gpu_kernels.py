@@ -1,6 +1,5 @@
 """Parity of the HIP kernels (through the C ABI, via common.quantity._native) against the CPU oracle
 and the committed golden vectors.  Needs a real MI355X:  pytest -m gpu"""
-import json
 import os
 
 import numpy as np

@@ -1,6 +1,5 @@
 """Per-channel calibration extension: rows = (tensor, channel).  Same kernels, same per-row arithmetic;
 checked against the CPU oracle channel by channel on the activations the GPU produced.  pytest -m gpu"""
-import math
 import os
 
 import numpy as np

@@ -10,7 +10,6 @@ import os
 
 import numpy as np
 import pytest
-import torch
 
 import cases
 from workdir_util import product_workdir

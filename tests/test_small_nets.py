@@ -6,7 +6,6 @@ import json
 import os
 
 import pytest
-import torch
 
 import cases
 from workdir_util import product_workdir
