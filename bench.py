@@ -18,6 +18,8 @@ The JSON line also carries
   cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded
                  sample on this box's host cores, scaled to the same workload (rank 0, N=1 only);
   int8_sim_images_per_s / fakequant_images_per_s : ReconModel / ReconTest forward throughput.
+  int8_sim_resident_images_per_s : the same ReconModel after common.quantity.resident.enable() (integer
+                     activations stay in HBM as int8/int16 NHWC between layers; identical logits).
 """
 import argparse
 import json
@@ -359,7 +361,17 @@ def main():
             result["fakequant_images_per_s"] = round(fwd_rate(rec.ReconTest(info, "./workdir/recontest.pth")), 1)
             rec2 = Reconstruction(build_model(args.model, HW, device))
             info2 = rec2.get_quantity_information()
-            result["int8_sim_images_per_s"] = round(fwd_rate(rec2.ReconModel(info2, "./workdir/recon.pth")), 1)
+            int8_net = rec2.ReconModel(info2, "./workdir/recon.pth")
+            result["int8_sim_images_per_s"] = round(fwd_rate(int8_net), 1)
+            # same model, same logits, activations kept as int8/int16 NHWC between the integer layers
+            from common.quantity import resident
+            with torch.no_grad():
+                logits_fp32_boundary = int8_net(batches[0])
+            plan = resident.enable(int8_net, batches[0])
+            with torch.no_grad():
+                same = bool(torch.equal(int8_net(batches[0]), logits_fp32_boundary))
+            result["int8_sim_resident_images_per_s"] = round(fwd_rate(int8_net), 1)
+            result["int8_sim_resident"] = {"bit_identical_logits": same, "plan": plan}
         except Exception as e:  # the headline number above stands on its own
             result["recon_error"] = repr(e)
 

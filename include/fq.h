@@ -156,6 +156,40 @@ int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias,
                  int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob, int bitwidth,
                  fq_stream_t stream);
 
+/* ---- resident integer activations (ReconModel without the fp32 module-boundary round trips) ------ */
+/* Between two integer layers the reference moves fp32 NCHW: DeQuantity (new_quantity_op.py:66-68), nn.ReLU,
+ * then the next layer's Quantity(ib) (:52-58) -- which recovers exactly the integer the previous tail held.
+ * These entry points keep that integer in HBM instead (int8 / int16 NHWC, channels padded to 16 with
+ * zeros); the values they stand for, q * 2^-g, are bit-identical to the reference's fp32 tensors. */
+
+/* fq_conv2d_i8 with selectable outputs:
+ *   y_nchw (may be NULL): fp32 [N][K][P][Q] as fq_conv2d_i8
+ *   q_nhwc (may be NULL): int8 [N][P][Q][Kpad], the integer BEFORE DeQuantity,
+ *                         clamp(RightShift(acc, rs) + qbias[k]) = Quantity(y, ib = ob); channels [K, Kpad) = 0;
+ *                         Kpad >= K, Kpad % 16 == 0, 16-byte aligned
+ *   relu != 0: a following nn.ReLU is fused into both outputs (max(., 0) commutes with the scale 2^-ob).
+ * bitwidth is 8.  At least one output must be given. */
+int fq_conv2d_i8_resident(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw,
+                          int8_t* q_nhwc, int Kpad, int relu, int N, int H, int W, int C, int K, int R,
+                          int S, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
+                          int rs, int ob, fq_stream_t stream);
+
+/* NewAdd.forward (new_quantity_op.py:171-174) on resident operands, with the nn.ReLU and the Quantity of
+ * the consumers fused.  x, y: int8 (x_bytes = 1) or int16 (x_bytes = 2) arrays of n elements in the same
+ * flat NHWC layout, standing for x * 2^-gx and y * 2^-gy.
+ *   s         = clamp(x * 2^-gx + y * 2^-gy, relu ? 0 : -128, 127)       (the reference's fp32 expression)
+ *   wide[i]   = (int16) (s * 2^g_wide),  g_wide = max(0, gx, gy) <= 8      exact: feeds the next residual add
+ *   narrow[i] = (int8) clamp(rint(s * 2^ib), -128, 127)                   = Quantity(ib) of the next conv
+ * wide / narrow may be NULL (not both).  n % 16 == 0, all pointers 16-byte aligned.
+ * FQ_ERR_UNSUPPORTED if the exact sum does not fit int16 (g_wide > 8): use the fp32 path there. */
+int fq_add_resident(const void* x, int x_bytes, int gx, const void* y, int y_bytes, int gy, int16_t* wide,
+                    int g_wide, int8_t* narrow, int ib, int relu, size_t n, fq_stream_t stream);
+
+/* Leaving the resident domain (DeQuantity, :66-68, fused with the layout change):
+ *   y[n][c][hw] = q[n][hw][c] * 2^-g,   q: int8 / int16 (q_bytes 1 / 2) NHWC [N][HW][Cpad], y: fp32 NCHW. */
+int fq_dequant_nhwc_to_nchw(const void* q_nhwc, int q_bytes, int g, float* y_nchw, int N, int C, int HW,
+                            int Cpad, fq_stream_t stream);
+
 /* ---- output files ------------------------------------------------------------------------------ */
 
 /* HOST helper: write an int32 array as nested JSON lists, byte-identical to Python's

@@ -41,8 +41,9 @@ struct ConvParams {
     int M;                               // N * P * Q
     int chunks;                          // R * S * C / 16   (16-byte units of the reduction axis)
     int c16;                             // C / 16
-    float inv_rs, inv_ob, lo, hi;        // 2^-rs, 2^-ob, clamp range
+    float inv_rs, inv_ob, lo, hi;        // 2^-rs, 2^-ob, clamp range (lo = 0 when a ReLU is fused)
     int ilo, ihi;
+    int Kpad;                            // channel stride of the int8 NHWC output (>= K, multiple of 16)
 };
 
 // 16 zero bytes in device memory: out-of-image taps load from here instead of being zeroed by selects
@@ -55,13 +56,17 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // RightShift -> BiasAdd -> Sp -> DeQuantity on one accumulator (new_quantity_op.py:127-132)
 // The values are integers (never NaN), so the clamps are single v_med3 instructions; v == 0 may round
 // with either sign of 0.5 (both truncate to 0), so the half is attached with a sign copy.
-__device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& p) {
+// Returns the saturated integer (as a float) that DeQuantity then scales by 2^-ob; that integer is
+// also exactly what the NEXT layer's Quantity(ib = ob) would recover from the fp32 value.
+__device__ __forceinline__ float conv_tail_int(int acc, float qb, const ConvParams& p) {
     const float v = (float)acc * p.inv_rs;
     const float w = v + __builtin_copysignf(0.5f, v);
     int r = (int)w;                                       // truncates toward zero, saturates
     r = min(max(r, p.ilo), p.ihi);
-    const float o = __builtin_amdgcn_fmed3f((float)r + qb, p.lo, p.hi);
-    return o * p.inv_ob;
+    return __builtin_amdgcn_fmed3f((float)r + qb, p.lo, p.hi);
+}
+__device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& p) {
+    return conv_tail_int(acc, qb, p) * p.inv_ob;
 }
 
 // Position of a 16-byte chunk on the reduction axis: tap (r, s) and 16-channel group cc.
@@ -91,10 +96,13 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
 // kC128: C % 128 == 0 and K % TK == 0 -- every K-step then lies inside one tap and every weight row /
 // chunk exists, so the per-step index arithmetic collapses to one tap update and pointer increments
 // (the general path spends ~260 VALU instructions per K-step on it, against 16 MFMAs).
-template <int TK, bool kC128>
+// kOut: bit 0 = fp32 NCHW output y (the module-boundary format), bit 1 = int8 NHWC output q (the
+// resident hand-off to the next integer layer: 1 byte per element instead of 4 written + 4 read + 1).
+constexpr int kOutF32 = 1, kOutI8 = 2;
+template <int TK, bool kC128, int kOut>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                const float* __restrict__ qbias, float* __restrict__ y,
-                                                               const ConvParams p) {
+                                                               int8_t* __restrict__ q, const ConvParams p) {
     constexpr int BKB = 128;              // bytes of the reduction axis per K-step (8 chunks, 4 MFMA sub-steps)
     constexpr int MT = TK / 32;           // 32-row MFMA tiles per wave along k_out
     constexpr int A_LOADS = TK / 32;      // 16-byte chunks per thread per K-step for the weight tile
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
 
     // epilogue: D row = k_out = (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel.  For a fixed
     // register the 32 lanes of a half-wave write 32 consecutive pixels of one channel (128 bytes).
-    if (m_ok) {
+    if ((kOut & kOutF32) && m_ok) {
         // one 64-bit base per lane; the 16*MT rows are 32-bit element offsets from it (a K-tile of one
         // image spans at most TK*PQ floats, far below 2^31)
         float* __restrict__ out = y + ((long)n_img * p.K + k0 + 4 * half) * PQ + pq;
@@ -259,6 +267,41 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
                 const int kl = a * 32 + (r & 3) + 8 * (r >> 2);          // compile-time constant
                 if (kl < kmax) out[(unsigned)(kl * PQ)] = conv_tail(acc[a][r], sBias[kl + 4 * half], p);
             }
+        }
+    }
+    if (kOut & kOutI8) {
+        // int8 NHWC: registers 4g..4g+3 of a tile are 4 consecutive channels = one dword of this lane's
+        // pixel.  The dwords go through LDS (the weight buffers are free now) as [pixel][TK + 16 bytes]
+        // and leave as 16-byte stores, TK contiguous bytes per pixel.  Rows k >= K carry zero weights
+        // and zero bias, so the channel padding [K, Kpad) is written as zeros.
+        constexpr int OS = TK + 16;                       // LDS row stride in bytes (16-byte aligned rows)
+        static_assert(kTP * OS <= 2 * TK * BKB, "output tile must fit in the weight buffers");
+        int8_t* sO = &sA[0][0];
+        __syncthreads();                                  // every wave is done reading sA
+        const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                unsigned d = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kl = a * 32 + e + 8 * g;
+                    const int v = (int)conv_tail_int(acc[a][4 * g + e], sBias[kl + 4 * half], p);
+                    d |= (unsigned)(v & 0xff) << (8 * e);
+                }
+                *reinterpret_cast<unsigned*>(&sO[prow + a * 32 + 8 * g]) = d;
+            }
+        }
+        __syncthreads();
+        constexpr int CPP = TK / 16;                      // 16-byte chunks per pixel
+#pragma unroll
+        for (int j = 0; j < (kTP * CPP) / kConvBlock; ++j) {
+            const int idx = tid + kConvBlock * j;
+            const int pix = idx / CPP, ch = idx - pix * CPP;
+            const int mm = m0 + pix, kk = k0 + 16 * ch;
+            if (mm < p.M && kk < p.Kpad)
+                *reinterpret_cast<v4i*>(q + (long)mm * p.Kpad + kk) = *reinterpret_cast<const v4i*>(&sO[pix * OS + 16 * ch]);
         }
     }
 }
@@ -441,20 +484,35 @@ extern "C" int fq_quantize_i8_unfold_w(const float* x_nchw, int8_t* y, int N, in
     return FQ_OK;
 }
 
-extern "C" int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw, int N, int H,
-                            int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
-                            int dil_h, int dil_w, int rs, int ob, int bitwidth, fq_stream_t stream) {
+namespace fq {
+
+template <int TK, bool kC128>
+static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
+                             int8_t* q, const ConvParams& p) {
+    if (y && q)
+        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutF32 | kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else if (q)
+        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else
+        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutF32>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+}
+
+static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw, int8_t* q_nhwc,
+                              int Kpad, int relu, int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
+                              int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob, int bitwidth, fq_stream_t stream) {
     if (!valid_bitwidth(bitwidth) || rs < -120 || rs > 120 || ob < -120 || ob > 120) return FQ_ERR_INVALID_ARG;
     if (N < 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride_h <= 0 || stride_w <= 0 ||
         pad_h < 0 || pad_w < 0 || dil_h <= 0 || dil_w <= 0)
         return FQ_ERR_INVALID_ARG;
     if (C % 16) return FQ_ERR_UNSUPPORTED;                // pad channels to 16 in fq_quantize_i8_nhwc
+    if (q_nhwc && (bitwidth != 8 || Kpad < K || (Kpad & 15))) return FQ_ERR_INVALID_ARG;
     const int P = (H + 2 * pad_h - dil_h * (R - 1) - 1) / stride_h + 1;
     const int Q = (W + 2 * pad_w - dil_w * (S - 1) - 1) / stride_w + 1;
     if (P <= 0 || Q <= 0) return FQ_ERR_INVALID_ARG;
     if (N == 0) return FQ_OK;
-    if (!x_nhwc || !w_krsc || !qbias || !y_nchw) return FQ_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w_krsc)) & 15u) return FQ_ERR_INVALID_ARG;
+    if (!x_nhwc || !w_krsc || !qbias || (!y_nchw && !q_nhwc)) return FQ_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w_krsc) | reinterpret_cast<uintptr_t>(q_nhwc)) & 15u)
+        return FQ_ERR_INVALID_ARG;
     const long M = (long)N * P * Q;
     if (M > 0x7fffffffL || (long)R * S * C / 16 > 0x7fffffffL) return FQ_ERR_UNSUPPORTED;
     if ((long)H * W * C > 0x7fffffffL || (long)R * S * C > 0x7fffffffL || (long)K * P * Q > 0x1fffffffL)
@@ -466,25 +524,41 @@ extern "C" int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const fl
     p.inv_rs = ldexpf(1.0f, -rs); p.inv_ob = ldexpf(1.0f, -ob);
     if (bitwidth == 8) { p.lo = -128.0f; p.hi = 127.0f; p.ilo = -128; p.ihi = 127; }
     else { p.lo = -32768.0f; p.hi = 32767.0f; p.ilo = -32768; p.ihi = 32767; }
+    if (relu) p.lo = 0.0f;                                // ReLU commutes with the positive scale 2^-ob
+    p.Kpad = q_nhwc ? Kpad : 0;
     hipStream_t st = as_stream(stream);
     const unsigned gx = (unsigned)((M + kTP - 1) / kTP);
     // 64-row tiles when the output is narrow, or when 128-row tiles would not even give one workgroup per CU
     const long wg128 = (long)gx * ((K + 127) / 128);
     if (K <= 64 || wg128 < kCUs) {
         if (C % 128 == 0 && K % 64 == 0)
-            hipLaunchKernelGGL((conv2d_i8_kernel<64, true>), dim3(gx, K / 64), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
-                               y_nchw, p);
+            launch_conv_tile<64, true>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else
-            hipLaunchKernelGGL((conv2d_i8_kernel<64, false>), dim3(gx, (K + 63) / 64), dim3(kConvBlock), 0, st, x_nhwc, w_krsc,
-                               qbias, y_nchw, p);
+            launch_conv_tile<64, false>(dim3(gx, (K + 63) / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
     } else {
         if (C % 128 == 0 && K % 128 == 0)
-            hipLaunchKernelGGL((conv2d_i8_kernel<128, true>), dim3(gx, K / 128), dim3(kConvBlock), 0, st, x_nhwc, w_krsc, qbias,
-                               y_nchw, p);
+            launch_conv_tile<128, true>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else
-            hipLaunchKernelGGL((conv2d_i8_kernel<128, false>), dim3(gx, (K + 127) / 128), dim3(kConvBlock), 0, st, x_nhwc, w_krsc,
-                               qbias, y_nchw, p);
+            launch_conv_tile<128, false>(dim3(gx, (K + 127) / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
     }
     FQ_LAUNCH_CHECK();
     return FQ_OK;
+}
+
+}  // namespace fq
+
+extern "C" int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw, int N, int H,
+                            int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
+                            int dil_h, int dil_w, int rs, int ob, int bitwidth, fq_stream_t stream) {
+    if (!y_nchw && N > 0) return FQ_ERR_INVALID_ARG;
+    return conv2d_i8_dispatch(x_nhwc, w_krsc, qbias, y_nchw, nullptr, 0, 0, N, H, W, C, K, R, S, stride_h, stride_w, pad_h,
+                              pad_w, dil_h, dil_w, rs, ob, bitwidth, stream);
+}
+
+extern "C" int fq_conv2d_i8_resident(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw,
+                                     int8_t* q_nhwc, int Kpad, int relu, int N, int H, int W, int C, int K, int R, int S,
+                                     int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob,
+                                     fq_stream_t stream) {
+    return conv2d_i8_dispatch(x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, Kpad, relu, N, H, W, C, K, R, S, stride_h, stride_w, pad_h,
+                              pad_w, dil_h, dil_w, rs, ob, 8, stream);
 }

@@ -1,0 +1,195 @@
+// fq_resident.hip -- the integer-simulation model with activations kept RESIDENT as integers between
+// layers (int8 / int16 NHWC in HBM) instead of crossing every nn.Module boundary as fp32 NCHW.
+//
+// The reference's ReconModel hands fp32 tensors from module to module (new_quantity_op.py:124-133
+// NewConv2d.forward, :171-174 NewAdd.forward): DeQuantity writes 4 B per element, nn.ReLU reads and
+// writes it, the next layer's Quantity reads it again and recovers -- exactly -- the integer the
+// previous tail had in registers.  Every value on that path is an integer times a power of two:
+//
+//   conv / linear output   y = q * 2^-ob,          q in [-128, 127]      -> int8, grid ob
+//   residual add           s = clamp(x + y)        (fp32 add of two such values: exact, no rounding,
+//                                                   while 8 + grid <= 24 bits)
+//                                                  -> S = s * 2^g integer, g = max(0, gx, gy),
+//                                                     |S| <= 128 * 2^g: int16 while g <= 8
+//   ReLU                   max(., 0)               commutes with the positive scale
+//   next Quantity(ib)      clamp(rint(s * 2^ib))   a function of the exact s
+//
+// so the same fp32 arithmetic can be carried out on the integers and the stored bytes drop from
+// 18-29 per activation to 2-6.  The kernels below evaluate the reference's fp32 expressions on the
+// de-scaled integers (bit-identical by construction); fq_conv2d_i8_resident (fq_conv_i8.hip) writes
+// the int8 form straight from the MFMA epilogue.
+#include "fq_common.h"
+
+namespace fq {
+
+constexpr int kResBlock = 256;
+
+typedef int v4i_r __attribute__((ext_vector_type(4)));
+
+struct AddResParams {
+    float sx, sy;          // 2^-gx, 2^-gy: integer -> value
+    float lo, hi;          // NewAdd's Sp range; lo = 0 when the following ReLU is fused
+    float s_wide;          // 2^g_out   (exact value -> int16)
+    float s_narrow;        // 2^ib      (next layers' Quantity)
+};
+
+template <typename T> struct Vec16;                       // 16 consecutive channels of one pixel
+template <> struct Vec16<int8_t> {
+    v4i_r a;
+    __device__ __forceinline__ void load(const int8_t* p) { a = *reinterpret_cast<const v4i_r*>(p); }
+    __device__ __forceinline__ float get(int i) const { return (float)(int)(int8_t)(((unsigned)a[i >> 2]) >> (8 * (i & 3))); }
+};
+template <> struct Vec16<int16_t> {
+    v4i_r a, b;
+    __device__ __forceinline__ void load(const int16_t* p) {
+        a = *reinterpret_cast<const v4i_r*>(p);
+        b = *reinterpret_cast<const v4i_r*>(p + 8);
+    }
+    __device__ __forceinline__ float get(int i) const {
+        const unsigned d = (unsigned)(i < 8 ? a[(i & 7) >> 1] : b[(i & 7) >> 1]);
+        return (float)(int)(int16_t)(d >> (16 * (i & 1)));
+    }
+};
+
+// NewAdd on resident operands (new_quantity_op.py:171-174 + the ReLU and Quantity that follow it):
+//   s = clamp(x * 2^-gx + y * 2^-gy, lo, hi)            the reference's fp32 expression, exact here
+//   wide[i]   = (int16) (s * 2^g_out)                    the exact sum, for the next residual add
+//   narrow[i] = (int8) clamp(rint(s * 2^ib), -128, 127)  what the next conv's Quantity(ib) computes
+// All operands share one flat NHWC layout [N][HW][Cpad]; 16 elements per thread.
+template <typename TX, typename TY>
+__global__ __launch_bounds__(kResBlock) void add_resident_kernel(const TX* __restrict__ x, const TY* __restrict__ y,
+                                                                 int16_t* __restrict__ wide, int8_t* __restrict__ narrow,
+                                                                 size_t n16, const AddResParams p) {
+    size_t i = (size_t)blockIdx.x * kResBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kResBlock;
+    for (; i < n16; i += stride) {
+        Vec16<TX> vx; Vec16<TY> vy;
+        vx.load(x + i * 16);
+        vy.load(y + i * 16);
+        float s[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const float v = vx.get(e) * p.sx + vy.get(e) * p.sy;
+            s[e] = __builtin_amdgcn_fmed3f(v, p.lo, p.hi);            // integers scaled by 2^k: never NaN
+        }
+        if (wide) {
+            v4i_r o0, o1;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const unsigned lo16 = (unsigned)(int)(s[2 * d] * p.s_wide) & 0xffffu;
+                const unsigned hi16 = (unsigned)(int)(s[2 * d + 1] * p.s_wide) << 16;
+                if (d < 4) o0[d] = (int)(lo16 | hi16); else o1[d - 4] = (int)(lo16 | hi16);
+            }
+            *reinterpret_cast<v4i_r*>(wide + i * 16) = o0;
+            *reinterpret_cast<v4i_r*>(wide + i * 16 + 8) = o1;
+        }
+        if (narrow) {
+            v4i_r o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                unsigned w = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float q = __builtin_amdgcn_fmed3f(rintf(s[4 * d + e] * p.s_narrow), -128.0f, 127.0f);
+                    w |= ((unsigned)(int)q & 0xffu) << (8 * e);
+                }
+                o[d] = (int)w;
+            }
+            *reinterpret_cast<v4i_r*>(narrow + i * 16) = o;
+        }
+    }
+}
+
+// Leaving the resident domain (the consumer is a module this library does not own: pooling, View, a
+// user op): integer NHWC [N][HW][Cpad] -> fp32 NCHW [N][C][HW], value = q * 2^-g (DeQuantity, exact).
+// 64 pixels x 64 channels per workgroup through an LDS tile; coalesced on both sides.
+template <typename T>
+__global__ __launch_bounds__(kResBlock) void dequant_nhwc_to_nchw_kernel(const T* __restrict__ q, float* __restrict__ y, int C,
+                                                                         int HW, int Cpad, float scale) {
+    __shared__ float tile[64][65];                        // [c][hw]
+    const int n = blockIdx.z, hw0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    {
+        const int hw = hw0 + (tid >> 2), cb = c0 + 16 * (tid & 3);
+        if (hw < HW && cb < Cpad) {
+            Vec16<T> v;
+            v.load(q + ((size_t)n * HW + hw) * Cpad + cb);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) tile[16 * (tid & 3) + e][tid >> 2] = v.get(e) * scale;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int idx = tid + kResBlock * j;
+        const int c = idx >> 6, hw = idx & 63;
+        if (c0 + c < C && hw0 + hw < HW) y[((size_t)n * C + c0 + c) * HW + hw0 + hw] = tile[c][hw];
+    }
+}
+
+inline unsigned res_grid(size_t items) {
+    size_t g = (items + kResBlock - 1) / kResBlock;
+    const size_t cap = (size_t)kCUs * 16;
+    if (g > cap) g = cap;
+    return (unsigned)(g ? g : 1);
+}
+
+template <typename TX, typename TY>
+static void launch_add(hipStream_t st, const void* x, const void* y, int16_t* wide, int8_t* narrow, size_t n16,
+                       const AddResParams& p) {
+    hipLaunchKernelGGL((add_resident_kernel<TX, TY>), dim3(res_grid(n16)), dim3(kResBlock), 0, st, static_cast<const TX*>(x),
+                       static_cast<const TY*>(y), wide, narrow, n16, p);
+}
+
+}  // namespace fq
+
+using namespace fq;
+
+extern "C" int fq_add_resident(const void* x, int x_bytes, int gx, const void* y, int y_bytes, int gy, int16_t* wide,
+                               int g_wide, int8_t* narrow, int ib, int relu, size_t n, fq_stream_t stream) {
+    if ((x_bytes != 1 && x_bytes != 2) || (y_bytes != 1 && y_bytes != 2)) return FQ_ERR_INVALID_ARG;
+    if (gx < -16 || gx > 16 || gy < -16 || gy > 16 || ib < -16 || ib > 16) return FQ_ERR_INVALID_ARG;
+    if (n & 15u) return FQ_ERR_INVALID_ARG;               // NHWC rows are padded to 16 channels
+    if (n == 0) return FQ_OK;
+    if (!x || !y || (!wide && !narrow)) return FQ_ERR_INVALID_ARG;
+    if (wide) {
+        // the exact sum must fit: grid max(0, gx, gy), |s| <= 128  =>  |S| <= 2^(7 + g) <= 2^15
+        const int g_need = gx > gy ? (gx > 0 ? gx : 0) : (gy > 0 ? gy : 0);
+        if (g_wide != g_need || g_wide > 8) return FQ_ERR_UNSUPPORTED;
+    }
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wide) |
+         reinterpret_cast<uintptr_t>(narrow)) & 15u)
+        return FQ_ERR_INVALID_ARG;
+    AddResParams p;
+    p.sx = ldexpf(1.0f, -gx); p.sy = ldexpf(1.0f, -gy);
+    p.lo = relu ? 0.0f : -128.0f; p.hi = 127.0f;
+    p.s_wide = ldexpf(1.0f, g_wide); p.s_narrow = ldexpf(1.0f, ib);
+    hipStream_t st = as_stream(stream);
+    const size_t n16 = n >> 4;
+    if (x_bytes == 1 && y_bytes == 1) launch_add<int8_t, int8_t>(st, x, y, wide, narrow, n16, p);
+    else if (x_bytes == 1) launch_add<int8_t, int16_t>(st, x, y, wide, narrow, n16, p);
+    else if (y_bytes == 1) launch_add<int16_t, int8_t>(st, x, y, wide, narrow, n16, p);
+    else launch_add<int16_t, int16_t>(st, x, y, wide, narrow, n16, p);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_dequant_nhwc_to_nchw(const void* q_nhwc, int q_bytes, int g, float* y_nchw, int N, int C, int HW, int Cpad,
+                                       fq_stream_t stream) {
+    if ((q_bytes != 1 && q_bytes != 2) || g < -120 || g > 120) return FQ_ERR_INVALID_ARG;
+    if (N < 0 || C <= 0 || HW < 0 || Cpad < C || (Cpad & 15)) return FQ_ERR_INVALID_ARG;
+    if (N == 0 || HW == 0) return FQ_OK;
+    if (!q_nhwc || !y_nchw || (reinterpret_cast<uintptr_t>(q_nhwc) & 15u)) return FQ_ERR_INVALID_ARG;
+    if (N > 65535) return FQ_ERR_UNSUPPORTED;
+    dim3 grid((HW + 63) / 64, (C + 63) / 64, N);
+    const float scale = ldexpf(1.0f, -g);
+    hipStream_t st = as_stream(stream);
+    if (q_bytes == 1)
+        hipLaunchKernelGGL(dequant_nhwc_to_nchw_kernel<int8_t>, grid, dim3(kResBlock), 0, st, static_cast<const int8_t*>(q_nhwc),
+                           y_nchw, C, HW, Cpad, scale);
+    else
+        hipLaunchKernelGGL(dequant_nhwc_to_nchw_kernel<int16_t>, grid, dim3(kResBlock), 0, st,
+                           static_cast<const int16_t*>(q_nhwc), y_nchw, C, HW, Cpad, scale);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}

@@ -75,6 +75,12 @@ def lib():
     L.fq_quantize_i8_unfold_w.argtypes = [vp, vp] + [ci] * 10 + [vp]
     L.fq_conv2d_i8.restype = ci
     L.fq_conv2d_i8.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
+    L.fq_conv2d_i8_resident.restype = ci
+    L.fq_conv2d_i8_resident.argtypes = [vp, vp, vp, vp, vp] + [ci] * 17 + [vp]
+    L.fq_add_resident.restype = ci
+    L.fq_add_resident.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, vp, ci, ci, sz, vp]
+    L.fq_dequant_nhwc_to_nchw.restype = ci
+    L.fq_dequant_nhwc_to_nchw.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, vp]
     L.fq_json_dump_i32.restype = ci
     L.fq_json_dump_i32.argtypes = [ctypes.c_char_p, vp, ci, vp, ci]
     _lib = L
@@ -316,6 +322,61 @@ def conv2d_i8(xq, wq, qbias, stride, padding, dilation, rs, ob, bitwidth=8):
                               stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], int(rs), int(ob),
                               int(bitwidth), _stream(xq)), "fq_conv2d_i8")
     return y.view(N, K) if linear else y
+
+
+def conv2d_i8_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, want_f32, want_i8, relu):
+    """fq_conv2d_i8_resident: returns (y fp32 [N,K,P,Q] or None, q int8 [N,P,Q,Kpad] or None).  q holds the
+    integers before DeQuantity (value = q * 2^-ob), channels zero-padded to a multiple of 16."""
+    _need_cuda(xq, torch.int8, "fq_conv2d_i8_resident")
+    _need_cuda(wq, torch.int8, "fq_conv2d_i8_resident")
+    _need_cuda(qbias, torch.float32, "fq_conv2d_i8_resident")
+    N, H, W, C = xq.shape
+    K, R, S, Cw = wq.shape
+    assert C == Cw and xq.is_contiguous() and wq.is_contiguous() and qbias.numel() == K and (want_f32 or want_i8)
+    P = (H + 2 * padding[0] - dilation[0] * (R - 1) - 1) // stride[0] + 1
+    Q = (W + 2 * padding[1] - dilation[1] * (S - 1) - 1) // stride[1] + 1
+    kpad = pad16(K)
+    y = torch.empty(N, K, P, Q, dtype=torch.float32, device=xq.device) if want_f32 else None
+    q = torch.empty(N, P, Q, kpad, dtype=torch.int8, device=xq.device) if want_i8 else None
+    _check(lib().fq_conv2d_i8_resident(xq.data_ptr(), wq.data_ptr(), qbias.contiguous().data_ptr(),
+                                       y.data_ptr() if want_f32 else None, q.data_ptr() if want_i8 else None, kpad,
+                                       1 if relu else 0, N, H, W, C, K, R, S, stride[0], stride[1], padding[0], padding[1],
+                                       dilation[0], dilation[1], int(rs), int(ob), _stream(xq)), "fq_conv2d_i8_resident")
+    return y, q
+
+
+_INT_BYTES = {torch.int8: 1, torch.int16: 2}
+
+
+def add_resident(x, gx, y, gy, want_wide, g_wide, want_narrow, ib, relu):
+    """fq_add_resident on two integer NHWC tensors of one shape: returns (wide int16 or None, narrow int8 or None)."""
+    for t in (x, y):
+        if not isinstance(t, torch.Tensor) or t.device.type != "cuda" or t.dtype not in _INT_BYTES:
+            raise FqError("fq_add_resident: expected int8 / int16 torch.cuda tensors")
+    assert x.shape == y.shape and x.is_contiguous() and y.is_contiguous() and (want_wide or want_narrow)
+    wide = torch.empty(x.shape, dtype=torch.int16, device=x.device) if want_wide else None
+    narrow = torch.empty(x.shape, dtype=torch.int8, device=x.device) if want_narrow else None
+    _check(lib().fq_add_resident(x.data_ptr(), _INT_BYTES[x.dtype], int(gx), y.data_ptr(), _INT_BYTES[y.dtype], int(gy),
+                                 wide.data_ptr() if want_wide else None, int(g_wide),
+                                 narrow.data_ptr() if want_narrow else None, int(ib), 1 if relu else 0, x.numel(),
+                                 _stream(x)), "fq_add_resident")
+    return wide, narrow
+
+
+def dequant_nhwc_to_nchw(q, g, channels):
+    """int8 / int16 [N, *spatial, Cpad] standing for q * 2^-g  ->  fp32 [N, channels, *spatial]."""
+    if not isinstance(q, torch.Tensor) or q.device.type != "cuda" or q.dtype not in _INT_BYTES:
+        raise FqError("fq_dequant_nhwc_to_nchw: expected an int8 / int16 torch.cuda tensor")
+    assert q.is_contiguous()
+    N, cpad = q.shape[0], q.shape[-1]
+    spatial = tuple(q.shape[1:-1])
+    HW = 1
+    for v in spatial:
+        HW *= v
+    y = torch.empty((N, int(channels)) + spatial, dtype=torch.float32, device=q.device)
+    _check(lib().fq_dequant_nhwc_to_nchw(q.data_ptr(), _INT_BYTES[q.dtype], int(g), y.data_ptr(), N, int(channels), HW, cpad,
+                                         _stream(q)), "fq_dequant_nhwc_to_nchw")
+    return y
 
 
 def quantize_i8_unfold_w(x, ib, S, stride_w, pad_w, dil_w, cpad2):

@@ -20,6 +20,7 @@ import torch
 from torch import nn
 
 from . import _native
+from .resident import QHandle, resident_of, as_f32
 
 QUANTIZE_BIT = 8
 
@@ -215,17 +216,48 @@ class NewConv2d(_IntegerSimLayer):
         conv = self.Conv
         if self._int8_ok(conv):
             wq = self._packed_weight(conv)
-            if self._stem_fold(conv):
+            plan = self.__dict__.get("_resident")         # set by common.quantity.resident.enable()
+            fold = self._stem_fold(conv)
+            if fold:
+                input = as_f32(input)
                 xq = _native.quantize_i8_unfold_w(input, self.input_bit, conv.kernel_size[1], conv.stride[1],
                                                   conv.padding[1], conv.dilation[1], wq.shape[-1])
-                return _native.conv2d_i8(xq, wq, self.quantized_bias, (conv.stride[0], 1), (conv.padding[0], 0),
-                                         (conv.dilation[0], 1), self.rs_bit, self.output_bit, 8)
-            xq = _xq_cache.get(input, self.input_bit, wq.shape[-1])
-            return _native.conv2d_i8(xq, wq, self.quantized_bias, conv.stride, conv.padding, conv.dilation,
-                                     self.rs_bit, self.output_bit, 8)
-        q = self.Quan(input)
+                geom = ((conv.stride[0], 1), (conv.padding[0], 0), (conv.dilation[0], 1))
+            else:
+                xq = self._resident_input(input, wq.shape[-1])
+                if xq is None:
+                    xq = _xq_cache.get(as_f32(input), self.input_bit, wq.shape[-1])
+                geom = (conv.stride, conv.padding, conv.dilation)
+            if plan is None:
+                return _native.conv2d_i8(xq, wq, self.quantized_bias, geom[0], geom[1], geom[2], self.rs_bit,
+                                         self.output_bit, 8)
+            y, q = _native.conv2d_i8_resident(xq, wq, self.quantized_bias, geom[0], geom[1], geom[2], self.rs_bit,
+                                              self.output_bit, plan.emit_f32, plan.emit_int, plan.relu)
+            handle = None
+            if q is not None:
+                handle = QHandle((q.shape[0], conv.out_channels, q.shape[1], q.shape[2]), q, self.output_bit, q,
+                                 self.output_bit, plan.relu)
+            if y is None:
+                return handle
+            if handle is not None:
+                y._fq_resident = handle
+            if plan.relu:
+                y._fq_relu_done = True
+            return y
+        q = self.Quan(as_f32(input))
         acc = conv(q)               # integer-valued fp32 in, exact below 2^24 per partial sum
         return self._tail(acc)
+
+    def _resident_input(self, input, cpad):
+        """int8 NHWC operand already in HBM (left by the producer), or None."""
+        h = resident_of(input)
+        if h is None:
+            return None
+        if h.narrow is not None and h.bit == self.input_bit and h.narrow.shape[-1] == cpad:
+            return h.narrow
+        if h.exact is not None and h.exact.dtype == torch.int8 and h.grid == self.input_bit and h.exact.shape[-1] == cpad:
+            return h.exact
+        return None
 
 
 class NewLinear(_IntegerSimLayer):
@@ -237,6 +269,7 @@ class NewLinear(_IntegerSimLayer):
 
     def forward(self, input):
         lin = self.Linear
+        input = as_f32(input)
         if self._int8_ok(lin) and input.dim() == 2:
             wq = self._packed_weight(lin)
             xq = _native.quantize_i8_nhwc(input, self.input_bit, wq.shape[-1])
@@ -256,7 +289,28 @@ class NewAdd(nn.Module):
         self.Sp = Sp(QUANTIZE_BIT)
 
     def forward(self, x, y):
-        return _native.add_sat(x, y, self.Sp.bitwidth)
+        plan = self.__dict__.get("_resident")             # set by common.quantity.resident.enable()
+        if plan is not None and plan.resident_add and self.Sp.bitwidth == 8:
+            hx, hy = resident_of(x), resident_of(y)
+            if (hx is not None and hy is not None and hx.exact is not None and hy.exact is not None
+                    and hx.exact.shape == hy.exact.shape and max(0, hx.grid, hy.grid) == plan.grid):
+                want_narrow = plan.emit_int and plan.narrow_bit is not None
+                wide, narrow = _native.add_resident(hx.exact, hx.grid, hy.exact, hy.grid, plan.want_wide or not want_narrow,
+                                                    plan.grid, want_narrow, plan.narrow_bit if want_narrow else 0, plan.relu)
+                handle = QHandle(hx.shape, wide, plan.grid, narrow, plan.narrow_bit, plan.relu)
+                if not plan.emit_f32:
+                    return handle
+                out = handle.to_f32()
+                if plan.emit_int:
+                    out._fq_resident = handle
+                if plan.relu:
+                    out._fq_relu_done = True
+                return out
+        out = _native.add_sat(as_f32(x), as_f32(y), self.Sp.bitwidth)
+        if plan is not None and plan.relu:
+            out = torch.relu_(out)                        # the ReLU module after this add passes through
+            out._fq_relu_done = True
+        return out
 
 
 class QuanDequan(nn.Module):

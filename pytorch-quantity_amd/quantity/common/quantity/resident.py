@@ -1,0 +1,335 @@
+"""Resident integer activations for the integer-simulation model (ReconModel).
+
+The reference's NewConv2d / NewAdd hand fp32 NCHW tensors from module to module
+(new_quantity_op.py:124-133, :171-174): DeQuantity writes 4 bytes per activation, nn.ReLU reads and
+writes them, the next layer's Quantity reads them again and recovers -- exactly -- the integer the
+previous layer's tail already held.  `enable(model, example)` keeps that integer in HBM instead:
+
+  * one traced forward (module hooks + a TorchFunctionMode) records, for the output of every
+    NewConv2d / NewAdd, who consumes it: another integer layer, a ReLU, or anything else;
+  * producers whose consumers are integer layers emit int8 NHWC straight from the MFMA epilogue
+    (conv) or int16 + int8 NHWC from the fused add kernel, with the following nn.ReLU folded in
+    (max(., 0) commutes with the power-of-two scale); consumers read those bytes directly;
+  * anything else still receives the ordinary fp32 NCHW tensor (a value used by both kinds gets both).
+
+Every resident value is `integer * 2^-grid` and stands for exactly the fp32 number the reference
+would have produced, so model outputs are bit-identical to the fp32-boundary path
+(tests/test_gpu_resident.py); the saving is HBM traffic: 18-29 bytes per activation become 2-6.
+
+The plan assumes a static dataflow (as a captured graph would).  Consumers stay adaptive -- a layer
+that unexpectedly receives fp32 quantises it as usual -- and a resident handle reaching code that
+is not part of the plan raises instead of computing garbage.
+"""
+import torch
+from torch import nn
+from torch.overrides import TorchFunctionMode
+
+from . import _native
+
+__all__ = ["QHandle", "enable", "disable", "is_enabled", "describe"]
+
+MAX_WIDE_GRID = 8          # int16 holds |s| <= 128 on a grid of 2^-8
+
+
+class QHandle(object):
+    """An activation kept as integers in HBM.  Not a tensor on purpose: code outside the plan that
+    touches it fails loudly.
+
+    exact : int8 / int16 NHWC tensor, value = exact * 2^-grid (the reference's fp32 value, exactly)
+    narrow: int8 NHWC tensor = Quantity(value, bit) for the next conv (conv outputs: the same tensor)
+    """
+    __slots__ = ("shape", "exact", "grid", "narrow", "bit", "relu_done")
+
+    def __init__(self, shape, exact, grid, narrow, bit, relu_done):
+        self.shape, self.exact, self.grid, self.narrow, self.bit, self.relu_done = shape, exact, grid, narrow, bit, relu_done
+
+    def to_f32(self):
+        """The fp32 NCHW tensor this handle stands for (DeQuantity + layout change, one kernel)."""
+        if self.exact is None:
+            raise _native.FqError("resident activation without an exact payload cannot leave the integer domain")
+        return _native.dequant_nhwc_to_nchw(self.exact, self.grid, self.shape[1])
+
+    def __repr__(self):
+        return "QHandle(shape=%s, exact=%s@%s, narrow_bit=%s, relu=%s)" % (
+            tuple(self.shape), None if self.exact is None else str(self.exact.dtype).replace("torch.", ""), self.grid,
+            self.bit if self.narrow is not None else None, self.relu_done)
+
+
+def resident_of(x):
+    """The integer form of an activation, if it has one (a handle, or an fp32 tensor carrying one)."""
+    if type(x) is QHandle:
+        return x
+    return getattr(x, "_fq_resident", None)
+
+
+def as_f32(x):
+    return x.to_f32() if type(x) is QHandle else x
+
+
+class Plan(object):
+    """What one producer emits.  Plain data (pickles with the module)."""
+    __slots__ = ("relu", "emit_f32", "emit_int", "narrow_bit", "want_wide", "grid", "resident_add")
+
+    def __init__(self):
+        self.relu = False            # the nn.ReLU that consumes this output is fused
+        self.emit_f32 = True         # some consumer needs the fp32 NCHW tensor
+        self.emit_int = False        # some consumer reads the integer form
+        self.narrow_bit = None       # NewAdd: Quantity bit of the conv consumers (None: no narrow output)
+        self.want_wide = False       # NewAdd: exact int16 sum needed (next add, or fp32 via dequant)
+        self.grid = None             # NewAdd: grid of the exact sum
+        self.resident_add = False    # NewAdd: operands arrive as integers
+
+    def __getstate__(self):
+        return {k: getattr(self, k) for k in self.__slots__}
+
+    def __setstate__(self, state):
+        for k, v in state.items():
+            setattr(self, k, v)
+
+    def __repr__(self):
+        return "Plan(%s)" % ", ".join("%s=%r" % (k, getattr(self, k)) for k in self.__slots__)
+
+
+class _ReluPassThrough(object):
+    """Instance-level forward of an nn.ReLU whose producer already applied it."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __call__(self, x):
+        if type(x) is QHandle:
+            if not x.relu_done:
+                raise _native.FqError("resident activation reached a ReLU that its producer did not fuse "
+                                      "(dataflow changed since resident.enable(); call it again)")
+            return x
+        if getattr(x, "_fq_relu_done", False):
+            return x
+        return type(self.module).forward(self.module, x)
+
+
+# ---- tracing -------------------------------------------------------------------------------------
+
+class _Value(object):
+    __slots__ = ("producer", "kind", "src", "consumers", "foreign", "order")
+
+    def __init__(self, producer, kind, src, order):
+        self.producer, self.kind, self.src, self.order = producer, kind, src, order
+        self.consumers = []          # (module, argument position)
+        self.foreign = False         # touched by code outside NewConv2d / NewLinear / NewAdd / nn.ReLU
+
+
+def _iter_tensors(obj):
+    if isinstance(obj, torch.Tensor):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            for t in _iter_tensors(o):
+                yield t
+    elif isinstance(obj, dict):
+        for o in obj.values():
+            for t in _iter_tensors(o):
+                yield t
+
+
+class _Tracer(TorchFunctionMode):
+
+    def __init__(self, planned_types):
+        super(_Tracer, self).__init__()
+        self.planned_types = planned_types
+        self.values = {}             # id(tensor) -> _Value
+        self.keep = []               # keeps traced tensors alive so ids are not reused
+        self.depth = 0
+        self.calls = {}              # module -> number of forward calls
+        self.order = 0
+        self.produced = []           # _Value of every NewConv2d / NewAdd output, in execution order
+        self.relu_values = []        # _Value of every nn.ReLU output whose input is traced
+
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if self.depth == 0:
+            for t in _iter_tensors(args):
+                v = self.values.get(id(t))
+                if v is not None:
+                    v.foreign = True
+            for t in _iter_tensors(kwargs):
+                v = self.values.get(id(t))
+                if v is not None:
+                    v.foreign = True
+        return func(*args, **kwargs)
+
+    # module hooks
+    def pre(self, module, args):
+        self.depth += 1
+        self.calls[module] = self.calls.get(module, 0) + 1
+        for pos, a in enumerate(args):
+            v = self.values.get(id(a)) if isinstance(a, torch.Tensor) else None
+            if v is not None:
+                v.consumers.append((module, pos))
+
+    def post(self, module, args, output):
+        self.depth -= 1
+        if not isinstance(output, torch.Tensor):
+            return
+        self.order += 1
+        if isinstance(module, nn.ReLU):
+            src = self.values.get(id(args[0])) if args and isinstance(args[0], torch.Tensor) else None
+            if src is None:
+                return
+            v = _Value(module, "relu", src, self.order)
+            self.relu_values.append(v)
+        else:
+            v = _Value(module, "add" if type(module).__name__ == "NewAdd" else "contraction", None, self.order)
+            self.produced.append(v)
+        self.values[id(output)] = v
+        self.keep.append(output)
+
+    def mark_foreign(self, obj):
+        for t in _iter_tensors(obj):
+            v = self.values.get(id(t))
+            if v is not None:
+                v.foreign = True
+
+
+def _clear(model):
+    for m in model.modules():
+        m.__dict__.pop("_resident", None)
+        fwd = m.__dict__.get("forward")
+        if isinstance(fwd, _ReluPassThrough):
+            del m.__dict__["forward"]
+    model.__dict__.pop("_fq_resident_enabled", None)
+
+
+def disable(model):
+    """Back to the reference's fp32 module boundaries."""
+    _clear(model)
+    return model
+
+
+def is_enabled(model):
+    return bool(model.__dict__.get("_fq_resident_enabled"))
+
+
+def enable(model, example_input):
+    """Trace one forward of `model` (an integer-simulation model built by Reconstruction.ReconModel,
+    on the GPU) and switch every eligible NewConv2d / NewAdd to resident integer outputs.  Returns a
+    summary dict.  `example_input` is any valid input batch; the plan does not depend on its size."""
+    from .new_quantity_op import NewConv2d, NewLinear, NewAdd, QUANTIZE_BIT
+    _clear(model)
+    if QUANTIZE_BIT != 8:
+        raise _native.FqError("resident activations are defined for QUANTIZE_BIT = 8")
+    planned_types = (NewConv2d, NewLinear, NewAdd, nn.ReLU)
+    tracer = _Tracer(planned_types)
+    hooks = []
+    for m in model.modules():
+        if isinstance(m, planned_types):
+            hooks.append(m.register_forward_pre_hook(tracer.pre))
+            hooks.append(m.register_forward_hook(tracer.post))
+    was_training = model.training
+    model.eval()
+    try:
+        with torch.no_grad():
+            with tracer:
+                out = model(example_input)
+            tracer.mark_foreign(out)
+    finally:
+        for h in hooks:
+            h.remove()
+        model.train(was_training)
+
+    relu_value = dict((id(c.src), c) for c in tracer.relu_values)
+
+    def effective(v):
+        """(value the consumers see, fused ReLU module or None)"""
+        if not v.foreign and len(v.consumers) == 1 and isinstance(v.consumers[0][0], nn.ReLU):
+            after = relu_value.get(id(v))
+            if after is not None:
+                return after, v.consumers[0][0]
+        return v, None
+
+    def conv_can_emit(m):
+        return isinstance(m, NewConv2d) and tracer.calls.get(m, 0) == 1 and m._int8_ok(m.Conv)
+
+    def conv_can_read(m):
+        return isinstance(m, NewConv2d) and m._int8_ok(m.Conv) and not m._stem_fold(m.Conv)
+
+    # pass 1 (execution order): integer format of every produced value
+    fmt = {}                         # id(effective _Value) -> (bytes, grid)
+    eff_of = {}                      # id(produced _Value) -> (effective _Value, relu module)
+    operands = {}                    # NewAdd module -> [value at arg 0, value at arg 1]
+    for v in tracer.values.values():
+        for (m, pos) in v.consumers:
+            if isinstance(m, NewAdd) and pos < 2:
+                operands.setdefault(m, [None, None])[pos] = v
+    add_resident = set()
+    for v in tracer.produced:
+        e, relu_mod = effective(v)
+        eff_of[id(v)] = (e, relu_mod)
+        m = v.producer
+        if v.kind == "contraction":
+            if conv_can_emit(m):
+                fmt[id(e)] = (1, m.output_bit)
+        else:
+            ops = operands.get(m)
+            if tracer.calls.get(m, 0) != 1 or ops is None or ops[0] is None or ops[1] is None:
+                continue
+            fx, fy = fmt.get(id(ops[0])), fmt.get(id(ops[1]))
+            if fx is None or fy is None:
+                continue
+            g = max(0, fx[1], fy[1])
+            if g > MAX_WIDE_GRID or min(fx[1], fy[1]) < -16:
+                continue
+            add_resident.add(m)
+            fmt[id(e)] = (2, g)
+
+    # pass 2: what every producer has to emit
+    summary = {"resident_convs": 0, "resident_adds": 0, "fused_relus": 0, "fp32_outputs": 0, "int_only_outputs": 0}
+    for v in tracer.produced:
+        m = v.producer
+        e, relu_mod = eff_of[id(v)]
+        if id(e) not in fmt:
+            continue                                        # plain fp32 producer
+        plan = Plan()
+        plan.relu = relu_mod is not None
+        need_f32 = e.foreign
+        int_consumers = 0
+        narrow_bits = []
+        for (c, pos) in e.consumers:
+            if conv_can_read(c):
+                narrow_bits.append(c.input_bit)
+            elif isinstance(c, NewAdd) and c in add_resident:
+                int_consumers += 1
+                plan.want_wide = True
+            else:
+                need_f32 = True
+        if v.kind == "contraction":
+            ok = [b for b in narrow_bits if b == m.output_bit]
+            if len(ok) != len(narrow_bits):
+                need_f32 = True                             # a consumer quantises at another bit: from fp32
+            int_consumers += len(ok)
+            plan.narrow_bit = m.output_bit
+        else:
+            plan.resident_add = True
+            plan.grid = fmt[id(e)][1]
+            if narrow_bits:
+                plan.narrow_bit = narrow_bits[0]
+                ok = [b for b in narrow_bits if b == plan.narrow_bit]
+                if len(ok) != len(narrow_bits):
+                    need_f32 = True
+                int_consumers += len(ok)
+            if need_f32:
+                plan.want_wide = True                       # fp32 leaves through the exact int16 sum
+        plan.emit_int = int_consumers > 0
+        plan.emit_f32 = need_f32 or not plan.emit_int
+        m.__dict__["_resident"] = plan
+        if plan.relu:
+            relu_mod.__dict__["forward"] = _ReluPassThrough(relu_mod)
+            summary["fused_relus"] += 1
+        summary["resident_convs" if v.kind == "contraction" else "resident_adds"] += 1
+        summary["fp32_outputs" if plan.emit_f32 else "int_only_outputs"] += 1
+    model.__dict__["_fq_resident_enabled"] = True
+    return summary
+
+
+def describe(model):
+    """{module name: Plan} of the current plan (for logs and tests)."""
+    return dict((name, m.__dict__["_resident"]) for name, m in model.named_modules() if "_resident" in m.__dict__)

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity")); sys.
 import bench
 from tools import Quantity, Reconstruction
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda")
 out = sys.stdout; sys.stdout = open(os.devnull, "w")
 model = bench.build_model("r50", 224, dev)
@@ -17,9 +18,12 @@ rec = Reconstruction(bench.build_model("r50", 224, dev))
 net = rec.ReconModel(rec.get_quantity_information(), "./workdir/recon.pth")
 sys.stdout = out
 x = data[0][0]
+if len(sys.argv) > 3 and sys.argv[3] == "resident":
+    from common.quantity import resident
+    print("resident plan:", resident.enable(net, x))
 with torch.no_grad():
     for _ in range(3): net(x)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): net(x)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    for _ in range(ITERS): net(x)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / ITERS
 print("ReconModel B=%d: %.3f ms/batch = %.0f img/s" % (B, dt * 1e3, B / dt))

@@ -1,0 +1,269 @@
+"""Resident integer activations (common.quantity.resident): the integer-simulation model with int8 /
+int16 NHWC hand-offs between layers must reproduce the fp32-boundary model -- and therefore the
+reference -- bit for bit.   pytest -m gpu"""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+import cases
+from workdir_util import product_workdir
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from common.quantity import _native
+    _native.lib()
+    return _native
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+RES_CASES = [
+    # N, C, H, W, K, R, S, stride, pad
+    (2, 16, 8, 8, 64, 3, 3, 1, 1),             # TK = 64, general path
+    (3, 32, 9, 7, 40, 3, 3, 2, 1),             # K = 40 -> Kpad 48, ragged pixel tile
+    (2, 128, 7, 7, 200, 3, 3, 1, 1),           # two k tiles, second partial, Kpad 208
+    (1, 256, 6, 6, 512, 1, 1, 2, 0),           # C % 128 fast path, TK = 64 (few workgroups)
+    (40, 128, 14, 14, 256, 1, 1, 1, 0),        # C % 128 fast path, TK = 128
+    (2, 3, 20, 20, 10, 3, 3, 1, 1),            # K = 10 -> Kpad 16
+]
+
+
+@pytest.mark.parametrize("case", RES_CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv_resident_outputs(nat, oracle, case, relu):
+    """q is what the NEXT layer's Quantity(ib = ob) recovers from the reference's fp32 output (after the
+    ReLU when fused); y is the fp32 output itself; both-outputs mode gives the same two arrays."""
+    N, C, H, W, K, R, S, st, pd = case
+    rng = np.random.default_rng(sum(case) + int(relu))
+    xq = rng.integers(-128, 128, size=(N, C, H, W)).astype(np.int32)
+    wq = rng.integers(-128, 128, size=(K, C, R, S)).astype(np.int32)
+    qb = rng.integers(-128, 128, size=K).astype(np.float32)
+    acc = oracle.conv2d_int(xq, wq, (st, st), (pd, pd), (1, 1))
+    cpad = (C + 15) // 16 * 16
+    kpad = (K + 15) // 16 * 16
+    x_nhwc = np.zeros((N, H, W, cpad), dtype=np.int8)
+    x_nhwc[..., :C] = xq.transpose(0, 2, 3, 1)
+    w_dev = nat.pack_weight_krsc(_dev(wq.astype(np.float32)))
+    x_dev, b_dev = _dev(x_nhwc), _dev(qb)
+    for rs, ob in ((12, 5), (9, 2), (16, -1)):
+        ref = oracle.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+        if relu:
+            ref = np.maximum(ref, np.float32(0))
+        ref_q = oracle.quantity(ref, ob).astype(np.int8).transpose(0, 2, 3, 1)
+        for want_f32, want_i8 in ((False, True), (True, True), (True, False)):
+            y, q = nat.conv2d_i8_resident(x_dev, w_dev, b_dev, (st, st), (pd, pd), (1, 1), rs, ob, want_f32, want_i8, relu)
+            if want_f32:
+                np.testing.assert_array_equal(y.cpu().numpy(), ref)
+            else:
+                assert y is None
+            if want_i8:
+                got = q.cpu().numpy()
+                assert got.shape == ref_q.shape[:3] + (kpad,)
+                np.testing.assert_array_equal(got[..., :K], ref_q)
+                assert not got[..., K:].any()
+            else:
+                assert q is None
+
+
+@pytest.mark.parametrize("xb,gx,yb,gy,ib,relu", [(1, 3, 1, 5, 4, True), (1, 5, 2, 5, 3, True), (2, 6, 1, 2, 6, False),
+                                                 (2, 8, 2, 7, 5, True), (1, -1, 1, 2, 0, False), (1, 0, 2, 0, 1, True)])
+def test_add_resident_equals_fp32_chain(nat, oracle, xb, gx, yb, gy, ib, relu):
+    """DeQuantity -> NewAdd -> ReLU -> Quantity of the reference, evaluated by the oracle on fp32, against
+    the fused integer kernel; the int16 output must be the exact sum."""
+    rng = np.random.default_rng(xb * 1000 + gx * 100 + yb * 10 + gy)
+    shape = (3, 5, 7, 32)
+    x = rng.integers(-128, 128, size=shape).astype(np.int8 if xb == 1 else np.int16)
+    if xb == 2:
+        x = (x.astype(np.int32) * rng.integers(1, 2 ** gx + 1, size=shape)).clip(-128 * 2 ** gx, 127 * 2 ** gx).astype(np.int16)
+    y = rng.integers(-128, 128, size=shape).astype(np.int8 if yb == 1 else np.int16)
+    if yb == 2:
+        y = (y.astype(np.int32) * rng.integers(1, 2 ** gy + 1, size=shape)).clip(-128 * 2 ** gy, 127 * 2 ** gy).astype(np.int16)
+    g = max(0, gx, gy)
+    xf = oracle.dequantity(x.astype(np.float32), gx)
+    yf = oracle.dequantity(y.astype(np.float32), gy)
+    s = oracle.add_sat(xf, yf)
+    if relu:
+        s = np.maximum(s, np.float32(0))
+    exact = s.astype(np.float64) * 2.0 ** g
+    assert np.all(exact == np.rint(exact)) and np.abs(exact).max() <= 32768
+    wide, narrow = nat.add_resident(_dev(x), gx, _dev(y), gy, True, g, True, ib, relu)
+    np.testing.assert_array_equal(wide.cpu().numpy(), exact.astype(np.int16))
+    np.testing.assert_array_equal(narrow.cpu().numpy(), oracle.quantity(s, ib).astype(np.int8))
+    w2, n2 = nat.add_resident(_dev(x), gx, _dev(y), gy, True, g, False, 0, relu)
+    assert n2 is None
+    np.testing.assert_array_equal(w2.cpu().numpy(), wide.cpu().numpy())
+    w3, n3 = nat.add_resident(_dev(x), gx, _dev(y), gy, False, g, True, ib, relu)
+    assert w3 is None
+    np.testing.assert_array_equal(n3.cpu().numpy(), narrow.cpu().numpy())
+
+
+def test_add_resident_refuses_a_sum_that_does_not_fit(nat):
+    x = torch.zeros(2, 2, 2, 16, dtype=torch.int8, device="cuda")
+    with pytest.raises(nat.FqError):
+        nat.add_resident(x, 9, x, 2, True, 9, False, 0, False)
+    with pytest.raises(nat.FqError):
+        nat.add_resident(x, 3, x, 2, True, 4, False, 0, False)          # wrong grid for the exact sum
+
+
+@pytest.mark.parametrize("dtype,g,N,C,H,W", [(np.int8, 4, 2, 64, 7, 7), (np.int16, 7, 3, 40, 5, 9), (np.int8, -1, 1, 10, 1, 1),
+                                             (np.int16, 0, 2, 130, 13, 3)])
+def test_dequant_nhwc_to_nchw(nat, oracle, dtype, g, N, C, H, W):
+    rng = np.random.default_rng(C + g)
+    cpad = (C + 15) // 16 * 16
+    info = np.iinfo(dtype)
+    q = rng.integers(info.min, info.max + 1, size=(N, H, W, cpad)).astype(dtype)
+    y = nat.dequant_nhwc_to_nchw(_dev(q), g, C).cpu().numpy()
+    ref = oracle.dequantity(q[..., :C].astype(np.float32), g).transpose(0, 3, 1, 2)
+    np.testing.assert_array_equal(y, ref)
+
+
+def _r18_recon(g3, tmp):
+    from model.resnet.ResNet_18_fabu import ResNet18
+    from tools import Reconstruction
+    wd = os.path.join(tmp, "test", "workdir")
+    os.makedirs(wd, exist_ok=True)
+    with open(os.path.join(wd, "feat.table"), "w") as fh:
+        fh.write(g3["feat_table"])
+    with open(os.path.join(wd, "weight.table"), "w") as fh:
+        fh.write(g3["weight_table_after_second_rewrite"])
+    rec = Reconstruction(cases.seed_model(ResNet18()).eval())
+    rec.merge_bn()
+    return rec.ReconModel(rec.get_quantity_information(), os.path.join(wd, "recon.pth")).cuda()
+
+
+@pytest.fixture(scope="module")
+def g3(golden_dir):
+    import json
+    with open(os.path.join(golden_dir, "g3_r18_e2e.json")) as fh:
+        return json.load(fh)
+
+
+def test_r18_resident_logits_equal_reference_golden(golden_dir, g3):
+    """ResNet-18 (basic blocks, identity and projection shortcuts, folded stem): the resident model must
+    give the logits the reference's CPU ReconModel gave (golden G4), and the plan must be non-trivial."""
+    from common.quantity import resident
+    g4 = np.load(os.path.join(golden_dir, "g4_r18_recon.npz"))
+    with product_workdir(device="gpu") as tmp:
+        net = _r18_recon(g3, tmp)
+        x = torch.from_numpy(g4["x"]).cuda()
+        with torch.no_grad():
+            plain = net(x).cpu().numpy()
+        np.testing.assert_array_equal(plain, g4["logits_recon"])
+        summary = resident.enable(net, x)
+        assert resident.is_enabled(net)
+        assert summary["resident_convs"] >= 15 and summary["fused_relus"] >= 10, summary
+        with torch.no_grad():
+            got = net(x).cpu().numpy()
+            again = net(torch.cat([x, x])).cpu().numpy()          # another batch size, same plan
+        np.testing.assert_array_equal(got, g4["logits_recon"])
+        np.testing.assert_array_equal(again[:x.shape[0]], g4["logits_recon"])
+        np.testing.assert_array_equal(again[x.shape[0]:], g4["logits_recon"])
+        resident.disable(net)
+        assert not resident.is_enabled(net) and not resident.describe(net)
+        with torch.no_grad():
+            np.testing.assert_array_equal(net(x).cpu().numpy(), plain)
+
+
+def _calibrated_recon(model_fn, image, batch):
+    """Calibrate a seeded model on the GPU and rebuild it as ReconModel; returns (net, input batch)."""
+    from tools import Quantity, Reconstruction
+    from common.quantity import merge_bn
+    dev = torch.device("cuda")
+    model = merge_bn(cases.seed_model(model_fn()).eval()).to(dev)
+    gen = np.random.default_rng(5)
+    data = [(torch.from_numpy(gen.standard_normal((batch, 3, image, image), dtype=np.float32)).to(dev), 0) for _ in range(2)]
+    q = Quantity(model)
+    q.activation_quantize(data)
+    q.weight_quantize()
+    q.rewrite_weight()
+    rec = Reconstruction(merge_bn(cases.seed_model(model_fn()).eval()).to(dev))
+    net = rec.ReconModel(rec.get_quantity_information(), "./workdir/recon.pth")
+    return net, data[0][0]
+
+
+def test_r50_resident_equals_fp32_boundary_model():
+    """Bottleneck ResNet-50 @64x64: every conv but the classifier and every Eltwise goes resident, all
+    49 ReLUs are fused, and logits (and an intermediate stage output) are bit-identical."""
+    from common.quantity import resident
+    from model.resnet.ResNet_fabu import ResNet50
+    with product_workdir(input_shape="1,3,64,64", device="gpu"):
+        net, x = _calibrated_recon(lambda: ResNet50(num_classes=100, input_size=64), 64, 8)
+        with torch.no_grad():
+            plain = net(x)
+            stage_plain = net.layer2[:3](net.layer1(net.maxpool(net.relu(net.conv1(x)))))
+        summary = resident.enable(net, x)
+        assert summary["resident_convs"] == 53 and summary["resident_adds"] == 16 and summary["fused_relus"] == 49, summary
+        plans = resident.describe(net)
+        assert plans["layer1.0.conv1"].emit_f32 is False and plans["layer1.0.conv1"].relu is True
+        assert plans["conv1"].emit_f32 is True and plans["conv1"].emit_int is False and plans["conv1"].relu is True
+        assert plans["layer4.2.Eltwise"].emit_f32 is True            # feeds the average pool
+        assert plans["layer1.1.Eltwise"].emit_f32 is False and plans["layer1.1.Eltwise"].want_wide is True
+        with torch.no_grad():
+            got = net(x)
+            stage = net.layer2[:3](net.layer1(net.maxpool(net.relu(net.conv1(x)))))   # feeds a conv and an add
+        assert type(stage).__name__ == "QHandle"
+        assert torch.equal(got, plain)
+        assert torch.equal(stage.to_f32(), stage_plain)
+        # a handle that reaches code outside the plan fails loudly instead of computing garbage
+        with pytest.raises(Exception):
+            torch.relu(stage)
+        # the plan survives pickling of the whole model (how the reference stores models)
+        torch.save(net, "./workdir/recon_resident.pth")
+        again = torch.load("./workdir/recon_resident.pth", weights_only=False)
+        with torch.no_grad():
+            assert torch.equal(again(x), plain)
+
+
+def test_foreign_consumers_and_shared_relu():
+    """A net that mixes integer layers with things the plan does not own: a functional op on a conv
+    output, one nn.ReLU instance used at three call sites, a Concat, a value used by both a conv and a
+    user op.  Resident mode must give identical outputs."""
+    from common.quantity import NewConv2d, NewAdd, resident
+
+    def info(i, o, w=6):
+        return {"weight_bit": w, "bias_bit": o, "input_bit": i, "output_bit": o}
+
+    class Net(nn.Module):
+        def __init__(self):
+            super(Net, self).__init__()
+            torch.manual_seed(3)
+            self.c1 = NewConv2d(nn.Conv2d(3, 32, 3, padding=1), info(5, 4))
+            self.c2 = NewConv2d(nn.Conv2d(32, 32, 3, padding=1), info(4, 3))
+            self.c3 = NewConv2d(nn.Conv2d(32, 32, 1), info(3, 3))
+            self.c4 = NewConv2d(nn.Conv2d(32, 48, 1), info(3, 2))
+            self.c5 = NewConv2d(nn.Conv2d(96, 16, 1), info(2, 2))
+            self.add = NewAdd()
+            self.relu = nn.ReLU()                             # shared by every call site
+
+        def forward(self, x):
+            a = self.relu(self.c1(x))                         # fused, int8 only
+            b = self.relu(self.c2(a))                         # fused; consumed by c3 AND by a user op below
+            c = self.c3(b)                                    # no ReLU; feeds the add
+            d = self.relu(self.add(c, b))                     # resident add, fused ReLU
+            e = self.c4(d)
+            f = torch.cat((e, e * 0.5 + b.mean()), dim=1)     # foreign consumers of e and b
+            return self.c5(self.relu(f))                      # ReLU on a foreign tensor: runs normally
+
+    net = Net().cuda().eval()
+    x = torch.randn(4, 3, 12, 12, device="cuda")
+    with torch.no_grad():
+        plain = net(x)
+    summary = resident.enable(net, x)
+    plans = resident.describe(net)
+    assert plans["c1"].emit_f32 is False and plans["c1"].relu
+    assert plans["c2"].emit_f32 is True and plans["c2"].emit_int is True and plans["c2"].relu
+    assert plans["c3"].emit_f32 is False and not plans["c3"].relu
+    assert plans["add"].resident_add and plans["add"].relu
+    assert plans["c4"].emit_f32 is True and plans["c4"].emit_int is False
+    assert summary["fused_relus"] == 3
+    with torch.no_grad():
+        assert torch.equal(net(x), plain)
+        assert torch.equal(net(x[:1]), plain[:1])
