@@ -44,10 +44,20 @@ struct ConvParams {
     float inv_rs, inv_ob, lo, hi;        // 2^-rs, 2^-ob, clamp range (lo = 0 when a ReLU is fused)
     int ilo, ihi;
     int Kpad;                            // channel stride of the int8 NHWC output (>= K, multiple of 16)
+    unsigned x_bytes;                    // N * H * W * C: num_records of the activation buffer descriptor
 };
 
-// 16 zero bytes in device memory: out-of-image taps load from here instead of being zeroed by selects
-__device__ const v4i g_zero_page = {0, 0, 0, 0};
+// Activation loads are buffer loads: an out-of-image tap (zero padding) or a chunk past the end of the
+// reduction axis gets the offset kOutOfRange, which is beyond num_records of the buffer descriptor, and the
+// hardware returns zeros -- no select, no branch, no zero page.  (A first version selected between the
+// activation pointer and a __device__ const zero page: the const object lives in the constant address
+// space, every operand load degraded to flat_load, and the compiler then waited for vmcnt(0) -- the whole
+// weight-tile latency -- before it issued the activation loads of each K-step.)
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+constexpr unsigned kOutOfRange = 0x80000000u;             // tensors on this path are < 2^31 bytes
+__device__ __forceinline__ v4i load_act(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return (v4i)__builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+}
 
 // 128-byte LDS rows hold 8 16-byte chunks; chunk ^= (row >> 1) & 7 makes every ds_read_b128 lane
 // group ({0-3,12-15,20-27}, ...) touch 16 distinct 16-byte slots of the 256-byte bank row.
@@ -127,7 +137,8 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
         ih0 = m_ok ? op * p.stride_h - p.pad_h : -(1 << 28);          // out-of-range pixel: every tap misses
         iw0 = oq * p.stride_w - p.pad_w;
     }
-    const int8_t* __restrict__ xin = x + (long)n_img * p.H * p.W * p.C;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(x), 0, p.x_bytes, 0x00020000);
+    const unsigned img_off = (unsigned)n_img * (unsigned)(p.H * p.W * p.C);
 
     // weight staging: thread -> (row = tid >> 3 (+32 per load), chunk-in-step = tid & 7)
     const int ld_row = tid >> 3, ld_chunk = tid & 7;
@@ -159,11 +170,9 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
             }
             const int ih = ih0 + tap_r * p.dil_h, iw = iw0 + tap_s * p.dil_w;
             const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const int8_t* src = ok ? xin + (unsigned)((ih * p.W + iw) * p.C + c_step * BKB + half * 16)
-                                   : reinterpret_cast<const int8_t*>(&g_zero_page) - 0;
-            const unsigned hop = ok ? 32u : 0u;           // chunks of one lane are 2 apart = 32 bytes
+            const unsigned off = ok ? img_off + (unsigned)((ih * p.W + iw) * p.C + c_step * BKB + half * 16) : kOutOfRange;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) rb[ks] = *reinterpret_cast<const v4i*>(src + ks * hop);
+            for (int ks = 0; ks < 4; ++ks) rb[ks] = load_act(xr, off + ks * 32);       // chunks of one lane are 2 apart
             if (++c_step == steps_per_tap) {
                 c_step = 0;
                 if (++tap_s == p.S) { tap_s = 0; ++tap_r; }
@@ -187,9 +196,7 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
         for (int ks = 0; ks < 4; ++ks) {
             const int ih = ih0 + q.fr * p.dil_h, iw = iw0 + q.fs * p.dil_w;
             const bool ok = gb + 2 * ks < p.chunks && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const unsigned off = ok ? (unsigned)((ih * p.W + iw) * p.C + q.cc * 16) : 0u;    // one image < 2^31 bytes
-            const v4i v = *reinterpret_cast<const v4i*>(xin + off);
-            rb[ks] = ok ? v : zero;
+            rb[ks] = load_act(xr, ok ? img_off + (unsigned)((ih * p.W + iw) * p.C + q.cc * 16) : kOutOfRange);
             red_advance(q, 2, p.c16, p.S);
         }
         pb = q;                                           // 4 x (+2) = +8: first chunk of the next K-step
@@ -515,8 +522,8 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
         return FQ_ERR_INVALID_ARG;
     const long M = (long)N * P * Q;
     if (M > 0x7fffffffL || (long)R * S * C / 16 > 0x7fffffffL) return FQ_ERR_UNSUPPORTED;
-    if ((long)H * W * C > 0x7fffffffL || (long)R * S * C > 0x7fffffffL || (long)K * P * Q > 0x1fffffffL)
-        return FQ_ERR_UNSUPPORTED;                        // 32-bit per-image / per-row offsets inside the kernel
+    if ((long)N * H * W * C >= 0x7fffffffL || (long)R * S * C > 0x7fffffffL || (long)K * P * Q > 0x1fffffffL)
+        return FQ_ERR_UNSUPPORTED;                        // 32-bit buffer / per-row offsets inside the kernel
     ConvParams p;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.P = P; p.Q = Q;
     p.stride_h = stride_h; p.stride_w = stride_w; p.pad_h = pad_h; p.pad_w = pad_w; p.dil_h = dil_h; p.dil_w = dil_w;
@@ -526,6 +533,7 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     else { p.lo = -32768.0f; p.hi = 32767.0f; p.ilo = -32768; p.ihi = 32767; }
     if (relu) p.lo = 0.0f;                                // ReLU commutes with the positive scale 2^-ob
     p.Kpad = q_nhwc ? Kpad : 0;
+    p.x_bytes = (unsigned)((long)N * H * W * C);
     hipStream_t st = as_stream(stream);
     const unsigned gx = (unsigned)((M + kTP - 1) / kTP);
     // 64-row tiles when the output is narrow, or when 128-row tiles would not even give one workgroup per CU

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity"))
 from common.quantity import _native as nat
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+I8OUT = len(sys.argv) > 2 and sys.argv[2] == "i8"      # resident mode: int8 NHWC output with fused ReLU
 # (C, H, K, R, stride, pad, count in the net)
 LAYERS = [(3, 224, 64, 7, 2, 3, 1),
           (64, 56, 64, 1, 1, 0, 1), (64, 56, 64, 3, 1, 1, 3), (64, 56, 256, 1, 1, 0, 4), (256, 56, 64, 1, 1, 0, 2),
@@ -37,10 +38,13 @@ for (C, H, K, R, st, pd, cnt) in LAYERS:
     wq = nat.pack_weight_krsc(w)
     xq = nat.quantize_i8_nhwc(x, 4, wq.shape[-1])
     P = (H + 2 * pd - R) // st + 1
-    t_c = timeit(lambda: nat.conv2d_i8(xq, wq, qb, (st, st), (pd, pd), (1, 1), 8, 4))
+    if I8OUT:
+        t_c = timeit(lambda: nat.conv2d_i8_resident(xq, wq, qb, (st, st), (pd, pd), (1, 1), 8, 4, False, True, True))
+    else:
+        t_c = timeit(lambda: nat.conv2d_i8(xq, wq, qb, (st, st), (pd, pd), (1, 1), 8, 4))
     t_q = timeit(lambda: nat.quantize_i8_nhwc(x, 4, wq.shape[-1]))
     macs = B * P * P * K * C * R * R
-    out_b = B * P * P * K * 4
+    out_b = B * P * P * K * (1 if I8OUT else 4)
     in_b = xq.numel()
     floor = (out_b + in_b) / 5.0e12 * 1e6
     print("%-34s %9.1f %9.1f %8.0f %8.1f | %9.1f %8.0f   x%d" % ("%d,%d,%d,%d,%d" % (C, H, K, R, st), t_c, 2 * macs / t_c / 1e6,
