@@ -22,6 +22,7 @@
 // waves, is staged global -> registers -> LDS (double buffered); its 128-byte rows are XOR-swizzled
 // (chunk ^= (row >> 1) & 7) so that ds_read_b128 fragment reads are bank-conflict free.
 #include <cstdlib>
+#include <type_traits>
 
 #include "fq_common.h"
 
@@ -45,6 +46,7 @@ struct ConvParams {
     int ilo, ihi;
     int Kpad;                            // channel stride of the int8 NHWC output (>= K, multiple of 16)
     unsigned x_bytes;                    // N * H * W * C: num_records of the activation buffer descriptor
+    int rs, half_rs, slo, shi;           // integer tail: shift, 2^(rs-1), Sp range; rs = 0 selects the fp32 tail
 };
 
 // Activation loads are buffer loads: an out-of-image tap (zero padding) or a chunk past the end of the
@@ -77,6 +79,27 @@ __device__ __forceinline__ float conv_tail_int(int acc, float qb, const ConvPara
 }
 __device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& p) {
     return conv_tail_int(acc, qb, p) * p.inv_ob;
+}
+// The same tail in integer arithmetic, 6 vector instructions instead of 11 (the epilogue of the
+// output-heavy 1x1 layers is bound by exactly these instructions: 64 accumulators per lane).  Valid for
+// 1 <= rs <= 16 and |acc| + 2^15 < 2^31 (checked on the host):
+//   trunc(v + copysign(0.5, v)), v = acc * 2^-rs, is round-half-away = (acc + 2^(rs-1) - (acc < 0)) >> rs
+//   with an arithmetic shift; below |acc| < 2^24 every fp32 step of the reference is exact, and from
+//   2^24 on both forms are far outside [-128, 127] (|v| >= 2^8) and saturate to the same bound.
+__device__ __forceinline__ int med3_i32(int v, int lo, int hi) {       // lo <= hi: clamp in one instruction
+    int r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ int conv_tail_i(int acc, int qb, const ConvParams& p) {
+    const int r = (acc + p.half_rs + (acc >> 31)) >> p.rs;
+    return med3_i32(med3_i32(r, p.ilo, p.ihi) + qb, p.slo, p.shi);
+}
+// bytes 0 of four registers -> one dword
+__device__ __forceinline__ unsigned pack4(int b0, int b1, int b2, int b3) {
+    const unsigned p01 = __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u);
+    const unsigned p23 = __builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x0c0c0400u);
+    return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
 }
 
 // Position of a 16-byte chunk on the reduction axis: tap (r, s) and 16-channel group cc.
@@ -118,13 +141,18 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     constexpr int A_LOADS = TK / 32;      // 16-byte chunks per thread per K-step for the weight tile
     __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * BKB];
     __shared__ float sBias[TK];
+    __shared__ int sBiasI[TK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;
     const int m0 = blockIdx.x * kTP;
     const int k0 = blockIdx.y * TK;
     const int PQ = p.P * p.Q;
-    if (tid < TK) sBias[tid] = (k0 + tid < p.K) ? qbias[k0 + tid] : 0.0f;    // visible after the first barrier
+    if (tid < TK) {                                       // visible after the first barrier
+        const float b = (k0 + tid < p.K) ? qbias[k0 + tid] : 0.0f;
+        sBias[tid] = b;
+        sBiasI[tid] = (int)b;                             // integer valued by contract
+    }
 
     // this lane's output pixel
     const int m = m0 + wave * 32 + (lane & 31);
@@ -260,57 +288,64 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
         }
     }
 
-    // epilogue: D row = k_out = (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel.  For a fixed
-    // register the 32 lanes of a half-wave write 32 consecutive pixels of one channel (128 bytes).
-    if ((kOut & kOutF32) && m_ok) {
-        // one 64-bit base per lane; the 16*MT rows are 32-bit element offsets from it (a K-tile of one
-        // image spans at most TK*PQ floats, far below 2^31)
-        float* __restrict__ out = y + ((long)n_img * p.K + k0 + 4 * half) * PQ + pq;
-        const int kmax = p.K - k0 - 4 * half;             // rows of this lane that exist
+    // epilogue: D row = k_out = (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel.  The tail runs in
+    // integer arithmetic when the host proved it equivalent (p.rs != 0), else as the reference's fp32 chain.
+    auto epilogue = [&](auto int_tail_tag) {
+        constexpr bool kIntTail = decltype(int_tail_tag)::value;
+        if ((kOut & kOutF32) && m_ok) {
+            // For a fixed register the 32 lanes of a half-wave write 32 consecutive pixels of one channel
+            // (128 bytes).  One 64-bit base per lane; the 16*MT rows are 32-bit element offsets from it (a
+            // K-tile of one image spans at most TK*PQ floats, far below 2^31)
+            float* __restrict__ out = y + ((long)n_img * p.K + k0 + 4 * half) * PQ + pq;
+            const int kmax = p.K - k0 - 4 * half;             // rows of this lane that exist
 #pragma unroll
-        for (int a = 0; a < MT; ++a) {
+            for (int a = 0; a < MT; ++a) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = a * 32 + (r & 3) + 8 * (r >> 2);          // compile-time constant
-                if (kl < kmax) out[(unsigned)(kl * PQ)] = conv_tail(acc[a][r], sBias[kl + 4 * half], p);
-            }
-        }
-    }
-    if (kOut & kOutI8) {
-        // int8 NHWC: registers 4g..4g+3 of a tile are 4 consecutive channels = one dword of this lane's
-        // pixel.  The dwords go through LDS (the weight buffers are free now) as [pixel][TK + 16 bytes]
-        // and leave as 16-byte stores, TK contiguous bytes per pixel.  Rows k >= K carry zero weights
-        // and zero bias, so the channel padding [K, Kpad) is written as zeros.
-        constexpr int OS = TK + 16;                       // LDS row stride in bytes (16-byte aligned rows)
-        static_assert(kTP * OS <= 2 * TK * BKB, "output tile must fit in the weight buffers");
-        int8_t* sO = &sA[0][0];
-        __syncthreads();                                  // every wave is done reading sA
-        const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
-#pragma unroll
-        for (int a = 0; a < MT; ++a) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                unsigned d = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kl = a * 32 + e + 8 * g;
-                    const int v = (int)conv_tail_int(acc[a][4 * g + e], sBias[kl + 4 * half], p);
-                    d |= (unsigned)(v & 0xff) << (8 * e);
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = a * 32 + (r & 3) + 8 * (r >> 2);          // compile-time constant
+                    if (kl < kmax)
+                        out[(unsigned)(kl * PQ)] = kIntTail ? (float)conv_tail_i(acc[a][r], sBiasI[kl + 4 * half], p) * p.inv_ob
+                                                            : conv_tail(acc[a][r], sBias[kl + 4 * half], p);
                 }
-                *reinterpret_cast<unsigned*>(&sO[prow + a * 32 + 8 * g]) = d;
             }
         }
-        __syncthreads();
-        constexpr int CPP = TK / 16;                      // 16-byte chunks per pixel
+        if (kOut & kOutI8) {
+            // int8 NHWC: registers 4g..4g+3 of a tile are 4 consecutive channels = one dword of this lane's
+            // pixel.  The dwords go through LDS (the weight buffers are free now) as [pixel][TK + 16 bytes]
+            // and leave as 16-byte stores, TK contiguous bytes per pixel.  Rows k >= K carry zero weights
+            // and zero bias, so the channel padding [K, Kpad) is written as zeros.
+            constexpr int OS = TK + 16;                       // LDS row stride in bytes (16-byte aligned rows)
+            static_assert(kTP * OS <= 2 * TK * BKB, "output tile must fit in the weight buffers");
+            int8_t* sO = &sA[0][0];
+            __syncthreads();                                  // every wave is done reading sA
+            const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
 #pragma unroll
-        for (int j = 0; j < (kTP * CPP) / kConvBlock; ++j) {
-            const int idx = tid + kConvBlock * j;
-            const int pix = idx / CPP, ch = idx - pix * CPP;
-            const int mm = m0 + pix, kk = k0 + 16 * ch;
-            if (mm < p.M && kk < p.Kpad)
-                *reinterpret_cast<v4i*>(q + (long)mm * p.Kpad + kk) = *reinterpret_cast<const v4i*>(&sO[pix * OS + 16 * ch]);
+            for (int a = 0; a < MT; ++a) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kl = a * 32 + e + 8 * g + 4 * half;
+                        v[e] = kIntTail ? conv_tail_i(acc[a][4 * g + e], sBiasI[kl], p)
+                                        : (int)conv_tail_int(acc[a][4 * g + e], sBias[kl], p);
+                    }
+                    *reinterpret_cast<unsigned*>(&sO[prow + a * 32 + 8 * g]) = pack4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __syncthreads();
+            constexpr int CPP = TK / 16;                      // 16-byte chunks per pixel
+#pragma unroll
+            for (int j = 0; j < (kTP * CPP) / kConvBlock; ++j) {
+                const int idx = tid + kConvBlock * j;
+                const int pix = idx / CPP, ch = idx - pix * CPP;
+                const int mm = m0 + pix, kk = k0 + 16 * ch;
+                if (mm < p.M && kk < p.Kpad)
+                    *reinterpret_cast<v4i*>(q + (long)mm * p.Kpad + kk) = *reinterpret_cast<const v4i*>(&sO[pix * OS + 16 * ch]);
+            }
         }
-    }
+    };
+    if (p.rs) epilogue(std::true_type{}); else epilogue(std::false_type{});
 }
 
 // ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
@@ -532,6 +567,11 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     if (bitwidth == 8) { p.lo = -128.0f; p.hi = 127.0f; p.ilo = -128; p.ihi = 127; }
     else { p.lo = -32768.0f; p.hi = 32767.0f; p.ilo = -32768; p.ihi = 32767; }
     if (relu) p.lo = 0.0f;                                // ReLU commutes with the positive scale 2^-ob
+    // integer tail where it is provably the same function (see conv_tail_i)
+    const bool int_tail = rs >= 1 && rs <= 16 && (long)R * S * C * 16384 + 65536 < 0x7fffffffL;
+    p.rs = int_tail ? rs : 0;
+    p.half_rs = int_tail ? 1 << (rs - 1) : 0;
+    p.slo = (int)p.lo; p.shi = (int)p.hi;
     p.Kpad = q_nhwc ? Kpad : 0;
     p.x_bytes = (unsigned)((long)N * H * W * C);
     hipStream_t st = as_stream(stream);

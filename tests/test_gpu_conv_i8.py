@@ -125,3 +125,29 @@ def test_stem_unfold_path_vs_integer_oracle(nat, oracle, C, H, W, K, R, S, st, p
     w_dev = nat.pack_weight_unfold_w(_dev(wq.astype(np.float32)), cpad2)
     got = nat.conv2d_i8(xq, w_dev, _dev(qb), (st, 1), (pd, 0), (dl, 1), 9, 3).cpu().numpy()
     np.testing.assert_array_equal(got, oracle.recon_epilogue(acc.astype(np.float32), qb, 9, 3))
+
+
+@pytest.mark.parametrize("rs", [-1, 0, 1, 2, 3, 7, 8, 15, 16, 17, 20])
+def test_conv_tail_rounding_ties_and_saturation(nat, oracle, rs):
+    """The fused tail runs in integer arithmetic for 1 <= rs <= 16 and as the reference's fp32 chain
+    otherwise; both must equal the oracle on accumulators that sit exactly on rounding ties (+-half),
+    on both sides of them, and far beyond the int8 range."""
+    C, K, H, W = 16, 64, 16, 16
+    xq = np.zeros((1, C, H, W), dtype=np.int32)
+    xq[0, 0] = np.arange(-128, 128).reshape(H, W)                     # every int8 value once
+    xq[0, 1] = 127
+    wq = np.zeros((K, C, 1, 1), dtype=np.int32)
+    wq[:, 0, 0, 0] = np.arange(K) - 32                                # acc = x * (k - 32) + 127 * w1
+    wq[:, 1, 0, 0] = np.where(np.arange(K) % 3 == 0, 127, 0)          # pushes some rows far out of range
+    qb = ((np.arange(K) % 7) - 3).astype(np.float32)
+    acc = oracle.conv2d_int(xq, wq, (1, 1), (0, 0), (1, 1))
+    x_nhwc = np.ascontiguousarray(xq.transpose(0, 2, 3, 1)).astype(np.int8)
+    w_dev = nat.pack_weight_krsc(_dev(wq.astype(np.float32)))
+    for ob in (0, 4):
+        ref = oracle.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+        got = nat.conv2d_i8(_dev(x_nhwc), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), rs, ob).cpu().numpy()
+        np.testing.assert_array_equal(got, ref)
+        y, q = nat.conv2d_i8_resident(_dev(x_nhwc), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), rs, ob, True, True, True)
+        np.testing.assert_array_equal(y.cpu().numpy(), np.maximum(ref, np.float32(0)))
+        np.testing.assert_array_equal(q.cpu().numpy().transpose(0, 3, 1, 2),
+                                      oracle.quantity(np.maximum(ref, np.float32(0)), ob).astype(np.int8))
