@@ -119,6 +119,73 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
     }
 }
 
+// kOut: bit 0 = fp32 NCHW output y (the module-boundary format), bit 1 = int8 NHWC output q (the
+// resident hand-off to the next integer layer: 1 byte per element instead of 4 written + 4 read + 1).
+constexpr int kOutF32 = 1, kOutI8 = 2;
+
+// Epilogue shared by the conv kernels.  Accumulator layout (v_mfma_i32_32x32x32_i8): D row = k_out =
+// (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel (wave*32 + lane&31 of the 128-pixel tile).  The tail
+// runs in integer arithmetic when the host proved it equivalent (kIntTail), else as the reference's fp32
+// chain.  sO: >= kTP * (TK + 16) bytes of LDS that no wave reads any more (the weight buffers).
+template <int TK, int kOut, bool kIntTail>
+__device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvParams& p, float* __restrict__ y,
+                                              int8_t* __restrict__ q, int8_t* sO, const float* sBias, const int* sBiasI, int m0,
+                                              int k0, int n_img, int pq, bool m_ok) {
+    constexpr int MT = TK / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    const int PQ = p.P * p.Q;
+    if ((kOut & kOutF32) && m_ok) {
+        // For a fixed register the 32 lanes of a half-wave write 32 consecutive pixels of one channel
+        // (128 bytes).  One 64-bit base per lane; the 16*MT rows are 32-bit element offsets from it (a
+        // K-tile of one image spans at most TK*PQ floats, far below 2^31)
+        float* __restrict__ out = y + ((long)n_img * p.K + k0 + 4 * half) * PQ + pq;
+        const int kmax = p.K - k0 - 4 * half;             // rows of this lane that exist
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = a * 32 + (r & 3) + 8 * (r >> 2);          // compile-time constant
+                if (kl < kmax)
+                    out[(unsigned)(kl * PQ)] = kIntTail ? (float)conv_tail_i(acc[a][r], sBiasI[kl + 4 * half], p) * p.inv_ob
+                                                        : conv_tail(acc[a][r], sBias[kl + 4 * half], p);
+            }
+        }
+    }
+    if (kOut & kOutI8) {
+        // int8 NHWC: registers 4g..4g+3 of a tile are 4 consecutive channels = one dword of this lane's
+        // pixel.  The dwords go through LDS as [pixel][TK + 16 bytes] and leave as 16-byte stores, TK
+        // contiguous bytes per pixel.  Rows k >= K carry zero weights and zero bias, so the channel
+        // padding [K, Kpad) is written as zeros.
+        constexpr int OS = TK + 16;                       // LDS row stride in bytes (16-byte aligned rows)
+        __syncthreads();                                  // every wave is done reading the operand tiles
+        const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kl = a * 32 + e + 8 * g + 4 * half;
+                    v[e] = kIntTail ? conv_tail_i(acc[a][4 * g + e], sBiasI[kl], p)
+                                    : (int)conv_tail_int(acc[a][4 * g + e], sBias[kl], p);
+                }
+                *reinterpret_cast<unsigned*>(&sO[prow + a * 32 + 8 * g]) = pack4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        constexpr int CPP = TK / 16;                      // 16-byte chunks per pixel
+#pragma unroll
+        for (int j = 0; j < (kTP * CPP) / kConvBlock; ++j) {
+            const int idx = tid + kConvBlock * j;
+            const int pix = idx / CPP, ch = idx - pix * CPP;
+            const int mm = m0 + pix, kk = k0 + 16 * ch;
+            if (mm < p.M && kk < p.Kpad)
+                *reinterpret_cast<v4i*>(q + (long)mm * p.Kpad + kk) = *reinterpret_cast<const v4i*>(&sO[pix * OS + 16 * ch]);
+        }
+    }
+}
+
 // Workgroup = 4 waves side by side along the pixel axis: wave w owns pixels [32w, 32w+32) of the
 // 128-pixel tile and ALL TK output channels (MT = TK/32 accumulator tiles).
 //   * activations (MFMA B operand) never touch LDS: lane l holds pixel (l & 31) and loads, per 32-deep
@@ -129,9 +196,6 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
 // kC128: C % 128 == 0 and K % TK == 0 -- every K-step then lies inside one tap and every weight row /
 // chunk exists, so the per-step index arithmetic collapses to one tap update and pointer increments
 // (the general path spends ~260 VALU instructions per K-step on it, against 16 MFMAs).
-// kOut: bit 0 = fp32 NCHW output y (the module-boundary format), bit 1 = int8 NHWC output q (the
-// resident hand-off to the next integer layer: 1 byte per element instead of 4 written + 4 read + 1).
-constexpr int kOutF32 = 1, kOutI8 = 2;
 template <int TK, bool kC128, int kOut>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                const float* __restrict__ qbias, float* __restrict__ y,
@@ -288,64 +352,164 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
         }
     }
 
-    // epilogue: D row = k_out = (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel.  The tail runs in
-    // integer arithmetic when the host proved it equivalent (p.rs != 0), else as the reference's fp32 chain.
-    auto epilogue = [&](auto int_tail_tag) {
-        constexpr bool kIntTail = decltype(int_tail_tag)::value;
-        if ((kOut & kOutF32) && m_ok) {
-            // For a fixed register the 32 lanes of a half-wave write 32 consecutive pixels of one channel
-            // (128 bytes).  One 64-bit base per lane; the 16*MT rows are 32-bit element offsets from it (a
-            // K-tile of one image spans at most TK*PQ floats, far below 2^31)
-            float* __restrict__ out = y + ((long)n_img * p.K + k0 + 4 * half) * PQ + pq;
-            const int kmax = p.K - k0 - 4 * half;             // rows of this lane that exist
+    static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the int8 output tile is staged in the weight buffers");
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
+}
+
+// ---- C % 128 == 0, K % TK == 0: activations by LDS-DMA ------------------------------------------------
+// The kernel above loads the activation operand straight into MFMA layout: lane = pixel, 16 bytes per
+// lane, so the 64 lanes of one load touch 64 different 64-byte sectors and the vector L1 spends one tag
+// lookup per lane.  rocprofv3 on the 3x3 256->256 14x14 layer (batch 128): 37 L1 accesses per wave-load,
+// L1 busy 73 % of the kernel, waves parked 58 %, MFMA busy 18 %, L2 latency 205 cycles -- neither a
+// two-deep register prefetch nor pinned ds_read/MFMA interleave moved it, because the limiter is L1
+// request throughput, not latency.  Here 8 adjacent lanes fetch the 8 chunks (128 contiguous bytes) of one
+// pixel's K-step, so a wave-load touches 8 full lines, and `buffer_load_dwordx4 ... lds` drops the data
+// into LDS without passing through registers (lane l lands at base + 16*l).  The XOR swizzle that makes
+// the MFMA-layout ds_read_b128 conflict free is applied on the global side: LDS position c of pixel row p
+// receives chunk c ^ ((p >> 1) & 7).  Out-of-image taps use an offset beyond num_records and arrive as zeros.
+// Each wave stages only the 32 pixels it multiplies itself, so the activation tile needs no extra barrier:
+// the wave's own vmcnt(0), then the step's workgroup barrier (which the weight tile needs anyway).
+template <int TK, int kOut>
+__global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                                   const float* __restrict__ qbias, float* __restrict__ y,
+                                                                   int8_t* __restrict__ q, const ConvParams p) {
+    constexpr int BKB = 128;
+    constexpr int MT = TK / 32;
+    constexpr int A_LOADS = TK / 32;
+    __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * BKB];
+    __shared__ __attribute__((aligned(16))) int8_t sB[2][kTP * BKB];
+    __shared__ float sBias[TK];
+    __shared__ int sBiasI[TK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5;
+    const int m0 = blockIdx.x * kTP;
+    const int k0 = blockIdx.y * TK;
+    const int PQ = p.P * p.Q;
+    if (tid < TK) {                                       // visible after the first barrier
+        const float b = qbias[k0 + tid];
+        sBias[tid] = b;
+        sBiasI[tid] = (int)b;
+    }
+
+    // output pixel of this lane in MFMA layout (used by the fp32 epilogue)
+    const int m = m0 + wave * 32 + (lane & 31);
+    const bool m_ok = m < p.M;
+    int n_img = 0, pq = 0;
+    if (kOut & kOutF32) {
+        const int mm = m_ok ? m : 0;
+        n_img = mm / PQ; pq = mm - n_img * PQ;
+    }
+
+    // staging: in load j this lane fetches pixel row pj = 8j + (lane >> 3) of the wave's 32, LDS position
+    // lane & 7, i.e. global chunk (lane & 7) ^ swz(pj)
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(x), 0, p.x_bytes, 0x00020000);
+    int ih0[4], iw0[4];
+    unsigned boff[4];                                     // image base + chunk byte offset inside a K-step
 #pragma unroll
-            for (int a = 0; a < MT; ++a) {
+    for (int j = 0; j < 4; ++j) {
+        const int pj = 8 * j + (lane >> 3);
+        const int mj = m0 + wave * 32 + pj;
+        const bool ok = mj < p.M;
+        const int mm = ok ? mj : 0;
+        const int nj = mm / PQ, pqj = mm - nj * PQ;
+        const int op = pqj / p.Q, oq = pqj - op * p.Q;
+        ih0[j] = ok ? op * p.stride_h - p.pad_h : -(1 << 28);         // out-of-range pixel: every tap misses
+        iw0[j] = oq * p.stride_w - p.pad_w;
+        boff[j] = (unsigned)nj * (unsigned)(p.H * p.W * p.C) + (unsigned)(((lane & 7) ^ swz(pj, 0)) * 16);
+    }
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+
+    // weight staging as in the kernel above: thread -> (row = tid >> 3 (+32 per load), chunk = tid & 7)
+    const int ld_row = tid >> 3, ld_chunk = tid & 7;
+    const int8_t* wp[A_LOADS];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = a * 32 + (r & 3) + 8 * (r >> 2);          // compile-time constant
-                    if (kl < kmax)
-                        out[(unsigned)(kl * PQ)] = kIntTail ? (float)conv_tail_i(acc[a][r], sBiasI[kl + 4 * half], p) * p.inv_ob
-                                                            : conv_tail(acc[a][r], sBias[kl + 4 * half], p);
-                }
-            }
+    for (int j = 0; j < A_LOADS; ++j) wp[j] = w + ((long)(k0 + ld_row + 32 * j) * p.chunks + ld_chunk) * 16;
+
+    v4i ra[A_LOADS];
+    int tap_r = 0, tap_s = 0, c_step = 0;                 // current tap (uniform) and K-step inside it
+    const int steps_per_tap = p.C >> 7;
+    auto load_step = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j) {
+            ra[j] = *reinterpret_cast<const v4i*>(wp[j]);
+            wp[j] += BKB;
         }
-        if (kOut & kOutI8) {
-            // int8 NHWC: registers 4g..4g+3 of a tile are 4 consecutive channels = one dword of this lane's
-            // pixel.  The dwords go through LDS (the weight buffers are free now) as [pixel][TK + 16 bytes]
-            // and leave as 16-byte stores, TK contiguous bytes per pixel.  Rows k >= K carry zero weights
-            // and zero bias, so the channel padding [K, Kpad) is written as zeros.
-            constexpr int OS = TK + 16;                       // LDS row stride in bytes (16-byte aligned rows)
-            static_assert(kTP * OS <= 2 * TK * BKB, "output tile must fit in the weight buffers");
-            int8_t* sO = &sA[0][0];
-            __syncthreads();                                  // every wave is done reading sA
-            const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
 #pragma unroll
-            for (int a = 0; a < MT; ++a) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    int v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int kl = a * 32 + e + 8 * g + 4 * half;
-                        v[e] = kIntTail ? conv_tail_i(acc[a][4 * g + e], sBiasI[kl], p)
-                                        : (int)conv_tail_int(acc[a][4 * g + e], sBias[kl], p);
-                    }
-                    *reinterpret_cast<unsigned*>(&sO[prow + a * 32 + 8 * g]) = pack4(v[0], v[1], v[2], v[3]);
-                }
-            }
-            __syncthreads();
-            constexpr int CPP = TK / 16;                      // 16-byte chunks per pixel
-#pragma unroll
-            for (int j = 0; j < (kTP * CPP) / kConvBlock; ++j) {
-                const int idx = tid + kConvBlock * j;
-                const int pix = idx / CPP, ch = idx - pix * CPP;
-                const int mm = m0 + pix, kk = k0 + 16 * ch;
-                if (mm < p.M && kk < p.Kpad)
-                    *reinterpret_cast<v4i*>(q + (long)mm * p.Kpad + kk) = *reinterpret_cast<const v4i*>(&sO[pix * OS + 16 * ch]);
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int ih = ih0[j] + tap_r * p.dil_h, iw = iw0[j] + tap_s * p.dil_w;
+            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned off = ok ? boff[j] + (unsigned)((ih * p.W + iw) * p.C + c_step * BKB) : kOutOfRange;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)&sB[buf][(wave * 32 + 8 * j) * BKB], 16, (int)off, 0, 0, 0);
+        }
+        if (++c_step == steps_per_tap) {
+            c_step = 0;
+            if (++tap_s == p.S) { tap_s = 0; ++tap_r; }
         }
     };
-    if (p.rs) epilogue(std::true_type{}); else epilogue(std::false_type{});
+    auto store_a = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j) {
+            const int row = ld_row + 32 * j;
+            *reinterpret_cast<v4i*>(&sA[buf][row * BKB + swz(row, ld_chunk) * 16]) = ra[j];
+        }
+    };
+
+    v16i acc[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0;
+
+    int a_off[MT], swz_off[4];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) a_off[a] = (a * 32 + (lane & 31)) * BKB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) swz_off[ks] = ((ks * 2 + half) ^ (((lane & 31) >> 1) & 7)) * 16;
+    const int b_row = (wave * 32 + (lane & 31)) * BKB;    // this lane's pixel row in the activation tile
+
+    v4i fb[4];
+    auto read_b = [&](int buf) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const v4i*>(&sB[buf][b_row + swz_off[ks]]);
+    };
+
+    const int nsteps = p.chunks >> 3;
+    load_step(0);
+    store_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA rows have landed
+    __syncthreads();
+    read_b(0);
+    for (int step = 0; step < nsteps; ++step) {
+        const int cur = step & 1;
+        if (step + 1 < nsteps) load_step(cur ^ 1);        // next step's operands fly under the MFMAs
+        v4i fa[2][MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+            fa[0][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[0]]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+                    fa[(ks + 1) & 1][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[ks + 1]]);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+                acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks], acc[a], 0, 0, 0);
+        }
+        if (step + 1 < nsteps) {
+            store_a(cur ^ 1);                             // the other buffers were last read one barrier ago
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            read_b(cur ^ 1);
+        }
+    }
+
+    static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the int8 output tile is staged in the weight buffers");
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
 }
 
 // ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
@@ -528,6 +692,17 @@ extern "C" int fq_quantize_i8_unfold_w(const float* x_nchw, int8_t* y, int N, in
 
 namespace fq {
 
+template <int TK>
+static void launch_conv_dma(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
+                            int8_t* q, const ConvParams& p) {
+    if (y && q)
+        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutF32 | kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else if (q)
+        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else
+        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutF32>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+}
+
 template <int TK, bool kC128>
 static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
                              int8_t* q, const ConvParams& p) {
@@ -578,13 +753,18 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     const unsigned gx = (unsigned)((M + kTP - 1) / kTP);
     // 64-row tiles when the output is narrow, or when 128-row tiles would not even give one workgroup per CU
     const long wg128 = (long)gx * ((K + 127) / 128);
+    static const bool use_dma = [] { const char* e = getenv("FQ_CONV_DMA"); return !(e && e[0] == '0'); }();
     if (K <= 64 || wg128 < kCUs) {
-        if (C % 128 == 0 && K % 64 == 0)
+        if (C % 128 == 0 && K % 64 == 0 && use_dma)
+            launch_conv_dma<64>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
+        else if (C % 128 == 0 && K % 64 == 0)
             launch_conv_tile<64, true>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else
             launch_conv_tile<64, false>(dim3(gx, (K + 63) / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
     } else {
-        if (C % 128 == 0 && K % 128 == 0)
+        if (C % 128 == 0 && K % 128 == 0 && use_dma)
+            launch_conv_dma<128>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
+        else if (C % 128 == 0 && K % 128 == 0)
             launch_conv_tile<128, true>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else
             launch_conv_tile<128, false>(dim3(gx, (K + 127) / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
