@@ -28,6 +28,20 @@
 
 namespace fq {
 
+// Debug build only (-DFQ_CONV_TRACE, libfq_hip_trace.so): s_memtime stamps of one wave of a few workgroups,
+// read back with fq_debug_read_trace (scripts/conv_trace.py).  Never part of libfq_hip.so.
+#ifdef FQ_CONV_TRACE
+__device__ unsigned long long g_trace[8192];
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define TR(slot) do { if (trace_on) { unsigned long long t__ = stamp(); if (lane == 0) g_trace[trace_base + (slot)] = t__; } } while (0)
+#else
+#define TR(slot) do {} while (0)
+#endif
+
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
@@ -47,6 +61,7 @@ struct ConvParams {
     int Kpad;                            // channel stride of the int8 NHWC output (>= K, multiple of 16)
     unsigned x_bytes;                    // N * H * W * C: num_records of the activation buffer descriptor
     int rs, half_rs, slo, shi;           // integer tail: shift, 2^(rs-1), Sp range; rs = 0 selects the fp32 tail
+    unsigned w_bytes;                    // K * R * S * C: num_records of the weight buffer descriptor
 };
 
 // Activation loads are buffer loads: an out-of-image tap (zero padding) or a chunk past the end of the
@@ -357,19 +372,27 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
 }
 
-// ---- C % 128 == 0, K % TK == 0: activations by LDS-DMA ------------------------------------------------
+// ---- C % 128 == 0, K % TK == 0: both operands by LDS-DMA ----------------------------------------------
 // The kernel above loads the activation operand straight into MFMA layout: lane = pixel, 16 bytes per
 // lane, so the 64 lanes of one load touch 64 different 64-byte sectors and the vector L1 spends one tag
-// lookup per lane.  rocprofv3 on the 3x3 256->256 14x14 layer (batch 128): 37 L1 accesses per wave-load,
-// L1 busy 73 % of the kernel, waves parked 58 %, MFMA busy 18 %, L2 latency 205 cycles -- neither a
-// two-deep register prefetch nor pinned ds_read/MFMA interleave moved it, because the limiter is L1
-// request throughput, not latency.  Here 8 adjacent lanes fetch the 8 chunks (128 contiguous bytes) of one
-// pixel's K-step, so a wave-load touches 8 full lines, and `buffer_load_dwordx4 ... lds` drops the data
-// into LDS without passing through registers (lane l lands at base + 16*l).  The XOR swizzle that makes
-// the MFMA-layout ds_read_b128 conflict free is applied on the global side: LDS position c of pixel row p
-// receives chunk c ^ ((p >> 1) & 7).  Out-of-image taps use an offset beyond num_records and arrive as zeros.
-// Each wave stages only the 32 pixels it multiplies itself, so the activation tile needs no extra barrier:
-// the wave's own vmcnt(0), then the step's workgroup barrier (which the weight tile needs anyway).
+// lookup per lane (rocprofv3, 3x3 256->256 14x14 layer at batch 128: 37 L1 accesses per wave-load, L1 busy
+// 73 % of the kernel).  An s_memtime trace of one wave of that kernel (FQ_CONV_TRACE build,
+// scripts/conv_trace.py) showed the K-step as a serial chain at one wave per SIMD: ~700 cycles issuing 8
+// loads and their address arithmetic, ~900 in the MFMA phase (512 of matrix work plus exposed ds_read
+// latency), ~330 waiting for the loads, ~280 staging the weight tile registers -> LDS, ~360 in the barrier,
+// ~220 re-reading the activation fragments: 2 800 cycles per 512 cycles of MFMA.  This variant removes the
+// links one by one:
+//   * both tiles arrive by `buffer_load_dwordx4 ... lds` (no staging registers, no ds_write): 8 adjacent
+//     lanes fetch the 8 chunks (128 contiguous bytes) of one row, so a wave-load touches 8 full lines, and
+//     lane l lands at LDS base + 16*l.  The XOR swizzle that makes the MFMA-layout ds_read_b128 conflict
+//     free is applied on the global side: LDS position c of row r receives chunk c ^ ((r >> 1) & 7);
+//   * the K-step advance is the scalar offset of the buffer instruction (no vector arithmetic per step);
+//     the per-lane offsets are recomputed only when the filter tap changes (every C / 128 steps).
+//     Out-of-image taps use an offset beyond num_records and arrive as zeros;
+//   * fragment reads are pinned ahead of the MFMAs that use them (sched_group_barrier), so ds_read
+//     latency hides under the matrix pipe.
+// Each wave stages the activation rows it multiplies itself and a quarter of the weight tile; one
+// vmcnt(0) + workgroup barrier per K-step orders the DMA writes before the next step's reads.
 template <int TK, int kOut>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                    const float* __restrict__ qbias, float* __restrict__ y,
@@ -381,12 +404,18 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     __shared__ __attribute__((aligned(16))) int8_t sB[2][kTP * BKB];
     __shared__ float sBias[TK];
     __shared__ int sBiasI[TK];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;
     const int m0 = blockIdx.x * kTP;
     const int k0 = blockIdx.y * TK;
     const int PQ = p.P * p.Q;
+#ifdef FQ_CONV_TRACE
+    const bool trace_on = (blockIdx.x % 37 == 5) && blockIdx.y == 0 && wave == 1 && blockIdx.x < 37 * 8;
+    const int trace_base = (blockIdx.x / 37) * 512;
+#endif
+    TR(0);
     if (tid < TK) {                                       // visible after the first barrier
         const float b = qbias[k0 + tid];
         sBias[tid] = b;
@@ -402,8 +431,8 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
         n_img = mm / PQ; pq = mm - n_img * PQ;
     }
 
-    // staging: in load j this lane fetches pixel row pj = 8j + (lane >> 3) of the wave's 32, LDS position
-    // lane & 7, i.e. global chunk (lane & 7) ^ swz(pj)
+    // activation staging: in load j this lane fetches pixel row pj = 8j + (lane >> 3) of the wave's 32 and
+    // LDS position lane & 7, i.e. global chunk (lane & 7) ^ swz(pj)
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(x), 0, p.x_bytes, 0x00020000);
     int ih0[4], iw0[4];
     unsigned boff[4];                                     // image base + chunk byte offset inside a K-step
@@ -419,40 +448,38 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
         iw0[j] = oq * p.stride_w - p.pad_w;
         boff[j] = (unsigned)nj * (unsigned)(p.H * p.W * p.C) + (unsigned)(((lane & 7) ^ swz(pj, 0)) * 16);
     }
-    typedef __attribute__((address_space(3))) void* lds_ptr;
-
-    // weight staging as in the kernel above: thread -> (row = tid >> 3 (+32 per load), chunk = tid & 7)
-    const int ld_row = tid >> 3, ld_chunk = tid & 7;
-    const int8_t* wp[A_LOADS];
+    // weight staging: load j of wave v covers tile rows 32j + 8v .. +7 (one 128-byte K-step row per 8 lanes)
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(w), 0, p.w_bytes, 0x00020000);
+    unsigned aoff[A_LOADS];
 #pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) wp[j] = w + ((long)(k0 + ld_row + 32 * j) * p.chunks + ld_chunk) * 16;
+    for (int j = 0; j < A_LOADS; ++j) {
+        const int row = 32 * j + 8 * wave + (lane >> 3);
+        aoff[j] = (unsigned)(k0 + row) * ((unsigned)p.chunks * 16u) + (unsigned)(((lane & 7) ^ swz(row, 0)) * 16);
+    }
 
-    v4i ra[A_LOADS];
-    int tap_r = 0, tap_s = 0, c_step = 0;                 // current tap (uniform) and K-step inside it
+    int tap_r = 0, tap_s = 0, c_step = 0;                 // filter tap (uniform) and K-step inside it
     const int steps_per_tap = p.C >> 7;
-    auto load_step = [&](int buf) {
+    unsigned bvo[4];                                      // activation offsets of the current tap
+    auto issue_step = [&](int buf, int step) {            // K-step `step` -> LDS buffers `buf`
 #pragma unroll
-        for (int j = 0; j < A_LOADS; ++j) {
-            ra[j] = *reinterpret_cast<const v4i*>(wp[j]);
-            wp[j] += BKB;
+        for (int j = 0; j < A_LOADS; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)&sA[buf][(32 * j + 8 * wave) * BKB], 16, (int)aoff[j],
+                                                     step * BKB, 0, 0);
+        if (c_step == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ih = ih0[j] + tap_r * p.dil_h, iw = iw0[j] + tap_s * p.dil_w;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                bvo[j] = ok ? boff[j] + (unsigned)((ih * p.W + iw) * p.C) : kOutOfRange;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int ih = ih0[j] + tap_r * p.dil_h, iw = iw0[j] + tap_s * p.dil_w;
-            const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const unsigned off = ok ? boff[j] + (unsigned)((ih * p.W + iw) * p.C + c_step * BKB) : kOutOfRange;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)&sB[buf][(wave * 32 + 8 * j) * BKB], 16, (int)off, 0, 0, 0);
-        }
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)&sB[buf][(wave * 32 + 8 * j) * BKB], 16, (int)bvo[j],
+                                                     c_step * BKB, 0, 0);
         if (++c_step == steps_per_tap) {
             c_step = 0;
             if (++tap_s == p.S) { tap_s = 0; ++tap_r; }
-        }
-    };
-    auto store_a = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < A_LOADS; ++j) {
-            const int row = ld_row + 32 * j;
-            *reinterpret_cast<v4i*>(&sA[buf][row * BKB + swz(row, ld_chunk) * 16]) = ra[j];
         }
     };
 
@@ -469,47 +496,55 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     for (int ks = 0; ks < 4; ++ks) swz_off[ks] = ((ks * 2 + half) ^ (((lane & 31) >> 1) & 7)) * 16;
     const int b_row = (wave * 32 + (lane & 31)) * BKB;    // this lane's pixel row in the activation tile
 
-    v4i fb[4];
-    auto read_b = [&](int buf) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const v4i*>(&sB[buf][b_row + swz_off[ks]]);
-    };
-
     const int nsteps = p.chunks >> 3;
-    load_step(0);
-    store_a(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA rows have landed
-    __syncthreads();
-    read_b(0);
+    TR(1);
+    issue_step(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA rows have landed ...
+    __syncthreads();                                      // ... and so have everybody else's
+    TR(2);
     for (int step = 0; step < nsteps; ++step) {
         const int cur = step & 1;
-        if (step + 1 < nsteps) load_step(cur ^ 1);        // next step's operands fly under the MFMAs
-        v4i fa[2][MT];
+        TR(8 + step * 8 + 0);
+        if (step + 1 < nsteps) issue_step(cur ^ 1, step + 1);          // next step's tiles fly under the MFMAs
+        TR(8 + step * 8 + 1);
+        v4i fb[4], fa[4][MT];
 #pragma unroll
-        for (int a = 0; a < MT; ++a)
-            fa[0][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[0]]);
+        for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const v4i*>(&sB[cur][b_row + swz_off[ks]]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks < 3) {
-#pragma unroll
-                for (int a = 0; a < MT; ++a)
-                    fa[(ks + 1) & 1][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[ks + 1]]);
-            }
+        for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int a = 0; a < MT; ++a)
-                acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks], acc[a], 0, 0, 0);
+                fa[ks][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[ks]]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+                acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks][a], fb[ks], acc[a], 0, 0, 0);
+#ifndef FQ_CONV_TRACE
+        // issue order: the 4 activation fragments and half of the weight fragments, then one read behind
+        // each MFMA (left alone, hipcc sinks every read to just above its MFMA and waits lgkmcnt(0) each time)
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * MT, 0);
+#pragma unroll
+        for (int i = 0; i < 2 * MT; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT, 0);
+#endif
+        TR(8 + step * 8 + 2);
         if (step + 1 < nsteps) {
-            store_a(cur ^ 1);                             // the other buffers were last read one barrier ago
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            TR(8 + step * 8 + 3);
             __syncthreads();
-            read_b(cur ^ 1);
+            TR(8 + step * 8 + 4);
         }
     }
+    TR(3);
 
     static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the int8 output tile is staged in the weight buffers");
     if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
     else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
+    TR(4);
 }
 
 // ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
@@ -732,7 +767,7 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
         return FQ_ERR_INVALID_ARG;
     const long M = (long)N * P * Q;
     if (M > 0x7fffffffL || (long)R * S * C / 16 > 0x7fffffffL) return FQ_ERR_UNSUPPORTED;
-    if ((long)N * H * W * C >= 0x7fffffffL || (long)R * S * C > 0x7fffffffL || (long)K * P * Q > 0x1fffffffL)
+    if ((long)N * H * W * C >= 0x7fffffffL || (long)K * R * S * C >= 0x7fffffffL || (long)K * P * Q > 0x1fffffffL)
         return FQ_ERR_UNSUPPORTED;                        // 32-bit buffer / per-row offsets inside the kernel
     ConvParams p;
     p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.R = R; p.S = S; p.P = P; p.Q = Q;
@@ -749,12 +784,19 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     p.slo = (int)p.lo; p.shi = (int)p.hi;
     p.Kpad = q_nhwc ? Kpad : 0;
     p.x_bytes = (unsigned)((long)N * H * W * C);
+    p.w_bytes = (unsigned)((long)K * R * S * C);
     hipStream_t st = as_stream(stream);
     const unsigned gx = (unsigned)((M + kTP - 1) / kTP);
     // 64-row tiles when the output is narrow, or when 128-row tiles would not even give one workgroup per CU
     const long wg128 = (long)gx * ((K + 127) / 128);
-    static const bool use_dma = [] { const char* e = getenv("FQ_CONV_DMA"); return !(e && e[0] == '0'); }();
-    if (K <= 64 || wg128 < kCUs) {
+    // Deep reductions (>= 8 K-steps: the 3x3 layers and the wide 1x1 reductions) are bound by L1/L2 request
+    // throughput and run faster with coalesced LDS-DMA staging; shallow ones are output-bound, and there the
+    // register-staged kernel's smaller LDS footprint (3 workgroups per CU instead of 2) wins.  Measured per
+    // layer on ResNet-50 at batch 128 (scripts/conv_bench.py); FQ_CONV_DMA=0/1 forces one of them.
+    static const int dma_env = [] { const char* e = getenv("FQ_CONV_DMA"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+    const bool use_dma = dma_env < 0 ? (p.chunks >> 3) >= 8 : dma_env == 1;
+    static const int force_tk = [] { const char* e = getenv("FQ_CONV_TK"); return e ? atoi(e) : 0; }();
+    if ((K <= 64 || wg128 < kCUs || force_tk == 64) && force_tk != 128) {
         if (C % 128 == 0 && K % 64 == 0 && use_dma)
             launch_conv_dma<64>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else if (C % 128 == 0 && K % 64 == 0)
@@ -790,3 +832,11 @@ extern "C" int fq_conv2d_i8_resident(const int8_t* x_nhwc, const int8_t* w_krsc,
     return conv2d_i8_dispatch(x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, Kpad, relu, N, H, W, C, K, R, S, stride_h, stride_w, pad_h,
                               pad_w, dil_h, dil_w, rs, ob, 8, stream);
 }
+
+#ifdef FQ_CONV_TRACE
+extern "C" int fq_debug_read_trace(unsigned long long* host_out) {
+    FQ_HIP_CHECK(hipDeviceSynchronize());
+    FQ_HIP_CHECK(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(fq::g_trace), sizeof(unsigned long long) * 8192));
+    return FQ_OK;
+}
+#endif
