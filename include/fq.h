@@ -190,6 +190,18 @@ int fq_add_resident(const void* x, int x_bytes, int gx, const void* y, int y_byt
 int fq_dequant_nhwc_to_nchw(const void* q_nhwc, int q_bytes, int g, float* y_nchw, int N, int C, int HW,
                             int Cpad, fq_stream_t stream);
 
+/* nn.MaxPool2d (dilation 1, ceil_mode False) on a resident int8 NHWC activation: max commutes with the
+ * monotone de-quantisation, so y = maxpool(x) on the integers; padding acts as -inf (2*pad <= kernel).
+ * x: int8 [N][H][W][Cpad], y: int8 [N][P][Q][Cpad], P = (H + 2*ph - kh)/sh + 1, Cpad % 16 == 0. */
+int fq_maxpool_i8_nhwc(const int8_t* x, int8_t* y, int N, int H, int W, int Cpad, int kh, int kw, int sh,
+                       int sw, int ph, int pw, fq_stream_t stream);
+
+/* Global average pooling (nn.AvgPool2d whose window is the whole plane) on a resident activation:
+ *   y[n][c] = ((float)(sum_hw q[n][hw][c]) * 2^-g) / HW      -- fp32 [N][C]; every partial sum of torch's fp32
+ * accumulation is exact here (HW * 2^15 < 2^24, else FQ_ERR_UNSUPPORTED), so this is the same number. */
+int fq_avgpool_global_nhwc(const void* q_nhwc, int q_bytes, int g, float* y, int N, int C, int HW, int Cpad,
+                           fq_stream_t stream);
+
 /* ---- output files ------------------------------------------------------------------------------ */
 
 /* HOST helper: write an int32 array as nested JSON lists, byte-identical to Python's

@@ -193,3 +193,110 @@ extern "C" int fq_dequant_nhwc_to_nchw(const void* q_nhwc, int q_bytes, int g, f
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }
+
+// ---- pooling layers between integer layers ----------------------------------------------------------
+namespace fq {
+
+// nn.MaxPool2d on a resident int8 NHWC activation.  max commutes with the (monotone) de-quantisation
+// q -> q * 2^-g, so pooling the integers gives exactly the integers of the pooled fp32 tensor.  Padding
+// behaves as -inf (torch): a window always holds at least one real element (pad <= kernel / 2).
+// One thread = 16 channels of one output pixel.
+__global__ __launch_bounds__(kResBlock) void maxpool_i8_nhwc_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int H, int W,
+                                                                    int C16, int P, int Q, int kh, int kw, int sh, int sw, int ph,
+                                                                    int pw, size_t total) {
+    size_t i = (size_t)blockIdx.x * kResBlock + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * kResBlock;
+    for (; i < total; i += stride) {                      // i = ((n*P + p)*Q + q)*C16 + c16
+        const int c16 = (int)(i % C16);
+        size_t r = i / C16;
+        const int oq = (int)(r % Q); r /= Q;
+        const int op = (int)(r % P);
+        const size_t n = r / P;
+        int m[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) m[e] = -128;
+        const int ih0 = op * sh - ph, iw0 = oq * sw - pw;
+        for (int a = 0; a < kh; ++a) {
+            const int ih = ih0 + a;
+            if ((unsigned)ih >= (unsigned)H) continue;
+            for (int b = 0; b < kw; ++b) {
+                const int iw = iw0 + b;
+                if ((unsigned)iw >= (unsigned)W) continue;
+                Vec16<int8_t> v;
+                v.load(x + (((n * H + ih) * W + iw) * C16 + c16) * 16);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int t = (int)(int8_t)(((unsigned)v.a[e >> 2]) >> (8 * (e & 3)));
+                    m[e] = t > m[e] ? t : m[e];
+                }
+            }
+        }
+        v4i_r o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            o[d] = (int)(((unsigned)m[4 * d] & 0xffu) | (((unsigned)m[4 * d + 1] & 0xffu) << 8) |
+                         (((unsigned)m[4 * d + 2] & 0xffu) << 16) | (((unsigned)m[4 * d + 3] & 0xffu) << 24));
+        *reinterpret_cast<v4i_r*>(y + i * 16) = o;
+    }
+}
+
+// Global average pooling (nn.AvgPool2d whose kernel covers the whole plane) on a resident activation:
+//   y[n][c] = (sum_hw q[n][hw][c]) * 2^-g / HW.
+// torch accumulates the window in fp32 and divides once; every partial sum here is an integer multiple of
+// 2^-g below 2^24 * 2^-g, i.e. exact in fp32 in any order, so the integer sum, one scaling by a power of two
+// and one correctly rounded fp32 division reproduce it bit for bit (HW * 2^15 < 2^24 is checked by the host).
+// One workgroup = 64 channels of one image; 4 pixel phases x 64 channels, reduced through LDS.
+template <typename T>
+__global__ __launch_bounds__(kResBlock) void avgpool_global_nhwc_kernel(const T* __restrict__ q, float* __restrict__ y, int C, int HW,
+                                                                        int Cpad, float scale, float divisor) {
+    __shared__ int part[4][64];
+    const int n = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    int s = 0;
+    if (c < Cpad)
+        for (int hw = ph; hw < HW; hw += 4) s += (int)q[((size_t)n * HW + hw) * Cpad + c];
+    part[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && c < C) {
+        const int t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+        y[(size_t)n * C + c] = ((float)t * scale) / divisor;
+    }
+}
+
+}  // namespace fq
+
+extern "C" int fq_maxpool_i8_nhwc(const int8_t* x, int8_t* y, int N, int H, int W, int Cpad, int kh, int kw, int sh, int sw,
+                                  int ph, int pw, fq_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || Cpad <= 0 || (Cpad & 15) || kh <= 0 || kw <= 0 || sh <= 0 || sw <= 0 || ph < 0 || pw < 0)
+        return FQ_ERR_INVALID_ARG;
+    if (2 * ph > kh || 2 * pw > kw) return FQ_ERR_INVALID_ARG;           // torch's own constraint: no empty windows
+    const int P = (H + 2 * ph - kh) / sh + 1, Q = (W + 2 * pw - kw) / sw + 1;
+    if (P <= 0 || Q <= 0) return FQ_ERR_INVALID_ARG;
+    if (N == 0) return FQ_OK;
+    if (!x || !y || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u)) return FQ_ERR_INVALID_ARG;
+    const size_t total = (size_t)N * P * Q * (Cpad / 16);
+    hipLaunchKernelGGL(maxpool_i8_nhwc_kernel, dim3(res_grid(total)), dim3(kResBlock), 0, as_stream(stream), x, y, H, W, Cpad / 16, P,
+                       Q, kh, kw, sh, sw, ph, pw, total);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_avgpool_global_nhwc(const void* q_nhwc, int q_bytes, int g, float* y, int N, int C, int HW, int Cpad,
+                                      fq_stream_t stream) {
+    if ((q_bytes != 1 && q_bytes != 2) || g < -120 || g > 120) return FQ_ERR_INVALID_ARG;
+    if (N < 0 || C <= 0 || HW <= 0 || Cpad < C || (Cpad & 15)) return FQ_ERR_INVALID_ARG;
+    if ((long)HW * 32768 >= (1L << 24)) return FQ_ERR_UNSUPPORTED;       // partial sums must stay exact in fp32
+    if (N == 0) return FQ_OK;
+    if (!q_nhwc || !y) return FQ_ERR_INVALID_ARG;
+    if (N > 65535) return FQ_ERR_UNSUPPORTED;
+    dim3 grid((Cpad + 63) / 64, N);
+    hipStream_t st = as_stream(stream);
+    const float scale = ldexpf(1.0f, -g), divisor = (float)HW;
+    if (q_bytes == 1)
+        hipLaunchKernelGGL(avgpool_global_nhwc_kernel<int8_t>, grid, dim3(kResBlock), 0, st, static_cast<const int8_t*>(q_nhwc), y, C,
+                           HW, Cpad, scale, divisor);
+    else
+        hipLaunchKernelGGL(avgpool_global_nhwc_kernel<int16_t>, grid, dim3(kResBlock), 0, st, static_cast<const int16_t*>(q_nhwc), y,
+                           C, HW, Cpad, scale, divisor);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}

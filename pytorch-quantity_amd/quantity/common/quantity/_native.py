@@ -81,6 +81,10 @@ def lib():
     L.fq_add_resident.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, vp, ci, ci, sz, vp]
     L.fq_dequant_nhwc_to_nchw.restype = ci
     L.fq_dequant_nhwc_to_nchw.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, vp]
+    L.fq_maxpool_i8_nhwc.restype = ci
+    L.fq_maxpool_i8_nhwc.argtypes = [vp, vp] + [ci] * 10 + [vp]
+    L.fq_avgpool_global_nhwc.restype = ci
+    L.fq_avgpool_global_nhwc.argtypes = [vp, ci, ci, vp, ci, ci, ci, ci, vp]
     L.fq_json_dump_i32.restype = ci
     L.fq_json_dump_i32.argtypes = [ctypes.c_char_p, vp, ci, vp, ci]
     _lib = L
@@ -376,6 +380,31 @@ def dequant_nhwc_to_nchw(q, g, channels):
     y = torch.empty((N, int(channels)) + spatial, dtype=torch.float32, device=q.device)
     _check(lib().fq_dequant_nhwc_to_nchw(q.data_ptr(), _INT_BYTES[q.dtype], int(g), y.data_ptr(), N, int(channels), HW, cpad,
                                          _stream(q)), "fq_dequant_nhwc_to_nchw")
+    return y
+
+
+def maxpool_i8_nhwc(x, kernel, stride, padding):
+    """nn.MaxPool2d on int8 [N, H, W, Cpad] -> int8 [N, P, Q, Cpad] (fq_maxpool_i8_nhwc)."""
+    _need_cuda(x, torch.int8, "fq_maxpool_i8_nhwc")
+    assert x.dim() == 4 and x.is_contiguous()
+    N, H, W, cpad = x.shape
+    P = (H + 2 * padding[0] - kernel[0]) // stride[0] + 1
+    Q = (W + 2 * padding[1] - kernel[1]) // stride[1] + 1
+    y = torch.empty(N, P, Q, cpad, dtype=torch.int8, device=x.device)
+    _check(lib().fq_maxpool_i8_nhwc(x.data_ptr(), y.data_ptr(), N, H, W, cpad, kernel[0], kernel[1], stride[0], stride[1],
+                                    padding[0], padding[1], _stream(x)), "fq_maxpool_i8_nhwc")
+    return y
+
+
+def avgpool_global_nhwc(q, g, channels):
+    """int8 / int16 [N, H, W, Cpad] standing for q * 2^-g -> fp32 [N, channels, 1, 1], the mean over the plane."""
+    if not isinstance(q, torch.Tensor) or q.device.type != "cuda" or q.dtype not in _INT_BYTES:
+        raise FqError("fq_avgpool_global_nhwc: expected an int8 / int16 torch.cuda tensor")
+    assert q.dim() == 4 and q.is_contiguous()
+    N, H, W, cpad = q.shape
+    y = torch.empty(N, int(channels), 1, 1, dtype=torch.float32, device=q.device)
+    _check(lib().fq_avgpool_global_nhwc(q.data_ptr(), _INT_BYTES[q.dtype], int(g), y.data_ptr(), N, int(channels), H * W, cpad,
+                                        _stream(q)), "fq_avgpool_global_nhwc")
     return y
 
 

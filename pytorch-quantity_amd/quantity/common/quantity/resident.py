@@ -107,6 +107,63 @@ class _ReluPassThrough(object):
         return type(self.module).forward(self.module, x)
 
 
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def _maxpool_supported(m):
+    k, st, pd, dl = _pair(m.kernel_size), _pair(m.stride if m.stride is not None else m.kernel_size), _pair(m.padding), \
+        _pair(m.dilation)
+    return (dl == (1, 1) and not m.ceil_mode and not m.return_indices and 2 * pd[0] <= k[0] and 2 * pd[1] <= k[1]
+            and min(st) >= 1)
+
+
+def _avgpool_is_global(m, h, w):
+    k = _pair(m.kernel_size)
+    return (k == (int(h), int(w)) and _pair(m.padding) == (0, 0) and not m.ceil_mode
+            and getattr(m, "divisor_override", None) is None)
+
+
+class _MaxPoolResident(object):
+    """Instance-level forward of an nn.MaxPool2d between integer layers: pooling the int8 NHWC integers is
+    pooling the values (max commutes with the monotone scale q -> q * 2^-g)."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __call__(self, x):
+        m = self.module
+        plan = m.__dict__.get("_resident")
+        h = resident_of(x)
+        if plan is None or h is None or h.exact is None or h.exact.dtype != torch.int8 or not _maxpool_supported(m):
+            return type(m).forward(m, as_f32(x))
+        k, st, pd = _pair(m.kernel_size), _pair(m.stride if m.stride is not None else m.kernel_size), _pair(m.padding)
+        y = _native.maxpool_i8_nhwc(h.exact, k, st, pd)
+        narrow = y if (h.narrow is h.exact or h.bit == h.grid) else None
+        out = QHandle((y.shape[0], h.shape[1], y.shape[1], y.shape[2]), y, h.grid, narrow, h.grid, h.relu_done)
+        if not plan.emit_f32:
+            return out
+        t = out.to_f32()
+        if plan.emit_int:
+            t._fq_resident = out
+        return t
+
+
+class _AvgPoolResident(object):
+    """Instance-level forward of an nn.AvgPool2d that covers the whole plane of a resident activation."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __call__(self, x):
+        m = self.module
+        h = resident_of(x)
+        if (h is not None and h.exact is not None and _avgpool_is_global(m, h.exact.shape[1], h.exact.shape[2])
+                and h.exact.shape[1] * h.exact.shape[2] * 32768 < (1 << 24)):
+            return _native.avgpool_global_nhwc(h.exact, h.grid, h.shape[1])
+        return type(m).forward(m, as_f32(x))
+
+
 # ---- tracing -------------------------------------------------------------------------------------
 
 class _Value(object):
@@ -143,6 +200,7 @@ class _Tracer(TorchFunctionMode):
         self.order = 0
         self.produced = []           # _Value of every NewConv2d / NewAdd output, in execution order
         self.relu_values = []        # _Value of every nn.ReLU output whose input is traced
+        self.avgpool_shapes = {}     # nn.AvgPool2d module -> shape of its (traced) input
 
     def __torch_function__(self, func, types, args=(), kwargs=None):
         kwargs = kwargs or {}
@@ -165,6 +223,8 @@ class _Tracer(TorchFunctionMode):
             v = self.values.get(id(a)) if isinstance(a, torch.Tensor) else None
             if v is not None:
                 v.consumers.append((module, pos))
+                if isinstance(module, nn.AvgPool2d) and pos == 0:
+                    self.avgpool_shapes[module] = tuple(a.shape)       # (depth > 0 here: not a foreign touch)
 
     def post(self, module, args, output):
         self.depth -= 1
@@ -177,6 +237,14 @@ class _Tracer(TorchFunctionMode):
                 return
             v = _Value(module, "relu", src, self.order)
             self.relu_values.append(v)
+        elif isinstance(module, nn.MaxPool2d):
+            src = self.values.get(id(args[0])) if args and isinstance(args[0], torch.Tensor) else None
+            if src is None:
+                return
+            v = _Value(module, "maxpool", src, self.order)
+            self.produced.append(v)
+        elif isinstance(module, nn.AvgPool2d):
+            return                                          # its output is an ordinary fp32 tensor
         else:
             v = _Value(module, "add" if type(module).__name__ == "NewAdd" else "contraction", None, self.order)
             self.produced.append(v)
@@ -194,7 +262,7 @@ def _clear(model):
     for m in model.modules():
         m.__dict__.pop("_resident", None)
         fwd = m.__dict__.get("forward")
-        if isinstance(fwd, _ReluPassThrough):
+        if isinstance(fwd, (_ReluPassThrough, _MaxPoolResident, _AvgPoolResident)):
             del m.__dict__["forward"]
     model.__dict__.pop("_fq_resident_enabled", None)
 
@@ -209,15 +277,18 @@ def is_enabled(model):
     return bool(model.__dict__.get("_fq_resident_enabled"))
 
 
-def enable(model, example_input):
+def enable(model, example_input, verify=True):
     """Trace one forward of `model` (an integer-simulation model built by Reconstruction.ReconModel,
-    on the GPU) and switch every eligible NewConv2d / NewAdd to resident integer outputs.  Returns a
-    summary dict.  `example_input` is any valid input batch; the plan does not depend on its size."""
+    on the GPU) and switch every eligible NewConv2d / NewAdd (and the nn.ReLU / nn.MaxPool2d / global
+    nn.AvgPool2d between them) to resident integer activations.  Returns a summary dict.
+    `example_input` is any valid input batch; the plan does not depend on its size.  With `verify`
+    (default) the planned model is run once on `example_input` and must reproduce the traced forward
+    bit for bit, otherwise the plan is removed and FqError raised."""
     from .new_quantity_op import NewConv2d, NewLinear, NewAdd, QUANTIZE_BIT
     _clear(model)
     if QUANTIZE_BIT != 8:
         raise _native.FqError("resident activations are defined for QUANTIZE_BIT = 8")
-    planned_types = (NewConv2d, NewLinear, NewAdd, nn.ReLU)
+    planned_types = (NewConv2d, NewLinear, NewAdd, nn.ReLU, nn.MaxPool2d, nn.AvgPool2d)
     tracer = _Tracer(planned_types)
     hooks = []
     for m in model.modules():
@@ -229,8 +300,8 @@ def enable(model, example_input):
     try:
         with torch.no_grad():
             with tracer:
-                out = model(example_input)
-            tracer.mark_foreign(out)
+                traced_out = model(example_input)
+            tracer.mark_foreign(traced_out)
     finally:
         for h in hooks:
             h.remove()
@@ -240,7 +311,7 @@ def enable(model, example_input):
 
     def effective(v):
         """(value the consumers see, fused ReLU module or None)"""
-        if not v.foreign and len(v.consumers) == 1 and isinstance(v.consumers[0][0], nn.ReLU):
+        if v.kind != "maxpool" and not v.foreign and len(v.consumers) == 1 and isinstance(v.consumers[0][0], nn.ReLU):
             after = relu_value.get(id(v))
             if after is not None:
                 return after, v.consumers[0][0]
@@ -260,7 +331,13 @@ def enable(model, example_input):
         for (m, pos) in v.consumers:
             if isinstance(m, NewAdd) and pos < 2:
                 operands.setdefault(m, [None, None])[pos] = v
-    add_resident = set()
+    add_resident, pool_resident = set(), set()
+
+    def avg_can_read(m):
+        shape = tracer.avgpool_shapes.get(m)
+        return (isinstance(m, nn.AvgPool2d) and shape is not None and len(shape) == 4
+                and _avgpool_is_global(m, shape[2], shape[3]) and shape[2] * shape[3] * 32768 < (1 << 24))
+
     for v in tracer.produced:
         e, relu_mod = effective(v)
         eff_of[id(v)] = (e, relu_mod)
@@ -268,6 +345,11 @@ def enable(model, example_input):
         if v.kind == "contraction":
             if conv_can_emit(m):
                 fmt[id(e)] = (1, m.output_bit)
+        elif v.kind == "maxpool":
+            f = fmt.get(id(v.src))
+            if f is not None and f[0] == 1 and tracer.calls.get(m, 0) == 1 and _maxpool_supported(m):
+                pool_resident.add(m)
+                fmt[id(e)] = f
         else:
             ops = operands.get(m)
             if tracer.calls.get(m, 0) != 1 or ops is None or ops[0] is None or ops[1] is None:
@@ -282,7 +364,8 @@ def enable(model, example_input):
             fmt[id(e)] = (2, g)
 
     # pass 2: what every producer has to emit
-    summary = {"resident_convs": 0, "resident_adds": 0, "fused_relus": 0, "fp32_outputs": 0, "int_only_outputs": 0}
+    summary = {"resident_convs": 0, "resident_adds": 0, "resident_pools": 0, "fused_relus": 0, "fp32_outputs": 0,
+               "int_only_outputs": 0}
     for v in tracer.produced:
         m = v.producer
         e, relu_mod = eff_of[id(v)]
@@ -296,17 +379,20 @@ def enable(model, example_input):
         for (c, pos) in e.consumers:
             if conv_can_read(c):
                 narrow_bits.append(c.input_bit)
-            elif isinstance(c, NewAdd) and c in add_resident:
+            elif (isinstance(c, NewAdd) and c in add_resident) or avg_can_read(c):
                 int_consumers += 1
-                plan.want_wide = True
+                plan.want_wide = True                       # these read the exact value
+            elif c in pool_resident and v.kind != "add":
+                int_consumers += 1                          # int8 max-pool of an int8 activation
             else:
                 need_f32 = True
-        if v.kind == "contraction":
-            ok = [b for b in narrow_bits if b == m.output_bit]
+        if v.kind in ("contraction", "maxpool"):
+            grid = m.output_bit if v.kind == "contraction" else fmt[id(e)][1]
+            ok = [b for b in narrow_bits if b == grid]
             if len(ok) != len(narrow_bits):
                 need_f32 = True                             # a consumer quantises at another bit: from fp32
             int_consumers += len(ok)
-            plan.narrow_bit = m.output_bit
+            plan.narrow_bit = grid
         else:
             plan.resident_add = True
             plan.grid = fmt[id(e)][1]
@@ -324,9 +410,23 @@ def enable(model, example_input):
         if plan.relu:
             relu_mod.__dict__["forward"] = _ReluPassThrough(relu_mod)
             summary["fused_relus"] += 1
-        summary["resident_convs" if v.kind == "contraction" else "resident_adds"] += 1
+        if v.kind == "maxpool":
+            m.__dict__["forward"] = _MaxPoolResident(m)
+        summary[{"contraction": "resident_convs", "add": "resident_adds", "maxpool": "resident_pools"}[v.kind]] += 1
         summary["fp32_outputs" if plan.emit_f32 else "int_only_outputs"] += 1
+    for m in tracer.avgpool_shapes:
+        if avg_can_read(m):
+            m.__dict__["forward"] = _AvgPoolResident(m)
+            summary["resident_pools"] += 1
     model.__dict__["_fq_resident_enabled"] = True
+    if verify:
+        with torch.no_grad():
+            planned_out = model(example_input)
+        same = all(torch.equal(a, b) for a, b in zip(_iter_tensors(planned_out), _iter_tensors(traced_out)))
+        if not same:
+            _clear(model)
+            raise _native.FqError("resident plan does not reproduce the fp32-boundary forward on the example input; "
+                                  "plan removed (please report the model)")
     return summary
 
 

@@ -125,6 +125,34 @@ def test_dequant_nhwc_to_nchw(nat, oracle, dtype, g, N, C, H, W):
     np.testing.assert_array_equal(y, ref)
 
 
+@pytest.mark.parametrize("N,C,H,W,k,st,pd", [(2, 64, 17, 17, 3, 2, 1), (1, 20, 9, 12, 2, 2, 0), (3, 16, 8, 8, 3, 1, 1), (2, 48, 7, 7, 5, 3, 2)])
+def test_maxpool_i8_equals_torch_on_the_values(nat, N, C, H, W, k, st, pd):
+    """Pooling the integers == quantising torch's max-pool of the de-quantised tensor."""
+    rng = np.random.default_rng(C * H)
+    cpad = (C + 15) // 16 * 16
+    q = np.zeros((N, H, W, cpad), dtype=np.int8)
+    q[..., :C] = rng.integers(-128, 128, size=(N, H, W, C))
+    g = 3
+    xf = torch.from_numpy(q[..., :C].astype(np.float32) / 2 ** g).permute(0, 3, 1, 2).contiguous().cuda()
+    ref = torch.nn.functional.max_pool2d(xf, k, st, pd)
+    got = nat.maxpool_i8_nhwc(_dev(q), (k, k), (st, st), (pd, pd))
+    assert tuple(got.shape) == (N, ref.shape[2], ref.shape[3], cpad)
+    np.testing.assert_array_equal(got.cpu().numpy()[..., :C].astype(np.float32) / 2 ** g, ref.permute(0, 2, 3, 1).cpu().numpy())
+
+
+@pytest.mark.parametrize("dtype,g,N,C,H", [(np.int16, 6, 4, 2048, 7), (np.int8, 3, 2, 100, 4), (np.int16, 0, 3, 64, 16), (np.int16, 8, 2, 48, 13)])
+def test_avgpool_global_equals_torch_avg_pool2d(nat, dtype, g, N, C, H):
+    """Bit-identical to torch's AvgPool2d(H) on the de-quantised fp32 tensor (exact partial sums, one division)."""
+    rng = np.random.default_rng(C + H)
+    cpad = (C + 15) // 16 * 16
+    info = np.iinfo(dtype)
+    q = rng.integers(info.min, info.max + 1, size=(N, H, H, cpad)).astype(dtype)
+    xf = torch.from_numpy(q[..., :C].astype(np.float32) * np.float32(2.0 ** -g)).permute(0, 3, 1, 2).contiguous().cuda()
+    ref = torch.nn.AvgPool2d(H)(xf)
+    got = nat.avgpool_global_nhwc(_dev(q), g, C)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
 def _r18_recon(g3, tmp):
     from model.resnet.ResNet_18_fabu import ResNet18
     from tools import Reconstruction
@@ -201,10 +229,12 @@ def test_r50_resident_equals_fp32_boundary_model():
             stage_plain = net.layer2[:3](net.layer1(net.maxpool(net.relu(net.conv1(x)))))
         summary = resident.enable(net, x)
         assert summary["resident_convs"] == 53 and summary["resident_adds"] == 16 and summary["fused_relus"] == 49, summary
+        assert summary["resident_pools"] == 2 and summary["fp32_outputs"] == 0, summary     # max-pool and global average pool
         plans = resident.describe(net)
         assert plans["layer1.0.conv1"].emit_f32 is False and plans["layer1.0.conv1"].relu is True
-        assert plans["conv1"].emit_f32 is True and plans["conv1"].emit_int is False and plans["conv1"].relu is True
-        assert plans["layer4.2.Eltwise"].emit_f32 is True            # feeds the average pool
+        assert plans["conv1"].emit_f32 is False and plans["conv1"].emit_int is True and plans["conv1"].relu is True
+        assert plans["maxpool"].emit_f32 is False and plans["maxpool"].emit_int is True
+        assert plans["layer4.2.Eltwise"].emit_f32 is False and plans["layer4.2.Eltwise"].want_wide is True   # -> average pool
         assert plans["layer1.1.Eltwise"].emit_f32 is False and plans["layer1.1.Eltwise"].want_wide is True
         with torch.no_grad():
             got = net(x)
