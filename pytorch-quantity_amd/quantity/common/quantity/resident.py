@@ -26,7 +26,7 @@ from torch.overrides import TorchFunctionMode
 
 from . import _native
 
-__all__ = ["QHandle", "enable", "disable", "is_enabled", "describe"]
+__all__ = ["QHandle", "enable", "disable", "is_enabled", "describe", "capture", "GraphedForward"]
 
 MAX_WIDE_GRID = 8          # int16 holds |s| <= 128 on a grid of 2^-8
 
@@ -433,3 +433,38 @@ def enable(model, example_input, verify=True):
 def describe(model):
     """{module name: Plan} of the current plan (for logs and tests)."""
     return dict((name, m.__dict__["_resident"]) for name, m in model.named_modules() if "_resident" in m.__dict__)
+
+
+class GraphedForward(object):
+    """One forward of a model captured as a HIP graph (torch.cuda.CUDAGraph) and replayed per call.
+
+    The integer-simulation forward is ~100 short kernels; below batch ~64 the Python / launch path, not
+    the GPU, sets its rate.  Every kernel of this library is enqueued on the caller's stream without
+    synchronising, so the whole forward captures as is.  The input is copied into a static buffer and the
+    returned tensor is the graph's static output: it is overwritten by the next call (clone it to keep it).
+    Batch shape is fixed at capture time."""
+
+    def __init__(self, model, example_input, warmup=2):
+        self.model = model
+        self.static_in = example_input.detach().clone()
+        side = torch.cuda.Stream(device=example_input.device)
+        side.wait_stream(torch.cuda.current_stream(example_input.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                model(self.static_in)
+        torch.cuda.current_stream(example_input.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.static_out = model(self.static_in)
+
+    def __call__(self, x):
+        if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype:
+            raise _native.FqError("GraphedForward was captured for input %s %s" % (tuple(self.static_in.shape), self.static_in.dtype))
+        self.static_in.copy_(x, non_blocking=True)
+        self.graph.replay()
+        return self.static_out
+
+
+def capture(model, example_input, warmup=2):
+    """HIP-graph capture of `model`'s forward at the shape of `example_input` (see GraphedForward)."""
+    return GraphedForward(model, example_input, warmup)

@@ -27,3 +27,10 @@ with torch.no_grad():
     for _ in range(ITERS): net(x)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / ITERS
 print("ReconModel B=%d: %.3f ms/batch = %.0f img/s" % (B, dt * 1e3, B / dt))
+if len(sys.argv) > 4 and sys.argv[4] == "graph":
+    g = resident.capture(net, x)
+    for _ in range(3): g(x)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(ITERS): g(x)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / ITERS
+    print("ReconModel B=%d HIP graph: %.3f ms/batch = %.0f img/s" % (B, dt * 1e3, B / dt))

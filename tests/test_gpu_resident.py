@@ -242,6 +242,13 @@ def test_r50_resident_equals_fp32_boundary_model():
         assert type(stage).__name__ == "QHandle"
         assert torch.equal(got, plain)
         assert torch.equal(stage.to_f32(), stage_plain)
+        # the whole resident forward captures as one HIP graph (no sync, no allocation outside torch's pool)
+        graphed = resident.capture(net, x)
+        assert torch.equal(graphed(x), plain)
+        x2 = torch.flip(x, dims=[0])
+        with torch.no_grad():
+            want2 = net(x2)
+        assert torch.equal(graphed(x2), want2)
         # a handle that reaches code outside the plan fails loudly instead of computing garbage
         with pytest.raises(Exception):
             torch.relu(stage)
