@@ -174,6 +174,16 @@ int fq_conv2d_i8_resident(const int8_t* x_nhwc, const int8_t* w_krsc, const floa
                           int S, int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w,
                           int rs, int ob, fq_stream_t stream);
 
+/* fq_conv2d_i8_resident followed by fq_add_resident in one kernel: the convolution's int8 result (no ReLU of
+ * its own, grid ob) is operand x of NewAdd and never reaches HBM; `res` is operand y (int8 / int16 NHWC
+ * [N][P][Q][Kpad], grid g_res).  Outputs as fq_add_resident: wide (int16, grid g_wide = max(0, ob, g_res) <= 8,
+ * may be NULL), narrow (int8 = Quantity(ib), may be NULL), relu fuses the nn.ReLU after the add. */
+int fq_conv2d_i8_add_resident(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, const void* res,
+                              int res_bytes, int g_res, int16_t* wide, int g_wide, int8_t* narrow, int ib,
+                              int relu, int Kpad, int N, int H, int W, int C, int K, int R, int S, int stride_h,
+                              int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob,
+                              fq_stream_t stream);
+
 /* NewAdd.forward (new_quantity_op.py:171-174) on resident operands, with the nn.ReLU and the Quantity of
  * the consumers fused.  x, y: int8 (x_bytes = 1) or int16 (x_bytes = 2) arrays of n elements in the same
  * flat NHWC layout, standing for x * 2^-gx and y * 2^-gy.

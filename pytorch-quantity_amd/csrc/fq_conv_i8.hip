@@ -24,7 +24,7 @@
 #include <cstdlib>
 #include <type_traits>
 
-#include "fq_common.h"
+#include "fq_resident.h"
 
 namespace fq {
 
@@ -62,6 +62,11 @@ struct ConvParams {
     unsigned x_bytes;                    // N * H * W * C: num_records of the activation buffer descriptor
     int rs, half_rs, slo, shi;           // integer tail: shift, 2^(rs-1), Sp range; rs = 0 selects the fp32 tail
     unsigned w_bytes;                    // K * R * S * C: num_records of the weight buffer descriptor
+    // fused residual add (kOutAdd): the conv output is operand x of NewAdd, `res` is operand y
+    const void* res;                     // int8 / int16 NHWC [N][P][Q][Kpad], same layout as the int8 output
+    int res_bytes;
+    int16_t* wide;                       // exact int16 sum (may be null); the int8 output pointer receives `narrow`
+    AddResParams ap;
 };
 
 // Activation loads are buffer loads: an out-of-image tap (zero padding) or a chunk past the end of the
@@ -136,7 +141,7 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
 
 // kOut: bit 0 = fp32 NCHW output y (the module-boundary format), bit 1 = int8 NHWC output q (the
 // resident hand-off to the next integer layer: 1 byte per element instead of 4 written + 4 read + 1).
-constexpr int kOutF32 = 1, kOutI8 = 2;
+constexpr int kOutF32 = 1, kOutI8 = 2, kOutAdd = 4;      // kOutAdd: with kOutI8, NewAdd fused into the store
 
 // Epilogue shared by the conv kernels.  Accumulator layout (v_mfma_i32_32x32x32_i8): D row = k_out =
 // (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel (wave*32 + lane&31 of the 128-pixel tile).  The tail
@@ -195,8 +200,28 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
             const int idx = tid + kConvBlock * j;
             const int pix = idx / CPP, ch = idx - pix * CPP;
             const int mm = m0 + pix, kk = k0 + 16 * ch;
-            if (mm < p.M && kk < p.Kpad)
-                *reinterpret_cast<v4i*>(q + (long)mm * p.Kpad + kk) = *reinterpret_cast<const v4i*>(&sO[pix * OS + 16 * ch]);
+            if (mm < p.M && kk < p.Kpad) {
+                const long off = (long)mm * p.Kpad + kk;
+                if (kOut & kOutAdd) {
+                    // NewAdd (+ ReLU + the consumers' Quantity) on the tile while it is in flight: the conv's
+                    // int8 result never reaches HBM, the residual is read here, 16 channels per thread
+                    Vec16<int8_t> cv;
+                    cv.a = *reinterpret_cast<const v4i_r*>(&sO[pix * OS + 16 * ch]);
+                    int16_t* wd = p.wide ? p.wide + off : nullptr;
+                    int8_t* nd = q ? q + off : nullptr;
+                    if (p.res_bytes == 1) {
+                        Vec16<int8_t> rv;
+                        rv.load(static_cast<const int8_t*>(p.res) + off);
+                        add_resident_16(cv, rv, wd, nd, p.ap);
+                    } else {
+                        Vec16<int16_t> rv;
+                        rv.load(static_cast<const int16_t*>(p.res) + off);
+                        add_resident_16(cv, rv, wd, nd, p.ap);
+                    }
+                } else {
+                    *reinterpret_cast<v4i*>(q + off) = *reinterpret_cast<const v4i*>(&sO[pix * OS + 16 * ch]);
+                }
+            }
         }
     }
 }
@@ -657,6 +682,46 @@ __global__ __launch_bounds__(256) void quantize_i8_unfold_w_kernel(const float* 
     }
 }
 
+// The common stem (C <= 4 channels, S <= 8 taps, S*C <= 32 folded channels): C is a template parameter and
+// the tap loop is fully unrolled, so every folded-channel index is a compile-time constant -- no division per
+// element, the 32 output bytes are assembled in registers and leave as two 16-byte stores.  Neighbouring
+// threads (q, q+1) read overlapping input columns, which the L1 absorbs.
+template <int C>
+__global__ __launch_bounds__(256) void quantize_i8_unfold_w_small_kernel(const float* __restrict__ x, int8_t* __restrict__ y, int H, int W,
+                                                                         int S, int stride_w, int pad_w, int dil_w, int Q, int Cpad2,
+                                                                         long total, float scale) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    const long stride = (long)gridDim.x * 256;
+    const long plane = (long)H * W;
+    for (; i < total; i += stride) {                      // i = (n*H + ih)*Q + q
+        const int q = (int)(i % Q);
+        const long nih = i / Q;
+        const int ih = (int)(nih % H);
+        const long n = nih / H;
+        const float* __restrict__ src = x + (n * C * H + ih) * (long)W;     // + c*H*W + iw
+        const int iw0 = q * stride_w - pad_w;
+        unsigned out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s_ = 0; s_ < 8; ++s_) {
+            const int iw = iw0 + s_ * dil_w;
+            const bool ok = s_ < S && (unsigned)iw < (unsigned)W;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const int f = s_ * C + c;                  // compile-time after unrolling
+                const float v = ok ? src[c * plane + iw] : 0.0f;
+                out[f >> 2] |= q8(v, scale) << (8 * (f & 3));
+            }
+        }
+        int8_t* dst = y + i * Cpad2;
+        uint4 o0; o0.x = out[0]; o0.y = out[1]; o0.z = out[2]; o0.w = out[3];
+        *reinterpret_cast<uint4*>(dst) = o0;
+        if (Cpad2 > 16) {
+            uint4 o1; o1.x = out[4]; o1.y = out[5]; o1.z = out[6]; o1.w = out[7];
+            *reinterpret_cast<uint4*>(dst + 16) = o1;
+        }
+    }
+}
+
 // HW == 1 (Linear input [N][F]): layouts coincide, plain element-wise with channel padding
 __global__ __launch_bounds__(256) void quantize_i8_rows_kernel(const float* __restrict__ x, int8_t* __restrict__ y, int C, int Cpad,
                                                                long rows, float scale) {
@@ -719,8 +784,23 @@ extern "C" int fq_quantize_i8_unfold_w(const float* x_nchw, int8_t* y, int N, in
     const long total = (long)N * H * Q;
     long g = (total + 255) / 256;
     if (g > kCUs * 32) g = kCUs * 32;
-    hipLaunchKernelGGL(quantize_i8_unfold_w_kernel, dim3((unsigned)g), dim3(256), 0, as_stream(stream), x_nchw, y, C, H, W, S,
-                       stride_w, pad_w, dil_w, Q, Cpad2, total, ldexpf(1.0f, ib));
+    const float scale = ldexpf(1.0f, ib);
+    hipStream_t st = as_stream(stream);
+    if (C <= 4 && S <= 8 && S * C <= 32 && Cpad2 <= 32) {
+        switch (C) {
+            case 1: hipLaunchKernelGGL(quantize_i8_unfold_w_small_kernel<1>, dim3((unsigned)g), dim3(256), 0, st, x_nchw, y, H, W, S,
+                                       stride_w, pad_w, dil_w, Q, Cpad2, total, scale); break;
+            case 2: hipLaunchKernelGGL(quantize_i8_unfold_w_small_kernel<2>, dim3((unsigned)g), dim3(256), 0, st, x_nchw, y, H, W, S,
+                                       stride_w, pad_w, dil_w, Q, Cpad2, total, scale); break;
+            case 3: hipLaunchKernelGGL(quantize_i8_unfold_w_small_kernel<3>, dim3((unsigned)g), dim3(256), 0, st, x_nchw, y, H, W, S,
+                                       stride_w, pad_w, dil_w, Q, Cpad2, total, scale); break;
+            default: hipLaunchKernelGGL(quantize_i8_unfold_w_small_kernel<4>, dim3((unsigned)g), dim3(256), 0, st, x_nchw, y, H, W, S,
+                                        stride_w, pad_w, dil_w, Q, Cpad2, total, scale); break;
+        }
+    } else {
+        hipLaunchKernelGGL(quantize_i8_unfold_w_kernel, dim3((unsigned)g), dim3(256), 0, st, x_nchw, y, C, H, W, S, stride_w, pad_w,
+                           dil_w, Q, Cpad2, total, scale);
+    }
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }
@@ -730,7 +810,9 @@ namespace fq {
 template <int TK>
 static void launch_conv_dma(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
                             int8_t* q, const ConvParams& p) {
-    if (y && q)
+    if (p.res)
+        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutI8 | kOutAdd>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else if (y && q)
         hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutF32 | kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else if (q)
         hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
@@ -741,7 +823,9 @@ static void launch_conv_dma(dim3 grid, hipStream_t st, const int8_t* x, const in
 template <int TK, bool kC128>
 static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
                              int8_t* q, const ConvParams& p) {
-    if (y && q)
+    if (p.res)
+        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutI8 | kOutAdd>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else if (y && q)
         hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutF32 | kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else if (q)
         hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
@@ -749,21 +833,30 @@ static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const i
         hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutF32>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
 }
 
+struct FusedAdd {                        // residual operand and outputs of a fused NewAdd (res == nullptr: none)
+    const void* res = nullptr;
+    int res_bytes = 0;
+    int16_t* wide = nullptr;
+    AddResParams ap = {};
+};
+
 static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw, int8_t* q_nhwc,
-                              int Kpad, int relu, int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
+                              int Kpad, int relu, const FusedAdd& fa, int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
                               int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob, int bitwidth, fq_stream_t stream) {
     if (!valid_bitwidth(bitwidth) || rs < -120 || rs > 120 || ob < -120 || ob > 120) return FQ_ERR_INVALID_ARG;
     if (N < 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride_h <= 0 || stride_w <= 0 ||
         pad_h < 0 || pad_w < 0 || dil_h <= 0 || dil_w <= 0)
         return FQ_ERR_INVALID_ARG;
     if (C % 16) return FQ_ERR_UNSUPPORTED;                // pad channels to 16 in fq_quantize_i8_nhwc
-    if (q_nhwc && (bitwidth != 8 || Kpad < K || (Kpad & 15))) return FQ_ERR_INVALID_ARG;
+    if ((q_nhwc || fa.res) && (bitwidth != 8 || Kpad < K || (Kpad & 15))) return FQ_ERR_INVALID_ARG;
+    if (fa.res && (y_nchw || relu || (!q_nhwc && !fa.wide))) return FQ_ERR_INVALID_ARG;
     const int P = (H + 2 * pad_h - dil_h * (R - 1) - 1) / stride_h + 1;
     const int Q = (W + 2 * pad_w - dil_w * (S - 1) - 1) / stride_w + 1;
     if (P <= 0 || Q <= 0) return FQ_ERR_INVALID_ARG;
     if (N == 0) return FQ_OK;
-    if (!x_nhwc || !w_krsc || !qbias || (!y_nchw && !q_nhwc)) return FQ_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w_krsc) | reinterpret_cast<uintptr_t>(q_nhwc)) & 15u)
+    if (!x_nhwc || !w_krsc || !qbias || (!y_nchw && !q_nhwc && !fa.res)) return FQ_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w_krsc) | reinterpret_cast<uintptr_t>(q_nhwc) |
+         reinterpret_cast<uintptr_t>(fa.res) | reinterpret_cast<uintptr_t>(fa.wide)) & 15u)
         return FQ_ERR_INVALID_ARG;
     const long M = (long)N * P * Q;
     if (M > 0x7fffffffL || (long)R * S * C / 16 > 0x7fffffffL) return FQ_ERR_UNSUPPORTED;
@@ -782,7 +875,8 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     p.rs = int_tail ? rs : 0;
     p.half_rs = int_tail ? 1 << (rs - 1) : 0;
     p.slo = (int)p.lo; p.shi = (int)p.hi;
-    p.Kpad = q_nhwc ? Kpad : 0;
+    p.Kpad = (q_nhwc || fa.res) ? Kpad : 0;
+    p.res = fa.res; p.res_bytes = fa.res_bytes; p.wide = fa.wide; p.ap = fa.ap;
     p.x_bytes = (unsigned)((long)N * H * W * C);
     p.w_bytes = (unsigned)((long)K * R * S * C);
     hipStream_t st = as_stream(stream);
@@ -821,7 +915,7 @@ extern "C" int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const fl
                             int W, int C, int K, int R, int S, int stride_h, int stride_w, int pad_h, int pad_w,
                             int dil_h, int dil_w, int rs, int ob, int bitwidth, fq_stream_t stream) {
     if (!y_nchw && N > 0) return FQ_ERR_INVALID_ARG;
-    return conv2d_i8_dispatch(x_nhwc, w_krsc, qbias, y_nchw, nullptr, 0, 0, N, H, W, C, K, R, S, stride_h, stride_w, pad_h,
+    return conv2d_i8_dispatch(x_nhwc, w_krsc, qbias, y_nchw, nullptr, 0, 0, FusedAdd{}, N, H, W, C, K, R, S, stride_h, stride_w, pad_h,
                               pad_w, dil_h, dil_w, rs, ob, bitwidth, stream);
 }
 
@@ -829,7 +923,20 @@ extern "C" int fq_conv2d_i8_resident(const int8_t* x_nhwc, const int8_t* w_krsc,
                                      int8_t* q_nhwc, int Kpad, int relu, int N, int H, int W, int C, int K, int R, int S,
                                      int stride_h, int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob,
                                      fq_stream_t stream) {
-    return conv2d_i8_dispatch(x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, Kpad, relu, N, H, W, C, K, R, S, stride_h, stride_w, pad_h,
+    return conv2d_i8_dispatch(x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, Kpad, relu, FusedAdd{}, N, H, W, C, K, R, S, stride_h, stride_w, pad_h,
+                              pad_w, dil_h, dil_w, rs, ob, 8, stream);
+}
+
+extern "C" int fq_conv2d_i8_add_resident(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, const void* res,
+                                         int res_bytes, int g_res, int16_t* wide, int g_wide, int8_t* narrow, int ib, int relu,
+                                         int Kpad, int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
+                                         int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob, fq_stream_t stream) {
+    if (!res || (res_bytes != 1 && res_bytes != 2)) return FQ_ERR_INVALID_ARG;
+    FusedAdd fa;
+    fa.res = res; fa.res_bytes = res_bytes; fa.wide = wide;
+    const int rc = make_add_params(ob, g_res, g_wide, wide != nullptr, ib, relu, &fa.ap);
+    if (rc != FQ_OK) return rc;
+    return conv2d_i8_dispatch(x_nhwc, w_krsc, qbias, nullptr, narrow, Kpad, 0, fa, N, H, W, C, K, R, S, stride_h, stride_w, pad_h,
                               pad_w, dil_h, dil_w, rs, ob, 8, stream);
 }
 

@@ -18,44 +18,14 @@
 // 18-29 per activation to 2-6.  The kernels below evaluate the reference's fp32 expressions on the
 // de-scaled integers (bit-identical by construction); fq_conv2d_i8_resident (fq_conv_i8.hip) writes
 // the int8 form straight from the MFMA epilogue.
-#include "fq_common.h"
+#include "fq_resident.h"
 
 namespace fq {
 
 constexpr int kResBlock = 256;
 
-typedef int v4i_r __attribute__((ext_vector_type(4)));
-
-struct AddResParams {
-    float sx, sy;          // 2^-gx, 2^-gy: integer -> value
-    float lo, hi;          // NewAdd's Sp range; lo = 0 when the following ReLU is fused
-    float s_wide;          // 2^g_out   (exact value -> int16)
-    float s_narrow;        // 2^ib      (next layers' Quantity)
-};
-
-template <typename T> struct Vec16;                       // 16 consecutive channels of one pixel
-template <> struct Vec16<int8_t> {
-    v4i_r a;
-    __device__ __forceinline__ void load(const int8_t* p) { a = *reinterpret_cast<const v4i_r*>(p); }
-    __device__ __forceinline__ float get(int i) const { return (float)(int)(int8_t)(((unsigned)a[i >> 2]) >> (8 * (i & 3))); }
-};
-template <> struct Vec16<int16_t> {
-    v4i_r a, b;
-    __device__ __forceinline__ void load(const int16_t* p) {
-        a = *reinterpret_cast<const v4i_r*>(p);
-        b = *reinterpret_cast<const v4i_r*>(p + 8);
-    }
-    __device__ __forceinline__ float get(int i) const {
-        const unsigned d = (unsigned)(i < 8 ? a[(i & 7) >> 1] : b[(i & 7) >> 1]);
-        return (float)(int)(int16_t)(d >> (16 * (i & 1)));
-    }
-};
-
-// NewAdd on resident operands (new_quantity_op.py:171-174 + the ReLU and Quantity that follow it):
-//   s = clamp(x * 2^-gx + y * 2^-gy, lo, hi)            the reference's fp32 expression, exact here
-//   wide[i]   = (int16) (s * 2^g_out)                    the exact sum, for the next residual add
-//   narrow[i] = (int8) clamp(rint(s * 2^ib), -128, 127)  what the next conv's Quantity(ib) computes
-// All operands share one flat NHWC layout [N][HW][Cpad]; 16 elements per thread.
+// NewAdd on resident operands (add_resident_16 in fq_resident.h).  All operands share one flat NHWC layout
+// [N][HW][Cpad]; 16 elements per thread.
 template <typename TX, typename TY>
 __global__ __launch_bounds__(kResBlock) void add_resident_kernel(const TX* __restrict__ x, const TY* __restrict__ y,
                                                                  int16_t* __restrict__ wide, int8_t* __restrict__ narrow,
@@ -66,37 +36,7 @@ __global__ __launch_bounds__(kResBlock) void add_resident_kernel(const TX* __res
         Vec16<TX> vx; Vec16<TY> vy;
         vx.load(x + i * 16);
         vy.load(y + i * 16);
-        float s[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const float v = vx.get(e) * p.sx + vy.get(e) * p.sy;
-            s[e] = __builtin_amdgcn_fmed3f(v, p.lo, p.hi);            // integers scaled by 2^k: never NaN
-        }
-        if (wide) {
-            v4i_r o0, o1;
-#pragma unroll
-            for (int d = 0; d < 8; ++d) {
-                const unsigned lo16 = (unsigned)(int)(s[2 * d] * p.s_wide) & 0xffffu;
-                const unsigned hi16 = (unsigned)(int)(s[2 * d + 1] * p.s_wide) << 16;
-                if (d < 4) o0[d] = (int)(lo16 | hi16); else o1[d - 4] = (int)(lo16 | hi16);
-            }
-            *reinterpret_cast<v4i_r*>(wide + i * 16) = o0;
-            *reinterpret_cast<v4i_r*>(wide + i * 16 + 8) = o1;
-        }
-        if (narrow) {
-            v4i_r o;
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                unsigned w = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float q = __builtin_amdgcn_fmed3f(rintf(s[4 * d + e] * p.s_narrow), -128.0f, 127.0f);
-                    w |= ((unsigned)(int)q & 0xffu) << (8 * e);
-                }
-                o[d] = (int)w;
-            }
-            *reinterpret_cast<v4i_r*>(narrow + i * 16) = o;
-        }
+        add_resident_16(vx, vy, wide ? wide + i * 16 : nullptr, narrow ? narrow + i * 16 : nullptr, p);
     }
 }
 
@@ -148,22 +88,15 @@ using namespace fq;
 extern "C" int fq_add_resident(const void* x, int x_bytes, int gx, const void* y, int y_bytes, int gy, int16_t* wide,
                                int g_wide, int8_t* narrow, int ib, int relu, size_t n, fq_stream_t stream) {
     if ((x_bytes != 1 && x_bytes != 2) || (y_bytes != 1 && y_bytes != 2)) return FQ_ERR_INVALID_ARG;
-    if (gx < -16 || gx > 16 || gy < -16 || gy > 16 || ib < -16 || ib > 16) return FQ_ERR_INVALID_ARG;
     if (n & 15u) return FQ_ERR_INVALID_ARG;               // NHWC rows are padded to 16 channels
     if (n == 0) return FQ_OK;
     if (!x || !y || (!wide && !narrow)) return FQ_ERR_INVALID_ARG;
-    if (wide) {
-        // the exact sum must fit: grid max(0, gx, gy), |s| <= 128  =>  |S| <= 2^(7 + g) <= 2^15
-        const int g_need = gx > gy ? (gx > 0 ? gx : 0) : (gy > 0 ? gy : 0);
-        if (g_wide != g_need || g_wide > 8) return FQ_ERR_UNSUPPORTED;
-    }
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(wide) |
          reinterpret_cast<uintptr_t>(narrow)) & 15u)
         return FQ_ERR_INVALID_ARG;
     AddResParams p;
-    p.sx = ldexpf(1.0f, -gx); p.sy = ldexpf(1.0f, -gy);
-    p.lo = relu ? 0.0f : -128.0f; p.hi = 127.0f;
-    p.s_wide = ldexpf(1.0f, g_wide); p.s_narrow = ldexpf(1.0f, ib);
+    const int rc = make_add_params(gx, gy, g_wide, wide != nullptr, ib, relu, &p);
+    if (rc != FQ_OK) return rc;
     hipStream_t st = as_stream(stream);
     const size_t n16 = n >> 4;
     if (x_bytes == 1 && y_bytes == 1) launch_add<int8_t, int8_t>(st, x, y, wide, narrow, n16, p);

@@ -77,6 +77,8 @@ def lib():
     L.fq_conv2d_i8.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_resident.restype = ci
     L.fq_conv2d_i8_resident.argtypes = [vp, vp, vp, vp, vp] + [ci] * 17 + [vp]
+    L.fq_conv2d_i8_add_resident.restype = ci
+    L.fq_conv2d_i8_add_resident.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, vp, ci, ci, ci] + [ci] * 15 + [vp]
     L.fq_add_resident.restype = ci
     L.fq_add_resident.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, vp, ci, ci, sz, vp]
     L.fq_dequant_nhwc_to_nchw.restype = ci
@@ -350,6 +352,31 @@ def conv2d_i8_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, want_f3
 
 
 _INT_BYTES = {torch.int8: 1, torch.int16: 2}
+
+
+def conv2d_i8_add_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, res, g_res, want_wide, g_wide, want_narrow, ib, relu):
+    """fq_conv2d_i8_add_resident: NewAdd(conv(xq), res) without writing the conv result.  res: int8 / int16
+    [N,P,Q,Kpad] standing for res * 2^-g_res.  Returns (wide int16 or None, narrow int8 or None)."""
+    _need_cuda(xq, torch.int8, "fq_conv2d_i8_add_resident")
+    _need_cuda(wq, torch.int8, "fq_conv2d_i8_add_resident")
+    _need_cuda(qbias, torch.float32, "fq_conv2d_i8_add_resident")
+    if not isinstance(res, torch.Tensor) or res.device.type != "cuda" or res.dtype not in _INT_BYTES:
+        raise FqError("fq_conv2d_i8_add_resident: the residual must be an int8 / int16 torch.cuda tensor")
+    N, H, W, C = xq.shape
+    K, R, S, Cw = wq.shape
+    assert C == Cw and xq.is_contiguous() and wq.is_contiguous() and res.is_contiguous() and (want_wide or want_narrow)
+    P = (H + 2 * padding[0] - dilation[0] * (R - 1) - 1) // stride[0] + 1
+    Q = (W + 2 * padding[1] - dilation[1] * (S - 1) - 1) // stride[1] + 1
+    kpad = pad16(K)
+    assert tuple(res.shape) == (N, P, Q, kpad), (tuple(res.shape), (N, P, Q, kpad))
+    wide = torch.empty(N, P, Q, kpad, dtype=torch.int16, device=xq.device) if want_wide else None
+    narrow = torch.empty(N, P, Q, kpad, dtype=torch.int8, device=xq.device) if want_narrow else None
+    _check(lib().fq_conv2d_i8_add_resident(xq.data_ptr(), wq.data_ptr(), qbias.contiguous().data_ptr(), res.data_ptr(),
+                                           _INT_BYTES[res.dtype], int(g_res), wide.data_ptr() if want_wide else None, int(g_wide),
+                                           narrow.data_ptr() if want_narrow else None, int(ib), 1 if relu else 0, kpad, N, H, W, C,
+                                           K, R, S, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
+                                           int(rs), int(ob), _stream(xq)), "fq_conv2d_i8_add_resident")
+    return wide, narrow
 
 
 def add_resident(x, gx, y, gy, want_wide, g_wide, want_narrow, ib, relu):

@@ -20,7 +20,7 @@ import torch
 from torch import nn
 
 from . import _native
-from .resident import QHandle, resident_of, as_f32
+from .resident import QHandle, DeferredConv, resident_of, as_f32
 
 QUANTIZE_BIT = 8
 
@@ -231,6 +231,8 @@ class NewConv2d(_IntegerSimLayer):
             if plan is None:
                 return _native.conv2d_i8(xq, wq, self.quantized_bias, geom[0], geom[1], geom[2], self.rs_bit,
                                          self.output_bit, 8)
+            if plan.defer:
+                return DeferredConv(self, xq, wq, geom)   # the resident NewAdd that consumes it runs it
             y, q = _native.conv2d_i8_resident(xq, wq, self.quantized_bias, geom[0], geom[1], geom[2], self.rs_bit,
                                               self.output_bit, plan.emit_f32, plan.emit_int, plan.relu)
             handle = None
@@ -291,6 +293,9 @@ class NewAdd(nn.Module):
     def forward(self, x, y):
         plan = self.__dict__.get("_resident")             # set by common.quantity.resident.enable()
         if plan is not None and plan.resident_add and self.Sp.bitwidth == 8:
+            fused = self._fused_conv_add(plan, x, y)
+            if fused is not None:
+                return fused
             hx, hy = resident_of(x), resident_of(y)
             if (hx is not None and hy is not None and hx.exact is not None and hy.exact is not None
                     and hx.exact.shape == hy.exact.shape and max(0, hx.grid, hy.grid) == plan.grid):
@@ -311,6 +316,30 @@ class NewAdd(nn.Module):
             out = torch.relu_(out)                        # the ReLU module after this add passes through
             out._fq_relu_done = True
         return out
+
+
+def _newadd_fused_conv_add(self, plan, x, y):
+    """conv -> add in one kernel when one operand is a DeferredConv and the other a resident activation."""
+    d, other = (x, y) if type(x) is DeferredConv else ((y, x) if type(y) is DeferredConv else (None, None))
+    if d is None or type(other) is DeferredConv or d._handle is not None:
+        return None
+    h = resident_of(other)
+    L = d.layer
+    if h is None or h.exact is None or max(0, L.output_bit, h.grid) != plan.grid or plan.emit_f32:
+        return None
+    want_narrow = plan.emit_int and plan.narrow_bit is not None
+    want_wide = plan.want_wide or not want_narrow
+    if h.exact.shape[0] != d.xq.shape[0] or h.exact.shape[-1] != _native.pad16(L.Conv.out_channels):
+        return None
+    wide, narrow = _native.conv2d_i8_add_resident(d.xq, d.wq, L.quantized_bias, d.geom[0], d.geom[1], d.geom[2], L.rs_bit,
+                                                  L.output_bit, h.exact, h.grid, want_wide, plan.grid, want_narrow,
+                                                  plan.narrow_bit if want_narrow else 0, plan.relu)
+    ref = wide if wide is not None else narrow
+    return QHandle((ref.shape[0], L.Conv.out_channels, ref.shape[1], ref.shape[2]), wide, plan.grid, narrow, plan.narrow_bit,
+                   plan.relu)
+
+
+NewAdd._fused_conv_add = _newadd_fused_conv_add
 
 
 class QuanDequan(nn.Module):

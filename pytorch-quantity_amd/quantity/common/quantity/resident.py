@@ -55,20 +55,44 @@ class QHandle(object):
             self.bit if self.narrow is not None else None, self.relu_done)
 
 
+class DeferredConv(object):
+    """A convolution whose only consumer is a resident NewAdd: nothing has been launched yet, the add runs
+    it with the residual fused into its store phase (fq_conv2d_i8_add_resident), so the convolution's own
+    int8 result never reaches HBM.  Anything else that touches it materialises the plain result."""
+    __slots__ = ("layer", "xq", "wq", "geom", "_handle")
+
+    def __init__(self, layer, xq, wq, geom):
+        self.layer, self.xq, self.wq, self.geom, self._handle = layer, xq, wq, geom, None
+
+    def materialise(self):
+        if self._handle is None:
+            L = self.layer
+            _, q = _native.conv2d_i8_resident(self.xq, self.wq, L.quantized_bias, self.geom[0], self.geom[1], self.geom[2],
+                                              L.rs_bit, L.output_bit, False, True, False)
+            self._handle = QHandle((q.shape[0], L.Conv.out_channels, q.shape[1], q.shape[2]), q, L.output_bit, q, L.output_bit,
+                                   False)
+        return self._handle
+
+    def to_f32(self):
+        return self.materialise().to_f32()
+
+
 def resident_of(x):
     """The integer form of an activation, if it has one (a handle, or an fp32 tensor carrying one)."""
     if type(x) is QHandle:
         return x
+    if type(x) is DeferredConv:
+        return x.materialise()
     return getattr(x, "_fq_resident", None)
 
 
 def as_f32(x):
-    return x.to_f32() if type(x) is QHandle else x
+    return x.to_f32() if type(x) in (QHandle, DeferredConv) else x
 
 
 class Plan(object):
     """What one producer emits.  Plain data (pickles with the module)."""
-    __slots__ = ("relu", "emit_f32", "emit_int", "narrow_bit", "want_wide", "grid", "resident_add")
+    __slots__ = ("relu", "emit_f32", "emit_int", "narrow_bit", "want_wide", "grid", "resident_add", "defer", "fuse_arg")
 
     def __init__(self):
         self.relu = False            # the nn.ReLU that consumes this output is fused
@@ -78,11 +102,14 @@ class Plan(object):
         self.want_wide = False       # NewAdd: exact int16 sum needed (next add, or fp32 via dequant)
         self.grid = None             # NewAdd: grid of the exact sum
         self.resident_add = False    # NewAdd: operands arrive as integers
+        self.defer = False           # NewConv2d: only consumer is a resident NewAdd, which runs this conv itself
+        self.fuse_arg = None         # NewAdd: operand position (0 / 1) that arrives as a DeferredConv
 
     def __getstate__(self):
         return {k: getattr(self, k) for k in self.__slots__}
 
     def __setstate__(self, state):
+        self.__init__()
         for k, v in state.items():
             setattr(self, k, v)
 
@@ -414,6 +441,21 @@ def enable(model, example_input, verify=True):
             m.__dict__["forward"] = _MaxPoolResident(m)
         summary[{"contraction": "resident_convs", "add": "resident_adds", "maxpool": "resident_pools"}[v.kind]] += 1
         summary["fp32_outputs" if plan.emit_f32 else "int_only_outputs"] += 1
+    # a convolution whose value goes to one resident add and nowhere else is run BY that add
+    summary["fused_conv_adds"] = 0
+    for add_mod in add_resident:
+        ops = operands[add_mod]
+        for pos in (0, 1):
+            v = ops[pos]
+            conv = v.producer
+            plan = conv.__dict__.get("_resident") if isinstance(conv, NewConv2d) else None
+            if (v.kind == "contraction" and plan is not None and not plan.relu and not plan.emit_f32 and not v.foreign
+                    and v.consumers == [(add_mod, pos)] and ops[1 - pos] is not v
+                    and not add_mod.__dict__["_resident"].emit_f32):
+                plan.defer = True
+                add_mod.__dict__["_resident"].fuse_arg = pos
+                summary["fused_conv_adds"] += 1
+                break
     for m in tracer.avgpool_shapes:
         if avg_can_read(m):
             m.__dict__["forward"] = _AvgPoolResident(m)

@@ -109,7 +109,8 @@ def test_newconv2d_int8_path_equals_float_path(nat):
 
 
 @pytest.mark.parametrize("C,H,W,K,R,S,st,pd,dl", [(3, 33, 31, 64, 7, 7, 2, 3, 1), (1, 28, 28, 6, 3, 3, 1, 1, 1), (4, 16, 20, 10, 5, 3, 1, 2, 2),
-                                                   (3, 224, 224, 64, 7, 7, 2, 3, 1)])
+                                                   (3, 224, 224, 64, 7, 7, 2, 3, 1),
+                                                   (2, 12, 40, 8, 3, 11, 1, 5, 1)])        # S > 8: generic unfold kernel
 def test_stem_unfold_path_vs_integer_oracle(nat, oracle, C, H, W, K, R, S, st, pd, dl):
     """Kernel width folded into the channel axis (stem layers): same integers as the plain convolution."""
     rng = np.random.default_rng(C * 100 + H)

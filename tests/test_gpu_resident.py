@@ -105,6 +105,45 @@ def test_add_resident_equals_fp32_chain(nat, oracle, xb, gx, yb, gy, ib, relu):
     np.testing.assert_array_equal(n3.cpu().numpy(), narrow.cpu().numpy())
 
 
+@pytest.mark.parametrize("case", [(2, 64, 9, 9, 256, 1, 1, 1, 0), (3, 128, 7, 7, 200, 3, 3, 1, 1), (1, 1024, 6, 6, 512, 1, 1, 1, 0)])
+@pytest.mark.parametrize("res_dtype,g_res,relu", [(np.int8, 3, True), (np.int16, 6, True), (np.int16, 5, False)])
+def test_conv_add_fused_equals_conv_then_add(nat, oracle, case, res_dtype, g_res, relu):
+    """fq_conv2d_i8_add_resident == fq_conv2d_i8_resident followed by fq_add_resident == the oracle's fp32 chain
+    DeQuantity -> NewAdd -> ReLU -> Quantity, for both conv kernels (register-staged and LDS-DMA)."""
+    N, C, H, W, K, R, S, st, pd = case
+    rng = np.random.default_rng(sum(case) + g_res)
+    xq = rng.integers(-128, 128, size=(N, C, H, W)).astype(np.int32)
+    wq = rng.integers(-8, 9, size=(K, C, R, S)).astype(np.int32)
+    qb = rng.integers(-20, 20, size=K).astype(np.float32)
+    rs, ob, ib = 10, 4, 4
+    acc = oracle.conv2d_int(xq, wq, (st, st), (pd, pd), (1, 1))
+    conv_f = oracle.recon_epilogue(acc.astype(np.float32), qb, rs, ob)                       # [N,K,P,Q] fp32
+    kpad = (K + 15) // 16 * 16
+    P, Q = conv_f.shape[2], conv_f.shape[3]
+    info = np.iinfo(res_dtype)
+    lim = 128 * 2 ** g_res if res_dtype == np.int16 else 128
+    res = np.zeros((N, P, Q, kpad), dtype=res_dtype)
+    res[..., :K] = rng.integers(max(info.min, -lim), min(info.max, lim - 1) + 1, size=(N, P, Q, K))
+    res_f = oracle.dequantity(res[..., :K].astype(np.float32), g_res).transpose(0, 3, 1, 2)
+    s = oracle.add_sat(conv_f, res_f)
+    if relu:
+        s = np.maximum(s, np.float32(0))
+    g = max(0, ob, g_res)
+    exact = (s.astype(np.float64) * 2.0 ** g)
+    assert np.all(exact == np.rint(exact))
+    x_nhwc = np.ascontiguousarray(xq.transpose(0, 2, 3, 1)).astype(np.int8)
+    w_dev = nat.pack_weight_krsc(_dev(wq.astype(np.float32)))
+    wide, narrow = nat.conv2d_i8_add_resident(_dev(x_nhwc), w_dev, _dev(qb), (st, st), (pd, pd), (1, 1), rs, ob, _dev(res), g_res,
+                                              True, g, True, ib, relu)
+    np.testing.assert_array_equal(wide.cpu().numpy()[..., :K].transpose(0, 3, 1, 2), exact.astype(np.int16))
+    np.testing.assert_array_equal(narrow.cpu().numpy()[..., :K].transpose(0, 3, 1, 2), oracle.quantity(s, ib).astype(np.int8))
+    assert not wide.cpu().numpy()[..., K:].any() and not narrow.cpu().numpy()[..., K:].any()
+    # and the two-kernel form gives the same bytes
+    _, cq = nat.conv2d_i8_resident(_dev(x_nhwc), w_dev, _dev(qb), (st, st), (pd, pd), (1, 1), rs, ob, False, True, False)
+    w2, n2 = nat.add_resident(cq, ob, _dev(res), g_res, True, g, True, ib, relu)
+    assert torch.equal(w2, wide) and torch.equal(n2, narrow)
+
+
 def test_add_resident_refuses_a_sum_that_does_not_fit(nat):
     x = torch.zeros(2, 2, 2, 16, dtype=torch.int8, device="cuda")
     with pytest.raises(nat.FqError):
@@ -230,6 +269,7 @@ def test_r50_resident_equals_fp32_boundary_model():
         summary = resident.enable(net, x)
         assert summary["resident_convs"] == 53 and summary["resident_adds"] == 16 and summary["fused_relus"] == 49, summary
         assert summary["resident_pools"] == 2 and summary["fp32_outputs"] == 0, summary     # max-pool and global average pool
+        assert summary["fused_conv_adds"] == 16, summary                                    # every conv3 runs inside its add
         plans = resident.describe(net)
         assert plans["layer1.0.conv1"].emit_f32 is False and plans["layer1.0.conv1"].relu is True
         assert plans["conv1"].emit_f32 is False and plans["conv1"].emit_int is True and plans["conv1"].relu is True
