@@ -237,10 +237,10 @@ def main():
 
     K, W, B, HW = args.steps, args.warmup, args.batch, args.image
     shape = "1,3,%d,%d" % (HW, HW)
-    model = build_model(args.model, HW, device)
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
-    sys.stdout = devnull                                   # the drop-in prints like the reference does
+    sys.stdout = devnull                                   # the drop-in prints like the reference does (merge_bn too):
+    model = build_model(args.model, HW, device)            # stdout must carry exactly one JSON line
 
     # ---- warmup: W batches per GPU through the same path (MIOpen algo search, RCCL init, code load)
     if W > 0:
