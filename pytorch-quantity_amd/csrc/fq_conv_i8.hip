@@ -23,6 +23,7 @@
 // (chunk ^= (row >> 1) & 7) so that ds_read_b128 fragment reads are bank-conflict free.
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "fq_resident.h"
 
@@ -77,6 +78,26 @@ struct ConvParams {
 // weight-tile latency -- before it issued the activation loads of each K-step.)
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 constexpr unsigned kOutOfRange = 0x80000000u;             // tensors on this path are < 2^31 bytes
+// LDS-DMA: 64 lanes x 16 bytes from a buffer straight into LDS at lds_base + 16 * lane.  Deliberately inline
+// asm rather than __builtin_amdgcn_raw_ptr_buffer_load_lds: hipcc treats the builtin as an LDS store that may
+// alias every later ds_read and inserts s_waitcnt vmcnt(0) right behind it -- in the K loop that serialised
+// the next step's loads with this step's MFMAs completely (found in the ISA, not in the timings of a
+// trace build whose stamps perturb the schedule).  The asm has no memory clobber; ordering is explicit:
+// every wave waits vmcnt(0) and passes a workgroup barrier before anyone reads the slot that was filled.
+typedef int rsrc_words __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ rsrc_words make_rsrc_words(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    rsrc_words r = {(int)(unsigned)(a & 0xffffffffu), (int)(unsigned)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
+    return r;
+}
+__device__ __forceinline__ void dma_to_lds(rsrc_words rsrc, unsigned lds_base, unsigned voffset, int soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :: "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(soffset) : "m0");
+}
+__device__ __forceinline__ unsigned lds_offset(const void* shared_ptr) {
+    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)shared_ptr;
+}
+
 __device__ __forceinline__ v4i load_act(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return (v4i)__builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
 }
@@ -429,9 +450,9 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     __shared__ __attribute__((aligned(16))) int8_t sB[2][kTP * BKB];
     __shared__ float sBias[TK];
     __shared__ int sBiasI[TK];
-    typedef __attribute__((address_space(3))) void* lds_ptr;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA bases live in SGPRs (M0)
     const int half = lane >> 5;
     const int m0 = blockIdx.x * kTP;
     const int k0 = blockIdx.y * TK;
@@ -458,7 +479,7 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
 
     // activation staging: in load j this lane fetches pixel row pj = 8j + (lane >> 3) of the wave's 32 and
     // LDS position lane & 7, i.e. global chunk (lane & 7) ^ swz(pj)
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(x), 0, p.x_bytes, 0x00020000);
+    const rsrc_words xr = make_rsrc_words(x, p.x_bytes);
     int ih0[4], iw0[4];
     unsigned boff[4];                                     // image base + chunk byte offset inside a K-step
 #pragma unroll
@@ -474,7 +495,7 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
         boff[j] = (unsigned)nj * (unsigned)(p.H * p.W * p.C) + (unsigned)(((lane & 7) ^ swz(pj, 0)) * 16);
     }
     // weight staging: load j of wave v covers tile rows 32j + 8v .. +7 (one 128-byte K-step row per 8 lanes)
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(w), 0, p.w_bytes, 0x00020000);
+    const rsrc_words wr = make_rsrc_words(w, p.w_bytes);
     unsigned aoff[A_LOADS];
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) {
@@ -484,24 +505,25 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
 
     int tap_r = 0, tap_s = 0, c_step = 0;                 // filter tap (uniform) and K-step inside it
     const int steps_per_tap = p.C >> 7;
-    unsigned bvo[4];                                      // activation offsets of the current tap
-    auto issue_step = [&](int buf, int step) {            // K-step `step` -> LDS buffers `buf`
+    unsigned bvo[4];                                      // activation offsets of the tap being loaded
+    auto tap_offsets = [&](bool live) {                   // branch-free; `live` = false: every lane out of range
 #pragma unroll
-        for (int j = 0; j < A_LOADS; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wr, (lds_ptr)&sA[buf][(32 * j + 8 * wave) * BKB], 16, (int)aoff[j],
-                                                     step * BKB, 0, 0);
-        if (c_step == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ih = ih0[j] + tap_r * p.dil_h, iw = iw0[j] + tap_s * p.dil_w;
-                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                bvo[j] = ok ? boff[j] + (unsigned)((ih * p.W + iw) * p.C) : kOutOfRange;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int ih = ih0[j] + tap_r * p.dil_h, iw = iw0[j] + tap_s * p.dil_w;
+            const bool ok = live && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            bvo[j] = ok ? boff[j] + (unsigned)((ih * p.W + iw) * p.C) : kOutOfRange;
         }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xr, (lds_ptr)&sB[buf][(wave * 32 + 8 * j) * BKB], 16, (int)bvo[j],
-                                                     c_step * BKB, 0, 0);
+    };
+    // DMA instruction k of a K-step (k < A_LOADS: weight rows, then the 4 activation row groups) into ring
+    // slot `buf`; a_live = false sends the weight lanes out of range too (a step past the end loads nothing)
+    auto dma = [&](auto k_tag, int buf, int step, bool a_live) {
+        constexpr int k = decltype(k_tag)::value;
+        if constexpr (k < A_LOADS)
+            dma_to_lds(wr, lds_offset(&sA[buf][(32 * k + 8 * wave) * BKB]), a_live ? aoff[k] : kOutOfRange, step * BKB);
+        else
+            dma_to_lds(xr, lds_offset(&sB[buf][(wave * 32 + 8 * (k - A_LOADS)) * BKB]), bvo[k - A_LOADS], c_step * BKB);
+    };
+    auto advance_tap = [&]() {
         if (++c_step == steps_per_tap) {
             c_step = 0;
             if (++tap_s == p.S) { tap_s = 0; ++tap_r; }
@@ -522,47 +544,66 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     const int b_row = (wave * 32 + (lane & 31)) * BKB;    // this lane's pixel row in the activation tile
 
     const int nsteps = p.chunks >> 3;
+    constexpr int kLoads = A_LOADS + 4;                   // DMA instructions one wave issues per K-step
+    auto for_each_dma = [&](auto&& f) {                   // f(integral_constant<k>) for k = 0 .. kLoads-1
+        [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
+        (std::make_integer_sequence<int, kLoads>{});
+    };
     TR(1);
-    issue_step(0, 0);
+    tap_offsets(true);
+    for_each_dma([&](auto k) { dma(k, 0, 0, true); });
+    advance_tap();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA rows have landed ...
     __syncthreads();                                      // ... and so have everybody else's
     TR(2);
+    // The loop body is one basic block: the next step's 8 DMA issues (~65 cycles each for the issuing wave)
+    // are written -- and pinned with sched_group_barrier -- BETWEEN this step's MFMAs, one behind each of the
+    // first 2*MT, together with the second half of the fragment reads, so that issue cost and ds_read latency
+    // hide under the matrix pipe instead of preceding it.  A step past the end sends every lane out of range
+    // (no traffic) rather than branching, which would split the block.
     for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1;
+        const int cur = step & 1, nxt = cur ^ 1;
+        const bool more = step + 1 < nsteps;
         TR(8 + step * 8 + 0);
-        if (step + 1 < nsteps) issue_step(cur ^ 1, step + 1);          // next step's tiles fly under the MFMAs
+        tap_offsets(more);
         TR(8 + step * 8 + 1);
         v4i fb[4], fa[4][MT];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) fb[ks] = *reinterpret_cast<const v4i*>(&sB[cur][b_row + swz_off[ks]]);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int a = 0; a < MT; ++a)
                 fa[ks][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[ks]]);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
+        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+            ([&] {
+                constexpr int i = Is, ks = i / MT, a = i % MT;
                 acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks][a], fb[ks], acc[a], 0, 0, 0);
+                if constexpr (i < 2 * MT) {
+                    fa[2 + ks][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[2 + ks]]);
+                    constexpr int k0_ = kLoads * i / (2 * MT), k1_ = kLoads * (i + 1) / (2 * MT);
+                    if constexpr (k1_ > k0_) dma(std::integral_constant<int, k0_>{}, nxt, step + 1, more);
+                    if constexpr (k1_ > k0_ + 1) dma(std::integral_constant<int, k0_ + 1>{}, nxt, step + 1, more);
+                }
+            }(), ...);
+        }(std::make_integer_sequence<int, 4 * MT>{});
 #ifndef FQ_CONV_TRACE
-        // issue order: the 4 activation fragments and half of the weight fragments, then one read behind
-        // each MFMA (left alone, hipcc sinks every read to just above its MFMA and waits lgkmcnt(0) each time)
         __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * MT, 0);
-#pragma unroll
-        for (int i = 0; i < 2 * MT; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        }
+        [&]<int... Is>(std::integer_sequence<int, Is...>) {
+            ([&] {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x010, kLoads * (Is + 1) / (2 * MT) - kLoads * Is / (2 * MT), 0);
+            }(), ...);
+        }(std::make_integer_sequence<int, 2 * MT>{});
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT, 0);
 #endif
+        advance_tap();
         TR(8 + step * 8 + 2);
-        if (step + 1 < nsteps) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            TR(8 + step * 8 + 3);
-            __syncthreads();
-            TR(8 + step * 8 + 4);
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next step's tiles have landed (last step: nothing was loaded)
+        TR(8 + step * 8 + 3);
+        __syncthreads();
+        TR(8 + step * 8 + 4);
     }
     TR(3);
 
