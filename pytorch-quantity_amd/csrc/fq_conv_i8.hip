@@ -432,13 +432,16 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
 //     lanes fetch the 8 chunks (128 contiguous bytes) of one row, so a wave-load touches 8 full lines, and
 //     lane l lands at LDS base + 16*l.  The XOR swizzle that makes the MFMA-layout ds_read_b128 conflict
 //     free is applied on the global side: LDS position c of row r receives chunk c ^ ((r >> 1) & 7);
-//   * the K-step advance is the scalar offset of the buffer instruction (no vector arithmetic per step);
-//     the per-lane offsets are recomputed only when the filter tap changes (every C / 128 steps).
-//     Out-of-image taps use an offset beyond num_records and arrive as zeros;
-//   * fragment reads are pinned ahead of the MFMAs that use them (sched_group_barrier), so ds_read
-//     latency hides under the matrix pipe.
+//   * the K-step advance is the scalar offset of the buffer instruction; the per-lane tap offsets are a
+//     handful of branch-free vector ops per step.  Out-of-image taps (and the step past the last one) use an
+//     offset beyond num_records and arrive as zeros without touching memory;
+//   * the loop body is one basic block in which the next step's 8 DMA issues and the second half of the
+//     fragment reads are written, and pinned with sched_group_barrier, one behind each of the first 2*MT
+//     MFMAs, so issue cost and ds_read latency hide under the matrix pipe (dma_to_lds explains why the DMA
+//     is inline asm).
 // Each wave stages the activation rows it multiplies itself and a quarter of the weight tile; one
 // vmcnt(0) + workgroup barrier per K-step orders the DMA writes before the next step's reads.
+// What bounds it now is operand delivery: ~16 bytes per clock per CU at 128 ops per loaded byte.
 template <int TK, int kOut>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                    const float* __restrict__ qbias, float* __restrict__ y,

@@ -98,6 +98,13 @@ class Reconstruction(object):
         return self._rebuild(all_quantize_infor, new_model_path,
                              lambda n, m, q: NewConv2d(m, q), lambda n, m, q: NewLinear(m, q), "ReconModel")
 
+    def make_resident(self, example_input, verify=True):
+        """Extension: keep the integer-simulation model's activations as integers between its layers
+        (common.quantity.resident.enable on self.model, which must already be the ReconModel on the GPU).
+        Same outputs bit for bit; returns the plan summary."""
+        from common.quantity import resident
+        return resident.enable(self.model, example_input, verify=verify)
+
     def ReconTest(self, all_quantize_infor, new_model_path):
         """Fake-quant evaluation model: w, b fake-quantised once; every output fake-quantised."""
         return self._rebuild(all_quantize_infor, new_model_path,
