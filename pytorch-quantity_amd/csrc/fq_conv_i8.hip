@@ -198,6 +198,28 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
         // contiguous bytes per pixel.  Rows k >= K carry zero weights and zero bias, so the channel
         // padding [K, Kpad) is written as zeros.
         constexpr int OS = TK + 16;                       // LDS row stride in bytes (16-byte aligned rows)
+        constexpr int CPP = TK / 16;                      // 16-byte chunks per pixel
+        constexpr int NJ = (kTP * CPP) / kConvBlock;      // 16-channel groups each thread stores
+        // fused NewAdd: the residual groups this thread will need are requested FIRST, so that their latency
+        // hides under the tail arithmetic and the LDS transpose below instead of sitting in front of the stores
+        // (the operand-fragment registers are dead here, so this costs no occupancy)
+        v4i_r res_lo[NJ], res_hi[NJ];
+        if (kOut & kOutAdd) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int idx = tid + kConvBlock * j;
+                const int pix = idx / CPP, ch = idx - pix * CPP;
+                const int mm = m0 + pix, kk = k0 + 16 * ch;
+                const bool live = mm < p.M && kk < p.Kpad;
+                const long off = live ? (long)mm * p.Kpad + kk : 0;
+                if (p.res_bytes == 1) {
+                    res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
+                } else {
+                    res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
+                    res_hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
+                }
+            }
+        }
         __syncthreads();                                  // every wave is done reading the operand tiles
         const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
 #pragma unroll
@@ -215,9 +237,8 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
             }
         }
         __syncthreads();
-        constexpr int CPP = TK / 16;                      // 16-byte chunks per pixel
 #pragma unroll
-        for (int j = 0; j < (kTP * CPP) / kConvBlock; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int idx = tid + kConvBlock * j;
             const int pix = idx / CPP, ch = idx - pix * CPP;
             const int mm = m0 + pix, kk = k0 + 16 * ch;
@@ -225,18 +246,18 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
                 const long off = (long)mm * p.Kpad + kk;
                 if (kOut & kOutAdd) {
                     // NewAdd (+ ReLU + the consumers' Quantity) on the tile while it is in flight: the conv's
-                    // int8 result never reaches HBM, the residual is read here, 16 channels per thread
+                    // int8 result never reaches HBM; 16 channels per thread
                     Vec16<int8_t> cv;
                     cv.a = *reinterpret_cast<const v4i_r*>(&sO[pix * OS + 16 * ch]);
                     int16_t* wd = p.wide ? p.wide + off : nullptr;
                     int8_t* nd = q ? q + off : nullptr;
                     if (p.res_bytes == 1) {
                         Vec16<int8_t> rv;
-                        rv.load(static_cast<const int8_t*>(p.res) + off);
+                        rv.a = res_lo[j];
                         add_resident_16(cv, rv, wd, nd, p.ap);
                     } else {
                         Vec16<int16_t> rv;
-                        rv.load(static_cast<const int16_t*>(p.res) + off);
+                        rv.a = res_lo[j]; rv.b = res_hi[j];
                         add_resident_16(cv, rv, wd, nd, p.ap);
                     }
                 } else {
