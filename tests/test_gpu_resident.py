@@ -239,14 +239,14 @@ def test_r18_resident_logits_equal_reference_golden(golden_dir, g3):
             np.testing.assert_array_equal(net(x).cpu().numpy(), plain)
 
 
-def _calibrated_recon(model_fn, image, batch):
+def _calibrated_recon(model_fn, image, batch, channels=3):
     """Calibrate a seeded model on the GPU and rebuild it as ReconModel; returns (net, input batch)."""
     from tools import Quantity, Reconstruction
     from common.quantity import merge_bn
     dev = torch.device("cuda")
     model = merge_bn(cases.seed_model(model_fn()).eval()).to(dev)
     gen = np.random.default_rng(5)
-    data = [(torch.from_numpy(gen.standard_normal((batch, 3, image, image), dtype=np.float32)).to(dev), 0) for _ in range(2)]
+    data = [(torch.from_numpy(gen.standard_normal((batch, channels, image, image), dtype=np.float32)).to(dev), 0) for _ in range(2)]
     q = Quantity(model)
     q.activation_quantize(data)
     q.weight_quantize()
@@ -344,3 +344,28 @@ def test_foreign_consumers_and_shared_relu():
     with torch.no_grad():
         assert torch.equal(net(x), plain)
         assert torch.equal(net(x[:1]), plain[:1])
+
+
+@pytest.mark.parametrize("tag", ["concat", "lenet"])
+def test_small_nets_with_concat_and_pool_only_topologies(tag, monkeypatch):
+    """Nets whose integer layers feed things the plan does not own (a Concat marker layer, View, Linear
+    chains): whatever goes resident, the logits must not change, and Concat operands must stay fp32."""
+    from common.quantity import resident
+    if tag == "concat":
+        fn, shape, image, ch = cases.tiny_concat_net, "1,3,8,8", 8, 3
+        monkeypatch.setattr(torch, "save", lambda *a, **k: None)       # the fixture net is a local class: not picklable
+    else:
+        fn, shape, image, ch = (lambda: __import__("model.lenet.lenet", fromlist=["Cnn"]).Cnn(1, 10)), "1,1,28,28", 28, 1
+    with product_workdir(input_shape=shape, device="gpu"):
+        net, x = _calibrated_recon(fn, image, 4, channels=ch)
+        with torch.no_grad():
+            plain = net(x)
+        summary = resident.enable(net, x)                     # verifies bit-identity on x itself
+        plans = resident.describe(net)
+        if tag == "concat":
+            assert plans["branch_a"].emit_f32 and plans["branch_b"].emit_f32, plans          # Concat is foreign code
+            assert plans["stem"].relu and plans["Eltwise"].resident_add, plans
+        assert summary["resident_convs"] >= 2
+        with torch.no_grad():
+            assert torch.equal(net(x), plain)
+            assert torch.equal(net(torch.flip(x, dims=[0])), torch.flip(plain, dims=[0]))
