@@ -207,6 +207,13 @@ def main():
     ap.add_argument("--no-recon", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON.  Native libraries write there too (RCCL prints a version
+    # banner on init), so file descriptor 1 itself is parked on /dev/null until the result is ready.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    null_fd = os.open(os.devnull, os.O_WRONLY)
+    os.dup2(null_fd, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -383,6 +390,8 @@ def main():
             result["cpu_baseline"] = {"error": repr(e)}
 
     sys.stdout = real_stdout
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
     if rank == 0:
         log("feat.table head:", feat_table.split("\n")[:4])
         print(json.dumps(result), flush=True)
