@@ -530,12 +530,19 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     int tap_r = 0, tap_s = 0, c_step = 0;                 // filter tap (uniform) and K-step inside it
     const int steps_per_tap = p.C >> 7;
     unsigned bvo[4];                                      // activation offsets of the tap being loaded
+    // offset of tap (r, s) = base0[j] + (r * dil_h * W + s * dil_w) * C: the second term is wave-uniform (scalar
+    // ALU), so a step costs each lane one add and two range checks per row group -- no vector multiplies (the
+    // first version recomputed (ih * W + iw) * C per lane: ~500 cycles of quarter-rate v_mul_lo_u32 per step)
+    unsigned base0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) base0[j] = boff[j] + (unsigned)((ih0[j] * p.W + iw0[j]) * p.C);
     auto tap_offsets = [&](bool live) {                   // branch-free; `live` = false: every lane out of range
+        const int dh = tap_r * p.dil_h, dw = tap_s * p.dil_w;
+        const unsigned tap_delta = (unsigned)((dh * p.W + dw) * p.C);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int ih = ih0[j] + tap_r * p.dil_h, iw = iw0[j] + tap_s * p.dil_w;
-            const bool ok = live && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            bvo[j] = ok ? boff[j] + (unsigned)((ih * p.W + iw) * p.C) : kOutOfRange;
+            const bool ok = live && (unsigned)(ih0[j] + dh) < (unsigned)p.H && (unsigned)(iw0[j] + dw) < (unsigned)p.W;
+            bvo[j] = ok ? base0[j] + tap_delta : kOutOfRange;
         }
     };
     // DMA instruction k of a K-step (k < A_LOADS: weight rows, then the 4 activation row groups) into ring
@@ -611,7 +618,6 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
                 }
             }(), ...);
         }(std::make_integer_sequence<int, 4 * MT>{});
-#ifndef FQ_CONV_TRACE
         __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * MT, 0);
         [&]<int... Is>(std::integer_sequence<int, Is...>) {
             ([&] {
@@ -621,7 +627,6 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
             }(), ...);
         }(std::make_integer_sequence<int, 2 * MT>{});
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT, 0);
-#endif
         advance_tap();
         TR(8 + step * 8 + 2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next step's tiles have landed (last step: nothing was loaded)

@@ -33,8 +33,8 @@ for wg in range(8):
     for s_ in range(nsteps):
         e = t[8 + 8 * s_: 16 + 8 * s_]
         if s_ + 1 < nsteps:
-            rows.append("  step %2d: issue %4d  reads+mfma %4d  vmcnt %4d  barrier %4d  | total %5d" %
+            rows.append("  step %2d: tap offsets %4d  reads+dma+mfma %4d  vmcnt %4d  barrier %4d  | total %5d" %
                         (s_, e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3], (t[8 + 8 * (s_ + 1)] - e[0])))
         else:
-            rows.append("  step %2d: issue %4d  reads+mfma %4d" % (s_, e[1] - e[0], e[2] - e[1]))
+            rows.append("  step %2d: tap offsets %4d  reads+dma+mfma %4d" % (s_, e[1] - e[0], e[2] - e[1]))
     print("\n".join(rows[:6] + rows[-2:]))
