@@ -463,15 +463,16 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
 // Each wave stages the activation rows it multiplies itself and a quarter of the weight tile; one
 // vmcnt(0) + workgroup barrier per K-step orders the DMA writes before the next step's reads.
 // What bounds it now is operand delivery: ~16 bytes per clock per CU at 128 ops per loaded byte.
-template <int TK, int kOut>
+template <int TK, int kOut, int STAGES>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                    const float* __restrict__ qbias, float* __restrict__ y,
                                                                    int8_t* __restrict__ q, const ConvParams p) {
     constexpr int BKB = 128;
     constexpr int MT = TK / 32;
     constexpr int A_LOADS = TK / 32;
-    __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * BKB];
-    __shared__ __attribute__((aligned(16))) int8_t sB[2][kTP * BKB];
+    static_assert(STAGES == 2 || STAGES == 3, "LDS ring of 2 or 3 K-steps");
+    __shared__ __attribute__((aligned(16))) int8_t sA[STAGES][TK * BKB];
+    __shared__ __attribute__((aligned(16))) int8_t sB[STAGES][kTP * BKB];
     __shared__ float sBias[TK];
     __shared__ int sBiasI[TK];
 
@@ -581,20 +582,30 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
         (std::make_integer_sequence<int, kLoads>{});
     };
     TR(1);
-    tap_offsets(true);
-    for_each_dma([&](auto k) { dma(k, 0, 0, true); });
-    advance_tap();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA rows have landed ...
+    // STAGES - 1 K-steps are in flight.  With a ring of 3 the wait at the end of step s is for step s + 1 only
+    // (vmcnt counts in issue order; the kLoads newest -- step s + 2 -- may stay outstanding), which takes the
+    // ~400 cycles of DMA latency that a ring of 2 exposes on every step off the critical path, at the price of
+    // 1.5x the LDS (96 / 72 KB: one / two workgroups per CU).
+#pragma unroll
+    for (int s0 = 0; s0 < STAGES - 1; ++s0) {
+        const bool live0 = s0 < nsteps;
+        tap_offsets(live0);
+        for_each_dma([&](auto k) { dma(k, s0, s0, live0); });
+        advance_tap();
+    }
+    if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's DMA rows of step 0 have landed ...
     __syncthreads();                                      // ... and so have everybody else's
     TR(2);
-    // The loop body is one basic block: the next step's 8 DMA issues (~65 cycles each for the issuing wave)
-    // are written -- and pinned with sched_group_barrier -- BETWEEN this step's MFMAs, one behind each of the
-    // first 2*MT, together with the second half of the fragment reads, so that issue cost and ds_read latency
-    // hide under the matrix pipe instead of preceding it.  A step past the end sends every lane out of range
-    // (no traffic) rather than branching, which would split the block.
+    // The loop body is one basic block: the 8 DMA issues of the step being prefetched (~65 cycles each for the
+    // issuing wave) are written -- and pinned with sched_group_barrier -- BETWEEN this step's MFMAs, one behind
+    // each of the first 2*MT, together with the second half of the fragment reads, so that issue cost and
+    // ds_read latency hide under the matrix pipe instead of preceding it.  A step past the end sends every lane
+    // out of range (no traffic) rather than branching, which would split the block.
+    int cur = 0, nxt = STAGES - 1;                        // ring slots of this step and of the step being prefetched
     for (int step = 0; step < nsteps; ++step) {
-        const int cur = step & 1, nxt = cur ^ 1;
-        const bool more = step + 1 < nsteps;
+        const int pre = step + STAGES - 1;                // the K-step whose tiles are requested during this one
+        const bool more = pre < nsteps;
         TR(8 + step * 8 + 0);
         tap_offsets(more);
         TR(8 + step * 8 + 1);
@@ -613,8 +624,8 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
                 if constexpr (i < 2 * MT) {
                     fa[2 + ks][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[2 + ks]]);
                     constexpr int k0_ = kLoads * i / (2 * MT), k1_ = kLoads * (i + 1) / (2 * MT);
-                    if constexpr (k1_ > k0_) dma(std::integral_constant<int, k0_>{}, nxt, step + 1, more);
-                    if constexpr (k1_ > k0_ + 1) dma(std::integral_constant<int, k0_ + 1>{}, nxt, step + 1, more);
+                    if constexpr (k1_ > k0_) dma(std::integral_constant<int, k0_>{}, nxt, pre, more);
+                    if constexpr (k1_ > k0_ + 1) dma(std::integral_constant<int, k0_ + 1>{}, nxt, pre, more);
                 }
             }(), ...);
         }(std::make_integer_sequence<int, 4 * MT>{});
@@ -629,14 +640,19 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
         __builtin_amdgcn_sched_group_barrier(0x008, 2 * MT, 0);
         advance_tap();
         TR(8 + step * 8 + 2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // next step's tiles have landed (last step: nothing was loaded)
+        // the next step's tiles must have landed; with a ring of 3 the one just requested may still be in flight
+        if (STAGES == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLoads) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         TR(8 + step * 8 + 3);
         __syncthreads();
         TR(8 + step * 8 + 4);
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing of this wave may still land in LDS: the epilogue reuses it
     TR(3);
 
-    static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the int8 output tile is staged in the weight buffers");
+    static_assert(kTP * (TK + 16) <= STAGES * TK * BKB, "the int8 output tile is staged in the weight buffers");
     if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
     else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
     TR(4);
@@ -877,17 +893,30 @@ extern "C" int fq_quantize_i8_unfold_w(const float* x_nchw, int8_t* y, int N, in
 
 namespace fq {
 
+template <int TK, int STAGES>
+static void launch_conv_dma_stages(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
+                                   int8_t* q, const ConvParams& p) {
+    if (p.res)
+        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutI8 | kOutAdd, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else if (y && q)
+        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutF32 | kOutI8, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else if (q)
+        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutI8, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    else
+        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutF32, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+}
+
 template <int TK>
 static void launch_conv_dma(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
                             int8_t* q, const ConvParams& p) {
-    if (p.res)
-        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutI8 | kOutAdd>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
-    else if (y && q)
-        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutF32 | kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
-    else if (q)
-        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
-    else
-        hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutF32>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+    // A ring of 3 takes the DMA latency off the per-step critical path (one wave's step: 1 960 -> 1 700 cycles) but
+    // needs 96 / 72 KB of LDS, i.e. one workgroup fewer per CU: it pays exactly when the launch cannot put a
+    // second workgroup on the CUs anyway (the 7x7 layers at batch 128, most layers at small batch) and costs
+    // 20-50 % otherwise (measured per layer, scripts/conv_bench.py with FQ_CONV_STAGES=2/3).
+    static const int stages_env = [] { const char* e = getenv("FQ_CONV_STAGES"); return e ? atoi(e) : 0; }();
+    const bool three = stages_env ? stages_env == 3 : (long)grid.x * grid.y <= kCUs;
+    if (three) launch_conv_dma_stages<TK, 3>(grid, st, x, w, qbias, y, q, p);
+    else launch_conv_dma_stages<TK, 2>(grid, st, x, w, qbias, y, q, p);
 }
 
 template <int TK, bool kC128>
