@@ -17,9 +17,12 @@ The JSON line also carries
                  per launch) / its mean launch duration measured with HIP events on the launch stream;
   cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded
                  sample on this box's host cores, scaled to the same workload (rank 0, N=1 only);
-  int8_sim_images_per_s / fakequant_images_per_s : ReconModel / ReconTest forward throughput.
-  int8_sim_resident_images_per_s : the same ReconModel after common.quantity.resident.enable() (integer
-                     activations stay in HBM as int8/int16 NHWC between layers; identical logits).
+  int8_sim_images_per_s : ReconModel forward throughput with resident integer activations
+                     (common.quantity.resident.enable(): int8/int16 NHWC between layers; logits checked
+                     bit-identical to the fp32-boundary model in the same run, see int8_sim_resident);
+  int8_sim_fp32_boundary_images_per_s : the same ReconModel with the reference's fp32 NCHW tensor at
+                     every module boundary (the drop-in default);
+  fakequant_images_per_s / float_forward_images_per_s : ReconTest and the float model.
 """
 import argparse
 import json
@@ -291,7 +294,8 @@ def main():
     result = {
         "metric": BASELINE_METRIC,
         "metric_note": "value = calibration images/s (both passes + KL sweep + feat.table, end to end); "
-                       "int8-sim images/s is reported beside it as int8_sim_images_per_s",
+                       "int8-sim images/s is reported beside it as int8_sim_images_per_s (resident integer activations, logits bit-identical "
+                       "to int8_sim_fp32_boundary_images_per_s, the reference's module-boundary form)",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host-resident, PCIe inclusive)" if args.host_inputs else ""),
@@ -369,7 +373,7 @@ def main():
             rec2 = Reconstruction(build_model(args.model, HW, device))
             info2 = rec2.get_quantity_information()
             int8_net = rec2.ReconModel(info2, "./workdir/recon.pth")
-            result["int8_sim_images_per_s"] = round(fwd_rate(int8_net), 1)
+            result["int8_sim_fp32_boundary_images_per_s"] = round(fwd_rate(int8_net), 1)
             # same model, same logits, activations kept as int8/int16 NHWC between the integer layers
             from common.quantity import resident
             with torch.no_grad():
@@ -377,8 +381,10 @@ def main():
             plan = resident.enable(int8_net, batches[0])
             with torch.no_grad():
                 same = bool(torch.equal(int8_net(batches[0]), logits_fp32_boundary))
-            result["int8_sim_resident_images_per_s"] = round(fwd_rate(int8_net), 1)
+            result["int8_sim_images_per_s"] = round(fwd_rate(int8_net), 1)
             result["int8_sim_resident"] = {"bit_identical_logits": same, "plan": plan}
+            if not same:                                   # never report a rate for a model that computes something else
+                result["int8_sim_images_per_s"] = result["int8_sim_fp32_boundary_images_per_s"]
         except Exception as e:  # the headline number above stands on its own
             result["recon_error"] = repr(e)
 
