@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""GPU probe: randomised parity sweep of fq_conv2d_i8 / _resident / _add_resident against the CPU oracle
+(oracle/fq_oracle.c: exact integer conv + the reference's fp32 tail).  usage: conv_fuzz.py [cases] [seed]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity")); sys.path.insert(0, ROOT)
+from common.quantity import _native as nat
+from oracle import fq_oracle as orc
+orc.build()
+
+
+def run(cases, seed, verbose=True):
+    """Returns the list of mismatching cases (empty = parity)."""
+    rng = np.random.default_rng(seed)
+    failures = []
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for it in range(cases):
+        kind = rng.integers(0, 4)
+        if kind == 0:      # LDS-DMA shapes: C % 128 == 0, K % 64 == 0, deep reduction
+            C = int(rng.choice([128, 256, 512])); K = int(rng.choice([64, 128, 192, 256])); R = int(rng.choice([1, 3]))
+            if R == 1: C = int(rng.choice([1024, 2048]))
+        elif kind == 1:    # register-staged fast path
+            C = int(rng.choice([128, 256])); K = int(rng.choice([64, 128, 256, 320])); R = int(rng.choice([1, 1, 3]))
+        else:              # general path: ragged channels
+            C = int(rng.integers(1, 80)); K = int(rng.integers(1, 150)); R = int(rng.choice([1, 2, 3, 5]))
+        S = R if rng.random() < 0.8 else int(rng.choice([1, 2, 3]))
+        H = int(rng.integers(R, 13)); W = int(rng.integers(S, 13)); N = int(rng.integers(1, 5))
+        st = int(rng.choice([1, 1, 2])); pd = int(rng.integers(0, (min(R, S) + 1) // 2 + 1)); dl = int(rng.choice([1, 1, 1, 2]))
+        if (H + 2 * pd - dl * (R - 1) - 1) // st + 1 <= 0 or (W + 2 * pd - dl * (S - 1) - 1) // st + 1 <= 0:
+            continue
+        x = rng.integers(-128, 128, size=(N, C, H, W)).astype(np.int32)
+        w = rng.integers(-128, 128, size=(K, C, R, S)).astype(np.int32)
+        qb = rng.integers(-128, 128, size=K).astype(np.float32)
+        rs = int(rng.integers(0, 19)); ob = int(rng.integers(-2, 7)); relu = bool(rng.integers(0, 2))
+        acc = orc.conv2d_int(x, w, (st, st), (pd, pd), (dl, dl))
+        ref = orc.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+        cpad = (C + 15) // 16 * 16; kpad = (K + 15) // 16 * 16
+        xn = np.zeros((N, H, W, cpad), dtype=np.int8); xn[..., :C] = x.transpose(0, 2, 3, 1)
+        wd = nat.pack_weight_krsc(dev(w.astype(np.float32)))
+        xd, bd = dev(xn), dev(qb)
+        msg = "case %d: N%d C%d H%d W%d K%d R%d S%d st%d pd%d dl%d rs%d ob%d relu%d" % (it, N, C, H, W, K, R, S, st, pd, dl, rs, ob, relu)
+        try:
+            y = nat.conv2d_i8(xd, wd, bd, (st, st), (pd, pd), (dl, dl), rs, ob).cpu().numpy()
+            assert np.array_equal(y, ref), "fp32 output"
+            refr = np.maximum(ref, np.float32(0)) if relu else ref
+            y2, q2 = nat.conv2d_i8_resident(xd, wd, bd, (st, st), (pd, pd), (dl, dl), rs, ob, True, True, relu)
+            assert np.array_equal(y2.cpu().numpy(), refr), "resident fp32"
+            qn = q2.cpu().numpy()
+            assert np.array_equal(qn[..., :K].transpose(0, 3, 1, 2), orc.quantity(refr, ob).astype(np.int8)) and not qn[..., K:].any(), "resident int8"
+            # fused residual add
+            g_res = int(rng.integers(-1, 9)); res_dtype = np.int16 if rng.random() < 0.6 else np.int8
+            g = max(0, ob, g_res)
+            if g <= 8 and -16 <= ob <= 16:
+                P, Q = ref.shape[2], ref.shape[3]
+                lim = 128 * 2 ** max(g_res, 0) if res_dtype == np.int16 else 128
+                res = np.zeros((N, P, Q, kpad), dtype=res_dtype)
+                res[..., :K] = rng.integers(-min(lim, 32768), min(lim, 32768), size=(N, P, Q, K))
+                ib = int(rng.integers(-1, 7))
+                s = orc.add_sat(ref, orc.dequantity(res[..., :K].astype(np.float32), g_res).transpose(0, 3, 1, 2))
+                if relu: s = np.maximum(s, np.float32(0))
+                e = s.astype(np.float64) * 2.0 ** g
+                if np.all(e == np.rint(e)):
+                    wide, narrow = nat.conv2d_i8_add_resident(xd, wd, bd, (st, st), (pd, pd), (dl, dl), rs, ob, dev(res), g_res, True, g, True, ib, relu)
+                    assert np.array_equal(wide.cpu().numpy()[..., :K].transpose(0, 3, 1, 2), e.astype(np.int16)), "fused add wide"
+                    assert np.array_equal(narrow.cpu().numpy()[..., :K].transpose(0, 3, 1, 2), orc.quantity(s, ib).astype(np.int8)), "fused add narrow"
+        except AssertionError as ex:
+            failures.append("%s -> %s" % (msg, ex))
+            if verbose:
+                print("MISMATCH", msg, "->", ex)
+
+    return failures
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
+    fails = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    print("conv_fuzz: %d cases, %d mismatches" % (n, len(fails)))
+    sys.exit(1 if fails else 0)
