@@ -65,6 +65,25 @@ def test_no_cpu_fallback_for_device_ops():
         NewAdd()(x, x)
     with pytest.raises(_native.FqError):
         _native.absmax_seg([x], [0], torch.zeros(1))
+    q = torch.zeros(1, 2, 2, 16, dtype=torch.int8)
+    for call in (lambda: _native.add_resident(q, 3, q, 3, True, 3, True, 3, False),
+                 lambda: _native.dequant_nhwc_to_nchw(q, 3, 16),
+                 lambda: _native.maxpool_i8_nhwc(q, (2, 2), (2, 2), (0, 0)),
+                 lambda: _native.avgpool_global_nhwc(q, 3, 16),
+                 lambda: _native.conv2d_i8_resident(q, q, torch.zeros(1), (1, 1), (0, 0), (1, 1), 8, 3, True, True, False)):
+        with pytest.raises(_native.FqError):
+            call()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    """No lazy build, no fallback: if libfq_hip.so is absent every entry point raises FqError."""
+    from common.quantity import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libfq_hip.so")
+    with pytest.raises(_native.FqError, match="no CPU fallback"):
+        _native.lib()
+    with pytest.raises(_native.FqError):
+        _native.json_dump_i32([1, 2], "/tmp/should_not_exist.json")
 
 
 # ---------------------------------------------------------------- JSON writer
