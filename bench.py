@@ -208,6 +208,7 @@ def main():
                     help="hand the calibrator pageable HOST batches (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recon", action="store_true")
+    ap.add_argument("--no-per-channel", action="store_true")
     args = ap.parse_args()
 
     # stdout carries exactly ONE line, the JSON.  Native libraries write there too (RCCL prints a version
@@ -394,6 +395,26 @@ def main():
                                                   4, HW, images, q, log)
         except Exception as e:
             result["cpu_baseline"] = {"error": repr(e)}
+
+    # ---- per-channel rows (extension; BASELINE configs[1] words the workload "per-channel"): same two passes with
+    # one histogram row per (tensor, channel), read in place by fq_absmax_chan / fq_hist2048_chan, on a bounded
+    # sample -- the KL sweep of all rows is a fixed cost of the same order as the passes themselves
+    if world == 1 and not args.no_per_channel:
+        try:
+            pc_batches = data.owned()[:min(K, 8)]
+            pc_data = [(b, 0) for b in pc_batches]
+            make_workdir(len(pc_data) - 1, shape, local_rank)
+            pq = Quantity(model)
+            barrier()
+            t0 = time.perf_counter()
+            pq.activation_quantize_per_channel(pc_data)
+            barrier()
+            dt = time.perf_counter() - t0
+            result["per_channel_calibration"] = {"images": len(pc_data) * B, "rows": int(pq._channel_collector.rows),
+                                                 "seconds": round(dt, 3), "images_per_s": round(len(pc_data) * B / dt, 1)}
+            del pq
+        except Exception as e:
+            result["per_channel_calibration"] = {"error": repr(e)}
 
     sys.stdout = real_stdout
     sys.stdout.flush()

@@ -100,6 +100,21 @@ int fq_bits_from_threshold(const int32_t* thr, const float* interval, int rows,
 /* HOST helper: pytorch_quantizer.py:651-653  bits = 7 - ceil(log(absmax)/log(2)). absmax > 0. */
 int fq_bits_from_absmax(const float* absmax, int n, int32_t* bits_out);
 
+/* ---- per-channel rows (extension: the reference calibrates per tensor, distribution_collector.py:40-42) ---- */
+/* One histogram row per (tensor, channel): tensor [N][C][HW] (dense NCHW; HW = 1 for [N][F]) feeds rows
+ * row0 .. row0 + C - 1, channel c being the N planes at (n*C + c)*HW.  Same arithmetic per row as the
+ * segmented entry points above (fq_absmax_seg / fq_hist2048_seg), the tensor is read in place. */
+typedef struct fq_chan_seg {
+    const float* ptr;      /* device, 4-byte aligned */
+    int32_t N, C;
+    int64_t HW;
+    int32_t row0;
+    int32_t reserved;      /* must be 0 */
+} fq_chan_seg;
+int fq_absmax_chan(const fq_chan_seg* segs, int nseg, float* max_inout, fq_stream_t stream);
+int fq_hist2048_chan(const fq_chan_seg* segs, int nseg, const float* interval, int64_t* hist,
+                     fq_stream_t stream);
+
 /* ---- element-wise quantisation ops (new_quantity_op.py) ------------------------------------ */
 /* bitwidth is 8 or 16 (QUANTIZE_BIT, new_quantity_op.py:8): clamp range [-128,127] / [-32768,32767].
  * In-place (y == x) is allowed for all of them. */

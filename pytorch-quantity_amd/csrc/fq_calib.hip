@@ -189,6 +189,156 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable
 }
 
 // ---------------------------------------------------------------------------------------------
+// per-channel rows: one histogram row per (tensor, channel) of an NCHW activation
+// ---------------------------------------------------------------------------------------------
+// A row is no longer one contiguous run: channel c of tensor [N][C][HW] is the N planes at (n*C + c)*HW.  A
+// workgroup owns ONE channel and a group of images, so its LDS histogram (or running max) belongs to a single
+// row and is flushed once; blockIdx -> (tensor, channel, image group) through a kernarg prefix table as above.
+// Large planes are swept by the whole workgroup with the 16-byte tile loader; small planes (the 14x14 / 7x7
+// stages, Linear outputs) go one plane per wave with 4-byte loads, which keeps lanes busy without any
+// per-element index arithmetic.  The tensor is read in place: no channel-major copy.
+constexpr int kChanChunk = 64;
+constexpr uint32_t kChanElemsPerWg = 32768;
+constexpr uint32_t kSmallPlane = 1024;
+
+struct ChanTable {
+    const float* ptr[kChanChunk];
+    uint32_t N[kChanChunk], C[kChanChunk], HW[kChanChunk];
+    uint32_t groups[kChanChunk], nb[kChanChunk];          // image groups per channel, images per group
+    int32_t row0[kChanChunk];
+    uint32_t wg_begin[kChanChunk + 1];
+    int32_t nseg;
+};
+
+struct ChanView { const float* base; uint32_t C, HW, n0, n1; int row; };
+
+__device__ __forceinline__ ChanView chan_of(const ChanTable& t) {
+    const uint32_t b = blockIdx.x;
+    int lo = 0, hi = t.nseg - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (t.wg_begin[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    const uint32_t local = b - t.wg_begin[lo];
+    const uint32_t c = local / t.groups[lo], g = local - c * t.groups[lo];
+    ChanView v;
+    v.C = t.C[lo]; v.HW = t.HW[lo];
+    v.n0 = g * t.nb[lo];
+    v.n1 = v.n0 + t.nb[lo] < t.N[lo] ? v.n0 + t.nb[lo] : t.N[lo];
+    v.base = t.ptr[lo] + (size_t)c * v.HW;
+    v.row = t.row0[lo] + (int)c;
+    return v;
+}
+
+// f(value) for every element of this workgroup's planes
+template <int kThreads, bool kFenceLoads, typename F>
+__device__ __forceinline__ void for_each_in_channel(const ChanView& cv, F&& f) {
+    const size_t plane_stride = (size_t)cv.C * cv.HW;
+    if (cv.HW >= kSmallPlane) {
+        for (uint32_t n = cv.n0; n < cv.n1; ++n) {
+            TileView tv;
+            tv.p = cv.base + (size_t)n * plane_stride; tv.cnt = cv.HW; tv.row = cv.row;
+            for_each_in_tile<kThreads, kFenceLoads>(tv, f);
+        }
+    } else {
+        const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+        for (uint32_t n = cv.n0 + wave; n < cv.n1; n += kThreads / kWave) {
+            const float* __restrict__ p = cv.base + (size_t)n * plane_stride;
+            for (uint32_t e = lane; e < cv.HW; e += kWave) f(p[e]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void absmax_chan_kernel(const ChanTable tab, float* __restrict__ max_inout) {
+    __shared__ float s_wave[kBlock / kWave];
+    const ChanView cv = chan_of(tab);
+    float m = 0.0f;
+    for_each_in_channel<kBlock, false>(cv, [&](float v) { m = fmaxf(m, fabsf(v)); });
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    if (lane == 0) s_wave[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
+        atomicMax(reinterpret_cast<unsigned int*>(max_inout + cv.row), __float_as_uint(m));
+    }
+}
+
+template <bool kFast>
+__device__ __forceinline__ void hist_channel(const ChanView& cv, float iv, unsigned int* s_bins) {
+    const float y = 1.0f / iv;
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    for_each_in_channel<kHistBlock, true>(cv, [&](float v) {
+        unsigned int* slot = (v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, y)) : park;
+        atomicAdd(slot, 1u);
+    });
+}
+
+__global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTable tab, const float* __restrict__ interval,
+                                                               unsigned long long* __restrict__ hist, const int allow_fast) {
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kHistBlock) s_bins[b] = 0u;
+    const ChanView cv = chan_of(tab);
+    const float iv = interval[cv.row];
+    __syncthreads();
+    const unsigned int ivb = __float_as_uint(iv);
+    const bool fast = allow_fast && ivb >= 0x21800000u && ivb <= 0x5d800000u;      // see hist2048_seg_kernel
+    if (fast) hist_channel<true>(cv, iv, s_bins); else hist_channel<false>(cv, iv, s_bins);
+    __syncthreads();
+    unsigned long long* __restrict__ dst = hist + (size_t)cv.row * FQ_BINS;
+    for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) {
+        const unsigned int c = s_bins[b];
+        if (c) atomicAdd(dst + b, (unsigned long long)c);
+    }
+}
+
+template <typename Launch>
+static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launch) {
+    if (nseg < 0 || nseg > FQ_MAX_SEGS || (nseg > 0 && segs == nullptr)) return FQ_ERR_INVALID_ARG;
+    for (int i = 0; i < nseg; ++i) {
+        const fq_chan_seg& s = segs[i];
+        if (s.N < 0 || s.C <= 0 || s.HW <= 0 || s.row0 < 0 || s.reserved != 0) return FQ_ERR_INVALID_ARG;
+        if (s.N > 0 && (s.ptr == nullptr || (reinterpret_cast<uintptr_t>(s.ptr) & 3u))) return FQ_ERR_INVALID_ARG;
+        if (s.HW > 0x7fffffffLL) return FQ_ERR_UNSUPPORTED;
+    }
+    int i = 0;
+    while (i < nseg) {
+        ChanTable tab;
+        int k = 0;
+        uint64_t wgs = 0;
+        while (i < nseg && k < kChanChunk) {
+            const fq_chan_seg& s = segs[i++];
+            if (s.N == 0) continue;
+            uint32_t nb = (uint32_t)(kChanElemsPerWg / (uint64_t)s.HW);
+            if (nb < 1) nb = 1;
+            if (nb > (uint32_t)s.N) nb = (uint32_t)s.N;
+            const uint32_t groups = ((uint32_t)s.N + nb - 1) / nb;
+            const uint64_t n_wg = (uint64_t)groups * (uint64_t)s.C;
+            if (wgs + n_wg > 0x7fffffffULL) { --i; break; }
+            tab.ptr[k] = s.ptr; tab.N[k] = (uint32_t)s.N; tab.C[k] = (uint32_t)s.C; tab.HW[k] = (uint32_t)s.HW;
+            tab.groups[k] = groups; tab.nb[k] = nb; tab.row0[k] = s.row0;
+            tab.wg_begin[k] = (uint32_t)wgs;
+            wgs += n_wg;
+            ++k;
+        }
+        if (k == 0) {
+            if (i < nseg && segs[i].N != 0) return FQ_ERR_INVALID_ARG;
+            continue;
+        }
+        tab.nseg = k;
+        for (int j = k; j <= kChanChunk; ++j) tab.wg_begin[j] = (uint32_t)wgs;
+        for (int j = k; j < kChanChunk; ++j) {
+            tab.ptr[j] = nullptr; tab.N[j] = 0; tab.C[j] = 1; tab.HW[j] = 1; tab.groups[j] = 1; tab.nb[j] = 1; tab.row0[j] = 0;
+        }
+        const int rc = launch(tab, (uint32_t)wgs);
+        if (rc != FQ_OK) return rc;
+    }
+    return FQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side: tiling and chunked launches
 // ---------------------------------------------------------------------------------------------
 // FQ_HIST_IEEE_DIV=1 forces the IEEE divide sequence (A/B timing, paranoia).
@@ -287,6 +437,31 @@ extern "C" int fq_hist2048_seg(const fq_seg* segs, int nseg, const float* interv
     hipStream_t st = as_stream(stream);
     return for_each_chunk(segs, nseg, kTilesPerCUHist, [&](const SegTable& tab, uint32_t tiles) -> int {
         hipLaunchKernelGGL(hist2048_seg_kernel, dim3(tiles), dim3(kHistBlock), 0, st, tab, interval,
+                           reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    });
+}
+
+extern "C" int fq_absmax_chan(const fq_chan_seg* segs, int nseg, float* max_inout, fq_stream_t stream) {
+    using namespace fq;
+    if (nseg == 0) return FQ_OK;
+    if (max_inout == nullptr) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    return for_each_chan_chunk(segs, nseg, [&](const ChanTable& tab, uint32_t wgs) -> int {
+        hipLaunchKernelGGL(absmax_chan_kernel, dim3(wgs), dim3(kBlock), 0, st, tab, max_inout);
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    });
+}
+
+extern "C" int fq_hist2048_chan(const fq_chan_seg* segs, int nseg, const float* interval, int64_t* hist, fq_stream_t stream) {
+    using namespace fq;
+    if (nseg == 0) return FQ_OK;
+    if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    return for_each_chan_chunk(segs, nseg, [&](const ChanTable& tab, uint32_t wgs) -> int {
+        hipLaunchKernelGGL(hist2048_chan_kernel, dim3(wgs), dim3(kHistBlock), 0, st, tab, interval,
                            reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
         FQ_LAUNCH_CHECK();
         return FQ_OK;

@@ -26,6 +26,11 @@ class _Seg(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class _ChanSeg(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("HW", ctypes.c_int64),
+                ("row0", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 _lib = None
 
 
@@ -48,6 +53,10 @@ def lib():
     L.fq_absmax_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp]
     L.fq_hist2048_seg.restype = ci
     L.fq_hist2048_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp, vp]
+    L.fq_absmax_chan.restype = ci
+    L.fq_absmax_chan.argtypes = [ctypes.POINTER(_ChanSeg), ci, vp, vp]
+    L.fq_hist2048_chan.restype = ci
+    L.fq_hist2048_chan.argtypes = [ctypes.POINTER(_ChanSeg), ci, vp, vp, vp]
     L.fq_kl_workspace_bytes.restype = sz
     L.fq_kl_workspace_bytes.argtypes = [ci]
     L.fq_kl_threshold.restype = ci
@@ -133,6 +142,45 @@ def _seg_array(tensors, rows):
         arr[i].row = int(r)
         arr[i].reserved = 0
     return arr, keep
+
+
+def _chan_array(tensors, row0s):
+    """fq_chan_seg table for dense [N, C, ...] tensors (one row per channel, starting at row0)."""
+    arr = (_ChanSeg * max(len(tensors), 1))()
+    keep = []
+    for i, (t, r0) in enumerate(zip(tensors, row0s)):
+        _need_cuda(t, torch.float32, "channel segment %d" % i)
+        d = t if t.is_contiguous() else t.contiguous()
+        keep.append(d)
+        hw = 1
+        for v in d.shape[2:]:
+            hw *= int(v)
+        arr[i].ptr = d.data_ptr()
+        arr[i].N, arr[i].C, arr[i].HW = int(d.shape[0]), int(d.shape[1]), hw
+        arr[i].row0 = int(r0)
+        arr[i].reserved = 0
+    return arr, keep
+
+
+def absmax_chan(tensors, row0s, max_inout):
+    """max_inout[row0 + c] = max(., max|x[:, c]|) for every tensor.  fq_absmax_chan."""
+    if not tensors:
+        return
+    _need_cuda(max_inout, torch.float32, "max_inout")
+    arr, keep = _chan_array(tensors, row0s)
+    _check(lib().fq_absmax_chan(arr, len(tensors), max_inout.data_ptr(), _stream(max_inout)), "fq_absmax_chan")
+    del keep
+
+
+def hist2048_chan(tensors, row0s, interval, hist):
+    """hist[row0 + c] += 2048-bin histogram of |x[:, c]| (x != 0) with bin width interval[row].  fq_hist2048_chan."""
+    if not tensors:
+        return
+    _need_cuda(interval, torch.float32, "interval")
+    _need_cuda(hist, torch.int64, "hist")
+    arr, keep = _chan_array(tensors, row0s)
+    _check(lib().fq_hist2048_chan(arr, len(tensors), interval.data_ptr(), hist.data_ptr(), _stream(hist)), "fq_hist2048_chan")
+    del keep
 
 
 def absmax_seg(tensors, rows, max_inout):

@@ -2,11 +2,11 @@
 
 EXTENSION, not part of the reference API: the reference's calibrator is per tensor
 (distribution_collector.py:40-42; feat.table holds one bit per layer), so there is nothing to be
-bit-compatible with.  The HIP kernels take a generic histogram ROW, and a row can just as well be
-(tensor, channel): this collector lays every [N, C, ...] activation out channel-major ([C, N*...], one
-contiguous run per channel) and feeds the SAME segmented kernels with row = first_row(tensor) + c.
-Arithmetic per row is exactly the per-tensor arithmetic (same interval formula, same binning, same KL
-sweep), which tests/test_gpu_per_channel.py checks against the CPU oracle channel by channel.
+bit-compatible with.  A histogram row here is (tensor, channel): fq_absmax_chan / fq_hist2048_chan read
+the NCHW activations IN PLACE (a workgroup owns one channel and a group of images, see csrc/fq_calib.hip) and
+write row = first_row(tensor) + c; one launch covers all tensors of a forward.  Arithmetic per row is exactly
+the per-tensor arithmetic (same interval formula, same binning, same KL sweep), which
+tests/test_gpu_per_channel.py checks against the CPU oracle channel by channel.
 """
 import math
 
@@ -45,27 +45,19 @@ class ChannelCollector(object):
     def row_range(self, name):
         return self._first[name], self._first[name] + self._channels[name]
 
-    def _segments(self, tensors):
-        segs, rows = [], []
+    def _dense(self, tensors):
+        ts, row0s = [], []
         for n in self._names:
             t = tensors[n]
-            C = self._channels[n]
-            assert t.shape[1] == C, (n, tuple(t.shape), C)
-            cm = t.detach().transpose(0, 1).reshape(C, -1)        # channel-major copy: [C, N*H*W]
-            if not cm.is_contiguous():
-                cm = cm.contiguous()
-            for c in range(C):
-                segs.append(cm[c])
-                rows.append(self._first[n] + c)
-        return segs, rows
-
-    def _call(self, fn, tensors, *extra):
-        segs, rows = self._segments(tensors)
-        for i in range(0, len(segs), _MAX_SEGS):
-            fn(segs[i:i + _MAX_SEGS], rows[i:i + _MAX_SEGS], *extra)
+            assert t.shape[1] == self._channels[n], (n, tuple(t.shape), self._channels[n])
+            ts.append(t.detach())
+            row0s.append(self._first[n])
+        return ts, row0s
 
     def refresh_max_val(self, tensors):
-        self._call(_native.absmax_seg, tensors, self._max)
+        ts, row0s = self._dense(tensors)
+        for i in range(0, len(ts), _MAX_SEGS):
+            _native.absmax_chan(ts[i:i + _MAX_SEGS], row0s[i:i + _MAX_SEGS], self._max)
 
     def intervals(self):
         """fp32 bin width per row: statistic * max / 2048 + 1e-12 with NumPy fp32 scalars (the
@@ -81,7 +73,9 @@ class ChannelCollector(object):
     def add_to_distributions(self, tensors):
         if self._interval is None:
             self.intervals()
-        self._call(_native.hist2048_seg, tensors, self._interval, self._hist)
+        ts, row0s = self._dense(tensors)
+        for i in range(0, len(ts), _MAX_SEGS):
+            _native.hist2048_chan(ts[i:i + _MAX_SEGS], row0s[i:i + _MAX_SEGS], self._interval, self._hist)
 
     def all_reduce_max(self):
         import torch.distributed as dist

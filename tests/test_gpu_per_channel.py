@@ -45,6 +45,35 @@ def test_channel_collector_vs_oracle(oracle):
             assert bits[name][c] == oracle.bits_from_threshold(t, ref_iv)[0]
 
 
+@pytest.mark.parametrize("shape", [(45, 3, 40, 40), (2, 5, 33, 33), (130, 7, 5, 5), (3, 2, 224, 224), (9, 1000), (1, 4, 1, 1)])
+def test_channel_kernels_large_and_ragged_planes(oracle, shape):
+    """fq_absmax_chan / fq_hist2048_chan on planes above and below the 1024-element switch, planes whose start
+    is not 16-byte aligned, several image groups per channel, [N, F] inputs -- row by row against the oracle."""
+    from common.quantity import _native as nat
+    rng = np.random.default_rng(sum(shape))
+    x = (rng.standard_normal(shape, dtype=np.float32) * np.float32(2.5)).astype(np.float32)
+    x[x < -3] = 0
+    C = shape[1]
+    row0 = 3
+    dev = torch.from_numpy(x).cuda()
+    mx = torch.zeros(row0 + C + 2, device="cuda")
+    nat.absmax_chan([dev], [row0], mx)
+    mxh = mx.cpu().numpy()
+    ref_m = np.array([oracle.absmax(np.ascontiguousarray(x[:, c]).ravel()) for c in range(C)], dtype=np.float32)
+    np.testing.assert_array_equal(mxh[row0:row0 + C], ref_m)
+    assert not mxh[:row0].any() and not mxh[row0 + C:].any()
+    iv = np.full(row0 + C + 2, 1.0, dtype=np.float32)
+    iv[row0:row0 + C] = [oracle.interval(m) for m in ref_m]
+    hist = torch.zeros(row0 + C + 2, 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_chan([dev], [row0], torch.from_numpy(iv).cuda(), hist)
+    nat.hist2048_chan([dev], [row0], torch.from_numpy(iv).cuda(), hist)          # accumulates
+    hh = hist.cpu().numpy()
+    for c in range(C):
+        ref = oracle.hist2048(np.ascontiguousarray(x[:, c]).ravel(), iv[row0 + c])
+        np.testing.assert_array_equal(hh[row0 + c], 2 * ref)
+    assert not hh[:row0].any() and not hh[row0 + C:].any()
+
+
 def test_per_channel_calibration_of_a_model():
     """Orchestrator level: per-channel table of the Concat net; pooling all channels of a tensor gives
     back the per-tensor maxima and histogram mass of the reference-compatible path."""
