@@ -194,12 +194,11 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable
 // A row is no longer one contiguous run: channel c of tensor [N][C][HW] is the N planes at (n*C + c)*HW.  A
 // workgroup owns ONE channel and a group of images, so its LDS histogram (or running max) belongs to a single
 // row and is flushed once; blockIdx -> (tensor, channel, image group) through a kernarg prefix table as above.
-// Large planes are swept by the whole workgroup with the 16-byte tile loader; small planes (the 14x14 / 7x7
-// stages, Linear outputs) go one plane per wave with 4-byte loads, which keeps lanes busy without any
-// per-element index arithmetic.  The tensor is read in place: no channel-major copy.
-constexpr int kChanChunk = 64;
-constexpr uint32_t kChanElemsPerWg = 32768;
-constexpr uint32_t kSmallPlane = 1024;
+// Each wave sweeps one plane at a time (16-byte loads, four in flight per lane, when planes are 16-byte aligned
+// and at least 256 elements; 4-byte loads otherwise): no per-element index arithmetic, and the tensor is read
+// in place -- no channel-major copy.
+constexpr int kChanChunk = 96;            // kernarg block 3.4 KB: ResNet-50 (71 tensors) in one launch
+constexpr uint32_t kChanElemsPerWg = 262144;   // per workgroup: enough to amortise zeroing + flushing 2048 bins (32 K: 3.8 TB/s)
 
 struct ChanTable {
     const float* ptr[kChanChunk];
@@ -230,20 +229,36 @@ __device__ __forceinline__ ChanView chan_of(const ChanTable& t) {
     return v;
 }
 
-// f(value) for every element of this workgroup's planes
+// f(value) for every element of this workgroup's planes: one plane per wave at a time (a plane of the 56x56 /
+// 28x28 stages is too short for the 256-thread tile loader to keep four loads per lane in flight; a wave does)
 template <int kThreads, bool kFenceLoads, typename F>
 __device__ __forceinline__ void for_each_in_channel(const ChanView& cv, F&& f) {
     const size_t plane_stride = (size_t)cv.C * cv.HW;
-    if (cv.HW >= kSmallPlane) {
-        for (uint32_t n = cv.n0; n < cv.n1; ++n) {
-            TileView tv;
-            tv.p = cv.base + (size_t)n * plane_stride; tv.cnt = cv.HW; tv.row = cv.row;
-            for_each_in_tile<kThreads, kFenceLoads>(tv, f);
-        }
-    } else {
-        const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-        for (uint32_t n = cv.n0 + wave; n < cv.n1; n += kThreads / kWave) {
-            const float* __restrict__ p = cv.base + (size_t)n * plane_stride;
+    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    // 16-byte loads when every plane starts on a 16-byte boundary
+    const bool vec = (cv.HW & 3u) == 0 && (reinterpret_cast<uintptr_t>(cv.base) & 15u) == 0 && cv.HW >= 256;
+    for (uint32_t n = cv.n0 + wave; n < cv.n1; n += kThreads / kWave) {
+        const float* __restrict__ p = cv.base + (size_t)n * plane_stride;
+        if (vec) {
+            const float4* __restrict__ v4 = reinterpret_cast<const float4*>(p);
+            const uint32_t nvec = cv.HW >> 2;
+            uint32_t i = lane;
+            for (; i + 3 * kWave < nvec; i += 4 * kWave) {
+                const float4 a = v4[i];
+                const float4 b = v4[i + kWave];
+                const float4 c = v4[i + 2 * kWave];
+                const float4 d = v4[i + 3 * kWave];
+                if (kFenceLoads) __builtin_amdgcn_sched_barrier(0);       // see for_each_in_tile
+                f(a.x); f(a.y); f(a.z); f(a.w);
+                f(b.x); f(b.y); f(b.z); f(b.w);
+                f(c.x); f(c.y); f(c.z); f(c.w);
+                f(d.x); f(d.y); f(d.z); f(d.w);
+            }
+            for (; i < nvec; i += kWave) {
+                const float4 a = v4[i];
+                f(a.x); f(a.y); f(a.z); f(a.w);
+            }
+        } else {
             for (uint32_t e = lane; e < cv.HW; e += kWave) f(p[e]);
         }
     }
@@ -312,7 +327,7 @@ static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launc
             const fq_chan_seg& s = segs[i++];
             if (s.N == 0) continue;
             uint32_t nb = (uint32_t)(kChanElemsPerWg / (uint64_t)s.HW);
-            if (nb < 1) nb = 1;
+            if (nb < kBlock / kWave) nb = kBlock / kWave;                  // at least one plane per wave
             if (nb > (uint32_t)s.N) nb = (uint32_t)s.N;
             const uint32_t groups = ((uint32_t)s.N + nb - 1) / nb;
             const uint64_t n_wg = (uint64_t)groups * (uint64_t)s.C;

@@ -83,5 +83,27 @@ def main():
     print("torch copy   : med %.3f ms (%.0f GB/s rd+wr)" % (ms, x.numel() * 8 / ms / 1e6))
 
 
+def bench_channel_kernels(batch=128):
+    """fq_absmax_chan / fq_hist2048_chan on ResNet-50-shaped NCHW tensors (one row per channel)."""
+    shapes = [(3, 224)] + [(64, 112)] + [(64, 56)] * 7 + [(256, 56)] * 7 + [(128, 56)] + [(128, 28)] * 8 + [(512, 28)] * 9 + \
+             [(256, 28)] + [(256, 14)] * 12 + [(1024, 14)] * 13 + [(512, 14)] + [(512, 7)] * 6 + [(2048, 7)] * 7
+    ts = [torch.randn(batch, c, h, h, device="cuda") for c, h in shapes]
+    row0, r = [], 0
+    for c, _ in shapes:
+        row0.append(r); r += c
+    elems = sum(t.numel() for t in ts)
+    mx = torch.zeros(r, device="cuda")
+    ms, best = timeit(lambda: nat.absmax_chan(ts, row0, mx), iters=10)
+    print("absmax_chan  : %d tensors %d rows %.1f Melem  med %.3f ms  (%.0f GB/s, best %.0f)" %
+          (len(ts), r, elems / 1e6, ms, elems * 4 / ms / 1e6, elems * 4 / best / 1e6))
+    iv = (mx / 2048 + 1e-12).float()
+    hist = torch.zeros(r, 2048, dtype=torch.int64, device="cuda")
+    ms, best = timeit(lambda: nat.hist2048_chan(ts, row0, iv, hist), iters=10)
+    print("hist2048_chan: med %.3f ms  (%.0f GB/s, best %.0f)" % (ms, elems * 4 / ms / 1e6, elems * 4 / best / 1e6))
+
+
 if __name__ == "__main__":
-    main()
+    if "--chan" in sys.argv:
+        bench_channel_kernels()
+    else:
+        main()
