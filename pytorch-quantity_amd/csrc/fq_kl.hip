@@ -212,11 +212,30 @@ __global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __rest
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (nzmask & (1u << k)) sT[pos++] = term[k];
-    if (tid == 0) {
-        int nl = 0;
-        if (m > 0)
-            pw_walk(m, [&](int off, int len) { s_leaf_off[nl] = off; s_leaf_len[nl] = len; ++nl; return 0.0; });
-        s_nleaf = nl;
+    // Leaves of NumPy's pairwise recursion over the m compacted terms, without walking the tree serially (one
+    // lane doing that took half of the kernel): the tree is at most 6 levels deep for m <= 2048, so lane c of
+    // wave 0 follows the 6-bit path c (bit = right child) from the root; a leaf reached before the path is used
+    // up belongs to the path whose remaining bits are zero.  Valid paths in increasing c are the leaves in
+    // order; their ranks give the compacted leaf list.
+    unsigned long long leaf_mask = 0;
+    int leaf_rank = 0;
+    bool leaf_valid = false;
+    if (wave == 0) {
+        int off = 0, n = m;
+        leaf_valid = m > 0;
+        for (int level = 5; level >= 0; --level) {
+            if (n <= 128) {
+                if (lane & ((2 << level) - 1)) leaf_valid = false;       // bits level..0 must be zero
+                break;
+            }
+            const int n2 = pw_half(n);
+            if ((lane >> level) & 1) { off += n2; n -= n2; } else { n = n2; }
+        }
+        if (n > 128) leaf_valid = false;
+        leaf_mask = __ballot(leaf_valid);
+        leaf_rank = __popcll(leaf_mask & ((1ull << lane) - 1ull));
+        if (leaf_valid) { s_leaf_off[leaf_rank] = off; s_leaf_len[leaf_rank] = n; }
+        if (lane == 0) s_nleaf = __popcll(leaf_mask);
     }
     __syncthreads();
 
@@ -250,13 +269,18 @@ __global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __rest
         }
     }
     __syncthreads();
-    if (tid == 0) {
-        double kl = 0.0;                                                  // np.sum of nothing
-        if (m > 0) {
-            int nl = 0;
-            kl = pw_walk(m, [&](int, int) { return s_leaf_val[nl++]; });
+    // combine the leaves along the same tree: the subtree whose leftmost leaf sits on path c keeps its running value
+    // in lane c; at stride s the node at c (c % 2s == 0) adds its right child, the subtree that starts at c + s
+    if (wave == 0) {
+        double v = leaf_valid ? s_leaf_val[leaf_rank] : 0.0;
+#pragma unroll
+        for (int sft = 0; sft < 6; ++sft) {
+            const int sd = 1 << sft;
+            const double other = __shfl_down(v, sd, kWave);
+            const bool right = lane + sd < kWave && ((leaf_mask >> (lane + sd)) & 1ull);
+            if ((lane & (2 * sd - 1)) == 0 && right) v = v + other;
         }
-        klw[(size_t)row * kCand + blockIdx.x] = kl;
+        if (lane == 0) klw[(size_t)row * kCand + blockIdx.x] = v;        // m == 0: np.sum of nothing = 0.0
     }
 }
 
