@@ -45,6 +45,31 @@ __device__ double pw_leaf(const double* a, int n) {          // n <= 128
     return res;
 }
 
+// pw_leaf for a slice of at most 16 elements that also reports which of them are non-zero (bit i = a[i] != 0):
+// the quantised-bin phase needs the sum, the count and, later, the positions -- one pass over LDS instead of
+// three (adjacent lanes read slices 128 bytes apart: every pass is a 32-way bank conflict).
+__device__ __forceinline__ double pw_leaf_nz(const double* a, int n, unsigned* nz) {          // n <= 16
+    unsigned m = 0;
+    double res;
+    if (n < 8) {
+        res = 0.0;
+        for (int i = 0; i < n; ++i) { const double v = a[i]; res += v; m |= (v != 0.0 ? 1u : 0u) << i; }
+    } else {
+        double r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r[k] = a[k]; m |= (r[k] != 0.0 ? 1u : 0u) << k; }
+        const int lim = n - (n & 7);                      // 8 or 16
+        if (lim == 16) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const double v = a[8 + k]; r[k] += v; m |= (v != 0.0 ? 1u : 0u) << (8 + k); }
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int i = lim; i < n; ++i) { const double v = a[i]; res += v; m |= (v != 0.0 ? 1u : 0u) << i; }
+    }
+    *nz = m;
+    return res;
+}
+
 // Walks the recursion tree of pairwise_sum(n) in order; leaf(off, len) supplies each leaf's value.
 template <typename LeafFn>
 __device__ double pw_walk(int n, LeafFn&& leaf) {
@@ -154,20 +179,20 @@ __global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __rest
         double q = 0.0;
         if (has_l) { ls = (double)lu - start; q += ls * sP[lu - 1]; }
         if (has_r) { rs = end - (double)rl;   q += rs * sP[rl]; }
-        q += pw_leaf(sP + lu, rl - lu);                                   // slice .sum(), length <= 16
+        unsigned nz = 0;
+        q += pw_leaf_nz(sP + lu, rl - lu, &nz);                           // slice .sum(), length <= 16
         double count = 1e-12;
         left_live = has_l && sP[lu - 1] != 0.0;
         const bool right_live = has_r && sP[rl] != 0.0;
         if (left_live) count += ls;
         if (right_live) count += rs;
-        for (int j = lu; j < rl; ++j)
-            if (sP[j] != 0.0) count = count + 1.0;
+        for (int k = __popc(nz); k > 0; --k) count = count + 1.0;         // one rounding per non-zero bin, as the reference
         ev = q / count;
         // this bin's right edge and interior first; its left edge is shared with bin i-1's right
         // edge, which the reference adds earlier (loop order), so left edges go in a second phase.
         if (right_live) sE[rl] = 1e-9 + ev * rs;
-        for (int j = lu; j < rl; ++j)
-            if (sP[j] != 0.0) sE[j] = 1e-9 + ev;
+        const double inner = 1e-9 + ev;
+        for (unsigned mm = nz; mm; mm &= mm - 1) sE[lu + __ffs(mm) - 1] = inner;
     }
     __syncthreads();
     if (left_live) sE[lu - 1] += ev * ls;
