@@ -1,0 +1,27 @@
+"""Randomised parity sweeps.  Convolution: the int8 MFMA convolution (every kernel variant the dispatcher picks, all output
+forms, the fused residual add) against the CPU oracle: scripts/conv_fuzz.py with a fixed seed.   pytest -m gpu"""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_random_shapes_match_the_oracle():
+    spec = importlib.util.spec_from_file_location("conv_fuzz", os.path.join(ROOT, "scripts", "conv_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    failures = mod.run(120, 101, verbose=False)
+    assert not failures, failures[:5]
+
+
+def test_random_histograms_kl_sweep_matches_the_oracle_bit_for_bit():
+    """scripts/kl_fuzz.py: 96 random histograms of eight families; thresholds and KL curves (same include/fq_log.h on
+    both sides) must agree bit for bit."""
+    spec = importlib.util.spec_from_file_location("kl_fuzz", os.path.join(ROOT, "scripts", "kl_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    failures = mod.run(96, 2024, verbose=False)
+    assert not failures, failures[:5]
