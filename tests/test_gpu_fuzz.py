@@ -25,3 +25,13 @@ def test_random_histograms_kl_sweep_matches_the_oracle_bit_for_bit():
     spec.loader.exec_module(mod)
     failures = mod.run(96, 2024, verbose=False)
     assert not failures, failures[:5]
+
+
+def test_random_segment_lists_match_the_oracle():
+    """scripts/calib_fuzz.py: ragged / unaligned / multi-segment rows, zeros, denormals, bin-edge values, accumulation,
+    and the per-channel kernels, all bit-exact against the oracle."""
+    spec = importlib.util.spec_from_file_location("calib_fuzz", os.path.join(ROOT, "scripts", "calib_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    failures = mod.run(25, 77, verbose=False)
+    assert not failures, failures[:5]
