@@ -275,10 +275,13 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
 //     from the int8 NHWC tensor into the operand registers -- each byte is fetched once per workgroup;
 //   * weights (A operand) are shared by the 4 waves and staged through a double-buffered, XOR-swizzled
 //     LDS tile of TK rows x 128 bytes per K-step.
-// kC128: C % 128 == 0 and K % TK == 0 -- every K-step then lies inside one tap and every weight row /
-// chunk exists, so the per-step index arithmetic collapses to one tap update and pointer increments
-// (the general path spends ~260 VALU instructions per K-step on it, against 16 MFMAs).
-template <int TK, bool kC128, int kOut>
+// kPath 1 (C % 128 == 0 and K % TK == 0): every K-step lies inside one tap and every weight row / chunk exists,
+// so the per-step index arithmetic collapses to one tap update and pointer increments (the general path, 0,
+// spends ~260 VALU instructions per K-step on it, against 16 MFMAs).  kPath 2 (C == 64, the first stage of a
+// ResNet): a K-step is exactly two taps of 64 bytes, again with uniform tap arithmetic; a missing second tap
+// (R*S odd) is an out-of-range activation offset, i.e. zeros.
+constexpr int kPathGeneral = 0, kPathC128 = 1, kPathC64 = 2;
+template <int TK, int kPath, int kOut>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                const float* __restrict__ qbias, float* __restrict__ y,
                                                                int8_t* __restrict__ q, const ConvParams p) {
@@ -335,8 +338,34 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __r
     const int8_t* wp[A_LOADS];
 #pragma unroll
     for (int j = 0; j < A_LOADS; ++j) wp[j] = wrow[j] + ld_chunk * 16;
+    // kPathC64: weight offsets for buffer loads (rows k >= K and the overrun of an odd tap count read as zeros
+    // or meet zero activations)
+    const __amdgpu_buffer_rsrc_t wr64 = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(w), 0, p.w_bytes, 0x00020000);
+    unsigned wo64[A_LOADS];
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+        const int k = k0 + ld_row + 32 * j;
+        wo64[j] = k < p.K ? (unsigned)k * (unsigned)(p.chunks * 16) + (unsigned)(ld_chunk * 16) : kOutOfRange;
+    }
     auto load_step = [&]() {
-        if (kC128) {
+        if (kPath == kPathC64) {
+#pragma unroll
+            for (int j = 0; j < A_LOADS; ++j) {
+                ra[j] = load_act(wr64, wo64[j]);
+                wo64[j] += BKB;
+            }
+#pragma unroll
+            for (int tp = 0; tp < 2; ++tp) {                // the two taps of this K-step
+                const int ih = ih0 + tap_r * p.dil_h, iw = iw0 + tap_s * p.dil_w;
+                const bool ok = tap_r < p.R && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const unsigned off = ok ? img_off + (unsigned)((ih * p.W + iw) * 64 + half * 16) : kOutOfRange;
+                rb[2 * tp] = load_act(xr, off);
+                rb[2 * tp + 1] = load_act(xr, off + 32);
+                if (++tap_s == p.S) { tap_s = 0; ++tap_r; }
+            }
+            return;
+        }
+        if (kPath == kPathC128) {
 #pragma unroll
             for (int j = 0; j < A_LOADS; ++j) {
                 ra[j] = *reinterpret_cast<const v4i*>(wp[j]);
@@ -919,17 +948,17 @@ static void launch_conv_dma(dim3 grid, hipStream_t st, const int8_t* x, const in
     else launch_conv_dma_stages<TK, 2>(grid, st, x, w, qbias, y, q, p);
 }
 
-template <int TK, bool kC128>
+template <int TK, int kPath>
 static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
                              int8_t* q, const ConvParams& p) {
     if (p.res)
-        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutI8 | kOutAdd>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutI8 | kOutAdd>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else if (y && q)
-        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutF32 | kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutF32 | kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else if (q)
-        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutI8>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else
-        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kC128, kOutF32>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
+        hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutF32>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
 }
 
 struct FusedAdd {                        // residual operand and outputs of a fused NewAdd (res == nullptr: none)
@@ -989,20 +1018,25 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     static const int dma_env = [] { const char* e = getenv("FQ_CONV_DMA"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
     const bool use_dma = dma_env < 0 ? (p.chunks >> 3) >= 8 : dma_env == 1;
     static const int force_tk = [] { const char* e = getenv("FQ_CONV_TK"); return e ? atoi(e) : 0; }();
+    static const bool use_c64 = [] { const char* e = getenv("FQ_CONV_C64"); return !(e && e[0] == '0'); }();
     if ((K <= 64 || wg128 < kCUs || force_tk == 64) && force_tk != 128) {
         if (C % 128 == 0 && K % 64 == 0 && use_dma)
             launch_conv_dma<64>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else if (C % 128 == 0 && K % 64 == 0)
-            launch_conv_tile<64, true>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
+            launch_conv_tile<64, kPathC128>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
+        else if (C == 64 && use_c64)
+            launch_conv_tile<64, kPathC64>(dim3(gx, (K + 63) / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else
-            launch_conv_tile<64, false>(dim3(gx, (K + 63) / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
+            launch_conv_tile<64, kPathGeneral>(dim3(gx, (K + 63) / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
     } else {
         if (C % 128 == 0 && K % 128 == 0 && use_dma)
             launch_conv_dma<128>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else if (C % 128 == 0 && K % 128 == 0)
-            launch_conv_tile<128, true>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
+            launch_conv_tile<128, kPathC128>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
+        else if (C == 64 && use_c64)
+            launch_conv_tile<128, kPathC64>(dim3(gx, (K + 127) / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else
-            launch_conv_tile<128, false>(dim3(gx, (K + 127) / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
+            launch_conv_tile<128, kPathGeneral>(dim3(gx, (K + 127) / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
     }
     FQ_LAUNCH_CHECK();
     return FQ_OK;

@@ -17,12 +17,14 @@ def run(cases, seed, verbose=True):
     failures = []
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     for it in range(cases):
-        kind = rng.integers(0, 4)
+        kind = rng.integers(0, 5)
         if kind == 0:      # LDS-DMA shapes: C % 128 == 0, K % 64 == 0, deep reduction
             C = int(rng.choice([128, 256, 512])); K = int(rng.choice([64, 128, 192, 256])); R = int(rng.choice([1, 3]))
             if R == 1: C = int(rng.choice([1024, 2048]))
         elif kind == 1:    # register-staged fast path
             C = int(rng.choice([128, 256])); K = int(rng.choice([64, 128, 256, 320])); R = int(rng.choice([1, 1, 3]))
+        elif kind == 2:    # C == 64 path (two taps per K-step; odd and even tap counts)
+            C = 64; K = int(rng.choice([64, 100, 128, 256])); R = int(rng.choice([1, 2, 3]))
         else:              # general path: ragged channels
             C = int(rng.integers(1, 80)); K = int(rng.integers(1, 150)); R = int(rng.choice([1, 2, 3, 5]))
         S = R if rng.random() < 0.8 else int(rng.choice([1, 2, 3]))
