@@ -22,6 +22,7 @@ The JSON line also carries
                      bit-identical to the fp32-boundary model in the same run, see int8_sim_resident);
   int8_sim_fp32_boundary_images_per_s : the same ReconModel with the reference's fp32 NCHW tensor at
                      every module boundary (the drop-in default);
+  int8_sim_hipgraph_images_per_s : the resident forward replayed as one HIP graph (input copy included);
   fakequant_images_per_s / float_forward_images_per_s : ReconTest and the float model.
 """
 import argparse
@@ -354,18 +355,21 @@ def main():
             barrier()
             batches = [b.to(device) for b in data.owned()[:min(K, 8)]]
 
-            def fwd_rate(net):
+            def fwd_rate(net, passes=1):
+                """images/s of net over the resident batches; the fast models take several passes so that one
+                host hiccup (a GC pause is longer than a whole int8 forward) does not decide the number."""
                 with torch.no_grad():
                     net(batches[0])
                     barrier()
                     t0 = time.perf_counter()
-                    for xb in batches:
-                        net(xb)
+                    for _ in range(passes):
+                        for xb in batches:
+                            net(xb)
                     barrier()
                 dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
                 if distributed:
                     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                return len(batches) * B * world / float(dt.item())
+                return passes * len(batches) * B * world / float(dt.item())
 
             result["float_forward_images_per_s"] = round(fwd_rate(model), 1)
             rec = Reconstruction(build_model(args.model, HW, device))
@@ -374,7 +378,7 @@ def main():
             rec2 = Reconstruction(build_model(args.model, HW, device))
             info2 = rec2.get_quantity_information()
             int8_net = rec2.ReconModel(info2, "./workdir/recon.pth")
-            result["int8_sim_fp32_boundary_images_per_s"] = round(fwd_rate(int8_net), 1)
+            result["int8_sim_fp32_boundary_images_per_s"] = round(fwd_rate(int8_net, 3), 1)
             # same model, same logits, activations kept as int8/int16 NHWC between the integer layers
             from common.quantity import resident
             with torch.no_grad():
@@ -382,10 +386,20 @@ def main():
             plan = resident.enable(int8_net, batches[0])
             with torch.no_grad():
                 same = bool(torch.equal(int8_net(batches[0]), logits_fp32_boundary))
-            result["int8_sim_images_per_s"] = round(fwd_rate(int8_net), 1)
+            result["int8_sim_images_per_s"] = round(fwd_rate(int8_net, 8), 1)
             result["int8_sim_resident"] = {"bit_identical_logits": same, "plan": plan}
             if not same:                                   # never report a rate for a model that computes something else
                 result["int8_sim_images_per_s"] = result["int8_sim_fp32_boundary_images_per_s"]
+            else:
+                try:                                       # the same forward replayed as one HIP graph (input copy included)
+                    graphed = resident.capture(int8_net, batches[0])
+                    with torch.no_grad():
+                        same_g = bool(torch.equal(graphed(batches[0]), logits_fp32_boundary))
+                    if same_g:
+                        result["int8_sim_hipgraph_images_per_s"] = round(fwd_rate(graphed, 8), 1)
+                    del graphed
+                except Exception as e:
+                    result["int8_sim_hipgraph_error"] = repr(e)
         except Exception as e:  # the headline number above stands on its own
             result["recon_error"] = repr(e)
 

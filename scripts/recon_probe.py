@@ -34,3 +34,15 @@ if len(sys.argv) > 4 and sys.argv[4] == "graph":
     for _ in range(ITERS): g(x)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / ITERS
     print("ReconModel B=%d HIP graph: %.3f ms/batch = %.0f img/s" % (B, dt * 1e3, B / dt))
+if "hostprof" in sys.argv:
+    # how long the host needs to ENQUEUE one forward (no sync inside the loop), and where it spends it
+    import cProfile, pstats
+    with torch.no_grad():
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(ITERS): net(x)
+        t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        print("host enqueue %.3f ms/forward; drain after the loop %.3f ms" % ((t1 - t0) / ITERS * 1e3, (t2 - t1) * 1e3))
+        pr = cProfile.Profile(); pr.enable()
+        for _ in range(ITERS): net(x)
+        pr.disable(); torch.cuda.synchronize()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(28)
