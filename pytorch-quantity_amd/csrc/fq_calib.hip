@@ -2,16 +2,16 @@
 //
 // Replaces the reference's per-element Python loop and per-call multiprocessing.Pool
 // (quantity/common/quantity/distribution_collector.py:70-78 and :80-142).  One launch covers every
-// hooked tensor of a forward pass ("segments"): blockIdx -> (segment, tile) through a prefix table
-// that travels in the kernel-argument block, so there is no per-tensor launch and no table memcpy.
+// hooked tensor of a forward pass ("segments"): the segments form one stream of 16 KB chunks, every
+// workgroup takes an equal share of it and finds its segments through a prefix table that travels in the
+// kernel-argument block, so there is no per-tensor launch, no table memcpy and no CU with more bytes than another.
 //
 // Both kernels are HBM-bound streaming reads (4 B per element, algorithmic bytes = 4 * elements):
-//   * 16-byte loads, 4 in flight per lane; tiles sized per kernel (abs-max: 256 threads, ~4
-//     workgroups per CU; histogram: 256 threads, ~8 per CU -- both measured optima).
+//   * 16-byte non-temporal loads, 4 in flight per lane; 256 threads, 2 workgroups per CU, all resident.
 //   * histogram bins live in LDS (8 KB per workgroup shared by its 4 waves, ds_add_u32); a
 //     workgroup flushes only its non-zero bins to the int64 global rows with 64-bit atomics
-//     (T*2048 counters, L2-resident).  Bin = trunc(|x| / interval) through a 3-instruction quotient
-//     proven identical to the IEEE divide (profiles/r01_verify_fastdiv.log).
+//     (T*2048 counters, L2-resident) when it leaves a row.  Bin = trunc(|x| / interval) through a
+//     3-instruction quotient proven identical to the IEEE divide (profiles/r01_verify_fastdiv.log).
 //   * abs-max keeps a per-lane running max, reduces across the wave with DPP shuffles, across waves
 //     through LDS, and publishes with one 32-bit atomic max on the (non-negative) float's bits.
 #include <cstdlib>
@@ -23,73 +23,70 @@ namespace fq {
 thread_local int g_last_hip_error = 0;
 
 constexpr int kSegChunk = 96;          // segments per launch (kernarg block stays < 4 KB)
-constexpr int kBlock = 256;            // abs-max: 4 waves per workgroup, ~4 workgroups per CU
-constexpr int kHistBlock = 256;        // histogram: 4 waves per LDS histogram, ~8 workgroups per CU (measured optimum;
+constexpr int kBlock = 256;            // abs-max: 4 waves per workgroup
+constexpr int kHistBlock = 256;        // histogram: 4 waves per LDS histogram (measured optimum;
                                        // 1024-thread workgroups at 2 per CU were 10 % slower)
-constexpr uint32_t kMinTile = 4096;    // elements
-constexpr uint32_t kMaxTile = 1u << 22;
-constexpr int kTilesPerCUAbsmax = 4;
-constexpr int kTilesPerCUHist = 8;
+// workgroups per CU, all resident at once.  Fewer, longer streams are faster (batch 128, 8.6 GB: 1 per CU 6.2 / 4.5 TB/s
+// abs-max / histogram, 2: 6.4-6.8 / 6.5-6.7, 4: 6.4-6.8 / 6.3-6.6, 8: 6.2 / 6.4, 16: 5.8 / 6.2 -- box-to-box spread 3 %)
+constexpr int kWgPerCUAbsmax = 2;
+constexpr int kWgPerCUHist = 2;
+constexpr uint32_t kChunkVec = 4 * 256;   // 16-byte vectors per chunk: one workgroup step (4 loads in flight per lane) = 16 KB
+constexpr uint32_t kMinChunksPerWg = 4;   // at least 64 KB per workgroup, so zeroing + flushing 2048 bins stays amortised
 constexpr int kHistFastQuotientDefault = 1;   // exhaustive proof: profiles/r01_verify_fastdiv.log
 
+// 16-byte streaming load.  The statistics kernels read every activation exactly once and a calibration batch
+// (8.6 GB for ResNet-50 at batch 128) is far larger than the 256 MB Infinity Cache, so the lines are marked
+// non-temporal: scripts/hbm_read_probe.hip measures 6.1-6.3 TB/s with plain loads, 7.0-7.1 TB/s with these.
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v stream_load(const f4v* p) { return __builtin_nontemporal_load(p); }
+
+// All segments of a launch form ONE virtual stream of 16 KB chunks; every workgroup takes the same number of
+// consecutive chunks of that stream, whichever segments they fall into.  (Round 1 gave each workgroup one tile of
+// one segment: with 71 segments of 0.5-411 MB the CUs ended up with unequal byte counts and the launch ran at
+// 6.1 TB/s where a single 8 GiB segment reached 7.1.)  A workgroup whose share crosses a segment boundary
+// publishes its partial result for the finished row and carries on with the next one.
 struct SegTable {
     const float* ptr[kSegChunk];
     uint64_t n[kSegChunk];
-    uint32_t tile_begin[kSegChunk + 1];   // exclusive prefix of tiles per segment
+    uint32_t chunk_begin[kSegChunk + 1];  // exclusive prefix of chunks per segment
     int32_t row[kSegChunk];
-    uint32_t tile_elems;                  // multiple of 4
+    uint32_t chunks_per_wg;
+    uint32_t total_chunks;
     int32_t nseg;
 };
 
-// blockIdx.x -> segment index (largest s with tile_begin[s] <= b). Uniform per workgroup.
-__device__ __forceinline__ int find_seg(const SegTable& t, uint32_t b) {
+// chunk index -> segment index (largest s with chunk_begin[s] <= c). Uniform per workgroup.
+__device__ __forceinline__ int find_seg(const SegTable& t, uint32_t c) {
     int lo = 0, hi = t.nseg - 1;
     while (lo < hi) {
         int mid = (lo + hi + 1) >> 1;
-        if (t.tile_begin[mid] <= b) lo = mid; else hi = mid - 1;
+        if (t.chunk_begin[mid] <= c) lo = mid; else hi = mid - 1;
     }
     return lo;
 }
 
-struct TileView {
-    const float* p;      // first element of this tile
-    uint64_t cnt;        // elements in this tile
-    int row;
-};
-
-__device__ __forceinline__ TileView tile_of(const SegTable& t) {
-    const uint32_t b = blockIdx.x;
-    const int s = find_seg(t, b);
-    const uint64_t off = (uint64_t)(b - t.tile_begin[s]) * t.tile_elems;
-    const uint64_t rem = t.n[s] - off;
-    TileView v;
-    v.p = t.ptr[s] + off;
-    v.cnt = rem < t.tile_elems ? rem : t.tile_elems;
-    v.row = t.row[s];
-    return v;
-}
-
-// Visit every element of the tile: scalar head until 16-B aligned, float4 body with 4 loads in
-// flight per lane, scalar tail.
+// The chunks [c0, c1) of one segment: scalar head (elements before the first 16-byte boundary) and scalar tail
+// (the last n % 4 elements) belong to the segment's chunk 0; the body is 16-byte vectors, 4 loads in flight per lane.
 template <int kThreads, bool kFenceLoads, typename F>
-__device__ __forceinline__ void for_each_in_tile(const TileView& tv, F&& f) {
+__device__ __forceinline__ void for_each_in_chunks(const float* p, uint64_t cnt, uint32_t c0, uint32_t c1, F&& f) {
+    static_assert(kChunkVec == 4 * kThreads, "one chunk = four 16-byte loads per lane");
     const int tid = threadIdx.x;
-    const float* p = tv.p;
-    uint64_t cnt = tv.cnt;
     const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(p) & 15u) >> 2);
     uint32_t head = mis ? 4u - mis : 0u;
     if (head > cnt) head = (uint32_t)cnt;
-    if ((uint32_t)tid < head) f(p[tid]);
+    if (c0 == 0 && (uint32_t)tid < head) f(p[tid]);
     p += head;
     cnt -= head;
-    const float4* __restrict__ v4 = reinterpret_cast<const float4*>(p);
+    const f4v* __restrict__ v4 = reinterpret_cast<const f4v*>(p);
     const uint64_t nvec = cnt >> 2;
-    uint64_t i = tid;
-    for (; i + 3 * kThreads < nvec; i += 4 * kThreads) {
-        const float4 a = v4[i];
-        const float4 b = v4[i + kThreads];
-        const float4 c = v4[i + 2 * kThreads];
-        const float4 d = v4[i + 3 * kThreads];
+    uint64_t base = (uint64_t)c0 * kChunkVec;
+    const uint64_t end = (uint64_t)c1 * kChunkVec < nvec ? (uint64_t)c1 * kChunkVec : nvec;
+    for (; base + kChunkVec <= end; base += kChunkVec) {
+        const uint64_t i = base + tid;
+        const f4v a = stream_load(&v4[i]);
+        const f4v b = stream_load(&v4[i + kThreads]);
+        const f4v c = stream_load(&v4[i + 2 * kThreads]);
+        const f4v d = stream_load(&v4[i + 3 * kThreads]);
         // histogram: keep the loads in flight together.  Without this fence the scheduler sinks
         // each load below the previous element group's LDS atomics (one 16-byte load in flight per
         // lane: 5.0 -> 5.5 TB/s with it; 8 fenced loads per lane were slower again, 5.3).  The abs-max
@@ -100,12 +97,27 @@ __device__ __forceinline__ void for_each_in_tile(const TileView& tv, F&& f) {
         f(c.x); f(c.y); f(c.z); f(c.w);
         f(d.x); f(d.y); f(d.z); f(d.w);
     }
-    for (; i < nvec; i += kThreads) {
-        const float4 a = v4[i];
+    for (uint64_t i = base + tid; i < end; i += kThreads) {        // the segment's last, partial chunk
+        const f4v a = stream_load(&v4[i]);
         f(a.x); f(a.y); f(a.z); f(a.w);
     }
     const uint32_t tail = (uint32_t)(cnt & 3u);
-    if ((uint32_t)tid < tail) f(p[(nvec << 2) + tid]);
+    if (c0 == 0 && (uint32_t)tid < tail) f(p[(nvec << 2) + tid]);
+}
+
+// Walk this workgroup's share of the chunk stream: piece(segment, first chunk, end chunk) per segment touched.
+template <typename Piece>
+__device__ __forceinline__ void for_each_piece(const SegTable& t, Piece&& piece) {
+    uint32_t c = blockIdx.x * t.chunks_per_wg;
+    const uint32_t c_end = c + t.chunks_per_wg < t.total_chunks ? c + t.chunks_per_wg : t.total_chunks;
+    int s = find_seg(t, c);
+    while (c < c_end) {
+        const uint32_t seg_end = t.chunk_begin[s + 1];
+        const uint32_t stop = seg_end < c_end ? seg_end : c_end;
+        piece(s, c - t.chunk_begin[s], stop - t.chunk_begin[s]);
+        c = stop;
+        ++s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -113,20 +125,22 @@ __device__ __forceinline__ void for_each_in_tile(const TileView& tv, F&& f) {
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void absmax_seg_kernel(const SegTable tab, float* __restrict__ max_inout) {
     __shared__ float s_wave[kBlock / kWave];
-    const TileView tv = tile_of(tab);
-    float m = 0.0f;
-    for_each_in_tile<kBlock, false>(tv, [&](float v) { m = fmaxf(m, fabsf(v)); });   // fmaxf drops NaN
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) s_wave[wave] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+    for_each_piece(tab, [&](int s, uint32_t c0, uint32_t c1) {
+        float m = 0.0f;
+        for_each_in_chunks<kBlock, false>(tab.ptr[s], tab.n[s], c0, c1, [&](float v) { m = fmaxf(m, fabsf(v)); });   // fmaxf drops NaN
 #pragma unroll
-        for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
-        // m >= 0, so the IEEE bit pattern orders like an unsigned integer
-        atomicMax(reinterpret_cast<unsigned int*>(max_inout + tv.row), __float_as_uint(m));
-    }
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+        __syncthreads();                              // s_wave of the previous piece has been read
+        if (lane == 0) s_wave[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
+            // m >= 0, so the IEEE bit pattern orders like an unsigned integer
+            atomicMax(reinterpret_cast<unsigned int*>(max_inout + tab.row[s]), __float_as_uint(m));
+        }
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -152,11 +166,11 @@ __device__ __forceinline__ int bin_of(float v, float iv, float y) {
 }
 
 template <bool kFast>
-__device__ __forceinline__ void hist_tile(const TileView& tv, float iv, unsigned int* s_bins) {
+__device__ __forceinline__ void hist_piece(const float* p, uint64_t n, uint32_t c0, uint32_t c1, float iv, unsigned int* s_bins) {
     const float y = 1.0f / iv;                        // IEEE, once per lane
     // branch-free: lanes holding an exact zero add into a private scratch slot (2048 + lane)
     unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
-    for_each_in_tile<kHistBlock, true>(tv, [&](float v) {
+    for_each_in_chunks<kHistBlock, true>(p, n, c0, c1, [&](float v) {
         unsigned int* slot = (v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, y)) : park;
         atomicAdd(slot, 1u);                          // ds_add_u32
     });
@@ -168,24 +182,32 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable
                                                               const int allow_fast) {
     __shared__ unsigned int s_bins[FQ_BINS + kWave];
     for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kHistBlock) s_bins[b] = 0u;
-    const TileView tv = tile_of(tab);
-    const float iv = interval[tv.row];
     __syncthreads();
-    // The exhaustive proof of the fast quotient covers every significand pair but assumes that no
-    // intermediate under/overflows.  For 2^-60 <= iv <= 2^60 that holds for every element that can
-    // land above bin 0 (|x| >= iv >= 2^-60 keeps the fma residual normal; quotients that overflow
-    // become inf/nan and fall into the last bin exactly like the IEEE path).  Calibration intervals
-    // are max/2048 + 1e-12, far inside that range; anything else takes the IEEE divide.  Uniform per
-    // workgroup.
-    const unsigned int ivb = __float_as_uint(iv);
-    const bool fast = allow_fast && ivb >= 0x21800000u && ivb <= 0x5d800000u;
-    if (fast) hist_tile<true>(tv, iv, s_bins); else hist_tile<false>(tv, iv, s_bins);
-    __syncthreads();
-    unsigned long long* __restrict__ dst = hist + (size_t)tv.row * FQ_BINS;
-    for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) {
-        const unsigned int c = s_bins[b];
-        if (c) atomicAdd(dst + b, (unsigned long long)c);
-    }
+    for_each_piece(tab, [&](int s, uint32_t c0, uint32_t c1) {
+        const int row = tab.row[s];
+        const float iv = interval[row];
+        // The exhaustive proof of the fast quotient covers every significand pair but assumes that no
+        // intermediate under/overflows.  For 2^-60 <= iv <= 2^60 that holds for every element that can
+        // land above bin 0 (|x| >= iv >= 2^-60 keeps the fma residual normal; quotients that overflow
+        // become inf/nan and fall into the last bin exactly like the IEEE path).  Calibration intervals
+        // are max/2048 + 1e-12, far inside that range; anything else takes the IEEE divide.  Uniform per
+        // workgroup.
+        const unsigned int ivb = __float_as_uint(iv);
+        const bool fast = allow_fast && ivb >= 0x21800000u && ivb <= 0x5d800000u;
+        if (fast) hist_piece<true>(tab.ptr[s], tab.n[s], c0, c1, iv, s_bins);
+        else hist_piece<false>(tab.ptr[s], tab.n[s], c0, c1, iv, s_bins);
+        __syncthreads();
+        // publish the non-zero bins of this row and clear them for the next piece
+        unsigned long long* __restrict__ dst = hist + (size_t)row * FQ_BINS;
+        for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) {
+            const unsigned int c = s_bins[b];
+            if (c) {
+                atomicAdd(dst + b, (unsigned long long)c);
+                s_bins[b] = 0u;
+            }
+        }
+        __syncthreads();
+    });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -230,7 +252,7 @@ __device__ __forceinline__ ChanView chan_of(const ChanTable& t) {
 }
 
 // f(value) for every element of this workgroup's planes: one plane per wave at a time (a plane of the 56x56 /
-// 28x28 stages is too short for the 256-thread tile loader to keep four loads per lane in flight; a wave does)
+// 28x28 stages is too short for the 256-thread chunk loader to keep four loads per lane in flight; a wave does)
 template <int kThreads, bool kFenceLoads, typename F>
 __device__ __forceinline__ void for_each_in_channel(const ChanView& cv, F&& f) {
     const size_t plane_stride = (size_t)cv.C * cv.HW;
@@ -240,22 +262,22 @@ __device__ __forceinline__ void for_each_in_channel(const ChanView& cv, F&& f) {
     for (uint32_t n = cv.n0 + wave; n < cv.n1; n += kThreads / kWave) {
         const float* __restrict__ p = cv.base + (size_t)n * plane_stride;
         if (vec) {
-            const float4* __restrict__ v4 = reinterpret_cast<const float4*>(p);
+            const f4v* __restrict__ v4 = reinterpret_cast<const f4v*>(p);
             const uint32_t nvec = cv.HW >> 2;
             uint32_t i = lane;
             for (; i + 3 * kWave < nvec; i += 4 * kWave) {
-                const float4 a = v4[i];
-                const float4 b = v4[i + kWave];
-                const float4 c = v4[i + 2 * kWave];
-                const float4 d = v4[i + 3 * kWave];
-                if (kFenceLoads) __builtin_amdgcn_sched_barrier(0);       // see for_each_in_tile
+                const f4v a = stream_load(&v4[i]);
+                const f4v b = stream_load(&v4[i + kWave]);
+                const f4v c = stream_load(&v4[i + 2 * kWave]);
+                const f4v d = stream_load(&v4[i + 3 * kWave]);
+                if (kFenceLoads) __builtin_amdgcn_sched_barrier(0);       // see for_each_in_chunks
                 f(a.x); f(a.y); f(a.z); f(a.w);
                 f(b.x); f(b.y); f(b.z); f(b.w);
                 f(c.x); f(c.y); f(c.z); f(c.w);
                 f(d.x); f(d.y); f(d.z); f(d.w);
             }
             for (; i < nvec; i += kWave) {
-                const float4 a = v4[i];
+                const f4v a = stream_load(&v4[i]);
                 f(a.x); f(a.y); f(a.z); f(a.w);
             }
         } else {
@@ -365,19 +387,23 @@ static int hist_fast_quotient_enabled() {
     return v;
 }
 
-static uint32_t pick_tile_elems(const fq_seg* segs, int nseg, int default_per_cu) {
-    uint64_t total = 0;
-    for (int i = 0; i < nseg; ++i) total += segs[i].n;
-    // aim for ~kTilesPerCU workgroups per CU over the whole call (FQ_TILES_PER_CU overrides: tuning knob)
+// FQ_WG_PER_CU overrides the workgroups per CU of both statistics kernels (tuning knob).
+static int wg_per_cu(int default_per_cu) {
     static const int env_per_cu = [] {
-        const char* e = getenv("FQ_TILES_PER_CU");
+        const char* e = getenv("FQ_WG_PER_CU");
         return e ? atoi(e) : 0;
     }();
-    const int per_cu = env_per_cu > 0 ? env_per_cu : default_per_cu;
-    uint64_t want = total / (uint64_t)(kCUs * per_cu);
-    uint32_t tile = kMinTile;
-    while (tile < want && tile < kMaxTile) tile <<= 1;
-    return tile;
+    return env_per_cu > 0 ? env_per_cu : default_per_cu;
+}
+
+// chunks of one segment: 16-byte vectors after the scalar head, in units of kChunkVec; at least one (head / tail)
+static uint64_t chunks_of(const fq_seg& s) {
+    const uint32_t mis = (uint32_t)((reinterpret_cast<uintptr_t>(s.ptr) & 15u) >> 2);
+    uint64_t head = mis ? 4u - mis : 0u;
+    if (head > s.n) head = s.n;
+    const uint64_t nvec = (s.n - head) >> 2;
+    const uint64_t c = (nvec + fq::kChunkVec - 1) / fq::kChunkVec;
+    return c ? c : 1;
 }
 
 static int validate(const fq_seg* segs, int nseg) {
@@ -393,34 +419,37 @@ static int validate(const fq_seg* segs, int nseg) {
 
 template <typename Launch>
 static int for_each_chunk(const fq_seg* segs, int nseg, int per_cu, Launch&& launch) {
-    const uint32_t tile = pick_tile_elems(segs, nseg, per_cu);
     int i = 0;
     while (i < nseg) {
         SegTable tab;
-        tab.tile_elems = tile;
         int k = 0;
-        uint64_t tiles = 0;
+        uint64_t chunks = 0;
         while (i < nseg && k < kSegChunk) {
             const fq_seg& s = segs[i++];
             if (s.n == 0) continue;
-            const uint64_t nt = (s.n + tile - 1) / tile;
-            if (tiles + nt > 0x7fffffffULL) { --i; break; }     // grid limit: start a new launch
+            const uint64_t nc = chunks_of(s);
+            if (chunks + nc > 0x7fffffffULL) { --i; break; }    // 32-bit chunk index: start a new launch
             tab.ptr[k] = s.ptr;
             tab.n[k] = s.n;
             tab.row[k] = s.row;
-            tab.tile_begin[k] = (uint32_t)tiles;
-            tiles += nt;
+            tab.chunk_begin[k] = (uint32_t)chunks;
+            chunks += nc;
             ++k;
         }
         if (k == 0) {
-            if (i < nseg && segs[i].n != 0) return FQ_ERR_INVALID_ARG;   // single segment over the grid limit
+            if (i < nseg && segs[i].n != 0) return FQ_ERR_INVALID_ARG;   // single segment over the index limit
             continue;
         }
-        tab.tile_begin[k] = (uint32_t)tiles;
         tab.nseg = k;
-        for (int j = k + 1; j <= kSegChunk; ++j) tab.tile_begin[j] = (uint32_t)tiles;
+        for (int j = k; j <= kSegChunk; ++j) tab.chunk_begin[j] = (uint32_t)chunks;
         for (int j = k; j < kSegChunk; ++j) { tab.ptr[j] = nullptr; tab.n[j] = 0; tab.row[j] = 0; }
-        int rc = launch(tab, (uint32_t)tiles);
+        // equal shares of the chunk stream, every workgroup resident at once
+        const uint64_t slots = (uint64_t)kCUs * wg_per_cu(per_cu);
+        uint64_t per_wg = (chunks + slots - 1) / slots;
+        if (per_wg < kMinChunksPerWg) per_wg = kMinChunksPerWg;
+        tab.chunks_per_wg = (uint32_t)per_wg;
+        tab.total_chunks = (uint32_t)chunks;
+        int rc = launch(tab, (uint32_t)((chunks + per_wg - 1) / per_wg));
         if (rc != FQ_OK) return rc;
     }
     return FQ_OK;
@@ -435,8 +464,8 @@ extern "C" int fq_absmax_seg(const fq_seg* segs, int nseg, float* max_inout, fq_
     if (nseg == 0) return FQ_OK;
     if (max_inout == nullptr) return FQ_ERR_INVALID_ARG;
     hipStream_t st = as_stream(stream);
-    return for_each_chunk(segs, nseg, kTilesPerCUAbsmax, [&](const SegTable& tab, uint32_t tiles) -> int {
-        hipLaunchKernelGGL(absmax_seg_kernel, dim3(tiles), dim3(kBlock), 0, st, tab, max_inout);
+    return for_each_chunk(segs, nseg, kWgPerCUAbsmax, [&](const SegTable& tab, uint32_t wgs) -> int {
+        hipLaunchKernelGGL(absmax_seg_kernel, dim3(wgs), dim3(kBlock), 0, st, tab, max_inout);
         FQ_LAUNCH_CHECK();
         return FQ_OK;
     });
@@ -450,8 +479,8 @@ extern "C" int fq_hist2048_seg(const fq_seg* segs, int nseg, const float* interv
     if (nseg == 0) return FQ_OK;
     if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
     hipStream_t st = as_stream(stream);
-    return for_each_chunk(segs, nseg, kTilesPerCUHist, [&](const SegTable& tab, uint32_t tiles) -> int {
-        hipLaunchKernelGGL(hist2048_seg_kernel, dim3(tiles), dim3(kHistBlock), 0, st, tab, interval,
+    return for_each_chunk(segs, nseg, kWgPerCUHist, [&](const SegTable& tab, uint32_t wgs) -> int {
+        hipLaunchKernelGGL(hist2048_seg_kernel, dim3(wgs), dim3(kHistBlock), 0, st, tab, interval,
                            reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
         FQ_LAUNCH_CHECK();
         return FQ_OK;

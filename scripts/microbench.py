@@ -12,18 +12,27 @@ sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity"))
 from common.quantity import _native as nat  # noqa: E402
 
 
-def timeit(fn, iters=20, warmup=3):
+def timeit(fn, iters=20, warmup=3, burst=5):
+    """(median, best) ms per call.  Calls are timed in back-to-back bursts behind a queued blocker, so the host's
+    argument marshalling for call k+1 overlaps the GPU running call k and is not counted as kernel time."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-    for a, b in ev:
+    ts = []
+    for _ in range(max(1, iters // burst)):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(2_000_000)                     # ~1 ms of GPU idle-spin: the burst queues up behind it
         a.record()
-        fn()
+        for _ in range(burst):
+            fn()
         b.record()
-    torch.cuda.synchronize()
-    ts = sorted(a.elapsed_time(b) for a, b in ev)
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b) / burst)
+    ts.sort()
     return ts[len(ts) // 2], ts[0]
+
+
+CARVED = "--carved" in sys.argv          # all segments are views into ONE allocation (large page-table fragments)
 
 
 def r50_like_segments(batch, dist="normal"):
@@ -33,6 +42,19 @@ def r50_like_segments(batch, dist="normal"):
         + [200704, 50176, 200704, 200704, 200704] + [50176, 50176, 200704, 200704] * 5 \
         + [100352, 25088, 100352, 100352, 100352] + [25088, 25088, 100352, 100352] * 2 + [1000]
     segs = []
+    if CARVED:
+        pool = torch.empty(sum((s * batch + 63) // 64 * 64 for s in sizes), device="cuda")
+        off = 0
+        for i, s in enumerate(sizes):
+            n = s * batch
+            t = pool[off:off + n]
+            t.normal_()
+            t.mul_(1.0 + (i % 5))
+            if dist == "relu":
+                t.relu_()
+            segs.append(t)
+            off += (n + 63) // 64 * 64
+        return segs
     for i, s in enumerate(sizes):
         n = s * batch
         if dist == "normal":
@@ -47,7 +69,7 @@ def r50_like_segments(batch, dist="normal"):
 
 
 def main():
-    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
     print("fq version", nat.lib().fq_version(), "device", torch.cuda.get_device_name(0))
     for dist in ("normal", "outlier", "relu"):
         segs = r50_like_segments(batch, dist)
@@ -102,8 +124,25 @@ def bench_channel_kernels(batch=128):
     print("hist2048_chan: med %.3f ms  (%.0f GB/s, best %.0f)" % (ms, elems * 4 / ms / 1e6, elems * 4 / best / 1e6))
 
 
+def bench_single_segment():
+    """One 8 GiB segment: the statistics kernels without the multi-segment tiling."""
+    x = torch.randn(1 << 31, device="cuda")
+    mx = torch.zeros(1, device="cuda")
+    ms, best = timeit(lambda: nat.absmax_seg([x], [0], mx))
+    print("absmax_seg one 8 GiB segment : med %.3f ms (%.0f GB/s, best %.0f)" % (ms, x.numel() * 4 / ms / 1e6, x.numel() * 4 / best / 1e6))
+    iv = (mx / 2048 + 1e-12).float()
+    hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+    ms, best = timeit(lambda: nat.hist2048_seg([x], [0], iv, hist))
+    print("hist2048_seg one 8 GiB segment: med %.3f ms (%.0f GB/s, best %.0f)" % (ms, x.numel() * 4 / ms / 1e6, x.numel() * 4 / best / 1e6))
+    x.fill_(0.75)
+    ms, best = timeit(lambda: nat.absmax_seg([x], [0], mx))
+    print("absmax_seg, constant data     : med %.3f ms (%.0f GB/s, best %.0f)" % (ms, x.numel() * 4 / ms / 1e6, x.numel() * 4 / best / 1e6))
+
+
 if __name__ == "__main__":
-    if "--chan" in sys.argv:
+    if "--single" in sys.argv:
+        bench_single_segment()
+    elif "--chan" in sys.argv:
         bench_channel_kernels()
     else:
         main()
