@@ -158,6 +158,19 @@ int fq_quantize_i8_nhwc(const float* x_nchw, int8_t* y_nhwc, int N, int C, int H
 int fq_quantize_i8_unfold_w(const float* x_nchw, int8_t* y, int N, int C, int H, int W, int S,
                             int stride_w, int pad_w, int dil_w, int Cpad2, int ib, fq_stream_t stream);
 
+/* The whole stem NewConv2d (new_quantity_op.py:124-133 on the network input, C <= 4) followed by nn.ReLU when
+ * relu != 0, in one kernel and without the width-unfolded copy of the image:
+ *   q[n][p][q][k] = Sp( RightShift( sum_{r,s,c} w[k][c][r][s] * Quantity_ib(x)[n][c][p*sh-ph+r][q*sw-pw+s], rs ) + qbias[k] )
+ *   (max(.,0) with relu), the integers in front of DeQuantity(ob): value = q * 2^-ob.
+ * x: fp32 NCHW.  w_stem: int8 [R][64][32], byte 4*s + c of row (r, k) = the quantised weight[k][c][r][s], every other
+ * byte 0 (rows k >= K zero).  q_nhwc: int8 [N][P][Q][Kpad], Kpad % 16 == 0, K <= Kpad <= 64, channels >= K written
+ * as zeros.  Limits: C <= 4, S <= 8, R <= 8, K <= 64, dilation 1, 1 <= rs <= 16, input patch of an 8x16 output tile
+ * ((7*sh + R) x (15*sw + S) pixels) <= 1024 pixels; FQ_ERR_INVALID_ARG otherwise (callers then use
+ * fq_quantize_i8_unfold_w + fq_conv2d_i8_resident, which compute the same integers). */
+int fq_conv2d_i8_stem(const float* x_nchw, const int8_t* w_stem, const float* qbias, int8_t* q_nhwc, int Kpad, int relu,
+                      int N, int C, int H, int W, int K, int R, int S, int stride_h, int stride_w, int pad_h,
+                      int pad_w, int ib, int rs, int ob, fq_stream_t stream);
+
 /* NewConv2d.forward / NewLinear.forward after Quantity (new_quantity_op.py:126-132, :199-204):
  *   acc[n][k][p][q] = sum_{r,s,c} w[k][r][s][c] * x[n][p*stride-pad+r*dil][q*stride-pad+s*dil][c]   (int32, exact)
  *   y = clamp( RightShift(acc, rs) + qbias[k] ) / 2^ob                                    (fp32 NCHW)

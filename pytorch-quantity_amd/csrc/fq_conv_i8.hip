@@ -26,6 +26,7 @@
 #include <utility>
 
 #include "fq_resident.h"
+#include "fq_int_tail.h"
 
 namespace fq {
 
@@ -43,8 +44,6 @@ __device__ __forceinline__ unsigned long long stamp() {
 #define TR(slot) do {} while (0)
 #endif
 
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v16i __attribute__((ext_vector_type(16)));
 
 constexpr int kConvBlock = 256;
 constexpr int kTP = 128;                 // pixels per workgroup tile
@@ -121,27 +120,7 @@ __device__ __forceinline__ float conv_tail_int(int acc, float qb, const ConvPara
 __device__ __forceinline__ float conv_tail(int acc, float qb, const ConvParams& p) {
     return conv_tail_int(acc, qb, p) * p.inv_ob;
 }
-// The same tail in integer arithmetic, 6 vector instructions instead of 11 (the epilogue of the
-// output-heavy 1x1 layers is bound by exactly these instructions: 64 accumulators per lane).  Valid for
-// 1 <= rs <= 16 and |acc| + 2^15 < 2^31 (checked on the host):
-//   trunc(v + copysign(0.5, v)), v = acc * 2^-rs, is round-half-away = (acc + 2^(rs-1) - (acc < 0)) >> rs
-//   with an arithmetic shift; below |acc| < 2^24 every fp32 step of the reference is exact, and from
-//   2^24 on both forms are far outside [-128, 127] (|v| >= 2^8) and saturate to the same bound.
-__device__ __forceinline__ int med3_i32(int v, int lo, int hi) {       // lo <= hi: clamp in one instruction
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ int conv_tail_i(int acc, int qb, const ConvParams& p) {
-    const int r = (acc + p.half_rs + (acc >> 31)) >> p.rs;
-    return med3_i32(med3_i32(r, p.ilo, p.ihi) + qb, p.slo, p.shi);
-}
-// bytes 0 of four registers -> one dword
-__device__ __forceinline__ unsigned pack4(int b0, int b1, int b2, int b3) {
-    const unsigned p01 = __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u);
-    const unsigned p23 = __builtin_amdgcn_perm((unsigned)b3, (unsigned)b2, 0x0c0c0400u);
-    return __builtin_amdgcn_perm(p23, p01, 0x05040100u);
-}
+// The same tail in integer arithmetic: conv_tail_i (fq_int_tail.h), selected when the host proved it equivalent.
 
 // Position of a 16-byte chunk on the reduction axis: tap (r, s) and 16-channel group cc.
 struct RedPos { int cc, fs, fr; };
@@ -688,11 +667,7 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
 }
 
 // ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
-__device__ __forceinline__ unsigned q8(float v, float scale) {
-    float q = rintf(v * scale);
-    q = q < -128.0f ? -128.0f : (q > 127.0f ? 127.0f : q);          // NaN stays NaN; the cast gives 0
-    return (unsigned)(uint8_t)(int8_t)(int)q;
-}
+// q8 (one element): fq_int_tail.h
 
 // block = (64 hw) x (64 c) tile of one image.  Each thread loads a 4(c) x 4(hw) patch with four
 // 16-byte loads along hw, quantises, and writes the patch transposed (4 dwords of 4 channels) into an

@@ -86,6 +86,8 @@ def lib():
     L.fq_conv2d_i8.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_resident.restype = ci
     L.fq_conv2d_i8_resident.argtypes = [vp, vp, vp, vp, vp] + [ci] * 17 + [vp]
+    L.fq_conv2d_i8_stem.restype = ci
+    L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
     L.fq_conv2d_i8_add_resident.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, vp, ci, ci, ci] + [ci] * 15 + [vp]
     L.fq_add_resident.restype = ci
@@ -405,6 +407,44 @@ def conv2d_i8_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, want_f3
                                        1 if relu else 0, N, H, W, C, K, R, S, stride[0], stride[1], padding[0], padding[1],
                                        dilation[0], dilation[1], int(rs), int(ob), _stream(xq)), "fq_conv2d_i8_resident")
     return y, q
+
+
+STEM_MAX_K, STEM_MAX_R, STEM_MAX_S, STEM_MAX_C = 64, 8, 8, 4
+
+
+def stem_supported(C, K, R, S, stride, dilation, rs):
+    """True when fq_conv2d_i8_stem takes this layer (include/fq.h); otherwise the unfold path computes the same integers."""
+    if C > STEM_MAX_C or K > STEM_MAX_K or R > STEM_MAX_R or S > STEM_MAX_S or tuple(dilation) != (1, 1) or not 1 <= rs <= 16:
+        return False
+    pr, pc = 7 * stride[0] + R, 15 * stride[1] + S
+    pcs = max(15 * stride[1] + 8, pc) | 1
+    return pr * pc <= 1024 and (pr - 1) * pcs + 15 * stride[1] + 8 <= 1536
+
+
+def pack_weight_stem(w):
+    """Integer-valued fp32 weights [K, C, R, S] (K <= 64, C <= 4, S <= 8) -> int8 [R, 64, 32]: byte 4*s + c."""
+    K, C, R, S = w.shape
+    out = torch.zeros(R, STEM_MAX_K, 8, 4, dtype=torch.int8, device=w.device)
+    out[:, :K, :S, :C] = w.permute(2, 0, 3, 1).to(torch.int8)            # [R, K, S, C]
+    return out.view(R, STEM_MAX_K, 32).contiguous()
+
+
+def conv2d_i8_stem(x, w_stem, qbias, K, S, stride, padding, ib, rs, ob, relu):
+    """fq_conv2d_i8_stem: fp32 NCHW image -> int8 [N,P,Q,Kpad] (the integers before DeQuantity(ob), ReLU folded in)."""
+    _need_cuda(x, torch.float32, "fq_conv2d_i8_stem")
+    _need_cuda(w_stem, torch.int8, "fq_conv2d_i8_stem")
+    _need_cuda(qbias, torch.float32, "fq_conv2d_i8_stem")
+    N, C, H, W = x.shape
+    R = w_stem.shape[0]
+    assert x.is_contiguous() and w_stem.is_contiguous() and tuple(w_stem.shape[1:]) == (STEM_MAX_K, 32) and qbias.numel() == K
+    P = (H + 2 * padding[0] - R) // stride[0] + 1
+    Q = (W + 2 * padding[1] - S) // stride[1] + 1
+    kpad = pad16(K)
+    q = torch.empty(N, P, Q, kpad, dtype=torch.int8, device=x.device)
+    _check(lib().fq_conv2d_i8_stem(x.data_ptr(), w_stem.data_ptr(), qbias.contiguous().data_ptr(), q.data_ptr(), kpad,
+                                   1 if relu else 0, N, C, H, W, K, R, S, stride[0], stride[1], padding[0], padding[1],
+                                   int(ib), int(rs), int(ob), _stream(x)), "fq_conv2d_i8_stem")
+    return q
 
 
 _INT_BYTES = {torch.int8: 1, torch.int16: 2}

@@ -144,6 +144,7 @@ class _IntegerSimLayer(nn.Module):
     integer-valued tensors -> fused tail kernel); both are exact below 2^24 per partial sum."""
 
     use_int8_mfma = True
+    use_stem_kernel = True        # False: the stem goes through fq_quantize_i8_unfold_w + the general kernel (same integers)
 
     def _int8_ok(self, layer):
         if not self.use_int8_mfma or QUANTIZE_BIT != 8:
@@ -170,9 +171,19 @@ class _IntegerSimLayer(nn.Module):
             cached = self._w_i8
         return cached[1]
 
+    def _stem_weight(self, layer):
+        """Weights packed for fq_conv2d_i8_stem (one kernel for the whole stem layer), cached like _packed_weight."""
+        w = layer.weight
+        cached = getattr(self, "_w_stem", None)
+        if cached is None or cached[0] != (w.data_ptr(), w._version, str(w.device)):
+            object.__setattr__(self, "_w_stem", ((w.data_ptr(), w._version, str(w.device)), _native.pack_weight_stem(w.detach())))
+            cached = self._w_stem
+        return cached[1]
+
     def __getstate__(self):
         state = self.__dict__.copy()
         state.pop("_w_i8", None)                  # derived data: rebuilt on first forward after loading
+        state.pop("_w_stem", None)
         return state
 
     def _setup(self, layer, quantize_infor, out_count, wide_weights):
@@ -218,6 +229,16 @@ class NewConv2d(_IntegerSimLayer):
             wq = self._packed_weight(conv)
             plan = self.__dict__.get("_resident")         # set by common.quantity.resident.enable()
             fold = self._stem_fold(conv)
+            if (fold and plan is not None and plan.emit_int and not plan.emit_f32 and not plan.defer and self.use_stem_kernel
+                    and _native.stem_supported(conv.in_channels, conv.out_channels, conv.kernel_size[0], conv.kernel_size[1],
+                                               conv.stride, conv.dilation, self.rs_bit)):
+                # the whole layer in one kernel: fp32 image in, int8 NHWC out (no unfolded copy of the image)
+                x = as_f32(input)
+                q = _native.conv2d_i8_stem(x if x.is_contiguous() else x.contiguous(), self._stem_weight(conv),
+                                           self.quantized_bias, conv.out_channels, conv.kernel_size[1], conv.stride,
+                                           conv.padding, self.input_bit, self.rs_bit, self.output_bit, plan.relu)
+                return QHandle((q.shape[0], conv.out_channels, q.shape[1], q.shape[2]), q, self.output_bit, q,
+                               self.output_bit, plan.relu)
             if fold:
                 input = as_f32(input)
                 xq = _native.quantize_i8_unfold_w(input, self.input_bit, conv.kernel_size[1], conv.stride[1],

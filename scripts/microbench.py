@@ -124,6 +124,51 @@ def bench_channel_kernels(batch=128):
     print("hist2048_chan: med %.3f ms  (%.0f GB/s, best %.0f)" % (ms, elems * 4 / ms / 1e6, elems * 4 / best / 1e6))
 
 
+def bench_rotating(batch, sets):
+    """The same segment list in `sets` different places of HBM, visited in turn: every launch reads addresses
+    it has not touched for sets-1 launches (cold TLB / page-table walks), as in a real calibration pass."""
+    groups = [r50_like_segments(batch, "normal") for _ in range(sets)]
+    rows = list(range(len(groups[0])))
+    nel = sum(t.numel() for t in groups[0])
+    mx = torch.zeros(len(rows), device="cuda")
+    hist = torch.zeros(len(rows), 2048, dtype=torch.int64, device="cuda")
+    state = {"i": 0}
+
+    def nxt():
+        state["i"] = (state["i"] + 1) % sets
+        return groups[state["i"]]
+    ms, best = timeit(lambda: nat.absmax_seg(nxt(), rows, mx))
+    print("absmax_seg  rotating over %d sets (%.0f GB): med %.3f ms (%.0f GB/s, best %.0f)" %
+          (sets, sets * nel * 4 / 1e9, ms, nel * 4 / ms / 1e6, nel * 4 / best / 1e6))
+    iv = (mx / 2048 + 1e-12).float()
+    ms, best = timeit(lambda: nat.hist2048_seg(nxt(), rows, iv, hist))
+    print("hist2048_seg rotating: med %.3f ms (%.0f GB/s, best %.0f)" % (ms, nel * 4 / ms / 1e6, nel * 4 / best / 1e6))
+
+
+def bench_after_compute(batch):
+    """One statistics launch right behind ~20 ms of fp32 matrix work, as in a calibration pass (the forward)."""
+    segs = r50_like_segments(batch, "normal")
+    rows = list(range(len(segs)))
+    nel = sum(t.numel() for t in segs)
+    mx = torch.zeros(len(rows), device="cuda")
+    iv = torch.full((len(rows),), 6.0 / 2048, device="cuda")
+    hist = torch.zeros(len(rows), 2048, dtype=torch.int64, device="cuda")
+    a_mat = torch.randn(8192, 8192, device="cuda")
+    for label, heat in (("idle GPU", 0), ("behind 4 fp32 8192^3 matmuls", 4), ("behind 16", 16)):
+        for name, fn in (("absmax_seg", lambda: nat.absmax_seg(segs, rows, mx)), ("hist2048_seg", lambda: nat.hist2048_seg(segs, rows, iv, hist))):
+            ts = []
+            for _ in range(6):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda._sleep(2_000_000)
+                for _ in range(heat):
+                    torch.mm(a_mat, a_mat)
+                a.record(); fn(); b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            ts.sort()
+            print("%-12s %-30s med %.3f ms (%.0f GB/s)" % (name, label, ts[len(ts) // 2], nel * 4 / ts[len(ts) // 2] / 1e6))
+
+
 def bench_single_segment():
     """One 8 GiB segment: the statistics kernels without the multi-segment tiling."""
     x = torch.randn(1 << 31, device="cuda")
@@ -140,7 +185,11 @@ def bench_single_segment():
 
 
 if __name__ == "__main__":
-    if "--single" in sys.argv:
+    if "--heat" in sys.argv:
+        bench_after_compute(int(sys.argv[1]))
+    elif "--rotate" in sys.argv:
+        bench_rotating(int(sys.argv[1]), int(sys.argv[sys.argv.index("--rotate") + 1]))
+    elif "--single" in sys.argv:
         bench_single_segment()
     elif "--chan" in sys.argv:
         bench_channel_kernels()

@@ -15,9 +15,24 @@ bench.make_workdir(K - 1, "1,3,224,224", 0)
 data = bench.DeviceBatches(K, B, 224, 0, 1, dev)
 q = Quantity(model)
 q.activation_quantize_per_channel(data)              # warm-up (MIOpen, code load)
+from common.quantity import channel_collector as cc
+phase = {}
+def timed(name):
+    orig = getattr(cc.ChannelCollector, name)
+    def wrapper(self, *a, **k):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        r = orig(self, *a, **k)
+        torch.cuda.synchronize(); phase[name] = phase.get(name, 0.0) + time.perf_counter() - t
+        return r
+    setattr(cc.ChannelCollector, name, wrapper)
+if "--phases" in sys.argv:                            # synchronising timers around the collector's entry points
+    for name in ("refresh_max_val", "add_to_distributions", "intervals", "quantize"):
+        timed(name)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 bits = q.activation_quantize_per_channel(data)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 sys.stdout = out
 rows = q._channel_collector.rows
 print("per-channel calibration: %d images, %d rows, %.3f s = %.0f images/s" % (K * B, rows, dt, K * B / dt))
+if phase:
+    print("  of which (synchronised): " + ", ".join("%s %.3f s" % kv for kv in phase.items()))

@@ -82,6 +82,19 @@ def conv2d_i8_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, want_f3
     return (torch.from_numpy(y) if want_f32 else None), q
 
 
+def conv2d_i8_stem(x, w_stem, qbias, K, S, stride, padding, ib, rs, ob, relu):
+    """The stem layer from the fp32 image: Quantity -> integer conv -> tail -> ReLU -> the next layer's Quantity(ob)."""
+    C, R = x.shape[1], w_stem.shape[0]
+    w = _np(w_stem).reshape(R, 64, 8, 4)[:, :K, :S, :C].astype(np.int32)                  # [R, K, S, C]
+    w = np.ascontiguousarray(np.transpose(w, (1, 3, 0, 2)))                                # [K, C, R, S]
+    xq = orc.quantity(_np(x).astype(np.float32), ib).astype(np.int32)
+    acc = orc.conv2d_int(np.ascontiguousarray(xq), w, tuple(stride), tuple(padding), (1, 1))
+    y = orc.recon_epilogue(acc.astype(np.float32), _np(qbias).astype(np.float32), rs, ob)
+    if relu:
+        y = np.maximum(y, np.float32(0))
+    return _to_i8_nhwc(y, ob, pad16(K))
+
+
 def _deq(t, g, channels=None):
     a = _np(t).astype(np.float32)
     if channels is not None:
@@ -140,7 +153,8 @@ def quantity(x, ib, bitwidth=8, out=None):
 
 
 _DOUBLES = dict(quantize_i8_nhwc=quantize_i8_nhwc, quantize_i8_unfold_w=quantize_i8_unfold_w, conv2d_i8=conv2d_i8,
-                conv2d_i8_resident=conv2d_i8_resident, conv2d_i8_add_resident=conv2d_i8_add_resident, add_resident=add_resident,
+                conv2d_i8_resident=conv2d_i8_resident, conv2d_i8_stem=conv2d_i8_stem,
+                conv2d_i8_add_resident=conv2d_i8_add_resident, add_resident=add_resident,
                 dequant_nhwc_to_nchw=dequant_nhwc_to_nchw, maxpool_i8_nhwc=maxpool_i8_nhwc, avgpool_global_nhwc=avgpool_global_nhwc,
                 add_sat=add_sat, quantity=quantity)
 

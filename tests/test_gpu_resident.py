@@ -73,6 +73,66 @@ def test_conv_resident_outputs(nat, oracle, case, relu):
                 assert q is None
 
 
+STEM_CASES = [
+    # N, C, H, W, K, R, S, stride, pad
+    (2, 3, 224, 224, 64, 7, 7, 2, 3),          # the ResNet stem
+    (3, 3, 32, 32, 64, 3, 3, 1, 1),            # the 32x32 ResNet-18 stem
+    (2, 1, 28, 28, 20, 5, 5, 1, 0),            # one channel, K = 20 -> Kpad 32, no padding
+    (1, 4, 37, 53, 33, 7, 5, 2, 2),            # ragged tiles on both axes, R != S, Kpad 48
+    (2, 2, 19, 23, 16, 8, 8, 2, 4),            # the limits: 8 x 8 taps
+    (1, 3, 9, 9, 64, 3, 3, 2, 0),              # a single partial tile
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES)
+@pytest.mark.parametrize("relu", [False, True])
+def test_stem_kernel_equals_oracle_and_the_unfold_path(nat, oracle, case, relu):
+    """fq_conv2d_i8_stem (fp32 image -> int8 NHWC in one kernel) against the reference chain Quantity -> integer
+    conv -> RightShift -> BiasAdd -> Sp (-> ReLU) -> next Quantity, and against the two-kernel unfold path."""
+    N, C, H, W, K, R, S, st, pd = case
+    rng = np.random.default_rng(sum(case) + 7 * int(relu))
+    x = (rng.standard_normal((N, C, H, W)) * 1.7).astype(np.float32)
+    x.flat[::97] = 0.0
+    x.flat[5::211] *= 40.0                                                 # saturating pixels
+    wq = rng.integers(-128, 128, size=(K, C, R, S)).astype(np.int32)
+    qb = rng.integers(-128, 128, size=K).astype(np.float32)
+    assert nat.stem_supported(C, K, R, S, (st, st), (1, 1), 9)
+    w_stem = nat.pack_weight_stem(_dev(wq.astype(np.float32)))
+    x_dev, b_dev = _dev(x), _dev(qb)
+    kpad = (K + 15) // 16 * 16
+    for ib, rs, ob in ((5, 12, 4), (6, 9, 2), (4, 16, -1), (7, 1, 6)):
+        xq = oracle.quantity(x, ib).astype(np.int32)
+        acc = oracle.conv2d_int(xq, wq, (st, st), (pd, pd), (1, 1))
+        ref = oracle.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+        if relu:
+            ref = np.maximum(ref, np.float32(0))
+        ref_q = np.zeros(ref.shape[:1] + ref.shape[2:] + (kpad,), dtype=np.int8)
+        ref_q[..., :K] = oracle.quantity(ref, ob).astype(np.int8).transpose(0, 2, 3, 1)
+        got = nat.conv2d_i8_stem(x_dev, w_stem, b_dev, K, S, (st, st), (pd, pd), ib, rs, ob, relu).cpu().numpy()
+        assert got.shape == ref_q.shape
+        assert np.array_equal(got, ref_q), (case, ib, rs, ob, int((got != ref_q).sum()))
+        # the two-kernel path the general layers use computes the same integers
+        fold = nat.pad16(S * C)
+        w_fold = nat.pack_weight_unfold_w(_dev(wq.astype(np.float32)), fold)
+        xu = nat.quantize_i8_unfold_w(x_dev, ib, S, st, pd, 1, fold)
+        _y, q2 = nat.conv2d_i8_resident(xu, w_fold, b_dev, (st, 1), (pd, 0), (1, 1), rs, ob, False, True, relu)
+        assert torch.equal(q2.cpu(), torch.from_numpy(got))
+
+
+def test_stem_kernel_refuses_what_it_does_not_cover(nat):
+    x = torch.zeros(1, 5, 8, 8, device="cuda")
+    w = torch.zeros(3, 64, 32, dtype=torch.int8, device="cuda")
+    b = torch.zeros(8, device="cuda")
+    assert not nat.stem_supported(5, 8, 3, 3, (1, 1), (1, 1), 9)           # five input channels
+    assert not nat.stem_supported(3, 8, 3, 3, (1, 1), (2, 2), 9)           # dilation
+    assert not nat.stem_supported(3, 8, 3, 3, (1, 1), (1, 1), 0)           # shift outside the integer tail
+    assert not nat.stem_supported(3, 8, 7, 7, (6, 6), (1, 1), 9)           # patch larger than the LDS budget
+    with pytest.raises(nat.FqError):
+        nat.conv2d_i8_stem(x, w, b, 8, 3, (1, 1), (1, 1), 5, 9, 3, False)
+    with pytest.raises(nat.FqError):
+        nat.conv2d_i8_stem(torch.zeros(1, 3, 8, 8), w, b, 8, 3, (1, 1), (1, 1), 5, 9, 3, False)    # CPU tensor
+
+
 @pytest.mark.parametrize("xb,gx,yb,gy,ib,relu", [(1, 3, 1, 5, 4, True), (1, 5, 2, 5, 3, True), (2, 6, 1, 2, 6, False),
                                                  (2, 8, 2, 7, 5, True), (1, -1, 1, 2, 0, False), (1, 0, 2, 0, 1, True)])
 def test_add_resident_equals_fp32_chain(nat, oracle, xb, gx, yb, gy, ib, relu):
