@@ -17,6 +17,7 @@ The JSON line also carries
                  per launch) / its mean launch duration measured with HIP events on the launch stream;
   cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded
                  sample on this box's host cores, scaled to the same workload (rank 0, N=1 only);
+  (the forward-throughput keys below run --int8-batch images per forward, default 256: two calibration batches)
   int8_sim_images_per_s : ReconModel forward throughput with resident integer activations
                      (common.quantity.resident.enable(): int8/int16 NHWC between layers; logits checked
                      bit-identical to the fp32-boundary model in the same run, see int8_sim_resident);
@@ -209,6 +210,9 @@ def main():
                     help="hand the calibrator pageable HOST batches (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recon", action="store_true")
+    ap.add_argument("--int8-batch", type=int, default=256,
+                    help="images per forward of the int8-sim / fake-quant throughput section (resident int8-sim forward on "
+                         "one MI355X: 62 k images/s at 128, 73 k at 256, 76 k at 512)")
     ap.add_argument("--no-per-channel", action="store_true")
     args = ap.parse_args()
 
@@ -354,6 +358,11 @@ def main():
             q.weight_quantize()
             barrier()
             batches = [b.to(device) for b in data.owned()[:min(K, 8)]]
+            if args.int8_batch > B:                        # larger forwards: concatenated calibration batches
+                per = (args.int8_batch + B - 1) // B
+                src = batches if len(batches) >= per else batches * per
+                batches = [torch.cat(src[i:i + per]) for i in range(0, len(src) - per + 1, per)][:4]
+            FB = int(batches[0].shape[0])
 
             def fwd_rate(net, passes=1):
                 """images/s of net over the resident batches; the fast models take several passes so that one
@@ -369,7 +378,7 @@ def main():
                 dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
                 if distributed:
                     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                return passes * len(batches) * B * world / float(dt.item())
+                return passes * len(batches) * FB * world / float(dt.item())
 
             result["float_forward_images_per_s"] = round(fwd_rate(model), 1)
             rec = Reconstruction(build_model(args.model, HW, device))
@@ -387,7 +396,7 @@ def main():
             with torch.no_grad():
                 same = bool(torch.equal(int8_net(batches[0]), logits_fp32_boundary))
             result["int8_sim_images_per_s"] = round(fwd_rate(int8_net, 8), 1)
-            result["int8_sim_resident"] = {"bit_identical_logits": same, "plan": plan}
+            result["int8_sim_resident"] = {"bit_identical_logits": same, "plan": plan, "images_per_forward": FB}
             if not same:                                   # never report a rate for a model that computes something else
                 result["int8_sim_images_per_s"] = result["int8_sim_fp32_boundary_images_per_s"]
             else:
