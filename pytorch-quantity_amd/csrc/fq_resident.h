@@ -1,7 +1,9 @@
 // fq_resident.h -- pieces shared by the resident-activation kernels (fq_resident.hip) and the conv epilogue
 // that fuses the residual add (fq_conv_i8.hip).
 #pragma once
+#include <cstdlib>
 #include "fq_common.h"
+#include "fq_int_tail.h"
 
 namespace fq {
 
@@ -12,13 +14,19 @@ struct AddResParams {
     float lo, hi;          // NewAdd's Sp range; lo = 0 when the following ReLU is fused
     float s_wide;          // 2^g_out   (exact value -> int16)
     float s_narrow;        // 2^ib      (next layers' Quantity)
+    // the same function in integer arithmetic on the grid g = max(0, gx, gy) (int_ok: the host proved the ranges)
+    int int_ok;
+    int shx, shy;          // g - gx, g - gy: operand -> grid g
+    int ilo, ihi;          // Sp range on grid g
+    int k, half_m1;        // narrow = S * 2^(ib - g): k = g - ib; k > 0: round-half-even right shift with 2^(k-1) - 1
 };
 
 template <typename T> struct Vec16;                       // 16 consecutive channels of one pixel
 template <> struct Vec16<int8_t> {
     v4i_r a;
     __device__ __forceinline__ void load(const int8_t* p) { a = *reinterpret_cast<const v4i_r*>(p); }
-    __device__ __forceinline__ float get(int i) const { return (float)(int)(int8_t)(((unsigned)a[i >> 2]) >> (8 * (i & 3))); }
+    __device__ __forceinline__ int geti(int i) const { return (int)(int8_t)(((unsigned)a[i >> 2]) >> (8 * (i & 3))); }
+    __device__ __forceinline__ float get(int i) const { return (float)geti(i); }
 };
 template <> struct Vec16<int16_t> {
     v4i_r a, b;
@@ -26,19 +34,65 @@ template <> struct Vec16<int16_t> {
         a = *reinterpret_cast<const v4i_r*>(p);
         b = *reinterpret_cast<const v4i_r*>(p + 8);
     }
-    __device__ __forceinline__ float get(int i) const {
+    __device__ __forceinline__ int geti(int i) const {
         const unsigned d = (unsigned)(i < 8 ? a[(i & 7) >> 1] : b[(i & 7) >> 1]);
-        return (float)(int)(int16_t)(d >> (16 * (i & 1)));
+        return (int)(int16_t)(d >> (16 * (i & 1)));
     }
+    __device__ __forceinline__ float get(int i) const { return (float)geti(i); }
 };
 
 // NewAdd on 16 resident elements (new_quantity_op.py:171-174 + the ReLU and Quantity that follow it):
 //   s = clamp(x * 2^-gx + y * 2^-gy, lo, hi)            the reference's fp32 expression, exact here
 //   wide[i]   = (int16) (s * 2^g_out)                    the exact sum, for the next residual add
 //   narrow[i] = (int8) clamp(rint(s * 2^ib), -128, 127)  what the next conv's Quantity(ib) computes
+//
+// Integer form (p.int_ok): every value above is an integer multiple of 2^-g, g = max(0, gx, gy), and small enough
+// that the fp32 chain is exact, so with S = s * 2^g
+//   S = med3((x << (g - gx)) + (y << (g - gy)), lo * 2^g, hi * 2^g),   wide = S,
+//   narrow = med3(k > 0 ? (S + 2^(k-1) - 1 + ((S >> k) & 1)) >> k : S << -k, -128, 127),  k = g - ib
+// (round-half-to-even of S / 2^k is exactly what rint does on the exact quotient) -- 10 vector instructions per
+// element instead of 17; the fused conv + add epilogue of the 1x1 expand layers is bound by exactly these.
+template <bool kShiftRight, typename VX, typename VY>
+__device__ __forceinline__ void add_resident_16_int(const VX& vx, const VY& vy, int16_t* __restrict__ wide,
+                                                    int8_t* __restrict__ narrow, const AddResParams& p) {
+    int s[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) s[e] = med3_i32((vx.geti(e) << p.shx) + (vy.geti(e) << p.shy), p.ilo, p.ihi);
+    if (wide) {
+        v4i_r o0, o1;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const int w = (int)__builtin_amdgcn_perm((unsigned)s[2 * d + 1], (unsigned)s[2 * d], 0x05040100u);   // low halves
+            if (d < 4) o0[d] = w; else o1[d - 4] = w;
+        }
+        *reinterpret_cast<v4i_r*>(wide) = o0;
+        *reinterpret_cast<v4i_r*>(wide + 8) = o1;
+    }
+    if (narrow) {
+        v4i_r o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            int q[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int S = s[4 * d + e];
+                const int r = kShiftRight ? (S + p.half_m1 + ((S >> p.k) & 1)) >> p.k : S << -p.k;
+                q[e] = med3_i32(r, -128, 127);
+            }
+            o[d] = (int)pack4(q[0], q[1], q[2], q[3]);
+        }
+        *reinterpret_cast<v4i_r*>(narrow) = o;
+    }
+}
+
 template <typename VX, typename VY>
 __device__ __forceinline__ void add_resident_16(const VX& vx, const VY& vy, int16_t* __restrict__ wide, int8_t* __restrict__ narrow,
                                                 const AddResParams& p) {
+    if (p.int_ok) {                                       // uniform
+        if (p.k > 0) add_resident_16_int<true>(vx, vy, wide, narrow, p);
+        else add_resident_16_int<false>(vx, vy, wide, narrow, p);
+        return;
+    }
     float s[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -83,6 +137,16 @@ inline int make_add_params(int gx, int gy, int g_wide, bool want_wide, int ib, i
     p->sx = ldexpf(1.0f, -gx); p->sy = ldexpf(1.0f, -gy);
     p->lo = relu ? 0.0f : -128.0f; p->hi = 127.0f;
     p->s_wide = ldexpf(1.0f, want_wide ? g_wide : 0); p->s_narrow = ldexpf(1.0f, ib);
+    // integer form: operands |x|, |y| <= 2^15 shifted by at most 12, the clamped sum |S| <= 2^(7+g) <= 2^15 shifted left by
+    // at most 15 -- nothing leaves int32.  FQ_ADD_FLOAT=1 keeps the fp32 chain (A/B timing).
+    static const bool force_float = [] { const char* e = getenv("FQ_ADD_FLOAT"); return e && e[0] && e[0] != '0'; }();
+    const int g = gx > gy ? (gx > 0 ? gx : 0) : (gy > 0 ? gy : 0);
+    p->shx = g - gx; p->shy = g - gy;
+    p->k = g - ib;
+    p->int_ok = !force_float && g <= 8 && p->shx <= 12 && p->shy <= 12 && p->k >= -15 && p->k <= 24;
+    p->half_m1 = p->k > 0 ? (1 << (p->k - 1)) - 1 : 0;
+    p->ilo = relu ? 0 : -(128 << g); p->ihi = 127 << g;
+    if (!p->int_ok) { p->shx = p->shy = 0; p->k = 0; }
     return FQ_OK;
 }
 

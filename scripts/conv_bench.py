@@ -38,14 +38,27 @@ for (C, H, K, R, st, pd, cnt) in LAYERS:
     wq = nat.pack_weight_krsc(w)
     xq = nat.quantize_i8_nhwc(x, 4, wq.shape[-1])
     P = (H + 2 * pd - R) // st + 1
-    if I8OUT:
+    if C <= 4:
+        # the stem as the model runs it: fq_conv2d_i8_stem from the fp32 image (int8 output), or the unfolded copy +
+        # the general kernel (fp32 output); the "quant" column is the unfold kernel of the latter
+        fold = nat.pad16(R * C)
+        w_fold, w_stem = nat.pack_weight_unfold_w(w, fold), nat.pack_weight_stem(w)
+        xu = nat.quantize_i8_unfold_w(x, 4, R, st, pd, 1, fold)
+        if I8OUT:
+            t_c = timeit(lambda: nat.conv2d_i8_stem(x, w_stem, qb, K, R, (st, st), (pd, pd), 4, 8, 4, True))
+        else:
+            t_c = timeit(lambda: nat.conv2d_i8(xu, w_fold, qb, (st, 1), (pd, 0), (1, 1), 8, 4))
+        t_q = 0.0 if I8OUT else timeit(lambda: nat.quantize_i8_unfold_w(x, 4, R, st, pd, 1, fold))
+        xq = x if I8OUT else xu
+    elif I8OUT:
         t_c = timeit(lambda: nat.conv2d_i8_resident(xq, wq, qb, (st, st), (pd, pd), (1, 1), 8, 4, False, True, True))
     else:
         t_c = timeit(lambda: nat.conv2d_i8(xq, wq, qb, (st, st), (pd, pd), (1, 1), 8, 4))
-    t_q = timeit(lambda: nat.quantize_i8_nhwc(x, 4, wq.shape[-1]))
+    if C > 4:
+        t_q = timeit(lambda: nat.quantize_i8_nhwc(x, 4, wq.shape[-1]))
     macs = B * P * P * K * C * R * R
     out_b = B * P * P * K * (1 if I8OUT else 4)
-    in_b = xq.numel()
+    in_b = xq.numel() * xq.element_size()
     floor = (out_b + in_b) / 5.0e12 * 1e6
     print("%-34s %9.1f %9.1f %8.0f %8.1f | %9.1f %8.0f   x%d" % ("%d,%d,%d,%d,%d" % (C, H, K, R, st), t_c, 2 * macs / t_c / 1e6,
                                                                  out_b / t_c / 1e3, floor, t_q, (x.numel() * 4 + xq.numel()) / t_q / 1e3, cnt))

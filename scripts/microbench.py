@@ -169,6 +169,38 @@ def bench_after_compute(batch):
             print("%-12s %-30s med %.3f ms (%.0f GB/s)" % (name, label, ts[len(ts) // 2], nel * 4 / ts[len(ts) // 2] / 1e6))
 
 
+def bench_real_activations(batch):
+    """The statistics kernels on the cared activations of one real forward of the bench's ResNet-50 (their value
+    distribution, their allocation pattern), timed in bursts like the synthetic segments."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tools import Quantity
+    out = sys.stdout; sys.stdout = open(os.devnull, "w")
+    model = bench.build_model("r50", 224, torch.device("cuda"))
+    bench.make_workdir(1, "1,3,224,224", 0)
+    q = Quantity(model)
+    feats, hooks = q.regist_hook_outfeature(model)
+    with torch.no_grad():
+        model(torch.randn(batch, 3, 224, 224, device="cuda"))
+    sys.stdout = out
+    names = ["image"] + list(q.net_info.keys())
+    segs = [nat.dense_view(feats[n]).reshape(-1) for n in names]
+    rows = list(range(len(segs)))
+    nel = sum(t.numel() for t in segs)
+    mx = torch.zeros(len(segs), device="cuda")
+    ms, best = timeit(lambda: nat.absmax_seg(segs, rows, mx))
+    print("[real] absmax_seg  : %d segs %.1f Melem  med %.3f ms  (%.0f GB/s, best %.0f)" % (len(segs), nel / 1e6, ms, nel * 4 / ms / 1e6, nel * 4 / best / 1e6))
+    iv = (mx / 2048 + 1e-12).float()
+    hist = torch.zeros(len(segs), 2048, dtype=torch.int64, device="cuda")
+    ms, best = timeit(lambda: nat.hist2048_seg(segs, rows, iv, hist))
+    print("[real] hist2048_seg: med %.3f ms  (%.0f GB/s, best %.0f)" % (ms, nel * 4 / ms / 1e6, nel * 4 / best / 1e6))
+    h = hist.cpu().numpy().astype(float)
+    occ = [(r > 0).sum() for r in h]
+    top = [r.max() / max(r.sum(), 1) for r in h]
+    print("[real] non-empty bins per row: min %d median %d; share of the fullest bin: median %.3f max %.3f" %
+          (min(occ), sorted(occ)[len(occ) // 2], sorted(top)[len(top) // 2], max(top)))
+
+
 def bench_single_segment():
     """One 8 GiB segment: the statistics kernels without the multi-segment tiling."""
     x = torch.randn(1 << 31, device="cuda")
@@ -185,7 +217,9 @@ def bench_single_segment():
 
 
 if __name__ == "__main__":
-    if "--heat" in sys.argv:
+    if "--real" in sys.argv:
+        bench_real_activations(int(sys.argv[1]))
+    elif "--heat" in sys.argv:
         bench_after_compute(int(sys.argv[1]))
     elif "--rotate" in sys.argv:
         bench_rotating(int(sys.argv[1]), int(sys.argv[sys.argv.index("--rotate") + 1]))
