@@ -260,8 +260,19 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
 // ResNet): a K-step is exactly two taps of 64 bytes, again with uniform tap arithmetic; a missing second tap
 // (R*S odd) is an out-of-range activation offset, i.e. zeros.
 constexpr int kPathGeneral = 0, kPathC128 = 1, kPathC64 = 2;
+// Register budget of the register-staged kernel, as waves per SIMD the compiler must make room for.  Left alone,
+// hipcc keeps the accumulators in AGPRs next to 85-164 VGPRs: 2 waves per SIMD for the fused-add epilogue (the
+// residual stream of the 1x1 expand layers then ran at 4.6-5.1 TB/s).  3 waves fit without spilling (resident
+// ResNet-50 forward at batch 128: 1.96 -> 1.83 ms); asking for 4 on the 128-row tiles spills 6-19 dwords and
+// costs more than it gains, the 64-row tiles fit 4.
+#ifndef FQ_WAVES_TK64
+#define FQ_WAVES_TK64 4
+#endif
+#ifndef FQ_WAVES_TK128
+#define FQ_WAVES_TK128 3
+#endif
 template <int TK, int kPath, int kOut>
-__global__ __launch_bounds__(kConvBlock) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+__global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK == 64 ? FQ_WAVES_TK64 : FQ_WAVES_TK128))) void conv2d_i8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                const float* __restrict__ qbias, float* __restrict__ y,
                                                                int8_t* __restrict__ q, const ConvParams p) {
     constexpr int BKB = 128;              // bytes of the reduction axis per K-step (8 chunks, 4 MFMA sub-steps)

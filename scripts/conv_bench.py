@@ -61,7 +61,7 @@ for (C, H, K, R, st, pd, cnt) in LAYERS:
     in_b = xq.numel() * xq.element_size()
     floor = (out_b + in_b) / 5.0e12 * 1e6
     print("%-34s %9.1f %9.1f %8.0f %8.1f | %9.1f %8.0f   x%d" % ("%d,%d,%d,%d,%d" % (C, H, K, R, st), t_c, 2 * macs / t_c / 1e6,
-                                                                 out_b / t_c / 1e3, floor, t_q, (x.numel() * 4 + xq.numel()) / t_q / 1e3, cnt))
+                                                                 out_b / t_c / 1e3, floor, t_q, (x.numel() * 4 + xq.numel()) / max(t_q, 1e-9) / 1e3, cnt))
     tot_c += t_c * cnt
     tot_q += t_q * cnt
 print("whole net per batch of %d: conv %.2f ms, quantize %.2f ms" % (B, tot_c / 1e3, tot_q / 1e3))
