@@ -70,7 +70,11 @@ __global__ __launch_bounds__(kStemBlock) void stem_conv_i8_kernel(const StemPara
     }
     const long plane = (long)p.H * p.W;
 
+    // Fetch = loads only.  Nothing here may USE a loaded value (a select on it would make the compiler wait for each
+    // load where it is issued) and nothing is conditional (hipcc waits vmcnt(0) at control-flow joins): a pixel outside
+    // the image or a channel >= C reads element 0 of an existing plane, and `okbits` says at quantise time what to keep.
     float raw[kStemPix][4];
+    unsigned okbits = 0;
     auto fetch = [&](unsigned tile) {
         const int tx = (int)(tile % (unsigned)p.tiles_x);
         const unsigned t2 = tile / (unsigned)p.tiles_x;
@@ -78,13 +82,15 @@ __global__ __launch_bounds__(kStemBlock) void stem_conv_i8_kernel(const StemPara
         const long n = (long)(t2 / (unsigned)p.tiles_y);
         const int ih0 = ty * kStemTH * p.sh - p.ph, iw0 = tx * kStemTW * p.sw - p.pw;
         const float* __restrict__ img = p.x + n * p.C * plane;
+        okbits = 0;
 #pragma unroll
         for (int j = 0; j < kStemPix; ++j) {
             const int ih = ih0 + prow[j], iw = iw0 + pcol[j];
             const bool ok = prow[j] >= 0 && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            okbits |= ok ? 1u << j : 0u;
             const long off = ok ? (long)ih * p.W + iw : 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) raw[j][c] = (ok && c < p.C) ? img[c * plane + off] : 0.0f;
+            for (int c = 0; c < 4; ++c) raw[j][c] = img[(c < p.C ? c : 0) * plane + off];
         }
     };
 
@@ -100,14 +106,15 @@ __global__ __launch_bounds__(kStemBlock) void stem_conv_i8_kernel(const StemPara
         // a. quantise the fetched patch into LDS
 #pragma unroll
         for (int j = 0; j < kStemPix; ++j) {
-            if (prow[j] >= 0)
-                sPatch[prow[j] * p.PCS + pcol[j]] = q8(raw[j][0], p.scale) | (q8(raw[j][1], p.scale) << 8) |
-                                                    (q8(raw[j][2], p.scale) << 16) | (q8(raw[j][3], p.scale) << 24);
+            unsigned word = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) word |= c < p.C ? q8(raw[j][c], p.scale) << (8 * c) : 0u;
+            if (prow[j] >= 0) sPatch[prow[j] * p.PCS + pcol[j]] = (okbits >> j) & 1u ? word : 0u;
         }
         __syncthreads();
-        // b. the next tile's loads fly under the matrix work
+        // b. the next tile's loads fly under the matrix work (the last tile fetches itself again: no branch)
         const unsigned next = tile + gridDim.x;
-        if (next < p.ntiles) fetch(next);
+        fetch(next < p.ntiles ? next : tile);
 
         // c. contraction: one MFMA per filter row and 32-channel block
         v16i acc[2];
