@@ -151,17 +151,27 @@ def bench_after_compute(batch):
     rows = list(range(len(segs)))
     nel = sum(t.numel() for t in segs)
     mx = torch.zeros(len(rows), device="cuda")
-    iv = torch.full((len(rows),), 6.0 / 2048, device="cuda")
+    nat.absmax_seg(segs, rows, mx)
+    iv = (mx / 2048 + 1e-12).float()
     hist = torch.zeros(len(rows), 2048, dtype=torch.int64, device="cuda")
     a_mat = torch.randn(8192, 8192, device="cuda")
-    for label, heat in (("idle GPU", 0), ("behind 4 fp32 8192^3 matmuls", 4), ("behind 16", 16)):
+    def rewrite():
+        for t in segs:
+            t.mul_(1.0)                                 # rewrites every element: the data is "fresh" like after a forward
+    for label, heat in (("idle GPU", 0), ("behind 4 fp32 8192^3 matmuls", 4), ("behind 16", 16), ("behind a rewrite of the data", -1),
+                        ("rewrite, then reversed segment order", -2)):
         for name, fn in (("absmax_seg", lambda: nat.absmax_seg(segs, rows, mx)), ("hist2048_seg", lambda: nat.hist2048_seg(segs, rows, iv, hist))):
             ts = []
             for _ in range(6):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda._sleep(2_000_000)
-                for _ in range(heat):
+                for _ in range(max(heat, 0)):
                     torch.mm(a_mat, a_mat)
+                if heat < 0:
+                    rewrite()
+                if heat == -2:
+                    rsegs, rrows = segs[::-1], rows[::-1]
+                    fn = (lambda: nat.absmax_seg(rsegs, rrows, mx)) if name == "absmax_seg" else (lambda: nat.hist2048_seg(rsegs, rrows, iv, hist))
                 a.record(); fn(); b.record()
                 torch.cuda.synchronize()
                 ts.append(a.elapsed_time(b))
