@@ -282,11 +282,15 @@ class Quantity(object):
         reserved, live = torch.cuda.memory_reserved(), torch.cuda.memory_allocated()
         pooled = reserved - live                   # held by the caching allocator, reusable by us
         foreign = (total - free) - reserved        # other processes / the driver
-        # measured on MI355X / ROCm 7.2: the first allocation that takes a process past ~128 GB costs
-        # ~4 s once (and ~3 ms per hipMalloc afterwards), more than the forwards it would save on
-        # a few thousand images -- so by default this process stays below 96 GB in total, which with
-        # the forward's own transient tensors (~14 GB for ResNet-50 at batch 128) is clear of that cliff.
-        return max(0, min(int((free + pooled) * 0.6), (96 << 30) - foreign - live))
+        # Growing the caching allocator is what a cache costs a COLD process: 10-30 ms per GB of fresh hipMalloc on
+        # MI355X / ROCm 7.2 (scripts/alloc_probe.py; one run also showed a one-off ~4 s stall past ~128 GB), more
+        # than the forwards it saves on a few thousand images -- so a cold process stays below 96 GB in total.
+        cold = max(0, min(int((free + pooled) * 0.6), (96 << 30) - foreign - live))
+        # Memory the allocator already holds (a long-running calibration service, or bench.py after its warm-up) costs
+        # nothing to use: all of it except 1/16 of the device, which stays with the forward's own transient tensors (the part of
+        # HBM the pool does not cover absorbs anything beyond that).
+        warm = pooled - (total >> 4)
+        return max(cold, warm, 0)
 
     def _stat_stream(self):
         """Side HIP stream for the abs-max / histogram launches, or None (CPU, or overlap disabled).
