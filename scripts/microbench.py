@@ -211,6 +211,47 @@ def bench_real_activations(batch):
           (min(occ), sorted(occ)[len(occ) // 2], sorted(top)[len(top) // 2], max(top)))
 
 
+def bench_per_tensor_launches(batch):
+    """Would launching the statistics kernel per tensor, right behind the kernel that wrote it (while it is still in the
+    Infinity Cache), beat one launch over all tensors after the whole forward?  Producer = an in-place rewrite."""
+    segs = r50_like_segments(batch, "normal")
+    rows = list(range(len(segs)))
+    mx = torch.zeros(len(rows), device="cuda")
+    nat.absmax_seg(segs, rows, mx)
+    iv = (mx / 2048 + 1e-12).float()
+    hist = torch.zeros(len(rows), 2048, dtype=torch.int64, device="cuda")
+
+    def produce_only():
+        for t in segs:
+            t.mul_(1.0)
+
+    def one_launch(fn):
+        produce_only()
+        fn(segs, rows)
+
+    def per_tensor(fn):
+        for i, t in enumerate(segs):
+            t.mul_(1.0)
+            fn([t], [i])
+
+    def per_group(fn, limit=96 << 20):
+        acc, ids, size = [], [], 0
+        for i, t in enumerate(segs):
+            t.mul_(1.0)
+            acc.append(t); ids.append(i); size += t.numel() * 4
+            if size >= limit:
+                fn(acc, ids); acc, ids, size = [], [], 0
+        if acc:
+            fn(acc, ids)
+    base, _ = timeit(produce_only, iters=10, burst=2)
+    for name, fn in (("absmax", lambda s, r: nat.absmax_seg(s, r, mx)), ("hist", lambda s, r: nat.hist2048_seg(s, r, iv, hist))):
+        a, _ = timeit(lambda: one_launch(fn), iters=10, burst=2)
+        b, _ = timeit(lambda: per_tensor(fn), iters=10, burst=2)
+        c, _ = timeit(lambda: per_group(fn), iters=10, burst=2)
+        print("%-6s producer alone %.3f ms | + one launch after all %.3f | + one launch per tensor %.3f | + one launch per ~96 MB %.3f  (ms added)" %
+              (name, base, a - base, b - base, c - base))
+
+
 def bench_single_segment():
     """One 8 GiB segment: the statistics kernels without the multi-segment tiling."""
     x = torch.randn(1 << 31, device="cuda")
@@ -227,7 +268,9 @@ def bench_single_segment():
 
 
 if __name__ == "__main__":
-    if "--real" in sys.argv:
+    if "--per-tensor" in sys.argv:
+        bench_per_tensor_launches(int(sys.argv[1]))
+    elif "--real" in sys.argv:
         bench_real_activations(int(sys.argv[1]))
     elif "--heat" in sys.argv:
         bench_after_compute(int(sys.argv[1]))

@@ -20,3 +20,7 @@ print(resident.enable(net, data[0][0]))
 for name, plan in resident.describe(net).items():
     if plan.emit_f32 or name in ("conv1", "maxpool", "layer4.2.Eltwise"):
         print(name, plan)
+print("residual adds: name, grid g (exact sum = S * 2^-g), narrow bit, fused ReLU")
+for name, plan in resident.describe(net).items():
+    if plan.resident_add:
+        print("  %-22s g=%s narrow_bit=%s relu=%s want_wide=%s" % (name, plan.grid, plan.narrow_bit, plan.relu, plan.want_wide))
