@@ -104,8 +104,8 @@ class DistributionCollector(object):
     def refresh_max_val(self, tensors):
         """Fold one batch into the running abs-max of every tensor in tensor_list."""
         self._max_vals_refreshed_flag = True
-        segs = [_as_device_f32(tensors[n], self._device) for n in self._tensor_list]
-        rows = list(range(len(segs)))
+        rows = self._rows_of(tensors)
+        segs = [_as_device_f32(tensors[self._tensor_list[r]], self._device) for r in rows]
         self._keepalive = _native.absmax_seg(segs, rows, self._max_dev)
 
     def add_to_distributions(self, tensors):
@@ -116,11 +116,20 @@ class DistributionCollector(object):
         if not hasattr(self, "_distribution_intervals"):
             print("interval:", self.distribution_intervals)
         self._sync_intervals()
-        segs = [_as_device_f32(tensors[n], self._device) for n in self._tensor_list]
-        rows = list(range(len(segs)))
+        rows = self._rows_of(tensors)
+        segs = [_as_device_f32(tensors[self._tensor_list[r]], self._device) for r in rows]
         self._keepalive = _native.hist2048_seg(segs, rows, self._interval_dev, self._hist_dev)
 
     # ------------------------------------------------------------------ beyond the reference API
+    supports_partial = True     # refresh_max_val / add_to_distributions accept a dict holding only SOME of the tensors
+
+    def _rows_of(self, tensors):
+        """Rows of the tensors present in `tensors` (the reference passes all of them; the calibration loop also feeds
+        them in groups, from inside the forward hooks, while they are still in the Infinity Cache)."""
+        if len(tensors) == len(self._tensor_list):
+            return list(range(len(self._tensor_list)))
+        return [r for r, n in enumerate(self._tensor_list) if n in tensors]
+
     def all_reduce_max(self):
         """Data-parallel calibration: combine the per-rank maxima (one MAX all-reduce of fp32[T],
         RCCL over xGMI when the process group is 'nccl')."""

@@ -65,6 +65,47 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
+class _EagerStats(object):
+    """Statistics launches from INSIDE the forward hooks.
+
+    The reference copies every hooked output to the host inside the hook (pytorch_quantizer.py:513), i.e. it sees the
+    value the module returned -- also when a later in-place op (nn.ReLU(inplace=True)) overwrites that tensor.  Taking
+    the statistics after the whole forward would see the overwritten values, so hooked tensors are handed to `fn`
+    (collector.refresh_max_val / add_to_distributions on a partial dict) from the hook itself:
+      limit = 0      one launch per tensor, before any later module can touch it (always correct);
+      limit = L > 0  tensors are grouped until L bytes are pending -- fewer, larger launches that still find their
+                     input in the 256 MB Infinity Cache instead of competing with its write-back.
+                     Only valid for models without in-place consumers, which the first forward establishes
+                     (`modified` below); every flush re-checks the version counters and refuses silently wrong data."""
+
+    def __init__(self, fn, limit):
+        self.fn, self.limit = fn, int(limit)
+        self.pending, self.bytes = OrderedDict(), 0
+        self.seen = []                     # (tensor, version at capture) of the whole forward
+
+    def add(self, key, t):
+        self.pending[key] = t
+        self.seen.append((t, t._version))
+        self.bytes += t.numel() * t.element_size()
+        if self.bytes >= self.limit:
+            self.flush()
+
+    def flush(self):
+        if not self.pending:
+            return
+        if self.limit > 0:
+            for (t, v) in self.seen[-len(self.pending):]:
+                if t._version != v:
+                    raise RuntimeError("a hooked activation was modified in place before its statistics were taken; "
+                                       "set Quantity.stats_group_bytes = 0")
+        self.fn(self.pending)
+        self.pending, self.bytes = OrderedDict(), 0
+
+    def modified(self):
+        """True if any tensor captured during this forward has been written to since (an in-place consumer)."""
+        return any(t._version != v for (t, v) in self.seen)
+
+
 class Quantity(object):
 
     # the statistics engine; tests substitute oracle-backed doubles to exercise the host logic on CPU
@@ -75,6 +116,10 @@ class Quantity(object):
     # 128) +0.8 % images/s, while the histogram kernel drops from 5.2 to 3.5 TB/s under contention and
     # deferred frees push the footprint from 106 to 150 GB -- not worth it, off by default.
     overlap_streams = False
+    # statistics launches from inside the forward hooks (_EagerStats): bytes of hooked activations gathered per launch.
+    # None = decide from the first forward: ~96 MB groups when no hooked tensor is modified in place afterwards, else one
+    # launch per tensor and no activation cache.  Engines without `supports_partial` take the statistics after the forward.
+    stats_group_bytes = None
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -292,6 +337,23 @@ class Quantity(object):
         warm = pooled - (total >> 4)
         return max(cold, warm, 0)
 
+    def _forward_with_stats(self, item, fn, named_feats):
+        """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced.
+        Returns the _EagerStats of that forward, or None when the statistics were taken after it."""
+        limit = self._stats_limit
+        if limit is None:
+            self.net_forward(self.model, item)
+            self._on_stat_stream(fn, named_feats)
+            return None
+        eager = _EagerStats(fn, limit)
+        self._hook_ctl["eager"] = eager
+        try:
+            self.net_forward(self.model, item)
+        finally:
+            self._hook_ctl["eager"] = None
+        eager.flush()
+        return eager
+
     def _stat_stream(self):
         """Side HIP stream for the abs-max / histogram launches, or None (CPU, or overlap disabled).
         The statistics kernels stream 4 B/element from HBM and use almost no ALU; the next batch's
@@ -430,6 +492,10 @@ class Quantity(object):
 
         # pass 1: running abs-max of every cared tensor; keep activations for pass 2 while HBM allows
         budget = self._activation_cache_budget()
+        eager_ok = (self.device == "gpu" and torch.cuda.is_available() and not self.overlap_streams
+                    and getattr(collector, "supports_partial", False))
+        # first forward: one launch per tensor (always correct); it also tells whether grouping and caching are safe
+        self._stats_limit = None if not eager_ok else 0
         n_owned = None
         if hasattr(images_files, "__len__") and hasattr(images_files, "__getitem__"):
             n_owned = len(range(rank, min(len(images_files), self._max_img_num + 1), world))
@@ -437,14 +503,20 @@ class Quantity(object):
         plan = None
         cached, cached_ids, used = {}, set(), 0
         step_ms = []
+        inplace = None                          # does a later module overwrite a hooked tensor?  (known after one forward)
         for i, item in self._device_items(images_files):
             ts = time.perf_counter()
             if budget and plan is None and self.device == "gpu" and torch.cuda.is_available():
                 start = torch.cuda.Event(enable_timing=True)
                 start.record()
                 ctl["events"] = []
-            self.net_forward(self.model, item)
-            self._on_stat_stream(collector.refresh_max_val, named_feats)
+            eager = self._forward_with_stats(item, collector.refresh_max_val, named_feats)
+            if eager is not None and inplace is None:
+                inplace = bool(eager.modified())
+                if inplace:
+                    budget = 0                  # kept tensors would hold overwritten values: no cache, per-tensor launches
+                else:
+                    self._stats_limit = (96 << 20) if self.stats_group_bytes is None else int(self.stats_group_bytes)
             if os.environ.get("FQ_DEBUG_STEP_TIMES"):
                 self._sync()
                 step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
@@ -492,8 +564,9 @@ class Quantity(object):
             try:
                 for i, item in self._device_items(images_files):
                     if plan["stop_after"]:
-                        self.net_forward(self.model, item)              # ends at the last tensor that was not kept
-                        feats = dict(named_feats)
+                        # ends at the last tensor that was not kept
+                        done = self._forward_with_stats(item, collector.add_to_distributions, named_feats)
+                        feats = {} if done is not None else dict(named_feats)
                     else:
                         feats = {"image": self.preprocess(item) if not torch.is_tensor(item) else item}
                         if self.device == "gpu" and feats["image"].device.type != "cuda":
@@ -506,8 +579,7 @@ class Quantity(object):
             for i in sorted(cached):
                 self._on_stat_stream(collector.add_to_distributions, cached[i])
             for i, item in self._device_items(self._skip(images_files, cached_ids)):
-                self.net_forward(self.model, item)
-                self._on_stat_stream(collector.add_to_distributions, named_feats)
+                self._forward_with_stats(item, collector.add_to_distributions, named_feats)
         self._join_stat_stream()
         del cached
         if _dist_on():
@@ -554,7 +626,8 @@ class Quantity(object):
                 for line in lines:
                     fh.write(line + "\n")
         self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0,
-                        "cached_batches": len(cached_ids), "cache_bytes": used,
+                        "cached_batches": len(cached_ids), "cache_bytes": used, "inplace_consumers": inplace,
+                        "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}
         if step_ms:
@@ -610,16 +683,21 @@ class Quantity(object):
         cared = set(self.net_info.keys())
         state = {"n": 0}
         total = int(self.layers_num)
-        ctl = self._hook_ctl = {"stop_after": None, "events": None}
+        ctl = self._hook_ctl = {"stop_after": None, "events": None, "eager": None}
 
         def on_forward(module, inputs, output):
+            eager = ctl["eager"]
             if state["n"] == 0:
                 out_feat.clear()
                 out_feat["image"] = inputs[0].detach()
+                if eager is not None:
+                    eager.add("image", out_feat["image"])
             state["n"] += 1
             key = "%s_%i" % (type(module).__name__, state["n"])
             if key in cared:
                 out_feat[key] = output.detach()
+                if eager is not None:
+                    eager.add(key, out_feat[key])
                 if ctl["events"] is not None:                 # time stamps of one forward, for the cache plan
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record()

@@ -197,3 +197,64 @@ def test_activation_cache_plans_do_not_change_the_tables(g3, monkeypatch, cache_
         assert info["cache_bytes"] == 0
     elif plan:
         assert info["cache_plan"]["kind"] == plan and info["cache_bytes"] > 0
+
+
+@pytest.mark.parametrize("group_bytes", [None, 0, 1 << 16, 1 << 40])
+def test_statistics_launch_grouping_does_not_change_the_tables(g3, group_bytes):
+    """The hooks hand the activations to the statistics kernels per tensor, in groups, or all at once: same tables."""
+    from tools import Quantity
+    with product_workdir(device="gpu", max_cali_img_num=1) as tmp:
+        q = Quantity(_r18_gpu())
+        q.stats_group_bytes = group_bytes
+        q.activation_quantize(cases.calib_batches(3, (4, 3, 32, 32)))
+        table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
+        info = q.timings
+    assert table == g3["feat_table"]
+    assert info["inplace_consumers"] is False
+    assert info["stats_group_bytes"] == (96 << 20 if group_bytes is None else group_bytes)
+
+
+class _InplaceNet(torch.nn.Module):
+    """conv -> ReLU -> conv -> ReLU -> Eltwise; with inplace=True every hooked conv output is overwritten by its ReLU."""
+
+    def __init__(self, inplace):
+        super(_InplaceNet, self).__init__()
+        from common.quantity import Eltwise
+        torch.manual_seed(5)
+        self.c1 = torch.nn.Conv2d(3, 8, 3, padding=1)
+        self.r1 = torch.nn.ReLU(inplace)
+        self.c2 = torch.nn.Conv2d(8, 8, 3, padding=1)
+        self.r2 = torch.nn.ReLU(inplace)
+        self.c3 = torch.nn.Conv2d(8, 8, 1)
+        self.add = Eltwise()
+
+    def forward(self, x):
+        a = self.r1(self.c1(x))
+        b = self.r2(self.c2(a))
+        return self.add(self.c3(b), a)
+
+
+@pytest.mark.parametrize("cache_gb", ["0", "1"])
+def test_inplace_relu_model_is_calibrated_on_the_values_the_hooks_saw(monkeypatch, cache_gb):
+    """The reference copies a hooked output inside the hook, before an in-place ReLU overwrites it.  The device path
+    must see the same values: per-tensor launches from the hooks, no activation cache -- and therefore the same
+    table as the same network with out-of-place ReLUs."""
+    from tools import Quantity
+    monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
+    tables, infos = [], []
+    for inplace in (False, True):
+        with product_workdir(device="gpu", max_cali_img_num=2, input_shape="1,3,16,16") as tmp:
+            q = Quantity(_InplaceNet(inplace).eval().cuda())
+            q.activation_quantize(cases.calib_batches(3, (4, 3, 16, 16)))
+            tables.append(open(os.path.join(tmp, "test", "workdir", "feat.table")).read())
+            infos.append(q.timings)
+    assert tables[0] == tables[1]
+    assert infos[0]["inplace_consumers"] is False and infos[1]["inplace_consumers"] is True
+    assert infos[1]["cache_bytes"] == 0 and infos[1]["stats_group_bytes"] == 0
+    # grouping requested on a model with in-place consumers is overruled by what the first forward shows
+    with product_workdir(device="gpu", max_cali_img_num=2, input_shape="1,3,16,16") as tmp:
+        q = Quantity(_InplaceNet(True).eval().cuda())
+        q.stats_group_bytes = 1 << 30
+        q.activation_quantize(cases.calib_batches(3, (4, 3, 16, 16)))
+        assert open(os.path.join(tmp, "test", "workdir", "feat.table")).read() == tables[0]
+        assert q.timings["stats_group_bytes"] == 0

@@ -35,12 +35,23 @@ def test_bottleneck_tables_hip_equals_cpu_oracle(oracle, arch, rows, batch):
     tape = {"max": [], "hist": []}
 
     class RecordingCollector(DistributionCollector):
+        """Records what the engine was fed.  The calibration loop hands the tensors of one forward over in several
+        partial dicts (from inside the hooks); the tape holds one merged dict per forward."""
+
+        def _record(self, kind, tensors):
+            cur = self.__dict__.setdefault("_open_" + kind, {})
+            assert not set(cur) & set(tensors), "a tensor was handed over twice in one forward"
+            cur.update({k: v.detach().cpu().numpy().copy() for k, v in tensors.items()})
+            if len(cur) == len(self._tensor_list):
+                tape[kind].append(dict(cur))
+                cur.clear()
+
         def refresh_max_val(self, tensors):
-            tape["max"].append({k: v.detach().cpu().numpy().copy() for k, v in tensors.items()})
+            self._record("max", tensors)
             super().refresh_max_val(tensors)
 
         def add_to_distributions(self, tensors):
-            tape["hist"].append({k: v.detach().cpu().numpy().copy() for k, v in tensors.items()})
+            self._record("hist", tensors)
             super().add_to_distributions(tensors)
 
     class ReplayCollector(OracleCollector):
