@@ -65,6 +65,9 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
+_AFTER_FORWARD = 1 << 62      # _EagerStats limit that is never reached: one flush, after the forward
+
+
 class _EagerStats(object):
     """Statistics launches from INSIDE the forward hooks.
 
@@ -73,37 +76,40 @@ class _EagerStats(object):
     the statistics after the whole forward would see the overwritten values, so hooked tensors are handed to `fn`
     (collector.refresh_max_val / add_to_distributions on a partial dict) from the hook itself:
       limit = 0      one launch per tensor, before any later module can touch it (always correct);
-      limit = L > 0  tensors are grouped until L bytes are pending -- fewer, larger launches that still find their
-                     input in the 256 MB Infinity Cache instead of competing with its write-back.
+      limit = L > 0  tensors are gathered until L bytes are pending (_AFTER_FORWARD: all of them, one launch per
+                     forward -- the fast path: one balanced launch streams at 6+ TB/s, 36 us launches do not).
                      Only valid for models without in-place consumers, which the first forward establishes
                      (`modified` below); every flush re-checks the version counters and refuses silently wrong data."""
 
     def __init__(self, fn, limit):
         self.fn, self.limit = fn, int(limit)
         self.pending, self.bytes = OrderedDict(), 0
-        self.seen = []                     # (tensor, version at capture) of the whole forward
+        self.seen = []                     # (key, tensor, version at capture) of the whole forward
 
     def add(self, key, t):
         self.pending[key] = t
-        self.seen.append((t, t._version))
+        self.seen.append((key, t, t._version))
         self.bytes += t.numel() * t.element_size()
         if self.bytes >= self.limit:
             self.flush()
 
-    def flush(self):
-        if not self.pending:
-            return
+    def flush(self, extra=None):
+        """Hand the pending tensors (plus `extra`: tensors kept from an earlier forward) to fn in one call."""
         if self.limit > 0:
-            for (t, v) in self.seen[-len(self.pending):]:
-                if t._version != v:
+            for (k, t, v) in self.seen:
+                if k in self.pending and t._version != v:
                     raise RuntimeError("a hooked activation was modified in place before its statistics were taken; "
                                        "set Quantity.stats_group_bytes = 0")
+        if extra:
+            self.pending.update(extra)
+        if not self.pending:
+            return
         self.fn(self.pending)
         self.pending, self.bytes = OrderedDict(), 0
 
     def modified(self):
         """True if any tensor captured during this forward has been written to since (an in-place consumer)."""
-        return any(t._version != v for (t, v) in self.seen)
+        return any(t._version != v for (_k, t, v) in self.seen)
 
 
 class Quantity(object):
@@ -116,9 +122,11 @@ class Quantity(object):
     # 128) +0.8 % images/s, while the histogram kernel drops from 5.2 to 3.5 TB/s under contention and
     # deferred frees push the footprint from 106 to 150 GB -- not worth it, off by default.
     overlap_streams = False
-    # statistics launches from inside the forward hooks (_EagerStats): bytes of hooked activations gathered per launch.
-    # None = decide from the first forward: ~96 MB groups when no hooked tensor is modified in place afterwards, else one
-    # launch per tensor and no activation cache.  Engines without `supports_partial` take the statistics after the forward.
+    # Hooked activations are handed to the statistics kernels through _EagerStats: bytes gathered per launch.
+    # None = decide from the first forward (which always runs one launch per tensor): everything in ONE launch after the
+    # forward when no hooked tensor is modified in place afterwards, else one launch per tensor, from the hook, and no
+    # activation cache.  Smaller groups (e.g. 96 << 20) were measured on ResNet-50: no gain.
+    # Engines without `supports_partial` (the CPU test doubles) take the statistics after the forward.
     stats_group_bytes = None
 
     def __init__(self, model):
@@ -337,13 +345,16 @@ class Quantity(object):
         warm = pooled - (total >> 4)
         return max(cold, warm, 0)
 
-    def _forward_with_stats(self, item, fn, named_feats):
-        """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced.
-        Returns the _EagerStats of that forward, or None when the statistics were taken after it."""
+    def _forward_with_stats(self, item, fn, named_feats, extra=None):
+        """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced and
+        to `extra` (tensors of the same batch kept from pass 1).  Returns the _EagerStats of that forward, or None
+        when the engine takes its statistics after the forward."""
         limit = self._stats_limit
         if limit is None:
             self.net_forward(self.model, item)
-            self._on_stat_stream(fn, named_feats)
+            feats = dict(named_feats)
+            feats.update(extra or {})
+            self._on_stat_stream(fn, feats)
             return None
         eager = _EagerStats(fn, limit)
         self._hook_ctl["eager"] = eager
@@ -351,7 +362,7 @@ class Quantity(object):
             self.net_forward(self.model, item)
         finally:
             self._hook_ctl["eager"] = None
-        eager.flush()
+        eager.flush(extra)
         return eager
 
     def _stat_stream(self):
@@ -516,7 +527,7 @@ class Quantity(object):
                 if inplace:
                     budget = 0                  # kept tensors would hold overwritten values: no cache, per-tensor launches
                 else:
-                    self._stats_limit = (96 << 20) if self.stats_group_bytes is None else int(self.stats_group_bytes)
+                    self._stats_limit = _AFTER_FORWARD if self.stats_group_bytes is None else int(self.stats_group_bytes)
             if os.environ.get("FQ_DEBUG_STEP_TIMES"):
                 self._sync()
                 step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
@@ -564,13 +575,12 @@ class Quantity(object):
             try:
                 for i, item in self._device_items(images_files):
                     if plan["stop_after"]:
-                        # ends at the last tensor that was not kept
-                        done = self._forward_with_stats(item, collector.add_to_distributions, named_feats)
-                        feats = {} if done is not None else dict(named_feats)
-                    else:
-                        feats = {"image": self.preprocess(item) if not torch.is_tensor(item) else item}
-                        if self.device == "gpu" and feats["image"].device.type != "cuda":
-                            feats["image"] = feats["image"].cuda()
+                        # ends at the last tensor that was not kept; fresh and kept tensors go out in one launch
+                        self._forward_with_stats(item, collector.add_to_distributions, named_feats, extra=cached.pop(i))
+                        continue
+                    feats = {"image": self.preprocess(item) if not torch.is_tensor(item) else item}
+                    if self.device == "gpu" and feats["image"].device.type != "cuda":
+                        feats["image"] = feats["image"].cuda()
                     feats.update(cached.pop(i))
                     self._on_stat_stream(collector.add_to_distributions, feats)
             finally:

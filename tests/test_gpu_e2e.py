@@ -211,7 +211,7 @@ def test_statistics_launch_grouping_does_not_change_the_tables(g3, group_bytes):
         info = q.timings
     assert table == g3["feat_table"]
     assert info["inplace_consumers"] is False
-    assert info["stats_group_bytes"] == (96 << 20 if group_bytes is None else group_bytes)
+    assert info["stats_group_bytes"] == (1 << 62 if group_bytes is None else group_bytes)
 
 
 class _InplaceNet(torch.nn.Module):
