@@ -48,6 +48,8 @@ class ChannelCollector(object):
     def _dense(self, tensors):
         ts, row0s = [], []
         for n in self._names:
+            if n not in tensors:             # a partial dict: the calibration loop may hand tensors over one by one
+                continue
             t = tensors[n]
             assert t.shape[1] == self._channels[n], (n, tuple(t.shape), self._channels[n])
             ts.append(t.detach())

@@ -654,16 +654,27 @@ class Quantity(object):
         names = ["image"] + list(self.net_info.keys())
         named_feats, hooks = self.regist_hook_outfeature(self.model)
         collector = None
+        ctl = self._hook_ctl
         for _pass in (1, 2):
             for i, item in self._device_items(images_files):
-                self.net_forward(self.model, item)
                 if collector is None:
+                    # the first forward tells the channel counts and whether later modules overwrite hooked tensors
+                    probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
+                    ctl["eager"] = probe
+                    try:
+                        self.net_forward(self.model, item)
+                    finally:
+                        ctl["eager"] = None
                     collector = ChannelCollector({n: int(named_feats[n].shape[1]) for n in names},
                                                  statistic=self.config["SETTINGS"]["STATISTIC"])
-                if _pass == 1:
-                    collector.refresh_max_val(named_feats)
-                else:
-                    collector.add_to_distributions(named_feats)
+                    self._stats_limit = 0 if probe.modified() else _AFTER_FORWARD
+                    if self._stats_limit:
+                        collector.refresh_max_val(named_feats)
+                        continue
+                    # in-place consumers: these tensors are already overwritten -- run the batch again, one launch per
+                    # tensor from inside the hooks (the values the reference's hooks would copy)
+                self._forward_with_stats(item, collector.refresh_max_val if _pass == 1 else collector.add_to_distributions,
+                                         named_feats)
             if _dist_on():
                 collector.all_reduce_max() if _pass == 1 else collector.all_reduce_hist()
             if _pass == 1:

@@ -98,3 +98,18 @@ def test_per_channel_calibration_of_a_model():
         # a channel never needs fewer fractional bits than its whole tensor's range allows
         for (module, b), n in zip(by_module.items(), names):
             assert min(b) >= per_tensor_bits[n] - 1, (module, b, per_tensor_bits[n])
+
+
+def test_per_channel_calibration_sees_hook_time_values_of_inplace_models():
+    """A conv output that an in-place ReLU overwrites is calibrated on the values the hook saw: same per-channel
+    table as the same network with out-of-place ReLUs."""
+    from test_gpu_e2e import _InplaceNet
+    from tools import Quantity
+    tables = []
+    for inplace in (False, True):
+        with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=2) as tmp:
+            q = Quantity(_InplaceNet(inplace).eval().cuda())
+            q.activation_quantize_per_channel(cases.calib_batches(3, (4, 3, 16, 16)))
+            tables.append(open(os.path.join(tmp, "test", "workdir", "feat_channel.table")).read())
+            assert q._stats_limit == (0 if inplace else 1 << 62)
+    assert tables[0] == tables[1] and tables[0].count("\n") == 5
