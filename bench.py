@@ -314,7 +314,10 @@ def main():
         "config": {"workload": "fabu ResNet-%s per-tensor KL calibration, %d synthetic 3x%dx%d images per GPU "
                                "(batch %d x %d steps), %d histogram rows x 2048 bins" %
                                ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K, len(q.net_info) + 1),
-                   "batch": B, "images_total": images, "parallelism": "dp%d" % world},
+                   "batch": B, "images_total": images, "parallelism": "dp%d" % world,
+                   "activation_cache": "pass-1 activations kept in a warm allocator pool (80 % of HBM, grown during warm-up); "
+                                       "bytes used: phases_s.cache_bytes",
+                   "int8_sim_images_per_forward": args.int8_batch},
         "phases_s": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
     }
     traffic = None
