@@ -134,6 +134,17 @@ namespace fq {
 // q -> q * 2^-g, so pooling the integers gives exactly the integers of the pooled fp32 tensor.  Padding
 // behaves as -inf (torch): a window always holds at least one real element (pad <= kernel / 2).
 // One thread = 16 channels of one output pixel.
+//   * branch-free window: a tap outside the image is replaced by the nearest row / column inside it, which lies in
+//     the same window (pad <= kernel / 2) -- max is idempotent, so the result is the one with -inf padding, and the
+//     kh*kw loads are issued back to back instead of one per control-flow join;
+//   * bytes are compared two at a time as the high bytes of packed int16 lanes (v_pk_max_i16): even bytes shifted
+//     up by 8, odd bytes masked in place -- 4 vector instructions per dword and tap instead of 8.
+typedef short s2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_max_i16(unsigned a, unsigned b) {
+    const s2v x = __builtin_bit_cast(s2v, a), y = __builtin_bit_cast(s2v, b);
+    return __builtin_bit_cast(unsigned, __builtin_elementwise_max(x, y));
+}
+
 __global__ __launch_bounds__(kResBlock) void maxpool_i8_nhwc_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int H, int W,
                                                                     int C16, int P, int Q, int kh, int kw, int sh, int sw, int ph,
                                                                     int pw, size_t total) {
@@ -145,30 +156,27 @@ __global__ __launch_bounds__(kResBlock) void maxpool_i8_nhwc_kernel(const int8_t
         const int oq = (int)(r % Q); r /= Q;
         const int op = (int)(r % P);
         const size_t n = r / P;
-        int m[16];
+        unsigned even[4], odd[4];                         // running maxima: bytes 0,2 / 1,3 of each dword, as int16 high bytes
 #pragma unroll
-        for (int e = 0; e < 16; ++e) m[e] = -128;
+        for (int d = 0; d < 4; ++d) even[d] = odd[d] = 0x80008000u;       // -32768: below every int8 << 8
         const int ih0 = op * sh - ph, iw0 = oq * sw - pw;
         for (int a = 0; a < kh; ++a) {
-            const int ih = ih0 + a;
-            if ((unsigned)ih >= (unsigned)H) continue;
+            const int ih = min(max(ih0 + a, 0), H - 1);
+            const int8_t* row = x + ((n * H + ih) * W) * (size_t)C16 * 16 + (size_t)c16 * 16;
             for (int b = 0; b < kw; ++b) {
-                const int iw = iw0 + b;
-                if ((unsigned)iw >= (unsigned)W) continue;
-                Vec16<int8_t> v;
-                v.load(x + (((n * H + ih) * W + iw) * C16 + c16) * 16);
+                const int iw = min(max(iw0 + b, 0), W - 1);
+                const v4i_r v = *reinterpret_cast<const v4i_r*>(row + (size_t)iw * C16 * 16);
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int t = (int)(int8_t)(((unsigned)v.a[e >> 2]) >> (8 * (e & 3)));
-                    m[e] = t > m[e] ? t : m[e];
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned u = (unsigned)v[d];
+                    even[d] = pk_max_i16(even[d], (u << 8) & 0xff00ff00u);
+                    odd[d] = pk_max_i16(odd[d], u & 0xff00ff00u);
                 }
             }
         }
         v4i_r o;
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-            o[d] = (int)(((unsigned)m[4 * d] & 0xffu) | (((unsigned)m[4 * d + 1] & 0xffu) << 8) |
-                         (((unsigned)m[4 * d + 2] & 0xffu) << 16) | (((unsigned)m[4 * d + 3] & 0xffu) << 24));
+        for (int d = 0; d < 4; ++d) o[d] = (int)(((even[d] >> 8) & 0x00ff00ffu) | (odd[d] & 0xff00ff00u));
         *reinterpret_cast<v4i_r*>(y + i * 16) = o;
     }
 }
