@@ -42,7 +42,10 @@ struct StemParams {
     int rs, half_rs, ilo, ihi, slo, shi;
 };
 
-__global__ __launch_bounds__(kStemBlock) void stem_conv_i8_kernel(const StemParams p) {
+// kC = input channels (compile time: the quantise and fetch loops touch exactly kC planes).  The waves-per-SIMD target
+// keeps the accumulators out of the AGPRs (no v_accvgpr_read per output in the tail).
+template <int kC>
+__global__ __launch_bounds__(kStemBlock) __attribute__((amdgpu_waves_per_eu(4))) void stem_conv_i8_kernel(const StemParams p) {
     __shared__ __attribute__((aligned(16))) int8_t sW[kStemMaxR * kStemK * 32];
     __shared__ __attribute__((aligned(16))) unsigned sPatch[kStemPatchWords];
     __shared__ __attribute__((aligned(16))) int8_t sOut[4][32 * kStemOS];
@@ -73,15 +76,18 @@ __global__ __launch_bounds__(kStemBlock) void stem_conv_i8_kernel(const StemPara
     // Fetch = loads only.  Nothing here may USE a loaded value (a select on it would make the compiler wait for each
     // load where it is issued) and nothing is conditional (hipcc waits vmcnt(0) at control-flow joins): a pixel outside
     // the image or a channel >= C reads element 0 of an existing plane, and `okbits` says at quantise time what to keep.
-    float raw[kStemPix][4];
+    float raw[kStemPix][kC];
     unsigned okbits = 0;
+    int nx_tx = 0, nx_ty = 0;                      // tile coordinates of the fetched tile: reused by its store phase
+    long nx_n = 0;
     auto fetch = [&](unsigned tile) {
         const int tx = (int)(tile % (unsigned)p.tiles_x);
         const unsigned t2 = tile / (unsigned)p.tiles_x;
         const int ty = (int)(t2 % (unsigned)p.tiles_y);
         const long n = (long)(t2 / (unsigned)p.tiles_y);
+        nx_tx = tx; nx_ty = ty; nx_n = n;
         const int ih0 = ty * kStemTH * p.sh - p.ph, iw0 = tx * kStemTW * p.sw - p.pw;
-        const float* __restrict__ img = p.x + n * p.C * plane;
+        const float* __restrict__ img = p.x + n * kC * plane;
         okbits = 0;
 #pragma unroll
         for (int j = 0; j < kStemPix; ++j) {
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(kStemBlock) void stem_conv_i8_kernel(const StemPara
             okbits |= ok ? 1u << j : 0u;
             const long off = ok ? (long)ih * p.W + iw : 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) raw[j][c] = img[(c < p.C ? c : 0) * plane + off];
+            for (int c = 0; c < kC; ++c) raw[j][c] = img[c * plane + off];
         }
     };
 
@@ -103,12 +109,14 @@ __global__ __launch_bounds__(kStemBlock) void stem_conv_i8_kernel(const StemPara
     if (tile < p.ntiles) fetch(tile);
     __syncthreads();
     for (; tile < p.ntiles; tile += gridDim.x) {
+        const int tx = nx_tx, ty = nx_ty;               // of `tile` (set when it was fetched)
+        const long n = nx_n;
         // a. quantise the fetched patch into LDS
 #pragma unroll
         for (int j = 0; j < kStemPix; ++j) {
             unsigned word = 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) word |= c < p.C ? q8(raw[j][c], p.scale) << (8 * c) : 0u;
+            for (int c = 0; c < kC; ++c) word |= q8(raw[j][c], p.scale) << (8 * c);
             if (prow[j] >= 0) sPatch[prow[j] * p.PCS + pcol[j]] = (okbits >> j) & 1u ? word : 0u;
         }
         __syncthreads();
@@ -152,10 +160,6 @@ __global__ __launch_bounds__(kStemBlock) void stem_conv_i8_kernel(const StemPara
         __syncthreads();          // the tile's bytes are in LDS; every wave is done reading the patch
 
         // e. 16-byte stores: 4 lanes cover the 64 channels of one pixel
-        const int tx = (int)(tile % (unsigned)p.tiles_x);
-        const unsigned t2 = tile / (unsigned)p.tiles_x;
-        const int ty = (int)(t2 % (unsigned)p.tiles_y);
-        const long n = (long)(t2 / (unsigned)p.tiles_y);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = lane + 64 * j;
@@ -212,7 +216,14 @@ extern "C" int fq_conv2d_i8_stem(const float* x_nchw, const int8_t* w_stem, cons
     static const int per_cu = [] { const char* e = getenv("FQ_STEM_WG_PER_CU"); return e ? atoi(e) : 0; }();
     long grid = (long)kCUs * (per_cu > 0 ? per_cu : 4);
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL(stem_conv_i8_kernel, dim3((unsigned)grid), dim3(kStemBlock), 0, as_stream(stream), p);
+    const dim3 g((unsigned)grid), b(kStemBlock);
+    hipStream_t st = as_stream(stream);
+    switch (C) {
+        case 1: hipLaunchKernelGGL(stem_conv_i8_kernel<1>, g, b, 0, st, p); break;
+        case 2: hipLaunchKernelGGL(stem_conv_i8_kernel<2>, g, b, 0, st, p); break;
+        case 3: hipLaunchKernelGGL(stem_conv_i8_kernel<3>, g, b, 0, st, p); break;
+        default: hipLaunchKernelGGL(stem_conv_i8_kernel<4>, g, b, 0, st, p); break;
+    }
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }
