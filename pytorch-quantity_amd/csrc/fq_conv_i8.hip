@@ -67,7 +67,22 @@ struct ConvParams {
     int res_bytes;
     int16_t* wide;                       // exact int16 sum (may be null); the int8 output pointer receives `narrow`
     AddResParams ap;
+    // XCD-aware workgroup order (0 = plain 2-D grid): see conv_tile_of()
+    int xcd_kt, tiles_m;
 };
+
+// Which (pixel tile, output-channel tile) this workgroup computes.  Workgroups are dealt to the 8 XCDs round robin
+// by linear id, and each XCD has its own L2.  With the plain grid (pixel tiles on x) the k-tiles of one pixel tile run
+// gridDim.x workgroups apart on whatever XCD that lands on: every one of them fetches the activation tile again from
+// beyond its L2.  With xcd_kt = number of k-tiles the 1-D grid is decoded so that all k-tiles of a pixel tile are
+// consecutive workgroups of ONE XCD (pixel tile = 8 * group + xcd): the tile is fetched into that L2 once.
+__device__ __forceinline__ bool conv_tile_of(const ConvParams& p, int& bx, int& by) {
+    if (p.xcd_kt == 0) { bx = blockIdx.x; by = blockIdx.y; return true; }
+    const unsigned id = blockIdx.x, slot = id >> 3;
+    by = (int)(slot % (unsigned)p.xcd_kt);
+    bx = (int)(slot / (unsigned)p.xcd_kt) * 8 + (int)(id & 7u);
+    return bx < p.tiles_m;                                // the grid is padded to a multiple of 8 pixel tiles
+}
 
 // Activation loads are buffer loads: an out-of-image tap (zero padding) or a chunk past the end of the
 // reduction axis gets the offset kOutOfRange, which is beyond num_records of the buffer descriptor, and the
@@ -284,8 +299,10 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;
-    const int m0 = blockIdx.x * kTP;
-    const int k0 = blockIdx.y * TK;
+    int tile_x, tile_y;
+    if (!conv_tile_of(p, tile_x, tile_y)) return;
+    const int m0 = tile_x * kTP;
+    const int k0 = tile_y * TK;
     const int PQ = p.P * p.Q;
     if (tid < TK) {                                       // visible after the first barrier
         const float b = (k0 + tid < p.K) ? qbias[k0 + tid] : 0.0f;
@@ -498,12 +515,14 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA bases live in SGPRs (M0)
     const int half = lane >> 5;
-    const int m0 = blockIdx.x * kTP;
-    const int k0 = blockIdx.y * TK;
+    int tile_x, tile_y;
+    if (!conv_tile_of(p, tile_x, tile_y)) return;
+    const int m0 = tile_x * kTP;
+    const int k0 = tile_y * TK;
     const int PQ = p.P * p.Q;
 #ifdef FQ_CONV_TRACE
-    const bool trace_on = (blockIdx.x % 37 == 5) && blockIdx.y == 0 && wave == 1 && blockIdx.x < 37 * 8;
-    const int trace_base = (blockIdx.x / 37) * 512;
+    const bool trace_on = (tile_x % 37 == 5) && tile_y == 0 && wave == 1 && tile_x < 37 * 8;
+    const int trace_base = (tile_x / 37) * 512;
 #endif
     TR(0);
     if (tid < TK) {                                       // visible after the first barrier
@@ -908,9 +927,23 @@ extern "C" int fq_quantize_i8_unfold_w(const float* x_nchw, int8_t* y, int N, in
 
 namespace fq {
 
+// FQ_CONV_XCD=0 keeps the plain 2-D grid (A/B timing)
+static ConvParams xcd_order(dim3& grid, const ConvParams& p0) {
+    static const bool on = [] { const char* e = getenv("FQ_CONV_XCD"); return !(e && e[0] == '0'); }();
+    ConvParams p = p0;
+    p.xcd_kt = 0;
+    p.tiles_m = (int)grid.x;
+    if (on && grid.y > 1 && (long)((grid.x + 7) / 8) * 8 * grid.y < 0x7fffffffL) {
+        p.xcd_kt = (int)grid.y;
+        grid = dim3(((grid.x + 7) / 8) * 8 * grid.y, 1);
+    }
+    return p;
+}
+
 template <int TK, int STAGES>
 static void launch_conv_dma_stages(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
-                                   int8_t* q, const ConvParams& p) {
+                                   int8_t* q, const ConvParams& p0) {
+    const ConvParams p = xcd_order(grid, p0);
     if (p.res)
         hipLaunchKernelGGL((conv2d_i8_dma_kernel<TK, kOutI8 | kOutAdd, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else if (y && q)
@@ -936,7 +969,8 @@ static void launch_conv_dma(dim3 grid, hipStream_t st, const int8_t* x, const in
 
 template <int TK, int kPath>
 static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
-                             int8_t* q, const ConvParams& p) {
+                             int8_t* q, const ConvParams& p0) {
+    const ConvParams p = xcd_order(grid, p0);
     if (p.res)
         hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutI8 | kOutAdd>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else if (y && q)
