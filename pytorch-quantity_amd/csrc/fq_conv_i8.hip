@@ -21,6 +21,15 @@
 // of one tap): the streamed operand never touches LDS.  Only the weight tile, shared by the four
 // waves, is staged global -> registers -> LDS (double buffered); its 128-byte rows are XOR-swizzled
 // (chunk ^= (row >> 1) & 7) so that ds_read_b128 fragment reads are bank-conflict free.
+//
+//   conv2d_i8_dma_kernel      the same contraction for deep reductions (C % 128 == 0, >= 8 K-steps): both operand
+//                             tiles arrive by buffer_load ... lds (LDS-DMA), ring of 2 or 3 K-steps.
+//   epilogues                 fp32 NCHW, int8 NHWC (the resident hand-off), both, or the residual add fused in
+//                             (fq_resident.h); integer tail where the host proved it equal to the fp32 chain.
+//   workgroup order           1-D grid decoded so that all output-channel tiles of a pixel tile run on one XCD
+//                             (conv_tile_of): the activation tile is fetched into that XCD's L2 once.
+//   quantize_i8_unfold_w*     stem layers outside fq_conv2d_i8_stem's limits (fq_stem.hip): kernel width folded
+//                             into the channel axis.
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
