@@ -75,8 +75,55 @@ def run(cases, seed, verbose=True):
     return failures
 
 
+def run_stem(cases, seed, verbose=True):
+    """fq_conv2d_i8_stem against the oracle chain (Quantity -> integer conv -> tail -> ReLU -> next Quantity) on random
+    stem-shaped layers: 1-4 input channels, kernels up to 8x8, strides 1-3, ragged images, K <= 64."""
+    import torch
+    rng = np.random.default_rng(seed)
+    failures = []
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    done = 0
+    while done < cases:
+        C = int(rng.integers(1, 5)); R = int(rng.integers(1, 9)); S = int(rng.integers(1, 9))
+        st = int(rng.integers(1, 4)); K = int(rng.integers(1, 65))
+        ph, pw = int(rng.integers(0, R // 2 + 1)), int(rng.integers(0, S // 2 + 1))
+        H, W = int(rng.integers(R, 60)), int(rng.integers(S, 75))
+        N = int(rng.integers(1, 4))
+        ib, rs, ob = int(rng.integers(3, 8)), int(rng.integers(1, 17)), int(rng.integers(-1, 7))
+        relu = bool(rng.integers(0, 2))
+        if not nat.stem_supported(C, K, R, S, (st, st), (1, 1), rs):
+            continue
+        done += 1
+        msg = "stem N%d C%d H%d W%d K%d R%d S%d st%d pad(%d,%d) ib%d rs%d ob%d relu%d" % (N, C, H, W, K, R, S, st, ph, pw, ib, rs, ob, relu)
+        try:
+            x = (rng.standard_normal((N, C, H, W)) * rng.choice([0.3, 1.5, 20.0])).astype(np.float32)
+            wq = rng.integers(-128, 128, size=(K, C, R, S)).astype(np.int32)
+            qb = rng.integers(-128, 128, size=K).astype(np.float32)
+            xq = orc.quantity(x, ib).astype(np.int32)
+            # the accumulator test of the general kernels holds here too: R*S*C <= 256 taps of 2^14
+            acc = orc.conv2d_int(xq, wq, (st, st), (ph, pw), (1, 1))
+            ref = orc.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+            if relu:
+                ref = np.maximum(ref, np.float32(0))
+            kpad = (K + 15) // 16 * 16
+            want = np.zeros((N,) + ref.shape[2:] + (kpad,), dtype=np.int8)
+            want[..., :K] = orc.quantity(ref, ob).astype(np.int8).transpose(0, 2, 3, 1)
+            got = nat.conv2d_i8_stem(dev(x), nat.pack_weight_stem(dev(wq.astype(np.float32))), dev(qb), K, S, (st, st), (ph, pw),
+                                     ib, rs, ob, relu).cpu().numpy()
+            assert got.shape == want.shape and np.array_equal(got, want), "%d differing bytes" % int((got != want).sum())
+        except AssertionError as ex:
+            failures.append("%s -> %s" % (msg, ex))
+            if verbose:
+                print("MISMATCH", msg, "->", ex)
+    return failures
+
+
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-    fails = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+    fails = run(n, seed)
     print("conv_fuzz: %d cases, %d mismatches" % (n, len(fails)))
-    sys.exit(1 if fails else 0)
+    n_stem = max(20, n // 4)
+    stem_fails = run_stem(n_stem, seed + 1)
+    print("stem_fuzz: %d cases, %d mismatches" % (n_stem, len(stem_fails)))
+    sys.exit(1 if fails or stem_fails else 0)

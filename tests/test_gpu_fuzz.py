@@ -15,6 +15,8 @@ def test_random_shapes_match_the_oracle():
     spec.loader.exec_module(mod)
     failures = mod.run(120, 101, verbose=False)
     assert not failures, failures[:5]
+    failures = mod.run_stem(40, 102, verbose=False)          # fq_conv2d_i8_stem on random stem-shaped layers
+    assert not failures, failures[:5]
 
 
 def test_random_histograms_kl_sweep_matches_the_oracle_bit_for_bit():
