@@ -24,6 +24,8 @@ The JSON line also carries
   int8_sim_fp32_boundary_images_per_s : the same ReconModel with the reference's fp32 NCHW tensor at
                      every module boundary (the drop-in default);
   int8_sim_hipgraph_images_per_s : the resident forward replayed as one HIP graph (input copy included);
+  roofline_int8_conv : 2 x MACs of the model / summed durations of the int8 conv launches of one resident forward
+                     (HIP events), against the 5 000 TOP/s dense int8 MFMA peak;
   fakequant_images_per_s / float_forward_images_per_s : ReconTest and the float model.
 """
 import argparse
@@ -141,6 +143,55 @@ class KernelTimer(object):
             return None
         ms = [a.elapsed_time(b) for a, b in self.events]
         return {"launches": len(ms), "mean_ms": float(np.mean(ms)), "bytes_per_launch": 4.0 * float(np.mean(self.elems))}
+
+
+def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
+    """MFMA-side roofline of the integer contraction (the one MFMA kernel on the path): 2 x MACs of every Conv2d / Linear
+    of the model per forward / the summed durations of the int8 conv launches of the resident forward, HIP events on
+    the launch stream around every C-ABI call.  Peak: 5 000 TOP/s dense int8 (2 x the BF16 MFMA rate, MI355X_MICROARCH.md)."""
+    from common.quantity import _native
+    macs, hooks = [0], []
+
+    def count(m, i, o):
+        w = m.weight
+        macs[0] += int(o.numel()) * int(w[0].numel())                 # outputs x (C_in / groups x kh x kw)
+    for m in float_model.modules():
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)):
+            hooks.append(m.register_forward_hook(count))
+    with torch.no_grad():
+        float_model(batch)
+    for h in hooks:
+        h.remove()
+    names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8")
+    events, saved = [], {n: getattr(_native, n) for n in names}
+
+    def timed(fn):
+        def wrapper(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = fn(*a, **k)
+            e1.record()
+            events.append((e0, e1))
+            return r
+        return wrapper
+    try:
+        for n in names:
+            setattr(_native, n, timed(saved[n]))
+        with torch.no_grad():
+            for _ in range(forwards):
+                int8_net(batch)
+        torch.cuda.synchronize()
+    finally:
+        for n in names:
+            setattr(_native, n, saved[n])
+    ms = sum(a.elapsed_time(b) for a, b in events) / forwards
+    achieved = 2.0 * macs[0] / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv2d_i8 / conv2d_i8_dma / stem_conv_i8 (all integer conv + linear launches of one forward)",
+            "achieved": round(achieved, 1), "peak": 5000.0, "unit": "TOP/s", "frac": round(achieved / 5000.0, 4),
+            "launches_per_forward": len(events) // forwards, "ms_per_forward": round(ms, 4), "images_per_forward": int(batch.shape[0]),
+            "gmac_per_image": round(macs[0] / int(batch.shape[0]) / 1e9, 3),
+            "note": "latency / output-traffic bound at these layer sizes (DESIGN.md 5b); SQ_VALU_MFMA_BUSY_CYCLES 21 % on the "
+                    "3x3 256->256 14x14 layer (profiles/r01j_conv_pmc_256x14x14_3x3.txt)"}
 
 
 def cpu_baseline(model_cpu_ctor, sample_images, hw, n_images_full, q, log):
@@ -409,6 +460,10 @@ def main():
             if not same:                                   # never report a rate for a model that computes something else
                 result["int8_sim_images_per_s"] = result["int8_sim_fp32_boundary_images_per_s"]
             else:
+                try:
+                    result["roofline_int8_conv"] = int8_conv_roofline(model, int8_net, batches[0])
+                except Exception as e:
+                    result["roofline_int8_conv"] = {"error": repr(e)}
                 try:                                       # the same forward replayed as one HIP graph (input copy included)
                     graphed = resident.capture(int8_net, batches[0])
                     with torch.no_grad():
