@@ -272,3 +272,36 @@ def test_image_file_input_mode(tmp_path):
         assert y.shape == (1, 3, 32, 32) and y.min() >= -128 and y.max() <= 127
         assert torch.equal(y, torch.round(y))
         assert q.preprocess(str(tmp_path / "missing.png")) is False
+
+
+def test_eager_stats_groups_launches_and_notices_inplace_consumers():
+    """tools.pytorch_quantizer._EagerStats (host logic of the in-hook statistics launches) on CPU tensors."""
+    import torch
+    from tools.pytorch_quantizer import _AFTER_FORWARD, _EagerStats
+    calls = []
+    fn = lambda tensors: calls.append(list(tensors))
+    a, b, c = torch.ones(100), torch.ones(100), torch.ones(100)
+
+    e = _EagerStats(fn, 0)                                   # one launch per tensor, from the hook
+    e.add("a", a); e.add("b", b)
+    assert calls == [["a"], ["b"]] and not e.modified()
+    a.mul_(2.0)                                              # an in-place consumer AFTER the statistics were taken
+    assert e.modified()
+    e.flush()                                                # nothing pending: no call
+    assert len(calls) == 2
+
+    calls.clear()
+    e = _EagerStats(fn, 800)                                 # 400-byte tensors: two per launch
+    e.add("a", a); assert calls == []
+    e.add("b", b); assert calls == [["a", "b"]]
+    e.add("c", c)
+    e.flush(extra={"kept": torch.zeros(3)})                  # end of forward: the rest plus tensors kept from pass 1
+    assert calls == [["a", "b"], ["c", "kept"]]
+
+    calls.clear()
+    e = _EagerStats(fn, _AFTER_FORWARD)                      # the default for models without in-place consumers
+    e.add("a", a); e.add("b", b)
+    assert calls == []
+    b.add_(1.0)                                              # ... which such a model must not do
+    with pytest.raises(RuntimeError):
+        e.flush()
