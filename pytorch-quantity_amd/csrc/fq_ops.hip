@@ -186,6 +186,45 @@ __global__ __launch_bounds__(kOpsBlock) void recon_epilogue_vec_kernel(const flo
     }
 }
 
+// ---- conv bias add with the running abs-max taken on the way out ---------------------------------
+// A float Conv2d on this stack is a MIOpen convolution followed by a separate broadcast add of the bias (8 B per
+// element); the calibration then reads the result once more for the abs-max (4 B).  This kernel IS that add --
+// y[n][c][hw] += bias[c], the same single fp32 rounding -- and folds max |y| into the tensor's row while the values
+// are in registers, so pass 1 does not read conv outputs a second time.  kVec: HW % 4 == 0 and y 16-byte aligned.
+template <bool kVec>
+__global__ __launch_bounds__(kOpsBlock) void bias_add_absmax_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                                    unsigned n_items, unsigned inner, unsigned C,
+                                                                    unsigned int* __restrict__ max_bits) {
+    __shared__ float s_wave[kOpsBlock / kWave];
+    float m = 0.0f;
+    const unsigned stride = gridDim.x * kOpsBlock;
+    for (unsigned i = blockIdx.x * kOpsBlock + threadIdx.x; i < n_items; i += stride) {
+        const float b = bias[(i / inner) % C];                      // inner = HW (scalar form) or HW / 4 (vector form)
+        if (kVec) {
+            f4v v = reinterpret_cast<f4v*>(y)[i];
+            v.x += b; v.y += b; v.z += b; v.w += b;
+            reinterpret_cast<f4v*>(y)[i] = v;
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+        } else {
+            const float v = y[i] + b;
+            y[i] = v;
+            m = fmaxf(m, fabsf(v));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) s_wave[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kOpsBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
+        // m >= 0: the bit pattern orders like an unsigned.  Thousands of workgroups publish into ONE word: only those
+        // that can still raise it pay the atomic (4 096 serialised atomics cost 40 us, more than the add itself)
+        const unsigned int bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, bits);
+    }
+}
+
 // ---- weight quantiser ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kOpsBlock) void quantize_param_i32_kernel(const float* __restrict__ w, int32_t* __restrict__ q,
                                                                        size_t n, float scale) {
@@ -279,6 +318,27 @@ extern "C" int fq_recon_epilogue_f32(const float* acc, const float* qbias, float
     } else {
         hipLaunchKernelGGL(recon_epilogue_kernel, dim3(grid_for(n)), dim3(kOpsBlock), 0, st, acc, qbias, y,
                            outer * C, C, inner, rso, r.lo, r.hi, oscale);
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C, int HW, float* max_inout, fq_stream_t stream) {
+    using namespace fq;
+    if (N < 0 || C <= 0 || HW <= 0) return FQ_ERR_INVALID_ARG;
+    const size_t n = (size_t)N * C * HW;
+    if (n == 0) return FQ_OK;
+    if (!y || !bias || !max_inout) return FQ_ERR_INVALID_ARG;
+    if (n >= 0xffffffffULL) return FQ_ERR_UNSUPPORTED;               // 32-bit element index inside the kernel
+    hipStream_t st = as_stream(stream);
+    unsigned int* bits = reinterpret_cast<unsigned int*>(max_inout);
+    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
+        const unsigned nvec = (unsigned)(n >> 2);
+        hipLaunchKernelGGL(bias_add_absmax_kernel<true>, dim3(grid_for(nvec, 8)), dim3(kOpsBlock), 0, st, y, bias, nvec,
+                           (unsigned)(HW >> 2), (unsigned)C, bits);
+    } else {
+        hipLaunchKernelGGL(bias_add_absmax_kernel<false>, dim3(grid_for(n, 8)), dim3(kOpsBlock), 0, st, y, bias, (unsigned)n,
+                           (unsigned)HW, (unsigned)C, bits);
     }
     FQ_LAUNCH_CHECK();
     return FQ_OK;

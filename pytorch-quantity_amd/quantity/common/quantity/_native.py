@@ -86,6 +86,8 @@ def lib():
     L.fq_conv2d_i8.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_resident.restype = ci
     L.fq_conv2d_i8_resident.argtypes = [vp, vp, vp, vp, vp] + [ci] * 17 + [vp]
+    L.fq_bias_add_absmax_f32.restype = ci
+    L.fq_bias_add_absmax_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp]
     L.fq_conv2d_i8_stem.restype = ci
     L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
@@ -232,6 +234,20 @@ def kl_threshold(hist, want_curve=False):
     _check(lib().fq_kl_threshold(hist.data_ptr(), rows, thr.data_ptr(), curve.data_ptr() if want_curve else None,
                                  ws.data_ptr(), wsb, _stream(hist)), "fq_kl_threshold")
     return (thr, curve) if want_curve else thr
+
+
+def bias_add_absmax(y, bias, max_dev, row):
+    """fq_bias_add_absmax_f32: y[n][c][...] += bias[c] in place and max_dev[row] = max(max_dev[row], max |y|)."""
+    _need_cuda(y, torch.float32, "fq_bias_add_absmax_f32")
+    _need_cuda(bias, torch.float32, "fq_bias_add_absmax_f32")
+    _need_cuda(max_dev, torch.float32, "fq_bias_add_absmax_f32")
+    assert y.is_contiguous() and y.dim() >= 2 and bias.is_contiguous() and bias.numel() == y.shape[1]
+    assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
+    N, C = int(y.shape[0]), int(y.shape[1])
+    hw = y.numel() // max(N * C, 1)
+    _check(lib().fq_bias_add_absmax_f32(y.data_ptr(), bias.data_ptr(), N, C, hw, max_dev.data_ptr() + 4 * int(row), _stream(y)),
+           "fq_bias_add_absmax_f32")
+    return y
 
 
 def bits_from_threshold(thr, interval):

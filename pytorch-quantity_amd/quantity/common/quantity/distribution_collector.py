@@ -123,6 +123,16 @@ class DistributionCollector(object):
     # ------------------------------------------------------------------ beyond the reference API
     supports_partial = True     # refresh_max_val / add_to_distributions accept a dict holding only SOME of the tensors
 
+    def row_of(self, name):
+        """Row of one tensor in max_device / hist_device (for kernels that fold a statistic into their own pass)."""
+        if not hasattr(self, "_row_index"):
+            self._row_index = {n: r for r, n in enumerate(self._tensor_list)}
+        return self._row_index[name]
+
+    def note_max_refreshed(self):
+        """fq_bias_add_absmax_f32 wrote a maximum straight into max_device."""
+        self._max_vals_refreshed_flag = True
+
     def _rows_of(self, tensors):
         """Rows of the tensors present in `tensors` (the reference passes all of them; the calibration loop also feeds
         them in groups, from inside the forward hooks, while they are still in the Infinity Cache)."""

@@ -36,6 +36,7 @@ import torch.nn as nn
 import yaml
 
 from common.quantity import DistributionCollector, Quantizer, walk_dirs, merge_bn, tid  # noqa: F401
+from common.quantity import _native
 from .rewriter import BiasReWriter
 from ._jsonio import dump_int_array
 
@@ -65,6 +66,7 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
+_FUSION_VERIFIED = "_fq_bias_fusion_verified"     # module attribute: conv-without-bias + fq_bias_add_absmax_f32 == its forward
 _AFTER_FORWARD = 1 << 62      # _EagerStats limit that is never reached: one flush, after the forward
 
 
@@ -92,6 +94,10 @@ class _EagerStats(object):
         self.bytes += t.numel() * t.element_size()
         if self.bytes >= self.limit:
             self.flush()
+
+    def note(self, key, t):
+        """A tensor whose statistics were already taken by its producer: only watched for in-place consumers."""
+        self.seen.append((key, t, t._version))
 
     def flush(self, extra=None):
         """Hand the pending tensors (plus `extra`: tensors kept from an earlier forward) to fn in one call."""
@@ -128,6 +134,11 @@ class Quantity(object):
     # activation cache.  Smaller groups (e.g. 96 << 20) were measured on ResNet-50: no gain.
     # Engines without `supports_partial` (the CPU test doubles) take the statistics after the forward.
     stats_group_bytes = None
+    # Pass 1: a hooked nn.Conv2d with a bias runs as convolution-without-bias + fq_bias_add_absmax_f32 (the bias add torch
+    # would launch anyway, with the running abs-max folded in), so its output is not read a second time for the maximum.
+    # Every module is checked bit for bit against torch's own forward the first time it is used; one mismatch turns the
+    # whole mechanism off for the run.
+    fuse_bias_absmax = True
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -345,6 +356,69 @@ class Quantity(object):
         warm = pooled - (total >> 4)
         return max(cold, warm, 0)
 
+    def _patch_fused_convs(self, model):
+        """Give every hooked nn.Conv2d with a bias a forward that, while pass 1 is running on the GPU, leaves the bias to
+        the forward hook (fq_bias_add_absmax_f32).  Returns the patched modules (undo: del module.forward)."""
+        patched = []
+        if not self.fuse_bias_absmax or "Conv2d" not in self._all_op_type or "Conv2d" not in self._cared_op_type:
+            return patched
+        ctl = self._hook_ctl
+        for m in model.modules():
+            if type(m) is not torch.nn.Conv2d or m.bias is None or m.padding_mode != "zeros" or "forward" in m.__dict__:
+                continue
+
+            def forward(x, m=m):
+                if (ctl["fuse_collector"] is None or ctl["fuse_off"] or not torch.is_tensor(x) or not x.is_cuda
+                        or x.dtype != torch.float32 or m.weight.dtype != torch.float32 or torch.is_grad_enabled()):
+                    return torch.nn.Conv2d.forward(m, x)
+                if m not in ctl["fuse_warm"] and not m.__dict__.get(_FUSION_VERIFIED):
+                    ctl["fuse_warm"].add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
+                    return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
+                y = m._conv_forward(x, m.weight, None)
+                ctl["fuse_bias"] = (m, x)                   # the hook of this very call adds the bias
+                return y
+            m.forward = forward
+            patched.append(m)
+        return patched
+
+    def _finish_fused_conv(self, module, pending, key, output):
+        """Forward-hook half of the fused conv: add the bias (and take the abs-max when the tensor is a cared one).
+        Returns True when the statistics of `output` are done."""
+        m, x = pending
+        ctl = self._hook_ctl
+        coll = ctl["fuse_collector"]
+        if module is not m or coll is None or key is None or not output.is_contiguous() or output.dim() < 2:
+            output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))     # what torch does
+            return False
+        row = coll.row_of(key)
+        if m in ctl["fuse_verified"] or m.__dict__.get(_FUSION_VERIFIED):
+            ctl["fuse_verified"].add(m)
+            _native.bias_add_absmax(output, m.bias, coll.max_device, row)
+            coll.note_max_refreshed()
+            return True
+        # First fused use of this module (its second batch).  Two things are checked once per module:
+        #   * the kernel itself: on the same convolution result it must leave exactly torch's `raw + bias` and that
+        #     tensor's maximum;
+        #   * the decomposition: torch's own forward must equal convolution-without-bias + bias bit for bit -- on layers
+        #     where torch's forward is reproducible at all (MIOpen's Winograd kernels for some 3x3 shapes are not: two
+        #     identical calls differ in the last bit, so there is nothing bitwise to compare against).
+        ref = torch.nn.Conv2d.forward(m, x)
+        raw = m._conv_forward(x, m.weight, None)
+        want = raw + m.bias.view(1, -1, *([1] * (raw.dim() - 2)))
+        scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
+        _native.bias_add_absmax(raw, m.bias, scratch, 0)
+        kernel_ok = torch.equal(raw, want) and float(scratch[0]) == float(want.abs().max())
+        reproducible = torch.equal(ref, torch.nn.Conv2d.forward(m, x))
+        if kernel_ok and (torch.equal(raw, ref) or not reproducible):
+            ctl["fuse_verified"].add(m)
+            m.__dict__[_FUSION_VERIFIED] = True             # a property of (module, MIOpen, this library): checked once per process
+            _native.bias_add_absmax(output, m.bias, coll.max_device, row)
+            coll.note_max_refreshed()
+            return True
+        ctl["fuse_off"] = True                              # never silently different: torch's add, statistics as usual
+        output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))
+        return False
+
     def _forward_with_stats(self, item, fn, named_feats, extra=None):
         """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced and
         to `extra` (tensors of the same batch kept from pass 1).  Returns the _EagerStats of that forward, or None
@@ -489,10 +563,13 @@ class Quantity(object):
         quantizer = self.quantizer_cls(top_feat_names, worker_num=settings["WORKER_NUM"], debug=False)
         named_feats, hooks = self.regist_hook_outfeature(self.model)
         self._collector, self._quantizer = collector, quantizer
+        patched = self._patch_fused_convs(self.model) if getattr(collector, "supports_partial", False) else []
         try:
             return self._calibrate(images_files, collector, quantizer, named_feats, merge_groups, top_feat_names,
                                    table_file)
         finally:
+            for m in patched:
+                del m.forward
             for h in hooks:                 # (the reference never removes its hooks)
                 h.remove()
             named_feats.clear()
@@ -515,6 +592,7 @@ class Quantity(object):
         cached, cached_ids, used = {}, set(), 0
         step_ms = []
         inplace = None                          # does a later module overwrite a hooked tensor?  (known after one forward)
+        ctl["fuse_collector"] = collector if eager_ok and self.fuse_bias_absmax else None
         for i, item in self._device_items(images_files):
             ts = time.perf_counter()
             if budget and plan is None and self.device == "gpu" and torch.cuda.is_available():
@@ -550,6 +628,7 @@ class Quantity(object):
                 kept = {n: t for n, t in named_feats.items() if n in plan["keep"]}
                 cached[i] = kept
                 used += sum(t.numel() * t.element_size() for t in kept.values())
+        ctl["fuse_collector"] = None              # pass 2 and later forwards: torch's own Conv2d.forward
         self._join_stat_stream()
         if _dist_on():                      # also at world size 1: same code path, trivial cost
             collector.all_reduce_max()
@@ -637,6 +716,7 @@ class Quantity(object):
                     fh.write(line + "\n")
         self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0,
                         "cached_batches": len(cached_ids), "cache_bytes": used, "inplace_consumers": inplace,
+                        "fused_bias_absmax_convs": 0 if ctl["fuse_off"] else len(ctl["fuse_verified"]),
                         "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}
@@ -704,7 +784,8 @@ class Quantity(object):
         cared = set(self.net_info.keys())
         state = {"n": 0}
         total = int(self.layers_num)
-        ctl = self._hook_ctl = {"stop_after": None, "events": None, "eager": None}
+        ctl = self._hook_ctl = {"stop_after": None, "events": None, "eager": None, "fuse_bias": None, "fuse_collector": None,
+                                "fuse_off": False, "fuse_verified": set(), "fuse_warm": set()}
 
         def on_forward(module, inputs, output):
             eager = ctl["eager"]
@@ -715,10 +796,15 @@ class Quantity(object):
                     eager.add("image", out_feat["image"])
             state["n"] += 1
             key = "%s_%i" % (type(module).__name__, state["n"])
+            pending_bias, ctl["fuse_bias"] = ctl.get("fuse_bias"), None
+            fused = pending_bias is not None and self._finish_fused_conv(module, pending_bias, key if key in cared else None, output)
             if key in cared:
                 out_feat[key] = output.detach()
                 if eager is not None:
-                    eager.add(key, out_feat[key])
+                    if fused:
+                        eager.note(key, out_feat[key])
+                    else:
+                        eager.add(key, out_feat[key])
                 if ctl["events"] is not None:                 # time stamps of one forward, for the cache plan
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record()

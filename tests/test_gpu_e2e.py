@@ -258,3 +258,41 @@ def test_inplace_relu_model_is_calibrated_on_the_values_the_hooks_saw(monkeypatc
         q.activation_quantize(cases.calib_batches(3, (4, 3, 16, 16)))
         assert open(os.path.join(tmp, "test", "workdir", "feat.table")).read() == tables[0]
         assert q.timings["stats_group_bytes"] == 0
+
+
+@pytest.mark.parametrize("fuse", [True, False])
+def test_fused_bias_absmax_does_not_change_the_tables(g3, fuse):
+    """Pass 1 may run a hooked Conv2d as convolution-without-bias + fq_bias_add_absmax_f32 (bias add and abs-max in one
+    pass): same activations bit for bit (checked per module on first use), same maxima, same table."""
+    from tools import Quantity
+    with product_workdir(device="gpu", max_cali_img_num=1) as tmp:
+        model = _r18_gpu()
+        q = Quantity(model)
+        q.fuse_bias_absmax = fuse
+        q.activation_quantize(cases.calib_batches(3, (4, 3, 32, 32)))     # two batches are used: plain, then verified + fused
+        table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
+        fused = q.timings["fused_bias_absmax_convs"]
+        assert not any("forward" in m.__dict__ for m in model.modules())            # the patched forwards are gone
+        if fuse:                                                                    # a second calibration of the same
+            q.activation_quantize(cases.calib_batches(3, (4, 3, 32, 32)))           # modules does not verify again
+            assert open(os.path.join(tmp, "test", "workdir", "feat.table")).read() == table
+            assert q.timings["fused_bias_absmax_convs"] == fused
+    assert table == g3["feat_table"]
+    n_convs = sum(1 for m in model.modules() if type(m) is torch.nn.Conv2d and m.bias is not None)
+    assert fused == (n_convs if fuse else 0) and n_convs > 0
+
+
+def test_bias_add_absmax_kernel_equals_torch():
+    from common.quantity import _native
+    g = torch.Generator(device="cpu").manual_seed(3)
+    for shape in [(3, 5, 7, 7), (2, 64, 56, 56), (4, 16, 8, 8), (1, 3, 5), (2, 7, 1, 1)]:
+        y = torch.randn(shape, generator=g).cuda()
+        b = torch.randn(shape[1], generator=g).cuda()
+        ref = y + b.view(1, -1, *([1] * (y.dim() - 2)))
+        mx = torch.tensor([0.25, 0.0], device="cuda")
+        _native.bias_add_absmax(y, b, mx, 1)
+        assert torch.equal(y, ref)
+        assert float(mx[1]) == float(ref.abs().max()) and float(mx[0]) == 0.25
+        mx[1] = 1e9                                                                  # a running maximum is kept
+        _native.bias_add_absmax(y.clone(), b, mx, 1)
+        assert float(mx[1]) == 1e9

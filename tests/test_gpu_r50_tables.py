@@ -65,6 +65,7 @@ def test_bottleneck_tables_hip_equals_cpu_oracle(oracle, arch, rows, batch):
 
     class HipQuantity(Quantity):
         collector_cls = RecordingCollector
+        fuse_bias_absmax = False          # the tape wants to see every tensor pass through refresh_max_val
 
     class CpuQuantity(Quantity):
         collector_cls = ReplayCollector
