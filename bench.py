@@ -389,7 +389,12 @@ def main():
         if max_s:
             ach2 = max_s["bytes_per_launch"] / (max_s["mean_ms"] * 1e-3) / 1e9
             result["roofline_absmax"] = {"kernel": "absmax_seg_kernel", "achieved": round(ach2, 1), "unit": "GB/s",
-                                         "frac": round(ach2 / HBM_PEAK_GBS, 4), "mean_launch_ms": round(max_s["mean_ms"], 4)}
+                                         "frac": round(ach2 / HBM_PEAK_GBS, 4), "mean_launch_ms": round(max_s["mean_ms"], 4),
+                                         "algorithmic_bytes_per_launch": max_s["bytes_per_launch"],
+                                         "note": "pass 1 takes the abs-max of conv and Eltwise outputs inside their own bias add / "
+                                                 "residual add (phases_s.fused_*): only what is left (the input image) goes "
+                                                 "through this kernel, a launch of tens of microseconds; its streaming rate on "
+                                                 "the full 8.6 GB tensor set is 6.2-6.8 TB/s (DESIGN.md section 5)"}
 
     # ---- the fused fake-quant kernel on its own (north_star: >= 60 % of the HBM roofline)
     try:

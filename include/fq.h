@@ -147,6 +147,11 @@ int fq_quantize_param_i32(const float* w, int32_t* q, size_t n, int bit, fq_stre
  * y: fp32 [N][C][HW] contiguous, bias: fp32 [C], max_inout: one fp32 (>= 0) in device memory, N*C*HW < 2^32. */
 int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C, int HW, float* max_inout, fq_stream_t stream);
 
+/* Eltwise.forward of the float model (fabu_layer.py:16-19, x + y) with the calibration's running abs-max
+ * (distribution_collector.py:70-78) taken on the way out:  z[i] = x[i] + y[i]  and  *max_inout = max(*max_inout, max |z|).
+ * x, y, z: fp32, 16-byte aligned, n elements (z may alias x or y); max_inout: one fp32 (>= 0) in device memory. */
+int fq_add_absmax_f32(const float* x, const float* y, float* z, size_t n, float* max_inout, fq_stream_t stream);
+
 /* Quantity.forward (new_quantity_op.py:52-58) fused with the layout change the MFMA kernel wants:
  *   y[n][hw][c] = (int8) clamp(rint(x[n][c][hw] * 2^ib), -128, 127),  c in [C, Cpad) = 0
  * x: fp32 [N][C][HW] (NCHW), y: int8 [N][HW][Cpad] (NHWC), Cpad >= C, Cpad % 4 == 0 (use a multiple

@@ -225,6 +225,38 @@ __global__ __launch_bounds__(kOpsBlock) void bias_add_absmax_kernel(float* __res
     }
 }
 
+// ---- residual add of the float model with the running abs-max taken on the way out ----------------
+// Eltwise.forward (fabu_layer.py:16-19: x + y) during calibration pass 1: z = x + y (one fp32 rounding, what torch.add
+// does) with max |z| folded into the tensor's row -- the sum is not read a second time for the maximum.
+__global__ __launch_bounds__(kOpsBlock) void add_absmax_kernel(const f4v* __restrict__ x, const f4v* __restrict__ y,
+                                                               f4v* __restrict__ z, size_t nvec, const float* __restrict__ xs,
+                                                               const float* __restrict__ ys, float* __restrict__ zs, unsigned tail,
+                                                               unsigned int* __restrict__ max_bits) {
+    __shared__ float s_wave[kOpsBlock / kWave];
+    float m = 0.0f;
+    const size_t stride = (size_t)gridDim.x * kOpsBlock;
+    for (size_t i = (size_t)blockIdx.x * kOpsBlock + threadIdx.x; i < nvec; i += stride) {
+        const f4v v = x[i] + y[i];
+        z[i] = v;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < tail) {          // the last n % 4 elements
+        const float v = xs[threadIdx.x] + ys[threadIdx.x];
+        zs[threadIdx.x] = v;
+        m = fmaxf(m, fabsf(v));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) s_wave[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kOpsBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
+        const unsigned int bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, bits);
+    }
+}
+
 // ---- weight quantiser ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kOpsBlock) void quantize_param_i32_kernel(const float* __restrict__ w, int32_t* __restrict__ q,
                                                                        size_t n, float scale) {
@@ -340,6 +372,21 @@ extern "C" int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C,
         hipLaunchKernelGGL(bias_add_absmax_kernel<false>, dim3(grid_for(n, 8)), dim3(kOpsBlock), 0, st, y, bias, (unsigned)n,
                            (unsigned)HW, (unsigned)C, bits);
     }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_add_absmax_f32(const float* x, const float* y, float* z, size_t n, float* max_inout, fq_stream_t stream) {
+    using namespace fq;
+    if (n == 0) return FQ_OK;
+    if (!x || !y || !z || !max_inout) return FQ_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z)) & 15u)
+        return FQ_ERR_INVALID_ARG;
+    const size_t nvec = n >> 2;
+    const unsigned tail = (unsigned)(n & 3u);
+    hipLaunchKernelGGL(add_absmax_kernel, dim3(grid_for(nvec ? nvec : 1, 8)), dim3(kOpsBlock), 0, as_stream(stream),
+                       reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
+                       x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, reinterpret_cast<unsigned int*>(max_inout));
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }

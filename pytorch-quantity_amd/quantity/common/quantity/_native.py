@@ -88,6 +88,8 @@ def lib():
     L.fq_conv2d_i8_resident.argtypes = [vp, vp, vp, vp, vp] + [ci] * 17 + [vp]
     L.fq_bias_add_absmax_f32.restype = ci
     L.fq_bias_add_absmax_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+    L.fq_add_absmax_f32.restype = ci
+    L.fq_add_absmax_f32.argtypes = [vp, vp, vp, sz, vp, vp]
     L.fq_conv2d_i8_stem.restype = ci
     L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
@@ -248,6 +250,19 @@ def bias_add_absmax(y, bias, max_dev, row):
     _check(lib().fq_bias_add_absmax_f32(y.data_ptr(), bias.data_ptr(), N, C, hw, max_dev.data_ptr() + 4 * int(row), _stream(y)),
            "fq_bias_add_absmax_f32")
     return y
+
+
+def add_absmax(x, y, max_dev, row, out=None):
+    """fq_add_absmax_f32: returns x + y (in `out` if given) and folds max |x + y| into max_dev[row]."""
+    _need_cuda(x, torch.float32, "fq_add_absmax_f32")
+    _need_cuda(y, torch.float32, "fq_add_absmax_f32")
+    _need_cuda(max_dev, torch.float32, "fq_add_absmax_f32")
+    assert x.shape == y.shape and x.is_contiguous() and y.is_contiguous() and 0 <= row < max_dev.numel()
+    z = torch.empty_like(x) if out is None else out
+    assert z.shape == x.shape and z.is_contiguous() and z.dtype == torch.float32 and z.is_cuda
+    _check(lib().fq_add_absmax_f32(x.data_ptr(), y.data_ptr(), z.data_ptr(), x.numel(), max_dev.data_ptr() + 4 * int(row),
+                                   _stream(x)), "fq_add_absmax_f32")
+    return z
 
 
 def bits_from_threshold(thr, interval):

@@ -379,6 +379,21 @@ class Quantity(object):
                 return y
             m.forward = forward
             patched.append(m)
+        if "Eltwise" in self._all_op_type and "Eltwise" in self._cared_op_type:
+            from common.quantity.fabu_layer import Eltwise
+            for m in model.modules():
+                if type(m) is not Eltwise or "forward" in m.__dict__:
+                    continue
+
+                def forward(x, y, m=m):
+                    if (ctl["fuse_collector"] is None or ctl["fuse_off"] or torch.is_grad_enabled() or not torch.is_tensor(x)
+                            or not torch.is_tensor(y) or not x.is_cuda or x.dtype != torch.float32 or y.dtype != torch.float32
+                            or x.shape != y.shape or not x.is_contiguous() or not y.is_contiguous() or y.device != x.device):
+                        return Eltwise.forward(m, x, y)
+                    ctl["fuse_bias"] = (m, (x, y))          # the hook of this very call computes the sum (+ its abs-max)
+                    return torch.empty_like(x)
+                m.forward = forward
+                patched.append(m)
         return patched
 
     def _finish_fused_conv(self, module, pending, key, output):
@@ -387,6 +402,25 @@ class Quantity(object):
         m, x = pending
         ctl = self._hook_ctl
         coll = ctl["fuse_collector"]
+        if isinstance(x, tuple):                            # Eltwise: output is an empty tensor waiting for x + y
+            a, b = x
+            if module is not m or coll is None or key is None:
+                torch.add(a, b, out=output)
+                return False
+            row = coll.row_of(key)
+            if not m.__dict__.get(_FUSION_VERIFIED):        # first use: the kernel against torch.add, once per process
+                scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
+                z = _native.add_absmax(a, b, scratch, 0)
+                want = torch.add(a, b)
+                if not (torch.equal(z, want) and float(scratch[0]) == float(want.abs().max())):
+                    ctl["fuse_off"] = True
+                    output.copy_(want)
+                    return False
+                m.__dict__[_FUSION_VERIFIED] = True
+            ctl["fuse_verified"].add(m)
+            _native.add_absmax(a, b, coll.max_device, row, out=output)
+            coll.note_max_refreshed()
+            return True
         if module is not m or coll is None or key is None or not output.is_contiguous() or output.dim() < 2:
             output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))     # what torch does
             return False
@@ -716,7 +750,8 @@ class Quantity(object):
                     fh.write(line + "\n")
         self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0,
                         "cached_batches": len(cached_ids), "cache_bytes": used, "inplace_consumers": inplace,
-                        "fused_bias_absmax_convs": 0 if ctl["fuse_off"] else len(ctl["fuse_verified"]),
+                        "fused_bias_absmax_convs": 0 if ctl["fuse_off"] else sum(1 for m in ctl["fuse_verified"] if isinstance(m, torch.nn.Conv2d)),
+                        "fused_add_absmax_eltwise": 0 if ctl["fuse_off"] else sum(1 for m in ctl["fuse_verified"] if not isinstance(m, torch.nn.Conv2d)),
                         "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}

@@ -280,6 +280,8 @@ def test_fused_bias_absmax_does_not_change_the_tables(g3, fuse):
     assert table == g3["feat_table"]
     n_convs = sum(1 for m in model.modules() if type(m) is torch.nn.Conv2d and m.bias is not None)
     assert fused == (n_convs if fuse else 0) and n_convs > 0
+    n_elt = sum(1 for m in model.modules() if type(m).__name__ == "Eltwise")
+    assert q.timings["fused_add_absmax_eltwise"] == (n_elt if fuse else 0) and n_elt > 0
 
 
 def test_bias_add_absmax_kernel_equals_torch():
@@ -296,3 +298,14 @@ def test_bias_add_absmax_kernel_equals_torch():
         mx[1] = 1e9                                                                  # a running maximum is kept
         _native.bias_add_absmax(y.clone(), b, mx, 1)
         assert float(mx[1]) == 1e9
+
+
+def test_add_absmax_kernel_equals_torch():
+    from common.quantity import _native
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for n in (1, 3, 4, 5, 1023, 4096, 100003):
+        x, y = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+        mx = torch.tensor([0.5, 0.0], device="cuda")
+        z = _native.add_absmax(x, y, mx, 1)
+        ref = x + y
+        assert torch.equal(z, ref) and float(mx[1]) == float(ref.abs().max()) and float(mx[0]) == 0.5
