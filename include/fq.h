@@ -144,13 +144,16 @@ int fq_quantize_param_i32(const float* w, int32_t* q, size_t n, int bit, fq_stre
 /* The bias add of a float convolution with the calibration's running abs-max (distribution_collector.py:70-78) taken
  * on the way out:  y[n][c][hw] += bias[c]  in place (what torch's Conv2d does after the MIOpen convolution, same
  * single fp32 rounding) and  *max_inout = max(*max_inout, max |y|)  -- pass 1 then does not read this tensor again.
- * y: fp32 [N][C][HW] contiguous, bias: fp32 [C], max_inout: one fp32 (>= 0) in device memory, N*C*HW < 2^32. */
-int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C, int HW, float* max_inout, fq_stream_t stream);
+ * relu_out (may be NULL): also writes max(y, 0) there (NaN kept, torch's clamp_min) -- the nn.ReLU that follows, served in
+ * the same pass.  y: fp32 [N][C][HW] contiguous, bias: fp32 [C], max_inout: one fp32 (>= 0) in device memory, N*C*HW < 2^32. */
+int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C, int HW, float* max_inout, float* relu_out,
+                           fq_stream_t stream);
 
 /* Eltwise.forward of the float model (fabu_layer.py:16-19, x + y) with the calibration's running abs-max
  * (distribution_collector.py:70-78) taken on the way out:  z[i] = x[i] + y[i]  and  *max_inout = max(*max_inout, max |z|).
- * x, y, z: fp32, 16-byte aligned, n elements (z may alias x or y); max_inout: one fp32 (>= 0) in device memory. */
-int fq_add_absmax_f32(const float* x, const float* y, float* z, size_t n, float* max_inout, fq_stream_t stream);
+ * relu_out (may be NULL): also writes max(z, 0) there.  x, y, z, relu_out: fp32, 16-byte aligned, n elements (z may alias
+ * x or y); max_inout: one fp32 (>= 0) in device memory. */
+int fq_add_absmax_f32(const float* x, const float* y, float* z, size_t n, float* max_inout, float* relu_out, fq_stream_t stream);
 
 /* Quantity.forward (new_quantity_op.py:52-58) fused with the layout change the MFMA kernel wants:
  *   y[n][hw][c] = (int8) clamp(rint(x[n][c][hw] * 2^ib), -128, 127),  c in [C, Cpad) = 0

@@ -191,10 +191,14 @@ __global__ __launch_bounds__(kOpsBlock) void recon_epilogue_vec_kernel(const flo
 // element); the calibration then reads the result once more for the abs-max (4 B).  This kernel IS that add --
 // y[n][c][hw] += bias[c], the same single fp32 rounding -- and folds max |y| into the tensor's row while the values
 // are in registers, so pass 1 does not read conv outputs a second time.  kVec: HW % 4 == 0 and y 16-byte aligned.
+// relu_out != nullptr: the nn.ReLU that consumes this tensor is served in the same pass (r = y > 0 ? y : 0 with NaN kept,
+// torch's clamp_min), one more 4-byte write instead of a separate 8-byte pass.
+__device__ __forceinline__ float relu_like_torch(float v) { return v > 0.0f ? v : (v != v ? v : 0.0f); }
+
 template <bool kVec>
 __global__ __launch_bounds__(kOpsBlock) void bias_add_absmax_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                                     unsigned n_items, unsigned inner, unsigned C,
-                                                                    unsigned int* __restrict__ max_bits) {
+                                                                    unsigned int* __restrict__ max_bits, float* __restrict__ relu_out) {
     __shared__ float s_wave[kOpsBlock / kWave];
     float m = 0.0f;
     const unsigned stride = gridDim.x * kOpsBlock;
@@ -204,10 +208,16 @@ __global__ __launch_bounds__(kOpsBlock) void bias_add_absmax_kernel(float* __res
             f4v v = reinterpret_cast<f4v*>(y)[i];
             v.x += b; v.y += b; v.z += b; v.w += b;
             reinterpret_cast<f4v*>(y)[i] = v;
+            if (relu_out) {
+                f4v r;
+                r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
+                reinterpret_cast<f4v*>(relu_out)[i] = r;
+            }
             m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         } else {
             const float v = y[i] + b;
             y[i] = v;
+            if (relu_out) relu_out[i] = relu_like_torch(v);
             m = fmaxf(m, fabsf(v));
         }
     }
@@ -231,18 +241,24 @@ __global__ __launch_bounds__(kOpsBlock) void bias_add_absmax_kernel(float* __res
 __global__ __launch_bounds__(kOpsBlock) void add_absmax_kernel(const f4v* __restrict__ x, const f4v* __restrict__ y,
                                                                f4v* __restrict__ z, size_t nvec, const float* __restrict__ xs,
                                                                const float* __restrict__ ys, float* __restrict__ zs, unsigned tail,
-                                                               unsigned int* __restrict__ max_bits) {
+                                                               unsigned int* __restrict__ max_bits, float* __restrict__ relu_out) {
     __shared__ float s_wave[kOpsBlock / kWave];
     float m = 0.0f;
     const size_t stride = (size_t)gridDim.x * kOpsBlock;
     for (size_t i = (size_t)blockIdx.x * kOpsBlock + threadIdx.x; i < nvec; i += stride) {
         const f4v v = x[i] + y[i];
         z[i] = v;
+        if (relu_out) {
+            f4v r;
+            r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
+            reinterpret_cast<f4v*>(relu_out)[i] = r;
+        }
         m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     if (blockIdx.x == 0 && threadIdx.x < tail) {          // the last n % 4 elements
         const float v = xs[threadIdx.x] + ys[threadIdx.x];
         zs[threadIdx.x] = v;
+        if (relu_out) relu_out[(nvec << 2) + threadIdx.x] = relu_like_torch(v);
         m = fmaxf(m, fabsf(v));
     }
 #pragma unroll
@@ -355,7 +371,8 @@ extern "C" int fq_recon_epilogue_f32(const float* acc, const float* qbias, float
     return FQ_OK;
 }
 
-extern "C" int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C, int HW, float* max_inout, fq_stream_t stream) {
+extern "C" int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C, int HW, float* max_inout, float* relu_out,
+                                      fq_stream_t stream) {
     using namespace fq;
     if (N < 0 || C <= 0 || HW <= 0) return FQ_ERR_INVALID_ARG;
     const size_t n = (size_t)N * C * HW;
@@ -364,29 +381,31 @@ extern "C" int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C,
     if (n >= 0xffffffffULL) return FQ_ERR_UNSUPPORTED;               // 32-bit element index inside the kernel
     hipStream_t st = as_stream(stream);
     unsigned int* bits = reinterpret_cast<unsigned int*>(max_inout);
-    if ((HW & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15u) == 0) {
+    if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(relu_out)) & 15u) == 0) {
         const unsigned nvec = (unsigned)(n >> 2);
         hipLaunchKernelGGL(bias_add_absmax_kernel<true>, dim3(grid_for(nvec, 8)), dim3(kOpsBlock), 0, st, y, bias, nvec,
-                           (unsigned)(HW >> 2), (unsigned)C, bits);
+                           (unsigned)(HW >> 2), (unsigned)C, bits, relu_out);
     } else {
         hipLaunchKernelGGL(bias_add_absmax_kernel<false>, dim3(grid_for(n, 8)), dim3(kOpsBlock), 0, st, y, bias, (unsigned)n,
-                           (unsigned)HW, (unsigned)C, bits);
+                           (unsigned)HW, (unsigned)C, bits, relu_out);
     }
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }
 
-extern "C" int fq_add_absmax_f32(const float* x, const float* y, float* z, size_t n, float* max_inout, fq_stream_t stream) {
+extern "C" int fq_add_absmax_f32(const float* x, const float* y, float* z, size_t n, float* max_inout, float* relu_out,
+                                 fq_stream_t stream) {
     using namespace fq;
     if (n == 0) return FQ_OK;
     if (!x || !y || !z || !max_inout) return FQ_ERR_INVALID_ARG;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z)) & 15u)
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z) |
+         reinterpret_cast<uintptr_t>(relu_out)) & 15u)
         return FQ_ERR_INVALID_ARG;
     const size_t nvec = n >> 2;
     const unsigned tail = (unsigned)(n & 3u);
     hipLaunchKernelGGL(add_absmax_kernel, dim3(grid_for(nvec ? nvec : 1, 8)), dim3(kOpsBlock), 0, as_stream(stream),
                        reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
-                       x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, reinterpret_cast<unsigned int*>(max_inout));
+                       x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, reinterpret_cast<unsigned int*>(max_inout), relu_out);
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }

@@ -87,9 +87,9 @@ def lib():
     L.fq_conv2d_i8_resident.restype = ci
     L.fq_conv2d_i8_resident.argtypes = [vp, vp, vp, vp, vp] + [ci] * 17 + [vp]
     L.fq_bias_add_absmax_f32.restype = ci
-    L.fq_bias_add_absmax_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp]
+    L.fq_bias_add_absmax_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp]
     L.fq_add_absmax_f32.restype = ci
-    L.fq_add_absmax_f32.argtypes = [vp, vp, vp, sz, vp, vp]
+    L.fq_add_absmax_f32.argtypes = [vp, vp, vp, sz, vp, vp, vp]
     L.fq_conv2d_i8_stem.restype = ci
     L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
@@ -238,8 +238,16 @@ def kl_threshold(hist, want_curve=False):
     return (thr, curve) if want_curve else thr
 
 
-def bias_add_absmax(y, bias, max_dev, row):
-    """fq_bias_add_absmax_f32: y[n][c][...] += bias[c] in place and max_dev[row] = max(max_dev[row], max |y|)."""
+def _relu_ptr(relu_out, like):
+    if relu_out is None:
+        return None
+    assert relu_out.shape == like.shape and relu_out.is_contiguous() and relu_out.dtype == torch.float32 and relu_out.is_cuda
+    return relu_out.data_ptr()
+
+
+def bias_add_absmax(y, bias, max_dev, row, relu_out=None):
+    """fq_bias_add_absmax_f32: y[n][c][...] += bias[c] in place and max_dev[row] = max(max_dev[row], max |y|);
+    relu_out (optional, same shape): also receives max(y, 0)."""
     _need_cuda(y, torch.float32, "fq_bias_add_absmax_f32")
     _need_cuda(bias, torch.float32, "fq_bias_add_absmax_f32")
     _need_cuda(max_dev, torch.float32, "fq_bias_add_absmax_f32")
@@ -247,13 +255,14 @@ def bias_add_absmax(y, bias, max_dev, row):
     assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
     N, C = int(y.shape[0]), int(y.shape[1])
     hw = y.numel() // max(N * C, 1)
-    _check(lib().fq_bias_add_absmax_f32(y.data_ptr(), bias.data_ptr(), N, C, hw, max_dev.data_ptr() + 4 * int(row), _stream(y)),
-           "fq_bias_add_absmax_f32")
+    _check(lib().fq_bias_add_absmax_f32(y.data_ptr(), bias.data_ptr(), N, C, hw, max_dev.data_ptr() + 4 * int(row),
+                                        _relu_ptr(relu_out, y), _stream(y)), "fq_bias_add_absmax_f32")
     return y
 
 
-def add_absmax(x, y, max_dev, row, out=None):
-    """fq_add_absmax_f32: returns x + y (in `out` if given) and folds max |x + y| into max_dev[row]."""
+def add_absmax(x, y, max_dev, row, out=None, relu_out=None):
+    """fq_add_absmax_f32: returns x + y (in `out` if given) and folds max |x + y| into max_dev[row]; relu_out (optional):
+    also receives max(x + y, 0)."""
     _need_cuda(x, torch.float32, "fq_add_absmax_f32")
     _need_cuda(y, torch.float32, "fq_add_absmax_f32")
     _need_cuda(max_dev, torch.float32, "fq_add_absmax_f32")
@@ -261,7 +270,7 @@ def add_absmax(x, y, max_dev, row, out=None):
     z = torch.empty_like(x) if out is None else out
     assert z.shape == x.shape and z.is_contiguous() and z.dtype == torch.float32 and z.is_cuda
     _check(lib().fq_add_absmax_f32(x.data_ptr(), y.data_ptr(), z.data_ptr(), x.numel(), max_dev.data_ptr() + 4 * int(row),
-                                   _stream(x)), "fq_add_absmax_f32")
+                                   _relu_ptr(relu_out, x), _stream(x)), "fq_add_absmax_f32")
     return z
 
 

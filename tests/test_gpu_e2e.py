@@ -282,6 +282,7 @@ def test_fused_bias_absmax_does_not_change_the_tables(g3, fuse):
     assert fused == (n_convs if fuse else 0) and n_convs > 0
     n_elt = sum(1 for m in model.modules() if type(m).__name__ == "Eltwise")
     assert q.timings["fused_add_absmax_eltwise"] == (n_elt if fuse else 0) and n_elt > 0
+    assert (q.timings["fused_relus"] > 0) == fuse
 
 
 def test_bias_add_absmax_kernel_equals_torch():
@@ -298,6 +299,11 @@ def test_bias_add_absmax_kernel_equals_torch():
         mx[1] = 1e9                                                                  # a running maximum is kept
         _native.bias_add_absmax(y.clone(), b, mx, 1)
         assert float(mx[1]) == 1e9
+        y2 = (ref - b.view(1, -1, *([1] * (y.dim() - 2)))).contiguous()              # with the ReLU that follows
+        want = y2 + b.view(1, -1, *([1] * (y.dim() - 2)))
+        r = torch.empty_like(y2)
+        _native.bias_add_absmax(y2, b, mx, 0, relu_out=r)
+        assert torch.equal(y2, want) and torch.equal(r, torch.relu(want))
 
 
 def test_add_absmax_kernel_equals_torch():
@@ -309,3 +315,6 @@ def test_add_absmax_kernel_equals_torch():
         z = _native.add_absmax(x, y, mx, 1)
         ref = x + y
         assert torch.equal(z, ref) and float(mx[1]) == float(ref.abs().max()) and float(mx[0]) == 0.5
+        r = torch.empty_like(x)
+        z = _native.add_absmax(x, y, mx, 1, relu_out=r)
+        assert torch.equal(z, ref) and torch.equal(r, torch.relu(ref))
