@@ -407,8 +407,8 @@ class Quantity(object):
                 last, ready = ctl["last_out"], ctl["relu_ready"]
                 if last is not None and torch.is_tensor(x) and last[1] == id(x):
                     ctl["relu_after"][last[0]] = m           # (re)learned on every call: who feeds this ReLU
-                if ready is not None and ready[0] == id(x) and ready[2] is m:
-                    ctl["relu_ready"] = None
+                if ready is not None and ready[0] == id(x) and ready[2] is m and ready[3] == x._version:
+                    ctl["relu_ready"] = None                 # (same tensor object, not written to since)
                     return ready[1]
                 return torch.nn.functional.relu(x)
             m.forward = forward
@@ -430,7 +430,7 @@ class Quantity(object):
                 self.fuse_relu = False
                 return
             m.__dict__[_RELU_VERIFIED] = True
-        ctl["relu_ready"] = (id(output), r, relu)
+        ctl["relu_ready"] = (id(output), r, relu, output._version)
         ctl["fused_relus"].add(relu)
 
     def _finish_fused_conv(self, module, pending, key, output):

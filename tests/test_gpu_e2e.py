@@ -318,3 +318,35 @@ def test_add_absmax_kernel_equals_torch():
         r = torch.empty_like(x)
         z = _native.add_absmax(x, y, mx, 1, relu_out=r)
         assert torch.equal(z, ref) and torch.equal(r, torch.relu(ref))
+
+
+class _TouchedBeforeRelu(torch.nn.Module):
+    """conv -> in-place scaling by plain tensor code -> ReLU: the ReLU must see the scaled values, not a result the
+    conv's fused kernel prepared before the scaling."""
+
+    def __init__(self):
+        super(_TouchedBeforeRelu, self).__init__()
+        from common.quantity import Eltwise
+        torch.manual_seed(8)
+        self.c1 = torch.nn.Conv2d(3, 8, 3, padding=1)
+        self.r1 = torch.nn.ReLU()
+        self.c2 = torch.nn.Conv2d(8, 8, 3, padding=1)
+        self.add = Eltwise()
+
+    def forward(self, x):
+        a = self.c1(x)
+        a.mul_(-1.5)                                       # same tensor object, new values
+        b = self.r1(a)
+        return self.add(self.c2(b), b)
+
+
+def test_a_relu_fed_by_a_tensor_that_was_modified_in_between_is_not_served_from_the_fused_kernel():
+    from tools import Quantity
+    tables = []
+    for fuse in (False, True):
+        with product_workdir(device="gpu", max_cali_img_num=3, input_shape="1,3,16,16") as tmp:
+            q = Quantity(_TouchedBeforeRelu().eval().cuda())
+            q.fuse_bias_absmax = fuse
+            q.activation_quantize(cases.calib_batches(4, (4, 3, 16, 16)))
+            tables.append(open(os.path.join(tmp, "test", "workdir", "feat.table")).read())
+    assert tables[0] == tables[1]
