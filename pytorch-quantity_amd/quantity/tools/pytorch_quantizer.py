@@ -405,9 +405,9 @@ class Quantity(object):
 
             def forward(x, m=m):
                 last, ready = ctl["last_out"], ctl["relu_ready"]
-                if last is not None and torch.is_tensor(x) and last[1] == id(x):
+                if last is not None and last[1] is x:
                     ctl["relu_after"][last[0]] = m           # (re)learned on every call: who feeds this ReLU
-                if ready is not None and ready[0] == id(x) and ready[2] is m and ready[3] == x._version:
+                if ready is not None and ready[0] is x and ready[2] is m and ready[3] == x._version:
                     ctl["relu_ready"] = None                 # (same tensor object, not written to since)
                     return ready[1]
                 return torch.nn.functional.relu(x)
@@ -430,7 +430,7 @@ class Quantity(object):
                 self.fuse_relu = False
                 return
             m.__dict__[_RELU_VERIFIED] = True
-        ctl["relu_ready"] = (id(output), r, relu, output._version)
+        ctl["relu_ready"] = (output, r, relu, output._version)      # holds the tensor itself: identity, not a reusable id
         ctl["fused_relus"].add(relu)
 
     def _finish_fused_conv(self, module, pending, key, output):
@@ -871,9 +871,10 @@ class Quantity(object):
                     eager.add("image", out_feat["image"])
             state["n"] += 1
             key = "%s_%i" % (type(module).__name__, state["n"])
+            ctl["relu_ready"] = None        # a ReLU result prepared by the previous module is for the very next forward only
             pending_bias, ctl["fuse_bias"] = ctl.get("fuse_bias"), None
             fused = pending_bias is not None and self._finish_fused_conv(module, pending_bias, key if key in cared else None, output)
-            ctl["last_out"] = (module, id(output)) if torch.is_tensor(output) else None
+            ctl["last_out"] = (module, output) if torch.is_tensor(output) else None
             if key in cared:
                 out_feat[key] = output.detach()
                 if eager is not None:
