@@ -297,7 +297,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.backends.cudnn.benchmark = False      # MIOpen immediate mode: same kernels here, no multi-second find
+    torch.backends.cudnn.benchmark = os.environ.get("FQ_BENCH_MIOPEN_FIND", "0") == "1"   # default: MIOpen immediate mode (find mode measured: see DESIGN.md)
     from common.quantity import _native
     from tools import Quantity, Reconstruction
     _native.lib()
