@@ -1,36 +1,44 @@
 #!/usr/bin/env python3
 """Headline benchmark: KL calibration throughput of a fabu ResNet-50 @224^2 on MI355X
-(BASELINE.json metric "calibration images/sec + int8-sim images/sec", config[1] at N=1).
+(BASELINE.json metric "calibration images/sec + int8-sim images/sec", configs[1] at N=1).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one calibration batch taken through the whole hot path: forward -> segmented abs-max
-(pass 1), forward -> 2048-bin histograms (pass 2); the timed region is ONE complete
-Quantity.activation_quantize() over K batches per GPU: both passes, the MAX / SUM all-reduces, the
-KL threshold sweep for all 71 tensors and the feat.table write.  Inputs are synthetic fp32 images
-generated on the device BEFORE the timed region.  value = images processed by all ranks / wall time
-(max over ranks, bracketed by barrier + synchronize).  Weak scaling: K batches per GPU.
+WORKLOAD.  `--images` (default 5120 = BASELINE configs[1]'s "5k") calibration images PER GPU; --steps only decides how
+they are cut into batches (batch = images / steps: 256 at the driver's 20 steps, 128 at 40), never how many there are.
+`--total-images T` instead fixes the WHOLE job (strong scaling: T / N images per GPU, "scaling": "strong";
+`--gpus 8 --total-images 50000` is BASELINE configs[3] verbatim).
+A "step" is one calibration batch taken through the whole hot path: forward -> abs-max (pass 1), forward -> 2048-bin
+histograms (pass 2); the timed region is ONE complete Quantity.activation_quantize() over the K batches of every GPU:
+both passes, the MAX / SUM all-reduces, the KL threshold sweep of all 71 rows and the feat.table write.  Inputs are
+synthetic fp32 images generated on the device BEFORE the timed region.  value = images processed by all ranks / wall
+time (max over ranks, bracketed by barrier + synchronize).
 
 The JSON line also carries
-  roofline     : the dominant hand-written kernel (hist2048_seg), algorithmic bytes (4 B x elements
-                 per launch) / its mean launch duration measured with HIP events on the launch stream;
-  cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded
-                 sample on this box's host cores, scaled to the same workload (rank 0, N=1 only);
-  (the forward-throughput keys below run --int8-batch images per forward, default 256: two calibration batches)
-  int8_sim_images_per_s : ReconModel forward throughput with resident integer activations
-                     (common.quantity.resident.enable(): int8/int16 NHWC between layers; logits checked
-                     bit-identical to the fp32-boundary model in the same run, see int8_sim_resident);
-  int8_sim_fp32_boundary_images_per_s : the same ReconModel with the reference's fp32 NCHW tensor at
-                     every module boundary (the drop-in default);
+  value_cold   : the same workload in a FRESH process whose allocator pool is empty when the clock starts (the engine's
+                 96 GB cold-process cache rule, every hipMalloc inside the clock) -- what a one-shot calibration script
+                 gets; `value` itself runs in a process that holds a warm pool (a long-running calibration service);
+  roofline     : the dominant hand-written kernel (hist2048_seg), algorithmic bytes (4 B x elements per launch) / its
+                 mean launch duration measured with HIP events on the launch stream inside the timed region;
+                 `traffic` is STATIC (PMC counters of the committed profile of this configuration), and says so;
+  roofline_bias_add_absmax / roofline_add_absmax : the two kernels pass 1's maxima ride on;
+  cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded sample on this
+                 box's host cores at 1 thread and at all cores, scaled to the same workload (rank 0, N=1 only);
+  (the forward-throughput keys below run --int8-batch images per forward, default 256)
+  int8_sim_images_per_s : ReconModel forward throughput with resident integer activations (logits checked
+                 bit-identical to the fp32-boundary model in the same run, see int8_sim_resident);
+  int8_sim_fp32_boundary_images_per_s : the same ReconModel with the reference's fp32 NCHW module boundaries;
   int8_sim_hipgraph_images_per_s : the resident forward replayed as one HIP graph (input copy included);
   roofline_int8_conv : 2 x MACs of the model / summed durations of the int8 conv launches of one resident forward
-                     (HIP events), against the 5 000 TOP/s dense int8 MFMA peak;
-  fakequant_images_per_s / float_forward_images_per_s : ReconTest and the float model.
+                 (HIP events), against the 5 000 TOP/s dense int8 MFMA peak;
+  fakequant_images_per_s / float_forward_images_per_s : ReconTest and the float model;
+  per_channel_calibration / roofline_per_channel : the per-(tensor, channel) extension.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
@@ -45,8 +53,8 @@ sys.path.insert(0, ROOT)
 
 with open(os.path.join(ROOT, "BASELINE.json")) as _fh:
     BASELINE_METRIC = json.load(_fh)["metric"]          # the reference's headline metric, verbatim
-R50_CARED_ELEMS_PER_IMAGE = 16784872        # image + 53 conv + fc + 16 Eltwise outputs @224^2
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+INT8_PEAK_TOPS = 5000.0                      # dense int8 MFMA peak (2 x the BF16 rate)
 
 
 class DeviceBatches(object):
@@ -110,27 +118,76 @@ def build_model(name, hw, device):
     return model.to(device)
 
 
-class KernelTimer(object):
-    """Wraps a _native entry point and brackets every call with HIP events on the launch stream
-    (torch's current stream is the stream the C ABI is handed)."""
+# ----------------------------------------------------------------------------------------------------------------------
+# collectives of the bench itself (the calibration's own two all-reduces live in common.quantity._collectives)
+# ----------------------------------------------------------------------------------------------------------------------
+def _dist():
+    import torch.distributed as dist
+    return dist if (dist.is_available() and dist.is_initialized()) else None
 
-    def __init__(self, native, name):
-        self.native, self.name = native, name
+
+def all_ok(local_ok, device=None):
+    """True on every rank iff `local_ok` is true on every rank (one MIN all-reduce).  Every rank must call it: errors
+    are never handled by skipping a collective -- a rank that failed locally reports it here and all ranks leave the
+    section together."""
+    dist = _dist()
+    if dist is None:
+        return bool(local_ok)
+    t = torch.tensor([1 if local_ok else 0], dtype=torch.int32, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return bool(int(t.item()))
+
+
+def run_section(fn, device=None):
+    """Run rank-LOCAL work `fn()` (no collectives inside) and agree on the outcome: returns (ok_everywhere, result or
+    None, repr of the local error or None)."""
+    result, err = None, None
+    try:
+        result = fn()
+    except Exception as e:           # local only; the agreement below is the collective
+        err = repr(e)
+    return all_ok(err is None, device), result, err
+
+
+def share_tables(workdir, names=("feat.table", "weight.table")):
+    """Quantity writes its tables on rank 0 only, into rank 0's own scratch directory; the other ranks need the text to
+    rebuild the model (Reconstruction.get_quantity_information reads ./workdir/*.table).  Rank 0 broadcasts the files,
+    every other rank writes them into ITS workdir.  A collective: every rank calls it."""
+    dist = _dist()
+    if dist is None:
+        return
+    rank = dist.get_rank()
+    payload = [None]
+    if rank == 0:
+        payload = [{n: open(os.path.join(workdir, n)).read() for n in names if os.path.isfile(os.path.join(workdir, n))}]
+    dist.broadcast_object_list(payload, src=0)
+    if rank != 0:
+        os.makedirs(workdir, exist_ok=True)
+        for n, text in payload[0].items():
+            with open(os.path.join(workdir, n), "w") as fh:
+                fh.write(text)
+
+
+class CallTimer(object):
+    """Wraps a _native entry point and brackets every call with HIP events on the launch stream (torch's current
+    stream is the stream the C ABI is handed).  bytes_fn(args, kwargs) -> algorithmic bytes of that launch."""
+
+    def __init__(self, native, name, bytes_fn):
+        self.native, self.name, self.bytes_fn = native, name, bytes_fn
         self.orig = getattr(native, name)
-        self.events = []
-        self.elems = []
+        self.events, self.bytes = [], []
         self.enabled = False
 
     def __enter__(self):
-        def wrapped(tensors, rows, *rest):
+        def wrapped(*a, **k):
             if not self.enabled:
-                return self.orig(tensors, rows, *rest)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            r = self.orig(tensors, rows, *rest)
-            b.record()
-            self.events.append((a, b))
-            self.elems.append(sum(int(t.numel()) for t in tensors))
+                return self.orig(*a, **k)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = self.orig(*a, **k)
+            e1.record()
+            self.events.append((e0, e1))
+            self.bytes.append(float(self.bytes_fn(a, k)))
             return r
         setattr(self.native, self.name, wrapped)
         return self
@@ -141,8 +198,33 @@ class KernelTimer(object):
     def summary(self):
         if not self.events:
             return None
-        ms = [a.elapsed_time(b) for a, b in self.events]
-        return {"launches": len(ms), "mean_ms": float(np.mean(ms)), "bytes_per_launch": 4.0 * float(np.mean(self.elems))}
+        ms = np.array([a.elapsed_time(b) for a, b in self.events])
+        by = np.array(self.bytes)
+        return {"launches": int(len(ms)), "mean_ms": float(ms.mean()), "bytes_per_launch": float(by.mean()),
+                "gbs": float(by.sum() / (ms.sum() * 1e-3) / 1e9)}
+
+
+def _seg_bytes(a, k):
+    return 4.0 * sum(int(t.numel()) for t in a[0])
+
+
+def _bias_add_bytes(a, k):          # y += bias[c] in place (4 B read + 4 B written) (+ 4 B for the fused ReLU's copy)
+    relu = k.get("relu_out") if "relu_out" in k else (a[4] if len(a) > 4 else None)
+    return (8.0 + (4.0 if relu is not None else 0.0)) * int(a[0].numel())
+
+
+def _add_bytes(a, k):               # z = x + y (8 B read + 4 B written) (+ 4 B for the fused ReLU's copy)
+    relu = k.get("relu_out") if "relu_out" in k else (a[5] if len(a) > 5 else None)
+    return (12.0 + (4.0 if relu is not None else 0.0)) * int(a[0].numel())
+
+
+def hbm_roofline(kernel, s, extra=None):
+    ach = s["bytes_per_launch"] / (s["mean_ms"] * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": kernel, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(ach / HBM_PEAK_GBS, 4), "launches": s["launches"], "mean_launch_ms": round(s["mean_ms"], 4),
+           "algorithmic_bytes_per_launch": s["bytes_per_launch"]}
+    out.update(extra or {})
+    return out
 
 
 def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
@@ -187,21 +269,18 @@ def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
     ms = sum(a.elapsed_time(b) for a, b in events) / forwards
     achieved = 2.0 * macs[0] / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "conv2d_i8 / conv2d_i8_dma / stem_conv_i8 (all integer conv + linear launches of one forward)",
-            "achieved": round(achieved, 1), "peak": 5000.0, "unit": "TOP/s", "frac": round(achieved / 5000.0, 4),
+            "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(achieved / INT8_PEAK_TOPS, 4),
             "launches_per_forward": len(events) // forwards, "ms_per_forward": round(ms, 4), "images_per_forward": int(batch.shape[0]),
-            "gmac_per_image": round(macs[0] / int(batch.shape[0]) / 1e9, 3),
-            "note": "latency / output-traffic bound at these layer sizes (DESIGN.md 5b); SQ_VALU_MFMA_BUSY_CYCLES 21 % on the "
-                    "3x3 256->256 14x14 layer (profiles/r01j_conv_pmc_256x14x14_3x3.txt)"}
+            "gmac_per_image": round(macs[0] / int(batch.shape[0]) / 1e9, 3)}
 
 
-def cpu_baseline(model_cpu_ctor, sample_images, hw, n_images_full, q, log):
-    """Bounded CPU run of the same workload: torch-CPU forward (what the reference does) + the CPU
-    oracle for abs-max / histogram / KL, scaled to the full image count.  Reported, not a target."""
+def cpu_baseline(model_cpu_ctor, hw, n_images_full, q, log):
+    """Bounded CPU run of the same workload: torch-CPU forward (what the reference does) + the CPU oracle for abs-max /
+    histogram / KL, at ONE thread and at all host cores (<= 32), each scaled to the full image count.  Reported, not a
+    target."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import fq_oracle as orc
     orc.build()
-    cores = min(os.cpu_count() or 1, 32)          # beyond one socket's worth oneDNN only gets slower
-    torch.set_num_threads(cores)
     model = model_cpu_ctor()
     names = ["image"] + list(q.net_info.keys())
     feats, hooks = {}, []
@@ -222,50 +301,144 @@ def cpu_baseline(model_cpu_ctor, sample_images, hw, n_images_full, q, log):
     for m in model.modules():
         if type(m).__name__ in q._all_op_type:
             hooks.append(m.register_forward_hook(hook))
-    x = torch.randn(sample_images, 3, hw, hw, generator=torch.Generator().manual_seed(1234))
-    pool = ThreadPoolExecutor(cores)
-    with torch.no_grad():
-        model(x[:1])                                                 # untimed: oneDNN primitive creation
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        model(x)                                                     # pass 1 forward
-    arrs = {n: feats[n].numpy().ravel() for n in names}
-    maxs = dict(zip(names, pool.map(lambda n: orc.absmax(arrs[n]), names)))
-    ivs = {n: orc.interval(maxs[n]) for n in names}
-    with torch.no_grad():
-        model(x)                                                     # pass 2 forward
-    arrs = {n: feats[n].numpy().ravel() for n in names}
-    hists = dict(zip(names, pool.map(lambda n: orc.hist2048(arrs[n], ivs[n]), names)))
-    t_img = (time.perf_counter() - t0) / sample_images
-    t1 = time.perf_counter()
-    list(pool.map(lambda n: orc.kl_threshold(orc.normalize(hists[n])), names))
-    t_kl = time.perf_counter() - t1
+
+    def measure(cores, sample_images):
+        torch.set_num_threads(cores)
+        pool = ThreadPoolExecutor(cores)
+        x = torch.randn(sample_images, 3, hw, hw, generator=torch.Generator().manual_seed(1234))
+        with torch.no_grad():
+            model(x[:1])                                                 # untimed: oneDNN primitive creation
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            model(x)                                                     # pass 1 forward
+        arrs = {n: feats[n].numpy().ravel() for n in names}
+        maxs = dict(zip(names, pool.map(lambda n: orc.absmax(arrs[n]), names)))
+        ivs = {n: orc.interval(maxs[n]) for n in names}
+        with torch.no_grad():
+            model(x)                                                     # pass 2 forward
+        arrs = {n: feats[n].numpy().ravel() for n in names}
+        hists = dict(zip(names, pool.map(lambda n: orc.hist2048(arrs[n], ivs[n]), names)))
+        t_img = (time.perf_counter() - t0) / sample_images
+        t1 = time.perf_counter()
+        list(pool.map(lambda n: orc.kl_threshold(orc.normalize(hists[n])), names))
+        t_kl = time.perf_counter() - t1
+        pool.shutdown()
+        log("cpu_baseline[%d threads]: %.3f s/image (2 forwards + absmax + hist), KL %.2f s for %d tensors"
+            % (cores, t_img, t_kl, len(names)))
+        return {"value": round(n_images_full / (n_images_full * t_img + t_kl), 3), "cores": cores,
+                "s_per_image": round(t_img, 4), "kl_sweep_s": round(t_kl, 3), "sample_images": sample_images}
+
+    many = min(os.cpu_count() or 1, 32)          # beyond one socket's worth oneDNN only gets slower
+    one = measure(1, 2)
+    full = measure(many, 8)
     for h in hooks:
         h.remove()
-    value = n_images_full / (n_images_full * t_img + t_kl)
-    log("cpu_baseline: %.3f s/image (2 forwards + absmax + hist), KL %.2f s for %d tensors" % (t_img, t_kl, len(names)))
-    return {"value": round(value, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d images through torch-CPU forward x2 + oracle absmax/hist2048, + oracle KL sweep of all %d "
-                      "tensors once; scaled to %d images" % (sample_images, len(names), n_images_full)}
+    return {"value": full["value"], "unit": "images/s", "cores": full["cores"], "kind": "port",
+            "single_thread": {"value": one["value"], "unit": "images/s", "cores": 1, "s_per_image": one["s_per_image"],
+                              "kl_sweep_s": one["kl_sweep_s"]},
+            "all_cores": full,
+            "sample": "%d images (all cores) / %d images (1 thread) through torch-CPU forward x2 + oracle absmax/hist2048, "
+                      "+ one oracle KL sweep of all %d rows; scaled to %d images" % (full["sample_images"], one["sample_images"],
+                                                                                     len(names), n_images_full)}
 
 
-def main():
+# ----------------------------------------------------------------------------------------------------------------------
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)      # 40 x 128 = 5 120 images: BASELINE configs[1] ("5k")
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--images", type=int, default=5120,
+                    help="calibration images PER GPU (weak scaling); BASELINE configs[1] = 5k")
+    ap.add_argument("--total-images", type=int, default=0,
+                    help="calibration images of the WHOLE job (strong scaling; overrides --images): "
+                         "--gpus 8 --total-images 50000 is BASELINE configs[3]")
+    ap.add_argument("--batch", type=int, default=0, help="images per step; default: images per GPU / steps")
     ap.add_argument("--model", default="r50", choices=["r50", "r101"])
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--host-inputs", action="store_true",
                     help="hand the calibrator pageable HOST batches (PCIe-inclusive rate; never the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-recon", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the fresh-process run behind value_cold")
+    ap.add_argument("--cold-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--int8-batch", type=int, default=256,
-                    help="images per forward of the int8-sim / fake-quant throughput section (resident int8-sim forward on "
-                         "one MI355X: 62 k images/s at 128, 73 k at 256, 76 k at 512)")
+                    help="images per forward of the int8-sim / fake-quant throughput section")
     ap.add_argument("--no-per-channel", action="store_true")
     args = ap.parse_args()
+    world = max(args.gpus, 1)
+    per_gpu = args.images if not args.total_images else -(-args.total_images // world)
+    if args.batch <= 0:
+        args.batch = max(1, -(-per_gpu // max(args.steps, 1)))
+    args.scaling = "strong" if args.total_images else "weak"
+    args.images_per_gpu = args.batch * args.steps            # what is actually run (== per_gpu when steps divides it)
+    return args
+
+
+def cold_child(args):
+    """Fresh process, N = 1: (1) the very first activation_quantize() of the process, nothing warmed up at all (MIOpen's
+    first-use solver search and code loading inside the clock): `one_shot_images_per_s`; (2) the allocator pool handed
+    back to the driver (empty_cache), then the same workload again: every hipMalloc inside the clock, the engine's
+    cold-process cache rule (96 GB), code and MIOpen warm: `value_cold`.  Prints one JSON line."""
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    from common.quantity import _native
+    from tools import Quantity
+    _native.lib()
+    K, B, HW = args.steps, args.batch, args.image
+    shape = "1,3,%d,%d" % (HW, HW)
+    real_stdout, sys.stdout = sys.stdout, open(os.devnull, "w")
+    model = build_model(args.model, HW, device)
+    data = DeviceBatches(K, B, HW, 0, 1, device)
+    out = {}
+    for tag in ("one_shot", "cold"):
+        make_workdir(K - 1, shape, 0)
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        torch.cuda.synchronize()
+        reserved0 = torch.cuda.memory_reserved()
+        q = Quantity(model)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        q.activation_quantize(data)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[tag] = {"images_per_s": round(K * B / dt, 1), "seconds": round(dt, 4),
+                    "reserved_before_gb": round(reserved0 / 2 ** 30, 2),
+                    "max_reserved_gb": round(torch.cuda.max_memory_reserved() / 2 ** 30, 1),
+                    "cache_bytes": q.timings.get("cache_bytes"), "cache_plan": q.timings.get("cache_plan"),
+                    "pass1_s": round(q.timings["pass1_s"], 4), "pass2_s": round(q.timings["pass2_s"], 4)}
+        del q
+    sys.stdout = real_stdout
+    os.dup2(stdout_fd, 1)
+    print(json.dumps(out), flush=True)
+
+
+def run_cold_child(args, log):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cold-child", "--gpus", "1", "--steps", str(args.steps),
+           "--batch", str(args.batch), "--model", args.model, "--image", str(args.image)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "FQ_ACT_CACHE_GB")}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            return {"error": "cold child rc %d: %s" % (r.returncode, r.stderr[-400:])}
+        line = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][-1]
+        out = json.loads(line)
+        out["process_wall_s"] = round(time.perf_counter() - t0, 1)
+        log("cold child:", out)
+        return out
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def main():
+    args = parse_args()
+    if args.cold_child:
+        return cold_child(args)
 
     # stdout carries exactly ONE line, the JSON.  Native libraries write there too (RCCL prints a version
     # banner on init), so file descriptor 1 itself is parked on /dev/null until the result is ready.
@@ -278,6 +451,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+
+    def log(*a):
+        if rank == 0:
+            print(*a, file=sys.stderr, flush=True)
+
+    # the fresh-process run goes FIRST, before this process touches the GPU: it needs the device's memory to itself
+    cold = None
+    if world == 1 and not args.no_cold and not args.host_inputs:
+        cold = run_cold_child(args, log)
+
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -287,17 +470,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)                  # backend nccl = RCCL on ROCm
 
-    def log(*a):
-        if rank == 0:
-            print(*a, file=sys.stderr, flush=True)
-
     def barrier():
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    torch.backends.cudnn.benchmark = os.environ.get("FQ_BENCH_MIOPEN_FIND", "0") == "1"   # default: MIOpen immediate mode (find mode measured: see DESIGN.md)
+    torch.backends.cudnn.benchmark = os.environ.get("FQ_BENCH_MIOPEN_FIND", "0") == "1"   # MIOpen find mode: see DESIGN.md
     from common.quantity import _native
     from tools import Quantity, Reconstruction
     _native.lib()
@@ -309,7 +488,7 @@ def main():
     sys.stdout = devnull                                   # the drop-in prints like the reference does (merge_bn too):
     model = build_model(args.model, HW, device)            # stdout must carry exactly one JSON line
 
-    # ---- warmup: W batches per GPU through the same path (MIOpen algo search, RCCL init, code load)
+    # ---- warmup: W batches per GPU through the same path (MIOpen first-use solver search, RCCL init, code load)
     if W > 0:
         make_workdir(W * world - 1, shape, local_rank)
         warm = DeviceBatches(W * world, B, HW, rank, world, device)
@@ -318,8 +497,8 @@ def main():
         del warm
         # Size the caching allocator's pool for the device before the clock starts: 80 % of HBM (288 GB per MI355X),
         # as a long-running calibration service would hold it.  The timed region then keeps pass 1's activations for
-        # pass 2 in that pool (phases_s.cache_bytes) instead of paying 10-30 ms per GB of fresh hipMalloc; a cold
-        # one-shot process keeps the engine's 96 GB rule (tools/pytorch_quantizer.py:_activation_cache_budget).
+        # pass 2 in that pool (phases_s.cache_bytes) instead of paying 10-30 ms per GB of fresh hipMalloc; what a cold
+        # one-shot process gets (the engine's 96 GB rule, allocation inside the clock) is `value_cold`.
         grow = wq._activation_cache_budget()
         if grow > 0 and "FQ_ACT_CACHE_GB" not in os.environ:
             free_b, total_b = torch.cuda.mem_get_info()
@@ -336,8 +515,9 @@ def main():
     data = DeviceBatches(K * world, B, HW, rank, world, device, on_host=args.host_inputs)
     q = Quantity(model)
     q.profile_phases = True
-    with KernelTimer(_native, "hist2048_seg") as kt_hist, KernelTimer(_native, "absmax_seg") as kt_max:
-        kt_hist.enabled = kt_max.enabled = True
+    cache_budget = q._activation_cache_budget()            # per rank: every rank budgets its own GPU's pool
+    with CallTimer(_native, "hist2048_seg", _seg_bytes) as kt_hist:
+        kt_hist.enabled = True
         barrier()
         t0 = time.perf_counter()
         q.activation_quantize(data)
@@ -349,56 +529,89 @@ def main():
     elapsed = float(t.item())
     images = K * world * B
     value = images / elapsed
-    hist_s, max_s = kt_hist.summary(), kt_max.summary()
+    hist_s = kt_hist.summary()
     timings = dict(q.timings)
     timings["max_reserved_gb"] = round(torch.cuda.max_memory_reserved() / 2 ** 30, 1)
+    timings["cache_budget_bytes_this_rank"] = int(cache_budget)
     feat_table = open("./workdir/feat.table").read() if rank == 0 else ""
+    rows = len(q.net_info) + 1
 
     result = {
         "metric": BASELINE_METRIC,
-        "metric_note": "value = calibration images/s (both passes + KL sweep + feat.table, end to end); "
-                       "int8-sim images/s is reported beside it as int8_sim_images_per_s (resident integer activations, logits bit-identical "
-                       "to int8_sim_fp32_boundary_images_per_s, the reference's module-boundary form)",
+        "metric_note": "value = calibration images/s (both passes + KL sweep + feat.table, end to end) in a process that holds a "
+                       "warm allocator pool; value_cold = the same workload in a fresh process (allocation inside the clock); "
+                       "int8-sim images/s is reported beside it as int8_sim_images_per_s (resident integer activations, logits "
+                       "bit-identical to int8_sim_fp32_boundary_images_per_s, the reference's module-boundary form)",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host-resident, PCIe inclusive)" if args.host_inputs else ""),
         "config": {"workload": "fabu ResNet-%s per-tensor KL calibration, %d synthetic 3x%dx%d images per GPU "
-                               "(batch %d x %d steps), %d histogram rows x 2048 bins" %
-                               ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K, len(q.net_info) + 1),
-                   "batch": B, "images_total": images, "parallelism": "dp%d" % world,
+                               "(batch %d x %d steps), %d images in the whole job, %d histogram rows x 2048 bins" %
+                               ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K, images, rows),
+                   "batch": B, "images_per_gpu": K * B, "images_total": images, "parallelism": "dp%d" % world,
+                   "sharding": "batch i -> rank i %% %d; one MAX all-reduce of fp32[%d] after pass 1, one SUM all-reduce of "
+                               "int64[%d] after pass 2 (RCCL); KL replicated; rank 0 writes feat.table" % (world, rows, rows * 2048),
                    "activation_cache": "pass-1 activations kept in a warm allocator pool (80 % of HBM, grown during warm-up); "
+                                       "budgeted PER RANK from that rank's own pool (phases_s.cache_budget_bytes_this_rank), "
                                        "bytes used: phases_s.cache_bytes",
                    "int8_sim_images_per_forward": args.int8_batch},
         "phases_s": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
     }
-    traffic = None
+    if cold is not None:
+        if "cold" in cold:
+            result["value_cold"] = cold["cold"]["images_per_s"]
+            result["cold_process"] = {"what": "fresh process, N=1, same workload; value_cold: allocator pool empty when the clock "
+                                              "starts (code + MIOpen warm from the process's first run), engine's 96 GB cold rule; "
+                                              "one_shot: the process's very first call, nothing warmed (MIOpen first-use solver "
+                                              "search, code load and allocation inside the clock)",
+                                      "cold": cold["cold"], "one_shot": cold.get("one_shot"),
+                                      "process_wall_s": cold.get("process_wall_s")}
+        else:
+            result["value_cold"] = None
+            result["cold_process"] = cold
+    traffic, traffic_src = None, None
     try:        # HBM bytes per launch from the PMC counters of the committed profile of this same configuration
         with open(os.path.join(ROOT, "profiles", "traffic_hist2048.json")) as fh:
             tj = json.load(fh)
-        if (tj["batch"], tj["model"], tj["image"]) == (B, args.model, HW):
-            traffic = tj["hbm_bytes_per_launch"]
+        for ent in (tj if isinstance(tj, list) else [tj]):
+            if (ent["batch"], ent["model"], ent["image"]) == (B, args.model, HW):
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = "static: %s (rocprofv3 --pmc of this configuration, not measured in this run)" % ent.get(
+                    "source", "profiles/traffic_hist2048.json")
     except (OSError, KeyError, ValueError):
         pass
     if hist_s:
-        ach = hist_s["bytes_per_launch"] / (hist_s["mean_ms"] * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": "hist2048_seg_kernel", "achieved": round(ach, 1),
-                              "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                              "traffic": traffic, "launches": hist_s["launches"],
-                              "mean_launch_ms": round(hist_s["mean_ms"], 4),
-                              "algorithmic_bytes_per_launch": hist_s["bytes_per_launch"]}
-        if max_s:
-            ach2 = max_s["bytes_per_launch"] / (max_s["mean_ms"] * 1e-3) / 1e9
-            result["roofline_absmax"] = {"kernel": "absmax_seg_kernel", "achieved": round(ach2, 1), "unit": "GB/s",
-                                         "frac": round(ach2 / HBM_PEAK_GBS, 4), "mean_launch_ms": round(max_s["mean_ms"], 4),
-                                         "algorithmic_bytes_per_launch": max_s["bytes_per_launch"],
-                                         "note": "pass 1 takes the abs-max of conv and Eltwise outputs inside their own bias add / "
-                                                 "residual add (phases_s.fused_*): only what is left (the input image) goes "
-                                                 "through this kernel, a launch of tens of microseconds; its streaming rate on "
-                                                 "the full 8.6 GB tensor set is 6.2-6.8 TB/s (DESIGN.md section 5)"}
+        result["roofline"] = hbm_roofline("hist2048_seg_kernel", hist_s, {"traffic": traffic, "traffic_source": traffic_src})
+
+    # ---- pass 1's statistics ride on the producers' own kernels: their rooflines, measured on three more batches of
+    # the same shape after the timed region (events around every one of the ~70 launches per forward would perturb it)
+    try:
+        with CallTimer(_native, "bias_add_absmax", _bias_add_bytes) as kt_b, CallTimer(_native, "add_absmax", _add_bytes) as kt_a:
+            make_workdir(3 * world - 1, shape, local_rank)
+            extra = DeviceBatches(3 * world, B, HW, rank, world, device)
+            eq = Quantity(model)
+            kt_b.enabled = kt_a.enabled = True
+            eq.activation_quantize(extra)
+            torch.cuda.synchronize()
+            del extra, eq
+        sb, sa = kt_b.summary(), kt_a.summary()
+        if sb:
+            result["roofline_bias_add_absmax"] = hbm_roofline(
+                "bias_add_absmax_kernel", sb,
+                {"note": "53 launches per forward: y += bias[c] in place with max|y| (and the following ReLU's output) folded in; "
+                         "8 B/element, 12 with the ReLU copy; mean over all layer sizes (the small late layers are launch bound)",
+                 "aggregate_gbs": round(sb["gbs"], 1)})
+        if sa:
+            result["roofline_add_absmax"] = hbm_roofline(
+                "add_absmax_kernel", sa,
+                {"note": "16 launches per forward: z = x + y with max|z| (and the ReLU's output) folded in; 12 B/element, 16 with "
+                         "the ReLU copy", "aggregate_gbs": round(sa["gbs"], 1)})
+    except Exception as e:
+        result["roofline_bias_add_absmax"] = {"error": repr(e)}
 
     # ---- the fused fake-quant kernel on its own (north_star: >= 60 % of the HBM roofline)
     try:
-        xq = torch.empty(802816 * B, device=device)                      # the largest ResNet-50 activation
+        xq = torch.empty(802816 * 128, device=device)                    # the largest ResNet-50 activation at batch 128
         xq.normal_()
         yq = torch.empty_like(xq)
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
@@ -409,101 +622,145 @@ def main():
             b.record()
         torch.cuda.synchronize()
         ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
-        ach = xq.numel() * 8 / (ms * 1e-3) / 1e9
-        result["roofline_fakequant"] = {"bound": "hbm", "kernel": "unary_vec_kernel<QuanDequanOp>", "achieved": round(ach, 1),
-                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                                        "mean_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": xq.numel() * 8.0}
+        result["roofline_fakequant"] = hbm_roofline("unary_vec_kernel<QuanDequanOp>",
+                                                    {"launches": 20, "mean_ms": ms, "bytes_per_launch": xq.numel() * 8.0})
         del xq, yq
     except Exception as e:
         result["roofline_fakequant"] = {"error": repr(e)}
 
-    # ---- int8-sim / fake-quant forward throughput (BASELINE config[2]); replicas only, no collective
+    # ---- int8-sim / fake-quant forward throughput (BASELINE config[2]); replicas only, no data-path collective.
+    # Collectives in this section (barriers, the MAX of the elapsed times) are never inside a try: local work is
+    # wrapped by run_section(), which ends in an agreement every rank takes part in.
     if not args.no_recon:
-        try:
-            q.weight_quantize()
-            barrier()
-            batches = [b.to(device) for b in data.owned()[:min(K, 8)]]
-            if args.int8_batch > B:                        # larger forwards: concatenated calibration batches
-                per = (args.int8_batch + B - 1) // B
-                src = batches if len(batches) >= per else batches * per
-                batches = [torch.cat(src[i:i + per]) for i in range(0, len(src) - per + 1, per)][:4]
-            FB = int(batches[0].shape[0])
+        ok, _, err = run_section(q.weight_quantize, device)              # rank 0 writes tables + JSON
+        barrier()
+        share_tables("./workdir")                                         # ... and every rank gets the two tables
+        batches = [b.to(device) for b in data.owned()[:min(K, 8)]]
+        if args.int8_batch > B:                            # larger forwards: concatenated calibration batches
+            per = (args.int8_batch + B - 1) // B
+            src = batches if len(batches) >= per else batches * per
+            batches = [torch.cat(src[i:i + per]) for i in range(0, len(src) - per + 1, per)][:4]
+        elif args.int8_batch < B:
+            batches = [b[:args.int8_batch] for b in batches[:4]]
+        FB = int(batches[0].shape[0])
 
-            def fwd_rate(net, passes=1):
-                """images/s of net over the resident batches; the fast models take several passes so that one
-                host hiccup (a GC pause is longer than a whole int8 forward) does not decide the number."""
-                with torch.no_grad():
-                    net(batches[0])
-                    barrier()
-                    t0 = time.perf_counter()
-                    for _ in range(passes):
-                        for xb in batches:
-                            net(xb)
-                    barrier()
-                dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-                if distributed:
-                    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-                return passes * len(batches) * FB * world / float(dt.item())
-
-            result["float_forward_images_per_s"] = round(fwd_rate(model), 1)
-            rec = Reconstruction(build_model(args.model, HW, device))
-            info = rec.get_quantity_information()
-            result["fakequant_images_per_s"] = round(fwd_rate(rec.ReconTest(info, "./workdir/recontest.pth")), 1)
-            rec2 = Reconstruction(build_model(args.model, HW, device))
-            info2 = rec2.get_quantity_information()
-            int8_net = rec2.ReconModel(info2, "./workdir/recon.pth")
-            result["int8_sim_fp32_boundary_images_per_s"] = round(fwd_rate(int8_net, 3), 1)
-            # same model, same logits, activations kept as int8/int16 NHWC between the integer layers
-            from common.quantity import resident
+        def fwd_rate(net, passes=1):
+            """images/s of net over the resident batches (None if any rank failed); the fast models take several
+            passes so that one host hiccup (a GC pause is longer than a whole int8 forward) does not decide it."""
+            err_local = None
             with torch.no_grad():
-                logits_fp32_boundary = int8_net(batches[0])
-            plan = resident.enable(int8_net, batches[0])
-            with torch.no_grad():
-                same = bool(torch.equal(int8_net(batches[0]), logits_fp32_boundary))
-            result["int8_sim_images_per_s"] = round(fwd_rate(int8_net, 8), 1)
-            result["int8_sim_resident"] = {"bit_identical_logits": same, "plan": plan, "images_per_forward": FB}
-            if not same:                                   # never report a rate for a model that computes something else
-                result["int8_sim_images_per_s"] = result["int8_sim_fp32_boundary_images_per_s"]
-            else:
                 try:
-                    result["roofline_int8_conv"] = int8_conv_roofline(model, int8_net, batches[0])
+                    net(batches[0])
                 except Exception as e:
-                    result["roofline_int8_conv"] = {"error": repr(e)}
-                try:                                       # the same forward replayed as one HIP graph (input copy included)
-                    graphed = resident.capture(int8_net, batches[0])
+                    err_local = repr(e)
+                barrier()
+                t0 = time.perf_counter()
+                if err_local is None:
+                    try:
+                        for _ in range(passes):
+                            for xb in batches:
+                                net(xb)
+                    except Exception as e:
+                        err_local = repr(e)
+                barrier()
+            dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+            if distributed:
+                dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+            if not all_ok(err_local is None, device):
+                result.setdefault("recon_errors", []).append(err_local)
+                return None
+            return round(passes * len(batches) * FB * world / float(dt.item()), 1)
+
+        if ok:
+            result["float_forward_images_per_s"] = fwd_rate(model)
+
+            def build_test():
+                rec = Reconstruction(build_model(args.model, HW, device))
+                return rec.ReconTest(rec.get_quantity_information(), "./workdir/recontest.pth")
+            ok_t, test_net, err_t = run_section(build_test, device)
+            if ok_t:
+                result["fakequant_images_per_s"] = fwd_rate(test_net)
+            del test_net
+
+            def build_int8():
+                rec2 = Reconstruction(build_model(args.model, HW, device))
+                return rec2.ReconModel(rec2.get_quantity_information(), "./workdir/recon.pth")
+            ok_i, int8_net, err_i = run_section(build_int8, device)
+            if ok_i:
+                result["int8_sim_fp32_boundary_images_per_s"] = fwd_rate(int8_net, 3)
+                from common.quantity import resident
+
+                def go_resident():
                     with torch.no_grad():
-                        same_g = bool(torch.equal(graphed(batches[0]), logits_fp32_boundary))
-                    if same_g:
-                        result["int8_sim_hipgraph_images_per_s"] = round(fwd_rate(graphed, 8), 1)
+                        ref_logits = int8_net(batches[0])
+                    plan = resident.enable(int8_net, batches[0])
+                    with torch.no_grad():
+                        same = bool(torch.equal(int8_net(batches[0]), ref_logits))
+                    return ref_logits, plan, same
+                ok_r, res, err_r = run_section(go_resident, device)
+                same_everywhere = ok_r and all_ok(res[2], device)
+                if ok_r:
+                    result["int8_sim_resident"] = {"bit_identical_logits": bool(res[2]), "plan": res[1], "images_per_forward": FB}
+                if same_everywhere:                        # never report a rate for a model that computes something else
+                    result["int8_sim_images_per_s"] = fwd_rate(int8_net, 8)
+                    if rank == 0:
+                        try:
+                            result["roofline_int8_conv"] = int8_conv_roofline(model, int8_net, batches[0])
+                        except Exception as e:
+                            result["roofline_int8_conv"] = {"error": repr(e)}
+
+                    def graph():
+                        g = resident.capture(int8_net, batches[0])
+                        with torch.no_grad():
+                            if not torch.equal(g(batches[0]), res[0]):
+                                raise RuntimeError("graph replay differs from the eager forward")
+                            if len(batches) > 1 and not torch.equal(g(batches[1]), int8_net(batches[1])):
+                                raise RuntimeError("graph replay on a second input differs from the eager forward")
+                        return g
+                    ok_g, graphed, err_g = run_section(graph, device)
+                    if ok_g:
+                        result["int8_sim_hipgraph_images_per_s"] = fwd_rate(graphed, 8)
+                    elif err_g:
+                        result["int8_sim_hipgraph_error"] = err_g
                     del graphed
-                except Exception as e:
-                    result["int8_sim_hipgraph_error"] = repr(e)
-        except Exception as e:  # the headline number above stands on its own
-            result["recon_error"] = repr(e)
+                else:
+                    result["int8_sim_images_per_s"] = result.get("int8_sim_fp32_boundary_images_per_s")
+                    if err_r:
+                        result["int8_sim_resident_error"] = err_r
+            for e in (err_t, err_i):
+                if e:
+                    result.setdefault("recon_errors", []).append(e)
+        else:
+            result["recon_error"] = err or "weight_quantize failed on another rank"
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(lambda: build_model(args.model, HW, torch.device("cpu")),
-                                                  4, HW, images, q, log)
+            result["cpu_baseline"] = cpu_baseline(lambda: build_model(args.model, HW, torch.device("cpu")), HW, images, q, log)
         except Exception as e:
             result["cpu_baseline"] = {"error": repr(e)}
 
     # ---- per-channel rows (extension; BASELINE configs[1] words the workload "per-channel"): same two passes with
-    # one histogram row per (tensor, channel), read in place by fq_absmax_chan / fq_hist2048_chan, on a bounded
-    # sample -- the KL sweep of all rows is a fixed cost of the same order as the passes themselves
+    # one histogram row per (tensor, channel), read in place by fq_absmax_chan / fq_hist2048_chan, then the KL sweep of
+    # all 42 667 rows -- on 1 024 images (the sweep is a fixed cost per row set)
     if world == 1 and not args.no_per_channel:
         try:
-            pc_batches = data.owned()[:min(K, 8)]
-            pc_data = [(b, 0) for b in pc_batches]
+            n_pc = max(1, min(K, 1024 // B if B <= 1024 else 1))
+            pc_data = [(b, 0) for b in data.owned()[:n_pc]]
             make_workdir(len(pc_data) - 1, shape, local_rank)
             pq = Quantity(model)
-            barrier()
-            t0 = time.perf_counter()
-            pq.activation_quantize_per_channel(pc_data)
-            barrier()
-            dt = time.perf_counter() - t0
+            with CallTimer(_native, "hist2048_chan", _seg_bytes) as kt_pc:
+                kt_pc.enabled = True
+                barrier()
+                t0 = time.perf_counter()
+                pq.activation_quantize_per_channel(pc_data)
+                barrier()
+                dt = time.perf_counter() - t0
             result["per_channel_calibration"] = {"images": len(pc_data) * B, "rows": int(pq._channel_collector.rows),
-                                                 "seconds": round(dt, 3), "images_per_s": round(len(pc_data) * B / dt, 1)}
+                                                 "seconds": round(dt, 3), "images_per_s": round(len(pc_data) * B / dt, 1),
+                                                 "kl_sweep_s": getattr(pq._channel_collector, "kl_seconds", None)}
+            s = kt_pc.summary()
+            if s:
+                result["roofline_per_channel"] = hbm_roofline("hist2048_chan_kernel", s)
             del pq
         except Exception as e:
             result["per_channel_calibration"] = {"error": repr(e)}
@@ -515,6 +772,7 @@ def main():
         log("feat.table head:", feat_table.split("\n")[:4])
         print(json.dumps(result), flush=True)
     if distributed:
+        barrier()
         dist.destroy_process_group()
 
 

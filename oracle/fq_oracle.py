@@ -21,7 +21,7 @@ def build(force=False):
     if (not force and os.path.exists(_LIB) and os.path.getmtime(_LIB) >= os.path.getmtime(src)
             and os.path.getmtime(_LIB) >= os.path.getmtime(hdr)):
         return _LIB
-    subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
     return _LIB
 
 

@@ -14,13 +14,14 @@ import numpy as np
 import torch
 
 from . import _native
+from ._collectives import StatCollectives
 
 __all__ = ["ChannelCollector"]
 
 _MAX_SEGS = 1024            # FQ_MAX_SEGS per C-ABI call
 
 
-class ChannelCollector(object):
+class ChannelCollector(StatCollectives):
 
     def __init__(self, channels, statistic=1, device=None):
         """channels: ordered {tensor name: channel count C} (dimension 1 of the activation)."""
@@ -79,13 +80,8 @@ class ChannelCollector(object):
         for i in range(0, len(ts), _MAX_SEGS):
             _native.hist2048_chan(ts[i:i + _MAX_SEGS], row0s[i:i + _MAX_SEGS], self._interval, self._hist)
 
-    def all_reduce_max(self):
-        import torch.distributed as dist
-        dist.all_reduce(self._max, op=dist.ReduceOp.MAX)
-
-    def all_reduce_hist(self):
-        import torch.distributed as dist
-        dist.all_reduce(self._hist, op=dist.ReduceOp.SUM)
+    def _stat_tensors(self):             # all_reduce_max() / all_reduce_hist(): StatCollectives
+        return self._max, self._hist
 
     @property
     def max_device(self):
@@ -97,8 +93,12 @@ class ChannelCollector(object):
 
     def quantize(self):
         """-> {tensor name: [bits per channel]} via the KL sweep (quantizer.py:86-90 per row)."""
+        import time
         iv = self._interval.cpu().numpy()
+        torch.cuda.synchronize(self._device)
+        t0 = time.perf_counter()
         thr = _native.kl_threshold(self._hist).cpu().numpy()
+        self.kl_seconds = round(time.perf_counter() - t0, 4)      # the sweep of all rows (device time: .cpu() waits)
         bits = {}
         for n in self._names:
             lo, hi = self.row_range(n)

@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from . import _native
+from ._collectives import StatCollectives
 
 __all__ = ["DistributionCollector"]
 
@@ -32,7 +33,7 @@ def _as_device_f32(t, device):
     return torch.from_numpy(a).to(device)
 
 
-class DistributionCollector(object):
+class DistributionCollector(StatCollectives):
 
     def __init__(self, tensor_list, interval_num=2048, statistic=1, worker_num=1, debug=False, device=None):
         if interval_num != _native.BINS:
@@ -140,17 +141,15 @@ class DistributionCollector(object):
             return list(range(len(self._tensor_list)))
         return [r for r, n in enumerate(self._tensor_list) if n in tensors]
 
-    def all_reduce_max(self):
-        """Data-parallel calibration: combine the per-rank maxima (one MAX all-reduce of fp32[T],
-        RCCL over xGMI when the process group is 'nccl')."""
-        import torch.distributed as dist
-        dist.all_reduce(self._max_dev, op=dist.ReduceOp.MAX)
+    # all_reduce_max() / all_reduce_hist(): StatCollectives (one MAX all-reduce of fp32[T], one SUM all-reduce of the
+    # flat int64[T*2048] buffer; RCCL over xGMI when the process group is 'nccl')
+    def _stat_tensors(self):
+        return self._max_dev, self._hist_dev
+
+    def _note_max_reduced(self):
         self._max_vals_refreshed_flag = True        # a rank that owned no batch still holds the global maxima
 
-    def all_reduce_hist(self):
-        """Combine the per-rank histograms: one SUM all-reduce of the flat int64[T*2048] buffer."""
-        import torch.distributed as dist
-        dist.all_reduce(self._hist_dev, op=dist.ReduceOp.SUM)
+    def _note_hist_reduced(self):
         self._added_to_distributions_flag = True
 
     def merged_distributions(self, groups):

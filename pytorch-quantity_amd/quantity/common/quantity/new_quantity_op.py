@@ -15,6 +15,7 @@ NewConv2d :104-163, NewAdd :166-174, NewLinear :177-236, QuanDequan :239-257, Te
 TestLinear :358-452.
 """
 import os
+import weakref
 
 import torch
 from torch import nn
@@ -115,18 +116,30 @@ def _round_clamp(t, bit, width):
 class _QuantizedInputCache(object):
     """One-entry memo of fq_quantize_i8_nhwc results.  A residual block hands the SAME tensor to its
     first conv and to its projection shortcut, both with the same input bit; the second caller reuses
-    the int8 NHWC copy instead of re-reading the fp32 tensor.  Keyed by tensor identity + version."""
+    the int8 NHWC copy instead of re-reading the fp32 tensor.  Keyed by tensor identity + version.
+
+    HIP-graph capture: an entry made outside a capture is never served inside one (the quantise launch
+    would be missing from the graph and every replay would convolve the capture-time input), and an
+    entry made inside a capture lives in the graph's private pool, so it is only served to the same
+    capture (resident.GraphedForward clears the memo before and after capturing).  The input tensor is
+    held weakly: the memo does not keep the last batch alive."""
 
     def __init__(self):
         self._key, self._ref, self._val = None, None, None
 
     def get(self, x, ib, cpad):
-        key = (id(x), x._version, x.data_ptr(), tuple(x.shape), int(ib), int(cpad))
-        if key == self._key and self._ref is x:
+        capturing = bool(x.is_cuda and torch.cuda.is_current_stream_capturing())
+        key = (id(x), x._version, x.data_ptr(), tuple(x.shape), int(ib), int(cpad), capturing)
+        if key == self._key and self._ref is not None and self._ref() is x:
             return self._val
         val = _native.quantize_i8_nhwc(x, ib, cpad)
-        self._key, self._ref, self._val = key, x, val
+        self._key, self._val = key, val
+        self._ref = weakref.ref(x, self._drop)
         return val
+
+    def _drop(self, ref):
+        if self._ref is ref:
+            self.clear()
 
     def clear(self):
         self._key, self._ref, self._val = None, None, None

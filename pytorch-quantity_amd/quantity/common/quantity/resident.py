@@ -487,8 +487,10 @@ class GraphedForward(object):
     Batch shape is fixed at capture time."""
 
     def __init__(self, model, example_input, warmup=2):
+        from . import new_quantity_op
         self.model = model
         self.static_in = example_input.detach().clone()
+        new_quantity_op._xq_cache.clear()       # nothing memoised before the capture may be served inside it
         side = torch.cuda.Stream(device=example_input.device)
         side.wait_stream(torch.cuda.current_stream(example_input.device))
         with torch.cuda.stream(side), torch.no_grad():
@@ -498,6 +500,7 @@ class GraphedForward(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = model(self.static_in)
+        new_quantity_op._xq_cache.clear()       # ... and nothing from the graph's private pool outside it
 
     def __call__(self, x):
         if x.shape != self.static_in.shape or x.dtype != self.static_in.dtype:

@@ -807,36 +807,38 @@ class Quantity(object):
         rank, _world = _dist_state()
         names = ["image"] + list(self.net_info.keys())
         named_feats, hooks = self.regist_hook_outfeature(self.model)
-        collector = None
         ctl = self._hook_ctl
-        for _pass in (1, 2):
-            for i, item in self._device_items(images_files):
-                if collector is None:
-                    # the first forward tells the channel counts and whether later modules overwrite hooked tensors
-                    probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
-                    ctl["eager"] = probe
-                    try:
-                        self.net_forward(self.model, item)
-                    finally:
-                        ctl["eager"] = None
-                    collector = ChannelCollector({n: int(named_feats[n].shape[1]) for n in names},
-                                                 statistic=self.config["SETTINGS"]["STATISTIC"])
-                    self._stats_limit = 0 if probe.modified() else _AFTER_FORWARD
-                    if self._stats_limit:
-                        collector.refresh_max_val(named_feats)
-                        continue
-                    # in-place consumers: these tensors are already overwritten -- run the batch again, one launch per
-                    # tensor from inside the hooks (the values the reference's hooks would copy)
-                self._forward_with_stats(item, collector.refresh_max_val if _pass == 1 else collector.add_to_distributions,
-                                         named_feats)
-            if _dist_on():
-                collector.all_reduce_max() if _pass == 1 else collector.all_reduce_hist()
-            if _pass == 1:
-                collector.intervals()
-        bits = collector.quantize()
-        for h in hooks:
-            h.remove()
-        named_feats.clear()
+        try:
+            # One probe forward on a random input of INPUT_SHAPE (what build_net_structure traces with) tells the
+            # channel counts and whether later modules overwrite hooked tensors -- on EVERY rank, also one that owns
+            # no calibration batch and must still take part in the two all-reduces.
+            probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
+            ctl["eager"] = probe
+            try:
+                dev = self._model_device(self.model)
+                shapes = [self.input_size] if isinstance(self.input_size, tuple) else list(self.input_size)
+                with torch.no_grad():
+                    self.model(*[torch.rand(*s, device=dev) for s in shapes])
+            finally:
+                ctl["eager"] = None
+            collector = ChannelCollector({n: int(named_feats[n].shape[1]) for n in names},
+                                         statistic=self.config["SETTINGS"]["STATISTIC"])
+            # in-place consumers: one launch per tensor from inside the hooks (the values the reference's hooks would copy)
+            self._stats_limit = 0 if probe.modified() else _AFTER_FORWARD
+            del probe
+            for _pass in (1, 2):
+                fn = collector.refresh_max_val if _pass == 1 else collector.add_to_distributions
+                for i, item in self._device_items(images_files):
+                    self._forward_with_stats(item, fn, named_feats)
+                if _dist_on():
+                    collector.all_reduce_max() if _pass == 1 else collector.all_reduce_hist()
+                if _pass == 1:
+                    collector.intervals()
+            bits = collector.quantize()
+        finally:
+            for h in hooks:
+                h.remove()
+            named_feats.clear()
         by_module = OrderedDict()
         by_module["image"] = bits["image"]
         for i, feat_name in enumerate(names[1:]):

@@ -30,6 +30,17 @@ def pytest_configure(config):
     _ensure_native_lib()
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests need the MI355X: on a box without one (the build container) they are skipped, not failed."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="needs MI355X (no HIP device visible)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """The CPU parity oracle (oracle/fq_oracle.c via ctypes). Test infrastructure only."""

@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from oracle import fq_oracle as orc
+from common.quantity._collectives import StatCollectives
 
 BINS = 2048
 
@@ -22,7 +23,7 @@ def _np(t):
     return np.asarray(t, dtype=np.float32).ravel()
 
 
-class OracleCollector(object):
+class OracleCollector(StatCollectives):
 
     def __init__(self, tensor_list, interval_num=2048, statistic=1, worker_num=1, debug=False):
         assert interval_num == BINS
@@ -65,16 +66,15 @@ class OracleCollector(object):
         for i, n in enumerate(self._tensor_list):
             orc.hist2048(_np(tensors[n]), np.float32(self._distribution_intervals[n]), self._hist[i])
 
-    def all_reduce_max(self):
-        import torch.distributed as dist
-        t = torch.from_numpy(self._max)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # all_reduce_max / all_reduce_hist are the PRODUCT's (common.quantity._collectives.StatCollectives): the double only
+    # says which host arrays hold its state, so the world_size-2 gloo tests run the lines the GPU collectors run
+    def _stat_tensors(self):
+        return torch.from_numpy(self._max), torch.from_numpy(self._hist)
+
+    def _note_max_reduced(self):
         self._refreshed = True
 
-    def all_reduce_hist(self):
-        import torch.distributed as dist
-        t = torch.from_numpy(self._hist)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    def _note_hist_reduced(self):
         self._added = True
 
     def merged_distributions(self, groups):

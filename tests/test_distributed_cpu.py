@@ -38,6 +38,11 @@ WORKER = textwrap.dedent('''
         model = merge_bn(cases.seed_model(ResNet18()).eval())
         q = CpuQuantity(model)
         bits = q.activation_quantize(cases.calib_batches(5, (2, 3, 32, 32)))
+        if os.environ.get("FQ_TEST_WEIGHTS") == "1":
+            q.weight_quantize()
+        wd = os.path.join(tmp, "test", "workdir")
+        listing = sorted(os.path.relpath(os.path.join(d, f), wd) for d, _s, fs in os.walk(wd) for f in fs)
+        json.dump(listing, open(r"{out}" + ".files.rank%d" % rank, "w"))
         if rank == 0:
             table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
             hs = {{k: int(v.sum()) for k, v in q._collector.distributions.items()}}
@@ -49,11 +54,11 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def _run(world, out, max_cali=3):
+def _run(world, out, max_cali=3, weights=False):
     script = os.path.join(tempfile.mkdtemp(prefix="fq_dist_"), "worker.py")
     with open(script, "w") as fh:
         fh.write(WORKER.format(root=ROOT, out=out))
-    env = dict(os.environ, OMP_NUM_THREADS="2", FQ_TEST_MAX_CALI=str(max_cali))
+    env = dict(os.environ, OMP_NUM_THREADS="2", FQ_TEST_MAX_CALI=str(max_cali), FQ_TEST_WEIGHTS="1" if weights else "0")
     if world == 1:
         cmd = [sys.executable, script]
     else:
@@ -66,8 +71,14 @@ def _run(world, out, max_cali=3):
 
 @pytest.mark.timeout(1800)
 def test_two_rank_gloo_calibration_is_shard_count_invariant(tmp_path):
-    one = _run(1, str(tmp_path / "w1.json"))
-    two = _run(2, str(tmp_path / "w2.json"))
+    one = _run(1, str(tmp_path / "w1.json"), weights=True)
+    two = _run(2, str(tmp_path / "w2.json"), weights=True)
+    # only rank 0 writes files: rank 1's scratch tree holds no table and no JSON, rank 0's holds what a single process writes
+    files0 = json.load(open(str(tmp_path / "w2.json") + ".files.rank0"))
+    files1 = json.load(open(str(tmp_path / "w2.json") + ".files.rank1"))
+    assert files1 == [], files1
+    assert files0 == json.load(open(str(tmp_path / "w1.json") + ".files.rank0"))
+    assert "feat.table" in files0 and "weight.table" in files0 and any(f.startswith("new_bias/") for f in files0)
     assert one["table"] == two["table"]
     assert one["hist_sums"] == two["hist_sums"]
     assert one["max"] == two["max"]

@@ -113,6 +113,28 @@ def test_weight_outputs_match_reference(calib, g3):
         assert text == g3["verbatim"][k], k
 
 
+def test_kl_weight_branch_with_the_hip_engine_matches_reference(golden_dir, g3):
+    """weight_quantize() with _DKL_weight = True (reference pytorch_quantizer.py:644-648) -- the parameters
+    themselves go through fq_absmax_seg / fq_hist2048_seg / fq_kl_threshold.  Weights never pass through a convolution,
+    so weight.table (including its worker-ordered lines) and every JSON file must equal the reference's (golden G3b)."""
+    import hashlib
+    from tools import Quantity
+    with open(os.path.join(golden_dir, "g3b_r18_dkl_weights.json")) as fh:
+        ref = json.load(fh)
+    with product_workdir(device="gpu", max_cali_img_num=1) as tmp:
+        q = Quantity(_r18_gpu())
+        assert type(q).collector_cls.__module__ == "common.quantity.distribution_collector"       # the HIP engine
+        wd = os.path.join(tmp, "test", "workdir")
+        with open(os.path.join(wd, "feat.table"), "w") as fh:
+            fh.write(g3["feat_table"])
+        q._DKL_weight = True
+        q.weight_quantize()
+        assert open(os.path.join(wd, "weight.table")).read() == ref["weight_table"]
+        files = {d: {f: hashlib.sha256(open(os.path.join(wd, d, f), "rb").read()).hexdigest()
+                     for f in sorted(os.listdir(os.path.join(wd, d)))} for d in ("weight", "bias", "new_weight", "new_bias")}
+        assert files == ref["files"]
+
+
 def test_reconmodel_logits_match_reference(golden_dir, g3):
     """Integer simulation: every accumulator is an exact integer below 2^24 (golden:
     recon_max_abs_accumulator), so the GPU result must equal the reference's CPU result exactly."""

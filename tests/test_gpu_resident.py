@@ -429,3 +429,45 @@ def test_small_nets_with_concat_and_pool_only_topologies(tag, monkeypatch):
         with torch.no_grad():
             assert torch.equal(net(x), plain)
             assert torch.equal(net(torch.flip(x, dims=[0])), torch.flip(plain, dims=[0]))
+
+
+def test_hipgraph_capture_of_a_model_whose_first_conv_is_not_a_stem_layer():
+    """A first integer conv with 16 input channels (and one with a 1-wide kernel) quantises its fp32 input through
+    the one-entry fq_quantize_i8_nhwc memo instead of the stem kernel.  The memo must not serve, inside a capture, a
+    copy made before it (the quantise launch would be missing from the graph and every replay would convolve the
+    capture-time input): replaying on a DIFFERENT input must give that input's logits."""
+    from common.quantity import NewConv2d, NewAdd, resident, new_quantity_op
+
+    def info(i, o, w=6):
+        return {"weight_bit": w, "bias_bit": o, "input_bit": i, "output_bit": o}
+
+    class Net(nn.Module):
+        def __init__(self, cin, k):
+            super(Net, self).__init__()
+            torch.manual_seed(11)
+            self.c1 = NewConv2d(nn.Conv2d(cin, 32, k, padding=k // 2), info(5, 4))
+            self.sc = NewConv2d(nn.Conv2d(cin, 32, 1), info(5, 4))        # shortcut on the SAME input: served by the memo
+            self.c2 = NewConv2d(nn.Conv2d(32, 32, 3, padding=1), info(4, 4))
+            self.add = NewAdd()
+            self.relu = nn.ReLU()
+
+        def forward(self, x):
+            return self.relu(self.add(self.c2(self.relu(self.c1(x))), self.sc(x)))
+
+    for cin, k in ((16, 3), (3, 1)):
+        net = Net(cin, k).cuda().eval()
+        x = torch.randn(4, cin, 10, 10, device="cuda")
+        x2 = torch.randn(4, cin, 10, 10, device="cuda") * 2
+        for use_plan in (False, True):
+            if use_plan:
+                resident.enable(net, x)
+            with torch.no_grad():
+                want, want2 = net(x).clone(), net(x2).clone()
+            assert not torch.equal(want, want2)
+            graphed = resident.capture(net, x)
+            assert torch.equal(graphed(x), want)
+            assert torch.equal(graphed(x2), want2)
+            assert torch.equal(graphed(x), want)
+            with torch.no_grad():                                         # eager calls after a capture: no pool-private copy served
+                assert torch.equal(net(x2), want2)
+        assert new_quantity_op._xq_cache._val is None or new_quantity_op._xq_cache._ref() is not None

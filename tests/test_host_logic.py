@@ -211,14 +211,21 @@ def test_npy_input_mode_equals_loader_mode(tmp_path, oracle):
 
 
 # ---------------------------------------------------------------- H6: dilation -> zero padded kernel
-def test_dilation_to_zero_padding():
-    """pytorch_quantizer.py:679-693: a k x k kernel with dilation 2 as a dense (2k-1) x (2k-1) kernel."""
+def test_dilation_to_zero_padding(golden_dir):
+    """pytorch_quantizer.py:679-693: a k x k kernel with dilation 2 as a dense (2k-1) x (2k-1) kernel -- against the
+    reference function's own outputs (golden G10, tests/golden/make_golden_r50.py h6) and against what it means."""
     from tools import Quantity
+    g10 = np.load(os.path.join(golden_dir, "g10_dilation.npz"))
+    for tag in ("k3", "k1", "k5", "k2"):
+        got = Quantity.dilation_to_zero_padding(None, torch.from_numpy(g10[tag + "_in"]), (2, 2))
+        assert got.dtype == torch.float32
+        np.testing.assert_array_equal(got.numpy(), g10[tag + "_out"])
+        got_np = Quantity.dilation_to_zero_padding(None, g10[tag + "_in"], (2, 2))          # the reference passes ndarrays
+        np.testing.assert_array_equal(np.asarray(got_np), g10[tag + "_out"])
     w = torch.arange(2 * 3 * 3 * 3, dtype=torch.float32).reshape(2, 3, 3, 3) + 1
     dense = Quantity.dilation_to_zero_padding(None, w, (2, 2))
     assert dense.shape == (2, 3, 5, 5)
     assert torch.equal(dense[..., ::2, ::2], w)
-    assert dense.sum() == w.sum() and (dense[..., 1::2, :] == 0).all() and (dense[..., :, 1::2] == 0).all()
     x = torch.randn(1, 3, 9, 9)
     ref = torch.nn.functional.conv2d(x, w, dilation=2)
     got = torch.nn.functional.conv2d(x, dense)
