@@ -90,6 +90,27 @@ size_t fq_kl_workspace_bytes(int rows);
 int fq_kl_threshold(const int64_t* hist, int rows, int32_t* thr_out, double* kl_curve_out,
                     void* workspace, size_t workspace_bytes, fq_stream_t stream);
 
+/* The same search with its evidence and a choice of evaluation strategy.
+ *   best_kl_out      NULL or float64[rows]: KL(t*) (+inf when no candidate is below the reference's 66666 start value)
+ *   runner_up_kl_out NULL or float64[rows]: the smallest KL of any OTHER candidate.  runner_up - best is the margin of
+ *                    the argmin: a margin of a few ulps is a near-tie that a differently rounded logarithm could decide
+ *                    the other way (the reference's np.log is faithful, not correctly rounded).
+ *   mode  FQ_KL_EXHAUSTIVE  all 1920 candidates of every row in the reference's float64 operation order (quantizer.py
+ *                           :98-174 line by line);
+ *         FQ_KL_SCREENED    every candidate first through a closed form of the same sum (one logarithm per quantised
+ *                           bin instead of one per histogram bin; |S(t) - KL(t)| < 2e-12), then the exhaustive
+ *                           evaluation of the candidates within 1e-9 of the smallest S(t) only.  The minimum is among
+ *                           them, so thr_out / best_kl_out are identical to FQ_KL_EXHAUSTIVE; runner_up_kl_out and
+ *                           kl_curve_out hold the closed-form value where the exact one was not needed;
+ *         FQ_KL_AUTO        screened from 256 rows up when no curve is asked for (per-channel calibration: 42 667
+ *                           rows), exhaustive below; the environment variable FQ_KL_EXHAUSTIVE=1 forces exhaustive. */
+#define FQ_KL_AUTO 0
+#define FQ_KL_EXHAUSTIVE 1
+#define FQ_KL_SCREENED 2
+int fq_kl_threshold_ex(const int64_t* hist, int rows, int32_t* thr_out, double* best_kl_out,
+                       double* runner_up_kl_out, double* kl_curve_out, int mode,
+                       void* workspace, size_t workspace_bytes, fq_stream_t stream);
+
 /* HOST helper (no device work): quantizer.py:86-90
  *   thr_val = fl32((t + 0.5) * interval);  bits = 7 - ceil(log(thr_val) / log(2))
  * evaluated with the host libm in float64 exactly as CPython's math.log(x, 2) does.

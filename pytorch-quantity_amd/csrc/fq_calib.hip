@@ -15,6 +15,7 @@
 //   * abs-max keeps a per-lane running max, reduces across the wave with DPP shuffles, across waves
 //     through LDS, and publishes with one 32-bit atomic max on the (non-negative) float's bits.
 #include <cstdlib>
+#include <type_traits>
 
 #include "fq_common.h"
 
@@ -213,25 +214,41 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable
 // ---------------------------------------------------------------------------------------------
 // per-channel rows: one histogram row per (tensor, channel) of an NCHW activation
 // ---------------------------------------------------------------------------------------------
-// A row is no longer one contiguous run: channel c of tensor [N][C][HW] is the N planes at (n*C + c)*HW.  A
-// workgroup owns ONE channel and a group of images, so its LDS histogram (or running max) belongs to a single
-// row and is flushed once; blockIdx -> (tensor, channel, image group) through a kernarg prefix table as above.
-// Each wave sweeps one plane at a time (16-byte loads, four in flight per lane, when planes are 16-byte aligned
-// and at least 256 elements; 4-byte loads otherwise): no per-element index arithmetic, and the tensor is read
-// in place -- no channel-major copy.
-constexpr int kChanChunk = 96;            // kernarg block 3.4 KB: ResNet-50 (71 tensors) in one launch
-constexpr uint32_t kChanElemsPerWg = 262144;   // per workgroup: enough to amortise zeroing + flushing 2048 bins (32 K: 3.8 TB/s)
+// A row is no longer one contiguous run: channel c of tensor [N][C][HW] is the N planes at (n*C + c)*HW.  The tensor is
+// read in place (no channel-major copy); blockIdx -> (tensor, channel block, image group) through a kernarg prefix
+// table as above.  Two shapes of workgroup, both sweeping their elements as ONE index space with four 16-byte loads in
+// flight per lane (round 1 let each wave walk one plane at a time: a 28x28 plane is 196 vectors, three per lane, so the
+// 4-deep loop never ran and the kernel sat at 4.1 TB/s):
+//   big planes (HW >= 1024, 16-byte aligned): a workgroup owns ONE channel and a group of images; its LDS histogram
+//     belongs to a single row (32-bit bins, up to 256 K elements per workgroup);
+//   small planes: a workgroup owns a block of 8 CONSECUTIVE channels and a group of images, i.e. one contiguous run of
+//     8*HW floats per image (a 7x7 plane is 196 bytes: owning one channel would use a quarter of every cache line it
+//     touches, and the neighbouring channels' workgroups sit on other XCDs); 8 histograms of 2048 16-bit bins packed
+//     two to a dword (32 KB of LDS; a workgroup never gives one row more than 32 768 elements, so a bin cannot carry
+//     into its neighbour).
+constexpr int kChanChunk = 64;            // kernarg block 3.4 KB; ResNet-50's 71 tensors take two launches
+constexpr uint32_t kChanElemsPerWg = 262144;   // per workgroup: enough to amortise zeroing + flushing the bins
+constexpr int kChanBlock = 8;             // channels per workgroup, small planes
+constexpr uint32_t kBigPlane = 1024;
 
 struct ChanTable {
     const float* ptr[kChanChunk];
     uint32_t N[kChanChunk], C[kChanChunk], HW[kChanChunk];
-    uint32_t groups[kChanChunk], nb[kChanChunk];          // image groups per channel, images per group
+    uint32_t groups[kChanChunk], nb[kChanChunk];          // image groups, images per group
+    uint32_t cb[kChanChunk];                              // channels per workgroup: 1 (big planes) or kChanBlock
+    uint32_t vec[kChanChunk];                             // 16-byte loads possible
     int32_t row0[kChanChunk];
     uint32_t wg_begin[kChanChunk + 1];
     int32_t nseg;
 };
 
-struct ChanView { const float* base; uint32_t C, HW, n0, n1; int row; };
+struct ChanView {
+    const float* base;          // first element of (image n0, channel c0)
+    size_t img_stride;          // C * HW
+    uint32_t HW, run;           // run = cb * HW contiguous floats per image
+    uint32_t nimg, cb, vec;
+    int row;                    // row of channel c0
+};
 
 __device__ __forceinline__ ChanView chan_of(const ChanTable& t) {
     const uint32_t b = blockIdx.x;
@@ -241,93 +258,169 @@ __device__ __forceinline__ ChanView chan_of(const ChanTable& t) {
         if (t.wg_begin[mid] <= b) lo = mid; else hi = mid - 1;
     }
     const uint32_t local = b - t.wg_begin[lo];
-    const uint32_t c = local / t.groups[lo], g = local - c * t.groups[lo];
+    const uint32_t cblk = local / t.groups[lo], g = local - cblk * t.groups[lo];
+    const uint32_t c0 = cblk * t.cb[lo];
+    const uint32_t n0 = g * t.nb[lo];
+    const uint32_t n1 = n0 + t.nb[lo] < t.N[lo] ? n0 + t.nb[lo] : t.N[lo];
     ChanView v;
-    v.C = t.C[lo]; v.HW = t.HW[lo];
-    v.n0 = g * t.nb[lo];
-    v.n1 = v.n0 + t.nb[lo] < t.N[lo] ? v.n0 + t.nb[lo] : t.N[lo];
-    v.base = t.ptr[lo] + (size_t)c * v.HW;
-    v.row = t.row0[lo] + (int)c;
+    v.HW = t.HW[lo];
+    v.cb = c0 + t.cb[lo] <= t.C[lo] ? t.cb[lo] : t.C[lo] - c0;        // ragged last block
+    v.run = v.cb * v.HW;
+    v.img_stride = (size_t)t.C[lo] * v.HW;
+    v.nimg = n1 - n0;
+    v.base = t.ptr[lo] + (size_t)n0 * v.img_stride + (size_t)c0 * v.HW;
+    v.row = t.row0[lo] + (int)c0;
+    v.vec = t.vec[lo] && ((v.run & 3u) == 0);
     return v;
 }
 
-// f(value) for every element of this workgroup's planes: one plane per wave at a time (a plane of the 56x56 /
-// 28x28 stages is too short for the 256-thread chunk loader to keep four loads per lane in flight; a wave does)
+// n / d for n * d < 2^32 (here n < 2^19, d < 2^13): one multiply-high
+__device__ __forceinline__ uint32_t magic_of(uint32_t d) { return (uint32_t)((0x100000000ull + d - 1) / d); }
+__device__ __forceinline__ uint32_t div_magic(uint32_t n, uint32_t magic, uint32_t d) { return d == 1 ? n : __umulhi(n, magic); }
+
+// f(value, channel within the block) for every element of this workgroup: the images' runs of cv.run floats form one
+// index space; 16-byte loads (four in flight per lane) when every run starts on a 16-byte boundary
 template <int kThreads, bool kFenceLoads, typename F>
-__device__ __forceinline__ void for_each_in_channel(const ChanView& cv, F&& f) {
-    const size_t plane_stride = (size_t)cv.C * cv.HW;
-    const uint32_t lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    // 16-byte loads when every plane starts on a 16-byte boundary
-    const bool vec = (cv.HW & 3u) == 0 && (reinterpret_cast<uintptr_t>(cv.base) & 15u) == 0 && cv.HW >= 256;
-    for (uint32_t n = cv.n0 + wave; n < cv.n1; n += kThreads / kWave) {
-        const float* __restrict__ p = cv.base + (size_t)n * plane_stride;
-        if (vec) {
-            const f4v* __restrict__ v4 = reinterpret_cast<const f4v*>(p);
-            const uint32_t nvec = cv.HW >> 2;
-            uint32_t i = lane;
-            for (; i + 3 * kWave < nvec; i += 4 * kWave) {
-                const f4v a = stream_load(&v4[i]);
-                const f4v b = stream_load(&v4[i + kWave]);
-                const f4v c = stream_load(&v4[i + 2 * kWave]);
-                const f4v d = stream_load(&v4[i + 3 * kWave]);
-                if (kFenceLoads) __builtin_amdgcn_sched_barrier(0);       // see for_each_in_chunks
-                f(a.x); f(a.y); f(a.z); f(a.w);
-                f(b.x); f(b.y); f(b.z); f(b.w);
-                f(c.x); f(c.y); f(c.z); f(c.w);
-                f(d.x); f(d.y); f(d.z); f(d.w);
+__device__ __forceinline__ void for_each_in_block(const ChanView& cv, F&& f) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t m_hw = magic_of(cv.HW);
+    if (cv.vec) {
+        const uint32_t runv = cv.run >> 2;
+        const uint32_t m_run = magic_of(runv);
+        const uint32_t total = cv.nimg * runv;
+        const size_t stridev = cv.img_stride >> 2;
+        const f4v* __restrict__ v4 = reinterpret_cast<const f4v*>(cv.base);
+        auto locate = [&](uint32_t v, uint32_t& e0) -> const f4v* {
+            const uint32_t img = cv.nimg == 1 ? 0u : div_magic(v, m_run, runv);    // (one image: any plane size)
+            const uint32_t vin = v - img * runv;
+            e0 = vin << 2;
+            return v4 + (size_t)img * stridev + vin;
+        };
+        auto emit = [&](const f4v a, uint32_t e0) {
+            if (cv.cb == 1) { f(a.x, 0u); f(a.y, 0u); f(a.z, 0u); f(a.w, 0u); return; }
+            const uint32_t ch = div_magic(e0, m_hw, cv.HW);
+            const uint32_t rem = e0 - ch * cv.HW;                  // elements of this vector may cross into channel ch + 1
+            if (cv.HW >= 4) {
+                f(a.x, ch); f(a.y, ch + (rem + 1 >= cv.HW)); f(a.z, ch + (rem + 2 >= cv.HW)); f(a.w, ch + (rem + 3 >= cv.HW));
+            } else {
+                f(a.x, ch); f(a.y, div_magic(e0 + 1, m_hw, cv.HW)); f(a.z, div_magic(e0 + 2, m_hw, cv.HW));
+                f(a.w, div_magic(e0 + 3, m_hw, cv.HW));
             }
-            for (; i < nvec; i += kWave) {
-                const f4v a = stream_load(&v4[i]);
-                f(a.x); f(a.y); f(a.z); f(a.w);
-            }
-        } else {
-            for (uint32_t e = lane; e < cv.HW; e += kWave) f(p[e]);
+        };
+        uint32_t v = tid;
+        for (; v + 3 * kThreads < total; v += 4 * kThreads) {
+            uint32_t ea, eb, ec, ed;
+            const f4v a = stream_load(locate(v, ea));
+            const f4v b = stream_load(locate(v + kThreads, eb));
+            const f4v c = stream_load(locate(v + 2 * kThreads, ec));
+            const f4v d = stream_load(locate(v + 3 * kThreads, ed));
+            if (kFenceLoads) __builtin_amdgcn_sched_barrier(0);       // see for_each_in_chunks
+            emit(a, ea); emit(b, eb); emit(c, ec); emit(d, ed);
+        }
+        for (; v < total; v += kThreads) {
+            uint32_t ea;
+            const f4v a = stream_load(locate(v, ea));
+            emit(a, ea);
+        }
+    } else {
+        const uint32_t m_run = magic_of(cv.run);
+        const uint32_t total = cv.nimg * cv.run;
+        for (uint32_t e = tid; e < total; e += kThreads) {
+            const uint32_t img = cv.nimg == 1 ? 0u : div_magic(e, m_run, cv.run);
+            const uint32_t ein = e - img * cv.run;
+            f(cv.base[(size_t)img * cv.img_stride + ein], cv.cb == 1 ? 0u : div_magic(ein, m_hw, cv.HW));
         }
     }
 }
 
 __global__ __launch_bounds__(kBlock) void absmax_chan_kernel(const ChanTable tab, float* __restrict__ max_inout) {
+    __shared__ unsigned int s_m[kChanBlock];
     __shared__ float s_wave[kBlock / kWave];
     const ChanView cv = chan_of(tab);
-    float m = 0.0f;
-    for_each_in_channel<kBlock, false>(cv, [&](float v) { m = fmaxf(m, fabsf(v)); });
+    if (cv.cb == 1) {                                         // one row: per-lane running maximum
+        float m = 0.0f;
+        for_each_in_block<kBlock, false>(cv, [&](float v, uint32_t) { m = fmaxf(m, fabsf(v)); });
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    if (lane == 0) s_wave[wave] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+        if (lane == 0) s_wave[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
 #pragma unroll
-        for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
-        atomicMax(reinterpret_cast<unsigned int*>(max_inout + cv.row), __float_as_uint(m));
+            for (int w = 1; w < kBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
+            atomicMax(reinterpret_cast<unsigned int*>(max_inout + cv.row), __float_as_uint(m));
+        }
+        return;
     }
-}
-
-template <bool kFast>
-__device__ __forceinline__ void hist_channel(const ChanView& cv, float iv, unsigned int* s_bins) {
-    const float y = 1.0f / iv;
-    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
-    for_each_in_channel<kHistBlock, true>(cv, [&](float v) {
-        unsigned int* slot = (v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, y)) : park;
-        atomicAdd(slot, 1u);
+    if (threadIdx.x < kChanBlock) s_m[threadIdx.x] = 0u;
+    __syncthreads();
+    // a lane keeps the maximum of the channel it is in and publishes it (ds_max_u32) when the channel changes
+    uint32_t cur = 0xffffffffu;
+    float m = 0.0f;
+    for_each_in_block<kBlock, false>(cv, [&](float v, uint32_t ch) {
+        if (ch != cur) {
+            if (cur != 0xffffffffu) atomicMax(&s_m[cur], __float_as_uint(m));
+            cur = ch; m = 0.0f;
+        }
+        m = fmaxf(m, fabsf(v));                               // fmaxf drops NaN
     });
+    if (cur != 0xffffffffu) atomicMax(&s_m[cur], __float_as_uint(m));
+    __syncthreads();
+    if (threadIdx.x < cv.cb) atomicMax(reinterpret_cast<unsigned int*>(max_inout + cv.row + threadIdx.x), s_m[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTable tab, const float* __restrict__ interval,
                                                                unsigned long long* __restrict__ hist, const int allow_fast) {
-    __shared__ unsigned int s_bins[FQ_BINS + kWave];
-    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kHistBlock) s_bins[b] = 0u;
+    // big planes: s_bins[0 .. 2047] 32-bit bins of one row (+ 64 parking slots)
+    // small planes: row r's bin b is the 16-bit half (b & 1) of dword r * 1024 + (b >> 1); parking dwords behind
+    __shared__ unsigned int s_bins[kChanBlock * (FQ_BINS / 2) + kWave];
+    __shared__ float s_iv[kChanBlock], s_y[kChanBlock];
+    __shared__ int s_fast;
     const ChanView cv = chan_of(tab);
-    const float iv = interval[cv.row];
+    const int nwords = cv.cb == 1 ? FQ_BINS : kChanBlock * (FQ_BINS / 2);
+    for (int b = threadIdx.x; b < nwords + kWave; b += kHistBlock) s_bins[b] = 0u;
+    if (threadIdx.x == 0) s_fast = allow_fast;
     __syncthreads();
-    const unsigned int ivb = __float_as_uint(iv);
-    const bool fast = allow_fast && ivb >= 0x21800000u && ivb <= 0x5d800000u;      // see hist2048_seg_kernel
-    if (fast) hist_channel<true>(cv, iv, s_bins); else hist_channel<false>(cv, iv, s_bins);
+    if (threadIdx.x < cv.cb) {
+        const float iv = interval[cv.row + threadIdx.x];
+        s_iv[threadIdx.x] = iv;
+        s_y[threadIdx.x] = 1.0f / iv;                         // IEEE
+        const unsigned int ivb = __float_as_uint(iv);
+        if (!(ivb >= 0x21800000u && ivb <= 0x5d800000u)) s_fast = 0;     // see hist2048_seg_kernel; any row outside: IEEE divide
+    }
     __syncthreads();
+    const bool fast = s_fast != 0;
+    unsigned int* park = s_bins + nwords + (threadIdx.x & (kWave - 1));
     unsigned long long* __restrict__ dst = hist + (size_t)cv.row * FQ_BINS;
-    for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) {
-        const unsigned int c = s_bins[b];
-        if (c) atomicAdd(dst + b, (unsigned long long)c);
+    if (cv.cb == 1) {
+        const float iv = s_iv[0], y = s_y[0];
+        if (fast) for_each_in_block<kHistBlock, true>(cv, [&](float v, uint32_t) {
+            atomicAdd((v != 0.0f) ? (s_bins + bin_of<true>(v, iv, y)) : park, 1u); });
+        else for_each_in_block<kHistBlock, true>(cv, [&](float v, uint32_t) {
+            atomicAdd((v != 0.0f) ? (s_bins + bin_of<false>(v, iv, y)) : park, 1u); });
+        __syncthreads();
+        for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) {
+            const unsigned int c = s_bins[b];
+            if (c) atomicAdd(dst + b, (unsigned long long)c);
+        }
+        return;
+    }
+    auto add = [&](float v, uint32_t ch, auto fast_tag) {
+        const int b = bin_of<decltype(fast_tag)::value>(v, s_iv[ch], s_y[ch]);
+        unsigned int* slot = (v != 0.0f) ? (s_bins + ch * (FQ_BINS / 2) + (b >> 1)) : park;
+        atomicAdd(slot, (v != 0.0f && (b & 1)) ? 0x10000u : 1u);          // ds_add_u32 on a 16-bit half
+    };
+    if (fast) for_each_in_block<kHistBlock, true>(cv, [&](float v, uint32_t ch) { add(v, ch, std::true_type{}); });
+    else for_each_in_block<kHistBlock, true>(cv, [&](float v, uint32_t ch) { add(v, ch, std::false_type{}); });
+    __syncthreads();
+    for (uint32_t w = threadIdx.x; w < cv.cb * (FQ_BINS / 2); w += kHistBlock) {
+        const unsigned int c = s_bins[w];
+        if (c) {
+            const uint32_t r = w / (FQ_BINS / 2), b = (w - r * (FQ_BINS / 2)) * 2;
+            unsigned long long* d = dst + (size_t)r * FQ_BINS + b;
+            if (c & 0xffffu) atomicAdd(d, (unsigned long long)(c & 0xffffu));
+            if (c >> 16) atomicAdd(d + 1, (unsigned long long)(c >> 16));
+        }
     }
 }
 
@@ -348,14 +441,32 @@ static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launc
         while (i < nseg && k < kChanChunk) {
             const fq_chan_seg& s = segs[i++];
             if (s.N == 0) continue;
-            uint32_t nb = (uint32_t)(kChanElemsPerWg / (uint64_t)s.HW);
-            if (nb < kBlock / kWave) nb = kBlock / kWave;                  // at least one plane per wave
+            const bool aligned = (reinterpret_cast<uintptr_t>(s.ptr) & 15u) == 0;
+            const bool big = (uint64_t)s.HW >= kBigPlane;
+            uint32_t cb, nb, vec;
+            if (big) {
+                // one channel per workgroup; planes of more than 256 K elements are still one image per workgroup
+                cb = 1;
+                vec = aligned && (s.HW & 3) == 0 && (((uint64_t)s.C * (uint64_t)s.HW) & 3u) == 0;
+                nb = (uint32_t)(kChanElemsPerWg / (uint64_t)s.HW);
+                if (nb < 1) nb = 1;
+                // the magic division by the run length needs n * d < 2^32; a single image per workgroup needs none
+                const uint64_t runl = (uint64_t)s.HW / (vec ? 4 : 1);
+                while (nb > 1 && (uint64_t)nb * runl * runl >= (1ull << 32)) nb >>= 1;
+            } else {
+                cb = kChanBlock;
+                // every image's run of cb * HW floats starts 16-byte aligned when the base is, the image stride is a
+                // multiple of 4 floats and so is a full block (the ragged last block is checked in the kernel)
+                vec = aligned && (((uint64_t)s.C * (uint64_t)s.HW) & 3u) == 0 && (((uint64_t)cb * (uint64_t)s.HW) & 3u) == 0;
+                nb = (uint32_t)(32768u / (uint64_t)s.HW);         // <= 32 768 elements per row and workgroup: 16-bit bins
+                if (nb < 1) nb = 1;
+            }
             if (nb > (uint32_t)s.N) nb = (uint32_t)s.N;
             const uint32_t groups = ((uint32_t)s.N + nb - 1) / nb;
-            const uint64_t n_wg = (uint64_t)groups * (uint64_t)s.C;
+            const uint64_t n_wg = (uint64_t)groups * (((uint64_t)s.C + cb - 1) / cb);
             if (wgs + n_wg > 0x7fffffffULL) { --i; break; }
             tab.ptr[k] = s.ptr; tab.N[k] = (uint32_t)s.N; tab.C[k] = (uint32_t)s.C; tab.HW[k] = (uint32_t)s.HW;
-            tab.groups[k] = groups; tab.nb[k] = nb; tab.row0[k] = s.row0;
+            tab.groups[k] = groups; tab.nb[k] = nb; tab.cb[k] = cb; tab.vec[k] = vec; tab.row0[k] = s.row0;
             tab.wg_begin[k] = (uint32_t)wgs;
             wgs += n_wg;
             ++k;
@@ -367,7 +478,8 @@ static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launc
         tab.nseg = k;
         for (int j = k; j <= kChanChunk; ++j) tab.wg_begin[j] = (uint32_t)wgs;
         for (int j = k; j < kChanChunk; ++j) {
-            tab.ptr[j] = nullptr; tab.N[j] = 0; tab.C[j] = 1; tab.HW[j] = 1; tab.groups[j] = 1; tab.nb[j] = 1; tab.row0[j] = 0;
+            tab.ptr[j] = nullptr; tab.N[j] = 0; tab.C[j] = 1; tab.HW[j] = 1; tab.groups[j] = 1; tab.nb[j] = 1; tab.cb[j] = 1;
+            tab.vec[j] = 0; tab.row0[j] = 0;
         }
         const int rc = launch(tab, (uint32_t)wgs);
         if (rc != FQ_OK) return rc;

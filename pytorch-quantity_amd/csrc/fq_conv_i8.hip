@@ -113,10 +113,15 @@ __device__ __forceinline__ rsrc_words make_rsrc_words(const void* base, unsigned
     rsrc_words r = {(int)(unsigned)(a & 0xffffffffu), (int)(unsigned)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
     return r;
 }
+// (m0 is what the instruction reads its LDS base from; naming it in the clobber list is the point, and clang's
+// "clobber list contains reserved registers" note about it is silenced here only)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
 __device__ __forceinline__ void dma_to_lds(rsrc_words rsrc, unsigned lds_base, unsigned voffset, int soffset) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
                  :: "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(soffset) : "m0");
 }
+#pragma clang diagnostic pop
 __device__ __forceinline__ unsigned lds_offset(const void* shared_ptr) {
     return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)shared_ptr;
 }

@@ -14,6 +14,16 @@
 //   kl_prepare_kernel  grid = rows          P = fp32(hist)/(sum+1e-12); tail[t] chain
 //   kl_sweep_kernel    grid = (1920, rows)  KL(t)
 //   kl_argmin_kernel   grid = rows          first strict minimum below 66666, else 2047
+//
+// Many rows (the per-channel extension: 42 667 rows for ResNet-50) make the sweep throughput bound: 82 M candidates x
+// ~1 100 logarithm + divide pairs in correctly rounded float64 is ~7e12 fp64 operations, 0.67 s.  The argmin does not
+// need all of them exactly: the SCREENED path first evaluates every candidate through a closed form that costs 128
+// bins instead of t elements (kl_screen_kernel, below: plain fp64, |S(t) - KL(t)| < 1e-11, measured < 2e-13), keeps
+// only the candidates within 1e-9 of the smallest S(t) -- the true minimum is provably among them -- and runs the
+// exact, bit-for-bit evaluation on those alone (kl_exact_list_kernel, typically 1-3 per row).  Same thresholds by
+// construction; tests/test_gpu_kernels.py checks the bound on every golden and fuzz histogram.
+#include <cstdlib>
+
 #include "fq_common.h"
 #include "../../include/fq_log.h"
 
@@ -143,20 +153,28 @@ __global__ __launch_bounds__(kKlBlock) void kl_prepare_kernel(const long long* _
 }
 
 // ---- sweep: one workgroup per (threshold, row) --------------------------------------------------
-__global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __restrict__ Pw, const double* __restrict__ tailw,
-                                                            double* __restrict__ klw) {
-    __shared__ double sP[FQ_BINS];
-    __shared__ double sE[FQ_BINS];            // expand_distribution, later reused for the compacted KL terms
-    __shared__ double s_leaf_val[kMaxLeaves];
-    __shared__ int s_leaf_off[kMaxLeaves];
-    __shared__ int s_leaf_len[kMaxLeaves];
-    __shared__ int s_wave_cnt[kKlBlock / kWave];
-    __shared__ int s_nleaf;
+struct SweepSmem {
+    double sP[FQ_BINS];
+    double sE[FQ_BINS];            // expand_distribution, later reused for the compacted KL terms
+    double s_leaf_val[kMaxLeaves];
+    int s_leaf_off[kMaxLeaves];
+    int s_leaf_len[kMaxLeaves];
+    int s_wave_cnt[kKlBlock / kWave];
+    int s_nleaf;
+};
 
-    const int t = kTarget + blockIdx.x;       // threshold
-    const int row = blockIdx.y;
+// KL(t) of one row, by the whole workgroup; lane 0 of wave 0 stores it to *out.  Exact: the reference's operations in
+// the reference's order.  (Every thread must call it; it ends without a barrier -- callers that reuse `sm` add one.)
+__device__ __forceinline__ void kl_exact_candidate(SweepSmem& sm, const double* __restrict__ P, const double tail, const int t,
+                                                   double* __restrict__ out) {
+    double* sP = sm.sP;
+    double* sE = sm.sE;
+    double* s_leaf_val = sm.s_leaf_val;
+    int* s_leaf_off = sm.s_leaf_off;
+    int* s_leaf_len = sm.s_leaf_len;
+    int* s_wave_cnt = sm.s_wave_cnt;
+    int& s_nleaf = sm.s_nleaf;
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    const double* P = Pw + (size_t)row * FQ_BINS;
 
     for (int j = tid; j < t; j += kKlBlock) {
         sP[j] = P[j];
@@ -199,7 +217,6 @@ __global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __rest
     __syncthreads();
 
     // KL terms (quantizer.py:169-174) for 8 consecutive bins per lane, compacted over a != 0
-    const double tail = tailw[(size_t)row * FQ_BINS + t];
     double term[8];
     unsigned nzmask = 0;
 #pragma unroll
@@ -305,67 +322,353 @@ __global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __rest
             const bool right = lane + sd < kWave && ((leaf_mask >> (lane + sd)) & 1ull);
             if ((lane & (2 * sd - 1)) == 0 && right) v = v + other;
         }
-        if (lane == 0) klw[(size_t)row * kCand + blockIdx.x] = v;        // m == 0: np.sum of nothing = 0.0
+        if (lane == 0) *out = v;                                         // m == 0: np.sum of nothing = 0.0
+    }
+}
+
+// ---- sweep: one workgroup per (threshold, row) --------------------------------------------------
+__global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __restrict__ Pw, const double* __restrict__ tailw,
+                                                            double* __restrict__ klw) {
+    __shared__ SweepSmem sm;
+    const int t = kTarget + blockIdx.x;       // threshold
+    const int row = blockIdx.y;
+    kl_exact_candidate(sm, Pw + (size_t)row * FQ_BINS, tailw[(size_t)row * FQ_BINS + t], t, klw + (size_t)row * kCand + blockIdx.x);
+}
+
+// ---- screened path ------------------------------------------------------------------------------
+// Closed form of the same sum.  With a_j = P[j] (a_{t-1} = P[t-1] + tail_t), E_j the expanded value and E'_j = E_j + 1e-12,
+//     KL(t) = sum_{a_j != 0} a_j * log(a_j / E'_j + 1e-12).
+// (i)  log(r + 1e-12) = log r + x - x^2/2 + ..., x = 1e-12 / r = 1e-12 E'_j / a_j: the first-order part of the sum is
+//      1e-12 * sum_j E'_j (kept, "corr" below); what is dropped is below a_j x^2 / 2 = 1e-24 E'_j^2 / (2 a_j) per term,
+//      < 1e-15 in total for any histogram of fewer than 1e9 samples per bin.
+// (ii) sum a_j log(a_j / E'_j) = sum a_j log a_j - sum a_j log E'_j; E'_j is the same number for every non-empty bin j in
+//      the interior of quantised bin i, so the second sum collapses to one logarithm per quantised bin (times the
+//      interior mass, a difference of two prefix sums), one per fractional bin edge and one for the folded last bin:
+//      <= 257 logarithms per candidate instead of ~t, and no dependence on which bins are empty beyond a prefix count.
+// (iii) Evaluated in float64 (ocml log, < 1 ulp) with the prefix sums held as double-double (a difference of two plain
+//      prefixes would carry 2^-53 of the PREFIX, which a logarithm of a tiny expanded value multiplies by up to 21:
+//      3e-12 on the golden "bimodal"); the rest is <= 260 products of magnitude <= 8 summed along a tree: < 1e-13.
+// Total |S(t) - KL(t)| < 2e-13 (the numpy restatement in tests/test_kl_screen_cpu.py stays below 1e-13 against the exact
+// oracle on every golden and fuzz histogram).  Candidates are kept when S(t) <= min S + 1e-10 (+ 1e-12 |min S|): 500
+// times the bound.  A NaN S(t) (the reference's incremental tail can go slightly negative; log of a negative number)
+// is always kept, so the exact pass reproduces the NaN, which never wins.
+constexpr double kScreenMargin = 1e-10;
+constexpr int kListPerRow = 64;               // rows with more survivors than this are swept exhaustively
+constexpr int kNzStride = FQ_BINS + 4;
+
+// exclusive prefixes of one row as double-double (hi, lo): 8 consecutive bins per thread, block scan of the 256 partial
+// sums, every addition error-free (two_sum) so that prefix DIFFERENCES are accurate to 2^-53 of the difference
+__device__ __forceinline__ fq_dd dd_acc(fq_dd s, double v) {          // s + v, renormalised
+    const fq_dd t = fq_two_sum(s.hi, v);
+    return fq_fast_two_sum(t.hi, t.lo + s.lo);
+}
+
+__global__ __launch_bounds__(kKlBlock) void kl_prefix_kernel(const double* __restrict__ Pw, double* __restrict__ SPw,
+                                                             double* __restrict__ ALw, unsigned short* __restrict__ NZw,
+                                                             int* __restrict__ counters) {
+    __shared__ double s_ph[kKlBlock], s_pl[kKlBlock], s_ah[kKlBlock], s_al[kKlBlock];
+    __shared__ int s_n[kKlBlock];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    if (row == 0 && tid < 2) counters[tid] = 0;
+    const double* P = Pw + (size_t)row * FQ_BINS + tid * 8;
+    double p[8], a[8];
+    fq_dd sp = {0.0, 0.0}, sa = {0.0, 0.0};
+    int sn = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        p[k] = P[k];
+        a[k] = p[k] != 0.0 ? p[k] * log(p[k]) : 0.0;
+        sp = dd_acc(sp, p[k]); sa = dd_acc(sa, a[k]); sn += p[k] != 0.0 ? 1 : 0;
+    }
+    s_ph[tid] = sp.hi; s_pl[tid] = sp.lo; s_ah[tid] = sa.hi; s_al[tid] = sa.lo; s_n[tid] = sn;
+    __syncthreads();
+    for (int d = 1; d < kKlBlock; d <<= 1) {              // Hillis-Steele inclusive scan in double-double
+        fq_dd vp = {0.0, 0.0}, va = {0.0, 0.0}; int vn = 0;
+        if (tid >= d) { vp.hi = s_ph[tid - d]; vp.lo = s_pl[tid - d]; va.hi = s_ah[tid - d]; va.lo = s_al[tid - d]; vn = s_n[tid - d]; }
+        __syncthreads();
+        if (tid >= d) {
+            fq_dd cp = {s_ph[tid], s_pl[tid]}, ca = {s_ah[tid], s_al[tid]};
+            cp = fq_dd_add(cp, vp); ca = fq_dd_add(ca, va);
+            s_ph[tid] = cp.hi; s_pl[tid] = cp.lo; s_ah[tid] = ca.hi; s_al[tid] = ca.lo; s_n[tid] += vn;
+        }
+        __syncthreads();
+    }
+    // exclusive base of this thread's 8 bins = inclusive value of the thread before
+    fq_dd bp = {0.0, 0.0}, ba = {0.0, 0.0};
+    int bn = 0;
+    if (tid > 0) { bp.hi = s_ph[tid - 1]; bp.lo = s_pl[tid - 1]; ba.hi = s_ah[tid - 1]; ba.lo = s_al[tid - 1]; bn = s_n[tid - 1]; }
+    double* SP = SPw + (size_t)row * 2 * (FQ_BINS + 1) + tid * 16;     // interleaved (hi, lo)
+    double* AL = ALw + (size_t)row * 2 * (FQ_BINS + 1) + tid * 16;
+    unsigned short* NZ = NZw + (size_t)row * kNzStride + tid * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        SP[2 * k] = bp.hi; SP[2 * k + 1] = bp.lo; AL[2 * k] = ba.hi; AL[2 * k + 1] = ba.lo; NZ[k] = (unsigned short)bn;
+        bp = dd_acc(bp, p[k]); ba = dd_acc(ba, a[k]); bn += p[k] != 0.0 ? 1 : 0;
+    }
+    if (tid == kKlBlock - 1) { SP[16] = bp.hi; SP[17] = bp.lo; AL[16] = ba.hi; AL[17] = ba.lo; NZ[8] = (unsigned short)bn; }
+}
+
+// S(t) for all 1920 candidates of one row: the row's P, prefix sums and prefix counts staged in LDS once, one wave per
+// candidate (no workgroup barrier inside the loop), two quantised bins per lane.
+__global__ __launch_bounds__(kKlBlock) void kl_screen_kernel(const double* __restrict__ Pw, const double* __restrict__ tailw,
+                                                             const double* __restrict__ SPw, const double* __restrict__ ALw,
+                                                             const unsigned short* __restrict__ NZw, double* __restrict__ klw) {
+    __shared__ double sP[FQ_BINS];
+    __shared__ double sSPh[FQ_BINS + 1], sSPl[FQ_BINS + 1];
+    __shared__ unsigned short sNZ[kNzStride];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+    for (int j = tid; j < FQ_BINS; j += kKlBlock) sP[j] = Pw[(size_t)row * FQ_BINS + j];
+    for (int j = tid; j <= FQ_BINS; j += kKlBlock) {
+        sSPh[j] = SPw[((size_t)row * (FQ_BINS + 1) + j) * 2];
+        sSPl[j] = SPw[((size_t)row * (FQ_BINS + 1) + j) * 2 + 1];
+        sNZ[j] = NZw[(size_t)row * kNzStride + j];
+    }
+    __syncthreads();
+    const double* tail = tailw + (size_t)row * FQ_BINS;
+    const double* AL = ALw + (size_t)row * 2 * (FQ_BINS + 1);
+    auto mass = [&](int lo, int hi) { return (sSPh[hi] - sSPh[lo]) + (sSPl[hi] - sSPl[lo]); };   // sum of P[lo..hi)
+    for (int c = wave; c < kCand; c += kKlBlock / kWave) {
+        const int t = kTarget + c;
+        const double npb = (double)t / (double)kTarget;              // exact dyadic
+        double ev[2], part = 0.0, corr = 0.0;
+        int rl_[2]; double rs_[2]; bool redge[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = lane + h * kWave;
+            const double start = (double)i * npb, end = start + npb;
+            const int lu = (int)ceil(start), rl = (int)floor(end);
+            const bool has_l = (double)lu > start, has_r = (double)rl < end;
+            const double ls = has_l ? (double)lu - start : 0.0, rs = has_r ? end - (double)rl : 0.0;
+            const double pl = has_l ? sP[lu - 1] : 0.0, pr = has_r ? sP[rl] : 0.0;
+            const double q = ls * pl + rs * pr + mass(lu, rl);
+            double count = 1e-12 + (double)((int)sNZ[rl] - (int)sNZ[lu]);
+            if (pl != 0.0) count += ls;
+            if (pr != 0.0) count += rs;
+            ev[h] = q / count;
+            // interior of this quantised bin; the folded last bin t-1 (always interior of bin 127) is handled apart
+            const int hi = (i == kTarget - 1) ? t - 1 : rl;
+            const int nint = (int)sNZ[hi] - (int)sNZ[lu];
+            if (nint > 0) {
+                const double e = (1e-9 + ev[h]) + 1e-12;
+                part += mass(lu, hi) * log(e);
+                corr += (double)nint * e;
+            }
+            rl_[h] = rl; rs_[h] = rs; redge[h] = has_r && pr != 0.0;
+        }
+        // fractional right edges: bin rl belongs to quantised bins i (weight rs) and i + 1 (weight 1 - rs).
+        // bin i = lane      -> neighbour i + 1 is lane + 1's first bin, or (lane 63) bin 64 = lane 0's SECOND bin
+        // bin i = lane + 64 -> neighbour is lane + 1's second bin; bin 127 has no right edge (end == t is an integer)
+        const double nxt0 = __shfl(ev[0], (lane + 1) & (kWave - 1), kWave);
+        const double nxt1 = __shfl(ev[1], (lane + 1) & (kWave - 1), kWave);
+        const double b64 = __shfl(ev[1], 0, kWave);
+        const double evn0 = (lane == kWave - 1) ? b64 : nxt0;
+        if (redge[0]) {
+            const double e = ((1e-9 + ev[0] * rs_[0]) + evn0 * (1.0 - rs_[0])) + 1e-12;
+            part += sP[rl_[0]] * log(e);
+            corr += e;
+        }
+        if (redge[1] && lane != kWave - 1) {
+            const double e = ((1e-9 + ev[1] * rs_[1]) + nxt1 * (1.0 - rs_[1])) + 1e-12;
+            part += sP[rl_[1]] * log(e);
+            corr += e;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            part += __shfl_xor(part, off, kWave);
+            corr += __shfl_xor(corr, off, kWave);
+        }
+        if (lane == kWave - 1) {
+            const double plast = sP[t - 1];
+            const double a_last = plast + tail[t];
+            double s = (AL[2 * (t - 1)] - part) + AL[2 * (t - 1) + 1];
+            if (a_last != 0.0) {                                      // negative (rounding of the tail chain): NaN, kept
+                const double e_last = (plast != 0.0 ? 1e-9 + ev[1] : 1e-9) + 1e-12;
+                s += a_last * log(a_last) - a_last * log(e_last);
+                corr += e_last;
+            }
+            klw[(size_t)row * kCand + c] = s + 1e-12 * corr;
+        }
+    }
+}
+
+// survivors of one row -> work list (or the row -> exhaustive list when there are too many)
+__global__ __launch_bounds__(kKlBlock) void kl_select_kernel(const double* __restrict__ klw, int* __restrict__ list,
+                                                             int* __restrict__ full_rows, int* __restrict__ counters,
+                                                             const int list_capacity) {
+    __shared__ double s_v[kKlBlock];
+    __shared__ int s_cnt;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const double* kl = klw + (size_t)row * kCand;
+    double mn = __builtin_inf();
+    for (int i = tid; i < kCand; i += kKlBlock) { const double v = kl[i]; if (v < mn) mn = v; }     // NaN never lowers it
+    s_v[tid] = mn;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    for (int s2 = kKlBlock / 2; s2 >= 1; s2 >>= 1) {
+        if (tid < s2 && s_v[tid + s2] < s_v[tid]) s_v[tid] = s_v[tid + s2];
+        __syncthreads();
+    }
+    mn = s_v[0];
+    const double limit = mn + (kScreenMargin + 1e-12 * fabs(mn));       // inf when no S is finite: everything survives
+    int mine = 0;
+    for (int i = tid; i < kCand; i += kKlBlock) mine += !(kl[i] > limit) ? 1 : 0;
+    if (mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    const int total = s_cnt;
+    if (total > kListPerRow) {
+        if (tid == 0) full_rows[atomicAdd(&counters[1], 1)] = row;
+        return;
+    }
+    for (int i = tid; i < kCand; i += kKlBlock)
+        if (!(kl[i] > limit)) {
+            const int slot = atomicAdd(&counters[0], 1);
+            if (slot < list_capacity) list[slot] = (row << 11) | i;
+        }
+}
+
+// exact KL of the listed candidates and of every candidate of the listed rows; a fixed grid strides over the work,
+// whose size lives on the device (no host round trip between the screen and the exact pass)
+__global__ __launch_bounds__(kKlBlock) void kl_exact_list_kernel(const double* __restrict__ Pw, const double* __restrict__ tailw,
+                                                                 double* __restrict__ klw, const int* __restrict__ list,
+                                                                 const int* __restrict__ full_rows,
+                                                                 const int* __restrict__ counters, const int list_capacity) {
+    __shared__ SweepSmem sm;
+    const int n_list = counters[0] < list_capacity ? counters[0] : list_capacity;
+    const long long total = (long long)n_list + (long long)counters[1] * kCand;
+    for (long long w = blockIdx.x; w < total; w += gridDim.x) {
+        int row, c;
+        if (w < n_list) {
+            const int e = list[w];
+            row = e >> 11; c = e & 2047;
+        } else {
+            const long long r = w - n_list;
+            row = full_rows[r / kCand]; c = (int)(r % kCand);
+        }
+        const int t = kTarget + c;
+        kl_exact_candidate(sm, Pw + (size_t)row * FQ_BINS, tailw[(size_t)row * FQ_BINS + t], t, klw + (size_t)row * kCand + c);
+        __syncthreads();                                               // sm is reused by the next item
     }
 }
 
 // ---- argmin: first strict minimum below 66666 (quantizer.py:99,:163-165), default 2047 (:101) ----
-__global__ __launch_bounds__(kKlBlock) void kl_argmin_kernel(const double* __restrict__ klw, int* __restrict__ thr_out) {
-    __shared__ double s_v[kKlBlock];
+// Also reports how decisive the choice was: best = KL(t*), runner_up = the smallest KL of any OTHER candidate (+inf when
+// there is none): a runner-up within an ulp-sized distance of the best is a near-tie that a differently rounded
+// logarithm (np.log vs fq_log, DESIGN.md "The logarithm") could have decided the other way.
+__global__ __launch_bounds__(kKlBlock) void kl_argmin_kernel(const double* __restrict__ klw, int* __restrict__ thr_out,
+                                                             double* __restrict__ best_out, double* __restrict__ runner_out) {
+    __shared__ double s_v[kKlBlock], s_w[kKlBlock];
     __shared__ int s_t[kKlBlock];
     const int row = blockIdx.x, tid = threadIdx.x;
     const double* kl = klw + (size_t)row * kCand;
-    double bv = 66666.0;
+    double bv = 66666.0, second = __builtin_inf();
     int bt = 0x7fffffff;
     for (int i = tid; i < kCand; i += kKlBlock) {
         const double v = kl[i];
-        if (v < bv) { bv = v; bt = kTarget + i; }                         // NaN never wins
+        if (v < bv) { if (bt != 0x7fffffff) second = bv; bv = v; bt = kTarget + i; }   // NaN never wins
+        else if (v < second) second = v;
     }
-    s_v[tid] = bv; s_t[tid] = bt;
+    s_v[tid] = bv; s_t[tid] = bt; s_w[tid] = second;
     __syncthreads();
     for (int s = kKlBlock / 2; s >= 1; s >>= 1) {
         if (tid < s) {
-            const double v2 = s_v[tid + s];
+            const double v2 = s_v[tid + s], w2 = s_w[tid + s];
             const int t2 = s_t[tid + s];
-            if (v2 < s_v[tid] || (v2 == s_v[tid] && t2 < s_t[tid])) { s_v[tid] = v2; s_t[tid] = t2; }
+            const bool take = v2 < s_v[tid] || (v2 == s_v[tid] && t2 < s_t[tid]);
+            // the loser's best is a candidate for runner-up (only if it stands for a real candidate)
+            double lose = take ? s_v[tid] : v2;
+            const int lose_t = take ? s_t[tid] : t2;
+            if (lose_t == 0x7fffffff) lose = __builtin_inf();
+            double w = s_w[tid] < w2 ? s_w[tid] : w2;
+            if (lose < w) w = lose;
+            if (take) { s_v[tid] = v2; s_t[tid] = t2; }
+            s_w[tid] = w;
         }
         __syncthreads();
     }
-    if (tid == 0) thr_out[row] = (s_t[0] == 0x7fffffff) ? (FQ_BINS - 1) : s_t[0];
+    if (tid == 0) {
+        const bool none = s_t[0] == 0x7fffffff;
+        thr_out[row] = none ? (FQ_BINS - 1) : s_t[0];
+        if (best_out) best_out[row] = none ? __builtin_inf() : s_v[0];
+        if (runner_out) runner_out[row] = s_w[0];
+    }
 }
 
-constexpr size_t kWsPerRow = (size_t)(FQ_BINS + FQ_BINS + kCand) * sizeof(double);
+constexpr int kRowChunk = 4096;              // rows per pass over the workspace (keeps it at ~340 MB for any row count)
+constexpr int kScreenMinRows = 256;          // FQ_KL_AUTO: below this the exhaustive sweep is latency bound anyway
+
+constexpr size_t align8(size_t v) { return (v + 7) & ~(size_t)7; }
+constexpr size_t kWsPerRow = (size_t)(FQ_BINS + FQ_BINS + kCand) * sizeof(double)             // P, tail, KL curve
+                             + 4 * (size_t)(FQ_BINS + 1) * sizeof(double)                      // SP, AL (double-double)
+                             + align8((size_t)kNzStride * sizeof(unsigned short))              // NZ
+                             + (size_t)(kListPerRow + 1) * sizeof(int) + 8;                    // work list, full-row list
+
+static bool kl_env_exhaustive() {
+    static const bool v = [] { const char* e = getenv("FQ_KL_EXHAUSTIVE"); return e && e[0] && e[0] != '0'; }();
+    return v;
+}
 
 }  // namespace fq
 
 extern "C" size_t fq_kl_workspace_bytes(int rows) {
-    return rows > 0 ? (size_t)rows * fq::kWsPerRow : 0;
+    if (rows <= 0) return 0;
+    const size_t r = rows < fq::kRowChunk ? (size_t)rows : (size_t)fq::kRowChunk;
+    return r * fq::kWsPerRow + 64;
 }
 
-extern "C" int fq_kl_threshold(const int64_t* hist, int rows, int32_t* thr_out, double* kl_curve_out,
-                               void* workspace, size_t workspace_bytes, fq_stream_t stream) {
+extern "C" int fq_kl_threshold_ex(const int64_t* hist, int rows, int32_t* thr_out, double* best_kl_out,
+                                  double* runner_up_kl_out, double* kl_curve_out, int mode,
+                                  void* workspace, size_t workspace_bytes, fq_stream_t stream) {
     using namespace fq;
-    if (rows < 0) return FQ_ERR_INVALID_ARG;
+    if (rows < 0 || mode < FQ_KL_AUTO || mode > FQ_KL_SCREENED) return FQ_ERR_INVALID_ARG;
     if (rows == 0) return FQ_OK;
     if (!hist || !thr_out || !workspace) return FQ_ERR_INVALID_ARG;
     if (workspace_bytes < fq_kl_workspace_bytes(rows)) return FQ_ERR_WORKSPACE;
     if (reinterpret_cast<uintptr_t>(workspace) & 7u) return FQ_ERR_INVALID_ARG;
     hipStream_t st = as_stream(stream);
-    double* Pw = reinterpret_cast<double*>(workspace);
-    double* tailw = Pw + (size_t)rows * FQ_BINS;
-    double* klw = kl_curve_out ? kl_curve_out : tailw + (size_t)rows * FQ_BINS;
-    const int kChunk = 32768;                                    // grid.y limit
-    for (int r0 = 0; r0 < rows; r0 += kChunk) {
-        const int nr = rows - r0 < kChunk ? rows - r0 : kChunk;
+    const bool screened = mode == FQ_KL_SCREENED ||
+                          (mode == FQ_KL_AUTO && rows >= kScreenMinRows && !kl_curve_out && !kl_env_exhaustive());
+    const size_t ch = rows < kRowChunk ? (size_t)rows : (size_t)kRowChunk;
+    char* w = reinterpret_cast<char*>(workspace);
+    double* Pw = reinterpret_cast<double*>(w);            w += ch * FQ_BINS * sizeof(double);
+    double* tailw = reinterpret_cast<double*>(w);         w += ch * FQ_BINS * sizeof(double);
+    double* kl_ws = reinterpret_cast<double*>(w);         w += ch * kCand * sizeof(double);
+    double* SPw = reinterpret_cast<double*>(w);           w += ch * 2 * (FQ_BINS + 1) * sizeof(double);
+    double* ALw = reinterpret_cast<double*>(w);           w += ch * 2 * (FQ_BINS + 1) * sizeof(double);
+    unsigned short* NZw = reinterpret_cast<unsigned short*>(w);  w += align8(ch * kNzStride * sizeof(unsigned short));
+    int* list = reinterpret_cast<int*>(w);                w += ch * kListPerRow * sizeof(int);
+    int* full_rows = reinterpret_cast<int*>(w);           w += align8(ch * sizeof(int));
+    int* counters = reinterpret_cast<int*>(w);
+    for (int r0 = 0; r0 < rows; r0 += kRowChunk) {
+        const int nr = rows - r0 < kRowChunk ? rows - r0 : kRowChunk;
+        double* klw = kl_curve_out ? kl_curve_out + (size_t)r0 * kCand : kl_ws;
         hipLaunchKernelGGL(kl_prepare_kernel, dim3(nr), dim3(kKlBlock), 0, st,
-                           reinterpret_cast<const long long*>(hist) + (size_t)r0 * FQ_BINS,
-                           Pw + (size_t)r0 * FQ_BINS, tailw + (size_t)r0 * FQ_BINS);
+                           reinterpret_cast<const long long*>(hist) + (size_t)r0 * FQ_BINS, Pw, tailw);
         FQ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(kl_sweep_kernel, dim3(kCand, nr), dim3(kKlBlock), 0, st, Pw + (size_t)r0 * FQ_BINS,
-                           tailw + (size_t)r0 * FQ_BINS, klw + (size_t)r0 * kCand);
-        FQ_LAUNCH_CHECK();
-        hipLaunchKernelGGL(kl_argmin_kernel, dim3(nr), dim3(kKlBlock), 0, st, klw + (size_t)r0 * kCand, thr_out + r0);
+        if (!screened) {
+            hipLaunchKernelGGL(kl_sweep_kernel, dim3(kCand, nr), dim3(kKlBlock), 0, st, Pw, tailw, klw);
+            FQ_LAUNCH_CHECK();
+        } else {
+            hipLaunchKernelGGL(kl_prefix_kernel, dim3(nr), dim3(kKlBlock), 0, st, Pw, SPw, ALw, NZw, counters);
+            FQ_LAUNCH_CHECK();
+            hipLaunchKernelGGL(kl_screen_kernel, dim3(nr), dim3(kKlBlock), 0, st, Pw, tailw, SPw, ALw, NZw, klw);
+            FQ_LAUNCH_CHECK();
+            hipLaunchKernelGGL(kl_select_kernel, dim3(nr), dim3(kKlBlock), 0, st, klw, list, full_rows, counters,
+                               nr * kListPerRow);
+            FQ_LAUNCH_CHECK();
+            const int wgs = nr * 8 < kCUs * 8 ? nr * 8 : kCUs * 8;
+            hipLaunchKernelGGL(kl_exact_list_kernel, dim3(wgs), dim3(kKlBlock), 0, st, Pw, tailw, klw, list, full_rows,
+                               counters, nr * kListPerRow);
+            FQ_LAUNCH_CHECK();
+        }
+        hipLaunchKernelGGL(kl_argmin_kernel, dim3(nr), dim3(kKlBlock), 0, st, klw, thr_out + r0,
+                           best_kl_out ? best_kl_out + r0 : nullptr, runner_up_kl_out ? runner_up_kl_out + r0 : nullptr);
         FQ_LAUNCH_CHECK();
     }
     return FQ_OK;
+}
+
+extern "C" int fq_kl_threshold(const int64_t* hist, int rows, int32_t* thr_out, double* kl_curve_out,
+                               void* workspace, size_t workspace_bytes, fq_stream_t stream) {
+    return fq_kl_threshold_ex(hist, rows, thr_out, nullptr, nullptr, kl_curve_out, FQ_KL_AUTO, workspace, workspace_bytes,
+                              stream);
 }

@@ -61,6 +61,8 @@ def lib():
     L.fq_kl_workspace_bytes.argtypes = [ci]
     L.fq_kl_threshold.restype = ci
     L.fq_kl_threshold.argtypes = [vp, ci, vp, vp, vp, sz, vp]
+    L.fq_kl_threshold_ex.restype = ci
+    L.fq_kl_threshold_ex.argtypes = [vp, ci, vp, vp, vp, vp, ci, vp, sz, vp]
     L.fq_bits_from_threshold.restype = ci
     L.fq_bits_from_threshold.argtypes = [vp, vp, ci, vp, vp]
     L.fq_bits_from_absmax.restype = ci
@@ -222,20 +224,30 @@ def hist2048_seg(tensors, rows, interval, hist):
     return keep
 
 
-def kl_threshold(hist, want_curve=False):
-    """Threshold bin per row (int32 cuda tensor); optionally the [rows,1920] float64 KL curves."""
+KL_AUTO, KL_EXHAUSTIVE, KL_SCREENED = 0, 1, 2
+
+
+def kl_threshold(hist, want_curve=False, mode=KL_AUTO, want_evidence=False):
+    """Threshold bin per row (int32 cuda tensor); optionally the [rows,1920] float64 KL curves and/or the evidence
+    (best KL, runner-up KL: float64 cuda tensors).  Returns thr, or (thr, curve), or (thr, best, runner_up), or
+    (thr, curve, best, runner_up).  mode: fq.h FQ_KL_AUTO / FQ_KL_EXHAUSTIVE / FQ_KL_SCREENED."""
     _need_cuda(hist, torch.int64, "hist")
     assert hist.is_contiguous() and hist.dim() == 2 and hist.shape[1] == BINS
     rows = hist.shape[0]
-    thr = torch.empty(rows, dtype=torch.int32, device=hist.device)
-    if rows == 0:
-        return (thr, torch.empty(0, KL_CANDIDATES, dtype=torch.float64, device=hist.device)) if want_curve else thr
-    wsb = lib().fq_kl_workspace_bytes(rows)
-    ws = torch.empty(wsb // 8, dtype=torch.float64, device=hist.device)
-    curve = torch.empty(rows, KL_CANDIDATES, dtype=torch.float64, device=hist.device) if want_curve else None
-    _check(lib().fq_kl_threshold(hist.data_ptr(), rows, thr.data_ptr(), curve.data_ptr() if want_curve else None,
-                                 ws.data_ptr(), wsb, _stream(hist)), "fq_kl_threshold")
-    return (thr, curve) if want_curve else thr
+    dev = hist.device
+    thr = torch.empty(rows, dtype=torch.int32, device=dev)
+    curve = torch.empty(rows, KL_CANDIDATES, dtype=torch.float64, device=dev) if want_curve else None
+    best = torch.empty(rows, dtype=torch.float64, device=dev) if want_evidence else None
+    runner = torch.empty(rows, dtype=torch.float64, device=dev) if want_evidence else None
+    if rows:
+        wsb = lib().fq_kl_workspace_bytes(rows)
+        ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
+        _check(lib().fq_kl_threshold_ex(hist.data_ptr(), rows, thr.data_ptr(), best.data_ptr() if want_evidence else None,
+                                        runner.data_ptr() if want_evidence else None,
+                                        curve.data_ptr() if want_curve else None, int(mode), ws.data_ptr(), wsb,
+                                        _stream(hist)), "fq_kl_threshold_ex")
+    out = (thr,) + ((curve,) if want_curve else ()) + ((best, runner) if want_evidence else ())
+    return out if len(out) > 1 else thr
 
 
 def _relu_ptr(relu_out, like):

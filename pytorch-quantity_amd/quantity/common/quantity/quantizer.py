@@ -51,6 +51,8 @@ class Quantizer(object):
         self._bits = {}
         self._threshold_value = {}
         self._threshold_bin = {}
+        self._kl_best = {}
+        self._kl_runner_up = {}
         self._quantized_flag = False
 
     @property
@@ -68,6 +70,24 @@ class Quantizer(object):
         """The raw threshold bin t* in [128, 2047] per tensor (not exposed by the reference)."""
         assert self._quantized_flag, "Please use quantize() first."
         return self._threshold_bin
+
+    @property
+    def kl_margin(self):
+        """{name: (KL(t*), smallest KL of any other candidate)} (not exposed by the reference).  The argmin is decided by
+        fq_log, a correctly rounded logarithm; the reference's np.log is faithful but not correctly rounded, so where the
+        two values are within a few ulps of each other the reference could have picked the other candidate.  near_ties()
+        lists those rows."""
+        assert self._quantized_flag, "Please use quantize() first."
+        return {n: (self._kl_best[n], self._kl_runner_up[n]) for n in self._kl_best}
+
+    def near_ties(self, rel=1e-12):
+        """Names whose best and second-best KL differ by less than rel * |best| (an argmin a last-bit difference in the
+        logarithm could flip).  Empty on every golden, fuzz and ResNet histogram seen so far."""
+        out = []
+        for n, (b, r) in self.kl_margin.items():
+            if math.isfinite(b) and math.isfinite(r) and (r - b) <= rel * abs(b):
+                out.append(n)
+        return out
 
     def _result_order(self):
         """The reference fills .bits worker by worker (worker 0 takes the first chunk plus the
@@ -89,7 +109,10 @@ class Quantizer(object):
             return
         self._quantized_flag = True
         hist = _rows_to_device(distributions, self._tensor_list, self._device)
-        thr = dict(zip(self._tensor_list, _native.kl_threshold(hist).cpu().numpy()))
+        thr_dev, best_dev, runner_dev = _native.kl_threshold(hist, want_evidence=True)
+        thr = dict(zip(self._tensor_list, thr_dev.cpu().numpy()))
+        self._kl_best = dict(zip(self._tensor_list, (float(v) for v in best_dev.cpu().numpy())))
+        self._kl_runner_up = dict(zip(self._tensor_list, (float(v) for v in runner_dev.cpu().numpy())))
         for name in self._result_order():
             t = int(thr[name])
             # reference quantizer.py:86-90; NumPy scalar typing decides fp32 vs float64 here exactly
@@ -100,3 +123,6 @@ class Quantizer(object):
             self._threshold_value[name] = threshold_bias
             self._bits[name] = bit
             print("{} ".format(name), "bit:", bit)
+        ties = self.near_ties()
+        if ties:
+            print("[WARNING] KL near-ties (best and second-best threshold within 1e-12 relative):", ties)

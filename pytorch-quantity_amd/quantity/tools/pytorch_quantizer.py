@@ -349,16 +349,16 @@ class Quantity(object):
         free, total = torch.cuda.mem_get_info()
         reserved, live = torch.cuda.memory_reserved(), torch.cuda.memory_allocated()
         pooled = reserved - live                   # held by the caching allocator, reusable by us
-        foreign = (total - free) - reserved        # other processes / the driver
-        # Growing the caching allocator is what a cache costs a COLD process: 10-30 ms per GB of fresh hipMalloc on
-        # MI355X / ROCm 7.2 (scripts/alloc_probe.py; one run also showed a one-off ~4 s stall past ~128 GB), more
-        # than the forwards it saves on a few thousand images -- so a cold process stays below 96 GB in total.
-        cold = max(0, min(int((free + pooled) * 0.6), (96 << 30) - foreign - live))
+        # What a cache costs a COLD process is growing the caching allocator: 28 ms per GB of fresh hipMalloc on MI355X /
+        # ROCm 7.2 (bench.py's fresh-process run: pass 1 of 5 120 ResNet-50 images 4.38 s with an 86 GB cache against
+        # 0.67 s in a warm pool; scripts/alloc_probe.py: 10-30 ms per GB).  What a cached GB saves is at most ~8 ms (the
+        # deepest activations: most forward time per byte; whole batches: 2 ms per GB).  So a process never GROWS its pool
+        # for the cache (round 1 allowed itself 96 GB and ran the 5 120-image config at 1 040 images/s cold).
         # Memory the allocator already holds (a long-running calibration service, or bench.py after its warm-up) costs
-        # nothing to use: all of it except 1/16 of the device, which stays with the forward's own transient tensors (the part of
-        # HBM the pool does not cover absorbs anything beyond that).
+        # nothing to use: all of it except 1/16 of the device, which stays with the forward's own transient tensors (the
+        # part of HBM the pool does not cover absorbs anything beyond that).
         warm = pooled - (total >> 4)
-        return max(cold, warm, 0)
+        return max(warm, 0)
 
     def _patch_fused_convs(self, model):
         """Give every hooked nn.Conv2d with a bias a forward that, while pass 1 is running on the GPU, leaves the bias to
@@ -826,15 +826,29 @@ class Quantity(object):
             # in-place consumers: one launch per tensor from inside the hooks (the values the reference's hooks would copy)
             self._stats_limit = 0 if probe.modified() else _AFTER_FORWARD
             del probe
+            # pass 2 histograms the very tensors pass 1 took the maxima of, for as many batches as fit the allocator's
+            # warm pool (whole batches only: _activation_cache_budget; nothing is kept when a later module overwrites
+            # hooked tensors in place)
+            budget = self._activation_cache_budget() if self._stats_limit else 0
+            cached, used = {}, 0
             for _pass in (1, 2):
                 fn = collector.refresh_max_val if _pass == 1 else collector.add_to_distributions
                 for i, item in self._device_items(images_files):
+                    if _pass == 2 and i in cached:
+                        fn(cached.pop(i))
+                        continue
                     self._forward_with_stats(item, fn, named_feats)
+                    if _pass == 1 and budget:
+                        need = sum(t.numel() * t.element_size() for t in named_feats.values())
+                        if used + need <= budget:
+                            cached[i] = dict(named_feats)
+                            used += need
                 if _dist_on():
                     collector.all_reduce_max() if _pass == 1 else collector.all_reduce_hist()
                 if _pass == 1:
                     collector.intervals()
             bits = collector.quantize()
+            self.timings = {"per_channel_cache_bytes": used, "per_channel_kl_s": getattr(collector, "kl_seconds", None)}
         finally:
             for h in hooks:
                 h.remove()

@@ -96,11 +96,19 @@ def capture_r50(cq, tl):
         out["recon_max_abs_accumulator"] = max(accmax)
         out["recon_conv1_out_sha256"] = _sha(c1)
         arrays["recon_conv1_out_sample"] = c1[:, :8, ::8, ::8].copy()
-        # stage outputs (after layer1 / layer4) as sha256: localises a mismatch without shipping 6 MB tensors
+        # stage outputs as sha256 (+ a small sub-sample) and the classifier's input in full: localises a mismatch
+        # without shipping 6 MB tensors
         with torch.no_grad():
             s = recon.maxpool(recon.relu(recon.conv1(x)))
-            s = recon.layer1(s)
-            out["recon_layer1_out_sha256"] = _sha(s.numpy())
+            out["recon_stage_sha256"] = {}
+            for stage in ("layer1", "layer2", "layer3", "layer4"):
+                s = getattr(recon, stage)(s)
+                out["recon_stage_sha256"][stage] = _sha(s.numpy())
+                arrays["recon_%s_sample" % stage] = s.numpy()[:, :16, ::4, ::4].copy()
+            out["recon_layer1_out_sha256"] = out["recon_stage_sha256"]["layer1"]
+            pooled = recon.view(recon.avgpool(s))
+            arrays["recon_fc_input"] = pooled.numpy().copy()
+            arrays["recon_layer4_out_int8"] = np.round(s.numpy() * 2.0 ** info["layer4.2.Eltwise"]["output_bit"]).astype(np.int16)[:, :64].copy()
         out["recon_state_dict_keys"] = sorted(recon.state_dict().keys())
 
         rec2 = tl.Reconstruction(cases.seed_model(ResNet50(), gamma_scale=GAMMA).eval())

@@ -204,6 +204,53 @@ def test_kl_threshold_random_rows_vs_oracle(nat, oracle):
         np.testing.assert_array_equal(curve[i][f].view(np.uint64), c_fq[f].view(np.uint64))
 
 
+def _fuzz_rows(n, seed):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import kl_fuzz_hist
+    rng = np.random.default_rng(seed)
+    return np.stack([kl_fuzz_hist.random_histogram(rng) for _ in range(n)])
+
+
+def test_kl_screened_search_equals_the_exhaustive_one(nat):
+    """FQ_KL_SCREENED (closed-form screen of all candidates, exact evaluation of the survivors) against FQ_KL_EXHAUSTIVE
+    on the goldens and 200 fuzz histograms: same thresholds, bit-identical best KL, and the screen's own values within
+    2e-13 of the exact curve at every candidate (its selection margin is 1e-10); NaNs at the same candidates."""
+    hs = cases.g2_cases()
+    H = np.concatenate([np.stack([np.asarray(hs[n]).astype(np.int64) for n in G2_NAMES]), _fuzz_rows(200, 11)])
+    dev = _dev(H)
+    thr_x, cur_x, best_x, run_x = (t.cpu().numpy() for t in nat.kl_threshold(dev, want_curve=True, mode=nat.KL_EXHAUSTIVE,
+                                                                               want_evidence=True))
+    thr_s, cur_s, best_s, run_s = (t.cpu().numpy() for t in nat.kl_threshold(dev, want_curve=True, mode=nat.KL_SCREENED,
+                                                                               want_evidence=True))
+    np.testing.assert_array_equal(thr_s, thr_x)
+    np.testing.assert_array_equal(best_s.view(np.uint64), best_x.view(np.uint64))
+    np.testing.assert_array_equal(np.isnan(cur_s), np.isnan(cur_x))
+    f = np.isfinite(cur_x)
+    assert np.max(np.abs(cur_s[f] - cur_x[f])) < 2e-13
+    exact_entries = (cur_s.view(np.uint64) == cur_x.view(np.uint64)) & f
+    rows = np.arange(len(H))
+    won = best_x < 66666.0
+    assert exact_entries[rows[won], thr_x[won] - 128].all()          # the winner was evaluated exactly
+    fr = np.isfinite(run_x)
+    assert np.max(np.abs(run_s[fr] - run_x[fr])) < 2e-13
+    # evidence of the exhaustive search itself: best = curve[thr], runner-up = smallest other entry
+    for r in (0, 5, 17, 40, 100):
+        c = np.where(np.isnan(cur_x[r]), np.inf, cur_x[r])
+        if c.min() < 66666.0:
+            assert best_x[r] == c[thr_x[r] - 128] == c.min()
+            assert run_x[r] == np.delete(c, thr_x[r] - 128).min()
+
+
+def test_kl_auto_mode_with_many_rows_matches_the_exhaustive_search(nat):
+    """From 256 rows up FQ_KL_AUTO takes the screened path (per-channel calibration: 42 667 rows): thresholds of 5 000
+    fuzz rows (chunked workspace: two passes: 4 096 + 904 rows) equal the exhaustive ones."""
+    dev = _dev(_fuzz_rows(5000, 5))
+    thr_auto = nat.kl_threshold(dev).cpu().numpy()
+    thr_x = nat.kl_threshold(dev, mode=nat.KL_EXHAUSTIVE).cpu().numpy()
+    np.testing.assert_array_equal(thr_auto, thr_x)
+
+
 # ---------------------------------------------------------------- element-wise ops
 def test_g5_ops_golden(nat, golden_dir):
     g = np.load(os.path.join(golden_dir, "g5_ops.npz"))

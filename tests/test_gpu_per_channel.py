@@ -45,10 +45,19 @@ def test_channel_collector_vs_oracle(oracle):
             assert bits[name][c] == oracle.bits_from_threshold(t, ref_iv)[0]
 
 
-@pytest.mark.parametrize("shape", [(45, 3, 40, 40), (2, 5, 33, 33), (130, 7, 5, 5), (3, 2, 224, 224), (9, 1000), (1, 4, 1, 1)])
+@pytest.mark.parametrize("shape", [(45, 3, 40, 40), (2, 5, 33, 33), (130, 7, 5, 5), (3, 2, 224, 224), (9, 1000), (1, 4, 1, 1),
+                                   (128, 64, 14, 14),      # small planes, 8-channel blocks, 16-byte loads
+                                   (40, 20, 7, 7),         # 7x7 planes (196 B), ragged last block of 4 channels
+                                   (33, 10, 7, 7),         # image stride not a multiple of 16 bytes: 4-byte loads
+                                   (200, 16, 28, 28),      # 5 image groups per channel block (<= 32 768 elements per row)
+                                   (40, 9, 33, 31),        # HW = 1023: just below the big-plane switch, odd everything
+                                   (5, 3, 300, 300),       # big planes, 90 000 elements, one image group of 2 + ...
+                                   (1, 2, 512, 512),       # config-5 sized plane: one image per workgroup, no division
+                                   (6, 12, 32, 32)])       # HW = 1024: the switch itself
 def test_channel_kernels_large_and_ragged_planes(oracle, shape):
-    """fq_absmax_chan / fq_hist2048_chan on planes above and below the 1024-element switch, planes whose start
-    is not 16-byte aligned, several image groups per channel, [N, F] inputs -- row by row against the oracle."""
+    """fq_absmax_chan / fq_hist2048_chan on planes above and below the 1024-element switch (one channel per workgroup
+    with 32-bit bins above, blocks of 8 channels with packed 16-bit bins below), planes whose start is not 16-byte
+    aligned, several image groups per channel, ragged channel blocks, [N, F] inputs -- row by row against the oracle."""
     from common.quantity import _native as nat
     rng = np.random.default_rng(sum(shape))
     x = (rng.standard_normal(shape, dtype=np.float32) * np.float32(2.5)).astype(np.float32)
@@ -72,6 +81,25 @@ def test_channel_kernels_large_and_ragged_planes(oracle, shape):
         ref = oracle.hist2048(np.ascontiguousarray(x[:, c]).ravel(), iv[row0 + c])
         np.testing.assert_array_equal(hh[row0 + c], 2 * ref)
     assert not hh[:row0].any() and not hh[row0 + C:].any()
+
+
+def test_channel_histogram_packed_bins_do_not_carry(oracle):
+    """Small planes count in 16-bit halves of a dword: a workgroup hands one row at most 32 768 elements, so even when
+    they all fall into ONE bin (a constant tensor: every element lands in bin 2047) nothing carries into the
+    neighbouring bin.  Odd and even bins, two image groups."""
+    from common.quantity import _native as nat
+    N, C, H, W = 70, 8, 31, 33                             # HW = 1023 -> 32 images per group: 32 736 elements per row
+    x = torch.ones(N, C, H, W, device="cuda")
+    x[:, 1] *= 0.5                                          # |x| / iv = 1023.99..: bin 1023 (odd half) with iv from max 1.0
+    x[:, 2] *= 512.5 / 2048                                 # bin 512 (even half)
+    iv = torch.full((C,), float(oracle.interval(np.float32(1.0))), device="cuda")
+    hist = torch.zeros(C, 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_chan([x], [0], iv, hist)
+    hh = hist.cpu().numpy()
+    for c in range(C):
+        ref = oracle.hist2048(x[:, c].cpu().numpy().ravel(), np.float32(iv[c].item()))
+        np.testing.assert_array_equal(hh[c], ref)
+    assert hh[0, 2047] == N * H * W and hh[1, 1023] == N * H * W and hh[2, 512] == N * H * W
 
 
 def test_per_channel_calibration_of_a_model():
@@ -113,3 +141,22 @@ def test_per_channel_calibration_sees_hook_time_values_of_inplace_models():
             tables.append(open(os.path.join(tmp, "test", "workdir", "feat_channel.table")).read())
             assert q._stats_limit == (0 if inplace else 1 << 62)
     assert tables[0] == tables[1] and tables[0].count("\n") == 5
+
+
+def test_per_channel_activation_cache_does_not_change_the_table(monkeypatch):
+    """Pass 2 may histogram the tensors kept from pass 1 instead of running the forward again (whole batches, inside
+    the allocator's warm pool): same per-channel table, histograms and maxima either way."""
+    from tools import Quantity
+    out = []
+    for cache_gb in ("0", "1"):
+        monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
+        with product_workdir(input_shape="1,3,8,8", device="gpu", max_cali_img_num=3) as tmp:
+            q = Quantity(cases.seed_model(cases.tiny_concat_net(), base_seed=7).eval().cuda())
+            q.activation_quantize_per_channel(cases.calib_batches(4, (4, 3, 8, 8), seed=4321))
+            out.append((open(os.path.join(tmp, "test", "workdir", "feat_channel.table")).read(),
+                        q._channel_collector.hist_device.cpu().numpy(), q._channel_collector.max_device.cpu().numpy(),
+                        q.timings["per_channel_cache_bytes"]))
+    assert out[0][0] == out[1][0]
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert out[0][3] == 0 and out[1][3] > 0

@@ -235,11 +235,20 @@ def test_r50_reconmodel_logits_equal_the_reference(g4r50):
         assert sorted(net.state_dict().keys()) == tables["recon_state_dict_keys"]
         with torch.no_grad():
             c1 = net.conv1(x).cpu().numpy()
-            l1 = net.layer1(net.maxpool(net.relu(net.conv1(x)))).cpu().numpy()
             logits = net(x).cpu().numpy()
+            # stage by stage (sha256 of the whole tensor + a sub-sample in the fixture), so that a mismatch names its layer
+            s = net.maxpool(net.relu(net.conv1(x)))
+            for stage in ("layer1", "layer2", "layer3", "layer4"):
+                s = getattr(net, stage)(s)
+                got = s.cpu().numpy()
+                np.testing.assert_array_equal(got[:, :16, ::4, ::4], g4["recon_%s_sample" % stage], err_msg=stage)
+                assert _sha(got) == tables["recon_stage_sha256"][stage], stage
+            pooled = net.view(net.avgpool(s))
+            np.testing.assert_array_equal(pooled.cpu().numpy(), g4["recon_fc_input"])          # AvgPool2d(7): sum / 49
+            # the classifier alone, on the reference's own input to it
+            np.testing.assert_array_equal(net.fc(torch.from_numpy(g4["recon_fc_input"]).cuda()).cpu().numpy(), g4["logits_recon"])
         np.testing.assert_array_equal(c1[:, :8, ::8, ::8], g4["recon_conv1_out_sample"])
         assert _sha(c1) == tables["recon_conv1_out_sha256"]
-        assert _sha(l1) == tables["recon_layer1_out_sha256"]
         np.testing.assert_array_equal(logits, g4["logits_recon"])
         summary = resident.enable(net, x)
         assert summary["resident_convs"] == 53 and summary["fused_conv_adds"] == 16, summary
