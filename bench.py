@@ -586,26 +586,29 @@ def main():
     # ---- pass 1's statistics ride on the producers' own kernels: their rooflines, measured on three more batches of
     # the same shape after the timed region (events around every one of the ~70 launches per forward would perturb it)
     try:
-        with CallTimer(_native, "bias_add_absmax", _bias_add_bytes) as kt_b, CallTimer(_native, "add_absmax", _add_bytes) as kt_a:
+        with CallTimer(_native, "bias_add_absmax", _bias_add_bytes) as kt_b, CallTimer(_native, "add_absmax", _add_bytes) as kt_a, \
+                CallTimer(_native, "bias_add_hist", _bias_add_bytes) as kt_bh, CallTimer(_native, "add_hist", _add_bytes) as kt_ah:
             make_workdir(3 * world - 1, shape, local_rank)
             extra = DeviceBatches(3 * world, B, HW, rank, world, device)
             eq = Quantity(model)
-            kt_b.enabled = kt_a.enabled = True
+            kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = True
             eq.activation_quantize(extra)
             torch.cuda.synchronize()
             del extra, eq
-        sb, sa = kt_b.summary(), kt_a.summary()
-        if sb:
-            result["roofline_bias_add_absmax"] = hbm_roofline(
-                "bias_add_absmax_kernel", sb,
-                {"note": "53 launches per forward: y += bias[c] in place with max|y| (and the following ReLU's output) folded in; "
-                         "8 B/element, 12 with the ReLU copy; mean over all layer sizes (the small late layers are launch bound)",
-                 "aggregate_gbs": round(sb["gbs"], 1)})
-        if sa:
-            result["roofline_add_absmax"] = hbm_roofline(
-                "add_absmax_kernel", sa,
-                {"note": "16 launches per forward: z = x + y with max|z| (and the ReLU's output) folded in; 12 B/element, 16 with "
-                         "the ReLU copy", "aggregate_gbs": round(sa["gbs"], 1)})
+        for key, kt, kernel, note in (
+                ("roofline_bias_add_absmax", kt_b, "bias_add_absmax_kernel",
+                 "pass 1, 53 launches per forward: y += bias[c] in place with max|y| (and the following ReLU's output) folded in; "
+                 "8 B/element, 12 with the ReLU copy; mean over all layer sizes (the small late layers are launch bound)"),
+                ("roofline_add_absmax", kt_a, "add_absmax_kernel",
+                 "pass 1, 16 launches per forward: z = x + y with max|z| (and the ReLU's output) folded in; 12 B/element, 16 with "
+                 "the ReLU copy"),
+                ("roofline_bias_add_hist", kt_bh, "bias_add_hist_kernel",
+                 "pass 2, the re-computed prefix of the network: y += bias[c] with the 2048-bin histogram of y (and the ReLU's "
+                 "output) folded in; same algorithmic bytes as the pass-1 form"),
+                ("roofline_add_hist", kt_ah, "add_hist_kernel", "pass 2: z = x + y with the histogram of z folded in")):
+            sm = kt.summary()
+            if sm:
+                result[key] = hbm_roofline(kernel, sm, {"note": note, "aggregate_gbs": round(sm["gbs"], 1)})
     except Exception as e:
         result["roofline_bias_add_absmax"] = {"error": repr(e)}
 

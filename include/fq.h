@@ -176,6 +176,15 @@ int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C, int HW, fl
  * x or y); max_inout: one fp32 (>= 0) in device memory. */
 int fq_add_absmax_f32(const float* x, const float* y, float* z, size_t n, float* max_inout, float* relu_out, fq_stream_t stream);
 
+/* The same two producers in calibration pass 2 (distribution_collector.py:127-135 taken on the way out): identical
+ * outputs (y += bias[c] in place / z = x + y, relu_out as above), and every output value is counted into the 2048-bin
+ * histogram row `hist_row` (int64[2048], accumulated into) with the bin width `*interval` (one fp32 in device memory) --
+ * exactly what fq_hist2048_seg would add for this tensor, without reading it a second time. */
+int fq_bias_add_hist_f32(float* y, const float* bias, int N, int C, int HW, const float* interval, int64_t* hist_row,
+                         float* relu_out, fq_stream_t stream);
+int fq_add_hist_f32(const float* x, const float* y, float* z, size_t n, const float* interval, int64_t* hist_row,
+                    float* relu_out, fq_stream_t stream);
+
 /* Quantity.forward (new_quantity_op.py:52-58) fused with the layout change the MFMA kernel wants:
  *   y[n][hw][c] = (int8) clamp(rint(x[n][c][hw] * 2^ib), -128, 127),  c in [C, Cpad) = 0
  * x: fp32 [N][C][HW] (NCHW), y: int8 [N][HW][Cpad] (NHWC), Cpad >= C, Cpad % 4 == 0 (use a multiple

@@ -18,6 +18,7 @@
 #include <type_traits>
 
 #include "fq_common.h"
+#include "fq_hist_bin.h"
 
 namespace fq {
 
@@ -147,25 +148,6 @@ __global__ __launch_bounds__(kBlock) void absmax_seg_kernel(const SegTable tab, 
 // ---------------------------------------------------------------------------------------------
 // 2048-bin histogram of |x|, x != 0  (distribution_collector.py:127-135)
 // ---------------------------------------------------------------------------------------------
-// Bin of one element.  kFast = false: the IEEE divide sequence.  kFast = true: the 3-instruction
-// quotient  q0 = a*y, r = fma(-q0, iv, a), q = fma(r, y, q0)  with y = RN(1/iv); it equals the
-// correctly rounded a/iv for every fp32 significand pair (checked exhaustively on the GPU,
-// scripts/verify_fastdiv.hip, result under profiles/), and overflow / inf / nan fall through to the
-// same "last bin" as the IEEE path because  q < 2048  is false for inf and nan.
-template <bool kFast>
-__device__ __forceinline__ int bin_of(float v, float iv, float y) {
-    const float a = fabsf(v);
-    float q;
-    if (kFast) {
-        const float q0 = a * y;
-        const float r = __builtin_fmaf(-q0, iv, a);
-        q = __builtin_fmaf(r, y, q0);
-    } else {
-        q = a / iv;                                   // v_div_scale / v_rcp / fma x4 / v_div_fmas / v_div_fixup
-    }
-    return (q < 2048.0f) ? (int)q : (FQ_BINS - 1);   // >= 2048, inf, nan -> last bin
-}
-
 template <bool kFast>
 __device__ __forceinline__ void hist_piece(const float* p, uint64_t n, uint32_t c0, uint32_t c1, float iv, unsigned int* s_bins) {
     const float y = 1.0f / iv;                        // IEEE, once per lane
@@ -374,7 +356,7 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTab
     // big planes: s_bins[0 .. 2047] 32-bit bins of one row (+ 64 parking slots)
     // small planes: row r's bin b is the 16-bit half (b & 1) of dword r * 1024 + (b >> 1); parking dwords behind
     __shared__ unsigned int s_bins[kChanBlock * (FQ_BINS / 2) + kWave];
-    __shared__ float s_iv[kChanBlock], s_y[kChanBlock];
+    __shared__ float2 s_ivy[kChanBlock];
     __shared__ int s_fast;
     const ChanView cv = chan_of(tab);
     const int nwords = cv.cb == 1 ? FQ_BINS : kChanBlock * (FQ_BINS / 2);
@@ -383,8 +365,7 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTab
     __syncthreads();
     if (threadIdx.x < cv.cb) {
         const float iv = interval[cv.row + threadIdx.x];
-        s_iv[threadIdx.x] = iv;
-        s_y[threadIdx.x] = 1.0f / iv;                         // IEEE
+        s_ivy[threadIdx.x] = make_float2(iv, 1.0f / iv);      // IEEE
         const unsigned int ivb = __float_as_uint(iv);
         if (!(ivb >= 0x21800000u && ivb <= 0x5d800000u)) s_fast = 0;     // see hist2048_seg_kernel; any row outside: IEEE divide
     }
@@ -393,7 +374,7 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTab
     unsigned int* park = s_bins + nwords + (threadIdx.x & (kWave - 1));
     unsigned long long* __restrict__ dst = hist + (size_t)cv.row * FQ_BINS;
     if (cv.cb == 1) {
-        const float iv = s_iv[0], y = s_y[0];
+        const float iv = s_ivy[0].x, y = s_ivy[0].y;
         if (fast) for_each_in_block<kHistBlock, true>(cv, [&](float v, uint32_t) {
             atomicAdd((v != 0.0f) ? (s_bins + bin_of<true>(v, iv, y)) : park, 1u); });
         else for_each_in_block<kHistBlock, true>(cv, [&](float v, uint32_t) {
@@ -406,7 +387,8 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTab
         return;
     }
     auto add = [&](float v, uint32_t ch, auto fast_tag) {
-        const int b = bin_of<decltype(fast_tag)::value>(v, s_iv[ch], s_y[ch]);
+        const float2 p = s_ivy[ch];                                        // one ds_read_b64: (interval, 1 / interval)
+        const int b = bin_of<decltype(fast_tag)::value>(v, p.x, p.y);
         unsigned int* slot = (v != 0.0f) ? (s_bins + ch * (FQ_BINS / 2) + (b >> 1)) : park;
         atomicAdd(slot, (v != 0.0f && (b & 1)) ? 0x10000u : 1u);          // ds_add_u32 on a 16-bit half
     };
@@ -442,12 +424,16 @@ static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launc
             const fq_chan_seg& s = segs[i++];
             if (s.N == 0) continue;
             const bool aligned = (reinterpret_cast<uintptr_t>(s.ptr) & 15u) == 0;
-            const bool big = (uint64_t)s.HW >= kBigPlane;
+            // one channel per workgroup wherever its planes can be read with 16-byte loads and are at least one
+            // wave-load long (measured per shape, batch 128: 28x28 planes 2.8 -> one-channel form; 7x7 planes, 196 bytes
+            // and never 16-byte aligned, stay with the 8-channel blocks), and for every plane of 1024 elements or more
+            const bool planes_vec = aligned && (s.HW & 3) == 0 && (((uint64_t)s.C * (uint64_t)s.HW) & 3u) == 0;
+            const bool big = (uint64_t)s.HW >= kBigPlane || (planes_vec && s.HW >= 64);
             uint32_t cb, nb, vec;
             if (big) {
                 // one channel per workgroup; planes of more than 256 K elements are still one image per workgroup
                 cb = 1;
-                vec = aligned && (s.HW & 3) == 0 && (((uint64_t)s.C * (uint64_t)s.HW) & 3u) == 0;
+                vec = planes_vec;
                 nb = (uint32_t)(kChanElemsPerWg / (uint64_t)s.HW);
                 if (nb < 1) nb = 1;
                 // the magic division by the run length needs n * d < 2^32; a single image per workgroup needs none

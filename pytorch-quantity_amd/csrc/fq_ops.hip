@@ -8,7 +8,10 @@
 //   torch.round                -> round half to even (v_rndne_f32 / rintf)
 //   torch.clamp                -> NaN-propagating clamp
 //   RightShift                 -> trunc(v + (v > 0 ? 0.5 : -0.5)) through int32, saturating cast
+#include <cstdlib>
+
 #include "fq_common.h"
+#include "fq_hist_bin.h"
 
 namespace fq {
 
@@ -273,6 +276,106 @@ __global__ __launch_bounds__(kOpsBlock) void add_absmax_kernel(const f4v* __rest
     }
 }
 
+// ---- the same two producers in calibration pass 2: the 2048-bin histogram taken on the way out ---------------------
+// Pass 2 re-runs (part of) the forward and histograms its outputs with the final bin widths.  A tensor that was just
+// written is the worst input for the streaming histogram kernel (it shares HBM with the write-back of the very lines it
+// reads: 6.6 -> 5.5 TB/s), and it costs a second 4 B/element read.  These variants bin every
+// output value while it is in registers (same arithmetic: fq_hist_bin.h), in an LDS histogram per workgroup flushed
+// with 64-bit atomics at the end; few, long-lived workgroups (2 per CU) keep the flush traffic at 2048 bins x 512.
+__device__ __forceinline__ void hist_flush(unsigned int* s_bins, unsigned long long* __restrict__ dst) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < FQ_BINS; b += kOpsBlock) {
+        const unsigned int c = s_bins[b];
+        if (c) atomicAdd(dst + b, (unsigned long long)c);
+    }
+}
+
+template <bool kVec, bool kFast>
+__device__ __forceinline__ void bias_add_hist_body(float* __restrict__ y, const float* __restrict__ bias, unsigned n_items,
+                                                   unsigned inner, unsigned C, float iv, unsigned int* s_bins,
+                                                   float* __restrict__ relu_out) {
+    const float yr = 1.0f / iv;
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    auto count = [&](float v) { atomicAdd((v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, yr)) : park, 1u); };
+    const unsigned stride = gridDim.x * kOpsBlock;
+    for (unsigned i = blockIdx.x * kOpsBlock + threadIdx.x; i < n_items; i += stride) {
+        const float b = bias[(i / inner) % C];
+        if (kVec) {
+            f4v v = reinterpret_cast<f4v*>(y)[i];
+            v.x += b; v.y += b; v.z += b; v.w += b;
+            reinterpret_cast<f4v*>(y)[i] = v;
+            if (relu_out) {
+                f4v r;
+                r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
+                reinterpret_cast<f4v*>(relu_out)[i] = r;
+            }
+            count(v.x); count(v.y); count(v.z); count(v.w);
+        } else {
+            const float v = y[i] + b;
+            y[i] = v;
+            if (relu_out) relu_out[i] = relu_like_torch(v);
+            count(v);
+        }
+    }
+}
+
+template <bool kVec>
+__global__ __launch_bounds__(kOpsBlock) void bias_add_hist_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                                  unsigned n_items, unsigned inner, unsigned C,
+                                                                  const float* __restrict__ interval,
+                                                                  unsigned long long* __restrict__ hist_row,
+                                                                  float* __restrict__ relu_out, const int allow_fast) {
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kOpsBlock) s_bins[b] = 0u;
+    __syncthreads();
+    const float iv = *interval;
+    if (allow_fast && fast_quotient_ok(iv)) bias_add_hist_body<kVec, true>(y, bias, n_items, inner, C, iv, s_bins, relu_out);
+    else bias_add_hist_body<kVec, false>(y, bias, n_items, inner, C, iv, s_bins, relu_out);
+    hist_flush(s_bins, hist_row);
+}
+
+template <bool kFast>
+__device__ __forceinline__ void add_hist_body(const f4v* __restrict__ x, const f4v* __restrict__ y, f4v* __restrict__ z,
+                                              size_t nvec, const float* __restrict__ xs, const float* __restrict__ ys,
+                                              float* __restrict__ zs, unsigned tail, float iv, unsigned int* s_bins,
+                                              float* __restrict__ relu_out) {
+    const float yr = 1.0f / iv;
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    auto count = [&](float v) { atomicAdd((v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, yr)) : park, 1u); };
+    const size_t stride = (size_t)gridDim.x * kOpsBlock;
+    for (size_t i = (size_t)blockIdx.x * kOpsBlock + threadIdx.x; i < nvec; i += stride) {
+        const f4v v = x[i] + y[i];
+        z[i] = v;
+        if (relu_out) {
+            f4v r;
+            r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
+            reinterpret_cast<f4v*>(relu_out)[i] = r;
+        }
+        count(v.x); count(v.y); count(v.z); count(v.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < tail) {          // the last n % 4 elements
+        const float v = xs[threadIdx.x] + ys[threadIdx.x];
+        zs[threadIdx.x] = v;
+        if (relu_out) relu_out[(nvec << 2) + threadIdx.x] = relu_like_torch(v);
+        count(v);
+    }
+}
+
+__global__ __launch_bounds__(kOpsBlock) void add_hist_kernel(const f4v* __restrict__ x, const f4v* __restrict__ y,
+                                                             f4v* __restrict__ z, size_t nvec, const float* __restrict__ xs,
+                                                             const float* __restrict__ ys, float* __restrict__ zs, unsigned tail,
+                                                             const float* __restrict__ interval,
+                                                             unsigned long long* __restrict__ hist_row,
+                                                             float* __restrict__ relu_out, const int allow_fast) {
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kOpsBlock) s_bins[b] = 0u;
+    __syncthreads();
+    const float iv = *interval;
+    if (allow_fast && fast_quotient_ok(iv)) add_hist_body<true>(x, y, z, nvec, xs, ys, zs, tail, iv, s_bins, relu_out);
+    else add_hist_body<false>(x, y, z, nvec, xs, ys, zs, tail, iv, s_bins, relu_out);
+    hist_flush(s_bins, hist_row);
+}
+
 // ---- weight quantiser ---------------------------------------------------------------------------
 __global__ __launch_bounds__(kOpsBlock) void quantize_param_i32_kernel(const float* __restrict__ w, int32_t* __restrict__ q,
                                                                        size_t n, float scale) {
@@ -406,6 +509,51 @@ extern "C" int fq_add_absmax_f32(const float* x, const float* y, float* z, size_
     hipLaunchKernelGGL(add_absmax_kernel, dim3(grid_for(nvec ? nvec : 1, 8)), dim3(kOpsBlock), 0, as_stream(stream),
                        reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
                        x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, reinterpret_cast<unsigned int*>(max_inout), relu_out);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+static int ops_hist_fast_quotient() {          // FQ_HIST_IEEE_DIV=1 forces the IEEE divide sequence (as in fq_calib.hip)
+    static const int v = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
+    return v;
+}
+
+extern "C" int fq_bias_add_hist_f32(float* y, const float* bias, int N, int C, int HW, const float* interval,
+                                    int64_t* hist_row, float* relu_out, fq_stream_t stream) {
+    using namespace fq;
+    if (N < 0 || C <= 0 || HW <= 0) return FQ_ERR_INVALID_ARG;
+    const size_t n = (size_t)N * C * HW;
+    if (n == 0) return FQ_OK;
+    if (!y || !bias || !interval || !hist_row) return FQ_ERR_INVALID_ARG;
+    if (n >= 0xffffffffULL) return FQ_ERR_UNSUPPORTED;               // 32-bit element index inside the kernel
+    hipStream_t st = as_stream(stream);
+    unsigned long long* h = reinterpret_cast<unsigned long long*>(hist_row);
+    if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(relu_out)) & 15u) == 0) {
+        const unsigned nvec = (unsigned)(n >> 2);
+        hipLaunchKernelGGL(bias_add_hist_kernel<true>, dim3(grid_for(nvec, 2)), dim3(kOpsBlock), 0, st, y, bias, nvec,
+                           (unsigned)(HW >> 2), (unsigned)C, interval, h, relu_out, ops_hist_fast_quotient());
+    } else {
+        hipLaunchKernelGGL(bias_add_hist_kernel<false>, dim3(grid_for(n, 2)), dim3(kOpsBlock), 0, st, y, bias, (unsigned)n,
+                           (unsigned)HW, (unsigned)C, interval, h, relu_out, ops_hist_fast_quotient());
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_add_hist_f32(const float* x, const float* y, float* z, size_t n, const float* interval, int64_t* hist_row,
+                               float* relu_out, fq_stream_t stream) {
+    using namespace fq;
+    if (n == 0) return FQ_OK;
+    if (!x || !y || !z || !interval || !hist_row) return FQ_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(z) |
+         reinterpret_cast<uintptr_t>(relu_out)) & 15u)
+        return FQ_ERR_INVALID_ARG;
+    const size_t nvec = n >> 2;
+    const unsigned tail = (unsigned)(n & 3u);
+    hipLaunchKernelGGL(add_hist_kernel, dim3(grid_for(nvec ? nvec : 1, 2)), dim3(kOpsBlock), 0, as_stream(stream),
+                       reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
+                       x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, interval,
+                       reinterpret_cast<unsigned long long*>(hist_row), relu_out, ops_hist_fast_quotient());
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }

@@ -92,6 +92,10 @@ def lib():
     L.fq_bias_add_absmax_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp]
     L.fq_add_absmax_f32.restype = ci
     L.fq_add_absmax_f32.argtypes = [vp, vp, vp, sz, vp, vp, vp]
+    L.fq_bias_add_hist_f32.restype = ci
+    L.fq_bias_add_hist_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp]
+    L.fq_add_hist_f32.restype = ci
+    L.fq_add_hist_f32.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
     L.fq_conv2d_i8_stem.restype = ci
     L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
@@ -283,6 +287,42 @@ def add_absmax(x, y, max_dev, row, out=None, relu_out=None):
     assert z.shape == x.shape and z.is_contiguous() and z.dtype == torch.float32 and z.is_cuda
     _check(lib().fq_add_absmax_f32(x.data_ptr(), y.data_ptr(), z.data_ptr(), x.numel(), max_dev.data_ptr() + 4 * int(row),
                                    _relu_ptr(relu_out, x), _stream(x)), "fq_add_absmax_f32")
+    return z
+
+
+def _hist_row_ptrs(interval_dev, hist_dev, row):
+    _need_cuda(interval_dev, torch.float32, "interval")
+    _need_cuda(hist_dev, torch.int64, "hist")
+    assert interval_dev.is_contiguous() and hist_dev.is_contiguous() and hist_dev.dim() == 2 and hist_dev.shape[1] == BINS
+    assert 0 <= row < hist_dev.shape[0] and interval_dev.numel() == hist_dev.shape[0]
+    return interval_dev.data_ptr() + 4 * int(row), hist_dev.data_ptr() + 8 * BINS * int(row)
+
+
+def bias_add_hist(y, bias, interval_dev, hist_dev, row, relu_out=None):
+    """fq_bias_add_hist_f32: y[n][c][...] += bias[c] in place and every output value counted into hist_dev[row] with the
+    bin width interval_dev[row]; relu_out (optional, same shape): also receives max(y, 0)."""
+    _need_cuda(y, torch.float32, "fq_bias_add_hist_f32")
+    _need_cuda(bias, torch.float32, "fq_bias_add_hist_f32")
+    assert y.is_contiguous() and y.dim() >= 2 and bias.is_contiguous() and bias.numel() == y.shape[1]
+    ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
+    N, C = int(y.shape[0]), int(y.shape[1])
+    hw = y.numel() // max(N * C, 1)
+    _check(lib().fq_bias_add_hist_f32(y.data_ptr(), bias.data_ptr(), N, C, hw, ivp, hp, _relu_ptr(relu_out, y), _stream(y)),
+           "fq_bias_add_hist_f32")
+    return y
+
+
+def add_hist(x, y, interval_dev, hist_dev, row, out=None, relu_out=None):
+    """fq_add_hist_f32: returns x + y (in `out` if given) with every sum counted into hist_dev[row]; relu_out (optional):
+    also receives max(x + y, 0)."""
+    _need_cuda(x, torch.float32, "fq_add_hist_f32")
+    _need_cuda(y, torch.float32, "fq_add_hist_f32")
+    assert x.shape == y.shape and x.is_contiguous() and y.is_contiguous()
+    ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
+    z = torch.empty_like(x) if out is None else out
+    assert z.shape == x.shape and z.is_contiguous() and z.dtype == torch.float32 and z.is_cuda
+    _check(lib().fq_add_hist_f32(x.data_ptr(), y.data_ptr(), z.data_ptr(), x.numel(), ivp, hp, _relu_ptr(relu_out, x),
+                                 _stream(x)), "fq_add_hist_f32")
     return z
 
 

@@ -134,6 +134,19 @@ class DistributionCollector(StatCollectives):
         """fq_bias_add_absmax_f32 wrote a maximum straight into max_device."""
         self._max_vals_refreshed_flag = True
 
+    def prepare_distributions(self):
+        """Upload the current bin widths (distribution_intervals, as edited by the caller) so that producer kernels can
+        histogram their own output (fq_bias_add_hist_f32 / fq_add_hist_f32) straight into hist_device."""
+        if not hasattr(self, "_distribution_intervals"):
+            self.distribution_intervals
+        self._sync_intervals()
+        self._added_to_distributions_flag = True
+
+    @property
+    def interval_device(self):
+        """fp32[T] bin widths on the device (valid after prepare_distributions() / add_to_distributions())."""
+        return self._interval_dev
+
     def _rows_of(self, tensors):
         """Rows of the tensors present in `tensors` (the reference passes all of them; the calibration loop also feeds
         them in groups, from inside the forward hooks, while they are still in the Infinity Cache)."""

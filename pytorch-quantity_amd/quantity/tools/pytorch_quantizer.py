@@ -143,6 +143,11 @@ class Quantity(object):
     # ... and when an out-of-place nn.ReLU consumes that output directly, the same kernel writes the ReLU's result too
     # (one more 4-byte write instead of the ReLU's own 8-byte pass); the patched ReLU.forward hands it out.
     fuse_relu = True
+    # Pass 2: the same producers histogram their own output (fq_bias_add_hist_f32 / fq_add_hist_f32) for every tensor the
+    # second forward re-computes, instead of handing it to the streaming histogram kernel right after writing it (which
+    # costs a second 4 B/element read and runs that kernel against the write-back of its own input).
+    # Only modules whose decomposition was verified in pass 1 take part.
+    fuse_hist = True
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -375,6 +380,8 @@ class Quantity(object):
                 if (ctl["fuse_collector"] is None or ctl["fuse_off"] or not torch.is_tensor(x) or not x.is_cuda
                         or x.dtype != torch.float32 or m.weight.dtype != torch.float32 or torch.is_grad_enabled()):
                     return torch.nn.Conv2d.forward(m, x)
+                if ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"]:
+                    return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
                 if m not in ctl["fuse_warm"] and not m.__dict__.get(_FUSION_VERIFIED):
                     ctl["fuse_warm"].add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
                     return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
@@ -392,7 +399,8 @@ class Quantity(object):
                 def forward(x, y, m=m):
                     if (ctl["fuse_collector"] is None or ctl["fuse_off"] or torch.is_grad_enabled() or not torch.is_tensor(x)
                             or not torch.is_tensor(y) or not x.is_cuda or x.dtype != torch.float32 or y.dtype != torch.float32
-                            or x.shape != y.shape or not x.is_contiguous() or not y.is_contiguous() or y.device != x.device):
+                            or x.shape != y.shape or not x.is_contiguous() or not y.is_contiguous() or y.device != x.device
+                            or (ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"])):
                         return Eltwise.forward(m, x, y)
                     ctl["fuse_bias"] = (m, (x, y))          # the hook of this very call computes the sum (+ its abs-max)
                     return torch.empty_like(x)
@@ -445,6 +453,11 @@ class Quantity(object):
                 torch.add(a, b, out=output)
                 return False
             row = coll.row_of(key)
+            if ctl["fuse_stat"] == "hist":                  # pass 2 (verified in pass 1): the sum, histogrammed on the way out
+                self._run_with_relu(m, output, lambda r: _native.add_hist(a, b, coll.interval_device, coll.hist_device, row,
+                                                                          out=output, relu_out=r))
+                ctl["hist_fused"] += 1
+                return True
             if not m.__dict__.get(_FUSION_VERIFIED):        # first use: the kernel against torch.add, once per process
                 scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
                 z = _native.add_absmax(a, b, scratch, 0)
@@ -462,6 +475,11 @@ class Quantity(object):
             output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))     # what torch does
             return False
         row = coll.row_of(key)
+        if ctl["fuse_stat"] == "hist":                      # pass 2 (verified in pass 1)
+            self._run_with_relu(m, output, lambda r: _native.bias_add_hist(output, m.bias, coll.interval_device,
+                                                                           coll.hist_device, row, relu_out=r))
+            ctl["hist_fused"] += 1
+            return True
         if m in ctl["fuse_verified"] or m.__dict__.get(_FUSION_VERIFIED):
             ctl["fuse_verified"].add(m)
             self._run_with_relu(m, output, lambda r: _native.bias_add_absmax(output, m.bias, coll.max_device, row, relu_out=r))
@@ -699,8 +717,7 @@ class Quantity(object):
                 kept = {n: t for n, t in named_feats.items() if n in plan["keep"]}
                 cached[i] = kept
                 used += sum(t.numel() * t.element_size() for t in kept.values())
-        ctl["fuse_collector"] = None              # pass 2 and later forwards: torch's own forwards (running the fused kernels
-        #                                           for their bias + ReLU part alone was measured: pass 2 0.203 -> 0.208 s)
+        ctl["fuse_collector"] = None
         self._join_stat_stream()
         if _dist_on():                      # also at world size 1: same code path, trivial cost
             collector.all_reduce_max()
@@ -721,6 +738,10 @@ class Quantity(object):
 
         # pass 2: histograms with the final intervals
         print("Collect histograms of activations:")
+        if (eager_ok and self.fuse_bias_absmax and self.fuse_hist and not ctl["fuse_off"] and ctl["fuse_verified"]
+                and inplace is False and hasattr(collector, "prepare_distributions")):
+            collector.prepare_distributions()
+            ctl["fuse_collector"], ctl["fuse_stat"] = collector, "hist"
         if plan is not None and plan["kind"] == "B":
             ctl["stop_after"] = plan["stop_after"] if plan["stop_after"] else None
             try:
@@ -743,6 +764,7 @@ class Quantity(object):
                 self._forward_with_stats(item, collector.add_to_distributions, named_feats)
         self._join_stat_stream()
         del cached
+        ctl["fuse_collector"], ctl["fuse_stat"] = None, "max"
         if _dist_on():
             collector.all_reduce_hist()
         if self.profile_phases:
@@ -791,6 +813,7 @@ class Quantity(object):
                         "fused_bias_absmax_convs": 0 if ctl["fuse_off"] else sum(1 for m in ctl["fuse_verified"] if isinstance(m, torch.nn.Conv2d)),
                         "fused_relus": len(ctl["fused_relus"]),
                         "fused_add_absmax_eltwise": 0 if ctl["fuse_off"] else sum(1 for m in ctl["fuse_verified"] if not isinstance(m, torch.nn.Conv2d)),
+                        "fused_hist_launches": ctl["hist_fused"],
                         "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}
@@ -876,7 +899,8 @@ class Quantity(object):
         total = int(self.layers_num)
         ctl = self._hook_ctl = {"stop_after": None, "events": None, "eager": None, "fuse_bias": None, "fuse_collector": None,
                                 "fuse_off": False, "fuse_verified": set(), "fuse_warm": set(),
-                                "relu_after": {}, "relu_ready": None, "last_out": None, "fused_relus": set()}
+                                "relu_after": {}, "relu_ready": None, "last_out": None, "fused_relus": set(),
+                                "fuse_stat": "max", "hist_fused": 0}
 
         def on_forward(module, inputs, output):
             eager = ctl["eager"]

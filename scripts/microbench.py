@@ -124,6 +124,28 @@ def bench_channel_kernels(batch=128):
     print("hist2048_chan: med %.3f ms  (%.0f GB/s, best %.0f)" % (ms, elems * 4 / ms / 1e6, elems * 4 / best / 1e6))
 
 
+def bench_channel_shapes(batch=128):
+    """The per-channel kernels one shape class at a time (enough copies of the tensor for >= 1 GB per launch)."""
+    for c, h in [(3, 224), (64, 112), (64, 56), (256, 56), (128, 56), (128, 28), (512, 28), (256, 28), (256, 14), (1024, 14),
+                 (512, 14), (512, 7), (2048, 7)]:
+        per = batch * c * h * h * 4
+        copies = max(1, min(16, (1 << 30) // per))
+        ts = [torch.randn(batch, c, h, h, device="cuda") for _ in range(copies)]
+        row0 = [i * c for i in range(copies)]
+        rows = copies * c
+        mx = torch.zeros(rows, device="cuda")
+        ms_a, _ = timeit(lambda: nat.absmax_chan(ts, row0, mx), iters=8)
+        iv = (mx / 2048 + 1e-12).float()
+        hist = torch.zeros(rows, 2048, dtype=torch.int64, device="cuda")
+        ms_h, _ = timeit(lambda: nat.hist2048_chan(ts, row0, iv, hist), iters=8)
+        flat = [t.view(-1) for t in ts]
+        mx1 = torch.zeros(copies, device="cuda")
+        ms_s, _ = timeit(lambda: nat.hist2048_seg(flat, list(range(copies)), (mx1 + 1).float(), hist[:copies]), iters=8)
+        gb = per * copies / 1e6
+        print("C=%4d HW=%5d x%2d (%.2f GB): absmax_chan %.0f GB/s  hist2048_chan %.0f GB/s  [per-tensor hist %.0f GB/s]" %
+              (c, h * h, copies, gb / 1e3, gb / ms_a, gb / ms_h, gb / ms_s))
+
+
 def bench_rotating(batch, sets):
     """The same segment list in `sets` different places of HBM, visited in turn: every launch reads addresses
     it has not touched for sets-1 launches (cold TLB / page-table walks), as in a real calibration pass."""
@@ -278,6 +300,8 @@ if __name__ == "__main__":
         bench_rotating(int(sys.argv[1]), int(sys.argv[sys.argv.index("--rotate") + 1]))
     elif "--single" in sys.argv:
         bench_single_segment()
+    elif "--chan-shapes" in sys.argv:
+        bench_channel_shapes()
     elif "--chan" in sys.argv:
         bench_channel_kernels()
     else:

@@ -185,6 +185,41 @@ def seed_model(model, base_seed=0, gamma_scale=1.0):
     return model
 
 
+def fold_bn_with_scales(model, scales):
+    """merge_bn (reference quantity/common/quantity/utils.py:7-65) with the per-channel factor
+    gamma / sqrt(running_var + 1e-5) TAKEN FROM A FIXTURE instead of recomputed.  torch.sqrt on CPU tensors goes through
+    MKL's vector math library, whose last bit differs between Intel and AMD hosts (measured: build container vs GPU box,
+    scripts/_dbg notes in DESIGN.md), so a model folded on the GPU box is not bit-identical to the one the reference
+    folded in the build container -- and a one-ulp difference in a weight can flip its 8-bit rounding.  Given the same
+    factors, the remaining operations (one multiply per weight, multiply-add per bias) are single IEEE operations and
+    identical everywhere; they are done in NumPy here.  `scales`: {BatchNorm module name: float32[C]}.
+    Returns the model with every BatchNorm2d replaced by the drop-in's Identity (as merge_bn does)."""
+    import torch
+    import torch.nn as nn
+    from common.quantity import Identity
+    pending, folded = None, []
+    for name, layer in list(model.named_modules()):
+        kind = type(layer).__name__
+        if kind == "Conv2d":
+            pending = layer
+        elif kind == "BatchNorm2d":
+            conv, pending = pending, None
+            sc = np.asarray(scales[name], dtype=np.float32)
+            w = conv.weight.data.numpy()
+            b = conv.bias.data.numpy() if conv.bias is not None else np.zeros(conv.out_channels, dtype=np.float32)
+            mean, beta = layer.running_mean.numpy(), layer.bias.data.numpy()
+            conv.weight = nn.Parameter(torch.from_numpy(sc.reshape(-1, 1, 1, 1) * w))
+            conv.bias = nn.Parameter(torch.from_numpy(sc * (b - mean) + beta))
+            folded.append(name)
+    for name in folded:
+        parent = model
+        parts = name.split(".")
+        for part in parts[:-1]:
+            parent = getattr(parent, part)
+        parent.add_module(parts[-1], Identity())
+    return model
+
+
 def calib_batches(n_batches, shape, seed=1234):
     """List of (images, labels) pairs as a DataLoader would yield them (PRE_PROCESS.IMG = 1)."""
     import torch

@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Capture, by running the imported reference in the build container,
 
-    python tests/golden/make_golden_r50.py [r50] [h6] [time18]
+    python tests/golden/make_golden_r50.py [r50] [scales] [h6] [time18]
 
   r50     G4-R50 (tests/golden/g4_r50_recon.npz + g4_r50_tables.json): the reference's own calibration, weight
           quantisation, ReconModel and ReconTest (quantity/tools/reconstruction.py:175-324,
           quantity/common/quantity/new_quantity_op.py:124-133,280-292) on the build's fabu ResNet-50 @224^2 --
           BASELINE configs 2/3 at their own model size: tables as text, logits for a fixed 2x3x224x224 input,
           a sub-sample + sha256 of the first layer's output, max |accumulator| over all integer layers.
+  scales  g4_r50_bn_scales.npz: the BatchNorm fold factors of that model as the reference's merge_bn computes them in the
+          build container (torch.sqrt on CPU is machine dependent in the last bit; see cases.fold_bn_with_scales).
   h6      G10 (g10_dilation.npz): Quantity.dilation_to_zero_padding (quantity/tools/pytorch_quantizer.py:679-693)
           on seeded kernels.
   time18  wall time of the reference's Python path on BASELINE config 1 (ResNet-18, 256 synthetic 3x32x32 images:
@@ -134,6 +136,39 @@ def capture_r50(cq, tl):
                                                                      out["feat_table"].split("\n")[:3]))
 
 
+def capture_scales(cq, tl):
+    """g4_r50_bn_scales.npz: the BatchNorm fold factors gamma / sqrt(running_var + 1e-5) of the seeded ResNet-50 exactly
+    as the reference's merge_bn evaluates them HERE (utils.py:37: torch ops on CPU tensors -- torch.sqrt goes through MKL
+    and is machine dependent in the last bit).  Checked on the spot: folding with these factors (cases.fold_bn_with_scales)
+    reproduces the reference's merged parameters bit for bit."""
+    import torch
+    sys.path.append(OURS)
+    from model.resnet.ResNet_fabu import ResNet50
+    ref_merged = cq.merge_bn(cases.seed_model(ResNet50(), gamma_scale=GAMMA).eval(), "cpu").state_dict()
+    model = cases.seed_model(ResNet50(), gamma_scale=GAMMA).eval()
+    scales = {}
+    for name, layer in model.named_modules():
+        if type(layer).__name__ == "BatchNorm2d":
+            scales[name] = (layer.weight.data / torch.sqrt(layer.running_var + 1e-5)).numpy().copy()
+    # fold with the drop-in's Identity class is not importable here (the reference's `common` is loaded): inline check
+    sd = model.state_dict()
+    pending = None
+    for name, layer in model.named_modules():
+        kind = type(layer).__name__
+        if kind == "Conv2d":
+            pending = name
+        elif kind == "BatchNorm2d":
+            sc = scales[name]
+            w = sd[pending + ".weight"].numpy()
+            got_w = sc.reshape(-1, 1, 1, 1) * w
+            got_b = sc * (np.zeros_like(sc) - sd[name + ".running_mean"].numpy()) + sd[name + ".bias"].numpy()
+            assert np.array_equal(got_w, ref_merged[pending + ".weight"].numpy()), pending
+            assert np.array_equal(got_b, ref_merged[pending + ".bias"].numpy()), pending
+    np.savez_compressed(os.path.join(HERE, "g4_r50_bn_scales.npz"), **scales)
+    print("BN fold factors written:", len(scales), "layers,", sum(v.size for v in scales.values()), "channels; "
+          "numpy fold == reference merge_bn bit for bit")
+
+
 def capture_h6(cq, tl):
     rng = np.random.default_rng(606)
     arrays = {}
@@ -176,6 +211,8 @@ def main():
     cq, tl = _refenv.import_reference()
     if "h6" in which:
         capture_h6(cq, tl)
+    if "scales" in which:
+        capture_scales(cq, tl)
     if "time18" in which:
         time_r18(cq, tl)
     if "r50" in which:

@@ -342,6 +342,67 @@ def test_add_absmax_kernel_equals_torch():
         assert torch.equal(z, ref) and torch.equal(r, torch.relu(ref))
 
 
+def test_bias_add_hist_and_add_hist_kernels_equal_torch_plus_the_oracle_histogram(oracle):
+    """Pass 2's producers (fq_bias_add_hist_f32 / fq_add_hist_f32): the outputs are torch's, and the histogram row gains
+    exactly what the oracle counts for the finished tensor -- accumulated, other rows untouched; bin edges, zeros and
+    values beyond the range included; a denormal interval takes the IEEE divide."""
+    from common.quantity import _native
+    g = torch.Generator(device="cpu").manual_seed(21)
+    for shape, scale in [((3, 5, 7, 7), 1.0), ((2, 64, 56, 56), 3.0), ((4, 16, 8, 8), 0.01), ((1, 3, 5), 1.0), ((2, 7, 1, 1), 1.0),
+                         ((5, 6, 9, 10), 1e-30)]:
+        y = (torch.randn(shape, generator=g) * scale).cuda()
+        y.view(-1)[::7] = 0.0
+        b = (torch.randn(shape[1], generator=g) * scale).cuda()
+        b[0] = 0.0                                                                    # channel 0 keeps its exact zeros
+        want = y + b.view(1, -1, *([1] * (y.dim() - 2)))
+        m = float(want.abs().max()) * 0.9                                            # some values beyond the last bin
+        iv = torch.tensor([1.0, float(oracle.interval(np.float32(m))), 2.0], device="cuda")
+        hist = torch.zeros(3, 2048, dtype=torch.int64, device="cuda")
+        hist[1, 5] = 7
+        r = torch.empty_like(y)
+        _native.bias_add_hist(y, b, iv, hist, 1, relu_out=r)
+        assert torch.equal(y, want) and torch.equal(r, torch.relu(want))
+        ref = oracle.hist2048(want.cpu().numpy().ravel(), np.float32(iv[1].item()))
+        ref[5] += 7
+        hh = hist.cpu().numpy()
+        np.testing.assert_array_equal(hh[1], ref)
+        assert not hh[0].any() and not hh[2].any()
+    for n in (1, 3, 4, 5, 1023, 4096, 100003):
+        x, y = torch.randn(n, generator=g).cuda(), torch.randn(n, generator=g).cuda()
+        x[::5] = 0.0
+        y[::5] = 0.0
+        want = x + y
+        iv = torch.tensor([float(oracle.interval(np.float32(want.abs().max().item())))], device="cuda")
+        hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+        r = torch.empty_like(x)
+        z = _native.add_hist(x, y, iv, hist, 0, relu_out=r)
+        z2 = _native.add_hist(x, y, iv, hist, 0)                                     # accumulates
+        assert torch.equal(z, want) and torch.equal(z2, want) and torch.equal(r, torch.relu(want))
+        np.testing.assert_array_equal(hist.cpu().numpy()[0], 2 * oracle.hist2048(want.cpu().numpy(), np.float32(iv[0].item())))
+
+
+def test_fused_pass2_histograms_do_not_change_the_tables(g3, monkeypatch):
+    """Pass 2 re-computes activations and either hands them to fq_hist2048_seg or lets their producers histogram them on
+    the way out (Quantity.fuse_hist): the reference's feat.table both ways, every conv / Eltwise of the model fused
+    from its third batch on, and the number of values counted per row identical."""
+    from tools import Quantity
+    monkeypatch.setenv("FQ_ACT_CACHE_GB", "0")                # every batch goes through the second forward
+    got = {}
+    for fuse_hist in (True, False):
+        with product_workdir(device="gpu", max_cali_img_num=1) as tmp:
+            q = Quantity(_r18_gpu())
+            q.fuse_hist = fuse_hist
+            q.activation_quantize(cases.calib_batches(3, (4, 3, 32, 32)))
+            got[fuse_hist] = (open(os.path.join(tmp, "test", "workdir", "feat.table")).read(),
+                              q._collector.hist_device.sum(dim=1).cpu().numpy(), dict(q.timings))
+    assert got[True][0] == got[False][0] == g3["feat_table"]
+    np.testing.assert_array_equal(got[True][1], got[False][1])
+    assert got[False][2]["fused_hist_launches"] == 0
+    # two batches; a module is verified on its second pass-1 batch, so pass 2 fuses every verified conv / Eltwise twice
+    n_fused = got[True][2]["fused_bias_absmax_convs"] + got[True][2]["fused_add_absmax_eltwise"]
+    assert n_fused > 0 and got[True][2]["fused_hist_launches"] == 2 * n_fused
+
+
 class _TouchedBeforeRelu(torch.nn.Module):
     """conv -> in-place scaling by plain tensor code -> ReLU: the ReLU must see the scaled values, not a result the
     conv's fused kernel prepared before the scaling."""

@@ -90,7 +90,7 @@ def test_channel_histogram_packed_bins_do_not_carry(oracle):
     from common.quantity import _native as nat
     N, C, H, W = 70, 8, 31, 33                             # HW = 1023 -> 32 images per group: 32 736 elements per row
     x = torch.ones(N, C, H, W, device="cuda")
-    x[:, 1] *= 0.5                                          # |x| / iv = 1023.99..: bin 1023 (odd half) with iv from max 1.0
+    x[:, 1] *= 1023.5 / 2048                                # bin 1023 (odd half): iv = fl32(1/2048 + 1e-12) = 2^-11
     x[:, 2] *= 512.5 / 2048                                 # bin 512 (even half)
     iv = torch.full((C,), float(oracle.interval(np.float32(1.0))), device="cuda")
     hist = torch.zeros(C, 2048, dtype=torch.int64, device="cuda")
@@ -99,7 +99,7 @@ def test_channel_histogram_packed_bins_do_not_carry(oracle):
     for c in range(C):
         ref = oracle.hist2048(x[:, c].cpu().numpy().ravel(), np.float32(iv[c].item()))
         np.testing.assert_array_equal(hh[c], ref)
-    assert hh[0, 2047] == N * H * W and hh[1, 1023] == N * H * W and hh[2, 512] == N * H * W
+    assert hh[0, 2047] == N * H * W and hh[1, 1023] == N * H * W and hh[2, 512] == N * H * W      # odd, odd, even halves
 
 
 def test_per_channel_calibration_of_a_model():

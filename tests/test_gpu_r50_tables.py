@@ -26,7 +26,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _state(wd):
-    out = {"feat": open(os.path.join(wd, "feat.table")).read(), "weight": open(os.path.join(wd, "weight.table")).read()}
+    out = {"feat": open(os.path.join(wd, "feat.table")).read(), "weight_table": open(os.path.join(wd, "weight.table")).read()}
     for d in ("weight", "bias", "new_weight", "new_bias"):
         out[d] = {f: hashlib.sha256(open(os.path.join(wd, d, f), "rb").read()).hexdigest()
                   for f in sorted(os.listdir(os.path.join(wd, d)))}
@@ -124,7 +124,7 @@ def _hip_vs_oracle(oracle, model, batches, input_shape, rows, fused, monkeypatch
     assert hip["feat"] == cpu["feat"]
     assert len(hip["feat"].strip().split("\n")) == rows
     if weights:
-        assert hip["weight"] == cpu["weight"]
+        assert hip["weight_table"] == cpu["weight_table"]
         for d in ("weight", "bias", "new_weight", "new_bias"):
             assert hip[d] == cpu[d], d
     return timings, noted["n"]
@@ -201,8 +201,18 @@ def g4r50(golden_dir):
     return tables, np.load(os.path.join(golden_dir, "g4_r50_recon.npz"))
 
 
-def _r50_rec(tables, tmp):
+def _r50_folded(tables, golden_dir=None):
+    """The seeded ResNet-50 with BatchNorm folded EXACTLY as the reference folded it in the build container: the fold
+    factors gamma / sqrt(var + 1e-5) come from the fixture (torch.sqrt on CPU tensors runs through MKL and differs in the
+    last bit between the build container's Intel host and the GPU box's AMD host -- one ulp in a weight is enough to flip
+    its 8-bit rounding; cases.fold_bn_with_scales).  The product's merge_bn is the reference's expression and, like it,
+    follows the machine it runs on; tests/test_host_logic.py pins it to golden G8."""
     from model.resnet.ResNet_fabu import ResNet50
+    scales = np.load(os.path.join(os.path.dirname(os.path.abspath(cases.__file__)), "g4_r50_bn_scales.npz"))
+    return cases.fold_bn_with_scales(cases.seed_model(ResNet50(), gamma_scale=tables["gamma_scale"]).eval(), scales)
+
+
+def _r50_rec(tables, tmp):
     from tools import Reconstruction
     wd = os.path.join(tmp, "test", "workdir")
     os.makedirs(wd, exist_ok=True)
@@ -210,8 +220,8 @@ def _r50_rec(tables, tmp):
         fh.write(tables["feat_table"])
     with open(os.path.join(wd, "weight.table"), "w") as fh:
         fh.write(tables["weight_table"])
-    rec = Reconstruction(cases.seed_model(ResNet50(), gamma_scale=tables["gamma_scale"]).eval())
-    rec.merge_bn()
+    rec = Reconstruction(_r50_folded(tables))
+    rec.merge_bn()                                            # nothing left to fold
     return rec, wd
 
 
@@ -289,18 +299,16 @@ def test_r50_recontest_logits_match_the_reference(g4r50):
 def test_r50_weight_tables_equal_the_reference(g4r50):
     """weight.table and all 214 JSON files of ResNet-50 (25.5 M parameters) written by the HIP engine are byte-identical
     to the reference's (weights never pass through a convolution, so this is exact on any device)."""
-    from common.quantity import merge_bn
-    from model.resnet.ResNet_fabu import ResNet50
     from tools import Quantity
     tables, _ = g4r50
     with product_workdir(input_shape="1,3,224,224", device="gpu") as tmp:
-        model = merge_bn(cases.seed_model(ResNet50(), gamma_scale=tables["gamma_scale"]).eval()).cuda()
+        model = _r50_folded(tables).cuda()
         q = Quantity(model)
         wd = os.path.join(tmp, "test", "workdir")
         with open(os.path.join(wd, "feat.table"), "w") as fh:
             fh.write(tables["feat_table"])
         q.weight_quantize()
         got = _state(wd)
-    assert got["weight"] == tables["weight_table"]
+    assert got["weight_table"] == tables["weight_table"]
     for d in ("weight", "bias", "new_weight", "new_bias"):
         assert got[d] == tables["files"][d], d
