@@ -152,3 +152,41 @@ def test_conv_tail_rounding_ties_and_saturation(nat, oracle, rs):
         np.testing.assert_array_equal(y.cpu().numpy(), np.maximum(ref, np.float32(0)))
         np.testing.assert_array_equal(q.cpu().numpy().transpose(0, 3, 1, 2),
                                       oracle.quantity(np.maximum(ref, np.float32(0)), ob).astype(np.int8))
+
+
+def test_grouped_and_circular_convolutions_take_the_reference_shaped_path(nat, oracle):
+    """fq_conv2d_i8 covers groups == 1 with zero padding.  A grouped (depth-wise) convolution or a circular padding
+    mode must take the reference-shaped forward instead (Quantity kernel -> fp32 conv on integer-valued data -> fused
+    tail kernel), also inside a resident plan, and give the oracle's integers."""
+    from common.quantity import new_quantity_op as nq
+    from common.quantity import resident
+    torch.manual_seed(4)
+    info = dict(weight_bit=7, bias_bit=4, input_bit=4, output_bit=4)
+    for conv in (nn.Conv2d(16, 32, 3, padding=1, groups=4), nn.Conv2d(8, 8, 3, padding=1, groups=8),
+                 nn.Conv2d(16, 16, 3, padding=1, padding_mode="circular")):
+        w_float, b_float = conv.weight.detach().clone(), conv.bias.detach().clone()
+        m = nq.NewConv2d(conv, info).cuda()
+        assert not m._int8_ok(m.Conv)
+        x = torch.randn(3, conv.in_channels, 9, 9, device="cuda") * 2
+        with torch.no_grad():
+            got = m(x).cpu().numpy()
+        # oracle: the reference's chain with an fp32 convolution over the integer-valued operands (exact here)
+        xq = torch.from_numpy(oracle.quantity(x.cpu().numpy(), 4))
+        wq = torch.clamp(torch.round(w_float * 2 ** 7), -128, 127)
+        qb = torch.clamp(torch.round(b_float * 2 ** 4), -128, 127).numpy()
+        ref_conv = nn.Conv2d(conv.in_channels, conv.out_channels, 3, padding=1, groups=conv.groups,
+                             padding_mode=conv.padding_mode, bias=False)
+        with torch.no_grad():
+            ref_conv.weight.copy_(wq)
+            acc = ref_conv(xq).numpy()
+        np.testing.assert_array_equal(got, oracle.recon_epilogue(acc, qb, 7, 4))
+    # inside a resident plan the layer stays an fp32-boundary producer and the model still reproduces itself
+    net = nn.Sequential(nq.NewConv2d(nn.Conv2d(16, 16, 3, padding=1), dict(info)), nn.ReLU(),
+                        nq.NewConv2d(nn.Conv2d(16, 16, 3, padding=1, groups=16), dict(info)), nn.ReLU(),
+                        nq.NewConv2d(nn.Conv2d(16, 8, 1), dict(info))).cuda().eval()
+    x = torch.randn(2, 16, 10, 10, device="cuda")
+    with torch.no_grad():
+        plain = net(x)
+    resident.enable(net, x)
+    with torch.no_grad():
+        assert torch.equal(net(x), plain)
