@@ -246,19 +246,31 @@ def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
         h.remove()
     names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8")
     events, saved = [], {n: getattr(_native, n) for n in names}
+    bytes_of, macs_of = [], []
 
-    def timed(fn):
+    def nbytes(*ts):
+        return sum(int(t.numel()) * t.element_size() for t in ts if isinstance(t, torch.Tensor))
+
+    def timed(fn, name):
         def wrapper(*a, **k):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             r = fn(*a, **k)
             e1.record()
             events.append((e0, e1))
+            outs = r if isinstance(r, tuple) else (r,)
+            # algorithmic traffic of the launch: activation operand + weights + (fused add) residual + everything written
+            res = a[8] if name == "conv2d_i8_add_resident" else None
+            bytes_of.append(nbytes(a[0], a[1], res, *outs))
+            first = next(t for t in outs if isinstance(t, torch.Tensor))
+            pixels = first.numel() // first.shape[1 if first.dtype == torch.float32 else -1]
+            wq = a[1]                                              # [K][R][S][Cpad] (stem: [R][64][32])
+            macs_of.append(pixels * int(wq.numel()))
             return r
         return wrapper
     try:
         for n in names:
-            setattr(_native, n, timed(saved[n]))
+            setattr(_native, n, timed(saved[n], n))
         with torch.no_grad():
             for _ in range(forwards):
                 int8_net(batch)
@@ -266,12 +278,27 @@ def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
     finally:
         for n in names:
             setattr(_native, n, saved[n])
-    ms = sum(a.elapsed_time(b) for a, b in events) / forwards
+    per = [a.elapsed_time(b) for a, b in events]
+    ms = sum(per) / forwards
     achieved = 2.0 * macs[0] / (ms * 1e-3) / 1e12
+    # what the semantics allow: every launch costs at least its matrix work at the int8 peak AND its operand / result
+    # traffic at the HBM peak (the exact int16 residual stream of the reference's fp32 adds is most of the bytes)
+    n_l = len(events) // forwards
+    t_mfma = [2.0 * m / (INT8_PEAK_TOPS * 1e12) * 1e3 for m in macs_of[:n_l]]
+    t_hbm = [b / (HBM_PEAK_GBS * 1e9) * 1e3 for b in bytes_of[:n_l]]
+    bound_ms = sum(max(a, b) for a, b in zip(t_mfma, t_hbm))
     return {"bound": "mfma", "kernel": "conv2d_i8 / conv2d_i8_dma / stem_conv_i8 (all integer conv + linear launches of one forward)",
             "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(achieved / INT8_PEAK_TOPS, 4),
-            "launches_per_forward": len(events) // forwards, "ms_per_forward": round(ms, 4), "images_per_forward": int(batch.shape[0]),
-            "gmac_per_image": round(macs[0] / int(batch.shape[0]) / 1e9, 3)}
+            "launches_per_forward": n_l, "ms_per_forward": round(ms, 4), "images_per_forward": int(batch.shape[0]),
+            "gmac_per_image": round(macs[0] / int(batch.shape[0]) / 1e9, 3),
+            "bound_ms_per_forward": round(bound_ms, 4), "frac_of_bound": round(bound_ms / ms, 4),
+            "mfma_floor_ms": round(sum(t_mfma), 4), "hbm_floor_ms": round(sum(t_hbm), 4),
+            "algorithmic_gb_per_forward": round(sum(bytes_of[:n_l]) / 1e9, 3),
+            "launches_hbm_bound_at_peak": sum(1 for a, b in zip(t_mfma, t_hbm) if b > a),
+            "note": "frac = 2 x MAC / time against the 5 POP/s int8 peak.  bound_ms = sum over the launches of max(matrix work at that "
+                    "peak, algorithmic bytes at 8 TB/s): the exact int16 residual stream (5 B per output element of every conv3 + "
+                    "NewAdd: the reference adds un-quantised fp32 values) makes most launches HBM bound -- frac_of_bound is the "
+                    "fraction of what the semantics allow (DESIGN.md 5b)"}
 
 
 def cpu_baseline(model_cpu_ctor, hw, n_images_full, q, log):
