@@ -3,6 +3,7 @@ against the exact integer oracle.   pytest -m gpu"""
 import numpy as np
 import pytest
 import torch
+from torch import nn
 
 pytestmark = pytest.mark.gpu
 
