@@ -710,171 +710,6 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     TR(4);
 }
 
-// ---- the same kernel with 64-byte K-steps and a deeper ring (round 2) -----------------------------------
-// What bounds the kernel above is operand delivery, not arithmetic: the L2 -> LDS path reaches its bandwidth only with
-// ~256 KB per CU in flight (scripts/l2_probe.hip), and a ring of 2 x 32 KB steps on 2 workgroups per CU keeps 48 KB
-// there.  Halving the K-step halves the LDS per stage (16 KB for a 128 x 128 tile), so a ring of 3 fits THREE workgroups
-// per CU (48 KB each) and a ring of 4 two: 96 KB in flight per CU either way, 3 (2) waves per SIMD instead of 2 -- and
-// C only has to be a multiple of 64, which brings the 64-channel 3x3 layers of the first stage onto the DMA path.
-// Rows are 64 bytes = 4 chunks; 4 adjacent lanes fetch one row, a wave-load covers 16 rows; the swizzle that keeps the
-// MFMA-layout ds_read_b128 conflict free is chunk ^= (row >> 2) & 3 (the 4 rows that share a 256-byte bank row within a
-// ds_read_b128 lane group get 4 different chunk slots).
-__device__ __forceinline__ int swz64(int row) { return (row >> 2) & 3; }
-
-template <int TK, int kOut, int STAGES>
-__global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma64_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
-                                                                     const float* __restrict__ qbias, float* __restrict__ y,
-                                                                     int8_t* __restrict__ q, const ConvParams p) {
-    constexpr int BKB = 64;
-    constexpr int MT = TK / 32;
-    constexpr int A_LOADS = TK / 64;                      // a wave-load covers 16 rows; 4 waves -> 64 rows per instruction index
-    constexpr int B_LOADS = 2;                            // the wave's own 32 pixel rows
-    static_assert(STAGES >= 3 && STAGES <= 4, "LDS ring of 3 or 4 K-steps");
-    __shared__ __attribute__((aligned(16))) int8_t sA[STAGES][TK * BKB];
-    __shared__ __attribute__((aligned(16))) int8_t sB[STAGES][kTP * BKB];
-    __shared__ float sBias[TK];
-    __shared__ int sBiasI[TK];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = lane >> 5;
-    int tile_x, tile_y;
-    if (!conv_tile_of(p, tile_x, tile_y)) return;
-    const int m0 = tile_x * kTP;
-    const int k0 = tile_y * TK;
-    const int PQ = p.P * p.Q;
-    if (tid < TK) {                                       // visible after the first barrier
-        const float b = qbias[k0 + tid];
-        sBias[tid] = b;
-        sBiasI[tid] = (int)b;
-    }
-    const int m = m0 + wave * 32 + (lane & 31);
-    const bool m_ok = m < p.M;
-    int n_img = 0, pq = 0;
-    if (kOut & kOutF32) {
-        const int mm = m_ok ? m : 0;
-        n_img = mm / PQ; pq = mm - n_img * PQ;
-    }
-
-    // activation staging: in load j this lane fetches pixel row pj = 16j + (lane >> 2) of the wave's 32 and LDS
-    // position lane & 3, i.e. global chunk (lane & 3) ^ swz64(pj)
-    const rsrc_words xr = make_rsrc_words(x, p.x_bytes);
-    int ih0[B_LOADS], iw0[B_LOADS];
-    unsigned base0[B_LOADS];
-#pragma unroll
-    for (int j = 0; j < B_LOADS; ++j) {
-        const int pj = 16 * j + (lane >> 2);
-        const int mj = m0 + wave * 32 + pj;
-        const bool ok = mj < p.M;
-        const int mm = ok ? mj : 0;
-        const int nj = mm / PQ, pqj = mm - nj * PQ;
-        const int op = pqj / p.Q, oq = pqj - op * p.Q;
-        ih0[j] = ok ? op * p.stride_h - p.pad_h : -(1 << 28);         // out-of-range pixel: every tap misses
-        iw0[j] = oq * p.stride_w - p.pad_w;
-        base0[j] = (unsigned)nj * (unsigned)(p.H * p.W * p.C) + (unsigned)(((lane & 3) ^ swz64(pj)) * 16)
-                   + (unsigned)((ih0[j] * p.W + iw0[j]) * p.C);
-    }
-    // weight staging: load j of wave v covers tile rows 64j + 16v .. +15
-    const rsrc_words wr = make_rsrc_words(w, p.w_bytes);
-    unsigned aoff[A_LOADS];
-#pragma unroll
-    for (int j = 0; j < A_LOADS; ++j) {
-        const int row = 64 * j + 16 * wave + (lane >> 2);
-        aoff[j] = (unsigned)(k0 + row) * ((unsigned)p.chunks * 16u) + (unsigned)(((lane & 3) ^ swz64(row)) * 16);
-    }
-
-    int tap_r = 0, tap_s = 0, c_step = 0;                 // filter tap (uniform) and K-step inside it
-    const int steps_per_tap = p.C >> 6;
-    unsigned bvo[B_LOADS];
-    auto tap_offsets = [&](bool live) {                   // branch-free; `live` = false: every lane out of range
-        const int dh = tap_r * p.dil_h, dw = tap_s * p.dil_w;
-        const unsigned tap_delta = (unsigned)((dh * p.W + dw) * p.C);
-#pragma unroll
-        for (int j = 0; j < B_LOADS; ++j) {
-            const bool ok = live && (unsigned)(ih0[j] + dh) < (unsigned)p.H && (unsigned)(iw0[j] + dw) < (unsigned)p.W;
-            bvo[j] = ok ? base0[j] + tap_delta : kOutOfRange;
-        }
-    };
-    constexpr int kLoads = A_LOADS + B_LOADS;             // DMA instructions one wave issues per K-step
-    auto dma = [&](auto k_tag, int buf, int step, bool a_live) {
-        constexpr int k = decltype(k_tag)::value;
-        if constexpr (k < A_LOADS)
-            dma_to_lds(wr, lds_offset(&sA[buf][(64 * k + 16 * wave) * BKB]), a_live ? aoff[k] : kOutOfRange, step * BKB);
-        else
-            dma_to_lds(xr, lds_offset(&sB[buf][(wave * 32 + 16 * (k - A_LOADS)) * BKB]), bvo[k - A_LOADS], c_step * BKB);
-    };
-    auto for_each_dma = [&](auto&& f) {
-        [&]<int... Ks>(std::integer_sequence<int, Ks...>) { (f(std::integral_constant<int, Ks>{}), ...); }
-        (std::make_integer_sequence<int, kLoads>{});
-    };
-    auto advance_tap = [&]() {
-        if (++c_step == steps_per_tap) {
-            c_step = 0;
-            if (++tap_s == p.S) { tap_s = 0; ++tap_r; }
-        }
-    };
-
-    v16i acc[MT];
-#pragma unroll
-    for (int a = 0; a < MT; ++a)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][r] = 0;
-
-    int a_off[MT], swz_off[2];
-#pragma unroll
-    for (int a = 0; a < MT; ++a) a_off[a] = (a * 32 + (lane & 31)) * BKB;
-    // rows a * 32 + (lane & 31) and wave * 32 + (lane & 31) have the same swizzle bits: (row >> 2) & 3 only sees lane & 31
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) swz_off[ks] = ((ks * 2 + half) ^ swz64(lane & 31)) * 16;
-    const int b_row = (wave * 32 + (lane & 31)) * BKB;
-
-    const int nsteps = p.chunks >> 2;
-    // STAGES - 1 K-steps are in flight; the wait at the end of step s is for step s + 1 only (vmcnt counts in issue
-    // order: the (STAGES - 2) * kLoads newest may stay outstanding)
-#pragma unroll
-    for (int s0 = 0; s0 < STAGES - 1; ++s0) {
-        const bool live0 = s0 < nsteps;
-        tap_offsets(live0);
-        for_each_dma([&](auto k) { dma(k, s0, s0, live0); });
-        advance_tap();
-    }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kLoads) : "memory");
-    __syncthreads();
-    int cur = 0, nxt = STAGES - 1;
-    for (int step = 0; step < nsteps; ++step) {
-        const int pre = step + STAGES - 1;                // the K-step whose tiles are requested during this one
-        const bool more = pre < nsteps;
-        tap_offsets(more);
-        v4i fb[2], fa[2][MT];
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) fb[ks] = *reinterpret_cast<const v4i*>(&sB[cur][b_row + swz_off[ks]]);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
-                fa[ks][a] = *reinterpret_cast<const v4i*>(&sA[cur][a_off[a] + swz_off[ks]]);
-        // the next ring slot's DMA is issued between the MFMAs (one behind each of the first kLoads)
-        [&]<int... Is>(std::integer_sequence<int, Is...>) {
-            ([&] {
-                constexpr int i = Is, ks = i / MT, a = i % MT;
-                acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks][a], fb[ks], acc[a], 0, 0, 0);
-                if constexpr (i < kLoads) dma(std::integral_constant<int, i>{}, nxt, pre, more);
-            }(), ...);
-        }(std::make_integer_sequence<int, 2 * MT>{});
-        static_assert(kLoads <= 2 * MT, "one DMA issue behind each of the first MFMAs");
-        advance_tap();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * kLoads) : "memory");
-        __syncthreads();
-        cur = cur + 1 == STAGES ? 0 : cur + 1;
-        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing of this wave may still land in LDS: the epilogue reuses it
-
-    static_assert(kTP * (TK + 16) <= STAGES * TK * BKB, "the int8 output tile is staged in the weight buffers");
-    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
-    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
-}
-
 // ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
 // q8 (one element): fq_int_tail.h
 
@@ -1146,20 +981,6 @@ static void launch_conv_dma(dim3 grid, hipStream_t st, const int8_t* x, const in
     else launch_conv_dma_stages<TK, 2>(grid, st, x, w, qbias, y, q, p);
 }
 
-template <int TK, int STAGES>
-static void launch_conv_dma64(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
-                              int8_t* q, const ConvParams& p0) {
-    const ConvParams p = xcd_order(grid, p0);
-    if (p.res)
-        hipLaunchKernelGGL((conv2d_i8_dma64_kernel<TK, kOutI8 | kOutAdd, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
-    else if (y && q)
-        hipLaunchKernelGGL((conv2d_i8_dma64_kernel<TK, kOutF32 | kOutI8, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
-    else if (q)
-        hipLaunchKernelGGL((conv2d_i8_dma64_kernel<TK, kOutI8, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
-    else
-        hipLaunchKernelGGL((conv2d_i8_dma64_kernel<TK, kOutF32, STAGES>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
-}
-
 template <int TK, int kPath>
 static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
                              int8_t* q, const ConvParams& p0) {
@@ -1232,20 +1053,6 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     const bool use_dma = dma_env < 0 ? (p.chunks >> 3) >= 8 : dma_env == 1;
     static const int force_tk = [] { const char* e = getenv("FQ_CONV_TK"); return e ? atoi(e) : 0; }();
     static const bool use_c64 = [] { const char* e = getenv("FQ_CONV_C64"); return !(e && e[0] == '0'); }();
-    // FQ_CONV_BKB64 = 3 / 4: the 64-byte K-step kernel with a ring of 3 / 4 wherever it applies (experiment knob)
-    static const int bkb64 = [] { const char* e = getenv("FQ_CONV_BKB64"); return e ? atoi(e) : 0; }();
-    if (bkb64 && C % 64 == 0 && (p.chunks >> 2) >= 4 && ((K % 128 == 0 && !(K <= 64 || wg128 < kCUs || force_tk == 64)) || K % 64 == 0)) {
-        const bool tk128 = K % 128 == 0 && !(K <= 64 || wg128 < kCUs || force_tk == 64) && force_tk != 64;
-        if (tk128) {
-            if (bkb64 == 4) launch_conv_dma64<128, 4>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
-            else launch_conv_dma64<128, 3>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
-        } else {
-            if (bkb64 == 4) launch_conv_dma64<64, 4>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
-            else launch_conv_dma64<64, 3>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
-        }
-        FQ_LAUNCH_CHECK();
-        return FQ_OK;
-    }
     if ((K <= 64 || wg128 < kCUs || force_tk == 64) && force_tk != 128) {
         if (C % 128 == 0 && K % 64 == 0 && use_dma)
             launch_conv_dma<64>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);

@@ -10,10 +10,6 @@ for tk in 64 128; do for dma in 0 1; do for st in 2 3; do
   [ $dma = 0 ] && [ $st = 3 ] && continue
   FQ_CONV_TK=$tk FQ_CONV_DMA=$dma FQ_CONV_STAGES=$st python scripts/conv_bench.py $B i8 > $OUT/tk${tk}_dma${dma}_st${st}.txt 2>/dev/null
 done; done; done
-for st in 3 4; do
-  FQ_CONV_BKB64=$st python scripts/conv_bench.py $B i8 > $OUT/bkb64_st${st}.txt 2>/dev/null
-  FQ_CONV_BKB64=$st FQ_CONV_TK=64 python scripts/conv_bench.py $B i8 > $OUT/bkb64_st${st}_tk64.txt 2>/dev/null
-done
 python - <<PY
 import glob, os
 rows = {}
