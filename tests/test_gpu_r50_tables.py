@@ -190,6 +190,57 @@ def test_config5_fused_fakequant_on_the_largest_r101_512_activation(oracle):
     assert np.array_equal(x.cpu().numpy(), oracle.quandequan(host, 3))
 
 
+def test_config5_recontest_r101_at_512_every_layer_output_equals_the_oracle(oracle):
+    """BASELINE config 5's second half: the fake-quant evaluation model (ReconTest) of ResNet-101 @3x512x512.  There is no
+    reference capture at this size (the reference's Python histogram loop needs minutes per image), so the check is per
+    layer and exact: for each of the 105 TestConv / TestLinear modules the output the model hands on must be the CPU
+    oracle's QuanDequan of the float convolution's own result -- i.e. the fused in-place kernel on every real activation
+    of the model, from 16 M-element planes down to the classifier -- and the fake-quantised parameters must be the
+    oracle's QuanDequan of the folded ones."""
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_fabu import ResNet101
+    from tools import Quantity, Reconstruction
+    with product_workdir(input_shape="1,3,512,512", device="gpu", max_cali_img_num=1):
+        model = merge_bn(cases.seed_model(ResNet101(input_size=512), gamma_scale=0.5).eval()).cuda()
+        q = Quantity(model)
+        q.activation_quantize(cases.calib_batches(2, (1, 3, 512, 512), seed=512))
+        q.weight_quantize()
+        float_model = merge_bn(cases.seed_model(ResNet101(input_size=512), gamma_scale=0.5).eval())
+        folded = {k: v.clone() for k, v in float_model.state_dict().items()}
+        rec = Reconstruction(float_model.cuda())
+        info = rec.get_quantity_information()
+        net = rec.ReconTest(info, "./workdir/recontest.pth")
+        checked = {"n": 0, "elems": 0}
+        raw = {}
+
+        def grab(name):
+            def hook(mod, inputs, out):
+                raw[name] = out.detach().clone()              # the float result, before QuanDequan overwrites it in place
+            return hook
+
+        def check(name, bit):
+            def hook(mod, inputs, out):
+                want = oracle.quandequan(raw.pop(name).cpu().numpy(), bit)
+                assert np.array_equal(out.detach().cpu().numpy(), want), name
+                checked["n"] += 1
+                checked["elems"] += want.size
+            return hook
+
+        for name, m in net.named_modules():
+            if type(m).__name__ in ("TestConv", "TestLinear"):
+                inner = m.Conv if hasattr(m, "Conv") else m.linear
+                inner.register_forward_hook(grab(name))
+                m.register_forward_hook(check(name, m.output_bit))
+                w = inner.weight.detach().cpu().numpy()
+                assert np.array_equal(w, oracle.quandequan(folded[name + ".weight"].numpy(), m.weight_bit)), name
+                assert np.array_equal(inner.bias.detach().cpu().numpy(),
+                                      oracle.quandequan(folded[name + ".bias"].numpy(), m.bias_bit)), name
+        with torch.no_grad():
+            logits = net(cases.fixed_input((1, 3, 512, 512), seed=5).cuda())
+        assert checked["n"] == 105 and checked["elems"] > 60_000_000, checked
+        assert torch.isfinite(logits).all()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # G4-R50: the reference's own ReconModel / ReconTest on the fabu ResNet-50 (tests/golden/make_golden_r50.py)
 # ------------------------------------------------------------------------------------------------------------------
