@@ -408,6 +408,36 @@ __global__ __launch_bounds__(kKlBlock) void kl_prefix_kernel(const double* __res
     if (tid == kKlBlock - 1) { SP[16] = bp.hi; SP[17] = bp.lo; AL[16] = ba.hi; AL[17] = ba.lo; NZ[8] = (unsigned short)bn; }
 }
 
+// log for the screen: the table-driven reduction of fq_log's fast path (include/fq_log.h) without its double-double
+// bookkeeping and without the rounding test -- x = 2^k z, z in [0.6875, 1.375), r = z * invc - 1 (|r| < 2^-7),
+// log x = k ln2 + log(1/invc) + log1p(r) with a degree-7 polynomial: relative error < 2^-58, ~25 flops where ocml's
+// (< 1 ulp) log costs ~120 instructions (the screen was 640 vector instructions per candidate and wave, two
+// thirds of them its two logarithms: 8.4 -> 5.4 ms per 4 096 rows).  Anything but a positive normal number goes to ocml's log
+// (a negative folded bin must give NaN).
+__device__ __forceinline__ double screen_log(double x) {
+    unsigned long long ix;
+    memcpy(&ix, &x, 8);
+    if (ix - 0x0010000000000000ULL >= 0x7ff0000000000000ULL - 0x0010000000000000ULL) return log(x);
+    const unsigned long long tmp = ix - 0x3fe6000000000000ULL;
+    const int i = (int)((tmp >> 45) & 127);
+    const long long k = (long long)tmp >> 52;
+    const unsigned long long iz = ix - (tmp & 0xfff0000000000000ULL);
+    double z;
+    memcpy(&z, &iz, 8);
+    const double invc = fq_log_table[i].invc, lch = fq_log_table[i].logc_hi, lcl = fq_log_table[i].logc_lo;
+    const double r = __builtin_fma(z, invc, -1.0);
+    double c = 1.0 / 7.0;
+    c = __builtin_fma(c, r, -1.0 / 6.0);
+    c = __builtin_fma(c, r, 1.0 / 5.0);
+    c = __builtin_fma(c, r, -1.0 / 4.0);
+    c = __builtin_fma(c, r, 1.0 / 3.0);
+    c = __builtin_fma(c, r, -0.5);
+    const double dk = (double)k;
+    const double hi = __builtin_fma(dk, 0x1.62e42fefa38p-1, lch);               // k * LN2_HI is exact
+    const double lo = __builtin_fma(dk, 0x1.ef35793c7673p-45, lcl);
+    return hi + (r + __builtin_fma(r * r, c, lo));
+}
+
 // S(t) for all 1920 candidates of one row: the row's P, prefix sums and prefix counts staged in LDS once, one wave per
 // candidate (no workgroup barrier inside the loop), two quantised bins per lane.
 __global__ __launch_bounds__(kKlBlock) void kl_screen_kernel(const double* __restrict__ Pw, const double* __restrict__ tailw,
@@ -450,7 +480,7 @@ __global__ __launch_bounds__(kKlBlock) void kl_screen_kernel(const double* __res
             const int nint = (int)sNZ[hi] - (int)sNZ[lu];
             if (nint > 0) {
                 const double e = (1e-9 + ev[h]) + 1e-12;
-                part += mass(lu, hi) * log(e);
+                part += mass(lu, hi) * screen_log(e);
                 corr += (double)nint * e;
             }
             rl_[h] = rl; rs_[h] = rs; redge[h] = has_r && pr != 0.0;
@@ -464,12 +494,12 @@ __global__ __launch_bounds__(kKlBlock) void kl_screen_kernel(const double* __res
         const double evn0 = (lane == kWave - 1) ? b64 : nxt0;
         if (redge[0]) {
             const double e = ((1e-9 + ev[0] * rs_[0]) + evn0 * (1.0 - rs_[0])) + 1e-12;
-            part += sP[rl_[0]] * log(e);
+            part += sP[rl_[0]] * screen_log(e);
             corr += e;
         }
         if (redge[1] && lane != kWave - 1) {
             const double e = ((1e-9 + ev[1] * rs_[1]) + nxt1 * (1.0 - rs_[1])) + 1e-12;
-            part += sP[rl_[1]] * log(e);
+            part += sP[rl_[1]] * screen_log(e);
             corr += e;
         }
 #pragma unroll
@@ -483,7 +513,7 @@ __global__ __launch_bounds__(kKlBlock) void kl_screen_kernel(const double* __res
             double s = (AL[2 * (t - 1)] - part) + AL[2 * (t - 1) + 1];
             if (a_last != 0.0) {                                      // negative (rounding of the tail chain): NaN, kept
                 const double e_last = (plast != 0.0 ? 1e-9 + ev[1] : 1e-9) + 1e-12;
-                s += a_last * log(a_last) - a_last * log(e_last);
+                s += a_last * screen_log(a_last) - a_last * screen_log(e_last);
                 corr += e_last;
             }
             klw[(size_t)row * kCand + c] = s + 1e-12 * corr;

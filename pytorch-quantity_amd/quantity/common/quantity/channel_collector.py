@@ -8,8 +8,6 @@ write row = first_row(tensor) + c; one launch covers all tensors of a forward.  
 the per-tensor arithmetic (same interval formula, same binning, same KL sweep), which
 tests/test_gpu_per_channel.py checks against the CPU oracle channel by channel.
 """
-import math
-
 import numpy as np
 import torch
 
@@ -66,10 +64,10 @@ class ChannelCollector(StatCollectives):
         """fp32 bin width per row: statistic * max / 2048 + 1e-12 with NumPy fp32 scalars (the
         reference's expression, distribution_collector.py:61); rows that never left zero get 1e-12."""
         m = self._max.cpu().numpy()
-        iv = np.empty(self._rows, dtype=np.float32)
-        for r in range(self._rows):
-            v = m[r] if m[r] > 0 else 0
-            iv[r] = np.float32(self._statistic * v / _native.BINS + 1e-12)
+        # element-wise the reference's scalar expression (NumPy-2 weak promotion keeps everything fp32; a row that never
+        # left zero gives 0 + 1e-12); one vector expression instead of 42 667 scalar ones (61 ms of Python for ResNet-50)
+        iv = (self._statistic * m / _native.BINS + 1e-12).astype(np.float32, copy=False)
+        assert iv.dtype == np.float32
         self._interval = torch.from_numpy(iv).to(self._device)
         return iv
 
@@ -99,13 +97,11 @@ class ChannelCollector(StatCollectives):
         t0 = time.perf_counter()
         thr = _native.kl_threshold(self._hist).cpu().numpy()
         self.kl_seconds = round(time.perf_counter() - t0, 4)      # the sweep of all rows (device time: .cpu() waits)
+        # quantizer.py:86-90 per row through the C helper (the host libm call CPython's math.log(x, 2) makes), all rows at once
+        all_bits, _thr_val = _native.bits_from_threshold(thr, iv)
         bits = {}
         for n in self._names:
             lo, hi = self.row_range(n)
-            out = []
-            for r in range(lo, hi):
-                tb = (int(thr[r]) + 0.5) * iv[r]
-                out.append(int(8 - 1 - math.ceil(math.log(tb, 2))))
-            bits[n] = out
+            bits[n] = [int(b) for b in all_bits[lo:hi]]
         self.threshold_bins = thr
         return bits
