@@ -33,8 +33,9 @@ for name in ("bn1", "layer1.0.bn1", "layer2.0.bn3"):
                                   bool(np.array_equal(t_b.numpy(), n_b))]}
     # 1e-5 as python float added to a float32 tensor: torch computes in float32? (v + 1e-5)
     out[name]["add_double_then_round"] = h((v.numpy().astype(np.float64) + 1e-5).astype(np.float32))
-path = os.path.join(ROOT, "gpurun_dbg_merge.json")
+path = os.path.join(ROOT, "gpurun_dbg", "merge.json")
 if len(sys.argv) > 1 and sys.argv[1] == "write":
+    os.makedirs(os.path.dirname(path), exist_ok=True)
     json.dump(out, open(path, "w"), indent=1)
     print(json.dumps(out, indent=0)[:1500])
 else:

@@ -7,7 +7,7 @@ import cases
 from workdir_util import product_workdir
 from model.resnet.ResNet_fabu import ResNet50
 from tools import Reconstruction
-ref = np.load(os.path.join(ROOT, "gpurun_dbg_r50.npz"))
+ref = np.load(os.path.join(ROOT, "gpurun_dbg", "r50_layer2.npz"))
 tables = json.load(open(os.path.join(ROOT, "tests", "golden", "g4_r50_tables.json")))
 x = cases.fixed_input((2, 3, 224, 224)).cuda()
 with product_workdir(input_shape="1,3,224,224", device="gpu") as tmp:

@@ -19,8 +19,9 @@ g = np.random.default_rng(12345)
 sd["probe.normal"] = hashlib.sha256(g.standard_normal(5_000_000, dtype=np.float32).tobytes()).hexdigest()[:16]
 sd["probe.random"] = hashlib.sha256(g.random(5_000_000, dtype=np.float32).tobytes()).hexdigest()[:16]
 sys.stdout = sys.__stdout__
-out = os.path.join(ROOT, "gpurun_dbg_seed.json")
+out = os.path.join(ROOT, "gpurun_dbg", "seed.json")
 if len(sys.argv) > 1 and sys.argv[1] == "write":
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(sd, open(out, "w"))
     print("written", len(sd))
 else:
