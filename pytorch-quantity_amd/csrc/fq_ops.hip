@@ -189,81 +189,132 @@ __global__ __launch_bounds__(kOpsBlock) void recon_epilogue_vec_kernel(const flo
     }
 }
 
-// ---- conv bias add with the running abs-max taken on the way out ---------------------------------
+// ---- conv bias add / residual add of the float model with a calibration statistic taken on the way out --------------
 // A float Conv2d on this stack is a MIOpen convolution followed by a separate broadcast add of the bias (8 B per
-// element); the calibration then reads the result once more for the abs-max (4 B).  This kernel IS that add --
-// y[n][c][hw] += bias[c], the same single fp32 rounding -- and folds max |y| into the tensor's row while the values
-// are in registers, so pass 1 does not read conv outputs a second time.  kVec: HW % 4 == 0 and y 16-byte aligned.
-// relu_out != nullptr: the nn.ReLU that consumes this tensor is served in the same pass (r = y > 0 ? y : 0 with NaN kept,
-// torch's clamp_min), one more 4-byte write instead of a separate 8-byte pass.
+// element); the calibration then reads the result once more for the abs-max (pass 1) or the histogram (pass 2), 4 B.
+// These kernels ARE that add -- y[n][c][hw] += bias[c], the same single fp32 rounding; z = x + y for the Eltwise module
+// (fabu_layer.py:16-19) -- and fold the statistic in while the values are in registers:
+//   Stat = MaxStat   pass 1 (distribution_collector.py:70-78): max |y| into the tensor's row of the collector;
+//   Stat = HistStat  pass 2 (distribution_collector.py:127-135): every value binned (fq_hist_bin.h) into an 8 KB LDS
+//                    histogram per workgroup, flushed with 64-bit atomics at the end.  A tensor that was just written
+//                    is the worst input for the streaming histogram kernel (it shares HBM with the write-back of the
+//                    very lines it reads) and would cost a second read; few, long-lived workgroups
+//                    (2 per CU) keep the flush at 2048 bins x 512.
+// relu_out != nullptr: the nn.ReLU that consumes the tensor is served in the same pass (r = y > 0 ? y : 0 with NaN kept,
+// torch's clamp_min): one more 4-byte write instead of a separate 8-byte pass.
+// kVec: HW % 4 == 0 and 16-byte aligned pointers.  kStream: the launch moves more than the 256 MB Infinity Cache holds --
+// non-temporal loads and stores, as in unary_vec_kernel.  Two items per lane are in flight per iteration, and the
+// channel of an item is carried along incrementally (plane = i / HW, c = plane % C advance by constants per grid stride:
+// two adds and two selects instead of two integer divisions per item).
 __device__ __forceinline__ float relu_like_torch(float v) { return v > 0.0f ? v : (v != v ? v : 0.0f); }
 
-template <bool kVec>
-__global__ __launch_bounds__(kOpsBlock) void bias_add_absmax_kernel(float* __restrict__ y, const float* __restrict__ bias,
-                                                                    unsigned n_items, unsigned inner, unsigned C,
-                                                                    unsigned int* __restrict__ max_bits, float* __restrict__ relu_out) {
-    __shared__ float s_wave[kOpsBlock / kWave];
+struct MaxStat {
     float m = 0.0f;
-    const unsigned stride = gridDim.x * kOpsBlock;
-    for (unsigned i = blockIdx.x * kOpsBlock + threadIdx.x; i < n_items; i += stride) {
-        const float b = bias[(i / inner) % C];                      // inner = HW (scalar form) or HW / 4 (vector form)
+    __device__ __forceinline__ void add(float v) { m = fmaxf(m, fabsf(v)); }                  // fmaxf drops NaN
+};
+template <bool kFast>
+struct HistStat {
+    unsigned int* bins;
+    unsigned int* park;                                       // exact zeros are not counted: a per-lane scratch slot
+    float iv, yr;
+    __device__ __forceinline__ void add(float v) { atomicAdd((v != 0.0f) ? (bins + bin_of<kFast>(v, iv, yr)) : park, 1u); }
+};
+
+template <bool kStream> __device__ __forceinline__ f4v ld4(const f4v* p) { return kStream ? __builtin_nontemporal_load(p) : *p; }
+template <bool kStream> __device__ __forceinline__ void st4(f4v v, f4v* p) { if (kStream) __builtin_nontemporal_store(v, p); else *p = v; }
+__device__ __forceinline__ f4v relu4(f4v v) {
+    f4v r;
+    r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
+    return r;
+}
+
+template <bool kVec, bool kStream, typename Stat>
+__device__ __forceinline__ void bias_add_body(float* __restrict__ y, const float* __restrict__ bias, unsigned n_items,
+                                              unsigned inner, unsigned C, float* __restrict__ relu_out, Stat& stat) {
+    const size_t stride = (size_t)gridDim.x * kOpsBlock;
+    size_t i = (size_t)blockIdx.x * kOpsBlock + threadIdx.x;
+    // item i lies in plane i / inner (inner = HW, or HW / 4 in the vector form), channel plane % C
+    unsigned plane = (unsigned)(i / inner), rem = (unsigned)(i - (size_t)plane * inner), c = plane % C;
+    const unsigned dq = (unsigned)(stride / inner), dr = (unsigned)(stride - (size_t)dq * inner), dc = dq % C;
+    auto next_channel = [&]() {                               // (rem, c) of item i + stride
+        rem += dr;
+        const unsigned carry = rem >= inner ? 1u : 0u;
+        rem -= carry ? inner : 0u;
+        c += dc + carry;
+        c -= c >= C ? C : 0u;
+    };
+    for (; i < n_items; i += 2 * stride) {
+        const size_t i1 = i + stride;
+        const bool two = i1 < n_items;
+        const float b0 = bias[c];
+        next_channel();
+        const float b1 = bias[c];
+        next_channel();
         if (kVec) {
-            f4v v = reinterpret_cast<f4v*>(y)[i];
-            v.x += b; v.y += b; v.z += b; v.w += b;
-            reinterpret_cast<f4v*>(y)[i] = v;
-            if (relu_out) {
-                f4v r;
-                r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
-                reinterpret_cast<f4v*>(relu_out)[i] = r;
+            f4v* y4 = reinterpret_cast<f4v*>(y);
+            f4v* r4 = reinterpret_cast<f4v*>(relu_out);
+            f4v v0 = ld4<kStream>(&y4[i]);
+            f4v v1 = two ? ld4<kStream>(&y4[i1]) : f4v{0.f, 0.f, 0.f, 0.f};
+            v0.x += b0; v0.y += b0; v0.z += b0; v0.w += b0;
+            v1.x += b1; v1.y += b1; v1.z += b1; v1.w += b1;
+            st4<kStream>(v0, &y4[i]);
+            if (relu_out) st4<kStream>(relu4(v0), &r4[i]);
+            stat.add(v0.x); stat.add(v0.y); stat.add(v0.z); stat.add(v0.w);
+            if (two) {
+                st4<kStream>(v1, &y4[i1]);
+                if (relu_out) st4<kStream>(relu4(v1), &r4[i1]);
+                stat.add(v1.x); stat.add(v1.y); stat.add(v1.z); stat.add(v1.w);
             }
-            m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
         } else {
-            const float v = y[i] + b;
-            y[i] = v;
-            if (relu_out) relu_out[i] = relu_like_torch(v);
-            m = fmaxf(m, fabsf(v));
+            const float v0 = y[i] + b0;
+            y[i] = v0;
+            if (relu_out) relu_out[i] = relu_like_torch(v0);
+            stat.add(v0);
+            if (two) {
+                const float v1 = y[i1] + b1;
+                y[i1] = v1;
+                if (relu_out) relu_out[i1] = relu_like_torch(v1);
+                stat.add(v1);
+            }
         }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-    if ((threadIdx.x & (kWave - 1)) == 0) s_wave[threadIdx.x / kWave] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < kOpsBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
-        // m >= 0: the bit pattern orders like an unsigned.  Thousands of workgroups publish into ONE word: only those
-        // that can still raise it pay the atomic (4 096 serialised atomics cost 40 us, more than the add itself)
-        const unsigned int bits = __float_as_uint(m);
-        if (bits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, bits);
     }
 }
 
-// ---- residual add of the float model with the running abs-max taken on the way out ----------------
-// Eltwise.forward (fabu_layer.py:16-19: x + y) during calibration pass 1: z = x + y (one fp32 rounding, what torch.add
-// does) with max |z| folded into the tensor's row -- the sum is not read a second time for the maximum.
-__global__ __launch_bounds__(kOpsBlock) void add_absmax_kernel(const f4v* __restrict__ x, const f4v* __restrict__ y,
-                                                               f4v* __restrict__ z, size_t nvec, const float* __restrict__ xs,
-                                                               const float* __restrict__ ys, float* __restrict__ zs, unsigned tail,
-                                                               unsigned int* __restrict__ max_bits, float* __restrict__ relu_out) {
-    __shared__ float s_wave[kOpsBlock / kWave];
-    float m = 0.0f;
+template <bool kStream, typename Stat>
+__device__ __forceinline__ void add_body(const f4v* __restrict__ x, const f4v* __restrict__ y, f4v* __restrict__ z, size_t nvec,
+                                         const float* __restrict__ xs, const float* __restrict__ ys, float* __restrict__ zs,
+                                         unsigned tail, float* __restrict__ relu_out, Stat& stat) {
     const size_t stride = (size_t)gridDim.x * kOpsBlock;
-    for (size_t i = (size_t)blockIdx.x * kOpsBlock + threadIdx.x; i < nvec; i += stride) {
-        const f4v v = x[i] + y[i];
-        z[i] = v;
-        if (relu_out) {
-            f4v r;
-            r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
-            reinterpret_cast<f4v*>(relu_out)[i] = r;
+    f4v* r4 = reinterpret_cast<f4v*>(relu_out);
+    for (size_t i = (size_t)blockIdx.x * kOpsBlock + threadIdx.x; i < nvec; i += 2 * stride) {
+        const size_t i1 = i + stride;
+        const bool two = i1 < nvec;
+        const f4v a0 = ld4<kStream>(&x[i]), c0 = ld4<kStream>(&y[i]);
+        const f4v a1 = two ? ld4<kStream>(&x[i1]) : f4v{0.f, 0.f, 0.f, 0.f};
+        const f4v c1 = two ? ld4<kStream>(&y[i1]) : f4v{0.f, 0.f, 0.f, 0.f};
+        const f4v v0 = a0 + c0, v1 = a1 + c1;
+        st4<kStream>(v0, &z[i]);
+        if (relu_out) st4<kStream>(relu4(v0), &r4[i]);
+        stat.add(v0.x); stat.add(v0.y); stat.add(v0.z); stat.add(v0.w);
+        if (two) {
+            st4<kStream>(v1, &z[i1]);
+            if (relu_out) st4<kStream>(relu4(v1), &r4[i1]);
+            stat.add(v1.x); stat.add(v1.y); stat.add(v1.z); stat.add(v1.w);
         }
-        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
     }
     if (blockIdx.x == 0 && threadIdx.x < tail) {          // the last n % 4 elements
         const float v = xs[threadIdx.x] + ys[threadIdx.x];
         zs[threadIdx.x] = v;
         if (relu_out) relu_out[(nvec << 2) + threadIdx.x] = relu_like_torch(v);
-        m = fmaxf(m, fabsf(v));
+        stat.add(v);
     }
+}
+
+// workgroup maximum -> the collector's row.  m >= 0: the bit pattern orders like an unsigned.  Thousands of workgroups
+// publish into ONE word: only those that can still raise it pay the atomic (4 096 serialised atomics cost 40 us, more
+// than the add itself)
+__device__ __forceinline__ void publish_max(float m, unsigned int* __restrict__ max_bits) {
+    __shared__ float s_wave[kOpsBlock / kWave];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
     if ((threadIdx.x & (kWave - 1)) == 0) s_wave[threadIdx.x / kWave] = m;
@@ -276,12 +327,6 @@ __global__ __launch_bounds__(kOpsBlock) void add_absmax_kernel(const f4v* __rest
     }
 }
 
-// ---- the same two producers in calibration pass 2: the 2048-bin histogram taken on the way out ---------------------
-// Pass 2 re-runs (part of) the forward and histograms its outputs with the final bin widths.  A tensor that was just
-// written is the worst input for the streaming histogram kernel (it shares HBM with the write-back of the very lines it
-// reads: 6.6 -> 5.5 TB/s), and it costs a second 4 B/element read.  These variants bin every
-// output value while it is in registers (same arithmetic: fq_hist_bin.h), in an LDS histogram per workgroup flushed
-// with 64-bit atomics at the end; few, long-lived workgroups (2 per CU) keep the flush traffic at 2048 bins x 512.
 __device__ __forceinline__ void hist_flush(unsigned int* s_bins, unsigned long long* __restrict__ dst) {
     __syncthreads();
     for (int b = threadIdx.x; b < FQ_BINS; b += kOpsBlock) {
@@ -290,89 +335,68 @@ __device__ __forceinline__ void hist_flush(unsigned int* s_bins, unsigned long l
     }
 }
 
-template <bool kVec, bool kFast>
-__device__ __forceinline__ void bias_add_hist_body(float* __restrict__ y, const float* __restrict__ bias, unsigned n_items,
-                                                   unsigned inner, unsigned C, float iv, unsigned int* s_bins,
-                                                   float* __restrict__ relu_out) {
-    const float yr = 1.0f / iv;
-    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
-    auto count = [&](float v) { atomicAdd((v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, yr)) : park, 1u); };
-    const unsigned stride = gridDim.x * kOpsBlock;
-    for (unsigned i = blockIdx.x * kOpsBlock + threadIdx.x; i < n_items; i += stride) {
-        const float b = bias[(i / inner) % C];
-        if (kVec) {
-            f4v v = reinterpret_cast<f4v*>(y)[i];
-            v.x += b; v.y += b; v.z += b; v.w += b;
-            reinterpret_cast<f4v*>(y)[i] = v;
-            if (relu_out) {
-                f4v r;
-                r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
-                reinterpret_cast<f4v*>(relu_out)[i] = r;
-            }
-            count(v.x); count(v.y); count(v.z); count(v.w);
-        } else {
-            const float v = y[i] + b;
-            y[i] = v;
-            if (relu_out) relu_out[i] = relu_like_torch(v);
-            count(v);
-        }
-    }
+template <bool kVec, bool kStream>
+__global__ __launch_bounds__(kOpsBlock) void bias_add_absmax_kernel(float* __restrict__ y, const float* __restrict__ bias,
+                                                                    unsigned n_items, unsigned inner, unsigned C,
+                                                                    unsigned int* __restrict__ max_bits, float* __restrict__ relu_out) {
+    MaxStat st;
+    bias_add_body<kVec, kStream>(y, bias, n_items, inner, C, relu_out, st);
+    publish_max(st.m, max_bits);
 }
 
-template <bool kVec>
+__device__ __forceinline__ unsigned int* hist_lds_zeroed() {
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kOpsBlock) s_bins[b] = 0u;
+    __syncthreads();
+    return s_bins;
+}
+
+template <bool kVec, bool kStream>
 __global__ __launch_bounds__(kOpsBlock) void bias_add_hist_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                                   unsigned n_items, unsigned inner, unsigned C,
                                                                   const float* __restrict__ interval,
                                                                   unsigned long long* __restrict__ hist_row,
                                                                   float* __restrict__ relu_out, const int allow_fast) {
-    __shared__ unsigned int s_bins[FQ_BINS + kWave];
-    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kOpsBlock) s_bins[b] = 0u;
-    __syncthreads();
+    unsigned int* s_bins = hist_lds_zeroed();
     const float iv = *interval;
-    if (allow_fast && fast_quotient_ok(iv)) bias_add_hist_body<kVec, true>(y, bias, n_items, inner, C, iv, s_bins, relu_out);
-    else bias_add_hist_body<kVec, false>(y, bias, n_items, inner, C, iv, s_bins, relu_out);
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (allow_fast && fast_quotient_ok(iv)) {
+        HistStat<true> st{s_bins, park, iv, 1.0f / iv};
+        bias_add_body<kVec, kStream>(y, bias, n_items, inner, C, relu_out, st);
+    } else {
+        HistStat<false> st{s_bins, park, iv, 1.0f / iv};
+        bias_add_body<kVec, kStream>(y, bias, n_items, inner, C, relu_out, st);
+    }
     hist_flush(s_bins, hist_row);
 }
 
-template <bool kFast>
-__device__ __forceinline__ void add_hist_body(const f4v* __restrict__ x, const f4v* __restrict__ y, f4v* __restrict__ z,
-                                              size_t nvec, const float* __restrict__ xs, const float* __restrict__ ys,
-                                              float* __restrict__ zs, unsigned tail, float iv, unsigned int* s_bins,
-                                              float* __restrict__ relu_out) {
-    const float yr = 1.0f / iv;
-    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
-    auto count = [&](float v) { atomicAdd((v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, yr)) : park, 1u); };
-    const size_t stride = (size_t)gridDim.x * kOpsBlock;
-    for (size_t i = (size_t)blockIdx.x * kOpsBlock + threadIdx.x; i < nvec; i += stride) {
-        const f4v v = x[i] + y[i];
-        z[i] = v;
-        if (relu_out) {
-            f4v r;
-            r.x = relu_like_torch(v.x); r.y = relu_like_torch(v.y); r.z = relu_like_torch(v.z); r.w = relu_like_torch(v.w);
-            reinterpret_cast<f4v*>(relu_out)[i] = r;
-        }
-        count(v.x); count(v.y); count(v.z); count(v.w);
-    }
-    if (blockIdx.x == 0 && threadIdx.x < tail) {          // the last n % 4 elements
-        const float v = xs[threadIdx.x] + ys[threadIdx.x];
-        zs[threadIdx.x] = v;
-        if (relu_out) relu_out[(nvec << 2) + threadIdx.x] = relu_like_torch(v);
-        count(v);
-    }
+template <bool kStream>
+__global__ __launch_bounds__(kOpsBlock) void add_absmax_kernel(const f4v* __restrict__ x, const f4v* __restrict__ y,
+                                                               f4v* __restrict__ z, size_t nvec, const float* __restrict__ xs,
+                                                               const float* __restrict__ ys, float* __restrict__ zs, unsigned tail,
+                                                               unsigned int* __restrict__ max_bits, float* __restrict__ relu_out) {
+    MaxStat st;
+    add_body<kStream>(x, y, z, nvec, xs, ys, zs, tail, relu_out, st);
+    publish_max(st.m, max_bits);
 }
 
+template <bool kStream>
 __global__ __launch_bounds__(kOpsBlock) void add_hist_kernel(const f4v* __restrict__ x, const f4v* __restrict__ y,
                                                              f4v* __restrict__ z, size_t nvec, const float* __restrict__ xs,
                                                              const float* __restrict__ ys, float* __restrict__ zs, unsigned tail,
                                                              const float* __restrict__ interval,
                                                              unsigned long long* __restrict__ hist_row,
                                                              float* __restrict__ relu_out, const int allow_fast) {
-    __shared__ unsigned int s_bins[FQ_BINS + kWave];
-    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kOpsBlock) s_bins[b] = 0u;
-    __syncthreads();
+    unsigned int* s_bins = hist_lds_zeroed();
     const float iv = *interval;
-    if (allow_fast && fast_quotient_ok(iv)) add_hist_body<true>(x, y, z, nvec, xs, ys, zs, tail, iv, s_bins, relu_out);
-    else add_hist_body<false>(x, y, z, nvec, xs, ys, zs, tail, iv, s_bins, relu_out);
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (allow_fast && fast_quotient_ok(iv)) {
+        HistStat<true> st{s_bins, park, iv, 1.0f / iv};
+        add_body<kStream>(x, y, z, nvec, xs, ys, zs, tail, relu_out, st);
+    } else {
+        HistStat<false> st{s_bins, park, iv, 1.0f / iv};
+        add_body<kStream>(x, y, z, nvec, xs, ys, zs, tail, relu_out, st);
+    }
     hist_flush(s_bins, hist_row);
 }
 
@@ -474,6 +498,15 @@ extern "C" int fq_recon_epilogue_f32(const float* acc, const float* qbias, float
     return FQ_OK;
 }
 
+// Workgroups per CU of the streaming form, measured on the ResNet-50 calibration at batch 256 (aggregate TB/s over all
+// launches of a forward, 8 / 16 / 32 / 64 per CU): bias add + abs-max 5.31 / 5.20 / 5.48 / 5.65, residual add + abs-max
+// 5.29 / 5.11 / 5.33 / 5.60 (more is better: nothing is flushed), bias add + histogram 4.75 / 4.26 / 3.32 / 2.09, residual
+// add + histogram 5.14 / 4.85 / 4.65 / 3.41 (every workgroup flushes up to 2048 bins).  FQ_PRODUCER_WG_PER_CU overrides all four.
+static int producer_wg_per_cu(int dflt) {
+    static const int v = [] { const char* e = getenv("FQ_PRODUCER_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    return v > 0 ? v : dflt;
+}
+
 extern "C" int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C, int HW, float* max_inout, float* relu_out,
                                       fq_stream_t stream) {
     using namespace fq;
@@ -484,12 +517,17 @@ extern "C" int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C,
     if (n >= 0xffffffffULL) return FQ_ERR_UNSUPPORTED;               // 32-bit element index inside the kernel
     hipStream_t st = as_stream(stream);
     unsigned int* bits = reinterpret_cast<unsigned int*>(max_inout);
+    const bool stream_form = n * (relu_out ? 12 : 8) > kStreamBytes;
     if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(relu_out)) & 15u) == 0) {
         const unsigned nvec = (unsigned)(n >> 2);
-        hipLaunchKernelGGL(bias_add_absmax_kernel<true>, dim3(grid_for(nvec, 8)), dim3(kOpsBlock), 0, st, y, bias, nvec,
-                           (unsigned)(HW >> 2), (unsigned)C, bits, relu_out);
+        if (stream_form)
+            hipLaunchKernelGGL((bias_add_absmax_kernel<true, true>), dim3(grid_for(nvec, producer_wg_per_cu(64))), dim3(kOpsBlock), 0, st,
+                               y, bias, nvec, (unsigned)(HW >> 2), (unsigned)C, bits, relu_out);
+        else
+            hipLaunchKernelGGL((bias_add_absmax_kernel<true, false>), dim3(grid_for(nvec, 8)), dim3(kOpsBlock), 0, st, y, bias, nvec,
+                               (unsigned)(HW >> 2), (unsigned)C, bits, relu_out);
     } else {
-        hipLaunchKernelGGL(bias_add_absmax_kernel<false>, dim3(grid_for(n, 8)), dim3(kOpsBlock), 0, st, y, bias, (unsigned)n,
+        hipLaunchKernelGGL((bias_add_absmax_kernel<false, false>), dim3(grid_for(n, 8)), dim3(kOpsBlock), 0, st, y, bias, (unsigned)n,
                            (unsigned)HW, (unsigned)C, bits, relu_out);
     }
     FQ_LAUNCH_CHECK();
@@ -506,9 +544,14 @@ extern "C" int fq_add_absmax_f32(const float* x, const float* y, float* z, size_
         return FQ_ERR_INVALID_ARG;
     const size_t nvec = n >> 2;
     const unsigned tail = (unsigned)(n & 3u);
-    hipLaunchKernelGGL(add_absmax_kernel, dim3(grid_for(nvec ? nvec : 1, 8)), dim3(kOpsBlock), 0, as_stream(stream),
-                       reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
-                       x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, reinterpret_cast<unsigned int*>(max_inout), relu_out);
+    if (n * (relu_out ? 16 : 12) > kStreamBytes)
+        hipLaunchKernelGGL(add_absmax_kernel<true>, dim3(grid_for(nvec, producer_wg_per_cu(64))), dim3(kOpsBlock), 0, as_stream(stream),
+                           reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
+                           x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, reinterpret_cast<unsigned int*>(max_inout), relu_out);
+    else
+        hipLaunchKernelGGL(add_absmax_kernel<false>, dim3(grid_for(nvec ? nvec : 1, 8)), dim3(kOpsBlock), 0, as_stream(stream),
+                           reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
+                           x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, reinterpret_cast<unsigned int*>(max_inout), relu_out);
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }
@@ -530,10 +573,14 @@ extern "C" int fq_bias_add_hist_f32(float* y, const float* bias, int N, int C, i
     unsigned long long* h = reinterpret_cast<unsigned long long*>(hist_row);
     if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(relu_out)) & 15u) == 0) {
         const unsigned nvec = (unsigned)(n >> 2);
-        hipLaunchKernelGGL(bias_add_hist_kernel<true>, dim3(grid_for(nvec, 2)), dim3(kOpsBlock), 0, st, y, bias, nvec,
-                           (unsigned)(HW >> 2), (unsigned)C, interval, h, relu_out, ops_hist_fast_quotient());
+        if (n * (relu_out ? 12 : 8) > kStreamBytes)
+            hipLaunchKernelGGL((bias_add_hist_kernel<true, true>), dim3(grid_for(nvec, producer_wg_per_cu(8))), dim3(kOpsBlock), 0, st, y, bias,
+                               nvec, (unsigned)(HW >> 2), (unsigned)C, interval, h, relu_out, ops_hist_fast_quotient());
+        else
+            hipLaunchKernelGGL((bias_add_hist_kernel<true, false>), dim3(grid_for(nvec, 2)), dim3(kOpsBlock), 0, st, y, bias, nvec,
+                               (unsigned)(HW >> 2), (unsigned)C, interval, h, relu_out, ops_hist_fast_quotient());
     } else {
-        hipLaunchKernelGGL(bias_add_hist_kernel<false>, dim3(grid_for(n, 2)), dim3(kOpsBlock), 0, st, y, bias, (unsigned)n,
+        hipLaunchKernelGGL((bias_add_hist_kernel<false, false>), dim3(grid_for(n, 2)), dim3(kOpsBlock), 0, st, y, bias, (unsigned)n,
                            (unsigned)HW, (unsigned)C, interval, h, relu_out, ops_hist_fast_quotient());
     }
     FQ_LAUNCH_CHECK();
@@ -550,10 +597,16 @@ extern "C" int fq_add_hist_f32(const float* x, const float* y, float* z, size_t 
         return FQ_ERR_INVALID_ARG;
     const size_t nvec = n >> 2;
     const unsigned tail = (unsigned)(n & 3u);
-    hipLaunchKernelGGL(add_hist_kernel, dim3(grid_for(nvec ? nvec : 1, 2)), dim3(kOpsBlock), 0, as_stream(stream),
-                       reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
-                       x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, interval,
-                       reinterpret_cast<unsigned long long*>(hist_row), relu_out, ops_hist_fast_quotient());
+    if (n * (relu_out ? 16 : 12) > kStreamBytes)
+        hipLaunchKernelGGL(add_hist_kernel<true>, dim3(grid_for(nvec, producer_wg_per_cu(4))), dim3(kOpsBlock), 0, as_stream(stream),
+                           reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
+                           x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, interval,
+                           reinterpret_cast<unsigned long long*>(hist_row), relu_out, ops_hist_fast_quotient());
+    else
+        hipLaunchKernelGGL(add_hist_kernel<false>, dim3(grid_for(nvec ? nvec : 1, 2)), dim3(kOpsBlock), 0, as_stream(stream),
+                           reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
+                           x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, interval,
+                           reinterpret_cast<unsigned long long*>(hist_row), relu_out, ops_hist_fast_quotient());
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }

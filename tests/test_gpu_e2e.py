@@ -381,6 +381,47 @@ def test_bias_add_hist_and_add_hist_kernels_equal_torch_plus_the_oracle_histogra
         np.testing.assert_array_equal(hist.cpu().numpy()[0], 2 * oracle.hist2048(want.cpu().numpy(), np.float32(iv[0].item())))
 
 
+def test_producer_kernels_streaming_form_on_tensors_beyond_the_infinity_cache(oracle):
+    """Launches that move more than 256 MB take the non-temporal form of the four producers (two items in flight per
+    lane, channel index carried incrementally): a 134 M-element conv output with 48 channels (odd channel count against
+    the grid stride) and a 100 M-element residual add -- outputs equal torch's, maxima exact, histograms the oracle's."""
+    from common.quantity import _native
+    g = torch.Generator(device="cuda").manual_seed(77)
+    N, C, H, W = 2, 48, 1168, 1200
+    y0 = torch.randn(N, C, H, W, generator=g, device="cuda")
+    b = torch.randn(C, generator=g, device="cuda")
+    want = y0 + b.view(1, -1, 1, 1)
+    for relu in (False, True):
+        y = y0.clone()
+        r = torch.empty_like(y) if relu else None
+        mx = torch.zeros(2, device="cuda")
+        _native.bias_add_absmax(y, b, mx, 1, relu_out=r)
+        assert torch.equal(y, want) and float(mx[1]) == float(want.abs().max()) and float(mx[0]) == 0.0
+        assert r is None or torch.equal(r, torch.relu(want))
+        del y, r
+    iv = torch.tensor([float(oracle.interval(np.float32(want.abs().max().item())))], device="cuda")
+    hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+    y = y0.clone()
+    r = torch.empty_like(y)
+    _native.bias_add_hist(y, b, iv, hist, 0, relu_out=r)
+    assert torch.equal(y, want) and torch.equal(r, torch.relu(want))
+    np.testing.assert_array_equal(hist.cpu().numpy()[0], oracle.hist2048(want.cpu().numpy().ravel(), np.float32(iv[0].item())))
+    del y, r, y0
+    n = 100_000_003
+    xa = torch.randn(n, generator=g, device="cuda")
+    xb = torch.randn(n, generator=g, device="cuda")
+    want = xa + xb
+    mx = torch.zeros(1, device="cuda")
+    r = torch.empty_like(xa)
+    z = _native.add_absmax(xa, xb, mx, 0, relu_out=r)
+    assert torch.equal(z, want) and torch.equal(r, torch.relu(want)) and float(mx[0]) == float(want.abs().max())
+    hist.zero_()
+    iv[0] = float(oracle.interval(np.float32(mx[0].item())))
+    z = _native.add_hist(xa, xb, iv, hist, 0, out=xa)                                # in place over x, as Eltwise may be called
+    assert torch.equal(z, want)
+    np.testing.assert_array_equal(hist.cpu().numpy()[0], oracle.hist2048(want.cpu().numpy(), np.float32(iv[0].item())))
+
+
 def test_fused_pass2_histograms_do_not_change_the_tables(g3, monkeypatch):
     """Pass 2 re-computes activations and either hands them to fq_hist2048_seg or lets their producers histogram them on
     the way out (Quantity.fuse_hist): the reference's feat.table both ways, every conv / Eltwise of the model fused
