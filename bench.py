@@ -489,13 +489,20 @@ def main():
         cold = run_cold_child(args, log)
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one process per GPU.  (Dry run of the N > 1 flow on a single-GPU box: FQ_BENCH_BACKEND=gloo lets two ranks share
+    # device 0 -- RCCL refuses duplicate devices -- with FQ_BENCH_POOL_FRAC sizing each rank's warm pool.)
+    backend = os.environ.get("FQ_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     import torch.distributed as dist
     distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ      # launched by torch.distributed.run
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)                  # backend nccl = RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)              # backend nccl = RCCL on ROCm
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         torch.cuda.synchronize()
@@ -517,7 +524,7 @@ def main():
 
     # ---- warmup: W batches per GPU through the same path (MIOpen first-use solver search, RCCL init, code load)
     if W > 0:
-        make_workdir(W * world - 1, shape, local_rank)
+        make_workdir(W * world - 1, shape, dev_index)
         warm = DeviceBatches(W * world, B, HW, rank, world, device)
         wq = Quantity(model)
         wq.activation_quantize(warm)
@@ -530,7 +537,8 @@ def main():
         if grow > 0 and "FQ_ACT_CACHE_GB" not in os.environ:
             free_b, total_b = torch.cuda.mem_get_info()
             pooled_b = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
-            grow = max(grow, min(int(total_b * 0.80) - torch.cuda.memory_allocated(), free_b + pooled_b - (8 << 30)))
+            frac = float(os.environ.get("FQ_BENCH_POOL_FRAC", "0.80"))
+            grow = max(grow, min(int(total_b * frac) - torch.cuda.memory_allocated(), free_b + pooled_b - (8 << 30)))
         if grow > 0:
             pool = torch.empty(grow, dtype=torch.uint8, device=device)
             del pool
@@ -538,7 +546,7 @@ def main():
     barrier()
 
     # ---- timed: K batches per GPU
-    make_workdir(K * world - 1, shape, local_rank)
+    make_workdir(K * world - 1, shape, dev_index)
     data = DeviceBatches(K * world, B, HW, rank, world, device, on_host=args.host_inputs)
     q = Quantity(model)
     q.profile_phases = True
@@ -612,10 +620,13 @@ def main():
 
     # ---- pass 1's statistics ride on the producers' own kernels: their rooflines, measured on three more batches of
     # the same shape after the timed region (events around every one of the ~70 launches per forward would perturb it)
+    # (one GPU only: the calibration below ends in the two all-reduces, and no collective may sit inside a try)
     try:
+        if world != 1:
+            raise RuntimeError("producer rooflines are measured at N = 1")
         with CallTimer(_native, "bias_add_absmax", _bias_add_bytes) as kt_b, CallTimer(_native, "add_absmax", _add_bytes) as kt_a, \
                 CallTimer(_native, "bias_add_hist", _bias_add_bytes) as kt_bh, CallTimer(_native, "add_hist", _add_bytes) as kt_ah:
-            make_workdir(3 * world - 1, shape, local_rank)
+            make_workdir(3 * world - 1, shape, dev_index)
             extra = DeviceBatches(3 * world, B, HW, rank, world, device)
             eq = Quantity(model)
             eq._activation_cache_budget = lambda: 0          # every batch through the second forward: all 69 producers fused
@@ -638,7 +649,8 @@ def main():
             if sm:
                 result[key] = hbm_roofline(kernel, sm, {"note": note, "aggregate_gbs": round(sm["gbs"], 1)})
     except Exception as e:
-        result["roofline_bias_add_absmax"] = {"error": repr(e)}
+        if world == 1:
+            result["roofline_bias_add_absmax"] = {"error": repr(e)}
 
     # ---- the fused fake-quant kernel on its own (north_star: >= 60 % of the HBM roofline)
     try:
@@ -777,7 +789,7 @@ def main():
         try:
             n_pc = max(1, min(K, 1024 // B if B <= 1024 else 1))
             pc_data = [(b, 0) for b in data.owned()[:n_pc]]
-            make_workdir(len(pc_data) - 1, shape, local_rank)
+            make_workdir(len(pc_data) - 1, shape, dev_index)
             pq = Quantity(model)
             with CallTimer(_native, "hist2048_chan", _seg_bytes) as kt_pc:
                 kt_pc.enabled = True
