@@ -96,9 +96,13 @@ class _EagerStats(object):
         if self.bytes >= self.limit:
             self.flush()
 
+    retain = True      # False: tensors served by their producers are not kept alive by this object (no cache wanted)
+
     def note(self, key, t):
-        """A tensor whose statistics were already taken by its producer: only watched for in-place consumers."""
-        self.seen.append((key, t, t._version))
+        """A tensor whose statistics were already taken by its producer: only watched for in-place consumers (the first
+        forward of a calibration decides that; later forwards with `retain` off do not even hold a reference)."""
+        if self.retain:
+            self.seen.append((key, t, t._version))
 
     def flush(self, extra=None):
         """Hand the pending tensors (plus `extra`: tensors kept from an earlier forward) to fn in one call."""
@@ -536,6 +540,7 @@ class Quantity(object):
             self._on_stat_stream(fn, feats)
             return None
         eager = _EagerStats(fn, limit)
+        eager.retain = self._hook_ctl.get("keep_feats", True)
         self._hook_ctl["eager"] = eager
         try:
             self.net_forward(self.model, item)
@@ -715,6 +720,8 @@ class Quantity(object):
                 self._sync()
                 step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
             if not budget:
+                if eager is not None and inplace is False:
+                    ctl["keep_feats"] = False       # nothing will be cached: producers' tensors need not outlive their hook
                 continue
             if plan is None:
                 cum_ms = {}
@@ -916,7 +923,7 @@ class Quantity(object):
         ctl = self._hook_ctl = {"stop_after": None, "events": None, "eager": None, "fuse_bias": None, "fuse_collector": None,
                                 "fuse_off": False, "fuse_verified": set(), "fuse_warm": set(),
                                 "relu_after": {}, "relu_ready": None, "last_out": None, "fused_relus": set(),
-                                "fuse_stat": "max", "hist_fused": 0}
+                                "fuse_stat": "max", "hist_fused": 0, "keep_feats": True}
 
         def on_forward(module, inputs, output):
             eager = ctl["eager"]
@@ -932,12 +939,19 @@ class Quantity(object):
             fused = pending_bias is not None and self._finish_fused_conv(module, pending_bias, key if key in cared else None, output)
             ctl["last_out"] = (module, output) if torch.is_tensor(output) else None
             if key in cared:
-                out_feat[key] = output.detach()
-                if eager is not None:
-                    if fused:
-                        eager.note(key, out_feat[key])
-                    else:
-                        eager.add(key, out_feat[key])
+                if fused and eager is not None and not ctl["keep_feats"]:
+                    # its statistic is taken and nothing will be cached: do not keep the tensor alive until the end of the
+                    # forward (17 GB of references per batch of 256 ResNet-50 images -- in a fresh process that is 30 GB
+                    # of allocator pool the forward would not otherwise need, up to a second of hipMalloc)
+                    out_feat.pop(key, None)
+                    eager.note(key, output)
+                else:
+                    out_feat[key] = output.detach()
+                    if eager is not None:
+                        if fused:
+                            eager.note(key, out_feat[key])
+                        else:
+                            eager.add(key, out_feat[key])
                 if ctl["events"] is not None:                 # time stamps of one forward, for the cache plan
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record()
