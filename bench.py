@@ -16,9 +16,9 @@ synthetic fp32 images generated on the device BEFORE the timed region.  value = 
 time (max over ranks, bracketed by barrier + synchronize).
 
 The JSON line also carries
-  value_cold   : the same workload in a FRESH process whose allocator pool is empty when the clock starts (the engine's
-                 96 GB cold-process cache rule, every hipMalloc inside the clock) -- what a one-shot calibration script
-                 gets; `value` itself runs in a process that holds a warm pool (a long-running calibration service);
+  value_cold   : the same workload in a FRESH process whose allocator pool is empty when the clock starts (no activation
+                 cache: the engine never grows its pool for one; every hipMalloc inside the clock) -- what a one-shot
+                 calibration script gets; `value` itself runs in a process that holds a warm pool (a long-running calibration service);
   roofline     : the dominant hand-written kernel (hist2048_seg), algorithmic bytes (4 B x elements per launch) / its
                  mean launch duration measured with HIP events on the launch stream inside the timed region;
                  `traffic` is STATIC (PMC counters of the committed profile of this configuration), and says so;
@@ -405,8 +405,8 @@ def parse_args():
 def cold_child(args):
     """Fresh process, N = 1: (1) the very first activation_quantize() of the process, nothing warmed up at all (MIOpen's
     first-use solver search and code loading inside the clock): `one_shot_images_per_s`; (2) the allocator pool handed
-    back to the driver (empty_cache), then the same workload again: every hipMalloc inside the clock, the engine's
-    cold-process cache rule (96 GB), code and MIOpen warm: `value_cold`.  Prints one JSON line."""
+    back to the driver (empty_cache), then the same workload again: every hipMalloc inside the clock, no activation
+    cache (the engine never grows its pool for one), code and MIOpen warm: `value_cold`.  Prints one JSON line."""
     sys.stdout.flush()
     stdout_fd = os.dup(1)
     os.dup2(os.open(os.devnull, os.O_WRONLY), 1)
@@ -532,16 +532,16 @@ def main():
         # Size the caching allocator's pool for the device before the clock starts: 80 % of HBM (288 GB per MI355X),
         # as a long-running calibration service would hold it.  The timed region then keeps pass 1's activations for
         # pass 2 in that pool (phases_s.cache_bytes) instead of paying 10-30 ms per GB of fresh hipMalloc; what a cold
-        # one-shot process gets (the engine's 96 GB rule, allocation inside the clock) is `value_cold`.
-        grow = wq._activation_cache_budget()
-        if grow > 0 and "FQ_ACT_CACHE_GB" not in os.environ:
+        # one-shot process gets (no cache: the engine never grows its pool for one; allocation inside the clock) is
+        # `value_cold`.
+        if "FQ_ACT_CACHE_GB" not in os.environ:
             free_b, total_b = torch.cuda.mem_get_info()
             pooled_b = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
             frac = float(os.environ.get("FQ_BENCH_POOL_FRAC", "0.80"))
-            grow = max(grow, min(int(total_b * frac) - torch.cuda.memory_allocated(), free_b + pooled_b - (8 << 30)))
-        if grow > 0:
-            pool = torch.empty(grow, dtype=torch.uint8, device=device)
-            del pool
+            grow = min(int(total_b * frac) - torch.cuda.memory_allocated(), free_b + pooled_b - (8 << 30))
+            if grow > 0:
+                pool = torch.empty(grow, dtype=torch.uint8, device=device)
+                del pool
         del wq
     barrier()
 
