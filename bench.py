@@ -596,7 +596,7 @@ def main():
         if "cold" in cold:
             result["value_cold"] = cold["cold"]["images_per_s"]
             result["cold_process"] = {"what": "fresh process, N=1, same workload; value_cold: allocator pool empty when the clock "
-                                              "starts (code + MIOpen warm from the process's first run), engine's 96 GB cold rule; "
+                                              "starts (code + MIOpen warm from the process's first run), no activation cache; "
                                               "one_shot: the process's very first call, nothing warmed (MIOpen first-use solver "
                                               "search, code load and allocation inside the clock)",
                                       "cold": cold["cold"], "one_shot": cold.get("one_shot"),
