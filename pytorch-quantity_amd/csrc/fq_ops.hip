@@ -499,8 +499,8 @@ extern "C" int fq_recon_epilogue_f32(const float* acc, const float* qbias, float
 }
 
 // Workgroups per CU of the streaming form, measured on the ResNet-50 calibration at batch 256 (aggregate TB/s over all
-// launches of a forward, 8 / 16 / 32 / 64 per CU): bias add + abs-max 5.31 / 5.20 / 5.48 / 5.65, residual add + abs-max
-// 5.29 / 5.11 / 5.33 / 5.60 (more is better: nothing is flushed), bias add + histogram 4.75 / 4.26 / 3.32 / 2.09, residual
+// launches of a forward, 8 / 16 / 32 / 64 / 128 / 256 per CU): bias add + abs-max 5.31 / 5.20 / 5.48 / 5.65 / 5.61 / 5.71, residual
+// add + abs-max 5.29 / 5.11 / 5.33 / 5.60 / 5.82 / 5.98 (more is better: nothing is flushed), bias add + histogram (8 .. 64) 4.75 / 4.26 / 3.32 / 2.09, residual
 // add + histogram 5.14 / 4.85 / 4.65 / 3.41 (every workgroup flushes up to 2048 bins).  FQ_PRODUCER_WG_PER_CU overrides all four.
 static int producer_wg_per_cu(int dflt) {
     static const int v = [] { const char* e = getenv("FQ_PRODUCER_WG_PER_CU"); return e ? atoi(e) : 0; }();
@@ -521,7 +521,7 @@ extern "C" int fq_bias_add_absmax_f32(float* y, const float* bias, int N, int C,
     if ((HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(relu_out)) & 15u) == 0) {
         const unsigned nvec = (unsigned)(n >> 2);
         if (stream_form)
-            hipLaunchKernelGGL((bias_add_absmax_kernel<true, true>), dim3(grid_for(nvec, producer_wg_per_cu(64))), dim3(kOpsBlock), 0, st,
+            hipLaunchKernelGGL((bias_add_absmax_kernel<true, true>), dim3(grid_for(nvec, producer_wg_per_cu(256))), dim3(kOpsBlock), 0, st,
                                y, bias, nvec, (unsigned)(HW >> 2), (unsigned)C, bits, relu_out);
         else
             hipLaunchKernelGGL((bias_add_absmax_kernel<true, false>), dim3(grid_for(nvec, 8)), dim3(kOpsBlock), 0, st, y, bias, nvec,
@@ -545,7 +545,7 @@ extern "C" int fq_add_absmax_f32(const float* x, const float* y, float* z, size_
     const size_t nvec = n >> 2;
     const unsigned tail = (unsigned)(n & 3u);
     if (n * (relu_out ? 16 : 12) > kStreamBytes)
-        hipLaunchKernelGGL(add_absmax_kernel<true>, dim3(grid_for(nvec, producer_wg_per_cu(64))), dim3(kOpsBlock), 0, as_stream(stream),
+        hipLaunchKernelGGL(add_absmax_kernel<true>, dim3(grid_for(nvec, producer_wg_per_cu(256))), dim3(kOpsBlock), 0, as_stream(stream),
                            reinterpret_cast<const f4v*>(x), reinterpret_cast<const f4v*>(y), reinterpret_cast<f4v*>(z), nvec,
                            x + (nvec << 2), y + (nvec << 2), z + (nvec << 2), tail, reinterpret_cast<unsigned int*>(max_inout), relu_out);
     else
