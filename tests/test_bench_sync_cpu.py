@@ -66,3 +66,23 @@ def test_bench_recon_section_helpers_keep_two_ranks_in_step(tmp_path):
     assert r1["one_fails"][1] is None and "boom on rank 1" in r1["one_fails"][2]
     assert r0["none_fails"] == [True, 10, None] and r1["none_fails"] == [True, 11, None]
     assert r0["all_ok"] == [True, False] and r1["all_ok"] == [True, False]
+
+
+@pytest.mark.parametrize("argv,per_gpu,batch,scaling", [
+    ([], 5120, 256, "weak"),                                        # the default: BASELINE configs[1], 20 steps
+    (["--steps", "20", "--warmup", "5"], 5120, 256, "weak"),        # the driver's command: same 5 120 images
+    (["--steps", "40"], 5120, 128, "weak"),                         # --steps only cuts the same images differently
+    (["--steps", "10", "--images", "1000"], 1000, 100, "weak"),
+    (["--gpus", "8", "--total-images", "50000"], 6260, 313, "strong"),      # config 4: 50 000 / 8 = 6 250 -> 313 x 20
+    (["--gpus", "2", "--total-images", "1024", "--steps", "2"], 512, 256, "strong"),
+    (["--batch", "64", "--steps", "4"], 256, 64, "weak"),
+])
+def test_bench_workload_arithmetic(monkeypatch, argv, per_gpu, batch, scaling):
+    """`--steps` must not change the workload (round-1 review): images per GPU come from --images / --total-images, the
+    batch follows from them."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(sys, "argv", ["bench.py"] + argv)
+    args = bench.parse_args()
+    assert (args.images_per_gpu, args.batch, args.scaling) == (per_gpu, batch, scaling)
+    assert args.images_per_gpu == args.batch * args.steps
