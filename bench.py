@@ -30,6 +30,7 @@ The JSON line also carries
                  bit-identical to the fp32-boundary model in the same run, see int8_sim_resident);
   int8_sim_fp32_boundary_images_per_s : the same ReconModel with the reference's fp32 NCHW module boundaries;
   int8_sim_hipgraph_images_per_s : the resident forward replayed as one HIP graph (input copy included);
+  int8_sim_dual_graph_images_per_s : the same batch as two graphs of half the images replayed on two streams;
   roofline_int8_conv : 2 x MACs of the model / summed durations of the int8 conv launches of one resident forward
                  (HIP events), against the 5 000 TOP/s dense int8 MFMA peak;
   fakequant_images_per_s / float_forward_images_per_s : ReconTest and the float model;
@@ -766,6 +767,19 @@ def main():
                     elif err_g:
                         result["int8_sim_hipgraph_error"] = err_g
                     del graphed
+
+                    def dual_graph():              # the same batch as two graphs of FB / 2 images on two streams
+                        g2 = resident.capture(int8_net, batches[0], streams=2)
+                        with torch.no_grad():
+                            if not torch.equal(g2(batches[0]), res[0]):
+                                raise RuntimeError("two-stream graph replay differs from the eager forward")
+                        return g2
+                    ok_d, dual, err_d = run_section(dual_graph, device) if FB % 2 == 0 else (False, None, None)
+                    if ok_d:
+                        result["int8_sim_dual_graph_images_per_s"] = fwd_rate(dual, 8)
+                    elif err_d:
+                        result["int8_sim_dual_graph_error"] = err_d
+                    del dual
                 else:
                     result["int8_sim_images_per_s"] = result.get("int8_sim_fp32_boundary_images_per_s")
                     if err_r:

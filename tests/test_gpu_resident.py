@@ -349,6 +349,12 @@ def test_r50_resident_equals_fp32_boundary_model():
         with torch.no_grad():
             want2 = net(x2)
         assert torch.equal(graphed(x2), want2)
+        # ... and as two graphs of half the batch replayed on two streams (the kernels of one half start while the other
+        # half's drain): same logits, also on another input
+        dual = resident.capture(net, x, streams=2)
+        assert torch.equal(dual(x), plain) and torch.equal(dual(x2), want2) and torch.equal(dual(x), plain)
+        with pytest.raises(Exception):
+            resident.capture(net, x[:3], streams=2)
         # a handle that reaches code outside the plan fails loudly instead of computing garbage
         with pytest.raises(Exception):
             torch.relu(stage)
