@@ -513,11 +513,12 @@ class GraphedForward(object):
 class MultiStreamGraphs(object):
     """One batch as S HIP graphs of batch / S images replayed on S streams.
 
-    At these layer sizes a kernel of the integer-simulation forward runs for 20-60 us, of which ~9 us are ramp-up and
-    drain (an almost empty launch of the conv kernel takes 9.5 us back to back, scripts/dual_graph_probe.py); kernels of
-    ONE stream run strictly one after the other, so that part is paid 54 times per forward.  Two independent halves of the
-    batch on two streams let one half's kernels start while the other half's drain: ResNet-50, 256 images, 3.21 ms as one
-    graph -> 2.99 ms as two graphs of 128 (79 800 -> 85 700 images/s; 512 images: 84 200 -> 90 500).  Three or four
+    At these layer sizes a kernel of the integer-simulation forward runs for 20-60 us, of which a third does not scale
+    with the reduction depth (prologue, epilogue, the half-empty last round of workgroups, drain:
+    profiles/r02d_conv_loop_ablation.txt); kernels of ONE stream run strictly one after the other, so that part is exposed
+    54 times per forward.  Two independent halves of the batch on two streams let one half's kernels fill the CUs the other
+    half's tail leaves idle: ResNet-50, 256 images, 3.21 ms as one graph -> 2.99 ms as two graphs of 128 (79 800 -> 85 700
+    images/s; 512 images: 84 200 -> 90 500).  Three or four
     streams are slower again (the kernels get too small).  Same logits: every image goes through the same kernels."""
 
     def __init__(self, model, example_input, streams=2, warmup=2):
