@@ -692,7 +692,6 @@ class Quantity(object):
         budget = self._activation_cache_budget()
         eager_ok = (self.device == "gpu" and torch.cuda.is_available() and not self.overlap_streams
                     and getattr(collector, "supports_partial", False))
-        # first forward: one launch per tensor (always correct); it also tells whether grouping and caching are safe
         self._stats_limit = None if not eager_ok else 0
         n_owned = None
         if hasattr(images_files, "__len__") and hasattr(images_files, "__getitem__"):
@@ -701,7 +700,31 @@ class Quantity(object):
         plan = None
         cached, cached_ids, used = {}, set(), 0
         step_ms = []
-        inplace = None                          # does a later module overwrite a hooked tensor?  (known after one forward)
+        inplace = None                          # does a later module overwrite a hooked tensor?
+        if eager_ok:
+            # One probe forward on a random input of INPUT_SHAPE (what build_net_structure traces with; nothing is taken
+            # from it) answers that BEFORE the first calibration batch: the first batch then already runs in its final
+            # mode -- in particular, when nothing will be cached, without the hooks keeping a batch's 17 GB of tensors
+            # alive (a fresh process would grow its allocator pool for them: up to 0.6 s of hipMalloc).
+            probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
+            ctl["eager"] = probe
+            try:
+                dev = self._model_device(self.model)
+                shapes = [self.input_size] if isinstance(self.input_size, tuple) else list(self.input_size)
+                with torch.no_grad():
+                    self.model(*[torch.rand(*s_, device=dev) for s_ in shapes])
+            finally:
+                ctl["eager"] = None
+            inplace = bool(probe.modified())
+            del probe
+            named_feats.clear()
+            if inplace:
+                budget = 0                      # kept tensors would hold overwritten values: no cache, per-tensor launches
+                self._stats_limit = 0
+            else:
+                self._stats_limit = _AFTER_FORWARD if self.stats_group_bytes is None else int(self.stats_group_bytes)
+                if not budget:
+                    ctl["keep_feats"] = False   # nothing will be cached: producers' tensors need not outlive their hook
         ctl["fuse_collector"] = collector if eager_ok and self.fuse_bias_absmax else None
         for i, item in self._device_items(images_files):
             ts = time.perf_counter()
@@ -709,19 +732,11 @@ class Quantity(object):
                 start = torch.cuda.Event(enable_timing=True)
                 start.record()
                 ctl["events"] = []
-            eager = self._forward_with_stats(item, collector.refresh_max_val, named_feats)
-            if eager is not None and inplace is None:
-                inplace = bool(eager.modified())
-                if inplace:
-                    budget = 0                  # kept tensors would hold overwritten values: no cache, per-tensor launches
-                else:
-                    self._stats_limit = _AFTER_FORWARD if self.stats_group_bytes is None else int(self.stats_group_bytes)
+            self._forward_with_stats(item, collector.refresh_max_val, named_feats)
             if os.environ.get("FQ_DEBUG_STEP_TIMES"):
                 self._sync()
                 step_ms.append(round((time.perf_counter() - ts) * 1e3, 2))
             if not budget:
-                if eager is not None and inplace is False:
-                    ctl["keep_feats"] = False       # nothing will be cached: producers' tensors need not outlive their hook
                 continue
             if plan is None:
                 cum_ms = {}
