@@ -1,0 +1,83 @@
+"""The RCCL path on hardware, as far as one GPU allows: a single-rank `nccl` process group (torch.distributed backend nccl IS
+RCCL on ROCm) around the product's calibration -- init with device_id, the MAX all-reduce of the fp32 maxima and the SUM
+all-reduce of the int64 histograms on the DEVICE buffers (common/quantity/_collectives.py), rank-0 file writing -- must give
+the reference's ResNet-18 tables; and bench.py's own multi-rank plumbing (barriers, table broadcast, agreement all-reduces)
+must run to its JSON line under the same launcher.  World sizes > 1 are covered on CPU with gloo (tests/test_distributed_cpu.py,
+tests/test_bench_sync_cpu.py); no multi-GPU box was available.   pytest -m gpu"""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path[:0] = [r"{root}", r"{root}/pytorch-quantity_amd/quantity", r"{root}/tests", r"{root}/tests/golden"]
+    import torch, torch.distributed as dist
+    import cases
+    from workdir_util import product_workdir
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_18_fabu import ResNet18
+    from tools import Quantity
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    calls, real = [], dist.all_reduce
+    def counted(t, op=dist.ReduceOp.SUM, **kw):
+        calls.append([str(op).split(".")[-1], str(t.dtype), t.device.type, t.numel()])
+        return real(t, op=op, **kw)
+    dist.all_reduce = counted
+    with product_workdir(device="gpu", max_cali_img_num=1) as tmp:
+        q = Quantity(merge_bn(cases.seed_model(ResNet18()).eval()).cuda())
+        q.activation_quantize(cases.calib_batches(3, (4, 3, 32, 32)))
+        out = {{"table": open(os.path.join(tmp, "test", "workdir", "feat.table")).read(),
+               "calls": list(calls)}}
+        by_module = q.activation_quantize_per_channel(cases.calib_batches(3, (4, 3, 32, 32)))
+        out["per_channel"] = {{k: [int(b) for b in v] for k, v in by_module.items()}}
+    dist.barrier()
+    json.dump(out, open(r"{out}", "w"))
+    dist.destroy_process_group()
+''')
+
+
+def _torchrun(args, port, timeout=1100):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.timeout(1200)
+def test_single_rank_rccl_calibration_gives_the_reference_tables(tmp_path, golden_dir):
+    with open(os.path.join(golden_dir, "g3_r18_e2e.json")) as fh:
+        g3 = json.load(fh)
+    script, out = str(tmp_path / "worker.py"), str(tmp_path / "rccl.json")
+    with open(script, "w") as fh:
+        fh.write(WORKER.format(root=ROOT, out=out))
+    r = _torchrun([script], 29671)
+    assert r.returncode == 0, r.stderr[-3000:]
+    with open(out) as fh:
+        got = json.load(fh)
+    assert got["table"] == g3["feat_table"]
+    # the two collectives of the per-tensor calibration really ran through RCCL, on the device buffers, one call each
+    assert ["MAX", "torch.float32", "cuda", 30] in got["calls"]
+    assert ["SUM", "torch.int64", "cuda", 30 * 2048] in got["calls"]
+    assert len(got["per_channel"]) == 30 and len(got["per_channel"]["image"]) == 3
+
+
+@pytest.mark.timeout(1200)
+def test_bench_runs_under_the_distributed_launcher_with_rccl():
+    """bench.py exactly as the driver launches it for N > 1, with N = 1: RCCL init, barriers, the MAX of the elapsed times,
+    the table broadcast and the agreement all-reduces of the int8 section all execute; small workload."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--images", "256", "--steps", "2", "--warmup", "1",
+                   "--int8-batch", "64", "--no-cold", "--no-cpu-baseline"], 29672)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["images_total"] == 256
+    assert d["int8_sim_resident"]["bit_identical_logits"] is True and d["int8_sim_images_per_s"] > 0
+    assert "recon_errors" not in d and "recon_error" not in d
