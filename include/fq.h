@@ -185,6 +185,22 @@ int fq_bias_add_hist_f32(float* y, const float* bias, int N, int C, int HW, cons
 int fq_add_hist_f32(const float* x, const float* y, float* z, size_t n, const float* interval, int64_t* hist_row,
                     float* relu_out, fq_stream_t stream);
 
+/* The float 1x1 convolutions of the calibration forward on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32,
+ * an fmaf chain over ci = 0 .. Cin-1), with the statistic the calibration takes of the output folded into the epilogue --
+ * the convolution itself is the producer, so the bias-add pass above disappears for these layers:
+ *   y[n][co][oh][ow] = sum_ci W[co][ci] * x[n][ci][oh*stride][ow*stride] + bias[co]      (padding 0, groups 1)
+ * wt: the weights TRANSPOSED, fp32 [Cin][Cout], 16-byte aligned, Cout % 4 == 0; bias: fp32 [Cout] or NULL;
+ * x: fp32 [N][Cin][Hin][Win] contiguous; y: fp32 [N][Cout][Hout][Wout], Hout = (Hin-1)/stride + 1;
+ * relu_out (may be NULL): max(y, 0) as well (the nn.ReLU behind the convolution);
+ * exactly one of {max_inout, hist_row} may be given (both NULL: plain convolution):
+ *   max_inout: *max_inout = max(*max_inout, max |y|)                 (distribution_collector.py:70-78)
+ *   hist_row + interval: y counted into int64[2048] with bin width *interval   (distribution_collector.py:127-135)
+ * Replaces, inside the float forward the reference runs at pytorch_quantizer.py:288-296, torch's Conv2d for these layers;
+ * not bit-identical to the library's convolution (different, fixed summation order), deterministic from run to run. */
+int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin,
+                   int Win, int Cout, int stride, float* max_inout, const float* interval, int64_t* hist_row,
+                   fq_stream_t stream);
+
 /* Quantity.forward (new_quantity_op.py:52-58) fused with the layout change the MFMA kernel wants:
  *   y[n][hw][c] = (int8) clamp(rint(x[n][c][hw] * 2^ib), -128, 127),  c in [C, Cpad) = 0
  * x: fp32 [N][C][HW] (NCHW), y: int8 [N][HW][Cpad] (NHWC), Cpad >= C, Cpad % 4 == 0 (use a multiple

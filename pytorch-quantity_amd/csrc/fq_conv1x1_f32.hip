@@ -1,0 +1,305 @@
+// fq_conv1x1_f32.hip -- the float 1x1 convolutions of the calibration forward on the fp32 matrix cores, with the
+// calibration's statistic taken in the epilogue.
+//
+// The calibration's wall time is the model's float forward: 36 of ResNet-50's 53 convolutions are
+// 1x1, the library runs them at 43-96 TFLOP/s (157 peak), and every hooked convolution output was then read and written
+// once more by the bias-add producer (fq_bias_add_absmax_f32 / fq_bias_add_hist_f32).  Here the convolution itself is
+// the producer:  y[n][co][p] = sum_ci W[co][ci] * x[n][ci][p*] + bias[co]  with the tensor's abs-max (pass 1,
+// distribution_collector.py:70-78) or 2048-bin histogram (pass 2, distribution_collector.py:127-135) taken while the
+// value is still in the accumulator registers, and the following nn.ReLU's output written by the same epilogue.
+//
+// Mapping.  One GEMM over the whole batch: M = Cout, K = Cin, and the N dimension is the flat list of output positions
+// (image n, pixel p) -- j = n * HWout + p -- so a 7x7 plane costs no padding (12 544 columns for 256 images, not 256 tiles
+// of 49).  NCHW keeps p contiguous for x and y, which is exactly what the f32 MFMA wants: v_mfma_f32_32x32x2_f32 takes
+// B[k][j] with j across lanes 0..31 (a 128-byte run of one input plane) and leaves D[i][j] with j across lanes (a
+// 128-byte run of one output plane).  The weights are passed transposed, Wt[Cin][Cout], so the A operand's tile is
+// k-major with Cout contiguous as well.  A stride-2 convolution (the downsample branches) only changes a column's input
+// offset.
+//
+// Workgroup: 256 threads = 4 waves, tile 128 (Cout) x 128 (columns), K in steps of 16 through two LDS buffers
+// (global -> registers for step s+1 is issued before the MFMAs of step s; one barrier per step).  Each wave owns 64 x 64
+// = 2 x 2 MFMA tiles: per two k it reads 4 dwords from LDS (conflict-free: lanes 0..31 read consecutive words) and issues
+// 4 MFMAs of 64 cycles -- the f32 matrix rate equals the vector rate, so feeding it is cheap and 3-4 workgroups per CU
+// (33-41 KB of LDS each) cover the load latency without deeper pipelining.
+//
+// Numerics: the MFMA is bit for bit an fmaf chain over k = 0 .. Cin-1 from 0 (cdna_hip_programming.md "FP32-input
+// MFMA"), then one rounding for the bias -- "convolution without bias, then the bias add", as torch does it.  It is
+// deterministic (the library's Winograd kernels are not), but it is NOT bit-identical to the library's convolution:
+// the float forward of the drop-in never was bit-identical to the reference's CPU forward either; tables are.
+#include "fq_common.h"
+#include "fq_producer_stat.h"
+
+namespace fq {
+namespace {
+
+constexpr int kT = 256;
+constexpr int kBK = 16;
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+struct C1Args {
+    const float* x;
+    const float* wt;          // [Cin][Cout]
+    const float* bias;        // [Cout] or null
+    float* y;
+    float* relu;              // or null
+    unsigned Cin, Cout, HWin, HWout, Win, Wout, stride;
+    unsigned cols;            // N * HWout
+    unsigned tiles_m, tiles;
+    int stream_stores;
+};
+
+struct NoStat {
+    __device__ __forceinline__ void add(float) {}
+};
+
+// Tile shapes: the 4 waves sit 2 x 2, each owns WM x WN MFMA tiles of 32 x 32 -> the workgroup tile is (64 WM) x (64 WN).
+// <2,2> = 128 x 128 for Cout >= 128; <1,4> = 64 x 256 for the 64-channel layers (no empty half tile).
+template <int WM, int WN>
+struct Shape {
+    static constexpr int BM = 64 * WM, BN = 64 * WN;
+    static constexpr int kXRows = kBK * BN / kT;              // x-tile dwords per thread and K step (column fixed per thread)
+    static constexpr int kXStep = kT / BN > 0 ? kT / BN : 1;  // rows between them (BN = 128: 2; BN = 256: 1)
+    static constexpr int kWVecs = kBK * BM / 4 / kT;          // W-tile float4 per thread and K step
+    static constexpr int kWRowStep = kT / (BM / 4);           // rows between them
+    static constexpr int kFloats = 2 * kBK * (BM + BN) + BM;  // two stages of both tiles + the bias slice
+};
+
+template <int WM, int WN, bool kTailK, typename Stat>
+__device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float* smem) {
+    typedef Shape<WM, WN> S;
+    constexpr int BM = S::BM, BN = S::BN;
+    float* Ws = smem;                                         // [2][kBK][BM]
+    float* Xs = smem + 2 * kBK * BM;                          // [2][kBK][BN]
+    float* s_bias = smem + 2 * kBK * (BM + BN);
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned r = lane & 31u, h = lane >> 5;
+    const unsigned m0 = (wave >> 1) * (32u * WM), n0 = (wave & 1u) * (32u * WN);
+    // Workgroup g runs on XCD g % 8, each with its own L2: give an XCD a contiguous run of tiles, so the m-tiles that
+    // share one x tile (and the column tiles that share one W tile) meet in the same L2.
+    const unsigned G = gridDim.x, G8 = G & ~7u, g = blockIdx.x;
+    const unsigned v0 = g < G8 ? (g & 7u) * (G8 >> 3) + (g >> 3) : g;
+    const unsigned xc = tid % BN, xk = tid / BN;              // x tile: this thread's column, rows xk + kXStep * i
+    const unsigned wr = tid / (BM / 4), wc = (tid % (BM / 4)) * 4u;   // W tile: rows wr + kWRowStep * i, columns wc .. wc + 3
+    const unsigned nk = (a.Cin + kBK - 1) / kBK;
+    const float* __restrict__ xg = a.x;
+    const float* __restrict__ wg = a.wt;
+
+    for (unsigned t = v0; t < a.tiles; t += G) {
+        const unsigned ct = t / a.tiles_m, mt = t - ct * a.tiles_m;
+        const unsigned mbase = mt * BM, jbase = ct * BN;
+        // Loads never leave the tensors: a column past the end re-reads the last one, a W column past Cout the last four
+        // (those accumulators are never stored), so no load is predicated; only a K tail needs zeros.
+        unsigned xoff;
+        {
+            const unsigned j = min(jbase + xc, a.cols - 1u);
+            const unsigned n = j / a.HWout, p = j - n * a.HWout;
+            unsigned pin = p;
+            if (a.stride != 1) {
+                const unsigned oh = p / a.Wout, ow = p - oh * a.Wout;
+                pin = oh * a.stride * a.Win + ow * a.stride;
+            }
+            xoff = n * a.Cin * a.HWin + pin;                  // < 2^32 (checked on the host)
+        }
+        const unsigned woff = min(mbase + wc, a.Cout - 4u);
+        float xr[S::kXRows];
+        f4v wreg[S::kWVecs];
+        auto gload = [&](unsigned kb) {
+#pragma unroll
+            for (int i = 0; i < S::kXRows; ++i) {
+                unsigned k = kb + xk + S::kXStep * i;
+                const bool in = !kTailK || k < a.Cin;
+                if (kTailK) k = min(k, a.Cin - 1u);
+                const float v = xg[xoff + k * a.HWin];
+                xr[i] = in ? v : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < S::kWVecs; ++i) {
+                unsigned k = kb + wr + S::kWRowStep * i;
+                const bool in = !kTailK || k < a.Cin;
+                if (kTailK) k = min(k, a.Cin - 1u);
+                const f4v v = *reinterpret_cast<const f4v*>(wg + (k * a.Cout + woff));
+                wreg[i] = in ? v : f4v{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        auto lstore = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < S::kXRows; ++i) Xs[(buf * kBK + xk + S::kXStep * i) * BN + xc] = xr[i];
+#pragma unroll
+            for (int i = 0; i < S::kWVecs; ++i) *reinterpret_cast<f4v*>(&Ws[(buf * kBK + wr + S::kWRowStep * i) * BM + wc]) = wreg[i];
+        };
+        f16v acc[WM][WN];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+        gload(0);
+        if (tid < (unsigned)BM) s_bias[tid] = (a.bias && mbase + tid < a.Cout) ? a.bias[mbase + tid] : 0.0f;
+        lstore(0);
+        __syncthreads();
+        for (unsigned ks = 0; ks < nk; ++ks) {
+            const int cur = (int)(ks & 1u);
+            const bool more = ks + 1 < nk;
+            if (more) gload((ks + 1) * kBK);
+            const float* wrow = Ws + (cur * kBK + h) * BM + m0 + r;
+            const float* xrow = Xs + (cur * kBK + h) * BN + n0 + r;
+            float fa[2][WM], fb[2][WN];                       // operands of this and of the next k pair
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) fa[0][mi] = wrow[32 * mi];
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) fb[0][ni] = xrow[32 * ni];
+#pragma unroll
+            for (int kk = 0; kk < kBK; kk += 2) {
+                const int c = (kk >> 1) & 1, nx = c ^ 1;
+                if (kk + 2 < kBK) {
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) fa[nx][mi] = wrow[(kk + 2) * BM + 32 * mi];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) fb[nx][ni] = xrow[(kk + 2) * BN + 32 * ni];
+                }
+                __builtin_amdgcn_sched_barrier(0);            // keep the next pair's LDS reads ahead of these MFMAs
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][mi], fb[c][ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (more) lstore(cur ^ 1);
+            __syncthreads();
+        }
+        // epilogue: D[i][j] has j = lane & 31 and i = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+        float* __restrict__ yg = a.y;
+        float* __restrict__ rg = a.relu;
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const unsigned jn = jbase + n0 + 32u * ni + r;
+            if (jn < a.cols) {
+                const unsigned n = jn / a.HWout, p = jn - n * a.HWout;
+                const unsigned col = n * a.Cout * a.HWout + p + (mbase + m0 + 4u * h) * a.HWout;   // < 2^32 (host check)
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const unsigned dm = 32u * mi + (e & 3) + 8u * (e >> 2);           // compile-time row within the wave tile
+                        if (mbase + m0 + 4u * h + dm < a.Cout) {
+                            const float val = acc[mi][ni][e] + s_bias[m0 + 4u * h + dm];
+                            const unsigned o = col + dm * a.HWout;
+                            if (a.stream_stores) {
+                                __builtin_nontemporal_store(val, yg + o);
+                                if (rg) __builtin_nontemporal_store(relu_like_torch(val), rg + o);
+                            } else {
+                                yg[o] = val;
+                                if (rg) rg[o] = relu_like_torch(val);
+                            }
+                            stat.add(val);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                      // the next tile overwrites s_bias and stage 0
+    }
+}
+
+template <int WM, int WN, bool kTailK>
+__global__ __launch_bounds__(kT) void conv1x1_f32_kernel(const C1Args a) {
+    __shared__ float smem[Shape<WM, WN>::kFloats];
+    NoStat st;
+    conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
+}
+
+template <int WM, int WN, bool kTailK>
+__global__ __launch_bounds__(kT) void conv1x1_f32_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
+    __shared__ float smem[Shape<WM, WN>::kFloats];
+    MaxStat st;
+    conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
+    publish_max<kT>(st.m, max_bits);
+}
+
+template <int WM, int WN, bool kTailK>
+__global__ __launch_bounds__(kT) void conv1x1_f32_hist_kernel(const C1Args a, const float* __restrict__ interval,
+                                                              unsigned long long* __restrict__ hist_row, const int allow_fast) {
+    __shared__ float smem[Shape<WM, WN>::kFloats];
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kT) s_bins[b] = 0u;
+    __syncthreads();
+    const float iv = *interval;
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (allow_fast && fast_quotient_ok(iv)) {
+        HistStat<true> st{s_bins, park, iv, 1.0f / iv};
+        conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
+    } else {
+        HistStat<false> st{s_bins, park, iv, 1.0f / iv};
+        conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
+    }
+    hist_flush<kT>(s_bins, hist_row);
+}
+
+template <int WM, int WN, bool kTailK>
+void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, int64_t* hist_row, int hist_per_cu, int fast,
+            hipStream_t st) {
+    typedef Shape<WM, WN> S;
+    a.tiles_m = (a.Cout + S::BM - 1) / S::BM;
+    a.tiles = ((cols + S::BN - 1) / S::BN) * a.tiles_m;
+    if (hist_row) {
+        // every workgroup flushes up to 2048 bins with 64-bit atomics at its end: a persistent grid
+        unsigned grid = (unsigned)kCUs * (unsigned)hist_per_cu;
+        if (grid > a.tiles) grid = a.tiles;
+        hipLaunchKernelGGL((conv1x1_f32_hist_kernel<WM, WN, kTailK>), dim3(grid), dim3(kT), 0, st, a, interval,
+                           reinterpret_cast<unsigned long long*>(hist_row), fast);
+    } else if (max_inout) {
+        hipLaunchKernelGGL((conv1x1_f32_absmax_kernel<WM, WN, kTailK>), dim3(a.tiles), dim3(kT), 0, st, a,
+                           reinterpret_cast<unsigned int*>(max_inout));
+    } else {
+        hipLaunchKernelGGL((conv1x1_f32_kernel<WM, WN, kTailK>), dim3(a.tiles), dim3(kT), 0, st, a);
+    }
+}
+
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+
+}  // namespace
+}  // namespace fq
+
+using namespace fq;
+
+extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin,
+                              int Hin, int Win, int Cout, int stride, float* max_inout, const float* interval,
+                              int64_t* hist_row, fq_stream_t stream) {
+    if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1) return FQ_ERR_INVALID_ARG;
+    if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
+    if (hist_row && !interval) return FQ_ERR_INVALID_ARG;
+    if (N == 0) return FQ_OK;
+    if (!x || !wt || !y) return FQ_ERR_INVALID_ARG;
+    if ((Cout & 3) || (reinterpret_cast<uintptr_t>(wt) & 15u)) return FQ_ERR_UNSUPPORTED;       // float4 loads of Wt rows
+    const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
+    const size_t cols = (size_t)N * Hout * Wout;
+    const size_t in_elems = (size_t)N * Cin * Hin * Win, out_elems = cols * Cout;
+    if (cols >= 0xffffff00ULL || in_elems >= 0xffffffffULL || out_elems >= 0xffffffffULL) return FQ_ERR_UNSUPPORTED;
+    C1Args a;
+    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out;
+    a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.HWin = (unsigned)(Hin * Win); a.HWout = (unsigned)(Hout * Wout);
+    a.Win = (unsigned)Win; a.Wout = (unsigned)Wout; a.stride = (unsigned)stride;
+    a.cols = (unsigned)cols;
+    a.tiles_m = a.tiles = 0;
+    a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);       // beyond the Infinity Cache
+    hipStream_t st = as_stream(stream);
+    static const int hist_per_cu = env_int("FQ_CONV1X1_HIST_WG_PER_CU", 3);
+    static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
+    const bool tail_k = (Cin % kBK) != 0;
+    const bool narrow = Cout <= 64;                          // a 128-row tile would be half empty
+    if (narrow) {
+        if (tail_k) launch<1, 4, true>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);
+        else launch<1, 4, false>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);
+    } else {
+        if (tail_k) launch<2, 2, true>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);
+        else launch<2, 2, false>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}

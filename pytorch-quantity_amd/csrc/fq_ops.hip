@@ -12,6 +12,7 @@
 
 #include "fq_common.h"
 #include "fq_hist_bin.h"
+#include "fq_producer_stat.h"
 
 namespace fq {
 
@@ -206,20 +207,6 @@ __global__ __launch_bounds__(kOpsBlock) void recon_epilogue_vec_kernel(const flo
 // non-temporal loads and stores, as in unary_vec_kernel.  Two items per lane are in flight per iteration, and the
 // channel of an item is carried along incrementally (plane = i / HW, c = plane % C advance by constants per grid stride:
 // two adds and two selects instead of two integer divisions per item).
-__device__ __forceinline__ float relu_like_torch(float v) { return v > 0.0f ? v : (v != v ? v : 0.0f); }
-
-struct MaxStat {
-    float m = 0.0f;
-    __device__ __forceinline__ void add(float v) { m = fmaxf(m, fabsf(v)); }                  // fmaxf drops NaN
-};
-template <bool kFast>
-struct HistStat {
-    unsigned int* bins;
-    unsigned int* park;                                       // exact zeros are not counted: a per-lane scratch slot
-    float iv, yr;
-    __device__ __forceinline__ void add(float v) { atomicAdd((v != 0.0f) ? (bins + bin_of<kFast>(v, iv, yr)) : park, 1u); }
-};
-
 template <bool kStream> __device__ __forceinline__ f4v ld4(const f4v* p) { return kStream ? __builtin_nontemporal_load(p) : *p; }
 template <bool kStream> __device__ __forceinline__ void st4(f4v v, f4v* p) { if (kStream) __builtin_nontemporal_store(v, p); else *p = v; }
 __device__ __forceinline__ f4v relu4(f4v v) {
@@ -313,35 +300,13 @@ __device__ __forceinline__ void add_body(const f4v* __restrict__ x, const f4v* _
 // workgroup maximum -> the collector's row.  m >= 0: the bit pattern orders like an unsigned.  Thousands of workgroups
 // publish into ONE word: only those that can still raise it pay the atomic (4 096 serialised atomics cost 40 us, more
 // than the add itself)
-__device__ __forceinline__ void publish_max(float m, unsigned int* __restrict__ max_bits) {
-    __shared__ float s_wave[kOpsBlock / kWave];
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
-    if ((threadIdx.x & (kWave - 1)) == 0) s_wave[threadIdx.x / kWave] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int w = 1; w < kOpsBlock / kWave; ++w) m = fmaxf(m, s_wave[w]);
-        const unsigned int bits = __float_as_uint(m);
-        if (bits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, bits);
-    }
-}
-
-__device__ __forceinline__ void hist_flush(unsigned int* s_bins, unsigned long long* __restrict__ dst) {
-    __syncthreads();
-    for (int b = threadIdx.x; b < FQ_BINS; b += kOpsBlock) {
-        const unsigned int c = s_bins[b];
-        if (c) atomicAdd(dst + b, (unsigned long long)c);
-    }
-}
-
 template <bool kVec, bool kStream>
 __global__ __launch_bounds__(kOpsBlock) void bias_add_absmax_kernel(float* __restrict__ y, const float* __restrict__ bias,
                                                                     unsigned n_items, unsigned inner, unsigned C,
                                                                     unsigned int* __restrict__ max_bits, float* __restrict__ relu_out) {
     MaxStat st;
     bias_add_body<kVec, kStream>(y, bias, n_items, inner, C, relu_out, st);
-    publish_max(st.m, max_bits);
+    publish_max<kOpsBlock>(st.m, max_bits);
 }
 
 __device__ __forceinline__ unsigned int* hist_lds_zeroed() {
@@ -367,7 +332,7 @@ __global__ __launch_bounds__(kOpsBlock) void bias_add_hist_kernel(float* __restr
         HistStat<false> st{s_bins, park, iv, 1.0f / iv};
         bias_add_body<kVec, kStream>(y, bias, n_items, inner, C, relu_out, st);
     }
-    hist_flush(s_bins, hist_row);
+    hist_flush<kOpsBlock>(s_bins, hist_row);
 }
 
 template <bool kStream>
@@ -377,7 +342,7 @@ __global__ __launch_bounds__(kOpsBlock) void add_absmax_kernel(const f4v* __rest
                                                                unsigned int* __restrict__ max_bits, float* __restrict__ relu_out) {
     MaxStat st;
     add_body<kStream>(x, y, z, nvec, xs, ys, zs, tail, relu_out, st);
-    publish_max(st.m, max_bits);
+    publish_max<kOpsBlock>(st.m, max_bits);
 }
 
 template <bool kStream>
@@ -397,7 +362,7 @@ __global__ __launch_bounds__(kOpsBlock) void add_hist_kernel(const f4v* __restri
         HistStat<false> st{s_bins, park, iv, 1.0f / iv};
         add_body<kStream>(x, y, z, nvec, xs, ys, zs, tail, relu_out, st);
     }
-    hist_flush(s_bins, hist_row);
+    hist_flush<kOpsBlock>(s_bins, hist_row);
 }
 
 // ---- weight quantiser ---------------------------------------------------------------------------

@@ -1,0 +1,52 @@
+// fq_producer_stat.h -- what a producer kernel does with each output value while it is still in registers: the running
+// abs-max of calibration pass 1 (distribution_collector.py:70-78) or the 2048-bin histogram of pass 2
+// (distribution_collector.py:127-135).  Shared by the elementwise producers (fq_ops.hip) and the fp32 1x1 convolution
+// (fq_conv1x1_f32.hip).
+#pragma once
+#include "fq_common.h"
+#include "fq_hist_bin.h"
+
+namespace fq {
+
+// torch's clamp_min(x, 0): NaN stays NaN
+__device__ __forceinline__ float relu_like_torch(float v) { return v > 0.0f ? v : (v != v ? v : 0.0f); }
+
+struct MaxStat {
+    float m = 0.0f;
+    __device__ __forceinline__ void add(float v) { m = fmaxf(m, fabsf(v)); }                  // fmaxf drops NaN
+};
+
+template <bool kFast>
+struct HistStat {
+    unsigned int* bins;                                       // 2048 LDS counters of this workgroup
+    unsigned int* park;                                       // exact zeros are not counted: a per-lane scratch slot
+    float iv, yr;
+    __device__ __forceinline__ void add(float v) { atomicAdd((v != 0.0f) ? (bins + bin_of<kFast>(v, iv, yr)) : park, 1u); }
+};
+
+// wave maximum -> LDS -> one atomicMax per workgroup on the non-negative float's bit pattern, and only when it can raise it
+template <int kThreads>
+__device__ __forceinline__ void publish_max(float m, unsigned int* __restrict__ max_bits) {
+    __shared__ float s_wave[kThreads / kWave];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, kWave));
+    if ((threadIdx.x & (kWave - 1)) == 0) s_wave[threadIdx.x / kWave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < kThreads / kWave; ++w) m = fmaxf(m, s_wave[w]);
+        const unsigned int bits = __float_as_uint(m);
+        if (bits > __hip_atomic_load(max_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_bits, bits);
+    }
+}
+
+template <int kThreads>
+__device__ __forceinline__ void hist_flush(unsigned int* s_bins, unsigned long long* __restrict__ dst) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < FQ_BINS; b += kThreads) {
+        const unsigned int c = s_bins[b];
+        if (c) atomicAdd(dst + b, (unsigned long long)c);
+    }
+}
+
+}  // namespace fq

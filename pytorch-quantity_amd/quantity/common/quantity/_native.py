@@ -96,6 +96,8 @@ def lib():
     L.fq_bias_add_hist_f32.argtypes = [vp, vp, ci, ci, ci, vp, vp, vp, vp]
     L.fq_add_hist_f32.restype = ci
     L.fq_add_hist_f32.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
+    L.fq_conv1x1_f32.restype = ci
+    L.fq_conv1x1_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [vp, vp, vp, vp]
     L.fq_conv2d_i8_stem.restype = ci
     L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
@@ -324,6 +326,33 @@ def add_hist(x, y, interval_dev, hist_dev, row, out=None, relu_out=None):
     _check(lib().fq_add_hist_f32(x.data_ptr(), y.data_ptr(), z.data_ptr(), x.numel(), ivp, hp, _relu_ptr(relu_out, x),
                                  _stream(x)), "fq_add_hist_f32")
     return z
+
+
+def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None, out=None):
+    """fq_conv1x1_f32: the float 1x1 convolution (padding 0, groups 1) of x [N, Cin, H, W] with the TRANSPOSED weights
+    wt [Cin, Cout] on the fp32 matrix cores; max_dev/row: abs-max of the output folded into max_dev[row]; interval_dev/
+    hist_dev/row: the output histogrammed into hist_dev[row]; relu_out: also receives max(y, 0).  Returns y."""
+    _need_cuda(x, torch.float32, "fq_conv1x1_f32")
+    _need_cuda(wt, torch.float32, "fq_conv1x1_f32")
+    assert x.dim() == 4 and x.is_contiguous() and wt.dim() == 2 and wt.is_contiguous() and wt.shape[0] == x.shape[1]
+    N, Cin, H, W = (int(v) for v in x.shape)
+    Cout, s = int(wt.shape[1]), int(stride)
+    shape = (N, Cout, (H - 1) // s + 1, (W - 1) // s + 1)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+    assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
+    if bias is not None:
+        _need_cuda(bias, torch.float32, "fq_conv1x1_f32")
+        assert bias.is_contiguous() and bias.numel() == Cout
+    mp = ivp = hp = None
+    if hist_dev is not None:
+        ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
+    elif max_dev is not None:
+        _need_cuda(max_dev, torch.float32, "fq_conv1x1_f32")
+        assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
+        mp = max_dev.data_ptr() + 4 * int(row)
+    _check(lib().fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                _relu_ptr(relu_out, y), N, Cin, H, W, Cout, s, mp, ivp, hp, _stream(x)), "fq_conv1x1_f32")
+    return y
 
 
 def bits_from_threshold(thr, interval):

@@ -13,6 +13,7 @@ sys.stdout = out
 torch.backends.cudnn.benchmark = False
 x = torch.randn(B, 3, 224, 224, device="cuda")
 recs = {}
+shapes = {}
 def pre(name):
     def f(m, i):
         e = torch.cuda.Event(enable_timing=True); e.record(); recs.setdefault(name, []).append([e, None])
@@ -20,6 +21,7 @@ def pre(name):
 def post(name):
     def f(m, i, o):
         e = torch.cuda.Event(enable_timing=True); e.record(); recs[name][-1][1] = e
+        shapes[name] = tuple(o.shape)
     return f
 for name, m in model.named_modules():
     if len(list(m.children())) == 0:
@@ -44,3 +46,14 @@ by = {}
 for r in rows: by[r[2]] = by.get(r[2], 0) + r[0]
 print("by module type (ms):", {k: round(v, 2) for k, v in sorted(by.items(), key=lambda kv: -kv[1])}, "sum %.2f" % tot)
 for r in rows[:14]: print("%7.3f ms  %-28s %-10s k%s s%s %s->%s" % r)
+print("convolutions, slowest first (fp32 TFLOP/s = 2 * MAC / time):")
+conv_ms = conv_flop = 0.0
+for ms, name, kind, k, st, ci, co in rows:
+    if kind != "Conv2d":
+        continue
+    m = dict(model.named_modules())[name]
+    n, c, h, w = shapes[name]
+    flop = 2.0 * n * c * h * w * (ci // m.groups) * m.kernel_size[0] * m.kernel_size[1]
+    conv_ms += ms; conv_flop += flop
+    print("%7.3f ms %6.1f TFLOP/s  %-24s k%s s%s %4s->%-4s out %dx%d" % (ms, flop / ms / 1e9, name, k, st, ci, co, h, w))
+print("all convolutions: %.2f ms, %.1f TFLOP/s" % (conv_ms, conv_flop / conv_ms / 1e9))

@@ -8,7 +8,8 @@ import bench
 sys.stdout = open(os.devnull, "w")
 m = bench.build_model("r50", 224, torch.device("cuda"))
 sys.stdout = sys.__stdout__
-x = torch.randn(64, 3, 224, 224, device="cuda")
+NB = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+x = torch.randn(NB, 3, 224, 224, device="cuda")
 def t(fn, n=10):
     fn(); fn(); torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
@@ -16,9 +17,9 @@ def t(fn, n=10):
 for bm in (False, True):
     torch.backends.cudnn.benchmark = bm
     with torch.no_grad():
-        print("benchmark=%s NCHW: %.2f ms/batch64" % (bm, t(lambda: m(x))))
+        print("benchmark=%s NCHW: %.2f ms/batch" % (bm, t(lambda: m(x))))
         mc = m.to(memory_format=torch.channels_last); xc = x.to(memory_format=torch.channels_last)
-        print("benchmark=%s NHWC: %.2f ms/batch64" % (bm, t(lambda: mc(xc))))
+        print("benchmark=%s NHWC: %.2f ms/batch" % (bm, t(lambda: mc(xc))))
         m = m.to(memory_format=torch.contiguous_format)
 for B in (32, 128, 256):
     xb = torch.randn(B, 3, 224, 224, device="cuda")
