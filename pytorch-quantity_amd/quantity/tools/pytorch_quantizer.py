@@ -67,6 +67,10 @@ def _dist_on():
 
 
 _RELU_VERIFIED = "_fq_relu_fusion_verified"
+_C1_VERIFIED = "_fq_conv1x1_verified"               # module attribute: fq_conv1x1_f32 agreed with torch's forward here
+_C1_OFF = "_fq_conv1x1_off"                         # module attribute: fq_conv1x1_f32 disagreed with torch's forward here
+_C1_WT = "_fq_conv1x1_wt"                           # module attribute: (weight version, storage address, transposed weights)
+_C1_TOL = 1e-5                                      # |own - torch| <= _C1_TOL * (|W| * |x| + |b|): summation order only
 _FUSION_VERIFIED = "_fq_bias_fusion_verified"     # module attribute: conv-without-bias + fq_bias_add_absmax_f32 == its forward
 _AFTER_FORWARD = 1 << 62      # _EagerStats limit that is never reached: one flush, after the forward
 
@@ -152,6 +156,12 @@ class Quantity(object):
     # costs a second 4 B/element read and runs that kernel against the write-back of its own input).
     # Only modules whose decomposition was verified in pass 1 take part.
     fuse_hist = True
+    # The float 1x1 convolutions themselves (36 of ResNet-50's 53): fq_conv1x1_f32 computes them on the fp32 matrix cores
+    # (exact fp32, fixed summation order) with the bias, the statistic of the pass and the following ReLU in its epilogue,
+    # so for these layers there is no library convolution and no bias-add pass at all.  Each module is checked once per
+    # process against torch's own forward (|difference| <= 1e-5 * (|W|*|x| + |b|): summation order only; the abs-max and
+    # the ReLU copy bit for bit); a module that disagrees keeps the path above.
+    own_conv1x1 = True
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -402,9 +412,14 @@ class Quantity(object):
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"]:
                     return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
-                if m not in ctl["fuse_warm"] and not m.__dict__.get(_FUSION_VERIFIED):
+                if m not in ctl["fuse_warm"] and not (m.__dict__.get(_FUSION_VERIFIED) or m.__dict__.get(_C1_VERIFIED)):
                     ctl["fuse_warm"].add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
                     return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
+                if self.own_conv1x1 and self._conv1x1_eligible(m, x):
+                    ctl["fuse_bias"] = (m, ("c1", x))       # the hook of this very call runs the whole convolution
+                    s = m.stride[0]
+                    return torch.empty((x.shape[0], m.out_channels, (x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1),
+                                       dtype=torch.float32, device=x.device)
                 y = m._conv_forward(x, m.weight, None)
                 ctl["fuse_bias"] = (m, x)                   # the hook of this very call adds the bias
                 return y
@@ -443,6 +458,56 @@ class Quantity(object):
             patched.append(m)
         return patched
 
+    @staticmethod
+    def _conv1x1_eligible(m, x):
+        return (m.kernel_size == (1, 1) and m.padding in ((0, 0), 0) and m.dilation == (1, 1) and m.groups == 1
+                and m.stride[0] == m.stride[1] and x.dim() == 4 and x.is_contiguous() and m.out_channels % 4 == 0
+                and not m.__dict__.get(_C1_OFF) and x.numel() < 2 ** 32 - 1
+                and x.shape[0] * m.out_channels * x.shape[2] * x.shape[3] < 2 ** 32 - 1)
+
+    @staticmethod
+    def _conv1x1_weight(m):
+        """Wt [Cin][Cout] of a 1x1 nn.Conv2d, rebuilt when the parameter was written to or replaced."""
+        w = m.weight
+        tag = (w._version, w.data_ptr(), w.device)
+        cached = m.__dict__.get(_C1_WT)
+        if cached is None or cached[0] != tag:
+            cached = (tag, w.detach().view(w.shape[0], w.shape[1]).t().contiguous())
+            m.__dict__[_C1_WT] = cached
+        return cached[1]
+
+    def _finish_own_conv1x1(self, module, m, x, key, output):
+        """Forward-hook half of a 1x1 convolution that runs on fq_conv1x1_f32: `output` is the empty tensor the patched
+        forward returned.  Returns True when the statistic of `output` is done."""
+        ctl = self._hook_ctl
+        coll = ctl["fuse_collector"]
+        wt, s = self._conv1x1_weight(m), m.stride[0]
+        if module is not m or coll is None or key is None:     # not a cared tensor: the convolution only
+            _native.conv1x1_f32(x, wt, m.bias, s, out=output)
+            return False
+        row = coll.row_of(key)
+        if ctl["fuse_stat"] == "hist":                         # pass 2 (verified in pass 1)
+            self._run_with_relu(m, output, lambda r: _native.conv1x1_f32(
+                x, wt, m.bias, s, interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row, relu_out=r, out=output))
+            ctl["hist_fused"] += 1
+            return True
+        if not m.__dict__.get(_C1_VERIFIED):               # first use: against torch's own forward, once per process
+            ref = torch.nn.Conv2d.forward(m, x)
+            bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride)
+            scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
+            own = _native.conv1x1_f32(x, wt, m.bias, s, max_dev=scratch, row=0)
+            if not (bool(((own - ref).abs() <= _C1_TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
+                m.__dict__[_C1_OFF] = True                     # this module keeps the library convolution from now on
+                output.copy_(ref)
+                return False
+            m.__dict__[_C1_VERIFIED] = True
+        ctl["fuse_verified"].add(m)
+        self._run_with_relu(m, output, lambda r: _native.conv1x1_f32(x, wt, m.bias, s, max_dev=coll.max_device, row=row,
+                                                                     relu_out=r, out=output))
+        coll.note_max_refreshed()
+        ctl["own_conv1x1"] = ctl.get("own_conv1x1", 0) + 1
+        return True
+
     def _run_with_relu(self, m, output, run):
         """run(relu_out) launches m's fused kernel.  When an out-of-place nn.ReLU is known to consume `output` directly,
         the kernel writes that ReLU's result as well and the patched ReLU.forward hands it out instead of launching."""
@@ -467,6 +532,8 @@ class Quantity(object):
         m, x = pending
         ctl = self._hook_ctl
         coll = ctl["fuse_collector"]
+        if isinstance(x, tuple) and isinstance(x[0], str):  # 1x1 convolution on fq_conv1x1_f32: output is still empty
+            return self._finish_own_conv1x1(module, m, x[1], key, output)
         if isinstance(x, tuple):                            # Eltwise: output is an empty tensor waiting for x + y
             a, b = x
             if module is not m or coll is None or key is None:
@@ -852,6 +919,7 @@ class Quantity(object):
                         "fused_relus": len(ctl["fused_relus"]),
                         "fused_add_absmax_eltwise": 0 if ctl["fuse_off"] else sum(1 for m in ctl["fuse_verified"] if not isinstance(m, torch.nn.Conv2d)),
                         "fused_hist_launches": ctl["hist_fused"],
+                        "own_conv1x1_launches": ctl.get("own_conv1x1", 0),
                         "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}
