@@ -1,0 +1,212 @@
+"""fq_conv1x1_f32 -- the float 1x1 convolution on the fp32 matrix cores with the calibration's statistic in its epilogue --
+through the C ABI: exact agreement with a float64 reference on integer-valued data (every partial sum is exact, so any
+indexing or tiling mistake shows as a wrong bit), agreement within the summation-order bound on Gaussian data (tolerance
+1e-5 * (|W| * |x| + |b|), the bound the product's own once-per-module check uses), the folded abs-max / histogram / ReLU
+copy bit for bit against the streaming kernels and torch on the SAME output, ragged shapes (K tails, partial tiles in both
+directions, strides, 7x7 and 1x1 planes, one image), the non-temporal form, determinism, error codes; and the product:
+a ResNet-style net calibrated with and without the kernel gives the same tables.    pytest -m gpu"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from workdir_util import product_workdir
+
+pytestmark = pytest.mark.gpu
+
+# N, Cin, Cout, H, W, stride
+SHAPES = [
+    (2, 64, 64, 56, 56, 1),       # the narrow 64 x 256 tile
+    (3, 64, 256, 28, 28, 1),      # 128 x 128 tiles, 2352 columns = 18.4 tiles
+    (5, 256, 64, 14, 14, 1),
+    (4, 128, 512, 7, 7, 1),       # 7x7 planes: runs of 49, columns cross images inside a 32-lane group
+    (7, 32, 100, 5, 3, 1),        # Cout = 100: partial m tile, K = 32
+    (1, 3, 8, 9, 11, 1),          # K tail (3), Cout 8, one image
+    (2, 20, 36, 6, 6, 1),         # K tail (20 = 16 + 4)
+    (3, 33, 132, 8, 8, 1),        # K tail (33), partial second m tile
+    (2, 256, 512, 56, 56, 2),     # the downsample branch
+    (3, 16, 64, 9, 7, 2),         # odd plane, stride 2
+    (2, 16, 128, 10, 10, 3),      # stride 3
+    (9, 512, 16, 1, 1, 1),        # 1x1 planes: 9 columns
+    (1, 2048, 512, 7, 7, 1),      # K = 2048
+]
+
+
+@pytest.fixture(scope="module")
+def nat():
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    from common.quantity import _native
+    _native.lib()
+    return _native
+
+
+def _ref64(x, w, bias, s):
+    y = torch.nn.functional.conv2d(x.double(), w.double(), None if bias is None else bias.double(), stride=s)
+    return y
+
+
+def _case(shape, seed, integer):
+    N, cin, cout, H, W, s = shape
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if integer:
+        x = torch.randint(-8, 9, (N, cin, H, W), device="cuda", generator=g).float()
+        w = torch.randint(-8, 9, (cout, cin, 1, 1), device="cuda", generator=g).float()
+        b = torch.randint(-100, 101, (cout,), device="cuda", generator=g).float()
+    else:
+        x = torch.randn(N, cin, H, W, device="cuda", generator=g)
+        w = torch.randn(cout, cin, 1, 1, device="cuda", generator=g) * cin ** -0.5
+        b = torch.randn(cout, device="cuda", generator=g)
+    return x, w, b, w.view(cout, cin).t().contiguous(), s
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_exact_on_integer_valued_data(nat, shape):
+    x, w, b, wt, s = _case(shape, 11, integer=True)       # |sum| <= 2048 * 64 + 100 < 2^24: fp32 is exact in any order
+    y = nat.conv1x1_f32(x, wt, b, s)
+    assert torch.equal(y.double(), _ref64(x, w, b, s))
+    assert torch.equal(nat.conv1x1_f32(x, wt, None, s).double(), _ref64(x, w, None, s))
+
+
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_gaussian_data_statistics_and_relu(nat, shape):
+    x, w, b, wt, s = _case(shape, 12, integer=False)
+    ref = _ref64(x, w, b, s)
+    bound = _ref64(x.abs(), w.abs(), b.abs(), s)
+    y = nat.conv1x1_f32(x, wt, b, s)
+    assert bool(((y.double() - ref).abs() <= 1e-5 * bound).all())
+    assert torch.equal(y, nat.conv1x1_f32(x, wt, b, s))                      # same bits from run to run
+    # pass 1: the abs-max folded into an existing maximum, the ReLU copy
+    mx = torch.tensor([0.0, 1e9, 0.0], device="cuda")
+    r = torch.empty_like(y)
+    y1 = nat.conv1x1_f32(x, wt, b, s, max_dev=mx, row=2, relu_out=r)
+    assert torch.equal(y1, y) and torch.equal(r, torch.relu(y))
+    assert mx.tolist() == [0.0, 1e9, float(y.abs().max())]
+    nat.conv1x1_f32(x, wt, b, s, max_dev=mx, row=1)
+    assert float(mx[1]) == 1e9                                               # a larger running maximum stays
+    # pass 2: the histogram, accumulated onto existing counts, against the streaming kernel on the same tensor
+    iv = torch.tensor([1.0, float(y.abs().max()) / 2048 + 1e-12], device="cuda")
+    hist = torch.zeros(2, 2048, dtype=torch.int64, device="cuda")
+    hist[1, 5] = 7
+    want = hist.clone()
+    y2 = nat.conv1x1_f32(x, wt, b, s, interval_dev=iv, hist_dev=hist, row=1, relu_out=r)
+    nat.hist2048_seg([y], [1], iv, want)
+    assert torch.equal(y2, y) and torch.equal(r, torch.relu(y)) and torch.equal(hist, want)
+    assert int(hist[1].sum()) - 7 == int((y != 0).sum()) and int(hist[0].sum()) == 0
+
+
+def test_histogram_with_an_interval_outside_the_fast_quotient_range(nat):
+    x, w, b, wt, s = _case((2, 16, 64, 6, 6, 1), 13, integer=False)
+    y = nat.conv1x1_f32(x, wt, b, s)
+    for ivv in (1e-30, 3e25):                                               # IEEE divide path; everything in the last / first bin
+        iv = torch.tensor([ivv], device="cuda")
+        hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+        want = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+        nat.conv1x1_f32(x, wt, b, s, interval_dev=iv, hist_dev=hist, row=0)
+        nat.hist2048_seg([y], [0], iv, want)
+        assert torch.equal(hist, want)
+
+
+def test_nan_and_zero_outputs(nat):
+    x, w, b, wt, s = _case((2, 16, 64, 6, 6, 1), 14, integer=True)
+    b.zero_()
+    x[0, :, 2, 3] = 0.0                                                      # an exactly-zero output column: not counted
+    x[1, 5, 1, 1] = float("nan")
+    r = torch.empty(2, 64, 6, 6, device="cuda")
+    mx = torch.zeros(1, device="cuda")
+    y = nat.conv1x1_f32(x, wt, b, s, max_dev=mx, row=0, relu_out=r)
+    assert bool((y[0, :, 2, 3] == 0).all()) and bool(torch.isnan(y[1, :, 1, 1]).all()) and bool(torch.isnan(r[1, :, 1, 1]).all())
+    finite = y[~torch.isnan(y)]
+    assert float(mx[0]) == float(finite.abs().max())                        # NaN does not enter the maximum (np.max would; the
+    iv = torch.tensor([float(mx[0]) / 2048 + 1e-12], device="cuda")          # reference never sees NaN activations)
+    hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+    want = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+    nat.conv1x1_f32(x, wt, b, s, interval_dev=iv, hist_dev=hist, row=0)
+    nat.hist2048_seg([y], [0], iv, want)
+    assert torch.equal(hist, want)
+
+
+def test_streaming_form_beyond_the_infinity_cache(nat):
+    shape = (48, 64, 256, 56, 56, 1)                                         # 154 MB out + 154 MB ReLU copy > 256 MB: non-temporal stores
+    x, w, b, wt, s = _case(shape, 15, integer=True)
+    r = torch.empty(48, 256, 56, 56, device="cuda")
+    mx = torch.zeros(1, device="cuda")
+    y = nat.conv1x1_f32(x, wt, b, s, max_dev=mx, row=0, relu_out=r)
+    ref = torch.nn.functional.conv2d(x, w, b)                                # exact in fp32 as well on this data
+    assert torch.equal(y, ref) and torch.equal(r, torch.relu(ref)) and float(mx[0]) == float(ref.abs().max())
+
+
+def test_argument_errors(nat):
+    L = nat.lib()
+    x = torch.zeros(1, 4, 2, 2, device="cuda")
+    wt = torch.zeros(4, 6, device="cuda")                                    # Cout = 6: not a multiple of 4
+    y = torch.zeros(1, 6, 2, 2, device="cuda")
+    one = torch.zeros(1, device="cuda")
+    h = torch.zeros(2048, dtype=torch.int64, device="cuda")
+    call = lambda *a: L.fq_conv1x1_f32(*a)
+    assert call(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 6, 1, None, None, None, None) == -4
+    wt8 = torch.zeros(4, 8, device="cuda")
+    assert call(x.data_ptr(), wt8.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 8, 1, one.data_ptr(), one.data_ptr(),
+                h.data_ptr(), None) == -1                                    # both statistics at once
+    assert call(x.data_ptr(), wt8.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 8, 1, None, None, h.data_ptr(), None) == -1
+    assert call(x.data_ptr(), wt8.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 8, 0, None, None, None, None) == -1
+    assert call(None, None, None, None, None, 0, 4, 2, 2, 8, 1, None, None, None, None) == 0        # no images: nothing to do
+
+
+def _bottleneck_net():
+    """conv3x3 -> [1x1 -> ReLU -> 3x3 -> ReLU -> 1x1] + 1x1 stride-2 downsample -> Eltwise -> ReLU -> pool -> fc."""
+    from torch import nn
+    from common.quantity import Eltwise, View
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem = nn.Conv2d(3, 32, 3, padding=1)
+            self.relu0 = nn.ReLU()
+            self.c1 = nn.Conv2d(32, 16, 1)
+            self.relu1 = nn.ReLU()
+            self.c2 = nn.Conv2d(16, 16, 3, stride=2, padding=1)
+            self.relu2 = nn.ReLU()
+            self.c3 = nn.Conv2d(16, 64, 1)
+            self.down = nn.Conv2d(32, 64, 1, stride=2)
+            self.add = Eltwise()
+            self.relu3 = nn.ReLU()
+            self.pool = nn.AvgPool2d(8)
+            self.view = View()
+            self.fc = nn.Linear(64, 10)
+
+        def forward(self, x):
+            x = self.relu0(self.stem(x))
+            y = self.c3(self.relu2(self.c2(self.relu1(self.c1(x)))))
+            x = self.relu3(self.add(y, self.down(x)))
+            return self.fc(self.view(self.pool(x)))
+    return Net()
+
+
+def test_calibration_tables_with_and_without_the_kernel():
+    from tools import Quantity
+    tables, launches = [], []
+    for own in (True, False):
+        with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=3) as tmp:
+            q = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
+            q.own_conv1x1 = own
+            bits = q.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77))
+            tables.append((dict(bits), open(tmp + "/test/workdir/feat.table").read()))
+            launches.append(q.timings["own_conv1x1_launches"])
+    assert tables[0] == tables[1]
+    assert launches[0] > 0 and launches[1] == 0          # three 1x1 convolutions from the third batch on / none
+
+
+def test_a_module_that_disagrees_keeps_the_library_convolution(monkeypatch):
+    from tools import Quantity, pytorch_quantizer
+    monkeypatch.setattr(pytorch_quantizer, "_C1_TOL", -1.0)                  # nothing can pass
+    with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=3) as tmp:
+        q = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
+        bits = dict(q.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77)))
+        assert q.timings["own_conv1x1_launches"] == 0
+        assert all(m.__dict__.get(pytorch_quantizer._C1_OFF) for m in (q.model.c1, q.model.c3, q.model.down))
+    monkeypatch.undo()
+    with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=3) as tmp:
+        q2 = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
+        assert dict(q2.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77))) == bits
