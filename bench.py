@@ -23,6 +23,8 @@ The JSON line also carries
                  mean launch duration measured with HIP events on the launch stream inside the timed region;
                  `traffic` is STATIC (PMC counters of the committed profile of this configuration), and says so;
   roofline_bias_add_absmax / roofline_add_absmax : the two kernels pass 1's maxima ride on;
+  roofline_conv1x1_f32 : the float forward's 1x1 convolutions on the fp32 matrix cores (fq_conv1x1_f32, statistic in the
+                 epilogue): 2 x MAC / summed launch durations against the 157.3 TFLOP/s dense fp32 MFMA peak;
   cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded sample on this
                  box's host cores at 1 thread and at all cores, scaled to the same workload (rank 0, N=1 only);
   (the forward-throughput keys below run --int8-batch images per forward, default 256)
@@ -56,6 +58,7 @@ with open(os.path.join(ROOT, "BASELINE.json")) as _fh:
     BASELINE_METRIC = json.load(_fh)["metric"]          # the reference's headline metric, verbatim
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 INT8_PEAK_TOPS = 5000.0                      # dense int8 MFMA peak (2 x the BF16 rate)
+F32_MFMA_PEAK_TFLOPS = 157.3                 # dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32; = the fp32 vector peak, MI355X_MICROARCH.md)
 
 
 class DeviceBatches(object):
@@ -173,10 +176,10 @@ class CallTimer(object):
     """Wraps a _native entry point and brackets every call with HIP events on the launch stream (torch's current
     stream is the stream the C ABI is handed).  bytes_fn(args, kwargs) -> algorithmic bytes of that launch."""
 
-    def __init__(self, native, name, bytes_fn):
-        self.native, self.name, self.bytes_fn = native, name, bytes_fn
+    def __init__(self, native, name, bytes_fn, flops_fn=None):
+        self.native, self.name, self.bytes_fn, self.flops_fn = native, name, bytes_fn, flops_fn
         self.orig = getattr(native, name)
-        self.events, self.bytes = [], []
+        self.events, self.bytes, self.flops = [], [], []
         self.enabled = False
 
     def __enter__(self):
@@ -189,6 +192,8 @@ class CallTimer(object):
             e1.record()
             self.events.append((e0, e1))
             self.bytes.append(float(self.bytes_fn(a, k)))
+            if self.flops_fn is not None:
+                self.flops.append(float(self.flops_fn(a, k)))
             return r
         setattr(self.native, self.name, wrapped)
         return self
@@ -217,6 +222,40 @@ def _bias_add_bytes(a, k):          # y += bias[c] in place (4 B read + 4 B writ
 def _add_bytes(a, k):               # z = x + y (8 B read + 4 B written) (+ 4 B for the fused ReLU's copy)
     relu = k.get("relu_out") if "relu_out" in k else (a[5] if len(a) > 5 else None)
     return (12.0 + (4.0 if relu is not None else 0.0)) * int(a[0].numel())
+
+
+def _c1_shape(a, k):
+    x, wt = a[0], a[1]
+    s = int(k.get("stride", a[3] if len(a) > 3 else 1))
+    return int(x.shape[0]), int(x.shape[1]), int(wt.shape[1]), (int(x.shape[2]) - 1) // s + 1, (int(x.shape[3]) - 1) // s + 1
+
+
+def _c1_flops(a, k):                # conv1x1_f32(x, wt, bias, stride, ...): 2 x MAC
+    n, cin, cout, ho, wo = _c1_shape(a, k)
+    return 2.0 * n * cout * ho * wo * cin
+
+
+def _c1_bytes(a, k):                # x read once, Wt, y written (+ the ReLU copy)
+    n, cin, cout, ho, wo = _c1_shape(a, k)
+    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
+
+
+def mfma_f32_roofline(kernel, kt, note):
+    """fp32 matrix-core roofline of the float 1x1 convolutions: 2 x MAC of all timed launches / their summed durations
+    against the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); bound_ms = sum over the launches of
+    max(matrix work at that peak, algorithmic bytes at 8 TB/s) -- the 64-channel layers of the first stage are HBM bound."""
+    if not kt.events:
+        return None
+    ms = np.array([a.elapsed_time(b) for a, b in kt.events])
+    fl, by = np.array(kt.flops), np.array(kt.bytes)
+    ach = fl.sum() / (ms.sum() * 1e-3) / 1e12
+    bound = np.maximum(fl / (F32_MFMA_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)) * 1e3
+    return {"bound": "mfma", "kernel": kernel, "achieved": round(float(ach), 1), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(float(ach) / F32_MFMA_PEAK_TFLOPS, 4), "launches": int(len(ms)), "mean_launch_ms": round(float(ms.mean()), 4),
+            "algorithmic_flops_per_launch": float(fl.mean()), "algorithmic_bytes_per_launch": float(by.mean()),
+            "hbm_gbs": round(float(by.sum() / (ms.sum() * 1e-3) / 1e9), 1), "bound_ms_per_launch": round(float(bound.mean()), 4),
+            "frac_of_bound": round(float(bound.sum() / ms.sum()), 4),
+            "launches_hbm_bound_at_peak": int((by / (HBM_PEAK_GBS * 1e9) > fl / (F32_MFMA_PEAK_TFLOPS * 1e12)).sum()), "note": note}
 
 
 def hbm_roofline(kernel, s, extra=None):
@@ -626,12 +665,13 @@ def main():
         if world != 1:
             raise RuntimeError("producer rooflines are measured at N = 1")
         with CallTimer(_native, "bias_add_absmax", _bias_add_bytes) as kt_b, CallTimer(_native, "add_absmax", _add_bytes) as kt_a, \
-                CallTimer(_native, "bias_add_hist", _bias_add_bytes) as kt_bh, CallTimer(_native, "add_hist", _add_bytes) as kt_ah:
+                CallTimer(_native, "bias_add_hist", _bias_add_bytes) as kt_bh, CallTimer(_native, "add_hist", _add_bytes) as kt_ah, \
+                CallTimer(_native, "conv1x1_f32", _c1_bytes, _c1_flops) as kt_c1:
             make_workdir(3 * world - 1, shape, dev_index)
             extra = DeviceBatches(3 * world, B, HW, rank, world, device)
             eq = Quantity(model)
             eq._activation_cache_budget = lambda: 0          # every batch through the second forward: all 69 producers fused
-            kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = True
+            kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = kt_c1.enabled = True
             eq.activation_quantize(extra)
             torch.cuda.synchronize()
             del extra, eq
@@ -649,6 +689,12 @@ def main():
             sm = kt.summary()
             if sm:
                 result[key] = hbm_roofline(kernel, sm, {"note": note, "aggregate_gbs": round(sm["gbs"], 1)})
+        c1 = mfma_f32_roofline(
+            "conv1x1_f32_absmax_kernel / conv1x1_f32_hist_kernel", kt_c1,
+            "the float forward's 36 1x1 convolutions (2.12 of ResNet-50's 4.09 GMAC per image) on v_mfma_f32_32x32x2_f32 with the "
+            "bias, the pass's statistic and the following ReLU in the epilogue: both passes of three batches, every layer size")
+        if c1:
+            result["roofline_conv1x1_f32"] = c1
     except Exception as e:
         if world == 1:
             result["roofline_bias_add_absmax"] = {"error": repr(e)}

@@ -47,7 +47,16 @@ struct C1Args {
     unsigned cols;            // N * HWout
     unsigned tiles_m, tiles;
     int stream_stores;
+#ifdef FQ_C1_ABLATE
+    int ablate;               // debug build only (scripts/conv1x1_ablate.py): 1 no stores, 2 global loads of the first K step only, 4 no barriers (wrong results)
+#endif
 };
+
+#ifdef FQ_C1_ABLATE
+#define FQ_C1_OFF(bit) (a.ablate & (bit))
+#else
+#define FQ_C1_OFF(bit) false
+#endif
 
 struct NoStat {
     __device__ __forceinline__ void add(float) {}
@@ -62,16 +71,16 @@ struct Shape {
     static constexpr int kXStep = kT / BN > 0 ? kT / BN : 1;  // rows between them (BN = 128: 2; BN = 256: 1)
     static constexpr int kWVecs = kBK * BM / 4 / kT;          // W-tile float4 per thread and K step
     static constexpr int kWRowStep = kT / (BM / 4);           // rows between them
-    static constexpr int kFloats = 2 * kBK * (BM + BN) + BM;  // two stages of both tiles + the bias slice
+    static constexpr int kFloats = 3 * kBK * (BM + BN) + BM;  // three stages of both tiles + the bias slice
 };
 
 template <int WM, int WN, bool kTailK, typename Stat>
 __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float* smem) {
     typedef Shape<WM, WN> S;
     constexpr int BM = S::BM, BN = S::BN;
-    float* Ws = smem;                                         // [2][kBK][BM]
-    float* Xs = smem + 2 * kBK * BM;                          // [2][kBK][BN]
-    float* s_bias = smem + 2 * kBK * (BM + BN);
+    float* Ws = smem;                                         // [3][kBK][BM]
+    float* Xs = smem + 3 * kBK * BM;                          // [3][kBK][BN]
+    float* s_bias = smem + 3 * kBK * (BM + BN);
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
     const unsigned m0 = (wave >> 1) * (32u * WM), n0 = (wave & 1u) * (32u * WN);
@@ -136,29 +145,52 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
+        // K pipeline over THREE LDS stages.  Step s multiplies out of stage s % 3; in the middle of it every wave stores
+        // the operands of step s + 1 (loaded one step earlier) into stage (s + 1) % 3, issues the global loads of step
+        // s + 2 and meets the others at the step's only barrier.  That stage was last read in step s - 2, which every wave
+        // had finished before it could pass the barrier of step s - 1; and what is read at the start of step s + 1 was
+        // complete half a step earlier.  So no wave waits for data at a step boundary: the first operands of the next
+        // step are fetched under the last MFMAs of this one, and the MFMA stream of a wave does not stop between steps.
         gload(0);
         if (tid < (unsigned)BM) s_bias[tid] = (a.bias && mbase + tid < a.Cout) ? a.bias[mbase + tid] : 0.0f;
         lstore(0);
+        if (nk > 1) gload(kBK);
         __syncthreads();
-        for (unsigned ks = 0; ks < nk; ++ks) {
-            const int cur = (int)(ks & 1u);
-            const bool more = ks + 1 < nk;
-            if (more) gload((ks + 1) * kBK);
-            const float* wrow = Ws + (cur * kBK + h) * BM + m0 + r;
-            const float* xrow = Xs + (cur * kBK + h) * BN + n0 + r;
-            float fa[2][WM], fb[2][WN];                       // operands of this and of the next k pair
+        float fa[2][WM], fb[2][WN];                           // operands of this and of the next k pair
+        {
+            const float* wrow = Ws + h * BM + m0 + r;
+            const float* xrow = Xs + h * BN + n0 + r;
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) fa[0][mi] = wrow[32 * mi];
 #pragma unroll
             for (int ni = 0; ni < WN; ++ni) fb[0][ni] = xrow[32 * ni];
+        }
+        int cur = 0;
+        for (unsigned ks = 0; ks < nk; ++ks) {
+            const int nxt = cur == 2 ? 0 : cur + 1;
+            const bool more = ks + 1 < nk;
+            const float* wrow = Ws + (cur * kBK + h) * BM + m0 + r;
+            const float* xrow = Xs + (cur * kBK + h) * BN + n0 + r;
+            const float* wnext = Ws + (nxt * kBK + h) * BM + m0 + r;
+            const float* xnext = Xs + (nxt * kBK + h) * BN + n0 + r;
 #pragma unroll
             for (int kk = 0; kk < kBK; kk += 2) {
                 const int c = (kk >> 1) & 1, nx = c ^ 1;
+                if (kk == kBK / 2 && more) {
+                    lstore(nxt);
+                    if (ks + 2 < nk && !FQ_C1_OFF(2)) gload((ks + 2) * kBK);
+                    if (!FQ_C1_OFF(4)) __syncthreads();
+                }
                 if (kk + 2 < kBK) {
 #pragma unroll
                     for (int mi = 0; mi < WM; ++mi) fa[nx][mi] = wrow[(kk + 2) * BM + 32 * mi];
 #pragma unroll
                     for (int ni = 0; ni < WN; ++ni) fb[nx][ni] = xrow[(kk + 2) * BN + 32 * ni];
+                } else if (more) {
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi) fa[nx][mi] = wnext[32 * mi];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) fb[nx][ni] = xnext[32 * ni];
                 }
                 __builtin_amdgcn_sched_barrier(0);            // keep the next pair's LDS reads ahead of these MFMAs
 #pragma unroll
@@ -167,8 +199,7 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
                     for (int ni = 0; ni < WN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][mi], fb[c][ni], acc[mi][ni], 0, 0, 0);
             }
-            if (more) lstore(cur ^ 1);
-            __syncthreads();
+            cur = nxt;
         }
         // epilogue: D[i][j] has j = lane & 31 and i = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
         float* __restrict__ yg = a.y;
@@ -187,7 +218,8 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
                         if (mbase + m0 + 4u * h + dm < a.Cout) {
                             const float val = acc[mi][ni][e] + s_bias[m0 + 4u * h + dm];
                             const unsigned o = col + dm * a.HWout;
-                            if (a.stream_stores) {
+                            if (FQ_C1_OFF(1)) {
+                            } else if (a.stream_stores) {
                                 __builtin_nontemporal_store(val, yg + o);
                                 if (rg) __builtin_nontemporal_store(relu_like_torch(val), rg + o);
                             } else {
@@ -245,8 +277,14 @@ void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, in
     a.tiles_m = (a.Cout + S::BM - 1) / S::BM;
     a.tiles = ((cols + S::BN - 1) / S::BN) * a.tiles_m;
     if (hist_row) {
-        // every workgroup flushes up to 2048 bins with 64-bit atomics at its end: a persistent grid
-        unsigned grid = (unsigned)kCUs * (unsigned)hist_per_cu;
+        // every workgroup flushes up to 2048 bins with 64-bit atomics at its end: a persistent grid of exactly the
+        // workgroups the chip holds at once (LDS: three stages + 8 KB of bins), each taking every grid-th tile
+        static const int resident = [] {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_f32_hist_kernel<WM, WN, kTailK>, kT, 0) != hipSuccess || n < 1) n = 1;
+            return n;
+        }();
+        unsigned grid = (unsigned)kCUs * (unsigned)(hist_per_cu > 0 ? hist_per_cu : resident);
         if (grid > a.tiles) grid = a.tiles;
         hipLaunchKernelGGL((conv1x1_f32_hist_kernel<WM, WN, kTailK>), dim3(grid), dim3(kT), 0, st, a, interval,
                            reinterpret_cast<unsigned long long*>(hist_row), fast);
@@ -288,18 +326,26 @@ extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias
     a.cols = (unsigned)cols;
     a.tiles_m = a.tiles = 0;
     a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);       // beyond the Infinity Cache
+#ifdef FQ_C1_ABLATE
+    a.ablate = env_int("FQ_C1_ABLATE", 0);
+#endif
     hipStream_t st = as_stream(stream);
-    static const int hist_per_cu = env_int("FQ_CONV1X1_HIST_WG_PER_CU", 3);
+    static const int hist_per_cu = env_int("FQ_CONV1X1_HIST_WG_PER_CU", 0);   // 0: what the occupancy query says
     static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
     const bool tail_k = (Cin % kBK) != 0;
-    const bool narrow = Cout <= 64;                          // a 128-row tile would be half empty
-    if (narrow) {
-        if (tail_k) launch<1, 4, true>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);
-        else launch<1, 4, false>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);
-    } else {
-        if (tail_k) launch<2, 2, true>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);
-        else launch<2, 2, false>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);
-    }
+    // tile shape: 64 x 256 for the 64-channel layers (a 128-row tile would be half empty), else 128 x 128;
+    // FQ_CONV1X1_SHAPE = 22 | 14 | 12 forces one (probing)
+    static const int forced = env_int("FQ_CONV1X1_SHAPE", 0);
+    const int shape = forced ? forced : (Cout <= 64 ? 14 : 22);
+#define FQ_C1_LAUNCH(WM, WN)                                                                                  \
+    do {                                                                                                      \
+        if (tail_k) launch<WM, WN, true>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);    \
+        else launch<WM, WN, false>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);          \
+    } while (0)
+    if (shape == 14) FQ_C1_LAUNCH(1, 4);
+    else if (shape == 12) FQ_C1_LAUNCH(1, 2);
+    else FQ_C1_LAUNCH(2, 2);
+#undef FQ_C1_LAUNCH
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }
