@@ -23,6 +23,7 @@ The JSON line also carries
                  mean launch duration measured with HIP events on the launch stream inside the timed region;
                  `traffic` is STATIC (PMC counters of the committed profile of this configuration), and says so;
   roofline_bias_add_absmax / roofline_add_absmax : the two kernels pass 1's maxima ride on;
+  roofline_conv_stem_f32 : the same for the 7x7 stride-2 stem (fq_conv_stem_f32);
   roofline_conv1x1_f32 : the float forward's 1x1 convolutions on the fp32 matrix cores (fq_conv1x1_f32, statistic in the
                  epilogue): 2 x MAC / summed launch durations against the 157.3 TFLOP/s dense fp32 MFMA peak;
   cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded sample on this
@@ -237,6 +238,22 @@ def _c1_flops(a, k):                # conv1x1_f32(x, wt, bias, stride, ...): 2 x
 
 def _c1_bytes(a, k):                # x read once, Wt, y written (+ the ReLU copy)
     n, cin, cout, ho, wo = _c1_shape(a, k)
+    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
+
+
+def _stem_shape(a, k):              # conv_stem_f32(x, wp, bias, cout, kernel, stride, pad, ...)
+    x, cout, (r, s_), stride, pad = a[0], int(a[3]), a[4], int(a[5]), int(a[6])
+    ho, wo = (int(x.shape[2]) + 2 * pad - r) // stride + 1, (int(x.shape[3]) + 2 * pad - s_) // stride + 1
+    return int(x.shape[0]), int(x.shape[1]), cout, ho, wo, r * s_
+
+
+def _stem_flops(a, k):
+    n, cin, cout, ho, wo, taps = _stem_shape(a, k)
+    return 2.0 * n * cout * ho * wo * cin * taps
+
+
+def _stem_bytes(a, k):
+    n, cin, cout, ho, wo, taps = _stem_shape(a, k)
     return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
 
 
@@ -666,12 +683,13 @@ def main():
             raise RuntimeError("producer rooflines are measured at N = 1")
         with CallTimer(_native, "bias_add_absmax", _bias_add_bytes) as kt_b, CallTimer(_native, "add_absmax", _add_bytes) as kt_a, \
                 CallTimer(_native, "bias_add_hist", _bias_add_bytes) as kt_bh, CallTimer(_native, "add_hist", _add_bytes) as kt_ah, \
-                CallTimer(_native, "conv1x1_f32", _c1_bytes, _c1_flops) as kt_c1:
+                CallTimer(_native, "conv1x1_f32", _c1_bytes, _c1_flops) as kt_c1, \
+                CallTimer(_native, "conv_stem_f32", _stem_bytes, _stem_flops) as kt_st:
             make_workdir(3 * world - 1, shape, dev_index)
             extra = DeviceBatches(3 * world, B, HW, rank, world, device)
             eq = Quantity(model)
             eq._activation_cache_budget = lambda: 0          # every batch through the second forward: all 69 producers fused
-            kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = kt_c1.enabled = True
+            kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = kt_c1.enabled = kt_st.enabled = True
             eq.activation_quantize(extra)
             torch.cuda.synchronize()
             del extra, eq
@@ -695,6 +713,12 @@ def main():
             "bias, the pass's statistic and the following ReLU in the epilogue: both passes of three batches, every layer size")
         if c1:
             result["roofline_conv1x1_f32"] = c1
+        stem = mfma_f32_roofline(
+            "conv_stem_f32_absmax_kernel / conv_stem_f32_hist_kernel", kt_st,
+            "the float forward's 7x7 stride-2 stem (0.118 GMAC per image) as an implicit GEMM on v_mfma_f32_32x32x2_f32, taps padded "
+            "7 -> 8 (the flops counted are the 147 real taps), bias + statistic + ReLU in the epilogue; writes 2 x 822 MB per launch")
+        if stem:
+            result["roofline_conv_stem_f32"] = stem
     except Exception as e:
         if world == 1:
             result["roofline_bias_add_absmax"] = {"error": repr(e)}

@@ -201,6 +201,18 @@ int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y,
                    int Win, int Cout, int stride, float* max_inout, const float* interval, int64_t* hist_row,
                    fq_stream_t stream);
 
+/* The float stem convolution of the calibration forward (ResNet-50/101's conv1: 7x7, stride 2, 3 -> Cout <= 64 channels,
+ * any padding) on the fp32 matrix cores, same epilogue contract as fq_conv1x1_f32 (bias, relu_out, and exactly one of
+ * {max_inout, hist_row + interval} or neither).  wp: the weights PACKED as fp32 [fq_conv_stem_f32_packed_rows()][64],
+ * 16-byte aligned: W[co][c][r][s] at row (c*R + r)*8 + s, column co; zero for s >= S and co >= Cout (the tap axis is
+ * padded to 8 so that a k-pair of the MFMA is an (even, odd) column pair of the stride-2 input).
+ * x: fp32 [N][Cin][H][W]; y: fp32 [N][Cout][Hout][Wout], Hout = (H + 2 pad - R)/stride + 1.
+ * FQ_ERR_UNSUPPORTED for any other (Cin, R, S, stride) or Cout > 64: callers keep the library convolution there. */
+int fq_conv_stem_f32_packed_rows(int Cin, int R, int S);
+int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* y, float* relu_out, int N, int Cin, int H,
+                     int W, int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval,
+                     int64_t* hist_row, fq_stream_t stream);
+
 /* Quantity.forward (new_quantity_op.py:52-58) fused with the layout change the MFMA kernel wants:
  *   y[n][hw][c] = (int8) clamp(rint(x[n][c][hw] * 2^ib), -128, 127),  c in [C, Cpad) = 0
  * x: fp32 [N][C][HW] (NCHW), y: int8 [N][HW][Cpad] (NHWC), Cpad >= C, Cpad % 4 == 0 (use a multiple

@@ -1,0 +1,273 @@
+// fq_conv_stem_f32.hip -- the float stem convolution of the calibration forward (7x7, stride 2, 3 input channels -> <= 64
+// output channels: ResNet-50/101's conv1) on the fp32 matrix cores, with the calibration's statistic in the epilogue.
+//
+// Companion of fq_conv1x1_f32.hip: after the 1x1 layers the stem is the most expensive single launch of the float forward
+// (1.4 ms of library convolution + 0.35 ms of bias-add producer per 256 images, twice: pass 2 re-runs the prefix of the
+// network).  Here it is an implicit GEMM  D[co][position] = sum_k W[co][k] * patch[k][position]  with k = (c, r, s) and
+// the tap axis s padded from 7 to 8 (zero weights), so that K = 3 * 7 * 8 = 168 = 84 steps of v_mfma_f32_32x32x2_f32.
+//
+// A persistent workgroup (4 waves) keeps the whole weight matrix in LDS (168 x 64 floats, 43 KB) and walks over output
+// tiles of 8 rows x 16 columns; wave w owns rows 2w, 2w+1, so the 32 columns of its MFMA tile are (dy, dx) = (j >> 4,
+// j & 15) and it produces all 64 output channels for them (two MFMA tiles sharing the B operand).  The tile's input
+// patch (3 x 21 x 38 floats, zero outside the image) is staged in LDS with even and odd columns in separate planes:
+// for a stride-2 convolution all lanes of a k-pair (s = 2q + h, h = lane >> 5) then read consecutive words -- the
+// address of every operand read is a per-lane base plus a compile-time immediate, no address arithmetic in the loop,
+// no bank conflicts (plane pitch 20: dy moves the read by 16 banks).  Two patch buffers: the next tile's patch is
+// fetched into registers before this tile's MFMAs and stored after them, one barrier per tile.
+//
+// Numerics: an fmaf chain over k in the order (c, r, s) from 0, then one rounding for the bias; deterministic; not
+// bit-identical to the library's convolution (summation order), like fq_conv1x1_f32.
+#include "fq_common.h"
+#include "fq_producer_stat.h"
+
+namespace fq {
+namespace {
+
+constexpr int kT = 256;
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+template <int CIN, int R, int S>
+struct StemShape {
+    static constexpr int STRIDE = 2;
+    static constexpr int S8 = (S + 1) & ~1;                   // taps padded to an even count
+    static constexpr int KP = CIN * R * S8;                   // padded reduction length
+    static constexpr int STEPS = KP / 2;
+    static constexpr int TH = 8, TW = 16;                     // output tile
+    static constexpr int PH = STRIDE * (TH - 1) + R;          // 21 input rows
+    static constexpr int PW = STRIDE * (TW - 1) + S8;         // 38 input columns (the padded tap reads one more)
+    static constexpr int PC = 20;                             // words per (row, parity) plane: >= PW / 2, = 4 mod 8
+    static constexpr int PATCH = CIN * PH * 2 * PC;           // floats per patch buffer
+    static constexpr int NFILL = (CIN * PH * PW + kT - 1) / kT;
+    static constexpr int COUT = 64;
+    static constexpr int kFloats = KP * COUT + 2 * PATCH + COUT;
+    static_assert(PW / 2 <= PC && (PC % 8) == 4, "patch plane pitch");
+};
+
+struct StemArgs {
+    const float* x;           // [N][CIN][H][W]
+    const float* wp;          // [KP][64]: W[co][c][r][s] at row (c * R + r) * S8 + s, zero for s >= S and co >= Cout
+    const float* bias;        // [Cout] or null
+    float* y;                 // [N][Cout][Hout][Wout]
+    float* relu;              // or null
+    int H, W, Hout, Wout, Cout, pad;
+    unsigned tiles_x, tiles_y, tiles;      // per image: tiles_y x tiles_x; tiles = N * tiles_y * tiles_x
+    int stream_stores;
+};
+
+struct NoStat {
+    __device__ __forceinline__ void add(float) {}
+};
+
+template <int CIN, int R, int S, typename Stat>
+__device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float* smem) {
+    typedef StemShape<CIN, R, S> G;
+    float* Wl = smem;                                         // [KP][64]
+    float* P = smem + G::KP * G::COUT;                        // [2][PATCH]
+    float* s_bias = P + 2 * G::PATCH;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned j = lane & 31u, h = lane >> 5, dy = j >> 4, dx = j & 15u;
+
+    for (unsigned i = tid; i < (unsigned)(G::KP * G::COUT / 4); i += kT)
+        reinterpret_cast<float4*>(Wl)[i] = reinterpret_cast<const float4*>(a.wp)[i];
+    if (tid < (unsigned)G::COUT) s_bias[tid] = (a.bias && (int)tid < a.Cout) ? a.bias[tid] : 0.0f;
+
+    const unsigned per_img = a.tiles_x * a.tiles_y;
+    float stage[G::NFILL];
+    auto fetch = [&](unsigned t) {                            // the input patch of tile t -> registers (zero outside the image)
+        const unsigned n = t / per_img, rem = t - n * per_img, ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+        const int iy0 = (int)(ty * G::TH) * G::STRIDE - a.pad, ix0 = (int)(tx * G::TW) * G::STRIDE - a.pad;
+        const float* __restrict__ xn = a.x + (size_t)n * CIN * a.H * a.W;
+#pragma unroll
+        for (int f = 0; f < G::NFILL; ++f) {
+            const unsigned e = tid + (unsigned)f * kT;
+            const unsigned c = e / (G::PH * G::PW), r2 = e - c * (G::PH * G::PW), row = r2 / G::PW, col = r2 - row * G::PW;
+            const int iy = iy0 + (int)row, ix = ix0 + (int)col;
+            const bool in = e < (unsigned)(CIN * G::PH * G::PW) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const size_t off = in ? ((size_t)c * a.H + iy) * a.W + ix : 0;
+            const float v = xn[off];
+            stage[f] = in ? v : 0.0f;
+        }
+    };
+    auto stash = [&](int buf) {                               // registers -> LDS, even / odd columns in separate planes
+#pragma unroll
+        for (int f = 0; f < G::NFILL; ++f) {
+            const unsigned e = tid + (unsigned)f * kT;
+            const unsigned c = e / (G::PH * G::PW), r2 = e - c * (G::PH * G::PW), row = r2 / G::PW, col = r2 - row * G::PW;
+            if (e < (unsigned)(CIN * G::PH * G::PW))
+                P[buf * G::PATCH + ((c * G::PH + row) * 2 + (col & 1u)) * G::PC + (col >> 1)] = stage[f];
+        }
+    };
+
+    unsigned t = blockIdx.x;
+    if (t < a.tiles) fetch(t);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    const float* wrow = Wl + h * G::COUT + j;                                            // + step * 128 (+ 32 for the upper channels)
+    const unsigned lane_patch = ((4u * wave + 2u * dy) * 2u + h) * G::PC + dx;            // + ((c * PH + r) * 2) * PC + q
+    for (; t < a.tiles; t += gridDim.x) {
+        const unsigned tn = t + gridDim.x;
+        if (tn < a.tiles) fetch(tn);
+        const float* prow = P + buf * G::PATCH + lane_patch;
+        f16v acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
+#pragma unroll
+        for (int c = 0; c < CIN; ++c)
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int q = 0; q < G::S8 / 2; ++q) {
+                    const int step = (c * R + r) * (G::S8 / 2) + q;
+                    const float b = prow[((c * G::PH + r) * 2) * G::PC + q];
+                    const float a0 = wrow[step * 2 * G::COUT], a1 = wrow[step * 2 * G::COUT + 32];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
+                }
+        // epilogue: D[i][j]: j = lane & 31 -> (dy, dx), i = (e & 3) + 8 (e >> 2) + 4 h -> output channel (+ 32 for acc1)
+        {
+            const unsigned n = t / per_img, rem = t - n * per_img, ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+            const int oy = (int)(ty * G::TH + 2u * wave + dy), ox = (int)(tx * G::TW + dx);
+            if (oy < a.Hout && ox < a.Wout) {
+                const size_t plane = (size_t)a.Hout * a.Wout;
+                const size_t base = (size_t)n * a.Cout * plane + (size_t)oy * a.Wout + ox;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int co = 32 * half + (e & 3) + 8 * (e >> 2) + 4 * (int)h;
+                        if (co < a.Cout) {
+                            const float val = (half ? acc1[e] : acc0[e]) + s_bias[co];
+                            const size_t o = base + (size_t)co * plane;
+                            if (a.stream_stores) {
+                                __builtin_nontemporal_store(val, a.y + o);
+                                if (a.relu) __builtin_nontemporal_store(relu_like_torch(val), a.relu + o);
+                            } else {
+                                a.y[o] = val;
+                                if (a.relu) a.relu[o] = relu_like_torch(val);
+                            }
+                            stat.add(val);
+                        }
+                    }
+                }
+            }
+        }
+        if (tn < a.tiles) stash(buf ^ 1);                     // that buffer was last read one tile ago: every wave is past it
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+template <int CIN, int R, int S>
+__global__ __launch_bounds__(kT) void conv_stem_f32_kernel(const StemArgs a) {
+    extern __shared__ float smem[];
+    NoStat st;
+    stem_tiles<CIN, R, S>(a, st, smem);
+}
+
+template <int CIN, int R, int S>
+__global__ __launch_bounds__(kT) void conv_stem_f32_absmax_kernel(const StemArgs a, unsigned int* __restrict__ max_bits) {
+    extern __shared__ float smem[];
+    MaxStat st;
+    stem_tiles<CIN, R, S>(a, st, smem);
+    publish_max<kT>(st.m, max_bits);
+}
+
+template <int CIN, int R, int S>
+__global__ __launch_bounds__(kT) void conv_stem_f32_hist_kernel(const StemArgs a, const float* __restrict__ interval,
+                                                                unsigned long long* __restrict__ hist_row, const int allow_fast) {
+    extern __shared__ float smem[];
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kT) s_bins[b] = 0u;
+    __syncthreads();
+    const float iv = *interval;
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (allow_fast && fast_quotient_ok(iv)) {
+        HistStat<true> st{s_bins, park, iv, 1.0f / iv};
+        stem_tiles<CIN, R, S>(a, st, smem);
+    } else {
+        HistStat<false> st{s_bins, park, iv, 1.0f / iv};
+        stem_tiles<CIN, R, S>(a, st, smem);
+    }
+    hist_flush<kT>(s_bins, hist_row);
+}
+
+template <typename K>
+int resident_per_cu(K kernel, size_t dyn) {
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kernel, kT, dyn) != hipSuccess || n < 1) n = 1;
+    return n;
+}
+
+template <int CIN, int R, int S>
+int launch_stem(StemArgs a, float* max_inout, const float* interval, int64_t* hist_row, int fast, hipStream_t st) {
+    typedef StemShape<CIN, R, S> G;
+    const size_t dyn = (size_t)G::kFloats * sizeof(float);
+    // persistent: every workgroup loads the 43 KB weight matrix once and walks over tiles
+    if (hist_row) {
+        auto k = conv_stem_f32_hist_kernel<CIN, R, S>;
+        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+        static const int per_cu = resident_per_cu(k, dyn);
+        unsigned grid = (unsigned)(kCUs * per_cu);
+        if (grid > a.tiles) grid = a.tiles;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kT), dyn, st, a, interval, reinterpret_cast<unsigned long long*>(hist_row), fast);
+    } else if (max_inout) {
+        auto k = conv_stem_f32_absmax_kernel<CIN, R, S>;
+        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+        static const int per_cu = resident_per_cu(k, dyn);
+        unsigned grid = (unsigned)(kCUs * per_cu);
+        if (grid > a.tiles) grid = a.tiles;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kT), dyn, st, a, reinterpret_cast<unsigned int*>(max_inout));
+    } else {
+        auto k = conv_stem_f32_kernel<CIN, R, S>;
+        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+        static const int per_cu = resident_per_cu(k, dyn);
+        unsigned grid = (unsigned)(kCUs * per_cu);
+        if (grid > a.tiles) grid = a.tiles;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kT), dyn, st, a);
+    }
+    return FQ_OK;
+}
+
+}  // namespace
+}  // namespace fq
+
+using namespace fq;
+
+extern "C" int fq_conv_stem_f32_packed_rows(int Cin, int R, int S) {
+    if (Cin == 3 && R == 7 && S == 7) return StemShape<3, 7, 7>::KP;
+    return FQ_ERR_UNSUPPORTED;
+}
+
+extern "C" int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* y, float* relu_out, int N, int Cin,
+                                int H, int W, int Cout, int R, int S, int stride, int pad, float* max_inout,
+                                const float* interval, int64_t* hist_row, fq_stream_t stream) {
+    if (N < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return FQ_ERR_INVALID_ARG;
+    if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
+    if (hist_row && !interval) return FQ_ERR_INVALID_ARG;
+    if (!(Cin == 3 && R == 7 && S == 7 && stride == 2) || Cout > 64) return FQ_ERR_UNSUPPORTED;
+    if (H + 2 * pad < R || W + 2 * pad < S) return FQ_ERR_INVALID_ARG;
+    if (N == 0) return FQ_OK;
+    if (!x || !wp || !y) return FQ_ERR_INVALID_ARG;
+    if (reinterpret_cast<uintptr_t>(wp) & 15u) return FQ_ERR_INVALID_ARG;
+    StemArgs a;
+    a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.relu = relu_out;
+    a.H = H; a.W = W; a.Cout = Cout; a.pad = pad;
+    a.Hout = (H + 2 * pad - R) / stride + 1;
+    a.Wout = (W + 2 * pad - S) / stride + 1;
+    a.tiles_x = (unsigned)((a.Wout + 15) / 16);
+    a.tiles_y = (unsigned)((a.Hout + 7) / 8);
+    const size_t tiles = (size_t)N * a.tiles_x * a.tiles_y;
+    if (tiles >= 0x7fffffffULL) return FQ_ERR_UNSUPPORTED;
+    a.tiles = (unsigned)tiles;
+    const size_t out_elems = (size_t)N * Cout * a.Hout * a.Wout;
+    a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);
+    static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
+    const int rc = launch_stem<3, 7, 7>(a, max_inout, interval, hist_row, fast, as_stream(stream));
+    if (rc != FQ_OK) return rc;
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}

@@ -98,6 +98,10 @@ def lib():
     L.fq_add_hist_f32.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
     L.fq_conv1x1_f32.restype = ci
     L.fq_conv1x1_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [vp, vp, vp, vp]
+    L.fq_conv_stem_f32_packed_rows.restype = ci
+    L.fq_conv_stem_f32_packed_rows.argtypes = [ci, ci, ci]
+    L.fq_conv_stem_f32.restype = ci
+    L.fq_conv_stem_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [vp, vp, vp, vp]
     L.fq_conv2d_i8_stem.restype = ci
     L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
@@ -352,6 +356,50 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
         mp = max_dev.data_ptr() + 4 * int(row)
     _check(lib().fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
                                 _relu_ptr(relu_out, y), N, Cin, H, W, Cout, s, mp, ivp, hp, _stream(x)), "fq_conv1x1_f32")
+    return y
+
+
+def conv_stem_f32_supported(weight, stride):
+    """True when fq_conv_stem_f32 takes a convolution with this weight [Cout, Cin, R, S] and stride."""
+    cout, cin, r, s = (int(v) for v in weight.shape)
+    return stride == 2 and cout <= 64 and lib().fq_conv_stem_f32_packed_rows(cin, r, s) > 0
+
+
+def pack_stem_weight(weight):
+    """[Cout, Cin, R, S] -> the [Cin*R*8, 64] layout fq_conv_stem_f32 reads (taps padded to 8, channels to 64, zeros)."""
+    cout, cin, r, s = (int(v) for v in weight.shape)
+    rows = lib().fq_conv_stem_f32_packed_rows(cin, r, s)
+    assert rows > 0 and cout <= 64, "fq_conv_stem_f32: unsupported stem shape"
+    wp = torch.zeros((cin, r, rows // (cin * r), 64), dtype=torch.float32, device=weight.device)
+    wp[:, :, :s, :cout] = weight.detach().permute(1, 2, 3, 0)
+    return wp.view(rows, 64)
+
+
+def conv_stem_f32(x, wp, bias, cout, kernel, stride, pad, max_dev=None, interval_dev=None, hist_dev=None, row=None,
+                  relu_out=None, out=None):
+    """fq_conv_stem_f32: the float stem convolution (kernel = (R, S), e.g. 7x7 stride 2) of x [N, Cin, H, W] with the packed
+    weights wp (pack_stem_weight); statistics / relu_out / out as in conv1x1_f32.  Returns y."""
+    _need_cuda(x, torch.float32, "fq_conv_stem_f32")
+    _need_cuda(wp, torch.float32, "fq_conv_stem_f32")
+    assert x.dim() == 4 and x.is_contiguous() and wp.is_contiguous()
+    N, Cin, H, W = (int(v) for v in x.shape)
+    R, S = int(kernel[0]), int(kernel[1])
+    shape = (N, int(cout), (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+    assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
+    if bias is not None:
+        _need_cuda(bias, torch.float32, "fq_conv_stem_f32")
+        assert bias.is_contiguous() and bias.numel() == cout
+    mp = ivp = hp = None
+    if hist_dev is not None:
+        ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
+    elif max_dev is not None:
+        _need_cuda(max_dev, torch.float32, "fq_conv_stem_f32")
+        assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
+        mp = max_dev.data_ptr() + 4 * int(row)
+    _check(lib().fq_conv_stem_f32(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                  _relu_ptr(relu_out, y), N, Cin, H, W, int(cout), R, S, int(stride), int(pad), mp, ivp, hp,
+                                  _stream(x)), "fq_conv_stem_f32")
     return y
 
 

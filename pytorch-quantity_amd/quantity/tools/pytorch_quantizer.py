@@ -156,12 +156,13 @@ class Quantity(object):
     # costs a second 4 B/element read and runs that kernel against the write-back of its own input).
     # Only modules whose decomposition was verified in pass 1 take part.
     fuse_hist = True
-    # The float 1x1 convolutions themselves (36 of ResNet-50's 53): fq_conv1x1_f32 computes them on the fp32 matrix cores
-    # (exact fp32, fixed summation order) with the bias, the statistic of the pass and the following ReLU in its epilogue,
-    # so for these layers there is no library convolution and no bias-add pass at all.  Each module is checked once per
+    # The float 1x1 convolutions themselves (36 of ResNet-50's 53) and the 7x7 stride-2 stem: fq_conv1x1_f32 /
+    # fq_conv_stem_f32 compute them on the fp32 matrix cores (exact fp32, fixed summation order) with the bias, the statistic
+    # of the pass and the following ReLU in the epilogue, so for these layers there is no library convolution and no
+    # bias-add pass at all.  Each module is checked once per
     # process against torch's own forward (|difference| <= 1e-5 * (|W|*|x| + |b|): summation order only; the abs-max and
     # the ReLU copy bit for bit); a module that disagrees keeps the path above.
-    own_conv1x1 = True
+    own_conv1x1 = os.environ.get("FQ_OWN_CONV1X1", "1") != "0"       # FQ_OWN_CONV1X1=0: A/B against the library convolutions
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -415,11 +416,12 @@ class Quantity(object):
                 if m not in ctl["fuse_warm"] and not (m.__dict__.get(_FUSION_VERIFIED) or m.__dict__.get(_C1_VERIFIED)):
                     ctl["fuse_warm"].add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
                     return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
-                if self.own_conv1x1 and self._conv1x1_eligible(m, x):
-                    ctl["fuse_bias"] = (m, ("c1", x))       # the hook of this very call runs the whole convolution
-                    s = m.stride[0]
-                    return torch.empty((x.shape[0], m.out_channels, (x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1),
-                                       dtype=torch.float32, device=x.device)
+                own = self._own_conv_kind(m, x) if self.own_conv1x1 else None
+                if own is not None:
+                    ctl["fuse_bias"] = (m, (own, x))        # the hook of this very call runs the whole convolution
+                    s, p, k = m.stride[0], m.padding[0], m.kernel_size
+                    return torch.empty((x.shape[0], m.out_channels, (x.shape[2] + 2 * p - k[0]) // s + 1,
+                                        (x.shape[3] + 2 * p - k[1]) // s + 1), dtype=torch.float32, device=x.device)
                 y = m._conv_forward(x, m.weight, None)
                 ctl["fuse_bias"] = (m, x)                   # the hook of this very call adds the bias
                 return y
@@ -459,51 +461,65 @@ class Quantity(object):
         return patched
 
     @staticmethod
-    def _conv1x1_eligible(m, x):
-        return (m.kernel_size == (1, 1) and m.padding in ((0, 0), 0) and m.dilation == (1, 1) and m.groups == 1
-                and m.stride[0] == m.stride[1] and x.dim() == 4 and x.is_contiguous() and m.out_channels % 4 == 0
-                and not m.__dict__.get(_C1_OFF) and x.numel() < 2 ** 32 - 1
-                and x.shape[0] * m.out_channels * x.shape[2] * x.shape[3] < 2 ** 32 - 1)
+    def _own_conv_kind(m, x):
+        """"c1" (fq_conv1x1_f32), "stem" (fq_conv_stem_f32) or None: which own float convolution takes this call."""
+        if (m.__dict__.get(_C1_OFF) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
+                or not x.is_contiguous() or isinstance(m.padding, str) or m.padding[0] != m.padding[1]
+                or x.numel() >= 2 ** 32 - 1 or x.shape[0] * m.out_channels * x.shape[2] * x.shape[3] >= 2 ** 32 - 1):
+            return None
+        if m.kernel_size == (1, 1) and m.padding == (0, 0) and m.out_channels % 4 == 0:
+            return "c1"
+        if (x.shape[2] + 2 * m.padding[0] >= m.kernel_size[0] and x.shape[3] + 2 * m.padding[1] >= m.kernel_size[1]
+                and _native.conv_stem_f32_supported(m.weight, m.stride[0])):
+            return "stem"
+        return None
 
     @staticmethod
-    def _conv1x1_weight(m):
-        """Wt [Cin][Cout] of a 1x1 nn.Conv2d, rebuilt when the parameter was written to or replaced."""
+    def _own_conv_weight(m, kind):
+        """The weights in the layout the own kernel reads (Wt [Cin][Cout] / the packed stem matrix), rebuilt when the
+        parameter was written to or replaced."""
         w = m.weight
-        tag = (w._version, w.data_ptr(), w.device)
+        tag = (kind, w._version, w.data_ptr(), w.device)
         cached = m.__dict__.get(_C1_WT)
         if cached is None or cached[0] != tag:
-            cached = (tag, w.detach().view(w.shape[0], w.shape[1]).t().contiguous())
+            packed = (w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if kind == "c1" else _native.pack_stem_weight(w))
+            cached = (tag, packed)
             m.__dict__[_C1_WT] = cached
         return cached[1]
 
-    def _finish_own_conv1x1(self, module, m, x, key, output):
-        """Forward-hook half of a 1x1 convolution that runs on fq_conv1x1_f32: `output` is the empty tensor the patched
-        forward returned.  Returns True when the statistic of `output` is done."""
+    def _finish_own_conv(self, module, m, kind, x, key, output):
+        """Forward-hook half of a convolution that runs on fq_conv1x1_f32 / fq_conv_stem_f32: `output` is the empty tensor
+        the patched forward returned.  Returns True when the statistic of `output` is done."""
         ctl = self._hook_ctl
         coll = ctl["fuse_collector"]
-        wt, s = self._conv1x1_weight(m), m.stride[0]
+        wq, s = self._own_conv_weight(m, kind), m.stride[0]
+        if kind == "c1":
+            def run(**kw):
+                return _native.conv1x1_f32(x, wq, m.bias, s, **kw)
+        else:
+            def run(**kw):
+                return _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
         if module is not m or coll is None or key is None:     # not a cared tensor: the convolution only
-            _native.conv1x1_f32(x, wt, m.bias, s, out=output)
+            run(out=output)
             return False
         row = coll.row_of(key)
         if ctl["fuse_stat"] == "hist":                         # pass 2 (verified in pass 1)
-            self._run_with_relu(m, output, lambda r: _native.conv1x1_f32(
-                x, wt, m.bias, s, interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row, relu_out=r, out=output))
+            self._run_with_relu(m, output, lambda r: run(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row,
+                                                         relu_out=r, out=output))
             ctl["hist_fused"] += 1
             return True
-        if not m.__dict__.get(_C1_VERIFIED):               # first use: against torch's own forward, once per process
+        if not m.__dict__.get(_C1_VERIFIED):                   # first use: against torch's own forward, once per process
             ref = torch.nn.Conv2d.forward(m, x)
-            bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride)
+            bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
             scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
-            own = _native.conv1x1_f32(x, wt, m.bias, s, max_dev=scratch, row=0)
+            own = run(max_dev=scratch, row=0)
             if not (bool(((own - ref).abs() <= _C1_TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
                 m.__dict__[_C1_OFF] = True                     # this module keeps the library convolution from now on
                 output.copy_(ref)
                 return False
             m.__dict__[_C1_VERIFIED] = True
         ctl["fuse_verified"].add(m)
-        self._run_with_relu(m, output, lambda r: _native.conv1x1_f32(x, wt, m.bias, s, max_dev=coll.max_device, row=row,
-                                                                     relu_out=r, out=output))
+        self._run_with_relu(m, output, lambda r: run(max_dev=coll.max_device, row=row, relu_out=r, out=output))
         coll.note_max_refreshed()
         ctl["own_conv1x1"] = ctl.get("own_conv1x1", 0) + 1
         return True
@@ -532,8 +548,8 @@ class Quantity(object):
         m, x = pending
         ctl = self._hook_ctl
         coll = ctl["fuse_collector"]
-        if isinstance(x, tuple) and isinstance(x[0], str):  # 1x1 convolution on fq_conv1x1_f32: output is still empty
-            return self._finish_own_conv1x1(module, m, x[1], key, output)
+        if isinstance(x, tuple) and isinstance(x[0], str):  # a convolution on fq_conv1x1_f32 / fq_conv_stem_f32: output is still empty
+            return self._finish_own_conv(module, m, x[0], x[1], key, output)
         if isinstance(x, tuple):                            # Eltwise: output is an empty tensor waiting for x + y
             a, b = x
             if module is not m or coll is None or key is None:

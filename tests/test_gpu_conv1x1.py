@@ -210,3 +210,77 @@ def test_a_module_that_disagrees_keeps_the_library_convolution(monkeypatch):
     with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=3) as tmp:
         q2 = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
         assert dict(q2.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77))) == bits
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fq_conv_stem_f32: the 7x7 stride-2 stem on the same matrix cores, same epilogue contract
+STEM_SHAPES = [  # N, H, W, Cout, pad
+    (2, 224, 224, 64, 3),         # ResNet-50's conv1
+    (3, 64, 64, 64, 3),
+    (2, 37, 53, 64, 3),           # odd planes: partial tiles both ways (Hout 19, Wout 27)
+    (1, 16, 16, 32, 3),           # Cout 32: the upper MFMA tile is never stored
+    (2, 31, 31, 48, 0),           # no padding
+    (5, 7, 7, 64, 3),             # one tap row of real data per tile; Hout = Wout = 4
+    (2, 40, 24, 20, 1),           # Cout 20, pad 1
+]
+
+
+def _stem_case(shape, seed, integer):
+    N, H, W, cout, pad = shape
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if integer:
+        x = torch.randint(-8, 9, (N, 3, H, W), device="cuda", generator=g).float()
+        w = torch.randint(-8, 9, (cout, 3, 7, 7), device="cuda", generator=g).float()
+        b = torch.randint(-100, 101, (cout,), device="cuda", generator=g).float()
+    else:
+        x = torch.randn(N, 3, H, W, device="cuda", generator=g)
+        w = torch.randn(cout, 3, 7, 7, device="cuda", generator=g) * 147 ** -0.5
+        b = torch.randn(cout, device="cuda", generator=g)
+    return x, w, b, pad
+
+
+def _stem(nat, x, w, b, pad, **kw):
+    return nat.conv_stem_f32(x, nat.pack_stem_weight(w), b, w.shape[0], (7, 7), 2, pad, **kw)
+
+
+@pytest.mark.parametrize("shape", STEM_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_stem_exact_on_integer_valued_data(nat, shape):
+    x, w, b, pad = _stem_case(shape, 21, integer=True)            # |sum| <= 147 * 64 + 100: exact in any order
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2, padding=pad)
+    assert torch.equal(_stem(nat, x, w, b, pad).double(), ref)
+    ref0 = torch.nn.functional.conv2d(x.double(), w.double(), None, stride=2, padding=pad)
+    assert torch.equal(_stem(nat, x, w, None, pad).double(), ref0)
+
+
+@pytest.mark.parametrize("shape", STEM_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_stem_gaussian_data_statistics_and_relu(nat, shape):
+    x, w, b, pad = _stem_case(shape, 22, integer=False)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2, padding=pad)
+    bound = torch.nn.functional.conv2d(x.abs().double(), w.abs().double(), b.abs().double(), stride=2, padding=pad)
+    y = _stem(nat, x, w, b, pad)
+    assert bool(((y.double() - ref).abs() <= 1e-5 * bound).all())
+    assert torch.equal(y, _stem(nat, x, w, b, pad))
+    mx = torch.tensor([0.0, 1e9, 0.0], device="cuda")
+    r = torch.empty_like(y)
+    y1 = _stem(nat, x, w, b, pad, max_dev=mx, row=2, relu_out=r)
+    assert torch.equal(y1, y) and torch.equal(r, torch.relu(y)) and mx.tolist() == [0.0, 1e9, float(y.abs().max())]
+    iv = torch.tensor([1.0, float(y.abs().max()) / 2048 + 1e-12], device="cuda")
+    hist = torch.zeros(2, 2048, dtype=torch.int64, device="cuda")
+    hist[1, 9] = 3
+    want = hist.clone()
+    y2 = _stem(nat, x, w, b, pad, interval_dev=iv, hist_dev=hist, row=1, relu_out=r)
+    nat.hist2048_seg([y], [1], iv, want)
+    assert torch.equal(y2, y) and torch.equal(r, torch.relu(y)) and torch.equal(hist, want)
+
+
+def test_stem_unsupported_shapes_are_refused(nat):
+    L = nat.lib()
+    assert L.fq_conv_stem_f32_packed_rows(3, 7, 7) == 168
+    assert L.fq_conv_stem_f32_packed_rows(3, 3, 3) == -4 and L.fq_conv_stem_f32_packed_rows(1, 7, 7) == -4
+    x = torch.zeros(1, 3, 16, 16, device="cuda")
+    wp = torch.zeros(168, 64, device="cuda")
+    y = torch.zeros(1, 64, 8, 8, device="cuda")
+    call = lambda cin, cout, r, s, stride: L.fq_conv_stem_f32(x.data_ptr(), wp.data_ptr(), None, y.data_ptr(), None, 1, cin, 16, 16,
+                                                              cout, r, s, stride, 3, None, None, None, None)
+    assert call(3, 64, 7, 7, 2) == 0
+    assert call(3, 64, 7, 7, 1) == -4 and call(3, 128, 7, 7, 2) == -4 and call(3, 64, 5, 5, 2) == -4 and call(4, 64, 7, 7, 2) == -4
