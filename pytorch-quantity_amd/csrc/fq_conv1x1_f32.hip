@@ -63,7 +63,7 @@ struct NoStat {
 };
 
 // Tile shapes: the 4 waves sit 2 x 2, each owns WM x WN MFMA tiles of 32 x 32 -> the workgroup tile is (64 WM) x (64 WN).
-// <2,2> = 128 x 128 for Cout >= 128; <1,4> = 64 x 256 for the 64-channel layers (no empty half tile).
+// <2,2> = 128 x 128 for Cout >= 128; <1,2> = 64 x 128 for the 64-channel layers (no empty half tile).
 template <int WM, int WN>
 struct Shape {
     static constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -73,6 +73,47 @@ struct Shape {
     static constexpr int kWRowStep = kT / (BM / 4);           // rows between them
     static constexpr int kFloats = 3 * kBK * (BM + BN) + BM;  // three stages of both tiles + the bias slice
 };
+
+// Epilogue of one workgroup tile.  D[i][j] has j = lane & 31 and i = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): the four rows
+// of a register quad are consecutive, so their biases come as one 16-byte LDS read; the ReLU copy, the store flavour and
+// "every row of this tile exists" are compile-time here (uniform per launch / per tile), so a value costs its add, its
+// store(s) and the statistic -- no branch, no LDS wait per value.
+template <int WM, int WN, bool kRelu, bool kStream, bool kFullM, typename Stat>
+__device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1Args& a, Stat& stat, const float* s_bias,
+                                            unsigned jbase, unsigned mbase, unsigned m0, unsigned n0, unsigned r, unsigned h) {
+    float* __restrict__ yg = a.y;
+    float* __restrict__ rg = a.relu;
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const unsigned jn = jbase + n0 + 32u * ni + r;
+        if (jn < a.cols) {
+            const unsigned n = jn / a.HWout, p = jn - n * a.HWout;
+            const unsigned col = n * a.Cout * a.HWout + p + (mbase + m0 + 4u * h) * a.HWout;   // < 2^32 (host check)
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) {
+                f4v b4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const f4v*>(s_bias + m0 + 32u * mi + 8u * q + 4u * h);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned dm = 32u * mi + (e & 3) + 8u * (e >> 2);           // compile-time row within the wave tile
+                    if (kFullM || mbase + m0 + 4u * h + dm < a.Cout) {
+                        const float val = acc[mi][ni][e] + b4[e >> 2][e & 3];
+                        const unsigned o = col + dm * a.HWout;
+                        if (kStream) {
+                            __builtin_nontemporal_store(val, yg + o);
+                            if (kRelu) __builtin_nontemporal_store(relu_like_torch(val), rg + o);
+                        } else {
+                            yg[o] = val;
+                            if (kRelu) rg[o] = relu_like_torch(val);
+                        }
+                        stat.add(val);
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int WM, int WN, bool kTailK, typename Stat>
 __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float* smem) {
@@ -201,51 +242,37 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
             }
             cur = nxt;
         }
-        // epilogue: D[i][j] has j = lane & 31 and i = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
-        float* __restrict__ yg = a.y;
-        float* __restrict__ rg = a.relu;
-#pragma unroll
-        for (int ni = 0; ni < WN; ++ni) {
-            const unsigned jn = jbase + n0 + 32u * ni + r;
-            if (jn < a.cols) {
-                const unsigned n = jn / a.HWout, p = jn - n * a.HWout;
-                const unsigned col = n * a.Cout * a.HWout + p + (mbase + m0 + 4u * h) * a.HWout;   // < 2^32 (host check)
-#pragma unroll
-                for (int mi = 0; mi < WM; ++mi) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const unsigned dm = 32u * mi + (e & 3) + 8u * (e >> 2);           // compile-time row within the wave tile
-                        if (mbase + m0 + 4u * h + dm < a.Cout) {
-                            const float val = acc[mi][ni][e] + s_bias[m0 + 4u * h + dm];
-                            const unsigned o = col + dm * a.HWout;
-                            if (FQ_C1_OFF(1)) {
-                            } else if (a.stream_stores) {
-                                __builtin_nontemporal_store(val, yg + o);
-                                if (rg) __builtin_nontemporal_store(relu_like_torch(val), rg + o);
-                            } else {
-                                yg[o] = val;
-                                if (rg) rg[o] = relu_like_torch(val);
-                            }
-                            stat.add(val);
-                        }
-                    }
-                }
+        {
+            const bool full_m = mbase + BM <= a.Cout;
+#ifdef FQ_C1_ABLATE
+            if (FQ_C1_OFF(1)) {
+            } else
+#endif
+#define FQ_C1_EPI(R, S, F) c1_epilogue<WM, WN, R, S, F>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
+            if (a.relu) {
+                if (a.stream_stores) { if (full_m) FQ_C1_EPI(true, true, true); else FQ_C1_EPI(true, true, false); }
+                else { if (full_m) FQ_C1_EPI(true, false, true); else FQ_C1_EPI(true, false, false); }
+            } else {
+                if (a.stream_stores) { if (full_m) FQ_C1_EPI(false, true, true); else FQ_C1_EPI(false, true, false); }
+                else { if (full_m) FQ_C1_EPI(false, false, true); else FQ_C1_EPI(false, false, false); }
             }
+#undef FQ_C1_EPI
         }
         __syncthreads();                                      // the next tile overwrites s_bias and stage 0
     }
 }
 
+// (3 waves per SIMD is what three 49 KB workgroups per CU need: <= 170 registers with the 64 accumulators)
 template <int WM, int WN, bool kTailK>
-__global__ __launch_bounds__(kT) void conv1x1_f32_kernel(const C1Args a) {
-    __shared__ float smem[Shape<WM, WN>::kFloats];
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_f32_kernel(const C1Args a) {
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN>::kFloats];
     NoStat st;
     conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
 }
 
 template <int WM, int WN, bool kTailK>
-__global__ __launch_bounds__(kT) void conv1x1_f32_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
-    __shared__ float smem[Shape<WM, WN>::kFloats];
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_f32_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN>::kFloats];
     MaxStat st;
     conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
     publish_max<kT>(st.m, max_bits);
@@ -254,7 +281,7 @@ __global__ __launch_bounds__(kT) void conv1x1_f32_absmax_kernel(const C1Args a, 
 template <int WM, int WN, bool kTailK>
 __global__ __launch_bounds__(kT) void conv1x1_f32_hist_kernel(const C1Args a, const float* __restrict__ interval,
                                                               unsigned long long* __restrict__ hist_row, const int allow_fast) {
-    __shared__ float smem[Shape<WM, WN>::kFloats];
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN>::kFloats];
     __shared__ unsigned int s_bins[FQ_BINS + kWave];
     for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kT) s_bins[b] = 0u;
     __syncthreads();
@@ -333,17 +360,16 @@ extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias
     static const int hist_per_cu = env_int("FQ_CONV1X1_HIST_WG_PER_CU", 0);   // 0: what the occupancy query says
     static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
     const bool tail_k = (Cin % kBK) != 0;
-    // tile shape: 64 x 256 for the 64-channel layers (a 128-row tile would be half empty), else 128 x 128;
-    // FQ_CONV1X1_SHAPE = 22 | 14 | 12 forces one (probing)
+    // tile shape: 64 x 128 for the 64-channel layers (a 128-row tile would be half empty), else 128 x 128;
+    // FQ_CONV1X1_SHAPE = 22 | 12 forces one (probing)
     static const int forced = env_int("FQ_CONV1X1_SHAPE", 0);
-    const int shape = forced ? forced : (Cout <= 64 ? 14 : 22);
+    const int shape = forced ? forced : (Cout <= 64 ? 12 : 22);
 #define FQ_C1_LAUNCH(WM, WN)                                                                                  \
     do {                                                                                                      \
         if (tail_k) launch<WM, WN, true>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);    \
         else launch<WM, WN, false>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);          \
     } while (0)
-    if (shape == 14) FQ_C1_LAUNCH(1, 4);
-    else if (shape == 12) FQ_C1_LAUNCH(1, 2);
+    if (shape == 12) FQ_C1_LAUNCH(1, 2);
     else FQ_C1_LAUNCH(2, 2);
 #undef FQ_C1_LAUNCH
     FQ_LAUNCH_CHECK();

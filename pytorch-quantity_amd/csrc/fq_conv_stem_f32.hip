@@ -58,6 +58,36 @@ struct NoStat {
     __device__ __forceinline__ void add(float) {}
 };
 
+template <bool kRelu, bool kStream, bool kFull, typename Stat>
+__device__ __forceinline__ void stem_epilogue(const f16v& acc0, const f16v& acc1, const StemArgs& a, Stat& stat, const float* s_bias,
+                                              size_t base, size_t plane, unsigned h) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float* __restrict__ yg = a.y + base;                      // channel 4 h of this lane's pixel
+    float* __restrict__ rg = kRelu ? a.relu + base : nullptr;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        f4 b4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const f4*>(s_bias + 32 * half + 8 * q + 4 * (int)h);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int dco = 32 * half + (e & 3) + 8 * (e >> 2);                    // + 4 h
+            if (kFull || dco + 4 * (int)h < a.Cout) {
+                const float val = (half ? acc1[e] : acc0[e]) + b4[e >> 2][e & 3];
+                const size_t o = (size_t)dco * plane;
+                if (kStream) {
+                    __builtin_nontemporal_store(val, yg + o);
+                    if (kRelu) __builtin_nontemporal_store(relu_like_torch(val), rg + o);
+                } else {
+                    yg[o] = val;
+                    if (kRelu) rg[o] = relu_like_torch(val);
+                }
+                stat.add(val);
+            }
+        }
+    }
+}
+
 template <int CIN, int R, int S, typename Stat>
 __device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float* smem) {
     typedef StemShape<CIN, R, S> G;
@@ -124,32 +154,24 @@ __device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float*
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
                 }
-        // epilogue: D[i][j]: j = lane & 31 -> (dy, dx), i = (e & 3) + 8 (e >> 2) + 4 h -> output channel (+ 32 for acc1)
+        // epilogue: D[i][j]: j = lane & 31 -> (dy, dx), i = (e & 3) + 8 (e >> 2) + 4 h -> output channel (+ 32 for acc1);
+        // ReLU copy / store flavour / "all 64 channels exist" are uniform: compile-time inside stem_epilogue
         {
             const unsigned n = t / per_img, rem = t - n * per_img, ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
             const int oy = (int)(ty * G::TH + 2u * wave + dy), ox = (int)(tx * G::TW + dx);
             if (oy < a.Hout && ox < a.Wout) {
                 const size_t plane = (size_t)a.Hout * a.Wout;
-                const size_t base = (size_t)n * a.Cout * plane + (size_t)oy * a.Wout + ox;
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-#pragma unroll
-                    for (int e = 0; e < 16; ++e) {
-                        const int co = 32 * half + (e & 3) + 8 * (e >> 2) + 4 * (int)h;
-                        if (co < a.Cout) {
-                            const float val = (half ? acc1[e] : acc0[e]) + s_bias[co];
-                            const size_t o = base + (size_t)co * plane;
-                            if (a.stream_stores) {
-                                __builtin_nontemporal_store(val, a.y + o);
-                                if (a.relu) __builtin_nontemporal_store(relu_like_torch(val), a.relu + o);
-                            } else {
-                                a.y[o] = val;
-                                if (a.relu) a.relu[o] = relu_like_torch(val);
-                            }
-                            stat.add(val);
-                        }
-                    }
+                const size_t base = (size_t)n * a.Cout * plane + (size_t)oy * a.Wout + ox + (size_t)(4u * h) * plane;
+                const bool full = a.Cout == G::COUT;
+#define FQ_STEM_EPI(R, S, F) stem_epilogue<R, S, F>(acc0, acc1, a, stat, s_bias, base, plane, h)
+                if (a.relu) {
+                    if (a.stream_stores) { if (full) FQ_STEM_EPI(true, true, true); else FQ_STEM_EPI(true, true, false); }
+                    else { if (full) FQ_STEM_EPI(true, false, true); else FQ_STEM_EPI(true, false, false); }
+                } else {
+                    if (a.stream_stores) { if (full) FQ_STEM_EPI(false, true, true); else FQ_STEM_EPI(false, true, false); }
+                    else { if (full) FQ_STEM_EPI(false, false, true); else FQ_STEM_EPI(false, false, false); }
                 }
+#undef FQ_STEM_EPI
             }
         }
         if (tn < a.tiles) stash(buf ^ 1);                     // that buffer was last read one tile ago: every wave is past it
@@ -160,14 +182,14 @@ __device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float*
 
 template <int CIN, int R, int S>
 __global__ __launch_bounds__(kT) void conv_stem_f32_kernel(const StemArgs a) {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     NoStat st;
     stem_tiles<CIN, R, S>(a, st, smem);
 }
 
 template <int CIN, int R, int S>
 __global__ __launch_bounds__(kT) void conv_stem_f32_absmax_kernel(const StemArgs a, unsigned int* __restrict__ max_bits) {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     MaxStat st;
     stem_tiles<CIN, R, S>(a, st, smem);
     publish_max<kT>(st.m, max_bits);
@@ -176,7 +198,7 @@ __global__ __launch_bounds__(kT) void conv_stem_f32_absmax_kernel(const StemArgs
 template <int CIN, int R, int S>
 __global__ __launch_bounds__(kT) void conv_stem_f32_hist_kernel(const StemArgs a, const float* __restrict__ interval,
                                                                 unsigned long long* __restrict__ hist_row, const int allow_fast) {
-    extern __shared__ float smem[];
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     __shared__ unsigned int s_bins[FQ_BINS + kWave];
     for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kT) s_bins[b] = 0u;
     __syncthreads();
