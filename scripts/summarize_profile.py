@@ -32,9 +32,9 @@ for counter, tag in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
     print("== %s per launch (KB as reported) ==" % counter)
     for name, vals in acc.items():
         if "hist2048_seg" in name or "hist2048_chan" in name:
-            # the first launches belong to the warm-up (and, for the per-channel kernel, every launch is the same size);
-            # the timed region's launches are the LAST 20 of the per-tensor kernel: report those separately
-            tail = vals[-20:] if "hist2048_seg" in name else vals
+            # the per-tensor kernel's launches of the warm-up and of the un-cached extra run only see the image (nothing is
+            # cached there); the timed region's launches are the big ones: report those separately
+            tail = [v for v in vals if v > 0.5 * max(vals)] if "hist2048_seg" in name else vals
             print("%-90s timed launches %4d mean %14.1f KB  -> %.3f GB%s" %
                   ((name[:60] + " [timed region]"), len(tail), sum(tail) / len(tail),
                    sum(tail) / len(tail) * 1024 / 1e9 * (2 if counter == "FETCH_SIZE" else 1),
