@@ -408,8 +408,13 @@ class Quantity(object):
                 continue
 
             def forward(x, m=m):
-                if (ctl["fuse_collector"] is None or ctl["fuse_off"] or not torch.is_tensor(x) or not x.is_cuda
-                        or x.dtype != torch.float32 or m.weight.dtype != torch.float32 or torch.is_grad_enabled()):
+                if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or m.weight.dtype != torch.float32
+                        or torch.is_grad_enabled()):
+                    return torch.nn.Conv2d.forward(m, x)
+                if ctl.get("own_plain"):                    # per-channel calibration: the convolution only, statistics by its hooks
+                    own = self._own_conv_kind(m, x) if self.own_conv1x1 else None
+                    return self._own_conv_plain(m, own, x) if own is not None else torch.nn.Conv2d.forward(m, x)
+                if ctl["fuse_collector"] is None or ctl["fuse_off"]:
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"]:
                     return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
@@ -487,18 +492,39 @@ class Quantity(object):
             m.__dict__[_C1_WT] = cached
         return cached[1]
 
+    def _own_conv_run(self, m, kind, x):
+        wq, s = self._own_conv_weight(m, kind), m.stride[0]
+        if kind == "c1":
+            return lambda **kw: _native.conv1x1_f32(x, wq, m.bias, s, **kw)
+        return lambda **kw: _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
+
+    def _own_conv_verified(self, m, run, x):
+        """Once per process and module: the own kernel against torch's forward on this very input.  Returns torch's result
+        when the module fails (and marks it: it keeps the library convolution from now on), None when it passes."""
+        if m.__dict__.get(_C1_VERIFIED):
+            return None
+        ref = torch.nn.Conv2d.forward(m, x)
+        bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
+        scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
+        own = run(max_dev=scratch, row=0)
+        if not (bool(((own - ref).abs() <= _C1_TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
+            m.__dict__[_C1_OFF] = True
+            return ref
+        m.__dict__[_C1_VERIFIED] = True
+        return None
+
+    def _own_conv_plain(self, m, kind, x):
+        """The convolution alone on the own kernel (bias in its epilogue): what the per-channel calibration's forward runs."""
+        run = self._own_conv_run(m, kind, x)
+        ref = self._own_conv_verified(m, run, x)
+        return ref if ref is not None else run()
+
     def _finish_own_conv(self, module, m, kind, x, key, output):
         """Forward-hook half of a convolution that runs on fq_conv1x1_f32 / fq_conv_stem_f32: `output` is the empty tensor
         the patched forward returned.  Returns True when the statistic of `output` is done."""
         ctl = self._hook_ctl
         coll = ctl["fuse_collector"]
-        wq, s = self._own_conv_weight(m, kind), m.stride[0]
-        if kind == "c1":
-            def run(**kw):
-                return _native.conv1x1_f32(x, wq, m.bias, s, **kw)
-        else:
-            def run(**kw):
-                return _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
+        run = self._own_conv_run(m, kind, x)
         if module is not m or coll is None or key is None:     # not a cared tensor: the convolution only
             run(out=output)
             return False
@@ -508,16 +534,10 @@ class Quantity(object):
                                                          relu_out=r, out=output))
             ctl["hist_fused"] += 1
             return True
-        if not m.__dict__.get(_C1_VERIFIED):                   # first use: against torch's own forward, once per process
-            ref = torch.nn.Conv2d.forward(m, x)
-            bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
-            scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
-            own = run(max_dev=scratch, row=0)
-            if not (bool(((own - ref).abs() <= _C1_TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
-                m.__dict__[_C1_OFF] = True                     # this module keeps the library convolution from now on
-                output.copy_(ref)
-                return False
-            m.__dict__[_C1_VERIFIED] = True
+        ref = self._own_conv_verified(m, run, x)               # first use: against torch's own forward, once per process
+        if ref is not None:
+            output.copy_(ref)                                  # this module keeps the library convolution from now on
+            return False
         ctl["fuse_verified"].add(m)
         self._run_with_relu(m, output, lambda r: run(max_dev=coll.max_device, row=row, relu_out=r, out=output))
         coll.note_max_refreshed()
@@ -953,6 +973,10 @@ class Quantity(object):
         names = ["image"] + list(self.net_info.keys())
         named_feats, hooks = self.regist_hook_outfeature(self.model)
         ctl = self._hook_ctl
+        # the forward's 1x1 convolutions and stem on the own fp32 MFMA kernels (convolution + bias only: the per-channel
+        # statistics are taken from the finished tensors)
+        patched = self._patch_fused_convs(self.model) if self.device == "gpu" and torch.cuda.is_available() else []
+        ctl["own_plain"] = bool(patched)
         try:
             # One probe forward on a random input of INPUT_SHAPE (what build_net_structure traces with) tells the
             # channel counts and whether later modules overwrite hooked tensors -- on EVERY rank, also one that owns
@@ -995,6 +1019,9 @@ class Quantity(object):
             bits = collector.quantize()
             self.timings = {"per_channel_cache_bytes": used, "per_channel_kl_s": getattr(collector, "kl_seconds", None)}
         finally:
+            ctl["own_plain"] = False
+            for m in patched:
+                del m.forward
             for h in hooks:
                 h.remove()
             named_feats.clear()
