@@ -159,9 +159,10 @@ class Quantity(object):
     # The float 1x1 convolutions themselves (36 of ResNet-50's 53) and the 7x7 stride-2 stem: fq_conv1x1_f32 /
     # fq_conv_stem_f32 compute them on the fp32 matrix cores (exact fp32, fixed summation order) with the bias, the statistic
     # of the pass and the following ReLU in the epilogue, so for these layers there is no library convolution and no
-    # bias-add pass at all.  Each module is checked once per
-    # process against torch's own forward (|difference| <= 1e-5 * (|W|*|x| + |b|): summation order only; the abs-max and
-    # the ReLU copy bit for bit); a module that disagrees keeps the path above.
+    # bias-add pass at all.  Each module is checked once per process, on its first batch, against an independent
+    # implementation of the same fp32 mathematics -- torch.matmul for the 1x1 layers, torch's Conv2d.forward for the stem
+    # (|difference| <= 1e-5 * (|W|*|x| + |b|): summation order only; the abs-max and the ReLU copy bit for bit); a module
+    # that disagrees keeps the path above.
     own_conv1x1 = os.environ.get("FQ_OWN_CONV1X1", "1") != "0"       # FQ_OWN_CONV1X1=0: A/B against the library convolutions
 
     def __init__(self, model):
@@ -418,10 +419,10 @@ class Quantity(object):
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"]:
                     return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
-                if m not in ctl["fuse_warm"] and not (m.__dict__.get(_FUSION_VERIFIED) or m.__dict__.get(_C1_VERIFIED)):
+                own = self._own_conv_kind(m, x) if self.own_conv1x1 else None
+                if own is None and m not in ctl["fuse_warm"] and not m.__dict__.get(_FUSION_VERIFIED):
                     ctl["fuse_warm"].add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
                     return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
-                own = self._own_conv_kind(m, x) if self.own_conv1x1 else None
                 if own is not None:
                     ctl["fuse_bias"] = (m, (own, x))        # the hook of this very call runs the whole convolution
                     s, p, k = m.stride[0], m.padding[0], m.kernel_size
@@ -499,12 +500,23 @@ class Quantity(object):
         return lambda **kw: _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
 
     def _own_conv_verified(self, m, run, x):
-        """Once per process and module: the own kernel against torch's forward on this very input.  Returns torch's result
-        when the module fails (and marks it: it keeps the library convolution from now on), None when it passes."""
+        """Once per process and module: the own kernel against torch (a GEMM for 1x1 layers, Conv2d.forward for the stem)
+        on this very input.  Returns torch's result when the module fails (and marks it: it keeps the library convolution from now on), None when it passes."""
         if m.__dict__.get(_C1_VERIFIED):
             return None
-        ref = torch.nn.Conv2d.forward(m, x)
-        bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
+        if m.kernel_size == (1, 1):
+            # an independent fp32 GEMM (rocBLAS through torch.matmul) is the same mathematics as torch's Conv2d.forward of a
+            # 1x1 layer, and asking the convolution library for a layer it will never run again would put its first-use
+            # solver search (tens of milliseconds per configuration) into a one-shot calibration for nothing
+            s = m.stride[0]
+            xs = (x if s == 1 else x[:, :, ::s, ::s]).reshape(x.shape[0], x.shape[1], -1)
+            w2 = m.weight.view(m.out_channels, -1)
+            shape = (x.shape[0], m.out_channels, (x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1)
+            ref = (torch.matmul(w2, xs) + m.bias.view(1, -1, 1)).view(shape)
+            bound = (torch.matmul(w2.abs(), xs.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
+        else:
+            ref = torch.nn.Conv2d.forward(m, x)
+            bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
         scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
         own = run(max_dev=scratch, row=0)
         if not (bool(((own - ref).abs() <= _C1_TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
@@ -534,7 +546,7 @@ class Quantity(object):
                                                          relu_out=r, out=output))
             ctl["hist_fused"] += 1
             return True
-        ref = self._own_conv_verified(m, run, x)               # first use: against torch's own forward, once per process
+        ref = self._own_conv_verified(m, run, x)               # first use: against torch, once per process
         if ref is not None:
             output.copy_(ref)                                  # this module keeps the library convolution from now on
             return False
