@@ -96,6 +96,23 @@ def test_gaussian_data_statistics_and_relu(nat, shape):
     assert int(hist[1].sum()) - 7 == int((y != 0).sum()) and int(hist[0].sum()) == 0
 
 
+def test_against_the_oracles_exact_integer_convolution(nat, oracle):
+    """The CPU oracle's integer convolution (oracle/fq_oracle.c, the checker of the int8 path) is exact; on integer-valued
+    fp32 data so are these kernels: equal results, element for element."""
+    rng = np.random.default_rng(5)
+    xi = rng.integers(-8, 9, (3, 48, 10, 9)).astype(np.int32)
+    wi = rng.integers(-8, 9, (72, 48, 1, 1)).astype(np.int32)
+    wt = torch.from_numpy(wi.reshape(72, 48).T.astype(np.float32).copy()).cuda()
+    for s in (1, 2):
+        y = nat.conv1x1_f32(torch.from_numpy(xi.astype(np.float32)).cuda(), wt, None, s).cpu().numpy()
+        assert np.array_equal(y, oracle.conv2d_int(xi, wi, stride=(s, s)).astype(np.float32))
+    xs = rng.integers(-8, 9, (2, 3, 30, 23)).astype(np.int32)
+    ws = rng.integers(-8, 9, (64, 3, 7, 7)).astype(np.int32)
+    ys = nat.conv_stem_f32(torch.from_numpy(xs.astype(np.float32)).cuda(),
+                           nat.pack_stem_weight(torch.from_numpy(ws.astype(np.float32)).cuda()), None, 64, (7, 7), 2, 3).cpu().numpy()
+    assert np.array_equal(ys, oracle.conv2d_int(xs, ws, stride=(2, 2), pad=(3, 3)).astype(np.float32))
+
+
 def test_histogram_with_an_interval_outside_the_fast_quotient_range(nat):
     x, w, b, wt, s = _case((2, 16, 64, 6, 6, 1), 13, integer=False)
     y = nat.conv1x1_f32(x, wt, b, s)
