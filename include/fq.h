@@ -213,6 +213,15 @@ int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* 
                      int W, int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval,
                      int64_t* hist_row, fq_stream_t stream);
 
+/* The pooling layers of the float calibration forward (nn.MaxPool2d / a global nn.AvgPool2d inside the model the
+ * reference runs at pytorch_quantizer.py:288-296), bit for bit what torch computes:
+ * fq_maxpool2d_f32: y[plane][oy][ox] = max over the window clipped to the image (NaN propagates); x fp32 [planes][H][W],
+ *   y fp32 [planes][Ho][Wo], Ho = (H + 2 ph - kh)/sh + 1 (floor mode, no dilation).
+ * fq_avgpool_global_f32: y[plane] = (x[plane][0] + x[plane][1] + ... in this order, fp32) / HW; HW <= 144. */
+int fq_maxpool2d_f32(const float* x, float* y, int planes, int H, int W, int kh, int kw, int sh, int sw, int ph, int pw,
+                     fq_stream_t stream);
+int fq_avgpool_global_f32(const float* x, float* y, int planes, int HW, fq_stream_t stream);
+
 /* Quantity.forward (new_quantity_op.py:52-58) fused with the layout change the MFMA kernel wants:
  *   y[n][hw][c] = (int8) clamp(rint(x[n][c][hw] * 2^ib), -128, 127),  c in [C, Cpad) = 0
  * x: fp32 [N][C][HW] (NCHW), y: int8 [N][HW][Cpad] (NHWC), Cpad >= C, Cpad % 4 == 0 (use a multiple

@@ -102,6 +102,10 @@ def lib():
     L.fq_conv_stem_f32_packed_rows.argtypes = [ci, ci, ci]
     L.fq_conv_stem_f32.restype = ci
     L.fq_conv_stem_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [vp, vp, vp, vp]
+    L.fq_maxpool2d_f32.restype = ci
+    L.fq_maxpool2d_f32.argtypes = [vp, vp] + [ci] * 9 + [vp]
+    L.fq_avgpool_global_f32.restype = ci
+    L.fq_avgpool_global_f32.argtypes = [vp, vp, ci, ci, vp]
     L.fq_conv2d_i8_stem.restype = ci
     L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
@@ -400,6 +404,27 @@ def conv_stem_f32(x, wp, bias, cout, kernel, stride, pad, max_dev=None, interval
     _check(lib().fq_conv_stem_f32(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
                                   _relu_ptr(relu_out, y), N, Cin, H, W, int(cout), R, S, int(stride), int(pad), mp, ivp, hp,
                                   _stream(x)), "fq_conv_stem_f32")
+    return y
+
+
+def maxpool2d_f32(x, kernel, stride, pad):
+    """fq_maxpool2d_f32: torch.nn.functional.max_pool2d(x, kernel, stride, pad) (floor mode, no dilation), bit for bit."""
+    _need_cuda(x, torch.float32, "fq_maxpool2d_f32")
+    assert x.dim() == 4 and x.is_contiguous()
+    N, C, H, W = (int(v) for v in x.shape)
+    (kh, kw), (sh, sw), (ph, pw) = kernel, stride, pad
+    y = torch.empty((N, C, (H + 2 * ph - kh) // sh + 1, (W + 2 * pw - kw) // sw + 1), dtype=torch.float32, device=x.device)
+    _check(lib().fq_maxpool2d_f32(x.data_ptr(), y.data_ptr(), N * C, H, W, kh, kw, sh, sw, ph, pw, _stream(x)), "fq_maxpool2d_f32")
+    return y
+
+
+def avgpool_global_f32(x):
+    """fq_avgpool_global_f32: the average of every [H, W] plane of x [N, C, H, W] -> [N, C, 1, 1], torch's summation order."""
+    _need_cuda(x, torch.float32, "fq_avgpool_global_f32")
+    assert x.dim() == 4 and x.is_contiguous()
+    N, C, H, W = (int(v) for v in x.shape)
+    y = torch.empty((N, C, 1, 1), dtype=torch.float32, device=x.device)
+    _check(lib().fq_avgpool_global_f32(x.data_ptr(), y.data_ptr(), N * C, H * W, _stream(x)), "fq_avgpool_global_f32")
     return y
 
 

@@ -71,6 +71,8 @@ _C1_VERIFIED = "_fq_conv1x1_verified"               # module attribute: fq_conv1
 _C1_OFF = "_fq_conv1x1_off"                         # module attribute: fq_conv1x1_f32 disagreed with torch's forward here
 _C1_WT = "_fq_conv1x1_wt"                           # module attribute: (weight version, storage address, transposed weights)
 _C1_TOL = 1e-5                                      # |own - torch| <= _C1_TOL * (|W| * |x| + |b|): summation order only
+_POOL_VERIFIED = "_fq_pool_verified"                 # module attribute: the own pooling kernel gave torch's bits here
+_POOL_OFF = "_fq_pool_off"
 _FUSION_VERIFIED = "_fq_bias_fusion_verified"     # module attribute: conv-without-bias + fq_bias_add_absmax_f32 == its forward
 _AFTER_FORWARD = 1 << 62      # _EagerStats limit that is never reached: one flush, after the forward
 
@@ -163,6 +165,9 @@ class Quantity(object):
     # implementation of the same fp32 mathematics -- torch.matmul for the 1x1 layers, torch's Conv2d.forward for the stem
     # (|difference| <= 1e-5 * (|W|*|x| + |b|): summation order only; the abs-max and the ReLU copy bit for bit); a module
     # that disagrees keeps the path above.
+    # nn.MaxPool2d and a global nn.AvgPool2d of the model run on fq_maxpool2d_f32 / fq_avgpool_global_f32 during a GPU
+    # calibration: the same bits as torch (checked once per module, torch.equal), at 2-7x torch's rate.
+    own_pools = os.environ.get("FQ_OWN_POOLS", "1") != "0"
     own_conv1x1 = os.environ.get("FQ_OWN_CONV1X1", "1") != "0"       # FQ_OWN_CONV1X1=0: A/B against the library convolutions
 
     def __init__(self, model):
@@ -449,6 +454,45 @@ class Quantity(object):
                     return torch.empty_like(x)
                 m.forward = forward
                 patched.append(m)
+        if self.own_pools:
+            def pair(v):
+                return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+            def pool_active(x):
+                return ((ctl.get("own_plain") or (ctl["fuse_collector"] is not None and not ctl["fuse_off"])) and torch.is_tensor(x)
+                        and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+                        and not torch.is_grad_enabled() and x.numel() < 2 ** 32 - 1)
+
+            def checked(m, cls, x, y):
+                if not m.__dict__.get(_POOL_VERIFIED):           # once per process: the same bits as torch's kernel?
+                    ref = cls.forward(m, x)
+                    if not torch.equal(y, ref):
+                        m.__dict__[_POOL_OFF] = True
+                        return ref
+                    m.__dict__[_POOL_VERIFIED] = True
+                return y
+            for m in model.modules():
+                if "forward" in m.__dict__:
+                    continue
+                if type(m) is torch.nn.MaxPool2d:
+                    def forward(x, m=m):
+                        if (m.__dict__.get(_POOL_OFF) or not pool_active(x) or pair(m.dilation) != (1, 1) or m.ceil_mode
+                                or m.return_indices):
+                            return torch.nn.MaxPool2d.forward(m, x)
+                        k, p = pair(m.kernel_size), pair(m.padding)
+                        st = pair(m.stride if m.stride is not None else m.kernel_size)
+                        return checked(m, torch.nn.MaxPool2d, x, _native.maxpool2d_f32(x, k, st, p))
+                    m.forward = forward
+                    patched.append(m)
+                elif type(m) is torch.nn.AvgPool2d:
+                    def forward(x, m=m):
+                        if (m.__dict__.get(_POOL_OFF) or not pool_active(x) or pair(m.kernel_size) != tuple(x.shape[2:])
+                                or pair(m.padding) != (0, 0) or m.ceil_mode or m.divisor_override is not None
+                                or x.shape[2] * x.shape[3] > 144):
+                            return torch.nn.AvgPool2d.forward(m, x)
+                        return checked(m, torch.nn.AvgPool2d, x, _native.avgpool_global_f32(x))
+                    m.forward = forward
+                    patched.append(m)
         # an out-of-place nn.ReLU fed directly by one of the modules above is served by that module's kernel
         for m in model.modules():
             if type(m) is not torch.nn.ReLU or m.inplace or "forward" in m.__dict__:

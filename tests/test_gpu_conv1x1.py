@@ -301,3 +301,58 @@ def test_stem_unsupported_shapes_are_refused(nat):
                                                               cout, r, s, stride, 3, None, None, None, None)
     assert call(3, 64, 7, 7, 2) == 0
     assert call(3, 64, 7, 7, 1) == -4 and call(3, 128, 7, 7, 2) == -4 and call(3, 64, 5, 5, 2) == -4 and call(4, 64, 7, 7, 2) == -4
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fq_maxpool2d_f32 / fq_avgpool_global_f32: the float forward's pooling layers, torch's bits
+@pytest.mark.parametrize("shape,k,s,p", [((3, 64, 112, 112), 3, 2, 1), ((2, 3, 8, 16), 3, 2, 1), ((1, 2, 10, 24), 3, 2, 1), ((2, 5, 17, 23), 3, 2, 1), ((2, 4, 9, 9), 2, 2, 0),
+                                         ((1, 3, 8, 11), 3, 1, 1), ((2, 2, 7, 7), (3, 2), (2, 1), (1, 0)), ((1, 1, 3, 3), 3, 3, 1)])
+def test_maxpool_equals_torch(nat, shape, k, s, p):
+    pair = lambda v: (v, v) if isinstance(v, int) else v
+    g = torch.Generator(device="cuda").manual_seed(31)
+    x = torch.randn(*shape, device="cuda", generator=g)
+    x.view(-1)[::97] = float("-inf")
+    want = torch.nn.functional.max_pool2d(x, k, s, p)
+    assert torch.equal(nat.maxpool2d_f32(x, pair(k), pair(s), pair(p)), want)
+    x.view(-1)[5::131] = float("nan")                                # NaN propagates the way torch's kernel does it
+    got, want = nat.maxpool2d_f32(x, pair(k), pair(s), pair(p)), torch.nn.functional.max_pool2d(x, k, s, p)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.equal(got.nan_to_num(0.0), want.nan_to_num(0.0))
+
+
+@pytest.mark.parametrize("shape", [(256, 2048, 7, 7), (3, 5, 1, 1), (2, 300, 12, 12), (1, 1, 4, 6), (7, 513, 3, 5)])
+def test_global_avgpool_equals_torch(nat, shape):
+    g = torch.Generator(device="cuda").manual_seed(32)
+    x = torch.randn(*shape, device="cuda", generator=g) * 3 + 0.5
+    assert torch.equal(nat.avgpool_global_f32(x), torch.nn.functional.avg_pool2d(x, shape[2:]))
+
+
+def test_pool_modules_are_served_and_tables_do_not_change():
+    from torch import nn
+    from common.quantity import View
+    from tools import Quantity, pytorch_quantizer
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.conv = nn.Conv2d(3, 16, 3, padding=1)
+            self.relu = nn.ReLU()
+            self.pool = nn.MaxPool2d(3, 2, 1)
+            self.conv2 = nn.Conv2d(16, 32, 1)
+            self.relu2 = nn.ReLU()
+            self.avg = nn.AvgPool2d(8)
+            self.view = View()
+            self.fc = nn.Linear(32, 10)
+
+        def forward(self, x):
+            x = self.pool(self.relu(self.conv(x)))
+            return self.fc(self.view(self.avg(self.relu2(self.conv2(x)))))
+    tables = []
+    for own in (True, False):
+        with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=3) as tmp:
+            q = Quantity(cases.seed_model(Net(), base_seed=9).eval().cuda())
+            q.own_pools = own
+            bits = dict(q.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=78)))
+            tables.append((bits, open(tmp + "/test/workdir/feat.table").read()))
+            served = [bool(m.__dict__.get(pytorch_quantizer._POOL_VERIFIED)) for m in (q.model.pool, q.model.avg)]
+            assert served == [own, own] and "forward" not in q.model.pool.__dict__      # patched only while calibrating
+    assert tables[0] == tables[1]
