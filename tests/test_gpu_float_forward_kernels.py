@@ -1,5 +1,6 @@
-"""fq_conv1x1_f32 -- the float 1x1 convolution on the fp32 matrix cores with the calibration's statistic in its epilogue --
-through the C ABI: exact agreement with a float64 reference on integer-valued data (every partial sum is exact, so any
+"""The kernels the float calibration forward runs instead of torch's (fq_conv1x1_f32, fq_conv_stem_f32 further down,
+fq_maxpool2d_f32 / fq_avgpool_global_f32 at the end).  First fq_conv1x1_f32 -- the float 1x1 convolution on the fp32
+matrix cores with the calibration's statistic in its epilogue -- through the C ABI: exact agreement with a float64 reference on integer-valued data (every partial sum is exact, so any
 indexing or tiling mistake shows as a wrong bit), agreement within the summation-order bound on Gaussian data (tolerance
 1e-5 * (|W| * |x| + |b|), the bound the product's own once-per-module check uses), the folded abs-max / histogram / ReLU
 copy bit for bit against the streaming kernels and torch on the SAME output, ragged shapes (K tails, partial tiles in both
