@@ -180,7 +180,7 @@ class CallTimer(object):
     def __init__(self, native, name, bytes_fn, flops_fn=None):
         self.native, self.name, self.bytes_fn, self.flops_fn = native, name, bytes_fn, flops_fn
         self.orig = getattr(native, name)
-        self.events, self.bytes, self.flops = [], [], []
+        self.events, self.bytes, self.flops, self.forms = [], [], [], []
         self.enabled = False
 
     def __enter__(self):
@@ -195,6 +195,7 @@ class CallTimer(object):
             self.bytes.append(float(self.bytes_fn(a, k)))
             if self.flops_fn is not None:
                 self.flops.append(float(self.flops_fn(a, k)))
+                self.forms.append("hist" if k.get("hist_dev") is not None else ("absmax" if k.get("max_dev") is not None else "plain"))
             return r
         setattr(self.native, self.name, wrapped)
         return self
@@ -257,14 +258,16 @@ def _stem_bytes(a, k):
     return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
 
 
-def mfma_f32_roofline(kernel, kt, note):
+def mfma_f32_roofline(kernel, kt, note, form=None):
     """fp32 matrix-core roofline of the float 1x1 convolutions: 2 x MAC of all timed launches / their summed durations
     against the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md); bound_ms = sum over the launches of
-    max(matrix work at that peak, algorithmic bytes at 8 TB/s) -- the 64-channel layers of the first stage are HBM bound."""
-    if not kt.events:
+    max(matrix work at that peak, algorithmic bytes at 8 TB/s) -- the 64-channel layers of the first stage are HBM bound.
+    form: only the launches of that epilogue ("absmax" = pass 1, "hist" = pass 2)."""
+    keep = [i for i, f in enumerate(kt.forms) if form is None or f == form]
+    if not keep:
         return None
-    ms = np.array([a.elapsed_time(b) for a, b in kt.events])
-    fl, by = np.array(kt.flops), np.array(kt.bytes)
+    ms = np.array([kt.events[i][0].elapsed_time(kt.events[i][1]) for i in keep])
+    fl, by = np.array(kt.flops)[keep], np.array(kt.bytes)[keep]
     ach = fl.sum() / (ms.sum() * 1e-3) / 1e12
     bound = np.maximum(fl / (F32_MFMA_PEAK_TFLOPS * 1e12), by / (HBM_PEAK_GBS * 1e9)) * 1e3
     return {"bound": "mfma", "kernel": kernel, "achieved": round(float(ach), 1), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -712,6 +715,13 @@ def main():
             "the float forward's 36 1x1 convolutions (2.12 of ResNet-50's 4.09 GMAC per image) on v_mfma_f32_32x32x2_f32 with the "
             "bias, the pass's statistic and the following ReLU in the epilogue: both passes of three batches, every layer size")
         if c1:
+            # both forms together, then each: the abs-max form is what pass 1 (78 % of the timed region) runs; the histogram
+            # form is a persistent grid of 2 workgroups per CU (8 KB of LDS bins on top of the three operand stages)
+            for form in ("absmax", "hist"):
+                part = mfma_f32_roofline("conv1x1_f32_%s_kernel" % form, kt_c1, None, form)
+                if part:
+                    c1["pass1_absmax_form" if form == "absmax" else "pass2_hist_form"] = {
+                        k: part[k] for k in ("achieved", "frac", "launches", "mean_launch_ms", "frac_of_bound")}
             result["roofline_conv1x1_f32"] = c1
         stem = mfma_f32_roofline(
             "conv_stem_f32_absmax_kernel / conv_stem_f32_hist_kernel", kt_st,

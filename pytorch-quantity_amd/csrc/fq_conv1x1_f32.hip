@@ -16,11 +16,12 @@
 // k-major with Cout contiguous as well.  A stride-2 convolution (the downsample branches) only changes a column's input
 // offset.
 //
-// Workgroup: 256 threads = 4 waves, tile 128 (Cout) x 128 (columns), K in steps of 16 through two LDS buffers
-// (global -> registers for step s+1 is issued before the MFMAs of step s; one barrier per step).  Each wave owns 64 x 64
-// = 2 x 2 MFMA tiles: per two k it reads 4 dwords from LDS (conflict-free: lanes 0..31 read consecutive words) and issues
-// 4 MFMAs of 64 cycles -- the f32 matrix rate equals the vector rate, so feeding it is cheap and 3-4 workgroups per CU
-// (33-41 KB of LDS each) cover the load latency without deeper pipelining.
+// Workgroup: 256 threads = 4 waves, tile 128 (Cout) x 128 (columns), K in steps of 8 through three LDS stages (see
+// conv1x1_tiles: one barrier per step, in the middle of it).  Each wave owns 64 x 64 = 2 x 2 MFMA tiles: per two k it
+// reads 4 dwords from LDS (conflict-free: lanes 0..31 read consecutive words) and issues 4 MFMAs of 64 cycles -- the f32
+// matrix rate equals the vector rate, so feeding it is cheap; the short K step keeps the staging registers at 8 and the
+// stages at 24 KB, so FOUR workgroups per CU are resident (64 accumulators + <= 64 other registers per lane) and cover
+// each other's load latency, barriers and epilogues.
 //
 // Numerics: the MFMA is bit for bit an fmaf chain over k = 0 .. Cin-1 from 0 (cdna_hip_programming.md "FP32-input
 // MFMA"), then one rounding for the bias -- "convolution without bias, then the bias add", as torch does it.  It is
@@ -33,7 +34,9 @@ namespace fq {
 namespace {
 
 constexpr int kT = 256;
-constexpr int kBK = 16;
+constexpr int kBK = 16;                                       // the unit of the K-tail test; K step of the 64-row tiles
+constexpr int kStepWide = 8;                                  // K step of the 128 x 128 tiles: 4 workgroups per CU (16: 3; measured +2 %)
+template <int WM> constexpr int step_of() { return WM == 2 ? kStepWide : kBK; }
 typedef float f4v __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
 
@@ -64,14 +67,15 @@ struct NoStat {
 
 // Tile shapes: the 4 waves sit 2 x 2, each owns WM x WN MFMA tiles of 32 x 32 -> the workgroup tile is (64 WM) x (64 WN).
 // <2,2> = 128 x 128 for Cout >= 128; <1,2> = 64 x 128 for the 64-channel layers (no empty half tile).
-template <int WM, int WN>
+template <int WM, int WN, int BK = kBK>
 struct Shape {
     static constexpr int BM = 64 * WM, BN = 64 * WN;
-    static constexpr int kXRows = kBK * BN / kT;              // x-tile dwords per thread and K step (column fixed per thread)
+    static constexpr int kXRows = BK * BN / kT;              // x-tile dwords per thread and K step (column fixed per thread)
     static constexpr int kXStep = kT / BN > 0 ? kT / BN : 1;  // rows between them (BN = 128: 2; BN = 256: 1)
-    static constexpr int kWVecs = kBK * BM / 4 / kT;          // W-tile float4 per thread and K step
+    static constexpr int kWVecs = BK * BM / 4 / kT;          // W-tile float4 per thread and K step
     static constexpr int kWRowStep = kT / (BM / 4);           // rows between them
-    static constexpr int kFloats = 3 * kBK * (BM + BN) + BM;  // three stages of both tiles + the bias slice
+    static constexpr int kFloats = 3 * BK * (BM + BN) + BM;
+    static_assert(kXRows >= 1 && kWVecs >= 1 && BK % 4 == 0, "tile too small for 256 loading threads");  // three stages of both tiles + the bias slice
 };
 
 // Epilogue of one workgroup tile.  D[i][j] has j = lane & 31 and i = (e & 3) + 8 (e >> 2) + 4 (lane >> 5): the four rows
@@ -115,13 +119,13 @@ __device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1A
     }
 }
 
-template <int WM, int WN, bool kTailK, typename Stat>
+template <int WM, int WN, int BK, bool kTailK, typename Stat>
 __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float* smem) {
-    typedef Shape<WM, WN> S;
+    typedef Shape<WM, WN, BK> S;
     constexpr int BM = S::BM, BN = S::BN;
-    float* Ws = smem;                                         // [3][kBK][BM]
-    float* Xs = smem + 3 * kBK * BM;                          // [3][kBK][BN]
-    float* s_bias = smem + 3 * kBK * (BM + BN);
+    float* Ws = smem;                                         // [3][BK][BM]
+    float* Xs = smem + 3 * BK * BM;                          // [3][BK][BN]
+    float* s_bias = smem + 3 * BK * (BM + BN);
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned r = lane & 31u, h = lane >> 5;
     const unsigned m0 = (wave >> 1) * (32u * WM), n0 = (wave & 1u) * (32u * WN);
@@ -131,7 +135,7 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
     const unsigned v0 = g < G8 ? (g & 7u) * (G8 >> 3) + (g >> 3) : g;
     const unsigned xc = tid % BN, xk = tid / BN;              // x tile: this thread's column, rows xk + kXStep * i
     const unsigned wr = tid / (BM / 4), wc = (tid % (BM / 4)) * 4u;   // W tile: rows wr + kWRowStep * i, columns wc .. wc + 3
-    const unsigned nk = (a.Cin + kBK - 1) / kBK;
+    const unsigned nk = (a.Cin + BK - 1) / BK;
     const float* __restrict__ xg = a.x;
     const float* __restrict__ wg = a.wt;
 
@@ -174,9 +178,9 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
         };
         auto lstore = [&](int buf) {
 #pragma unroll
-            for (int i = 0; i < S::kXRows; ++i) Xs[(buf * kBK + xk + S::kXStep * i) * BN + xc] = xr[i];
+            for (int i = 0; i < S::kXRows; ++i) Xs[(buf * BK + xk + S::kXStep * i) * BN + xc] = xr[i];
 #pragma unroll
-            for (int i = 0; i < S::kWVecs; ++i) *reinterpret_cast<f4v*>(&Ws[(buf * kBK + wr + S::kWRowStep * i) * BM + wc]) = wreg[i];
+            for (int i = 0; i < S::kWVecs; ++i) *reinterpret_cast<f4v*>(&Ws[(buf * BK + wr + S::kWRowStep * i) * BM + wc]) = wreg[i];
         };
         f16v acc[WM][WN];
 #pragma unroll
@@ -195,7 +199,7 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
         gload(0);
         if (tid < (unsigned)BM) s_bias[tid] = (a.bias && mbase + tid < a.Cout) ? a.bias[mbase + tid] : 0.0f;
         lstore(0);
-        if (nk > 1) gload(kBK);
+        if (nk > 1) gload(BK);
         __syncthreads();
         float fa[2][WM], fb[2][WN];                           // operands of this and of the next k pair
         {
@@ -210,19 +214,19 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
         for (unsigned ks = 0; ks < nk; ++ks) {
             const int nxt = cur == 2 ? 0 : cur + 1;
             const bool more = ks + 1 < nk;
-            const float* wrow = Ws + (cur * kBK + h) * BM + m0 + r;
-            const float* xrow = Xs + (cur * kBK + h) * BN + n0 + r;
-            const float* wnext = Ws + (nxt * kBK + h) * BM + m0 + r;
-            const float* xnext = Xs + (nxt * kBK + h) * BN + n0 + r;
+            const float* wrow = Ws + (cur * BK + h) * BM + m0 + r;
+            const float* xrow = Xs + (cur * BK + h) * BN + n0 + r;
+            const float* wnext = Ws + (nxt * BK + h) * BM + m0 + r;
+            const float* xnext = Xs + (nxt * BK + h) * BN + n0 + r;
 #pragma unroll
-            for (int kk = 0; kk < kBK; kk += 2) {
+            for (int kk = 0; kk < BK; kk += 2) {
                 const int c = (kk >> 1) & 1, nx = c ^ 1;
-                if (kk == kBK / 2 && more) {
+                if (kk == BK / 2 && more) {
                     lstore(nxt);
-                    if (ks + 2 < nk && !FQ_C1_OFF(2)) gload((ks + 2) * kBK);
+                    if (ks + 2 < nk && !FQ_C1_OFF(2)) gload((ks + 2) * BK);
                     if (!FQ_C1_OFF(4)) __syncthreads();
                 }
-                if (kk + 2 < kBK) {
+                if (kk + 2 < BK) {
 #pragma unroll
                     for (int mi = 0; mi < WM; ++mi) fa[nx][mi] = wrow[(kk + 2) * BM + 32 * mi];
 #pragma unroll
@@ -262,26 +266,27 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
     }
 }
 
-// (3 waves per SIMD is what three 49 KB workgroups per CU need: <= 170 registers with the 64 accumulators)
+// (4 waves per SIMD = four workgroups per CU: <= 128 registers with the 64 accumulators)
 template <int WM, int WN, bool kTailK>
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_f32_kernel(const C1Args a) {
-    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN>::kFloats];
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_kernel(const C1Args a) {
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
     NoStat st;
-    conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
+    conv1x1_tiles<WM, WN, step_of<WM>(), kTailK>(a, st, smem);
 }
 
 template <int WM, int WN, bool kTailK>
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_f32_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
-    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN>::kFloats];
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
     MaxStat st;
-    conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
+    conv1x1_tiles<WM, WN, step_of<WM>(), kTailK>(a, st, smem);
     publish_max<kT>(st.m, max_bits);
 }
 
-template <int WM, int WN, bool kTailK>
-__global__ __launch_bounds__(kT) void conv1x1_f32_hist_kernel(const C1Args a, const float* __restrict__ interval,
-                                                              unsigned long long* __restrict__ hist_row, const int allow_fast) {
-    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN>::kFloats];
+// (the histogram form carries 8 KB of LDS bins on top of the stages; the persistent grid is what the occupancy query says)
+template <int WM, int WN, int BK, bool kTailK>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_f32_hist_kernel(
+    const C1Args a, const float* __restrict__ interval, unsigned long long* __restrict__ hist_row, const int allow_fast) {
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, BK>::kFloats];
     __shared__ unsigned int s_bins[FQ_BINS + kWave];
     for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kT) s_bins[b] = 0u;
     __syncthreads();
@@ -289,10 +294,10 @@ __global__ __launch_bounds__(kT) void conv1x1_f32_hist_kernel(const C1Args a, co
     unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
     if (allow_fast && fast_quotient_ok(iv)) {
         HistStat<true> st{s_bins, park, iv, 1.0f / iv};
-        conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
+        conv1x1_tiles<WM, WN, BK, kTailK>(a, st, smem);
     } else {
         HistStat<false> st{s_bins, park, iv, 1.0f / iv};
-        conv1x1_tiles<WM, WN, kTailK>(a, st, smem);
+        conv1x1_tiles<WM, WN, BK, kTailK>(a, st, smem);
     }
     hist_flush<kT>(s_bins, hist_row);
 }
@@ -308,12 +313,12 @@ void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, in
         // workgroups the chip holds at once (LDS: three stages + 8 KB of bins), each taking every grid-th tile
         static const int resident = [] {
             int n = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_f32_hist_kernel<WM, WN, kTailK>, kT, 0) != hipSuccess || n < 1) n = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_f32_hist_kernel<WM, WN, step_of<WM>(), kTailK>, kT, 0) != hipSuccess || n < 1) n = 1;
             return n;
         }();
         unsigned grid = (unsigned)kCUs * (unsigned)(hist_per_cu > 0 ? hist_per_cu : resident);
         if (grid > a.tiles) grid = a.tiles;
-        hipLaunchKernelGGL((conv1x1_f32_hist_kernel<WM, WN, kTailK>), dim3(grid), dim3(kT), 0, st, a, interval,
+        hipLaunchKernelGGL((conv1x1_f32_hist_kernel<WM, WN, step_of<WM>(), kTailK>), dim3(grid), dim3(kT), 0, st, a, interval,
                            reinterpret_cast<unsigned long long*>(hist_row), fast);
     } else if (max_inout) {
         hipLaunchKernelGGL((conv1x1_f32_absmax_kernel<WM, WN, kTailK>), dim3(a.tiles), dim3(kT), 0, st, a,
