@@ -47,6 +47,7 @@ struct C1Args {
     float* y;
     float* relu;              // or null
     unsigned Cin, Cout, HWin, HWout, Win, Wout, stride;
+    unsigned x_bytes, w_bytes;
     unsigned cols;            // N * HWout
     unsigned tiles_m, tiles;
     int stream_stores;
@@ -63,6 +64,11 @@ struct C1Args {
 
 struct NoStat {
     __device__ __forceinline__ void add(float) {}
+};
+
+template <int I>
+struct Stage {
+    static constexpr int value = I;
 };
 
 // Tile shapes: the 4 waves sit 2 x 2, each owns WM x WN MFMA tiles of 32 x 32 -> the workgroup tile is (64 WM) x (64 WN).
@@ -136,15 +142,39 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
     const unsigned xc = tid % BN, xk = tid / BN;              // x tile: this thread's column, rows xk + kXStep * i
     const unsigned wr = tid / (BM / 4), wc = (tid % (BM / 4)) * 4u;   // W tile: rows wr + kWRowStep * i, columns wc .. wc + 3
     const unsigned nk = (a.Cin + BK - 1) / BK;
-    const float* __restrict__ xg = a.x;
-    const float* __restrict__ wg = a.wt;
+    // x and Wt through buffer descriptors: address = descriptor base + scalar offset (the K row, advanced with scalar adds)
+    // + 32-bit per-thread byte offset (computed once per tile) -- no vector instruction per load
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wt), 0, a.w_bytes, 0x00020000);
+    // Every LDS address of the K loop is one of these per-thread bases plus a compile-time offset (the stage index is a
+    // template constant: the loop is unrolled over the three stages), and every global address is a uniform base (scalar
+    // registers, advanced by scalar adds) plus a 32-bit per-thread byte offset computed once per tile.  A vector
+    // instruction of ANY wave of a SIMD takes issue cycles from its matrix pipe (scripts/mfma_f32_probe.hip: 99 % of the
+    // matrix cycles with register operands, 93 % with this loop's LDS reads and barriers): the first form of this loop
+    // spent 28 vector instructions per 16 MFMAs on addresses and ran at 82 %.
+    const float* wrd[WM];                                     // A operand reads: wrd[mi] + (stage * BK + kk) * BM
+    const float* xrd[WN];                                     // B operand reads: xrd[ni] + (stage * BK + kk) * BN
+#pragma unroll
+    for (int mi = 0; mi < WM; ++mi) {
+        unsigned i0 = h * BM + m0 + r + 32 * mi;
+        asm volatile("" : "+v"(i0));                          // (unrelated bases: two ds_read_b32 with 16-bit immediates each,
+        wrd[mi] = Ws + i0;                                    //  not one ds_read2_b32 whose 8-bit offsets need a vector add)
+    }
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        unsigned i0 = h * BN + n0 + r + 32 * ni;
+        asm volatile("" : "+v"(i0));
+        xrd[ni] = Xs + i0;
+    }
+    float* const ww0 = Ws + wr * BM + wc;                     // W tile stores:   + (stage * BK + kWRowStep * i) * BM
+    float* const xw0 = Xs + xk * BN + xc;                     // x tile stores:   + (stage * BK + kXStep * i) * BN
 
     for (unsigned t = v0; t < a.tiles; t += G) {
         const unsigned ct = t / a.tiles_m, mt = t - ct * a.tiles_m;
         const unsigned mbase = mt * BM, jbase = ct * BN;
         // Loads never leave the tensors: a column past the end re-reads the last one, a W column past Cout the last four
         // (those accumulators are never stored), so no load is predicated; only a K tail needs zeros.
-        unsigned xoff;
+        unsigned xo[S::kXRows], wo[S::kWVecs];                // byte offsets of this thread's loads in K step 0 (< 2^32: host check)
         {
             const unsigned j = min(jbase + xc, a.cols - 1u);
             const unsigned n = j / a.HWout, p = j - n * a.HWout;
@@ -153,34 +183,44 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
                 const unsigned oh = p / a.Wout, ow = p - oh * a.Wout;
                 pin = oh * a.stride * a.Win + ow * a.stride;
             }
-            xoff = n * a.Cin * a.HWin + pin;                  // < 2^32 (checked on the host)
+            const unsigned xoff = n * a.Cin * a.HWin + pin;
+#pragma unroll
+            for (int i = 0; i < S::kXRows; ++i) xo[i] = (xoff + (xk + S::kXStep * i) * a.HWin) * 4u;
+            const unsigned woff = min(mbase + wc, a.Cout - 4u);
+#pragma unroll
+            for (int i = 0; i < S::kWVecs; ++i) wo[i] = ((wr + S::kWRowStep * i) * a.Cout + woff) * 4u;
         }
-        const unsigned woff = min(mbase + wc, a.Cout - 4u);
         float xr[S::kXRows];
         f4v wreg[S::kWVecs];
-        auto gload = [&](unsigned kb) {
+        auto gload = [&](unsigned kb) {                       // kb is uniform: the row advance is scalar arithmetic
+            const int xs = (int)(kb * a.HWin * 4u), ws = (int)(kb * a.Cout * 4u);
 #pragma unroll
             for (int i = 0; i < S::kXRows; ++i) {
-                unsigned k = kb + xk + S::kXStep * i;
-                const bool in = !kTailK || k < a.Cin;
-                if (kTailK) k = min(k, a.Cin - 1u);
-                const float v = xg[xoff + k * a.HWin];
-                xr[i] = in ? v : 0.0f;
+                if (kTailK) {                                 // rows past Cin: re-read row Cin - 1, use zero
+                    const unsigned k = kb + xk + S::kXStep * i, back = k < a.Cin ? 0u : (k - (a.Cin - 1u)) * a.HWin * 4u;
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(xo[i] - back), xs, 0));
+                    xr[i] = k < a.Cin ? v : 0.0f;
+                } else {
+                    xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)xo[i], xs, 0));
+                }
             }
 #pragma unroll
             for (int i = 0; i < S::kWVecs; ++i) {
-                unsigned k = kb + wr + S::kWRowStep * i;
-                const bool in = !kTailK || k < a.Cin;
-                if (kTailK) k = min(k, a.Cin - 1u);
-                const f4v v = *reinterpret_cast<const f4v*>(wg + (k * a.Cout + woff));
-                wreg[i] = in ? v : f4v{0.f, 0.f, 0.f, 0.f};
+                if (kTailK) {
+                    const unsigned k = kb + wr + S::kWRowStep * i, back = k < a.Cin ? 0u : (k - (a.Cin - 1u)) * a.Cout * 4u;
+                    const f4v v = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)(wo[i] - back), ws, 0));
+                    wreg[i] = k < a.Cin ? v : f4v{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    wreg[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)wo[i], ws, 0));
+                }
             }
         };
-        auto lstore = [&](int buf) {
+        auto lstore = [&](auto stage) {
+            constexpr int buf = decltype(stage)::value;
 #pragma unroll
-            for (int i = 0; i < S::kXRows; ++i) Xs[(buf * BK + xk + S::kXStep * i) * BN + xc] = xr[i];
+            for (int i = 0; i < S::kXRows; ++i) xw0[(buf * BK + S::kXStep * i) * BN] = xr[i];
 #pragma unroll
-            for (int i = 0; i < S::kWVecs; ++i) *reinterpret_cast<f4v*>(&Ws[(buf * BK + wr + S::kWRowStep * i) * BM + wc]) = wreg[i];
+            for (int i = 0; i < S::kWVecs; ++i) *reinterpret_cast<f4v*>(ww0 + (buf * BK + S::kWRowStep * i) * BM) = wreg[i];
         };
         f16v acc[WM][WN];
 #pragma unroll
@@ -198,44 +238,35 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
         // step are fetched under the last MFMAs of this one, and the MFMA stream of a wave does not stop between steps.
         gload(0);
         if (tid < (unsigned)BM) s_bias[tid] = (a.bias && mbase + tid < a.Cout) ? a.bias[mbase + tid] : 0.0f;
-        lstore(0);
+        lstore(Stage<0>{});
         if (nk > 1) gload(BK);
         __syncthreads();
         float fa[2][WM], fb[2][WN];                           // operands of this and of the next k pair
-        {
-            const float* wrow = Ws + h * BM + m0 + r;
-            const float* xrow = Xs + h * BN + n0 + r;
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi) fa[0][mi] = wrow[32 * mi];
+        for (int mi = 0; mi < WM; ++mi) fa[0][mi] = wrd[mi][0];
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) fb[0][ni] = xrow[32 * ni];
-        }
-        int cur = 0;
-        for (unsigned ks = 0; ks < nk; ++ks) {
-            const int nxt = cur == 2 ? 0 : cur + 1;
+        for (int ni = 0; ni < WN; ++ni) fb[0][ni] = xrd[ni][0];
+        auto kstep = [&](auto stage, unsigned ks) {
+            constexpr int cur = decltype(stage)::value, nxt = (cur + 1) % 3;
             const bool more = ks + 1 < nk;
-            const float* wrow = Ws + (cur * BK + h) * BM + m0 + r;
-            const float* xrow = Xs + (cur * BK + h) * BN + n0 + r;
-            const float* wnext = Ws + (nxt * BK + h) * BM + m0 + r;
-            const float* xnext = Xs + (nxt * BK + h) * BN + n0 + r;
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 const int c = (kk >> 1) & 1, nx = c ^ 1;
                 if (kk == BK / 2 && more) {
-                    lstore(nxt);
+                    lstore(Stage<nxt>{});
                     if (ks + 2 < nk && !FQ_C1_OFF(2)) gload((ks + 2) * BK);
                     if (!FQ_C1_OFF(4)) __syncthreads();
                 }
                 if (kk + 2 < BK) {
 #pragma unroll
-                    for (int mi = 0; mi < WM; ++mi) fa[nx][mi] = wrow[(kk + 2) * BM + 32 * mi];
+                    for (int mi = 0; mi < WM; ++mi) fa[nx][mi] = wrd[mi][(cur * BK + kk + 2) * BM];
 #pragma unroll
-                    for (int ni = 0; ni < WN; ++ni) fb[nx][ni] = xrow[(kk + 2) * BN + 32 * ni];
+                    for (int ni = 0; ni < WN; ++ni) fb[nx][ni] = xrd[ni][(cur * BK + kk + 2) * BN];
                 } else if (more) {
 #pragma unroll
-                    for (int mi = 0; mi < WM; ++mi) fa[nx][mi] = wnext[32 * mi];
+                    for (int mi = 0; mi < WM; ++mi) fa[nx][mi] = wrd[mi][nxt * BK * BM];
 #pragma unroll
-                    for (int ni = 0; ni < WN; ++ni) fb[nx][ni] = xnext[32 * ni];
+                    for (int ni = 0; ni < WN; ++ni) fb[nx][ni] = xrd[ni][nxt * BK * BN];
                 }
                 __builtin_amdgcn_sched_barrier(0);            // keep the next pair's LDS reads ahead of these MFMAs
 #pragma unroll
@@ -244,7 +275,15 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
                     for (int ni = 0; ni < WN; ++ni)
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][mi], fb[c][ni], acc[mi][ni], 0, 0, 0);
             }
-            cur = nxt;
+        };
+        static_assert((BK / 2) % 2 == 0, "a K step must hold an even number of k pairs: the operand double buffer starts each step at 0");
+        for (unsigned ks = 0;;) {
+            kstep(Stage<0>{}, ks);
+            if (++ks >= nk) break;
+            kstep(Stage<1>{}, ks);
+            if (++ks >= nk) break;
+            kstep(Stage<2>{}, ks);
+            if (++ks >= nk) break;
         }
         {
             const bool full_m = mbase + BM <= a.Cout;
@@ -350,12 +389,16 @@ extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias
     const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
     const size_t cols = (size_t)N * Hout * Wout;
     const size_t in_elems = (size_t)N * Cin * Hin * Win, out_elems = cols * Cout;
-    if (cols >= 0xffffff00ULL || in_elems >= 0xffffffffULL || out_elems >= 0xffffffffULL) return FQ_ERR_UNSUPPORTED;
+    // 32-bit BYTE offsets into x and Wt, 32-bit element offsets into y
+    if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || (size_t)Cin * Cout >= (1ULL << 30) || out_elems >= 0xffffffffULL)
+        return FQ_ERR_UNSUPPORTED;
     C1Args a;
     a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out;
     a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.HWin = (unsigned)(Hin * Win); a.HWout = (unsigned)(Hout * Wout);
     a.Win = (unsigned)Win; a.Wout = (unsigned)Wout; a.stride = (unsigned)stride;
     a.cols = (unsigned)cols;
+    a.x_bytes = (unsigned)(in_elems * 4);
+    a.w_bytes = (unsigned)((size_t)Cin * Cout * 4);
     a.tiles_m = a.tiles = 0;
     a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);       // beyond the Infinity Cache
 #ifdef FQ_C1_ABLATE
