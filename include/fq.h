@@ -191,7 +191,7 @@ int fq_add_hist_f32(const float* x, const float* y, float* z, size_t n, const fl
  *   y[n][co][oh][ow] = sum_ci W[co][ci] * x[n][ci][oh*stride][ow*stride] + bias[co]      (padding 0, groups 1)
  * wt: the weights TRANSPOSED, fp32 [Cin][Cout], 16-byte aligned, Cout % 4 == 0; bias: fp32 [Cout] or NULL;
  * x: fp32 [N][Cin][Hin][Win] contiguous, < 2^30 elements (FQ_ERR_UNSUPPORTED beyond); y: fp32 [N][Cout][Hout][Wout],
- * Hout = (Hin-1)/stride + 1, < 2^32 elements;
+ * Hout = (Hin-1)/stride + 1, < 2^30 elements;
  * relu_out (may be NULL): max(y, 0) as well (the nn.ReLU behind the convolution);
  * exactly one of {max_inout, hist_row} may be given (both NULL: plain convolution):
  *   max_inout: *max_inout = max(*max_inout, max |y|)                 (distribution_collector.py:70-78)

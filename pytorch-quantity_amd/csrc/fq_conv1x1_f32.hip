@@ -47,7 +47,7 @@ struct C1Args {
     float* y;
     float* relu;              // or null
     unsigned Cin, Cout, HWin, HWout, Win, Wout, stride;
-    unsigned x_bytes, w_bytes;
+    unsigned x_bytes, w_bytes, y_bytes;
     unsigned cols;            // N * HWout
     unsigned tiles_m, tiles;
     int stream_stores;
@@ -91,14 +91,17 @@ struct Shape {
 template <int WM, int WN, bool kRelu, bool kStream, bool kFullM, typename Stat>
 __device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1Args& a, Stat& stat, const float* s_bias,
                                             unsigned jbase, unsigned mbase, unsigned m0, unsigned n0, unsigned r, unsigned h) {
-    float* __restrict__ yg = a.y;
-    float* __restrict__ rg = a.relu;
+    // stores through buffer descriptors too: per-lane byte offset of (column, first row of the lane) once per column
+    // block, the row advance as the scalar offset -- a value costs its bias add, the ReLU select and the statistic
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(kRelu ? a.relu : a.y, 0, a.y_bytes, 0x00020000);
+    constexpr int aux = kStream ? 2 : 0;                      // nt
 #pragma unroll
     for (int ni = 0; ni < WN; ++ni) {
         const unsigned jn = jbase + n0 + 32u * ni + r;
         if (jn < a.cols) {
             const unsigned n = jn / a.HWout, p = jn - n * a.HWout;
-            const unsigned col = n * a.Cout * a.HWout + p + (mbase + m0 + 4u * h) * a.HWout;   // < 2^32 (host check)
+            const unsigned col4 = (n * a.Cout * a.HWout + p + (mbase + m0 + 4u * h) * a.HWout) * 4u;   // < 2^32 (host check)
 #pragma unroll
             for (int mi = 0; mi < WM; ++mi) {
                 f4v b4[4];
@@ -109,14 +112,11 @@ __device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1A
                     const unsigned dm = 32u * mi + (e & 3) + 8u * (e >> 2);           // compile-time row within the wave tile
                     if (kFullM || mbase + m0 + 4u * h + dm < a.Cout) {
                         const float val = acc[mi][ni][e] + b4[e >> 2][e & 3];
-                        const unsigned o = col + dm * a.HWout;
-                        if (kStream) {
-                            __builtin_nontemporal_store(val, yg + o);
-                            if (kRelu) __builtin_nontemporal_store(relu_like_torch(val), rg + o);
-                        } else {
-                            yg[o] = val;
-                            if (kRelu) rg[o] = relu_like_torch(val);
-                        }
+                        const int row4 = (int)(dm * a.HWout * 4u);                     // uniform
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs, (int)col4, row4, aux);
+                        if (kRelu)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(val)), rrs, (int)col4,
+                                                                  row4, aux);
                         stat.add(val);
                     }
                 }
@@ -389,8 +389,8 @@ extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias
     const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
     const size_t cols = (size_t)N * Hout * Wout;
     const size_t in_elems = (size_t)N * Cin * Hin * Win, out_elems = cols * Cout;
-    // 32-bit BYTE offsets into x and Wt, 32-bit element offsets into y
-    if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || (size_t)Cin * Cout >= (1ULL << 30) || out_elems >= 0xffffffffULL)
+    // 32-bit BYTE offsets into x, Wt and y
+    if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || (size_t)Cin * Cout >= (1ULL << 30) || out_elems >= (1ULL << 30))
         return FQ_ERR_UNSUPPORTED;
     C1Args a;
     a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out;
@@ -399,6 +399,7 @@ extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias
     a.cols = (unsigned)cols;
     a.x_bytes = (unsigned)(in_elems * 4);
     a.w_bytes = (unsigned)((size_t)Cin * Cout * 4);
+    a.y_bytes = (unsigned)(out_elems * 4);
     a.tiles_m = a.tiles = 0;
     a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);       // beyond the Infinity Cache
 #ifdef FQ_C1_ABLATE

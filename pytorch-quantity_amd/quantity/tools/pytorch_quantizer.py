@@ -515,7 +515,7 @@ class Quantity(object):
         """"c1" (fq_conv1x1_f32), "stem" (fq_conv_stem_f32) or None: which own float convolution takes this call."""
         if (m.__dict__.get(_C1_OFF) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
                 or not x.is_contiguous() or isinstance(m.padding, str) or m.padding[0] != m.padding[1]
-                or x.numel() >= 2 ** 30 or x.shape[0] * m.out_channels * x.shape[2] * x.shape[3] >= 2 ** 32 - 1):
+                or x.numel() >= 2 ** 30 or x.shape[0] * m.out_channels * x.shape[2] * x.shape[3] >= 2 ** 30):
             return None
         if m.kernel_size == (1, 1) and m.padding == (0, 0) and m.out_channels % 4 == 0:
             return "c1"
