@@ -409,10 +409,13 @@ extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias
     static const int hist_per_cu = env_int("FQ_CONV1X1_HIST_WG_PER_CU", 0);   // 0: what the occupancy query says
     static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
     const bool tail_k = (Cin % kBK) != 0;
-    // tile shape: 64 x 128 for the 64-channel layers (a 128-row tile would be half empty), else 128 x 128;
+    // tile shape: 128 x 128; 64 x 128 for the 64-channel layers (a 128-row tile would be half empty) and for launches whose
+    // 128 x 128 tiles would not even fill the 1 024 resident slots once (1024 -> 256 @14x14 at 256 images: 784 tiles leave
+    // a quarter of the CUs with 4 tiles and the rest with 3; 1 568 half-size tiles balance better: 0.257 -> 0.230 ms).
     // FQ_CONV1X1_SHAPE = 22 | 12 forces one (probing)
     static const int forced = env_int("FQ_CONV1X1_SHAPE", 0);
-    const int shape = forced ? forced : (Cout <= 64 ? 12 : 22);
+    const size_t tiles22 = ((cols + 127) / 128) * (size_t)((Cout + 127) / 128);
+    const int shape = forced ? forced : ((Cout <= 64 || tiles22 <= (size_t)kCUs * 4) ? 12 : 22);
 #define FQ_C1_LAUNCH(WM, WN)                                                                                  \
     do {                                                                                                      \
         if (tail_k) launch<WM, WN, true>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);    \
