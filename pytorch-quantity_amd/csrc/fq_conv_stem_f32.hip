@@ -52,18 +52,27 @@ struct StemArgs {
     int H, W, Hout, Wout, Cout, pad;
     unsigned tiles_x, tiles_y, tiles;      // per image: tiles_y x tiles_x; tiles = N * tiles_y * tiles_x
     int stream_stores;
+    unsigned x_bytes, y_bytes;
 };
 
 struct NoStat {
     __device__ __forceinline__ void add(float) {}
 };
 
+template <int I>
+struct Buf {
+    static constexpr int value = I;
+};
+
 template <bool kRelu, bool kStream, bool kFull, typename Stat>
 __device__ __forceinline__ void stem_epilogue(const f16v& acc0, const f16v& acc1, const StemArgs& a, Stat& stat, const float* s_bias,
-                                              size_t base, size_t plane, unsigned h) {
+                                              unsigned base4, unsigned plane4, unsigned h) {
+    // buffer stores: per-lane byte offset of (pixel, channel 4 h) + the channel advance as the scalar offset: a value costs its
+    // bias add, the ReLU select and the statistic (a vector instruction of any wave takes issue cycles from the matrix pipe)
     typedef float f4 __attribute__((ext_vector_type(4)));
-    float* __restrict__ yg = a.y + base;                      // channel 4 h of this lane's pixel
-    float* __restrict__ rg = kRelu ? a.relu + base : nullptr;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(kRelu ? a.relu : a.y, 0, a.y_bytes, 0x00020000);
+    constexpr int aux = kStream ? 2 : 0;                      // nt
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         f4 b4[4];
@@ -74,14 +83,10 @@ __device__ __forceinline__ void stem_epilogue(const f16v& acc0, const f16v& acc1
             const int dco = 32 * half + (e & 3) + 8 * (e >> 2);                    // + 4 h
             if (kFull || dco + 4 * (int)h < a.Cout) {
                 const float val = (half ? acc1[e] : acc0[e]) + b4[e >> 2][e & 3];
-                const size_t o = (size_t)dco * plane;
-                if (kStream) {
-                    __builtin_nontemporal_store(val, yg + o);
-                    if (kRelu) __builtin_nontemporal_store(relu_like_torch(val), rg + o);
-                } else {
-                    yg[o] = val;
-                    if (kRelu) rg[o] = relu_like_torch(val);
-                }
+                const int row4 = (int)((unsigned)dco * plane4);                     // uniform
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs, (int)base4, row4, aux);
+                if (kRelu)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(val)), rrs, (int)base4, row4, aux);
                 stat.add(val);
             }
         }
@@ -102,43 +107,60 @@ __device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float*
     if (tid < (unsigned)G::COUT) s_bias[tid] = (a.bias && (int)tid < a.Cout) ? a.bias[tid] : 0.0f;
 
     const unsigned per_img = a.tiles_x * a.tiles_y;
+    // What a thread fetches is the same patch element for every tile: its (channel, row, column) and its place in the LDS
+    // patch are worked out once, here; per tile and element there remain the two coordinates, the two border tests, one
+    // multiply-add and two selects.  The image comes through a buffer descriptor: scalar offset = the image, vector offset
+    // = the pixel (0 for a pixel outside the image: its value is replaced by the padding zero).
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    unsigned meta[G::NFILL];                                  // LDS word index | row << 12 | col << 17 | valid << 23
+    unsigned chan[G::NFILL];                                  // c * H * W
+#pragma unroll
+    for (int f = 0; f < G::NFILL; ++f) {
+        const unsigned e = tid + (unsigned)f * kT;
+        const unsigned c = e / (G::PH * G::PW), r2 = e - c * (G::PH * G::PW), row = r2 / G::PW, col = r2 - row * G::PW;
+        const unsigned valid = e < (unsigned)(CIN * G::PH * G::PW) ? 1u : 0u;
+        meta[f] = (((c * G::PH + row) * 2 + (col & 1u)) * G::PC + (col >> 1)) | (row << 12) | (col << 17) | (valid << 23);
+        chan[f] = c * (unsigned)(a.H * a.W);
+    }
+    static_assert(G::PATCH < 4096 && G::PH < 32 && G::PW < 64, "meta packing");
     float stage[G::NFILL];
     auto fetch = [&](unsigned t) {                            // the input patch of tile t -> registers (zero outside the image)
         const unsigned n = t / per_img, rem = t - n * per_img, ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
         const int iy0 = (int)(ty * G::TH) * G::STRIDE - a.pad, ix0 = (int)(tx * G::TW) * G::STRIDE - a.pad;
-        const float* __restrict__ xn = a.x + (size_t)n * CIN * a.H * a.W;
+        const int img4 = (int)(n * (unsigned)(CIN * a.H * a.W) * 4u);              // < 2^32 (host check)
 #pragma unroll
         for (int f = 0; f < G::NFILL; ++f) {
-            const unsigned e = tid + (unsigned)f * kT;
-            const unsigned c = e / (G::PH * G::PW), r2 = e - c * (G::PH * G::PW), row = r2 / G::PW, col = r2 - row * G::PW;
-            const int iy = iy0 + (int)row, ix = ix0 + (int)col;
-            const bool in = e < (unsigned)(CIN * G::PH * G::PW) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const size_t off = in ? ((size_t)c * a.H + iy) * a.W + ix : 0;
-            const float v = xn[off];
+            const int iy = iy0 + (int)((meta[f] >> 12) & 31u), ix = ix0 + (int)((meta[f] >> 17) & 63u);
+            const bool in = (meta[f] >> 23) != 0u && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            const unsigned off4 = in ? (chan[f] + (unsigned)iy * (unsigned)a.W + (unsigned)ix) * 4u : 0u;
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)off4, img4, 0));
             stage[f] = in ? v : 0.0f;
         }
     };
-    auto stash = [&](int buf) {                               // registers -> LDS, even / odd columns in separate planes
+    auto stash = [&](auto which) {                            // registers -> LDS, even / odd columns in separate planes
+        constexpr int buf = decltype(which)::value;
 #pragma unroll
-        for (int f = 0; f < G::NFILL; ++f) {
-            const unsigned e = tid + (unsigned)f * kT;
-            const unsigned c = e / (G::PH * G::PW), r2 = e - c * (G::PH * G::PW), row = r2 / G::PW, col = r2 - row * G::PW;
-            if (e < (unsigned)(CIN * G::PH * G::PW))
-                P[buf * G::PATCH + ((c * G::PH + row) * 2 + (col & 1u)) * G::PC + (col >> 1)] = stage[f];
-        }
+        for (int f = 0; f < G::NFILL; ++f)
+            if ((meta[f] >> 23) != 0u) P[buf * G::PATCH + (meta[f] & 4095u)] = stage[f];
     };
 
     unsigned t = blockIdx.x;
     if (t < a.tiles) fetch(t);
-    stash(0);
+    stash(Buf<0>{});
     __syncthreads();
-    int buf = 0;
-    const float* wrow = Wl + h * G::COUT + j;                                            // + step * 128 (+ 32 for the upper channels)
-    const unsigned lane_patch = ((4u * wave + 2u * dy) * 2u + h) * G::PC + dx;            // + ((c * PH + r) * 2) * PC + q
-    for (; t < a.tiles; t += gridDim.x) {
+    // operand read bases (compile-time offsets from here on; the two A reads get unrelated bases so that they stay two
+    // ds_read_b32 with 16-bit immediates instead of one ds_read2_b32 whose 8-bit offsets need a vector add per step)
+    unsigned wi0 = h * G::COUT + j, wi1 = wi0 + 32u;
+    asm volatile("" : "+v"(wi0));
+    asm volatile("" : "+v"(wi1));
+    const float* const wrow0 = Wl + wi0;                      // + step * 128
+    const float* const wrow1 = Wl + wi1;
+    const float* const prow0 = P + ((4u * wave + 2u * dy) * 2u + h) * G::PC + dx;        // + buf * PATCH + ((c * PH + r) * 2) * PC + q
+    const unsigned plane4 = (unsigned)(a.Hout * a.Wout) * 4u;
+    auto tile = [&](auto which) {
+        constexpr int buf = decltype(which)::value;
         const unsigned tn = t + gridDim.x;
         if (tn < a.tiles) fetch(tn);
-        const float* prow = P + buf * G::PATCH + lane_patch;
         f16v acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.0f; acc1[e] = 0.0f; }
@@ -149,8 +171,8 @@ __device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float*
 #pragma unroll
                 for (int q = 0; q < G::S8 / 2; ++q) {
                     const int step = (c * R + r) * (G::S8 / 2) + q;
-                    const float b = prow[((c * G::PH + r) * 2) * G::PC + q];
-                    const float a0 = wrow[step * 2 * G::COUT], a1 = wrow[step * 2 * G::COUT + 32];
+                    const float b = prow0[buf * G::PATCH + ((c * G::PH + r) * 2) * G::PC + q];
+                    const float a0 = wrow0[step * 2 * G::COUT], a1 = wrow1[step * 2 * G::COUT];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);
                 }
@@ -160,10 +182,9 @@ __device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float*
             const unsigned n = t / per_img, rem = t - n * per_img, ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
             const int oy = (int)(ty * G::TH + 2u * wave + dy), ox = (int)(tx * G::TW + dx);
             if (oy < a.Hout && ox < a.Wout) {
-                const size_t plane = (size_t)a.Hout * a.Wout;
-                const size_t base = (size_t)n * a.Cout * plane + (size_t)oy * a.Wout + ox + (size_t)(4u * h) * plane;
+                const unsigned base4 = (n * (unsigned)a.Cout + 4u * h) * plane4 + (unsigned)(oy * a.Wout + ox) * 4u;   // < 2^32 (host)
                 const bool full = a.Cout == G::COUT;
-#define FQ_STEM_EPI(R, S, F) stem_epilogue<R, S, F>(acc0, acc1, a, stat, s_bias, base, plane, h)
+#define FQ_STEM_EPI(R, S, F) stem_epilogue<R, S, F>(acc0, acc1, a, stat, s_bias, base4, plane4, h)
                 if (a.relu) {
                     if (a.stream_stores) { if (full) FQ_STEM_EPI(true, true, true); else FQ_STEM_EPI(true, true, false); }
                     else { if (full) FQ_STEM_EPI(true, false, true); else FQ_STEM_EPI(true, false, false); }
@@ -174,9 +195,14 @@ __device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float*
 #undef FQ_STEM_EPI
             }
         }
-        if (tn < a.tiles) stash(buf ^ 1);                     // that buffer was last read one tile ago: every wave is past it
+        if (tn < a.tiles) stash(Buf<buf ^ 1>{});              // that buffer was last read one tile ago: every wave is past it
         __syncthreads();
-        buf ^= 1;
+        t = tn;
+    };
+    while (t < a.tiles) {
+        tile(Buf<0>{});
+        if (t >= a.tiles) break;
+        tile(Buf<1>{});
     }
 }
 
@@ -285,7 +311,10 @@ extern "C" int fq_conv_stem_f32(const float* x, const float* wp, const float* bi
     const size_t tiles = (size_t)N * a.tiles_x * a.tiles_y;
     if (tiles >= 0x7fffffffULL) return FQ_ERR_UNSUPPORTED;
     a.tiles = (unsigned)tiles;
-    const size_t out_elems = (size_t)N * Cout * a.Hout * a.Wout;
+    const size_t out_elems = (size_t)N * Cout * a.Hout * a.Wout, in_elems = (size_t)N * Cin * H * W;
+    if (out_elems >= (1ULL << 30) || in_elems >= (1ULL << 30)) return FQ_ERR_UNSUPPORTED;          // 32-bit byte offsets
+    a.x_bytes = (unsigned)(in_elems * 4);
+    a.y_bytes = (unsigned)(out_elems * 4);
     a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);
     static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
     const int rc = launch_stem<3, 7, 7>(a, max_inout, interval, hist_row, fast, as_stream(stream));
