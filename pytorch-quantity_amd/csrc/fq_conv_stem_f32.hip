@@ -13,7 +13,8 @@
 // for a stride-2 convolution all lanes of a k-pair (s = 2q + h, h = lane >> 5) then read consecutive words -- the
 // address of every operand read is a per-lane base plus a compile-time immediate, no address arithmetic in the loop,
 // no bank conflicts (plane pitch 20: dy moves the read by 16 banks).  Two patch buffers: the next tile's patch is
-// fetched into registers before this tile's MFMAs and stored after them, one barrier per tile.
+// fetched into registers before this tile's MFMAs and stored after them, one barrier per tile.  (4 x 32 tiles -- 128-byte
+// instead of 64-byte store runs, 12.5 % of the columns of a 112-wide plane wasted -- were measured: 0.89 instead of 0.81 ms.)
 //
 // Numerics: an fmaf chain over k in the order (c, r, s) from 0, then one rounding for the bias; deterministic; not
 // bit-identical to the library's convolution (summation order), like fq_conv1x1_f32.
