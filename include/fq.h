@@ -207,7 +207,7 @@ int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y,
  * {max_inout, hist_row + interval} or neither).  wp: the weights PACKED as fp32 [fq_conv_stem_f32_packed_rows()][64],
  * 16-byte aligned: W[co][c][r][s] at row (c*R + r)*8 + s, column co; zero for s >= S and co >= Cout (the tap axis is
  * padded to 8 so that a k-pair of the MFMA is an (even, odd) column pair of the stride-2 input).
- * x: fp32 [N][Cin][H][W]; y: fp32 [N][Cout][Hout][Wout], Hout = (H + 2 pad - R)/stride + 1.
+ * x: fp32 [N][Cin][H][W]; y: fp32 [N][Cout][Hout][Wout], Hout = (H + 2 pad - R)/stride + 1; both < 2^30 elements.
  * FQ_ERR_UNSUPPORTED for any other (Cin, R, S, stride) or Cout > 64: callers keep the library convolution there. */
 int fq_conv_stem_f32_packed_rows(int Cin, int R, int S);
 int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* y, float* relu_out, int N, int Cin, int H,
