@@ -665,15 +665,19 @@ def main():
             result["value_cold"] = None
             result["cold_process"] = cold
     traffic, traffic_src = None, None
-    try:        # HBM bytes per launch from the PMC counters of the committed profile of this same configuration
+    try:        # HBM bytes per launch from the PMC counters of the committed profile of this same configuration.  What a launch
+        # covers depends on the cache plan, which follows the time stamps of the run's first forward: the committed entry
+        # holds the measured RATIO of HBM bytes to algorithmic bytes, applied to this run's algorithmic bytes per launch.
         with open(os.path.join(ROOT, "profiles", "traffic_hist2048.json")) as fh:
             tj = json.load(fh)
         for ent in (tj if isinstance(tj, list) else [tj]):
-            if (ent["batch"], ent["model"], ent["image"]) == (B, args.model, HW):
-                traffic = ent["hbm_bytes_per_launch"]
-                traffic_src = "static: %s (rocprofv3 --pmc of this configuration, not measured in this run)" % ent.get(
-                    "source", "profiles/traffic_hist2048.json")
-    except (OSError, KeyError, ValueError):
+            if (ent["batch"], ent["model"], ent["image"]) == (B, args.model, HW) and hist_s:
+                ratio = ent["hbm_bytes_per_launch"] / ent["algorithmic_bytes_per_launch"]
+                traffic = round(ratio * hist_s["bytes_per_launch"], 1)
+                traffic_src = ("static: %.4f x this run's algorithmic bytes; the ratio is from %s (rocprofv3 --pmc of this "
+                               "configuration, not measured in this run)" % (ratio, ent.get("source", "profiles/traffic_hist2048.json")))
+                break
+    except (OSError, KeyError, ValueError, ZeroDivisionError):
         pass
     if hist_s:
         result["roofline"] = hbm_roofline("hist2048_seg_kernel", hist_s, {"traffic": traffic, "traffic_source": traffic_src})
