@@ -1,0 +1,105 @@
+"""The float convolutions this package runs on its own fp32 MFMA kernels instead of torch's (no reference counterpart: the
+reference calls torch's Conv2d.forward -- pytorch_quantizer.py:288-296 inside the calibration forward, new_quantity_op.py:283-292
+inside TestConv): 1x1 layers on fq_conv1x1_f32, the 7x7 stride-2 stem on fq_conv_stem_f32 (csrc/).  Which call qualifies, the
+weights in the kernels' layout (cached on the module), the once-per-process check of every module against an independent
+implementation of the same fp32 mathematics, and the plain (no statistic) forward.  Shared by tools.Quantity (which adds the
+statistic epilogues) and TestConv."""
+import os
+
+import torch
+
+from . import _native
+
+__all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "TOL", "VERIFIED", "OFF"]
+
+VERIFIED = "_fq_conv1x1_verified"               # module attribute: the own kernel agreed with torch here
+OFF = "_fq_conv1x1_off"                         # module attribute: it disagreed: this module keeps torch's convolution
+_WT = "_fq_conv1x1_wt"                          # module attribute: (tag of the parameter, weights in the kernel's layout)
+TOL = 1e-5                                      # |own - torch| <= TOL * (|W| * |x| + |b|): summation order only
+
+
+def enabled():
+    return os.environ.get("FQ_OWN_CONV1X1", "1") != "0"
+
+
+def kind(m, x):
+    """"c1" (fq_conv1x1_f32), "stem" (fq_conv_stem_f32) or None: which own kernel takes this call of the nn.Conv2d m."""
+    if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or m.weight.dtype != torch.float32 or m.bias is None
+            or m.__dict__.get(OFF) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
+            or not x.is_contiguous() or isinstance(m.padding, str) or m.padding[0] != m.padding[1] or m.padding_mode != "zeros"
+            or x.numel() >= 2 ** 30 or x.shape[0] * m.out_channels * x.shape[2] * x.shape[3] >= 2 ** 30):
+        return None
+    if m.kernel_size == (1, 1) and m.padding == (0, 0) and m.out_channels % 4 == 0:
+        return "c1"
+    if (x.shape[2] + 2 * m.padding[0] >= m.kernel_size[0] and x.shape[3] + 2 * m.padding[1] >= m.kernel_size[1]
+            and _native.conv_stem_f32_supported(m.weight, m.stride[0])):
+        return "stem"
+    return None
+
+
+def weight(m, k):
+    """The weights in the layout the kernel reads (Wt [Cin][Cout] / the packed stem matrix), rebuilt when the parameter
+    was written to or replaced."""
+    w = m.weight
+    tag = (k, w._version, w.data_ptr(), w.device)
+    cached = m.__dict__.get(_WT)
+    if cached is None or cached[0] != tag:
+        packed = (w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1" else _native.pack_stem_weight(w))
+        cached = (tag, packed)
+        m.__dict__[_WT] = cached
+    return cached[1]
+
+
+def runner(m, k, x):
+    """run(**epilogue) -> y: the kernel for this call (epilogue: max_dev/row, interval_dev/hist_dev/row, relu_out, out)."""
+    wq, s = weight(m, k), m.stride[0]
+    if k == "c1":
+        return lambda **kw: _native.conv1x1_f32(x, wq, m.bias, s, **kw)
+    return lambda **kw: _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
+
+
+def verified(m, run, x):
+    """Once per process and module: the own kernel against torch on this very input.  Returns torch's result when the
+    module fails (and marks it: it keeps the library convolution from now on), None when it passes."""
+    if m.__dict__.get(VERIFIED):
+        return None
+    if m.kernel_size == (1, 1):
+        # an independent fp32 GEMM (rocBLAS through torch.matmul) is the same mathematics as torch's Conv2d.forward of a
+        # 1x1 layer, and asking the convolution library for a layer it will never run again would put its first-use
+        # solver search (tens of milliseconds per configuration) into a one-shot calibration for nothing
+        s = m.stride[0]
+        xs = (x if s == 1 else x[:, :, ::s, ::s]).reshape(x.shape[0], x.shape[1], -1)
+        w2 = m.weight.view(m.out_channels, -1)
+        shape = (x.shape[0], m.out_channels, (x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1)
+        ref = (torch.matmul(w2, xs) + m.bias.view(1, -1, 1)).view(shape)
+        bound = (torch.matmul(w2.abs(), xs.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
+    else:
+        ref = torch.nn.Conv2d.forward(m, x)
+        bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
+    scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
+    own = run(max_dev=scratch, row=0)
+    if not (bool(((own - ref).abs() <= TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
+        m.__dict__[OFF] = True
+        return ref
+    m.__dict__[VERIFIED] = True
+    return None
+
+
+def plain(m, k, x):
+    """The convolution alone on the own kernel (bias in its epilogue)."""
+    run = runner(m, k, x)
+    ref = verified(m, run, x)
+    return ref if ref is not None else run()
+
+
+def call(m, x):
+    """m(x) for an nn.Conv2d with the own kernel as its forward when the call qualifies -- through Module.__call__, so
+    forward hooks on m still fire; nothing stays attached to the module (whole models are pickled)."""
+    k = kind(m, x) if (enabled() and not torch.is_grad_enabled() and "forward" not in m.__dict__) else None
+    if k is None:
+        return m(x)
+    m.forward = lambda inp: plain(m, k, inp)
+    try:
+        return m(x)
+    finally:
+        del m.forward

@@ -20,7 +20,7 @@ import weakref
 import torch
 from torch import nn
 
-from . import _native
+from . import _native, _float_conv
 from .resident import QHandle, DeferredConv, resident_of, as_f32
 
 QUANTIZE_BIT = 8
@@ -479,7 +479,8 @@ class TestConv(_FakeQuantLayer):
         self._setup(name, module, quantize_infor, new_model_path, module.out_channels)
 
     def forward(self, x):
-        out = self.Conv(x)
+        # (1x1 layers and the 7x7 stem run on the fp32 MFMA kernels when the call qualifies: _float_conv.call)
+        out = _float_conv.call(self.Conv, x)
         return self.output_qdp(out, out=out if out.is_contiguous() else None)
 
 

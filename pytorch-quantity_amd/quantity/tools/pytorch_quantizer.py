@@ -36,7 +36,7 @@ import torch.nn as nn
 import yaml
 
 from common.quantity import DistributionCollector, Quantizer, walk_dirs, merge_bn, tid  # noqa: F401
-from common.quantity import _native
+from common.quantity import _native, _float_conv
 from .rewriter import BiasReWriter
 from ._jsonio import dump_int_array
 
@@ -67,10 +67,7 @@ def _dist_on():
 
 
 _RELU_VERIFIED = "_fq_relu_fusion_verified"
-_C1_VERIFIED = "_fq_conv1x1_verified"               # module attribute: fq_conv1x1_f32 agreed with torch's forward here
-_C1_OFF = "_fq_conv1x1_off"                         # module attribute: fq_conv1x1_f32 disagreed with torch's forward here
-_C1_WT = "_fq_conv1x1_wt"                           # module attribute: (weight version, storage address, transposed weights)
-_C1_TOL = 1e-5                                      # |own - torch| <= _C1_TOL * (|W| * |x| + |b|): summation order only
+_C1_OFF = _float_conv.OFF                           # (tests reach these through this module)
 _POOL_VERIFIED = "_fq_pool_verified"                 # module attribute: the own pooling kernel gave torch's bits here
 _POOL_OFF = "_fq_pool_off"
 _FUSION_VERIFIED = "_fq_bias_fusion_verified"     # module attribute: conv-without-bias + fq_bias_add_absmax_f32 == its forward
@@ -168,7 +165,7 @@ class Quantity(object):
     # nn.MaxPool2d and a global nn.AvgPool2d of the model run on fq_maxpool2d_f32 / fq_avgpool_global_f32 during a GPU
     # calibration: the same bits as torch (checked once per module, torch.equal), at 2-7x torch's rate.
     own_pools = os.environ.get("FQ_OWN_POOLS", "1") != "0"
-    own_conv1x1 = os.environ.get("FQ_OWN_CONV1X1", "1") != "0"       # FQ_OWN_CONV1X1=0: A/B against the library convolutions
+    own_conv1x1 = _float_conv.enabled()                              # FQ_OWN_CONV1X1=0: A/B against the library convolutions
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -418,13 +415,13 @@ class Quantity(object):
                         or torch.is_grad_enabled()):
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl.get("own_plain"):                    # per-channel calibration: the convolution only, statistics by its hooks
-                    own = self._own_conv_kind(m, x) if self.own_conv1x1 else None
-                    return self._own_conv_plain(m, own, x) if own is not None else torch.nn.Conv2d.forward(m, x)
+                    own = _float_conv.kind(m, x) if self.own_conv1x1 else None
+                    return _float_conv.plain(m, own, x) if own is not None else torch.nn.Conv2d.forward(m, x)
                 if ctl["fuse_collector"] is None or ctl["fuse_off"]:
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"]:
                     return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
-                own = self._own_conv_kind(m, x) if self.own_conv1x1 else None
+                own = _float_conv.kind(m, x) if self.own_conv1x1 else None
                 if own is None and m not in ctl["fuse_warm"] and not m.__dict__.get(_FUSION_VERIFIED):
                     ctl["fuse_warm"].add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
                     return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
@@ -510,77 +507,12 @@ class Quantity(object):
             patched.append(m)
         return patched
 
-    @staticmethod
-    def _own_conv_kind(m, x):
-        """"c1" (fq_conv1x1_f32), "stem" (fq_conv_stem_f32) or None: which own float convolution takes this call."""
-        if (m.__dict__.get(_C1_OFF) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
-                or not x.is_contiguous() or isinstance(m.padding, str) or m.padding[0] != m.padding[1]
-                or x.numel() >= 2 ** 30 or x.shape[0] * m.out_channels * x.shape[2] * x.shape[3] >= 2 ** 30):
-            return None
-        if m.kernel_size == (1, 1) and m.padding == (0, 0) and m.out_channels % 4 == 0:
-            return "c1"
-        if (x.shape[2] + 2 * m.padding[0] >= m.kernel_size[0] and x.shape[3] + 2 * m.padding[1] >= m.kernel_size[1]
-                and _native.conv_stem_f32_supported(m.weight, m.stride[0])):
-            return "stem"
-        return None
-
-    @staticmethod
-    def _own_conv_weight(m, kind):
-        """The weights in the layout the own kernel reads (Wt [Cin][Cout] / the packed stem matrix), rebuilt when the
-        parameter was written to or replaced."""
-        w = m.weight
-        tag = (kind, w._version, w.data_ptr(), w.device)
-        cached = m.__dict__.get(_C1_WT)
-        if cached is None or cached[0] != tag:
-            packed = (w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if kind == "c1" else _native.pack_stem_weight(w))
-            cached = (tag, packed)
-            m.__dict__[_C1_WT] = cached
-        return cached[1]
-
-    def _own_conv_run(self, m, kind, x):
-        wq, s = self._own_conv_weight(m, kind), m.stride[0]
-        if kind == "c1":
-            return lambda **kw: _native.conv1x1_f32(x, wq, m.bias, s, **kw)
-        return lambda **kw: _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
-
-    def _own_conv_verified(self, m, run, x):
-        """Once per process and module: the own kernel against torch (a GEMM for 1x1 layers, Conv2d.forward for the stem)
-        on this very input.  Returns torch's result when the module fails (and marks it: it keeps the library convolution from now on), None when it passes."""
-        if m.__dict__.get(_C1_VERIFIED):
-            return None
-        if m.kernel_size == (1, 1):
-            # an independent fp32 GEMM (rocBLAS through torch.matmul) is the same mathematics as torch's Conv2d.forward of a
-            # 1x1 layer, and asking the convolution library for a layer it will never run again would put its first-use
-            # solver search (tens of milliseconds per configuration) into a one-shot calibration for nothing
-            s = m.stride[0]
-            xs = (x if s == 1 else x[:, :, ::s, ::s]).reshape(x.shape[0], x.shape[1], -1)
-            w2 = m.weight.view(m.out_channels, -1)
-            shape = (x.shape[0], m.out_channels, (x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1)
-            ref = (torch.matmul(w2, xs) + m.bias.view(1, -1, 1)).view(shape)
-            bound = (torch.matmul(w2.abs(), xs.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
-        else:
-            ref = torch.nn.Conv2d.forward(m, x)
-            bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
-        scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
-        own = run(max_dev=scratch, row=0)
-        if not (bool(((own - ref).abs() <= _C1_TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
-            m.__dict__[_C1_OFF] = True
-            return ref
-        m.__dict__[_C1_VERIFIED] = True
-        return None
-
-    def _own_conv_plain(self, m, kind, x):
-        """The convolution alone on the own kernel (bias in its epilogue): what the per-channel calibration's forward runs."""
-        run = self._own_conv_run(m, kind, x)
-        ref = self._own_conv_verified(m, run, x)
-        return ref if ref is not None else run()
-
     def _finish_own_conv(self, module, m, kind, x, key, output):
         """Forward-hook half of a convolution that runs on fq_conv1x1_f32 / fq_conv_stem_f32: `output` is the empty tensor
         the patched forward returned.  Returns True when the statistic of `output` is done."""
         ctl = self._hook_ctl
         coll = ctl["fuse_collector"]
-        run = self._own_conv_run(m, kind, x)
+        run = _float_conv.runner(m, kind, x)
         if module is not m or coll is None or key is None:     # not a cared tensor: the convolution only
             run(out=output)
             return False
@@ -590,7 +522,7 @@ class Quantity(object):
                                                          relu_out=r, out=output))
             ctl["hist_fused"] += 1
             return True
-        ref = self._own_conv_verified(m, run, x)               # first use: against torch, once per process
+        ref = _float_conv.verified(m, run, x)                  # first use: against torch, once per process
         if ref is not None:
             output.copy_(ref)                                  # this module keeps the library convolution from now on
             return False

@@ -218,7 +218,8 @@ def test_calibration_tables_with_and_without_the_kernel():
 
 def test_a_module_that_disagrees_keeps_the_library_convolution(monkeypatch):
     from tools import Quantity, pytorch_quantizer
-    monkeypatch.setattr(pytorch_quantizer, "_C1_TOL", -1.0)                  # nothing can pass
+    from common.quantity import _float_conv
+    monkeypatch.setattr(_float_conv, "TOL", -1.0)                            # nothing can pass
     with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=3) as tmp:
         q = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
         bits = dict(q.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77)))
@@ -325,6 +326,28 @@ def test_global_avgpool_equals_torch(nat, shape):
     g = torch.Generator(device="cuda").manual_seed(32)
     x = torch.randn(*shape, device="cuda", generator=g) * 3 + 0.5
     assert torch.equal(nat.avgpool_global_f32(x), torch.nn.functional.avg_pool2d(x, shape[2:]))
+
+
+def test_testconv_runs_its_1x1_layers_on_the_own_kernel_and_hooks_still_fire():
+    """ReconTest's TestConv (float convolution -> QuanDequan, new_quantity_op.py:283-292): a 1x1 layer goes through
+    fq_conv1x1_f32 (checked once against torch), forward hooks on the inner nn.Conv2d still see its raw output, the module
+    keeps no patched forward (whole models are pickled), and the result is QuanDequan of that raw output, bit for bit."""
+    import pickle
+    from torch import nn
+    from common.quantity import TestConv, _float_conv, _native
+    conv = nn.Conv2d(32, 64, 1).cuda().eval()
+    with product_workdir(device="gpu") as tmp:
+        layer = TestConv("c", conv, {"weight_bit": 6, "bias_bit": 5, "input_bit": 4, "output_bit": 4}, tmp + "/test/workdir/rt.pth")
+        seen = []
+        layer.Conv.register_forward_hook(lambda m, i, o: seen.append(o.clone()))
+        x = torch.randn(4, 32, 14, 14, device="cuda")
+        with torch.no_grad():
+            out = layer(x)
+            assert layer.Conv.__dict__.get(_float_conv.VERIFIED) and "forward" not in layer.Conv.__dict__ and len(seen) == 1
+            assert torch.equal(out, _native.quandequan(seen[0], 4))
+            ref = torch.nn.functional.conv2d(x, layer.Conv.weight, layer.Conv.bias)
+            assert float((seen[0] - ref).abs().max()) <= 1e-4
+        pickle.dumps(layer.Conv.state_dict())
 
 
 def test_pool_modules_are_served_and_tables_do_not_change():
