@@ -312,3 +312,21 @@ def test_eager_stats_groups_launches_and_notices_inplace_consumers():
     b.add_(1.0)                                              # ... which such a model must not do
     with pytest.raises(RuntimeError):
         e.flush()
+
+
+def test_float_conv_dispatch_declines_what_the_kernels_do_not_take():
+    """common/quantity/_float_conv.py on CPU tensors and unsupported layers: kind() says None, call() is plain m(x) (hooks
+    fire once, nothing stays attached to the module), TestConv therefore behaves as in the reference off the GPU."""
+    import torch
+    from torch import nn
+    from common.quantity import _float_conv
+    x = torch.randn(2, 8, 5, 5)
+    for conv in (nn.Conv2d(8, 16, 1), nn.Conv2d(8, 16, 3, padding=1), nn.Conv2d(8, 16, 1, bias=False), nn.Conv2d(8, 16, 1, groups=2)):
+        conv.eval()
+        assert _float_conv.kind(conv, x) is None
+        seen = []
+        h = conv.register_forward_hook(lambda m, i, o: seen.append(1))
+        with torch.no_grad():
+            assert torch.equal(_float_conv.call(conv, x), conv(x))
+        h.remove()
+        assert len(seen) == 2 and "forward" not in conv.__dict__ and not conv.__dict__.get(_float_conv.VERIFIED)
