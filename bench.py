@@ -23,7 +23,8 @@ The JSON line also carries
                  mean launch duration measured with HIP events on the launch stream inside the timed region;
                  `traffic` is STATIC (PMC counters of the committed profile of this configuration), and says so;
   roofline_bias_add_absmax / roofline_add_absmax : the two kernels pass 1's maxima ride on;
-  roofline_conv_stem_f32 : the same for the 7x7 stride-2 stem (fq_conv_stem_f32);
+  roofline_conv_stem_f32 / roofline_conv_kxk_f32 : the same for the 7x7 stride-2 stem (fq_conv_stem_f32) and the 3x3 layers
+                 (fq_conv_kxk_f32);
   roofline_conv1x1_f32 : the float forward's 1x1 convolutions on the fp32 matrix cores (fq_conv1x1_f32, statistic in the
                  epilogue): 2 x MAC / summed launch durations against the 157.3 TFLOP/s dense fp32 MFMA peak;
   cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded sample on this
@@ -255,6 +256,22 @@ def _stem_flops(a, k):
 
 def _stem_bytes(a, k):
     n, cin, cout, ho, wo, taps = _stem_shape(a, k)
+    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
+
+
+def _kxk_shape(a, k):               # conv_kxk_f32(x, wt, bias, kernel, stride, pad, ...)
+    x, wt, (r, s_), stride, pad = a[0], a[1], a[3], int(a[4]), int(a[5])
+    ho, wo = (int(x.shape[2]) + 2 * pad - r) // stride + 1, (int(x.shape[3]) + 2 * pad - s_) // stride + 1
+    return int(x.shape[0]), int(x.shape[1]), int(wt.shape[1]), ho, wo, r * s_
+
+
+def _kxk_flops(a, k):
+    n, cin, cout, ho, wo, taps = _kxk_shape(a, k)
+    return 2.0 * n * cout * ho * wo * cin * taps
+
+
+def _kxk_bytes(a, k):
+    n, cin, cout, ho, wo, taps = _kxk_shape(a, k)
     return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
 
 
@@ -691,12 +708,13 @@ def main():
         with CallTimer(_native, "bias_add_absmax", _bias_add_bytes) as kt_b, CallTimer(_native, "add_absmax", _add_bytes) as kt_a, \
                 CallTimer(_native, "bias_add_hist", _bias_add_bytes) as kt_bh, CallTimer(_native, "add_hist", _add_bytes) as kt_ah, \
                 CallTimer(_native, "conv1x1_f32", _c1_bytes, _c1_flops) as kt_c1, \
-                CallTimer(_native, "conv_stem_f32", _stem_bytes, _stem_flops) as kt_st:
+                CallTimer(_native, "conv_stem_f32", _stem_bytes, _stem_flops) as kt_st, \
+                CallTimer(_native, "conv_kxk_f32", _kxk_bytes, _kxk_flops) as kt_kk:
             make_workdir(3 * world - 1, shape, dev_index)
             extra = DeviceBatches(3 * world, B, HW, rank, world, device)
             eq = Quantity(model)
             eq._activation_cache_budget = lambda: 0          # every batch through the second forward: all 69 producers fused
-            kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = kt_c1.enabled = kt_st.enabled = True
+            kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = kt_c1.enabled = kt_st.enabled = kt_kk.enabled = True
             eq.activation_quantize(extra)
             torch.cuda.synchronize()
             del extra, eq
@@ -733,6 +751,17 @@ def main():
             "7 -> 8 (the flops counted are the 147 real taps), bias + statistic + ReLU in the epilogue; writes 2 x 822 MB per launch")
         if stem:
             result["roofline_conv_stem_f32"] = stem
+        kk = mfma_f32_roofline(
+            "conv1x1_f32_absmax_kernel<.., 2> / conv1x1_f32_hist_kernel<.., 2> (the R x S form of the same kernel)", kt_kk,
+            "the float forward's 16 3x3 convolutions (1.85 GMAC per image) as direct convolutions on v_mfma_f32_32x32x2_f32: the "
+            "1x1 kernel run tap by tap over shifted x rows, zero padding by select; both passes of three batches")
+        if kk:
+            for form in ("absmax", "hist"):
+                part = mfma_f32_roofline("", kt_kk, None, form)
+                if part:
+                    kk["pass1_absmax_form" if form == "absmax" else "pass2_hist_form"] = {
+                        k: part[k] for k in ("achieved", "frac", "launches", "mean_launch_ms", "frac_of_bound")}
+            result["roofline_conv_kxk_f32"] = kk
     except Exception as e:
         if world == 1:
             result["roofline_bias_add_absmax"] = {"error": repr(e)}

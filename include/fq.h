@@ -202,6 +202,17 @@ int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y,
                    int Win, int Cout, int stride, float* max_inout, const float* interval, int64_t* hist_row,
                    fq_stream_t stream);
 
+/* The same kernel for R x S convolutions with zero padding (ResNet's 3x3 layers, stride 1 and 2): the reduction runs tap by
+ * tap over the same x rows, shifted -- a 1x1 convolution per tap whose per-thread pixel offset (or "outside the image:
+ * zero") is worked out once per tap.  wt: fp32 [(r*S + s)*Cin + ci][Cout] = W[co][ci][r][s], 16-byte aligned;
+ * Cin % 16 == 0, Cout % 4 == 0, dilation 1, groups 1 (FQ_ERR_UNSUPPORTED otherwise);
+ * Hout = (Hin + 2 pad - R)/stride + 1.  Epilogue contract as fq_conv1x1_f32.  With this, fq_conv1x1_f32 and fq_conv_stem_f32
+ * every convolution of a ResNet's float forward runs on this library: the calibration forward is deterministic
+ * (the convolution library's Winograd kernels are not reproducible from call to call) and does not touch that library. */
+int fq_conv_kxk_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin,
+                    int Win, int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval,
+                    int64_t* hist_row, fq_stream_t stream);
+
 /* The float stem convolution of the calibration forward (ResNet-50/101's conv1: 7x7, stride 2, 3 -> Cout <= 64 channels,
  * any padding) on the fp32 matrix cores, same epilogue contract as fq_conv1x1_f32 (bias, relu_out, and exactly one of
  * {max_inout, hist_row + interval} or neither).  wp: the weights PACKED as fp32 [fq_conv_stem_f32_packed_rows()][64],

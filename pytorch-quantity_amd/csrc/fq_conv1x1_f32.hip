@@ -47,6 +47,7 @@ struct C1Args {
     float* y;
     float* relu;              // or null
     unsigned Cin, Cout, HWin, HWout, Win, Wout, stride;
+    int Hin, R, S, pad;       // (R x S taps, zero padding: the K x K form; 1, 1, 0 for the 1x1 form)
     unsigned x_bytes, w_bytes, y_bytes;
     unsigned cols;            // N * HWout
     unsigned tiles_m, tiles;
@@ -125,8 +126,10 @@ __device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1A
     }
 }
 
-template <int WM, int WN, int BK, bool kTailK, typename Stat>
+// kMode: 0 = 1x1, Cin a multiple of the K step; 1 = 1x1 with a K tail; 2 = R x S taps with zero padding (Cin a multiple of 16)
+template <int WM, int WN, int BK, int kMode, typename Stat>
 __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float* smem) {
+    constexpr bool kTailK = kMode == 1, kTaps = kMode == 2;
     typedef Shape<WM, WN, BK> S;
     constexpr int BM = S::BM, BN = S::BN;
     float* Ws = smem;                                         // [3][BK][BM]
@@ -141,7 +144,9 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
     const unsigned v0 = g < G8 ? (g & 7u) * (G8 >> 3) + (g >> 3) : g;
     const unsigned xc = tid % BN, xk = tid / BN;              // x tile: this thread's column, rows xk + kXStep * i
     const unsigned wr = tid / (BM / 4), wc = (tid % (BM / 4)) * 4u;   // W tile: rows wr + kWRowStep * i, columns wc .. wc + 3
-    const unsigned nk = (a.Cin + BK - 1) / BK;
+    // K x K: the reduction runs tap by tap over the same x rows, shifted -- a 1x1 convolution per tap whose per-thread
+    // pixel offset (or "outside the image: zero") is worked out once per tap
+    const unsigned nk = kTaps ? (unsigned)(a.R * a.S) * (a.Cin / BK) : (a.Cin + BK - 1) / BK;
     // x and Wt through buffer descriptors: address = descriptor base + scalar offset (the K row, advanced with scalar adds)
     // + 32-bit per-thread byte offset (computed once per tile) -- no vector instruction per load
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
@@ -175,17 +180,37 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
         // Loads never leave the tensors: a column past the end re-reads the last one, a W column past Cout the last four
         // (those accumulators are never stored), so no load is predicated; only a K tail needs zeros.
         unsigned xo[S::kXRows], wo[S::kWVecs];                // byte offsets of this thread's loads in K step 0 (< 2^32: host check)
+        int iy0 = 0, ix0 = 0;                                 // K x K: top-left input pixel of this thread's column
+        unsigned nbase = 0;
+        bool tap_ok = true;
+        int ld_r = 0, ld_s = 0;                               // K x K: the tap the NEXT gload reads (uniform), its channel row
+        unsigned ld_kb = 0;
+        auto tap_offsets = [&]() {                            // per-thread pixel of tap (ld_r, ld_s), or "zero"
+            const int iy = iy0 + ld_r, ix = ix0 + ld_s;
+            tap_ok = (unsigned)iy < (unsigned)a.Hin && (unsigned)ix < (unsigned)a.Win;
+            const unsigned pix = tap_ok ? nbase + (unsigned)iy * a.Win + (unsigned)ix : 0u;
+#pragma unroll
+            for (int i = 0; i < S::kXRows; ++i) xo[i] = (pix + (xk + S::kXStep * i) * a.HWin) * 4u;
+        };
         {
             const unsigned j = min(jbase + xc, a.cols - 1u);
             const unsigned n = j / a.HWout, p = j - n * a.HWout;
-            unsigned pin = p;
-            if (a.stride != 1) {
+            if (kTaps) {
                 const unsigned oh = p / a.Wout, ow = p - oh * a.Wout;
-                pin = oh * a.stride * a.Win + ow * a.stride;
-            }
-            const unsigned xoff = n * a.Cin * a.HWin + pin;
+                iy0 = (int)(oh * a.stride) - a.pad;
+                ix0 = (int)(ow * a.stride) - a.pad;
+                nbase = n * a.Cin * a.HWin;
+                tap_offsets();
+            } else {
+                unsigned pin = p;
+                if (a.stride != 1) {
+                    const unsigned oh = p / a.Wout, ow = p - oh * a.Wout;
+                    pin = oh * a.stride * a.Win + ow * a.stride;
+                }
+                const unsigned xoff = n * a.Cin * a.HWin + pin;
 #pragma unroll
-            for (int i = 0; i < S::kXRows; ++i) xo[i] = (xoff + (xk + S::kXStep * i) * a.HWin) * 4u;
+                for (int i = 0; i < S::kXRows; ++i) xo[i] = (xoff + (xk + S::kXStep * i) * a.HWin) * 4u;
+            }
             const unsigned woff = min(mbase + wc, a.Cout - 4u);
 #pragma unroll
             for (int i = 0; i < S::kWVecs; ++i) wo[i] = ((wr + S::kWRowStep * i) * a.Cout + woff) * 4u;
@@ -193,13 +218,16 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
         float xr[S::kXRows];
         f4v wreg[S::kWVecs];
         auto gload = [&](unsigned kb) {                       // kb is uniform: the row advance is scalar arithmetic
-            const int xs = (int)(kb * a.HWin * 4u), ws = (int)(kb * a.Cout * 4u);
+            const int xs = (int)((kTaps ? ld_kb : kb) * a.HWin * 4u), ws = (int)(kb * a.Cout * 4u);
 #pragma unroll
             for (int i = 0; i < S::kXRows; ++i) {
                 if (kTailK) {                                 // rows past Cin: re-read row Cin - 1, use zero
                     const unsigned k = kb + xk + S::kXStep * i, back = k < a.Cin ? 0u : (k - (a.Cin - 1u)) * a.HWin * 4u;
                     const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)(xo[i] - back), xs, 0));
                     xr[i] = k < a.Cin ? v : 0.0f;
+                } else if (kTaps) {
+                    const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)xo[i], xs, 0));
+                    xr[i] = tap_ok ? v : 0.0f;
                 } else {
                     xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)xo[i], xs, 0));
                 }
@@ -212,6 +240,14 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
                     wreg[i] = k < a.Cin ? v : f4v{0.f, 0.f, 0.f, 0.f};
                 } else {
                     wreg[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)wo[i], ws, 0));
+                }
+            }
+            if (kTaps) {                                      // gload is called once per K step, in order: advance to the next rows / tap
+                ld_kb += BK;
+                if (ld_kb == a.Cin) {
+                    ld_kb = 0;
+                    if (++ld_s == a.S) { ld_s = 0; ++ld_r; }
+                    tap_offsets();
                 }
             }
         };
@@ -306,14 +342,14 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
 }
 
 // (4 waves per SIMD = four workgroups per CU: <= 128 registers with the 64 accumulators)
-template <int WM, int WN, bool kTailK>
+template <int WM, int WN, int kTailK>
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_kernel(const C1Args a) {
     __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
     NoStat st;
     conv1x1_tiles<WM, WN, step_of<WM>(), kTailK>(a, st, smem);
 }
 
-template <int WM, int WN, bool kTailK>
+template <int WM, int WN, int kTailK>
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
     __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
     MaxStat st;
@@ -322,7 +358,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void co
 }
 
 // (the histogram form carries 8 KB of LDS bins on top of the stages; the persistent grid is what the occupancy query says)
-template <int WM, int WN, int BK, bool kTailK>
+template <int WM, int WN, int BK, int kTailK>
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_f32_hist_kernel(
     const C1Args a, const float* __restrict__ interval, unsigned long long* __restrict__ hist_row, const int allow_fast) {
     __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, BK>::kFloats];
@@ -341,7 +377,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void co
     hist_flush<kT>(s_bins, hist_row);
 }
 
-template <int WM, int WN, bool kTailK>
+template <int WM, int WN, int kTailK>
 void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, int64_t* hist_row, int hist_per_cu, int fast,
             hipStream_t st) {
     typedef Shape<WM, WN> S;
@@ -377,28 +413,35 @@ int env_int(const char* name, int dflt) {
 
 using namespace fq;
 
-extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin,
-                              int Hin, int Win, int Cout, int stride, float* max_inout, const float* interval,
-                              int64_t* hist_row, fq_stream_t stream) {
-    if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1) return FQ_ERR_INVALID_ARG;
+namespace {
+
+// the common host side of fq_conv1x1_f32 (R = S = 1, pad = 0) and fq_conv_kxk_f32
+int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin, int Win,
+                    int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval, int64_t* hist_row,
+                    fq_stream_t stream) {
+    if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1 || R < 1 || S < 1 || pad < 0) return FQ_ERR_INVALID_ARG;
+    if (Hin + 2 * pad < R || Win + 2 * pad < S) return FQ_ERR_INVALID_ARG;
     if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
     if (hist_row && !interval) return FQ_ERR_INVALID_ARG;
     if (N == 0) return FQ_OK;
     if (!x || !wt || !y) return FQ_ERR_INVALID_ARG;
     if ((Cout & 3) || (reinterpret_cast<uintptr_t>(wt) & 15u)) return FQ_ERR_UNSUPPORTED;       // float4 loads of Wt rows
-    const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
+    const bool taps = R * S > 1 || pad > 0;
+    if (taps && (Cin % 16) != 0) return FQ_ERR_UNSUPPORTED;                                   // whole K steps per tap
+    const int Hout = (Hin + 2 * pad - R) / stride + 1, Wout = (Win + 2 * pad - S) / stride + 1;
     const size_t cols = (size_t)N * Hout * Wout;
-    const size_t in_elems = (size_t)N * Cin * Hin * Win, out_elems = cols * Cout;
+    const size_t in_elems = (size_t)N * Cin * Hin * Win, out_elems = cols * Cout, w_elems = (size_t)R * S * Cin * Cout;
     // 32-bit BYTE offsets into x, Wt and y
-    if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || (size_t)Cin * Cout >= (1ULL << 30) || out_elems >= (1ULL << 30))
+    if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || w_elems >= (1ULL << 30) || out_elems >= (1ULL << 30))
         return FQ_ERR_UNSUPPORTED;
     C1Args a;
     a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out;
     a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.HWin = (unsigned)(Hin * Win); a.HWout = (unsigned)(Hout * Wout);
     a.Win = (unsigned)Win; a.Wout = (unsigned)Wout; a.stride = (unsigned)stride;
+    a.Hin = Hin; a.R = R; a.S = S; a.pad = pad;
     a.cols = (unsigned)cols;
     a.x_bytes = (unsigned)(in_elems * 4);
-    a.w_bytes = (unsigned)((size_t)Cin * Cout * 4);
+    a.w_bytes = (unsigned)(w_elems * 4);
     a.y_bytes = (unsigned)(out_elems * 4);
     a.tiles_m = a.tiles = 0;
     a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);       // beyond the Infinity Cache
@@ -408,7 +451,7 @@ extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias
     hipStream_t st = as_stream(stream);
     static const int hist_per_cu = env_int("FQ_CONV1X1_HIST_WG_PER_CU", 0);   // 0: what the occupancy query says
     static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
-    const bool tail_k = (Cin % kBK) != 0;
+    const int mode = taps ? 2 : ((Cin % kBK) != 0 ? 1 : 0);
     // tile shape: 128 x 128; 64 x 128 for the 64-channel layers (a 128-row tile would be half empty) and for launches whose
     // 128 x 128 tiles would not even fill the 1 024 resident slots once (1024 -> 256 @14x14 at 256 images: 784 tiles leave
     // a quarter of the CUs with 4 tiles and the rest with 3; 1 568 half-size tiles balance better: 0.257 -> 0.230 ms).
@@ -416,14 +459,29 @@ extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias
     static const int forced = env_int("FQ_CONV1X1_SHAPE", 0);
     const size_t tiles22 = ((cols + 127) / 128) * (size_t)((Cout + 127) / 128);
     const int shape = forced ? forced : ((Cout <= 64 || tiles22 <= (size_t)kCUs * 4) ? 12 : 22);
-#define FQ_C1_LAUNCH(WM, WN)                                                                                  \
-    do {                                                                                                      \
-        if (tail_k) launch<WM, WN, true>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);    \
-        else launch<WM, WN, false>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);          \
+#define FQ_C1_LAUNCH(WM, WN)                                                                                       \
+    do {                                                                                                           \
+        if (mode == 2) launch<WM, WN, 2>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);         \
+        else if (mode == 1) launch<WM, WN, 1>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);    \
+        else launch<WM, WN, 0>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);                   \
     } while (0)
     if (shape == 12) FQ_C1_LAUNCH(1, 2);
     else FQ_C1_LAUNCH(2, 2);
 #undef FQ_C1_LAUNCH
     FQ_LAUNCH_CHECK();
     return FQ_OK;
+}
+
+}  // namespace
+
+extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin,
+                              int Hin, int Win, int Cout, int stride, float* max_inout, const float* interval,
+                              int64_t* hist_row, fq_stream_t stream) {
+    return conv_f32_launch(x, wt, bias, y, relu_out, N, Cin, Hin, Win, Cout, 1, 1, stride, 0, max_inout, interval, hist_row, stream);
+}
+
+extern "C" int fq_conv_kxk_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin,
+                               int Hin, int Win, int Cout, int R, int S, int stride, int pad, float* max_inout,
+                               const float* interval, int64_t* hist_row, fq_stream_t stream) {
+    return conv_f32_launch(x, wt, bias, y, relu_out, N, Cin, Hin, Win, Cout, R, S, stride, pad, max_inout, interval, hist_row, stream);
 }

@@ -1,6 +1,8 @@
 """The float convolutions this package runs on its own fp32 MFMA kernels instead of torch's (no reference counterpart: the
 reference calls torch's Conv2d.forward -- pytorch_quantizer.py:288-296 inside the calibration forward, new_quantity_op.py:283-292
-inside TestConv): 1x1 layers on fq_conv1x1_f32, the 7x7 stride-2 stem on fq_conv_stem_f32 (csrc/).  Which call qualifies, the
+inside TestConv): 1x1 layers on fq_conv1x1_f32, R x S layers with zero padding (the 3x3 ones) on fq_conv_kxk_f32, the 7x7
+stride-2 stem on fq_conv_stem_f32 (csrc/) -- every convolution of a ResNet, so that the calibration forward is deterministic
+and never enters the convolution library (whose first-use solver search costs seconds in a fresh process).  Which call qualifies, the
 weights in the kernels' layout (cached on the module), the once-per-process check of every module against an independent
 implementation of the same fp32 mathematics, and the plain (no statistic) forward.  Shared by tools.Quantity (which adds the
 statistic epilogues) and TestConv."""
@@ -23,7 +25,8 @@ def enabled():
 
 
 def kind(m, x):
-    """"c1" (fq_conv1x1_f32), "stem" (fq_conv_stem_f32) or None: which own kernel takes this call of the nn.Conv2d m."""
+    """"c1" (fq_conv1x1_f32), "kxk" (fq_conv_kxk_f32), "stem" (fq_conv_stem_f32) or None: which own kernel takes this call of
+    the nn.Conv2d m."""
     if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or m.weight.dtype != torch.float32 or m.bias is None
             or m.__dict__.get(OFF) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
             or not x.is_contiguous() or isinstance(m.padding, str) or m.padding[0] != m.padding[1] or m.padding_mode != "zeros"
@@ -34,6 +37,10 @@ def kind(m, x):
     if (x.shape[2] + 2 * m.padding[0] >= m.kernel_size[0] and x.shape[3] + 2 * m.padding[1] >= m.kernel_size[1]
             and _native.conv_stem_f32_supported(m.weight, m.stride[0])):
         return "stem"
+    if (m.kernel_size != (1, 1) and m.in_channels % 16 == 0 and m.out_channels % 4 == 0
+            and x.shape[2] + 2 * m.padding[0] >= m.kernel_size[0] and x.shape[3] + 2 * m.padding[1] >= m.kernel_size[1]
+            and m.kernel_size[0] * m.kernel_size[1] * m.in_channels * m.out_channels < 2 ** 30):
+        return "kxk"
     return None
 
 
@@ -44,7 +51,8 @@ def weight(m, k):
     tag = (k, w._version, w.data_ptr(), w.device)
     cached = m.__dict__.get(_WT)
     if cached is None or cached[0] != tag:
-        packed = (w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1" else _native.pack_stem_weight(w))
+        packed = (w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1"
+                  else _native.pack_kxk_weight(w) if k == "kxk" else _native.pack_stem_weight(w))
         cached = (tag, packed)
         m.__dict__[_WT] = cached
     return cached[1]
@@ -55,6 +63,8 @@ def runner(m, k, x):
     wq, s = weight(m, k), m.stride[0]
     if k == "c1":
         return lambda **kw: _native.conv1x1_f32(x, wq, m.bias, s, **kw)
+    if k == "kxk":
+        return lambda **kw: _native.conv_kxk_f32(x, wq, m.bias, m.kernel_size, s, m.padding[0], **kw)
     return lambda **kw: _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
 
 
@@ -63,31 +73,46 @@ def verified(m, run, x):
     module fails (and marks it: it keeps the library convolution from now on), None when it passes."""
     if m.__dict__.get(VERIFIED):
         return None
-    if m.kernel_size == (1, 1):
-        # an independent fp32 GEMM (rocBLAS through torch.matmul) is the same mathematics as torch's Conv2d.forward of a
-        # 1x1 layer, and asking the convolution library for a layer it will never run again would put its first-use
-        # solver search (tens of milliseconds per configuration) into a one-shot calibration for nothing
+    # The reference result comes from an independent implementation of the same fp32 mathematics that is NOT the convolution
+    # library wherever that is cheap: asking that library for a layer it will never run again would put its first-use solver
+    # search (tens of milliseconds to seconds per configuration) into a one-shot calibration for nothing.
+    head = None                                                 # compare only the first `head` images (None: all)
+    if m.kernel_size == (1, 1):                                 # 1x1: a GEMM (rocBLAS through torch.matmul)
         s = m.stride[0]
         xs = (x if s == 1 else x[:, :, ::s, ::s]).reshape(x.shape[0], x.shape[1], -1)
         w2 = m.weight.view(m.out_channels, -1)
         shape = (x.shape[0], m.out_channels, (x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1)
         ref = (torch.matmul(w2, xs) + m.bias.view(1, -1, 1)).view(shape)
         bound = (torch.matmul(w2.abs(), xs.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
-    else:
+    elif m.in_channels >= 16:                                   # R x S: im2col (unfold) + GEMM on the first images
+        head = max(1, min(x.shape[0], (1 << 28) // max(x[0].numel() * m.kernel_size[0] * m.kernel_size[1], 1)))
+        xh = x[:head]
+        cols = torch.nn.functional.unfold(xh, m.kernel_size, padding=m.padding, stride=m.stride)
+        w2 = m.weight.view(m.out_channels, -1)
+        ho = (x.shape[2] + 2 * m.padding[0] - m.kernel_size[0]) // m.stride[0] + 1
+        shape = (head, m.out_channels, ho, cols.shape[2] // ho)
+        ref = (torch.matmul(w2, cols) + m.bias.view(1, -1, 1)).view(shape)
+        bound = (torch.matmul(w2.abs(), cols.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
+        del cols
+    else:                                                       # the stem: torch's own convolution (one configuration)
         ref = torch.nn.Conv2d.forward(m, x)
         bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
     scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
     own = run(max_dev=scratch, row=0)
-    if not (bool(((own - ref).abs() <= TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
+    cmp = own if head is None else own[:head]
+    if not (bool(((cmp - ref).abs() <= TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
         m.__dict__[OFF] = True
-        return ref
+        return ref if head is None else torch.nn.Conv2d.forward(m, x)
     m.__dict__[VERIFIED] = True
     return None
 
 
-def plain(m, k, x):
-    """The convolution alone on the own kernel (bias in its epilogue)."""
+def plain(m, k, x, check=True):
+    """The convolution alone on the own kernel (bias in its epilogue).  check=False: without the once-per-module check (for
+    a forward whose values nobody uses)."""
     run = runner(m, k, x)
+    if not check:
+        return run()
     ref = verified(m, run, x)
     return ref if ref is not None else run()
 

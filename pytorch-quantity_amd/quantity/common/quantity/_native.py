@@ -98,6 +98,8 @@ def lib():
     L.fq_add_hist_f32.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
     L.fq_conv1x1_f32.restype = ci
     L.fq_conv1x1_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [vp, vp, vp, vp]
+    L.fq_conv_kxk_f32.restype = ci
+    L.fq_conv_kxk_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [vp, vp, vp, vp]
     L.fq_conv_stem_f32_packed_rows.restype = ci
     L.fq_conv_stem_f32_packed_rows.argtypes = [ci, ci, ci]
     L.fq_conv_stem_f32.restype = ci
@@ -360,6 +362,41 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
         mp = max_dev.data_ptr() + 4 * int(row)
     _check(lib().fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
                                 _relu_ptr(relu_out, y), N, Cin, H, W, Cout, s, mp, ivp, hp, _stream(x)), "fq_conv1x1_f32")
+    return y
+
+
+def pack_kxk_weight(weight):
+    """[Cout, Cin, R, S] -> Wt [(r*S + s)*Cin + ci][Cout], the layout fq_conv_kxk_f32 reads."""
+    cout, cin, r, s = (int(v) for v in weight.shape)
+    return weight.detach().permute(2, 3, 1, 0).reshape(r * s * cin, cout).contiguous()
+
+
+def conv_kxk_f32(x, wt, bias, kernel, stride, pad, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None,
+                 out=None):
+    """fq_conv_kxk_f32: the float R x S convolution (zero padding `pad`, dilation 1, groups 1) of x [N, Cin, H, W] with the
+    weights packed by pack_kxk_weight; statistics / relu_out / out as in conv1x1_f32.  Returns y."""
+    _need_cuda(x, torch.float32, "fq_conv_kxk_f32")
+    _need_cuda(wt, torch.float32, "fq_conv_kxk_f32")
+    R, S = int(kernel[0]), int(kernel[1])
+    assert x.dim() == 4 and x.is_contiguous() and wt.dim() == 2 and wt.is_contiguous() and wt.shape[0] == R * S * x.shape[1]
+    N, Cin, H, W = (int(v) for v in x.shape)
+    Cout, st, pd = int(wt.shape[1]), int(stride), int(pad)
+    shape = (N, Cout, (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1)
+    y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+    assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
+    if bias is not None:
+        _need_cuda(bias, torch.float32, "fq_conv_kxk_f32")
+        assert bias.is_contiguous() and bias.numel() == Cout
+    mp = ivp = hp = None
+    if hist_dev is not None:
+        ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
+    elif max_dev is not None:
+        _need_cuda(max_dev, torch.float32, "fq_conv_kxk_f32")
+        assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
+        mp = max_dev.data_ptr() + 4 * int(row)
+    _check(lib().fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                 _relu_ptr(relu_out, y), N, Cin, H, W, Cout, R, S, st, pd, mp, ivp, hp, _stream(x)),
+           "fq_conv_kxk_f32")
     return y
 
 

@@ -416,7 +416,9 @@ class Quantity(object):
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl.get("own_plain"):                    # per-channel calibration: the convolution only, statistics by its hooks
                     own = _float_conv.kind(m, x) if self.own_conv1x1 else None
-                    return _float_conv.plain(m, own, x) if own is not None else torch.nn.Conv2d.forward(m, x)
+                    if own is None:
+                        return torch.nn.Conv2d.forward(m, x)
+                    return _float_conv.plain(m, own, x, check=ctl["own_plain"] != "unchecked")
                 if ctl["fuse_collector"] is None or ctl["fuse_off"]:
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"]:
@@ -799,6 +801,10 @@ class Quantity(object):
             # alive (a fresh process would grow its allocator pool for them: up to 0.6 s of hipMalloc).
             probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
             ctl["eager"] = probe
+            # (its values are not used, so the convolutions the own kernels take run on them here too, unchecked: a
+            # calibration then never enters the convolution library, whose first-use solver search is most of what a
+            # fresh process used to wait for; every module is still checked on the first real batch)
+            ctl["own_plain"] = "unchecked"
             try:
                 dev = self._model_device(self.model)
                 shapes = [self.input_size] if isinstance(self.input_size, tuple) else list(self.input_size)
@@ -806,6 +812,7 @@ class Quantity(object):
                     self.model(*[torch.rand(*s_, device=dev) for s_ in shapes])
             finally:
                 ctl["eager"] = None
+                ctl["own_plain"] = False
             inplace = bool(probe.modified())
             del probe
             named_feats.clear()

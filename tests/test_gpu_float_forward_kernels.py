@@ -216,6 +216,35 @@ def test_calibration_tables_with_and_without_the_kernel():
     assert launches[0] > 0 and launches[1] == 0          # three 1x1 convolutions from the third batch on / none
 
 
+def test_resnet50_calibration_is_reproducible_bit_for_bit_and_leaves_the_convolution_library_alone(monkeypatch):
+    """Every convolution of the fabu ResNet-50 runs on this library's kernels (stem, 1x1, 3x3), so two calibrations of the
+    same batches give the same histograms bit for bit (the convolution library's Winograd kernels are not reproducible from
+    call to call), and once every module has been checked (its first real batch) torch's convolution is never called."""
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_fabu import ResNet50
+    from tools import Quantity
+    model = merge_bn(cases.seed_model(ResNet50(input_size=64)).eval()).cuda()
+    batches = cases.calib_batches(4, (4, 3, 64, 64), seed=55)
+    hists, calls = [], []
+    real = torch.nn.functional.conv2d
+
+    def counting(*a, **k):
+        calls[-1] += 1
+        return real(*a, **k)
+    for _run in range(2):
+        calls.append(0)
+        with product_workdir(input_shape="1,3,64,64", device="gpu", max_cali_img_num=3):
+            q = Quantity(model)
+            if _run == 1:
+                monkeypatch.setattr(torch.nn.functional, "conv2d", counting)     # Conv2d._conv_forward goes through F.conv2d
+            q.activation_quantize(batches)
+            hists.append((q._collector.hist_device.clone(), dict(q._collector.max_vals)))
+            assert q.timings["own_conv1x1_launches"] > 0
+    monkeypatch.undo()
+    assert torch.equal(hists[0][0], hists[1][0]) and hists[0][1] == hists[1][1]
+    assert calls[1] == 0                      # second run: every module already checked, no library convolution at all
+
+
 def test_a_module_that_disagrees_keeps_the_library_convolution(monkeypatch):
     from tools import Quantity, pytorch_quantizer
     from common.quantity import _float_conv
@@ -229,6 +258,83 @@ def test_a_module_that_disagrees_keeps_the_library_convolution(monkeypatch):
     with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=3) as tmp:
         q2 = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
         assert dict(q2.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77))) == bits
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fq_conv_kxk_f32: R x S taps with zero padding through the same kernel (ResNet's 3x3 layers)
+KXK_SHAPES = [  # N, Cin, Cout, H, W, R, S, stride, pad
+    (2, 64, 64, 56, 56, 3, 3, 1, 1),
+    (3, 128, 128, 28, 28, 3, 3, 2, 1),
+    (4, 256, 256, 14, 14, 3, 3, 1, 1),
+    (5, 512, 512, 7, 7, 3, 3, 1, 1),
+    (2, 16, 36, 9, 11, 3, 3, 1, 1),      # odd planes, Cout 36 (partial m tile)
+    (3, 32, 64, 10, 7, 3, 3, 2, 1),      # stride 2, odd width
+    (2, 16, 64, 8, 8, 5, 5, 1, 2),       # 5x5 taps
+    (2, 48, 20, 6, 9, 3, 3, 1, 0),       # no padding: Hout = 4, Wout = 7
+    (1, 16, 128, 12, 12, 3, 3, 3, 1),    # stride 3
+    (2, 16, 16, 5, 5, 1, 3, 1, 1),       # 1x3 taps with padding on both axes
+    (7, 32, 32, 1, 1, 3, 3, 1, 1),       # 1x1 planes: eight of the nine taps are padding
+]
+
+
+def _kxk_case(shape, seed, integer):
+    N, cin, cout, H, W, R, S, st, pad = shape
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if integer:
+        x = torch.randint(-8, 9, (N, cin, H, W), device="cuda", generator=g).float()
+        w = torch.randint(-8, 9, (cout, cin, R, S), device="cuda", generator=g).float()
+        b = torch.randint(-100, 101, (cout,), device="cuda", generator=g).float()
+    else:
+        x = torch.randn(N, cin, H, W, device="cuda", generator=g)
+        w = torch.randn(cout, cin, R, S, device="cuda", generator=g) * (cin * R * S) ** -0.5
+        b = torch.randn(cout, device="cuda", generator=g)
+    return x, w, b, (R, S), st, pad
+
+
+@pytest.mark.parametrize("shape", KXK_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_kxk_exact_on_integer_valued_data(nat, shape):
+    x, w, b, k, st, pad = _kxk_case(shape, 41, integer=True)       # |sum| <= 4608 * 64 + 100 < 2^24: exact in any order
+    y = nat.conv_kxk_f32(x, nat.pack_kxk_weight(w), b, k, st, pad)
+    assert torch.equal(y.double(), torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=st, padding=pad))
+    y0 = nat.conv_kxk_f32(x, nat.pack_kxk_weight(w), None, k, st, pad)
+    assert torch.equal(y0.double(), torch.nn.functional.conv2d(x.double(), w.double(), None, stride=st, padding=pad))
+
+
+@pytest.mark.parametrize("shape", KXK_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_kxk_gaussian_data_statistics_and_relu(nat, shape):
+    x, w, b, k, st, pad = _kxk_case(shape, 42, integer=False)
+    wt = nat.pack_kxk_weight(w)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=st, padding=pad)
+    bound = torch.nn.functional.conv2d(x.abs().double(), w.abs().double(), b.abs().double(), stride=st, padding=pad)
+    y = nat.conv_kxk_f32(x, wt, b, k, st, pad)
+    assert bool(((y.double() - ref).abs() <= 1e-5 * bound).all()) and torch.equal(y, nat.conv_kxk_f32(x, wt, b, k, st, pad))
+    mx = torch.tensor([0.0, 1e9, 0.0], device="cuda")
+    r = torch.empty_like(y)
+    y1 = nat.conv_kxk_f32(x, wt, b, k, st, pad, max_dev=mx, row=2, relu_out=r)
+    assert torch.equal(y1, y) and torch.equal(r, torch.relu(y)) and mx.tolist() == [0.0, 1e9, float(y.abs().max())]
+    iv = torch.tensor([1.0, float(y.abs().max()) / 2048 + 1e-12], device="cuda")
+    hist = torch.zeros(2, 2048, dtype=torch.int64, device="cuda")
+    hist[1, 3] = 11
+    want = hist.clone()
+    y2 = nat.conv_kxk_f32(x, wt, b, k, st, pad, interval_dev=iv, hist_dev=hist, row=1, relu_out=r)
+    nat.hist2048_seg([y], [1], iv, want)
+    assert torch.equal(y2, y) and torch.equal(r, torch.relu(y)) and torch.equal(hist, want)
+
+
+def test_kxk_argument_errors_and_oracle(nat, oracle):
+    L = nat.lib()
+    x = torch.zeros(1, 8, 4, 4, device="cuda")                               # Cin = 8: not a multiple of 16
+    wt = torch.zeros(72, 8, device="cuda")
+    y = torch.zeros(1, 8, 4, 4, device="cuda")
+    assert L.fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 8, 4, 4, 8, 3, 3, 1, 1, None, None, None, None) == -4
+    assert L.fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 16, 2, 2, 8, 5, 5, 1, 1, None, None, None, None) == -1
+    rng = np.random.default_rng(6)
+    xi = rng.integers(-8, 9, (2, 32, 9, 8)).astype(np.int32)
+    wi = rng.integers(-8, 9, (40, 32, 3, 3)).astype(np.int32)
+    for st in (1, 2):
+        got = nat.conv_kxk_f32(torch.from_numpy(xi.astype(np.float32)).cuda(), nat.pack_kxk_weight(torch.from_numpy(wi.astype(np.float32)).cuda()),
+                               None, (3, 3), st, 1).cpu().numpy()
+        assert np.array_equal(got, oracle.conv2d_int(xi, wi, stride=(st, st), pad=(1, 1)).astype(np.float32))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
