@@ -2,14 +2,14 @@
 ResNet-50"): the bottleneck ResNet-50 / ResNet-101 calibrated with the HIP engine and with the CPU oracle engine on the
 SAME activations must give identical maxima, 2048-bin histograms, tables and JSON files.
 
-The activations come from the GPU forward (MIOpen's fp32 convolutions differ from a CPU's in the last bits, so running
-the CPU engine on its own forward would compare convolution libraries, not calibrators): the HIP run tapes every tensor
+The activations come from the GPU forward (its fp32 convolutions -- this library's own MFMA kernels -- differ from a CPU's
+in the last bits, so running the CPU engine on its own forward would compare convolution implementations, not calibrators): the HIP run tapes every tensor
 its statistics were taken from, the oracle run replays the tape.
 
 The tape sees BOTH ways a tensor reaches the statistics: handed to the collector (refresh_max_val /
 add_to_distributions), or -- the default pass-1 path that bench.py times -- served by its producer
-(fq_bias_add_absmax_f32 for the 53 convolutions, fq_add_absmax_f32 for the 16 Eltwise adds, the 49 ReLUs fed from those
-kernels); those are taped from the forward hook (`_EagerStats.note`), after the fused kernel wrote them.
+(the 53 convolutions' own epilogues -- fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32; fq_bias_add_absmax_f32 with
+FQ_OWN_CONV1X1=0 --, fq_add_absmax_f32 for the 16 Eltwise adds, the 49 ReLUs fed from those kernels); those are taped from the forward hook (`_EagerStats.note`), after the fused kernel wrote them.
 
 pytest -m gpu"""
 import hashlib
