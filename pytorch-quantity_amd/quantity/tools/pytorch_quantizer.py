@@ -400,8 +400,12 @@ class Quantity(object):
         return max(warm, 0)
 
     def _patch_fused_convs(self, model):
-        """Give every hooked nn.Conv2d with a bias a forward that, while pass 1 is running on the GPU, leaves the bias to
-        the forward hook (fq_bias_add_absmax_f32).  Returns the patched modules (undo: del module.forward)."""
+        """Instance-level forwards for the duration of a GPU calibration (undo: del module.forward; returns the patched modules):
+        every hooked nn.Conv2d with a bias leaves its work to its forward hook -- the whole convolution with the statistic in
+        the epilogue where common.quantity._float_conv takes the layer (1x1, R x S with zero padding, the 7x7/2 stem), else
+        convolution-without-bias here and fq_bias_add_absmax_f32 / fq_bias_add_hist_f32 in the hook; `Eltwise` likewise
+        (fq_add_absmax_f32 / fq_add_hist_f32); nn.MaxPool2d / a global nn.AvgPool2d run on fq_maxpool2d_f32 /
+        fq_avgpool_global_f32; an out-of-place nn.ReLU fed by one of the producers hands out the copy that producer wrote."""
         patched = []
         if not self.fuse_bias_absmax or "Conv2d" not in self._all_op_type or "Conv2d" not in self._cared_op_type:
             return patched
