@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""GPU fuzz: fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32 on random shapes with integer-valued data (every partial sum
+exact in fp32, so any indexing mistake is a wrong bit) against a float64 convolution, with the abs-max / histogram / ReLU copy
+checked on the same output.  usage: float_conv_fuzz.py [cases=300] [seed=0]"""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity"))
+from common.quantity import _native as nat
+
+
+def run(cases, seed, verbose=True):
+    """Returns the list of failing configurations."""
+    rng = np.random.default_rng(seed)
+    failures = []
+    for it in range(cases):
+        kind = rng.choice(["c1", "kxk", "stem"], p=[0.4, 0.45, 0.15])
+        N = int(rng.integers(1, 9))
+        if kind == "stem":
+            cin, R, S, st = 3, 7, 7, 2
+            cout = int(rng.integers(1, 65)); pad = int(rng.integers(0, 4))
+            H, W = int(rng.integers(7, 80)), int(rng.integers(7, 80))
+        elif kind == "c1":
+            cin = int(rng.integers(1, 200)); cout = 4 * int(rng.integers(1, 80)); R = S = 1; pad = 0
+            st = int(rng.choice([1, 1, 2, 3])); H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        else:
+            cin = 16 * int(rng.integers(1, 9)); cout = 4 * int(rng.integers(1, 60))
+            R, S = int(rng.choice([1, 2, 3, 5])), int(rng.choice([1, 2, 3, 5]))
+            if R == 1 and S == 1:
+                S = 3
+            st = int(rng.choice([1, 1, 2, 3])); pad = int(rng.integers(0, 3))
+            H, W = int(rng.integers(max(1, R - 2 * pad), 36)), int(rng.integers(max(1, S - 2 * pad), 36))
+        g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+        x = torch.randint(-8, 9, (N, cin, H, W), device="cuda", generator=g).float()
+        w = torch.randint(-8, 9, (cout, cin, R, S), device="cuda", generator=g).float()
+        b = torch.randint(-50, 51, (cout,), device="cuda", generator=g).float()
+        ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=st, padding=pad)
+        mx = torch.zeros(1, device="cuda")
+        r = torch.empty(ref.shape, device="cuda")
+        if kind == "c1":
+            run_k = lambda **kw: nat.conv1x1_f32(x, w.view(cout, cin).t().contiguous(), b, st, **kw)
+        elif kind == "kxk":
+            run_k = lambda **kw: nat.conv_kxk_f32(x, nat.pack_kxk_weight(w), b, (R, S), st, pad, **kw)
+        else:
+            run_k = lambda **kw: nat.conv_stem_f32(x, nat.pack_stem_weight(w), b, cout, (7, 7), 2, pad, **kw)
+        y = run_k(max_dev=mx, row=0, relu_out=r)
+        iv = torch.tensor([float(mx[0]) / 2048 + 1e-12], device="cuda")
+        hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+        want = torch.zeros_like(hist)
+        y2 = run_k(interval_dev=iv, hist_dev=hist, row=0)
+        nat.hist2048_seg([y], [0], iv, want)
+        ok = (torch.equal(y.double(), ref) and torch.equal(y2, y) and float(mx[0]) == float(y.abs().max())
+              and torch.equal(r, torch.relu(y)) and torch.equal(hist, want))
+        if not ok:
+            cfg = (kind, dict(N=N, cin=cin, cout=cout, H=H, W=W, R=R, S=S, stride=st, pad=pad))
+            failures.append(cfg)
+            if verbose:
+                print("MISMATCH", cfg, flush=True)
+    return failures
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+    bad = run(n, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print("%d cases, %d mismatches" % (n, len(bad)))
+    sys.exit(1 if bad else 0)

@@ -37,3 +37,14 @@ def test_random_segment_lists_match_the_oracle():
     spec.loader.exec_module(mod)
     failures = mod.run(25, 77, verbose=False)
     assert not failures, failures[:5]
+
+
+def test_random_float_convolutions_are_exact_on_integer_data():
+    """scripts/float_conv_fuzz.py: fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32 on 150 random shapes (K tails, partial
+    tiles, strides 1-3, paddings 0-3, 1x1 .. 5x5 taps, 1-pixel planes) with integer-valued data against a float64
+    convolution -- exact -- plus the folded abs-max / histogram / ReLU copy on the same output."""
+    spec = importlib.util.spec_from_file_location("float_conv_fuzz", os.path.join(ROOT, "scripts", "float_conv_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    failures = mod.run(150, 909, verbose=False)
+    assert not failures, failures[:5]
