@@ -34,8 +34,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "fq_resident.h"
-#include "fq_int_tail.h"
+#include "fq_conv_i8_common.h"
 
 namespace fq {
 
@@ -54,32 +53,6 @@ __device__ __forceinline__ unsigned long long stamp() {
 #endif
 
 
-constexpr int kConvBlock = 256;
-constexpr int kTP = 128;                 // pixels per workgroup tile
-
-struct ConvParams {
-    int N, H, W, C;                      // input NHWC, C % 16 == 0
-    int K, R, S;                         // weights [K][R][S][C]
-    int P, Q;                            // output spatial
-    int stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
-    int M;                               // N * P * Q
-    int chunks;                          // R * S * C / 16   (16-byte units of the reduction axis)
-    int c16;                             // C / 16
-    float inv_rs, inv_ob, lo, hi;        // 2^-rs, 2^-ob, clamp range (lo = 0 when a ReLU is fused)
-    int ilo, ihi;
-    int Kpad;                            // channel stride of the int8 NHWC output (>= K, multiple of 16)
-    unsigned x_bytes;                    // N * H * W * C: num_records of the activation buffer descriptor
-    int rs, half_rs, slo, shi;           // integer tail: shift, 2^(rs-1), Sp range; rs = 0 selects the fp32 tail
-    unsigned w_bytes;                    // K * R * S * C: num_records of the weight buffer descriptor
-    // fused residual add (kOutAdd): the conv output is operand x of NewAdd, `res` is operand y
-    const void* res;                     // int8 / int16 NHWC [N][P][Q][Kpad], same layout as the int8 output
-    int res_bytes;
-    int16_t* wide;                       // exact int16 sum (may be null); the int8 output pointer receives `narrow`
-    AddResParams ap;
-    // XCD-aware workgroup order (0 = plain 2-D grid): see conv_tile_of()
-    int xcd_kt, tiles_m;
-};
-
 // Which (pixel tile, output-channel tile) this workgroup computes.  Workgroups are dealt to the 8 XCDs round robin
 // by linear id, and each XCD has its own L2.  With the plain grid (pixel tiles on x) the k-tiles of one pixel tile run
 // gridDim.x workgroups apart on whatever XCD that lands on: every one of them fetches the activation tile again from
@@ -92,47 +65,6 @@ __device__ __forceinline__ bool conv_tile_of(const ConvParams& p, int& bx, int& 
     bx = (int)(slot / (unsigned)p.xcd_kt) * 8 + (int)(id & 7u);
     return bx < p.tiles_m;                                // the grid is padded to a multiple of 8 pixel tiles
 }
-
-// Activation loads are buffer loads: an out-of-image tap (zero padding) or a chunk past the end of the
-// reduction axis gets the offset kOutOfRange, which is beyond num_records of the buffer descriptor, and the
-// hardware returns zeros -- no select, no branch, no zero page.  (A first version selected between the
-// activation pointer and a __device__ const zero page: the const object lives in the constant address
-// space, every operand load degraded to flat_load, and the compiler then waited for vmcnt(0) -- the whole
-// weight-tile latency -- before it issued the activation loads of each K-step.)
-typedef unsigned v4u __attribute__((ext_vector_type(4)));
-constexpr unsigned kOutOfRange = 0x80000000u;             // tensors on this path are < 2^31 bytes
-// LDS-DMA: 64 lanes x 16 bytes from a buffer straight into LDS at lds_base + 16 * lane.  Deliberately inline
-// asm rather than __builtin_amdgcn_raw_ptr_buffer_load_lds: hipcc treats the builtin as an LDS store that may
-// alias every later ds_read and inserts s_waitcnt vmcnt(0) right behind it -- in the K loop that serialised
-// the next step's loads with this step's MFMAs completely (found in the ISA, not in the timings of a
-// trace build whose stamps perturb the schedule).  The asm has no memory clobber; ordering is explicit:
-// every wave waits vmcnt(0) and passes a workgroup barrier before anyone reads the slot that was filled.
-typedef int rsrc_words __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ rsrc_words make_rsrc_words(const void* base, unsigned bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
-    rsrc_words r = {(int)(unsigned)(a & 0xffffffffu), (int)(unsigned)((a >> 32) & 0xffffu), (int)bytes, 0x00020000};
-    return r;
-}
-// (m0 is what the instruction reads its LDS base from; naming it in the clobber list is the point, and clang's
-// "clobber list contains reserved registers" note about it is silenced here only)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
-__device__ __forceinline__ void dma_to_lds(rsrc_words rsrc, unsigned lds_base, unsigned voffset, int soffset) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
-                 :: "s"(lds_base), "v"(voffset), "s"(rsrc), "s"(soffset) : "m0");
-}
-#pragma clang diagnostic pop
-__device__ __forceinline__ unsigned lds_offset(const void* shared_ptr) {
-    return (unsigned)(unsigned long long)(__attribute__((address_space(3))) const void*)shared_ptr;
-}
-
-__device__ __forceinline__ v4i load_act(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return (v4i)__builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
-}
-
-// 128-byte LDS rows hold 8 16-byte chunks; chunk ^= (row >> 1) & 7 makes every ds_read_b128 lane
-// group ({0-3,12-15,20-27}, ...) touch 16 distinct 16-byte slots of the 256-byte bank row.
-__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 // RightShift -> BiasAdd -> Sp -> DeQuantity on one accumulator (new_quantity_op.py:127-132)
 // The values are integers (never NaN), so the clamps are single v_med3 instructions; v == 0 may round
@@ -168,9 +100,6 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
     }
 }
 
-// kOut: bit 0 = fp32 NCHW output y (the module-boundary format), bit 1 = int8 NHWC output q (the
-// resident hand-off to the next integer layer: 1 byte per element instead of 4 written + 4 read + 1).
-constexpr int kOutF32 = 1, kOutI8 = 2, kOutAdd = 4;      // kOutAdd: with kOutI8, NewAdd fused into the store
 
 // Epilogue shared by the conv kernels.  Accumulator layout (v_mfma_i32_32x32x32_i8): D row = k_out =
 // (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel (wave*32 + lane&31 of the 128-pixel tile).  The tail
@@ -1042,6 +971,11 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     p.x_bytes = (unsigned)((long)N * H * W * C);
     p.w_bytes = (unsigned)((long)K * R * S * C);
     hipStream_t st = as_stream(stream);
+    // 1x1 layers with an int8 output: the streaming kernel with stationary weights (fq_conv1x1_i8.hip) where it applies
+    if (launch_conv1x1_stream(st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p)) {
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    }
     const unsigned gx = (unsigned)((M + kTP - 1) / kTP);
     // 64-row tiles when the output is narrow, or when 128-row tiles would not even give one workgroup per CU
     const long wg128 = (long)gx * ((K + 127) / 128);

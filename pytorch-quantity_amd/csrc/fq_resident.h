@@ -52,24 +52,25 @@ template <> struct Vec16<int16_t> {
 //   narrow = med3(k > 0 ? (S + 2^(k-1) - 1 + ((S >> k) & 1)) >> k : S << -k, -128, 127),  k = g - ib
 // (round-half-to-even of S / 2^k is exactly what rint does on the exact quotient) -- 10 vector instructions per
 // element instead of 17; the fused conv + add epilogue of the 1x1 expand layers is bound by exactly these.
+struct Add16Out {                                         // 16 elements: the exact sum as 16 int16, its re-quantisation as 16 int8
+    v4i_r w0, w1, n;
+};
+
 template <bool kShiftRight, typename VX, typename VY>
-__device__ __forceinline__ void add_resident_16_int(const VX& vx, const VY& vy, int16_t* __restrict__ wide,
-                                                    int8_t* __restrict__ narrow, const AddResParams& p) {
+__device__ __forceinline__ Add16Out add_resident_16_int(const VX& vx, const VY& vy, bool want_wide, bool want_narrow,
+                                                        const AddResParams& p) {
+    Add16Out o = {};
     int s[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) s[e] = med3_i32((vx.geti(e) << p.shx) + (vy.geti(e) << p.shy), p.ilo, p.ihi);
-    if (wide) {
-        v4i_r o0, o1;
+    if (want_wide) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             const int w = (int)__builtin_amdgcn_perm((unsigned)s[2 * d + 1], (unsigned)s[2 * d], 0x05040100u);   // low halves
-            if (d < 4) o0[d] = w; else o1[d - 4] = w;
+            if (d < 4) o.w0[d] = w; else o.w1[d - 4] = w;
         }
-        *reinterpret_cast<v4i_r*>(wide) = o0;
-        *reinterpret_cast<v4i_r*>(wide + 8) = o1;
     }
-    if (narrow) {
-        v4i_r o;
+    if (want_narrow) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             int q[4];
@@ -79,39 +80,37 @@ __device__ __forceinline__ void add_resident_16_int(const VX& vx, const VY& vy, 
                 const int r = kShiftRight ? (S + p.half_m1 + ((S >> p.k) & 1)) >> p.k : S << -p.k;
                 q[e] = med3_i32(r, -128, 127);
             }
-            o[d] = (int)pack4(q[0], q[1], q[2], q[3]);
+            o.n[d] = (int)pack4(q[0], q[1], q[2], q[3]);
         }
-        *reinterpret_cast<v4i_r*>(narrow) = o;
     }
+    return o;
 }
 
+// The sum of 16 elements in registers (the callers store it: plain pointers in fq_resident.hip / the general conv epilogue,
+// buffer stores in fq_conv1x1_i8.hip)
 template <typename VX, typename VY>
-__device__ __forceinline__ void add_resident_16(const VX& vx, const VY& vy, int16_t* __restrict__ wide, int8_t* __restrict__ narrow,
-                                                const AddResParams& p) {
+__device__ __forceinline__ Add16Out add_resident_16_regs(const VX& vx, const VY& vy, bool want_wide, bool want_narrow,
+                                                         const AddResParams& p) {
     if (p.int_ok) {                                       // uniform
-        if (p.k > 0) add_resident_16_int<true>(vx, vy, wide, narrow, p);
-        else add_resident_16_int<false>(vx, vy, wide, narrow, p);
-        return;
+        if (p.k > 0) return add_resident_16_int<true>(vx, vy, want_wide, want_narrow, p);
+        return add_resident_16_int<false>(vx, vy, want_wide, want_narrow, p);
     }
+    Add16Out o = {};
     float s[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const float v = vx.get(e) * p.sx + vy.get(e) * p.sy;
         s[e] = __builtin_amdgcn_fmed3f(v, p.lo, p.hi);                // integers scaled by 2^k: never NaN
     }
-    if (wide) {
-        v4i_r o0, o1;
+    if (want_wide) {
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
             const unsigned lo16 = (unsigned)(int)(s[2 * d] * p.s_wide) & 0xffffu;
             const unsigned hi16 = (unsigned)(int)(s[2 * d + 1] * p.s_wide) << 16;
-            if (d < 4) o0[d] = (int)(lo16 | hi16); else o1[d - 4] = (int)(lo16 | hi16);
+            if (d < 4) o.w0[d] = (int)(lo16 | hi16); else o.w1[d - 4] = (int)(lo16 | hi16);
         }
-        *reinterpret_cast<v4i_r*>(wide) = o0;
-        *reinterpret_cast<v4i_r*>(wide + 8) = o1;
     }
-    if (narrow) {
-        v4i_r o;
+    if (want_narrow) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             unsigned w = 0;
@@ -120,10 +119,21 @@ __device__ __forceinline__ void add_resident_16(const VX& vx, const VY& vy, int1
                 const float q = __builtin_amdgcn_fmed3f(rintf(s[4 * d + e] * p.s_narrow), -128.0f, 127.0f);
                 w |= ((unsigned)(int)q & 0xffu) << (8 * e);
             }
-            o[d] = (int)w;
+            o.n[d] = (int)w;
         }
-        *reinterpret_cast<v4i_r*>(narrow) = o;
     }
+    return o;
+}
+
+template <typename VX, typename VY>
+__device__ __forceinline__ void add_resident_16(const VX& vx, const VY& vy, int16_t* __restrict__ wide, int8_t* __restrict__ narrow,
+                                                const AddResParams& p) {
+    const Add16Out o = add_resident_16_regs(vx, vy, wide != nullptr, narrow != nullptr, p);
+    if (wide) {
+        *reinterpret_cast<v4i_r*>(wide) = o.w0;
+        *reinterpret_cast<v4i_r*>(wide + 8) = o.w1;
+    }
+    if (narrow) *reinterpret_cast<v4i_r*>(narrow) = o.n;
 }
 
 // host: parameters of one resident add; FQ_OK or an error code (ranges, exact-sum grid)

@@ -5,19 +5,47 @@ stride-2 stem on fq_conv_stem_f32 (csrc/) -- every convolution of a ResNet, so t
 and never enters the convolution library (whose first-use solver search costs seconds in a fresh process).  Which call qualifies, the
 weights in the kernels' layout (cached on the module), the once-per-process check of every module against an independent
 implementation of the same fp32 mathematics, and the plain (no statistic) forward.  Shared by tools.Quantity (which adds the
-statistic epilogues) and TestConv."""
+statistic epilogues) and TestConv.
+
+Nothing of this is stored ON the module: the reference pickles whole models (reconstruction.py:107-140, torch.save(self.model)),
+and a packed CUDA copy of the weights or a flag in m.__dict__ would travel into that file (and survive model.cpu()).  The
+per-module state lives in a WeakKeyDictionary of this file instead and dies with the module."""
 import os
+import weakref
 
 import torch
 
 from . import _native
 
-__all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "TOL", "VERIFIED", "OFF"]
+__all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "state", "is_verified", "is_off", "forget", "TOL"]
 
-VERIFIED = "_fq_conv1x1_verified"               # module attribute: the own kernel agreed with torch here
-OFF = "_fq_conv1x1_off"                         # module attribute: it disagreed: this module keeps torch's convolution
-_WT = "_fq_conv1x1_wt"                          # module attribute: (tag of the parameter, weights in the kernel's layout)
 TOL = 1e-5                                      # |own - torch| <= TOL * (|W| * |x| + |b|): summation order only
+# module -> {"verified": the own kernel agreed with torch here, "off": it disagreed (the module keeps torch's convolution),
+#            "wt": (tag of the parameter, weights in the kernel's layout)}
+_STATE = weakref.WeakKeyDictionary()
+
+
+def state(m):
+    st = _STATE.get(m)
+    if st is None:
+        st = _STATE[m] = {}
+    return st
+
+
+def is_verified(m):
+    return bool(_STATE.get(m, {}).get("verified"))
+
+
+def is_off(m):
+    return bool(_STATE.get(m, {}).get("off"))
+
+
+def forget(m=None):
+    """Drop the cached weights and the check result of one module (None: of every module)."""
+    if m is None:
+        _STATE.clear()
+    else:
+        _STATE.pop(m, None)
 
 
 def enabled():
@@ -28,7 +56,7 @@ def kind(m, x):
     """"c1" (fq_conv1x1_f32), "kxk" (fq_conv_kxk_f32), "stem" (fq_conv_stem_f32) or None: which own kernel takes this call of
     the nn.Conv2d m."""
     if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or m.weight.dtype != torch.float32 or m.bias is None
-            or m.__dict__.get(OFF) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
+            or is_off(m) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
             or not x.is_contiguous() or isinstance(m.padding, str) or m.padding[0] != m.padding[1] or m.padding_mode != "zeros"
             or x.numel() >= 2 ** 30 or x.shape[0] * m.out_channels * x.shape[2] * x.shape[3] >= 2 ** 30):
         return None
@@ -49,12 +77,13 @@ def weight(m, k):
     was written to or replaced."""
     w = m.weight
     tag = (k, w._version, w.data_ptr(), w.device)
-    cached = m.__dict__.get(_WT)
+    st = state(m)
+    cached = st.get("wt")
     if cached is None or cached[0] != tag:
         packed = (w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1"
                   else _native.pack_kxk_weight(w) if k == "kxk" else _native.pack_stem_weight(w))
         cached = (tag, packed)
-        m.__dict__[_WT] = cached
+        st["wt"] = cached
     return cached[1]
 
 
@@ -71,7 +100,7 @@ def runner(m, k, x):
 def verified(m, run, x):
     """Once per process and module: the own kernel against torch on this very input.  Returns torch's result when the
     module fails (and marks it: it keeps the library convolution from now on), None when it passes."""
-    if m.__dict__.get(VERIFIED):
+    if is_verified(m):
         return None
     # The reference result comes from an independent implementation of the same fp32 mathematics that is NOT the convolution
     # library wherever that is cheap: asking that library for a layer it will never run again would put its first-use solver
@@ -101,9 +130,9 @@ def verified(m, run, x):
     own = run(max_dev=scratch, row=0)
     cmp = own if head is None else own[:head]
     if not (bool(((cmp - ref).abs() <= TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
-        m.__dict__[OFF] = True
+        state(m)["off"] = True
         return ref if head is None else torch.nn.Conv2d.forward(m, x)
-    m.__dict__[VERIFIED] = True
+    state(m)["verified"] = True
     return None
 
 

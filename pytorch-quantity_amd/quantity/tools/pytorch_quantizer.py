@@ -66,11 +66,22 @@ def _dist_on():
     return dist.is_available() and dist.is_initialized()
 
 
-_RELU_VERIFIED = "_fq_relu_fusion_verified"
-_C1_OFF = _float_conv.OFF                           # (tests reach these through this module)
-_POOL_VERIFIED = "_fq_pool_verified"                 # module attribute: the own pooling kernel gave torch's bits here
-_POOL_OFF = "_fq_pool_off"
-_FUSION_VERIFIED = "_fq_bias_fusion_verified"     # module attribute: conv-without-bias + fq_bias_add_absmax_f32 == its forward
+# Once-per-process check results, per module.  Kept in _float_conv's WeakKeyDictionary, never on the module: the reference
+# pickles whole models (reconstruction.py:107-140) and nothing of this package may travel into that file.
+_RELU_VERIFIED = "relu_fusion_verified"
+_POOL_VERIFIED = "pool_verified"                  # the own pooling kernel gave torch's bits here
+_POOL_OFF = "pool_off"
+_FUSION_VERIFIED = "bias_fusion_verified"         # conv-without-bias + fq_bias_add_absmax_f32 == its forward
+
+
+def _flag(m, name):
+    return bool(_float_conv.state(m).get(name))
+
+
+def _set_flag(m, name):
+    _float_conv.state(m)[name] = True
+
+
 _AFTER_FORWARD = 1 << 62      # _EagerStats limit that is never reached: one flush, after the forward
 
 
@@ -428,7 +439,7 @@ class Quantity(object):
                 if ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"]:
                     return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
                 own = _float_conv.kind(m, x) if self.own_conv1x1 else None
-                if own is None and m not in ctl["fuse_warm"] and not m.__dict__.get(_FUSION_VERIFIED):
+                if own is None and m not in ctl["fuse_warm"] and not _flag(m, _FUSION_VERIFIED):
                     ctl["fuse_warm"].add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
                     return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
                 if own is not None:
@@ -467,19 +478,19 @@ class Quantity(object):
                         and not torch.is_grad_enabled() and x.numel() < 2 ** 32 - 1)
 
             def checked(m, cls, x, y):
-                if not m.__dict__.get(_POOL_VERIFIED):           # once per process: the same bits as torch's kernel?
+                if not _flag(m, _POOL_VERIFIED):           # once per process: the same bits as torch's kernel?
                     ref = cls.forward(m, x)
                     if not torch.equal(y, ref):
-                        m.__dict__[_POOL_OFF] = True
+                        _set_flag(m, _POOL_OFF)
                         return ref
-                    m.__dict__[_POOL_VERIFIED] = True
+                    _set_flag(m, _POOL_VERIFIED)
                 return y
             for m in model.modules():
                 if "forward" in m.__dict__:
                     continue
                 if type(m) is torch.nn.MaxPool2d:
                     def forward(x, m=m):
-                        if (m.__dict__.get(_POOL_OFF) or not pool_active(x) or pair(m.dilation) != (1, 1) or m.ceil_mode
+                        if (_flag(m, _POOL_OFF) or not pool_active(x) or pair(m.dilation) != (1, 1) or m.ceil_mode
                                 or m.return_indices):
                             return torch.nn.MaxPool2d.forward(m, x)
                         k, p = pair(m.kernel_size), pair(m.padding)
@@ -489,7 +500,7 @@ class Quantity(object):
                     patched.append(m)
                 elif type(m) is torch.nn.AvgPool2d:
                     def forward(x, m=m):
-                        if (m.__dict__.get(_POOL_OFF) or not pool_active(x) or pair(m.kernel_size) != tuple(x.shape[2:])
+                        if (_flag(m, _POOL_OFF) or not pool_active(x) or pair(m.kernel_size) != tuple(x.shape[2:])
                                 or pair(m.padding) != (0, 0) or m.ceil_mode or m.divisor_override is not None
                                 or x.shape[2] * x.shape[3] > 144):
                             return torch.nn.AvgPool2d.forward(m, x)
@@ -548,11 +559,11 @@ class Quantity(object):
             return
         r = torch.empty_like(output)
         run(r)
-        if not m.__dict__.get(_RELU_VERIFIED):              # once per process: the same bits as torch's ReLU?
+        if not _flag(m, _RELU_VERIFIED):              # once per process: the same bits as torch's ReLU?
             if not torch.equal(r, torch.nn.functional.relu(output)):
                 self.fuse_relu = False
                 return
-            m.__dict__[_RELU_VERIFIED] = True
+            _set_flag(m, _RELU_VERIFIED)
         ctl["relu_ready"] = (output, r, relu, output._version)      # holds the tensor itself: identity, not a reusable id
         ctl["fused_relus"].add(relu)
 
@@ -575,7 +586,7 @@ class Quantity(object):
                                                                           out=output, relu_out=r))
                 ctl["hist_fused"] += 1
                 return True
-            if not m.__dict__.get(_FUSION_VERIFIED):        # first use: the kernel against torch.add, once per process
+            if not _flag(m, _FUSION_VERIFIED):        # first use: the kernel against torch.add, once per process
                 scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
                 z = _native.add_absmax(a, b, scratch, 0)
                 want = torch.add(a, b)
@@ -583,7 +594,7 @@ class Quantity(object):
                     ctl["fuse_off"] = True
                     output.copy_(want)
                     return False
-                m.__dict__[_FUSION_VERIFIED] = True
+                _set_flag(m, _FUSION_VERIFIED)
             ctl["fuse_verified"].add(m)
             self._run_with_relu(m, output, lambda r: _native.add_absmax(a, b, coll.max_device, row, out=output, relu_out=r))
             coll.note_max_refreshed()
@@ -597,7 +608,7 @@ class Quantity(object):
                                                                            coll.hist_device, row, relu_out=r))
             ctl["hist_fused"] += 1
             return True
-        if m in ctl["fuse_verified"] or m.__dict__.get(_FUSION_VERIFIED):
+        if m in ctl["fuse_verified"] or _flag(m, _FUSION_VERIFIED):
             ctl["fuse_verified"].add(m)
             self._run_with_relu(m, output, lambda r: _native.bias_add_absmax(output, m.bias, coll.max_device, row, relu_out=r))
             coll.note_max_refreshed()
@@ -617,7 +628,7 @@ class Quantity(object):
         reproducible = torch.equal(ref, torch.nn.Conv2d.forward(m, x))
         if kernel_ok and (torch.equal(raw, ref) or not reproducible):
             ctl["fuse_verified"].add(m)
-            m.__dict__[_FUSION_VERIFIED] = True             # a property of (module, MIOpen, this library): checked once per process
+            _set_flag(m, _FUSION_VERIFIED)             # a property of (module, MIOpen, this library): checked once per process
             _native.bias_add_absmax(output, m.bias, coll.max_device, row)
             coll.note_max_refreshed()
             return True

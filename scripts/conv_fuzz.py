@@ -75,6 +75,61 @@ def run(cases, seed, verbose=True):
     return failures
 
 
+def run_stream(cases, seed, verbose=True):
+    """The streaming 1x1 kernel (csrc/fq_conv1x1_i8.hip): every shape class it takes -- C = 64 or a multiple of 128, K a
+    multiple of 64, stride 1 / 2, int8 output alone or the fused NewAdd with an int8 / int16 residual and any subset of
+    {wide, narrow} -- on pixel counts that end inside a tile, inside a wave and inside a DMA row group.  With
+    FQ_STREAM_GROUPS=1 in the environment (read once, at the first launch) every launch runs as 8 streams, so that small
+    inputs walk several pixel tiles per workgroup."""
+    rng = np.random.default_rng(seed)
+    failures = []
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for it in range(cases):
+        C = int(rng.choice([64, 64, 128, 128, 256, 384, 512, 1024])); K = int(rng.choice([64, 128, 192, 256, 512]))
+        st = int(rng.choice([1, 1, 1, 2]))
+        N = int(rng.integers(1, 7)); H = int(rng.integers(1, 40)); W = int(rng.integers(1, 40))
+        if rng.random() < 0.3:
+            N, H, W = int(rng.integers(1, 4)), int(rng.integers(30, 64)), int(rng.integers(30, 64))
+        x = rng.integers(-128, 128, size=(N, C, H, W)).astype(np.int32)
+        w = rng.integers(-128, 128, size=(K, C, 1, 1)).astype(np.int32)
+        qb = rng.integers(-128, 128, size=K).astype(np.float32)
+        rs = int(rng.integers(1, 17)); ob = int(rng.integers(-2, 7)); relu = bool(rng.integers(0, 2))
+        acc = orc.conv2d_int(x, w, (st, st), (0, 0), (1, 1))
+        ref = orc.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+        xd, wd, bd = dev(x.transpose(0, 2, 3, 1).astype(np.int8)), nat.pack_weight_krsc(dev(w.astype(np.float32))), dev(qb)
+        msg = "stream %d: N%d C%d H%d W%d K%d st%d rs%d ob%d relu%d" % (it, N, C, H, W, K, st, rs, ob, relu)
+        try:
+            refr = np.maximum(ref, np.float32(0)) if relu else ref
+            _, q2 = nat.conv2d_i8_resident(xd, wd, bd, (st, st), (0, 0), (1, 1), rs, ob, False, True, relu)
+            assert np.array_equal(q2.cpu().numpy().transpose(0, 3, 1, 2), orc.quantity(refr, ob).astype(np.int8)), "int8 output"
+            if st != 1:
+                continue
+            g_res = int(rng.integers(-1, 9)); res_dtype = np.int16 if rng.random() < 0.6 else np.int8
+            g = max(0, ob, g_res)
+            if g > 8:
+                continue
+            P, Q = ref.shape[2], ref.shape[3]
+            lim = 128 * 2 ** max(g_res, 0) if res_dtype == np.int16 else 128
+            res = rng.integers(-min(lim, 32768), min(lim, 32768), size=(N, P, Q, K)).astype(res_dtype)
+            ib = int(rng.integers(-1, 7))
+            s = orc.add_sat(ref, orc.dequantity(res.astype(np.float32), g_res).transpose(0, 3, 1, 2))
+            if relu: s = np.maximum(s, np.float32(0))
+            e = s.astype(np.float64) * 2.0 ** g
+            if not np.all(e == np.rint(e)):
+                continue
+            want_w, want_n = [(True, True), (True, False), (False, True)][int(rng.integers(0, 3))]
+            wide, narrow = nat.conv2d_i8_add_resident(xd, wd, bd, (st, st), (0, 0), (1, 1), rs, ob, dev(res), g_res, want_w, g, want_n, ib, relu)
+            if want_w:
+                assert np.array_equal(wide.cpu().numpy().transpose(0, 3, 1, 2), e.astype(np.int16)), "fused add wide (%s residual)" % res_dtype.__name__
+            if want_n:
+                assert np.array_equal(narrow.cpu().numpy().transpose(0, 3, 1, 2), orc.quantity(s, ib).astype(np.int8)), "fused add narrow (%s residual)" % res_dtype.__name__
+        except AssertionError as ex:
+            failures.append("%s -> %s" % (msg, ex))
+            if verbose:
+                print("MISMATCH", msg, "->", ex)
+    return failures
+
+
 def run_stem(cases, seed, verbose=True):
     """fq_conv2d_i8_stem against the oracle chain (Quantity -> integer conv -> tail -> ReLU -> next Quantity) on random
     stem-shaped layers: 1-4 input channels, kernels up to 8x8, strides 1-3, ragged images, K <= 64."""
@@ -121,9 +176,17 @@ def run_stem(cases, seed, verbose=True):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+    if len(sys.argv) > 3 and sys.argv[3] == "stream":          # only the streaming 1x1 kernel (run with FQ_CONV_STREAM=1)
+        stream_fails = run_stream(n, seed)
+        print("stream_fuzz: %d cases, %d mismatches (FQ_CONV_STREAM=%s FQ_STREAM_GROUPS=%s)"
+              % (n, len(stream_fails), os.environ.get("FQ_CONV_STREAM", ""), os.environ.get("FQ_STREAM_GROUPS", "")))
+        sys.exit(1 if stream_fails else 0)
     fails = run(n, seed)
     print("conv_fuzz: %d cases, %d mismatches" % (n, len(fails)))
     n_stem = max(20, n // 4)
     stem_fails = run_stem(n_stem, seed + 1)
     print("stem_fuzz: %d cases, %d mismatches" % (n_stem, len(stem_fails)))
-    sys.exit(1 if fails or stem_fails else 0)
+    n_stream = max(30, n // 2)
+    stream_fails = run_stream(n_stream, seed + 2)
+    print("stream_fuzz: %d cases, %d mismatches (FQ_STREAM_GROUPS=%s)" % (n_stream, len(stream_fails), os.environ.get("FQ_STREAM_GROUPS", "")))
+    sys.exit(1 if fails or stem_fails or stream_fails else 0)

@@ -253,11 +253,14 @@ def test_a_module_that_disagrees_keeps_the_library_convolution(monkeypatch):
         q = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
         bits = dict(q.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77)))
         assert q.timings["own_conv1x1_launches"] == 0
-        assert all(m.__dict__.get(pytorch_quantizer._C1_OFF) for m in (q.model.c1, q.model.c3, q.model.down))
+        assert all(_float_conv.is_off(m) for m in (q.model.c1, q.model.c3, q.model.down))
     monkeypatch.undo()
     with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=3) as tmp:
         q2 = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
         assert dict(q2.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77))) == bits
+        import pickle
+        blob = pickle.dumps(q2.model)                   # what Reconstruction's torch.save(self.model) would write
+        assert b"_fq_" not in blob and not any(k.startswith("_fq") for m in q2.model.modules() for k in m.__dict__)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -449,11 +452,13 @@ def test_testconv_runs_its_1x1_layers_on_the_own_kernel_and_hooks_still_fire():
         x = torch.randn(4, 32, 14, 14, device="cuda")
         with torch.no_grad():
             out = layer(x)
-            assert layer.Conv.__dict__.get(_float_conv.VERIFIED) and "forward" not in layer.Conv.__dict__ and len(seen) == 1
+            assert _float_conv.is_verified(layer.Conv) and "forward" not in layer.Conv.__dict__ and len(seen) == 1
+            assert not any(k.startswith("_fq") for k in layer.Conv.__dict__)
             assert torch.equal(out, _native.quandequan(seen[0], 4))
             ref = torch.nn.functional.conv2d(x, layer.Conv.weight, layer.Conv.bias)
             assert float((seen[0] - ref).abs().max()) <= 1e-4
         pickle.dumps(layer.Conv.state_dict())
+        assert b"_fq_" not in pickle.dumps(layer)                   # the whole-module pickle carries no packed copy / flag
 
 
 def test_pool_modules_are_served_and_tables_do_not_change():
@@ -483,6 +488,6 @@ def test_pool_modules_are_served_and_tables_do_not_change():
             q.own_pools = own
             bits = dict(q.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=78)))
             tables.append((bits, open(tmp + "/test/workdir/feat.table").read()))
-            served = [bool(m.__dict__.get(pytorch_quantizer._POOL_VERIFIED)) for m in (q.model.pool, q.model.avg)]
+            served = [pytorch_quantizer._flag(m, pytorch_quantizer._POOL_VERIFIED) for m in (q.model.pool, q.model.avg)]
             assert served == [own, own] and "forward" not in q.model.pool.__dict__      # patched only while calibrating
     assert tables[0] == tables[1]

@@ -19,6 +19,21 @@ def test_random_shapes_match_the_oracle():
     assert not failures, failures[:5]
 
 
+@pytest.mark.parametrize("groups", ["", "1"])
+def test_streaming_1x1_kernel_matches_the_oracle(groups):
+    """csrc/fq_conv1x1_i8.hip (opt-in: FQ_CONV_STREAM=1, read once per process, hence the child process): every shape class it
+    takes, int8 output and the fused NewAdd with int8 / int16 residuals, against the CPU oracle -- as many streams as the
+    device holds, and with FQ_STREAM_GROUPS=1 (8 streams: several pixel tiles per workgroup on small inputs)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FQ_CONV_STREAM="1")
+    if groups:
+        env["FQ_STREAM_GROUPS"] = groups
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_fuzz.py"), "40", "303", "stream"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "40 cases, 0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_random_histograms_kl_sweep_matches_the_oracle_bit_for_bit():
     """scripts/kl_fuzz.py: 96 random histograms of eight families; thresholds and KL curves (same include/fq_log.h on
     both sides) must agree bit for bit."""

@@ -329,4 +329,4 @@ def test_float_conv_dispatch_declines_what_the_kernels_do_not_take():
         with torch.no_grad():
             assert torch.equal(_float_conv.call(conv, x), conv(x))
         h.remove()
-        assert len(seen) == 2 and "forward" not in conv.__dict__ and not conv.__dict__.get(_float_conv.VERIFIED)
+        assert len(seen) == 2 and "forward" not in conv.__dict__ and not _float_conv.is_verified(conv)
