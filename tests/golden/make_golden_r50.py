@@ -8,6 +8,10 @@
           quantity/common/quantity/new_quantity_op.py:124-133,280-292) on the build's fabu ResNet-50 @224^2 --
           BASELINE configs 2/3 at their own model size: tables as text, logits for a fixed 2x3x224x224 input,
           a sub-sample + sha256 of the first layer's output, max |accumulator| over all integer layers.
+  r50stats  g4_r50_calib_stats.npz: what the reference's calibration of that model handed to its KL search (the merged
+          intervals and 2048-bin histograms of all 71 rows, quantity/tools/pytorch_quantizer.py:393-448) and the bits it
+          found -- so that a GPU calibration whose float forward differs in the last bits can be compared row by row
+          (maxima, histogram L1 distance), not only through the table.
   scales  g4_r50_bn_scales.npz: the BatchNorm fold factors of that model as the reference's merge_bn computes them in the
           build container (torch.sqrt on CPU is machine dependent in the last bit; see cases.fold_bn_with_scales).
   h6      G10 (g10_dilation.npz): Quantity.dilation_to_zero_padding (quantity/tools/pytorch_quantizer.py:679-693)
@@ -136,6 +140,38 @@ def capture_r50(cq, tl):
                                                                      out["feat_table"].split("\n")[:3]))
 
 
+def capture_r50_stats(cq, tl):
+    import torch
+    sys.path.append(OURS)
+    from model.resnet.ResNet_fabu import ResNet50
+    torch.set_num_threads(8)
+    seen = {}
+    qmod = sys.modules[tl.Quantity.__module__]
+    real = qmod.Quantizer.quantize
+
+    def spy(self, distributions, distribution_intervals):
+        seen["names"] = list(distributions.keys())
+        seen["hist"] = np.stack([np.asarray(distributions[k], dtype=np.int64) for k in seen["names"]])
+        seen["interval"] = np.array([distribution_intervals[k] for k in seen["names"]], dtype=np.float64)
+        real(self, distributions, distribution_intervals)
+        seen["bits"] = np.array([self.bits[k] for k in seen["names"]], dtype=np.int64)
+    qmod.Quantizer.quantize = spy
+    try:
+        with _refenv.reference_workdir(input_shape="1,3,224,224", max_cali_img_num=1) as tmp:
+            model = cq.merge_bn(cases.seed_model(ResNet50(), gamma_scale=GAMMA).eval(), "cpu")
+            q = tl.Quantity(model)
+            q.activation_quantize(cases.calib_batches(2, (2, 3, 224, 224), seed=77))
+            feat = _read(os.path.join(tmp, "test", "workdir", "feat.table"))
+    finally:
+        qmod.Quantizer.quantize = real
+    with open(os.path.join(HERE, "g4_r50_tables.json")) as fh:
+        assert json.load(fh)["feat_table"] == feat, "this run's feat.table differs from the committed G4-R50 one"
+    np.savez_compressed(os.path.join(HERE, "g4_r50_calib_stats.npz"), names=np.array(seen["names"]), hist=seen["hist"],
+                        interval=seen["interval"], bits=seen["bits"])
+    print("G4-R50 calibration statistics written:", seen["hist"].shape, "rows x bins; elements per row",
+          seen["hist"].sum(axis=1)[:4], "...")
+
+
 def capture_scales(cq, tl):
     """g4_r50_bn_scales.npz: the BatchNorm fold factors gamma / sqrt(running_var + 1e-5) of the seeded ResNet-50 exactly
     as the reference's merge_bn evaluates them HERE (utils.py:37: torch ops on CPU tensors -- torch.sqrt goes through MKL
@@ -217,6 +253,8 @@ def main():
         time_r18(cq, tl)
     if "r50" in which:
         capture_r50(cq, tl)
+    if "r50stats" in which:
+        capture_r50_stats(cq, tl)
 
 
 if __name__ == "__main__":

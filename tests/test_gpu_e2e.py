@@ -42,9 +42,8 @@ def calib(oracle):
         out["names"] = ["image"] + list(q.net_info.keys())
         out["intervals"] = {k: np.float32(v) for k, v in q._collector._distribution_intervals.items()}
         out["thr"] = dict(q._quantizer.threshold_bins)
-        # kernel-level exactness on real data: capture ONE set of activations per batch (MIOpen
-        # convolutions are not bitwise reproducible from call to call) and hand the very same
-        # tensors to a fresh HIP collector and to the oracle
+        # kernel-level exactness on real data: capture ONE set of activations per batch and hand the very
+        # same tensors to a fresh HIP collector and to the oracle
         from common.quantity import DistributionCollector
         feats, hooks = q.regist_hook_outfeature(q.model)
         captured = []
@@ -96,8 +95,8 @@ def test_engine_equals_oracle_on_gpu_activations(calib):
 
 
 def test_feat_table_matches_reference(calib, g3):
-    """MIOpen and oneDNN convolutions differ in the last bits, so activations are not bit-identical
-    to the reference's CPU run; the fractional bits are a coarse function of them and must agree."""
+    """This library's fp32 MFMA convolutions and the reference's oneDNN ones sum in different orders, so activations
+    are not bit-identical to the reference's CPU run; the fractional bits are a coarse function of them and must agree."""
     assert calib["feat_table"] == g3["feat_table"]
     assert {k: int(v) for k, v in calib["bits"].items()} == g3["bits_final"]
 
@@ -173,10 +172,11 @@ def test_reconmodel_logits_match_reference(golden_dir, g3):
 
 
 def test_recontest_logits_match_reference(golden_dir, g3):
-    """Fake-quant model: float convolutions (MIOpen vs oneDNN rounding) followed by quantise ->
-    dequantise.  Tolerance: fp32 conv noise may move a value across a rounding tie, so an output may
-    differ by one quantisation step (2^-output_bit) on a small fraction of elements; logits within
-    2 steps of the last layer (output_bit 0 -> 2.0) and >= 99% of first-layer outputs identical."""
+    """Fake-quant model: float convolutions (this library's fp32 MFMA kernels vs the reference's oneDNN: another
+    summation order) followed by quantise -> dequantise.  A value may land on the other side of a rounding tie, so an
+    output may differ by one quantisation step (2^-output_bit).  Observed on MI355X (scripts/_dbg/recontest_diff.py):
+    1 of 262 144 first-layer outputs differs, by one step; all logits identical.  Stated tolerance: >= 99.99 % of the
+    first layer identical, none more than one step apart; logits within one step of the last layer (output_bit 0 -> 1.0)."""
     from model.resnet.ResNet_18_fabu import ResNet18
     from tools import Reconstruction
     g4 = np.load(os.path.join(golden_dir, "g4_r18_recon.npz"))
@@ -196,9 +196,9 @@ def test_recontest_logits_match_reference(golden_dir, g3):
             first = net.conv1[0](x).cpu().numpy()
             logits = net(x).cpu().numpy()
         same = np.mean(first == g4["recontest_conv1_out"])
-        assert same >= 0.99, same
+        assert same >= 0.9999, same
         assert np.max(np.abs(first - g4["recontest_conv1_out"])) <= 2.0 ** -3 + 1e-6     # conv1.0 output_bit = 3
-        assert np.max(np.abs(logits - g4["logits_recontest"])) <= 2.0
+        assert np.max(np.abs(logits - g4["logits_recontest"])) <= 1.0
 
 
 @pytest.mark.parametrize("cache_gb,plan", [("0", ""), ("0.02", "A"), ("0.012", "B"), ("1", "B"), ("1", "A")])

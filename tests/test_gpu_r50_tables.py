@@ -324,11 +324,13 @@ def test_r50_reconmodel_logits_equal_the_reference(g4r50):
 
 
 def test_r50_recontest_logits_match_the_reference(g4r50):
-    """Fake-quant ResNet-50: float convolutions (MIOpen vs the reference's oneDNN) followed by QuanDequan.  fp32
-    convolution noise can move a value across a rounding tie, so an output may differ by one quantisation step
-    (2^-output_bit) on a small fraction of elements, and such flips propagate through 53 layers.
-    Tolerance (stated): first layer >= 99.9 % identical and never more than one step apart; logits within
-    4 steps of the classifier's grid (2^-output_bit of fc) of the reference's, and the same arg-max per image."""
+    """Fake-quant ResNet-50: float convolutions followed by QuanDequan.  The convolutions are this library's fp32 MFMA
+    kernels (fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32: a fixed k-ordered fma chain), the reference's are oneDNN's
+    on the CPU: same mathematics, different summation order, so a value can land on the other side of a rounding tie and
+    an output may differ by one quantisation step (2^-output_bit), which then propagates.
+    Observed on MI355X (scripts/_dbg/recontest_diff.py, round 3): the first layer's sample and ALL logits identical to the
+    reference's.  Stated tolerance: first layer >= 99.99 % identical and never more than one step apart; logits >= 99 %
+    identical, none more than one step of the classifier's grid apart, the same arg-max per image."""
     tables, g4 = g4r50
     x = cases.fixed_input(tuple(tables["input"]["shape"]), seed=tables["input"]["seed"]).cuda()
     with product_workdir(input_shape="1,3,224,224", device="gpu") as tmp:
@@ -340,11 +342,56 @@ def test_r50_recontest_logits_match_the_reference(g4r50):
             logits = net(x).cpu().numpy()
     step1 = 2.0 ** -info["conv1"]["output_bit"]
     sample = c1[:, :8, ::8, ::8]
-    assert np.mean(sample == g4["recontest_conv1_out_sample"]) >= 0.999
+    assert np.mean(sample == g4["recontest_conv1_out_sample"]) >= 0.9999
     assert np.max(np.abs(sample - g4["recontest_conv1_out_sample"])) <= step1 * (1 + 1e-6)
     step = 2.0 ** -info["fc"]["output_bit"]
-    assert np.max(np.abs(logits - g4["logits_recontest"])) <= 4 * step, (np.max(np.abs(logits - g4["logits_recontest"])), step)
+    diff = np.abs(logits - g4["logits_recontest"])
+    assert np.max(diff) <= step * (1 + 1e-6), (float(np.max(diff)), step)
+    assert np.mean(diff == 0) >= 0.99, float(np.mean(diff == 0))
     assert np.array_equal(logits.argmax(1), g4["logits_recontest"].argmax(1))
+
+
+def test_r50_end_to_end_feat_table_equals_the_reference(g4r50, golden_dir):
+    """north_star's target itself: the fabu ResNet-50, calibrated END TO END on the GPU -- this library's float forward
+    (fp32 MFMA convolutions, pooling, adds), its abs-max / histogram kernels and its KL search -- on the recipe the
+    reference was run on in the build container (tests/golden/make_golden_r50.py: seed 77, 2 batches of 2x3x224x224,
+    gamma 0.5, MAX_CALI_IMG_NUM 1) writes the reference's feat.table, all 71 rows.
+
+    The float forward is not bit-identical to the reference's CPU forward (summation order of the convolutions), so the
+    statistics differ in their last digits; the tolerance is stated on what the reference's KL search was handed
+    (g4_r50_calib_stats.npz, `r50stats` capture): every merged interval within 2e-6 relative (observed on MI355X:
+    8.5e-7, 60 of 71 rows differ at all), every 2048-bin histogram within 2e-3 of its element count in L1 distance
+    (observed: 1.0e-3 on the classifier row, 70 of 71 rows differ) -- and none of that moves a threshold across a bit."""
+    from common.quantity import Quantizer
+    from tools import Quantity
+    tables, _ = g4r50
+    stats = np.load(os.path.join(golden_dir, "g4_r50_calib_stats.npz"))
+    seen = {}
+
+    class SpyQuantizer(Quantizer):
+        def quantize(self, distributions, distribution_intervals):
+            seen["names"] = list(distribution_intervals.keys())
+            seen["interval"] = np.array([float(distribution_intervals[k]) for k in seen["names"]])
+            seen["hist"] = distributions.cpu().numpy().copy()
+            return super().quantize(distributions, distribution_intervals)
+
+    class SpyQuantity(Quantity):
+        quantizer_cls = SpyQuantizer
+
+    recipe = tables["calib"]
+    with product_workdir(input_shape="1,3,224,224", device="gpu", max_cali_img_num=recipe["n_batches"] - 1) as tmp:
+        q = SpyQuantity(_r50_folded(tables).cuda())
+        q.activation_quantize(cases.calib_batches(recipe["n_batches"], tuple(recipe["shape"]), seed=recipe["seed"]))
+        feat = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
+    assert seen["names"] == list(stats["names"])
+    ref_i, ref_h = stats["interval"], stats["hist"]
+    assert np.max(np.abs(seen["interval"] - ref_i) / ref_i) <= 2e-6
+    l1 = np.abs(seen["hist"] - ref_h).sum(axis=1) / ref_h.sum(axis=1)
+    assert l1.max() <= 2e-3, (float(l1.max()), seen["names"][int(l1.argmax())])
+    got, want = feat.strip().split("\n"), tables["feat_table"].strip().split("\n")
+    assert len(got) == len(want) == 71
+    assert [a for a, b in zip(got, want) if a != b] == []         # (names the differing rows on failure)
+    assert feat == tables["feat_table"]
 
 
 def test_r50_weight_tables_equal_the_reference(g4r50):
