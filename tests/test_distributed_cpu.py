@@ -37,7 +37,7 @@ WORKER = textwrap.dedent('''
     with product_workdir(device="cpu", max_cali_img_num=int(os.environ.get("FQ_TEST_MAX_CALI", "3"))) as tmp:
         model = merge_bn(cases.seed_model(ResNet18()).eval())
         q = CpuQuantity(model)
-        bits = q.activation_quantize(cases.calib_batches(5, (2, 3, 32, 32)))
+        bits = q.activation_quantize(cases.calib_batches(int(os.environ.get("FQ_TEST_BATCHES", "5")), (2, 3, 32, 32)))
         if os.environ.get("FQ_TEST_WEIGHTS") == "1":
             q.weight_quantize()
         wd = os.path.join(tmp, "test", "workdir")
@@ -54,16 +54,17 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def _run(world, out, max_cali=3, weights=False):
+def _run(world, out, max_cali=3, weights=False, batches=5, port=29617, threads=2):
     script = os.path.join(tempfile.mkdtemp(prefix="fq_dist_"), "worker.py")
     with open(script, "w") as fh:
         fh.write(WORKER.format(root=ROOT, out=out))
-    env = dict(os.environ, OMP_NUM_THREADS="2", FQ_TEST_MAX_CALI=str(max_cali), FQ_TEST_WEIGHTS="1" if weights else "0")
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), FQ_TEST_MAX_CALI=str(max_cali), FQ_TEST_WEIGHTS="1" if weights else "0",
+               FQ_TEST_BATCHES=str(batches))
     if world == 1:
         cmd = [sys.executable, script]
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-               "--master-addr", "127.0.0.1", "--master-port", "29617", script]
+               "--master-addr", "127.0.0.1", "--master-port", str(port), script]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     return json.load(open(out))
@@ -95,3 +96,19 @@ def test_rank_without_batches_still_gets_global_statistics(tmp_path):
     two = _run(2, str(tmp_path / "w2.json"), max_cali=0)
     assert one["table"] == two["table"]
     assert one["hist_sums"] == two["hist_sums"] and one["hist_sums"]["image"] == 2 * 3 * 32 * 32
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_rank_gloo_calibration_equals_the_single_process_table(tmp_path, world):
+    """BASELINE config 4's rank count (and half of it) on CPU: 10 calibration batches dealt round robin over 4 / 8 gloo ranks
+    (uneven shares: ranks 0 and 1 own one batch more than the others), one MAX and one SUM all-reduce -- the product's own
+    lines (common/quantity/_collectives.py) -- and rank 0's feat.table equals the single-process one byte for byte; no
+    other rank writes a file."""
+    one = _run(1, str(tmp_path / "w1.json"), max_cali=9, batches=10)
+    many = _run(world, str(tmp_path / "wn.json"), max_cali=9, batches=10, port=29640 + world, threads=1)
+    assert one["table"] == many["table"]
+    assert one["hist_sums"] == many["hist_sums"] and one["max"] == many["max"]
+    assert one["hist_sums"]["image"] == 10 * 2 * 3 * 32 * 32
+    for r in range(1, world):
+        assert json.load(open(str(tmp_path / "wn.json") + ".files.rank%d" % r)) == []

@@ -44,10 +44,10 @@ WORKER = textwrap.dedent('''
 ''')
 
 
-def _torchrun(args, port, timeout=1100):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+def _torchrun(args, port, timeout=1100, nproc=1, extra_env=None):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + args
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
 
 
@@ -80,4 +80,22 @@ def test_bench_runs_under_the_distributed_launcher_with_rccl():
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["images_total"] == 256
     assert d["int8_sim_resident"]["bit_identical_logits"] is True and d["int8_sim_images_per_s"] > 0
+    assert "recon_errors" not in d and "recon_error" not in d
+
+
+@pytest.mark.timeout(1500)
+def test_bench_eight_rank_flow_runs_to_its_json_line_on_one_gpu():
+    """The command the driver will issue on an 8-GPU node (BASELINE config 4: `--gpus 8 --total-images ...`, strong scaling),
+    as 8 ranks that share this box's one GPU (FQ_BENCH_BACKEND=gloo: RCCL refuses duplicate devices; every collective, barrier,
+    table broadcast and agreement all-reduce of the flow still executes, over gloo) on a small image count: rank 0 must print
+    one JSON line with the whole job's throughput, the per-rank sharding and no error key -- so that the first real 8-GPU run
+    cannot die on plumbing."""
+    r = _torchrun([os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-images", "1024", "--steps", "2", "--warmup", "1",
+                   "--int8-batch", "32", "--no-cold", "--no-cpu-baseline", "--no-per-channel"], 29673, timeout=1400, nproc=8,
+                  extra_env={"FQ_BENCH_BACKEND": "gloo", "FQ_BENCH_POOL_FRAC": "0.05", "OMP_NUM_THREADS": "2"})
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["images_total"] == 1024 and d["config"]["images_per_gpu"] == 128 and d["config"]["parallelism"] == "dp8"
     assert "recon_errors" not in d and "recon_error" not in d
