@@ -98,8 +98,8 @@ int fq_kl_threshold(const int64_t* hist, int rows, int32_t* thr_out, double* kl_
  *   mode  FQ_KL_EXHAUSTIVE  all 1920 candidates of every row in the reference's float64 operation order (quantizer.py
  *                           :98-174 line by line);
  *         FQ_KL_SCREENED    every candidate first through a closed form of the same sum (one logarithm per quantised
- *                           bin instead of one per histogram bin; |S(t) - KL(t)| < 2e-12), then the exhaustive
- *                           evaluation of the candidates within 1e-9 of the smallest S(t) only.  The minimum is among
+ *                           bin instead of one per histogram bin; |S(t) - KL(t)| < FQ_KL_SCREEN_BOUND), then the exhaustive
+ *                           evaluation of the candidates within FQ_KL_SCREEN_MARGIN of the smallest S(t) only.  The minimum is among
  *                           them, so thr_out / best_kl_out are identical to FQ_KL_EXHAUSTIVE; runner_up_kl_out and
  *                           kl_curve_out hold the closed-form value where the exact one was not needed;
  *         FQ_KL_AUTO        screened from 256 rows up when no curve is asked for (per-channel calibration: 42 667
@@ -107,6 +107,12 @@ int fq_kl_threshold(const int64_t* hist, int rows, int32_t* thr_out, double* kl_
 #define FQ_KL_AUTO 0
 #define FQ_KL_EXHAUSTIVE 1
 #define FQ_KL_SCREENED 2
+/* The two numbers the screened search rests on (one definition; csrc/fq_kl.hip asserts 2 * bound < margin):
+ *   FQ_KL_SCREEN_BOUND   |S(t) - KL(t)| of the closed form, proven in csrc/fq_kl.hip (measured: < 1e-13 on every golden
+ *                        and fuzz histogram, tests/test_kl_screen_cpu.py);
+ *   FQ_KL_SCREEN_MARGIN  candidates with S(t) <= min S + margin (+ 1e-12 |min S|) get the exact evaluation: 500 x bound. */
+#define FQ_KL_SCREEN_BOUND 2e-13
+#define FQ_KL_SCREEN_MARGIN 1e-10
 int fq_kl_threshold_ex(const int64_t* hist, int rows, int32_t* thr_out, double* best_kl_out,
                        double* runner_up_kl_out, double* kl_curve_out, int mode,
                        void* workspace, size_t workspace_bytes, fq_stream_t stream);

@@ -172,7 +172,10 @@ __device__ __forceinline__ void stem_tiles(const StemArgs& a, Stat& stat, float*
 #pragma unroll
                 for (int q = 0; q < G::S8 / 2; ++q) {
                     const int step = (c * R + r) * (G::S8 / 2) + q;
-                    const float b = prow0[buf * G::PATCH + ((c * G::PH + r) * 2) * G::PC + q];
+                    float b = prow0[buf * G::PATCH + ((c * G::PH + r) * 2) * G::PC + q];
+                    // taps 2 q + h >= S are padding: their weights are zero, but the patch word there is a real neighbouring
+                    // pixel, and 0 * Inf (or NaN) must not reach an output whose own window is finite
+                    if (2 * q + 1 >= S) b = (2 * q >= S || h) ? 0.0f : b;
                     const float a0 = wrow0[step * 2 * G::COUT], a1 = wrow1[step * 2 * G::COUT];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc1, 0, 0, 0);

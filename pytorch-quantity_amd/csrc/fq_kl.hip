@@ -18,8 +18,8 @@
 // Many rows (the per-channel extension: 42 667 rows for ResNet-50) make the sweep throughput bound: 82 M candidates x
 // ~1 100 logarithm + divide pairs in correctly rounded float64 is ~7e12 fp64 operations, 0.67 s.  The argmin does not
 // need all of them exactly: the SCREENED path first evaluates every candidate through a closed form that costs 128
-// bins instead of t elements (kl_screen_kernel, below: plain fp64, |S(t) - KL(t)| < 1e-11, measured < 2e-13), keeps
-// only the candidates within 1e-9 of the smallest S(t) -- the true minimum is provably among them -- and runs the
+// bins instead of t elements (kl_screen_kernel, below: plain fp64, |S(t) - KL(t)| < FQ_KL_SCREEN_BOUND = 2e-13), keeps
+// only the candidates within FQ_KL_SCREEN_MARGIN = 1e-10 of the smallest S(t) -- the true minimum is provably among them -- and runs the
 // exact, bit-for-bit evaluation on those alone (kl_exact_list_kernel, typically 1-3 per row).  Same thresholds by
 // construction; tests/test_gpu_kernels.py checks the bound on every golden and fuzz histogram.
 #include <cstdlib>
@@ -348,11 +348,12 @@ __global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __rest
 // (iii) Evaluated in float64 (ocml log, < 1 ulp) with the prefix sums held as double-double (a difference of two plain
 //      prefixes would carry 2^-53 of the PREFIX, which a logarithm of a tiny expanded value multiplies by up to 21:
 //      3e-12 on the golden "bimodal"); the rest is <= 260 products of magnitude <= 8 summed along a tree: < 1e-13.
-// Total |S(t) - KL(t)| < 2e-13 (the numpy restatement in tests/test_kl_screen_cpu.py stays below 1e-13 against the exact
-// oracle on every golden and fuzz histogram).  Candidates are kept when S(t) <= min S + 1e-10 (+ 1e-12 |min S|): 500
-// times the bound.  A NaN S(t) (the reference's incremental tail can go slightly negative; log of a negative number)
+// Total |S(t) - KL(t)| < FQ_KL_SCREEN_BOUND = 2e-13 (the numpy restatement in tests/test_kl_screen_cpu.py stays below 1e-13
+// against the exact oracle on every golden and fuzz histogram).  Candidates are kept when S(t) <= min S +
+// FQ_KL_SCREEN_MARGIN = 1e-10 (+ 1e-12 |min S|): 500 times the bound (include/fq.h holds both numbers).  A NaN S(t) (the reference's incremental tail can go slightly negative; log of a negative number)
 // is always kept, so the exact pass reproduces the NaN, which never wins.
-constexpr double kScreenMargin = 1e-10;
+constexpr double kScreenMargin = FQ_KL_SCREEN_MARGIN;
+static_assert(2.0 * FQ_KL_SCREEN_BOUND < FQ_KL_SCREEN_MARGIN, "the true minimum must survive the screen");
 constexpr int kListPerRow = 64;               // rows with more survivors than this are swept exhaustively
 constexpr int kNzStride = FQ_BINS + 4;
 

@@ -76,7 +76,9 @@ class Quantizer(object):
         """{name: (KL(t*), smallest KL of any other candidate)} (not exposed by the reference).  The argmin is decided by
         fq_log, a correctly rounded logarithm; the reference's np.log is faithful but not correctly rounded, so where the
         two values are within a few ulps of each other the reference could have picked the other candidate.  near_ties()
-        lists those rows."""
+        lists those rows.  (Exact when the search ran exhaustively -- always below 256 rows, i.e. for every per-tensor
+        calibration; in the screened mode of fq_kl_threshold_ex the runner-up is the closed-form value, within
+        FQ_KL_SCREEN_BOUND = 2e-13 of the exact one, unless it was itself a survivor.)"""
         assert self._quantized_flag, "Please use quantize() first."
         return {n: (self._kl_best[n], self._kl_runner_up[n]) for n in self._kl_best}
 

@@ -344,9 +344,23 @@ class Quantity(object):
         """(index, network input) for this rank's calibration items; host tensors are copied to the device ahead of the
         compute stream (see prefetch_inputs).  Round 1 measured a helper-THREAD prefetcher with pinned staging buffers as
         slower than a plain `.cuda()` (3 077-3 287 vs 4 232 images/s: the extra host memcpy and GIL traffic outweigh the
-        PCIe copy they hide); a side stream needs neither."""
+        PCIe copy they hide); a side stream needs neither.
+
+        The copy only overlaps the previous batch's kernels for PINNED host tensors (a pageable source makes the copy
+        host-synchronous whatever the flag says).  For those nothing on the host waits for the DMA, so the source must
+        stay untouched until it is done: the copy's event is waited for before the iterable is asked for its next item --
+        a loader that refills one pinned staging buffer per batch would otherwise overwrite a batch still in flight."""
         use_side = (self.prefetch_inputs and self.device == "gpu" and torch.cuda.is_available())
-        for i, item in self._calibration_items(images_files):
+        in_flight = None                                      # event of a copy whose pinned source is still being read
+        items = iter(self._calibration_items(images_files))
+        while True:
+            if in_flight is not None:
+                in_flight.synchronize()
+                in_flight = None
+            try:
+                i, item = next(items)
+            except StopIteration:
+                return
             img = self.preprocess(item)
             if use_side and torch.is_tensor(img) and img.device.type != "cuda":
                 if getattr(self, "_copy_stream", None) is None:
@@ -354,6 +368,9 @@ class Quantity(object):
                 main = torch.cuda.current_stream()
                 with torch.cuda.stream(self._copy_stream):
                     dev = img.cuda(non_blocking=True)
+                    if img.is_pinned():
+                        in_flight = torch.cuda.Event()
+                        in_flight.record(self._copy_stream)
                 main.wait_stream(self._copy_stream)
                 dev.record_stream(main)
                 img = dev
@@ -636,6 +653,26 @@ class Quantity(object):
         output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))
         return False
 
+    def _probe_forward(self, own_plain):
+        """One forward of the model on a random input of INPUT_SHAPE with the hooks watching for in-place consumers; returns
+        whether a hooked tensor was written to after its hook ran.  The reference feeds its models random input exactly
+        once, in build_net_structure (pytorch_quantizer.py:21-62); this additional draw comes from a generator of its own,
+        so the global RNG stream a user script sees afterwards is the reference's."""
+        ctl = self._hook_ctl
+        probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
+        saved = ctl.get("own_plain", False)
+        ctl["eager"], ctl["own_plain"] = probe, own_plain
+        try:
+            dev = self._model_device(self.model)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(0x5eed)
+            shapes = [self.input_size] if isinstance(self.input_size, tuple) else list(self.input_size)
+            with torch.no_grad():
+                self.model(*[torch.rand(*s_, device=dev, generator=gen) for s_ in shapes])
+        finally:
+            ctl["eager"], ctl["own_plain"] = None, saved
+        return bool(probe.modified())
+
     def _forward_with_stats(self, item, fn, named_feats, extra=None):
         """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced and
         to `extra` (tensors of the same batch kept from pass 1).  Returns the _EagerStats of that forward, or None
@@ -809,27 +846,19 @@ class Quantity(object):
         cached, cached_ids, used = {}, set(), 0
         step_ms = []
         inplace = None                          # does a later module overwrite a hooked tensor?
-        if eager_ok:
+        if eager_ok and any(m.training for m in self.model.modules()):
+            # a model in training mode (BatchNorm statistics, dropout): nothing but calibration data may pass through it, so
+            # no probe -- one launch per tensor from inside the hooks (always correct), nothing cached, pass 2 not fused
+            budget = 0
+        elif eager_ok:
             # One probe forward on a random input of INPUT_SHAPE (what build_net_structure traces with; nothing is taken
             # from it) answers that BEFORE the first calibration batch: the first batch then already runs in its final
             # mode -- in particular, when nothing will be cached, without the hooks keeping a batch's 17 GB of tensors
             # alive (a fresh process would grow its allocator pool for them: up to 0.6 s of hipMalloc).
-            probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
-            ctl["eager"] = probe
             # (its values are not used, so the convolutions the own kernels take run on them here too, unchecked: a
             # calibration then never enters the convolution library, whose first-use solver search is most of what a
             # fresh process used to wait for; every module is still checked on the first real batch)
-            ctl["own_plain"] = "unchecked"
-            try:
-                dev = self._model_device(self.model)
-                shapes = [self.input_size] if isinstance(self.input_size, tuple) else list(self.input_size)
-                with torch.no_grad():
-                    self.model(*[torch.rand(*s_, device=dev) for s_ in shapes])
-            finally:
-                ctl["eager"] = None
-                ctl["own_plain"] = False
-            inplace = bool(probe.modified())
-            del probe
+            inplace = self._probe_forward("unchecked")
             named_feats.clear()
             if inplace:
                 budget = 0                      # kept tensors would hold overwritten values: no cache, per-tensor launches
@@ -990,21 +1019,20 @@ class Quantity(object):
         try:
             # One probe forward on a random input of INPUT_SHAPE (what build_net_structure traces with) tells the
             # channel counts and whether later modules overwrite hooked tensors -- on EVERY rank, also one that owns
-            # no calibration batch and must still take part in the two all-reduces.
-            probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
-            ctl["eager"] = probe
+            # no calibration batch and must still take part in the two all-reduces.  A model in training mode is probed
+            # in eval mode (no BatchNorm statistic sees the noise) and then takes one launch per tensor, always correct.
+            was_training = [m for m in self.model.modules() if m.training]
+            for m in was_training:
+                m.training = False
             try:
-                dev = self._model_device(self.model)
-                shapes = [self.input_size] if isinstance(self.input_size, tuple) else list(self.input_size)
-                with torch.no_grad():
-                    self.model(*[torch.rand(*s, device=dev) for s in shapes])
+                modified = self._probe_forward(ctl["own_plain"])
             finally:
-                ctl["eager"] = None
+                for m in was_training:
+                    m.training = True
             collector = ChannelCollector({n: int(named_feats[n].shape[1]) for n in names},
                                          statistic=self.config["SETTINGS"]["STATISTIC"])
             # in-place consumers: one launch per tensor from inside the hooks (the values the reference's hooks would copy)
-            self._stats_limit = 0 if probe.modified() else _AFTER_FORWARD
-            del probe
+            self._stats_limit = 0 if (modified or was_training) else _AFTER_FORWARD
             # pass 2 histograms the very tensors pass 1 took the maxima of, for as many batches as fit the allocator's
             # warm pool (whole batches only: _activation_cache_budget; nothing is kept when a later module overwrites
             # hooked tensors in place)

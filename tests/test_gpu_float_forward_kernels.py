@@ -401,6 +401,21 @@ def test_stem_gaussian_data_statistics_and_relu(nat, shape):
     assert torch.equal(y2, y) and torch.equal(r, torch.relu(y)) and torch.equal(hist, want)
 
 
+def test_stem_inf_next_to_a_window_does_not_leak_through_the_padded_tap(nat):
+    """The stem pads its 7 taps per row to 8 (zero weights); the patch word behind the 7th tap is a real pixel.  An Inf /
+    NaN there must not turn 0 * Inf into NaN in outputs whose own 7x7 window is finite (torch's convolution leaves them
+    finite): every output must be NaN exactly where the reference convolution's is."""
+    x, w, b, pad = _stem_case((2, 40, 44, 64, 3), 23, integer=True)
+    x[0, 1, 10, 17] = float("inf")
+    x[1, 2, 25, 30] = float("nan")
+    x[1, 0, 0, 43] = float("-inf")
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=2, padding=pad)
+    y = _stem(nat, x, w, b, pad).double()
+    assert torch.equal(torch.isnan(y), torch.isnan(ref))
+    fin = torch.isfinite(ref)
+    assert torch.equal(y[fin], ref[fin]) and torch.equal(torch.isinf(y), torch.isinf(ref))
+
+
 def test_stem_unsupported_shapes_are_refused(nat):
     L = nat.lib()
     assert L.fq_conv_stem_f32_packed_rows(3, 7, 7) == 168
