@@ -469,6 +469,10 @@ def parse_args():
     ap.add_argument("--int8-batch", type=int, default=256,
                     help="images per forward of the int8-sim / fake-quant throughput section")
     ap.add_argument("--no-per-channel", action="store_true")
+    ap.add_argument("--input-mode", default="both", choices=["tensor", "npy", "both"],
+                    help="tensor: device-resident batches only (the headline); npy / both: also the same images as one .npy file "
+                         "each through PRE_PROCESS.IMG = 2 (reported as file_input, never the headline)")
+    ap.add_argument("--no-file-input", action="store_true")
     args = ap.parse_args()
     world = max(args.gpus, 1)
     per_gpu = args.images if not args.total_images else -(-args.total_images // world)
@@ -908,6 +912,50 @@ def main():
             result["cpu_baseline"] = cpu_baseline(lambda: build_model(args.model, HW, torch.device("cpu")), HW, images, q, log)
         except Exception as e:
             result["cpu_baseline"] = {"error": repr(e)}
+
+    # ---- file inputs (reference pytorch_quantizer.py:252-284, PRE_PROCESS.IMG = 2: one .npy file per
+    # calibration item): the SAME images as the timed region, written as .npy files outside the clock, calibrated through
+    # the drop-in's file mode (Quantity.file_batch files per forward, decoded by a thread pool into pinned staging, H2D on a
+    # side stream).  Never the headline: reported beside it with its ratio to the tensor-input rate.
+    if world == 1 and args.input_mode in ("npy", "both") and not args.no_file_input:
+        try:
+            import shutil
+            import yaml
+            fdir = tempfile.mkdtemp(prefix="fq_bench_npy_", dir=os.environ.get("FQ_BENCH_FILE_DIR") or None)
+            paths = []
+            t_w = time.perf_counter()
+            for bi, xb in enumerate(data.owned()):
+                host = xb.cpu().numpy()
+                for j in range(host.shape[0]):
+                    paths.append(os.path.join(fdir, "img_%05d.npy" % (bi * B + j)))
+                    np.save(paths[-1], host[j])
+            write_s = time.perf_counter() - t_w
+            wd = make_workdir(len(paths) - 1, shape, dev_index)
+            ucfg_path = os.path.join(wd, "test", "user_configs.yml")
+            with open(ucfg_path) as fh:
+                ucfg = yaml.safe_load(fh)
+            ucfg["PRE_PROCESS"]["IMG"] = 2
+            with open(ucfg_path, "w") as fh:
+                yaml.safe_dump(ucfg, fh)
+            fq = Quantity(model)
+            fq.file_batch = B
+            fq.profile_phases = True
+            barrier()
+            t0 = time.perf_counter()
+            fq.activation_quantize(paths)
+            barrier()
+            dt = time.perf_counter() - t0
+            same = open("./workdir/feat.table").read() == feat_table
+            result["file_input"] = {"mode": "npy (PRE_PROCESS.IMG = 2)", "files": len(paths), "file_bytes": int(os.path.getsize(paths[0])),
+                                    "files_per_forward": B, "decode_threads": fq.decode_workers, "seconds": round(dt, 3),
+                                    "images_per_s": round(len(paths) / dt, 1), "ratio_to_tensor_inputs": round(len(paths) / dt / value, 3),
+                                    "same_table_as_tensor_inputs": bool(same), "write_files_s_outside_clock": round(write_s, 2),
+                                    "pass1_s": round(fq.timings.get("pass1_s", 0.0), 4), "pass2_s": round(fq.timings.get("pass2_s", 0.0), 4),
+                                    "host_wait_s": {k: round(v, 4) for k, v in getattr(fq, "input_wait_s", {}).items()}}
+            del fq
+            shutil.rmtree(fdir, ignore_errors=True)
+        except Exception as e:
+            result["file_input"] = {"error": repr(e)}
 
     # ---- per-channel rows (extension; BASELINE configs[1] words the workload "per-channel"): same two passes with
     # one histogram row per (tensor, channel), read in place by fq_absmax_chan / fq_hist2048_chan, then the KL sweep of

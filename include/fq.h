@@ -231,6 +231,19 @@ int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* 
                      int W, int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval,
                      int64_t* hist_row, fq_stream_t stream);
 
+/* TestConv.forward / TestLinear.forward (new_quantity_op.py:283-292, :248-256) in ONE kernel: the float convolution above
+ * with QuanDequan(bit) applied to each value as it leaves the accumulator,
+ *   y = clamp(rint((conv(x) + bias) * 2^bit), lo, hi) / 2^bit,   [lo, hi] = the integer range of bitwidth (8 or 16),
+ * instead of the reference's two passes (the convolution's store, then an 8 B/element read-modify-write).  The value
+ * QuanDequan sees is exactly what fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32 would have stored, so the result equals
+ * fq_quandequan_f32 of their output bit for bit.  Same operand contracts as the plain entry points. */
+int fq_conv1x1_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
+                      int Cout, int stride, int bit, int bitwidth, fq_stream_t stream);
+int fq_conv_kxk_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
+                       int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream);
+int fq_conv_stem_qd_f32(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int H, int W,
+                        int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream);
+
 /* The pooling layers of the float calibration forward (nn.MaxPool2d / a global nn.AvgPool2d inside the model the
  * reference runs at pytorch_quantizer.py:288-296), bit for bit what torch computes:
  * fq_maxpool2d_f32: y[plane][oy][ox] = max over the window clipped to the image (NaN propagates); x fp32 [planes][H][W],
@@ -338,6 +351,16 @@ int fq_maxpool_i8_nhwc(const int8_t* x, int8_t* y, int N, int H, int W, int Cpad
  * accumulation is exact here (HW * 2^15 < 2^24, else FQ_ERR_UNSUPPORTED), so this is the same number. */
 int fq_avgpool_global_nhwc(const void* q_nhwc, int q_bytes, int g, float* y, int N, int C, int HW, int Cpad,
                            fq_stream_t stream);
+
+/* ---- input files ------------------------------------------------------------------------------- */
+
+/* HOST helper for PRE_PROCESS.IMG = 2 (pytorch_quantizer.py:276-280: np.load of one CHW fp32 image per calibration item):
+ * n .npy files that share one header (same dtype, order and shape: `header` / `header_bytes` are the bytes in front of the
+ * payload of any one of them) are read into consecutive slots of dst -- fp32 [n][elems_per_file], host memory the caller
+ * owns (pinned, so that the H2D copy that follows is asynchronous) -- by `threads` host threads.  ok_out[i] = 1 when file
+ * i had exactly that header and payload, else 0 (the caller falls back to its general reader for that slot). */
+int fq_read_npy_batch_f32(const char* const* paths, int n, const void* header, size_t header_bytes, float* dst,
+                          size_t elems_per_file, int threads, int* ok_out);
 
 /* ---- output files ------------------------------------------------------------------------------ */
 

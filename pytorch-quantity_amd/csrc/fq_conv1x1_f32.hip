@@ -112,7 +112,7 @@ __device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1A
                 for (int e = 0; e < 16; ++e) {
                     const unsigned dm = 32u * mi + (e & 3) + 8u * (e >> 2);           // compile-time row within the wave tile
                     if (kFullM || mbase + m0 + 4u * h + dm < a.Cout) {
-                        const float val = acc[mi][ni][e] + b4[e >> 2][e & 3];
+                        const float val = stat_map(stat, acc[mi][ni][e] + b4[e >> 2][e & 3]);
                         const int row4 = (int)(dm * a.HWout * 4u);                     // uniform
                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs, (int)col4, row4, aux);
                         if (kRelu)
@@ -357,6 +357,14 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void co
     publish_max<kT>(st.m, max_bits);
 }
 
+// TestConv / TestLinear's forward in one kernel: convolution + bias, then QuanDequan on the accumulator's way out
+template <int WM, int WN, int kTailK>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_qd_kernel(const C1Args a, const QdStat qd) {
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
+    QdStat st = qd;
+    conv1x1_tiles<WM, WN, step_of<WM>(), kTailK>(a, st, smem);
+}
+
 // (the histogram form carries 8 KB of LDS bins on top of the stages; the persistent grid is what the occupancy query says)
 template <int WM, int WN, int BK, int kTailK>
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_f32_hist_kernel(
@@ -379,11 +387,13 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void co
 
 template <int WM, int WN, int kTailK>
 void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, int64_t* hist_row, int hist_per_cu, int fast,
-            hipStream_t st) {
+            const QdStat* qd, hipStream_t st) {
     typedef Shape<WM, WN> S;
     a.tiles_m = (a.Cout + S::BM - 1) / S::BM;
     a.tiles = ((cols + S::BN - 1) / S::BN) * a.tiles_m;
-    if (hist_row) {
+    if (qd) {
+        hipLaunchKernelGGL((conv1x1_f32_qd_kernel<WM, WN, kTailK>), dim3(a.tiles), dim3(kT), 0, st, a, *qd);
+    } else if (hist_row) {
         // every workgroup flushes up to 2048 bins with 64-bit atomics at its end: a persistent grid of exactly the
         // workgroups the chip holds at once (LDS: three stages + 8 KB of bins), each taking every grid-th tile
         static const int resident = [] {
@@ -418,7 +428,7 @@ namespace {
 // the common host side of fq_conv1x1_f32 (R = S = 1, pad = 0) and fq_conv_kxk_f32
 int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin, int Win,
                     int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval, int64_t* hist_row,
-                    fq_stream_t stream) {
+                    fq_stream_t stream, const QdStat* qd = nullptr) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1 || R < 1 || S < 1 || pad < 0) return FQ_ERR_INVALID_ARG;
     if (Hin + 2 * pad < R || Win + 2 * pad < S) return FQ_ERR_INVALID_ARG;
     if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
@@ -461,9 +471,9 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     const int shape = forced ? forced : ((Cout <= 64 || tiles22 <= (size_t)kCUs * 4) ? 12 : 22);
 #define FQ_C1_LAUNCH(WM, WN)                                                                                       \
     do {                                                                                                           \
-        if (mode == 2) launch<WM, WN, 2>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);         \
-        else if (mode == 1) launch<WM, WN, 1>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);    \
-        else launch<WM, WN, 0>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, st);                   \
+        if (mode == 2) launch<WM, WN, 2>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, st);     \
+        else if (mode == 1) launch<WM, WN, 1>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, st); \
+        else launch<WM, WN, 0>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, st);               \
     } while (0)
     if (shape == 12) FQ_C1_LAUNCH(1, 2);
     else FQ_C1_LAUNCH(2, 2);
@@ -484,4 +494,28 @@ extern "C" int fq_conv_kxk_f32(const float* x, const float* wt, const float* bia
                                int Hin, int Win, int Cout, int R, int S, int stride, int pad, float* max_inout,
                                const float* interval, int64_t* hist_row, fq_stream_t stream) {
     return conv_f32_launch(x, wt, bias, y, relu_out, N, Cin, Hin, Win, Cout, R, S, stride, pad, max_inout, interval, hist_row, stream);
+}
+
+// TestConv.forward (new_quantity_op.py:283-292) / TestLinear.forward (:248-256 on the classifier seen as a 1x1 layer) in one
+// kernel: y = QuanDequan(conv(x) + bias, bit).  The value QuanDequan sees is the kernel's own fp32 sum -- the same one
+// fq_conv1x1_f32 / fq_conv_kxk_f32 would have stored -- so the result equals fq_quandequan_f32 of their output bit for bit.
+static bool qd_params(int bit, int bitwidth, QdStat* qd) {
+    if ((bitwidth != 8 && bitwidth != 16) || bit < -120 || bit > 120) return false;
+    qd->scale = ldexpf(1.0f, bit); qd->inv = ldexpf(1.0f, -bit);
+    qd->lo = bitwidth == 8 ? -128.0f : -32768.0f; qd->hi = bitwidth == 8 ? 127.0f : 32767.0f;
+    return true;
+}
+
+extern "C" int fq_conv1x1_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
+                                 int Cout, int stride, int bit, int bitwidth, fq_stream_t stream) {
+    QdStat qd;
+    if (!qd_params(bit, bitwidth, &qd)) return FQ_ERR_INVALID_ARG;
+    return conv_f32_launch(x, wt, bias, y, nullptr, N, Cin, Hin, Win, Cout, 1, 1, stride, 0, nullptr, nullptr, nullptr, stream, &qd);
+}
+
+extern "C" int fq_conv_kxk_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
+                                  int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream) {
+    QdStat qd;
+    if (!qd_params(bit, bitwidth, &qd)) return FQ_ERR_INVALID_ARG;
+    return conv_f32_launch(x, wt, bias, y, nullptr, N, Cin, Hin, Win, Cout, R, S, stride, pad, nullptr, nullptr, nullptr, stream, &qd);
 }

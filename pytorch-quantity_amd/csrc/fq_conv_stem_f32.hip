@@ -83,7 +83,7 @@ __device__ __forceinline__ void stem_epilogue(const f16v& acc0, const f16v& acc1
         for (int e = 0; e < 16; ++e) {
             const int dco = 32 * half + (e & 3) + 8 * (e >> 2);                    // + 4 h
             if (kFull || dco + 4 * (int)h < a.Cout) {
-                const float val = (half ? acc1[e] : acc0[e]) + b4[e >> 2][e & 3];
+                const float val = stat_map(stat, (half ? acc1[e] : acc0[e]) + b4[e >> 2][e & 3]);
                 const int row4 = (int)((unsigned)dco * plane4);                     // uniform
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs, (int)base4, row4, aux);
                 if (kRelu)
@@ -218,6 +218,13 @@ __global__ __launch_bounds__(kT) void conv_stem_f32_kernel(const StemArgs a) {
 }
 
 template <int CIN, int R, int S>
+__global__ __launch_bounds__(kT) void conv_stem_f32_qd_kernel(const StemArgs a, const QdStat qd) {   // TestConv's stem: QuanDequan on the way out
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    QdStat st = qd;
+    stem_tiles<CIN, R, S>(a, st, smem);
+}
+
+template <int CIN, int R, int S>
 __global__ __launch_bounds__(kT) void conv_stem_f32_absmax_kernel(const StemArgs a, unsigned int* __restrict__ max_bits) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     MaxStat st;
@@ -252,11 +259,19 @@ int resident_per_cu(K kernel, size_t dyn) {
 }
 
 template <int CIN, int R, int S>
-int launch_stem(StemArgs a, float* max_inout, const float* interval, int64_t* hist_row, int fast, hipStream_t st) {
+int launch_stem(StemArgs a, float* max_inout, const float* interval, int64_t* hist_row, int fast, const QdStat* qd, hipStream_t st) {
     typedef StemShape<CIN, R, S> G;
     const size_t dyn = (size_t)G::kFloats * sizeof(float);
     // persistent: every workgroup loads the 43 KB weight matrix once and walks over tiles
-    if (hist_row) {
+    if (qd) {
+        auto k = conv_stem_f32_qd_kernel<CIN, R, S>;
+        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+        static const int per_cu = resident_per_cu(k, dyn);
+        unsigned grid = (unsigned)(kCUs * per_cu);
+        if (grid > a.tiles) grid = a.tiles;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kT), dyn, st, a, *qd);
+    } else if (hist_row) {
         auto k = conv_stem_f32_hist_kernel<CIN, R, S>;
         static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
@@ -294,9 +309,9 @@ extern "C" int fq_conv_stem_f32_packed_rows(int Cin, int R, int S) {
     return FQ_ERR_UNSUPPORTED;
 }
 
-extern "C" int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* y, float* relu_out, int N, int Cin,
-                                int H, int W, int Cout, int R, int S, int stride, int pad, float* max_inout,
-                                const float* interval, int64_t* hist_row, fq_stream_t stream) {
+static int stem_launch(const float* x, const float* wp, const float* bias, float* y, float* relu_out, int N, int Cin,
+                       int H, int W, int Cout, int R, int S, int stride, int pad, float* max_inout,
+                       const float* interval, int64_t* hist_row, const QdStat* qd, fq_stream_t stream) {
     if (N < 0 || Cin <= 0 || H <= 0 || W <= 0 || Cout <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return FQ_ERR_INVALID_ARG;
     if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
     if (hist_row && !interval) return FQ_ERR_INVALID_ARG;
@@ -321,8 +336,24 @@ extern "C" int fq_conv_stem_f32(const float* x, const float* wp, const float* bi
     a.y_bytes = (unsigned)(out_elems * 4);
     a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);
     static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
-    const int rc = launch_stem<3, 7, 7>(a, max_inout, interval, hist_row, fast, as_stream(stream));
+    const int rc = launch_stem<3, 7, 7>(a, max_inout, interval, hist_row, fast, qd, as_stream(stream));
     if (rc != FQ_OK) return rc;
     FQ_LAUNCH_CHECK();
     return FQ_OK;
+}
+
+extern "C" int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* y, float* relu_out, int N, int Cin,
+                                int H, int W, int Cout, int R, int S, int stride, int pad, float* max_inout,
+                                const float* interval, int64_t* hist_row, fq_stream_t stream) {
+    return stem_launch(x, wp, bias, y, relu_out, N, Cin, H, W, Cout, R, S, stride, pad, max_inout, interval, hist_row, nullptr, stream);
+}
+
+// TestConv.forward of the stem in one kernel: y = QuanDequan(conv(x) + bias, bit) (fq_conv1x1_qd_f32's contract)
+extern "C" int fq_conv_stem_qd_f32(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int H, int W,
+                                   int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream) {
+    if ((bitwidth != 8 && bitwidth != 16) || bit < -120 || bit > 120) return FQ_ERR_INVALID_ARG;
+    QdStat qd;
+    qd.scale = ldexpf(1.0f, bit); qd.inv = ldexpf(1.0f, -bit);
+    qd.lo = bitwidth == 8 ? -128.0f : -32768.0f; qd.hi = bitwidth == 8 ? 127.0f : 32767.0f;
+    return stem_launch(x, wp, bias, y, nullptr, N, Cin, H, W, Cout, R, S, stride, pad, nullptr, nullptr, nullptr, &qd, stream);
 }

@@ -1,6 +1,12 @@
 // fq_host.cpp -- host-only entry points of libfq_hip.so: version/status, and the two scalar formulas
 // of the reference that must run on the host libm to reproduce CPython's math.log(x, 2) bit for bit.
 #include <cmath>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include <fcntl.h>
+#include <unistd.h>
 
 #include "fq_common.h"
 
@@ -122,4 +128,53 @@ extern "C" int fq_json_dump_i32(const char* path, const int32_t* data, int ndim,
     w.flush();
     const bool ok = w.ok && fclose(fh) == 0;
     return ok ? FQ_OK : FQ_ERR_INVALID_ARG;
+}
+
+// ---- input side: PRE_PROCESS.IMG = 2 (pytorch_quantizer.py:276-280: np.load of one CHW image per calibration item) ----
+// n .npy files that share one header (written by one np.save loop: same dtype / order / shape) read straight into
+// consecutive slots of a caller-owned (pinned) host buffer: open, compare the header bytes, read the payload.  One call per
+// batch from Python: the interpreter lock is released for all of it (the same loop in Python needs the lock three times per
+// file, and loses it to the thread that is launching kernels).
+static void read_npy_range(const char* const* paths, int lo, int hi, const void* header, size_t header_bytes, float* dst,
+                           size_t elems, int* ok) {
+    std::vector<char> head(header_bytes);
+    for (int i = lo; i < hi; ++i) {
+        ok[i] = 0;
+        const int fd = open(paths[i], O_RDONLY | O_CLOEXEC);
+        if (fd < 0) continue;
+        bool good = header_bytes == 0 || ((size_t)pread(fd, head.data(), header_bytes, 0) == header_bytes &&
+                                          std::memcmp(head.data(), header, header_bytes) == 0);
+        char* out = reinterpret_cast<char*>(dst + (size_t)i * elems);
+        size_t want = elems * sizeof(float), got = 0;
+        while (good && got < want) {
+            const ssize_t r = pread(fd, out + got, want - got, (off_t)(header_bytes + got));
+            if (r <= 0) good = false;
+            else got += (size_t)r;
+        }
+        if (good) {                                           // nothing may follow the payload
+            char extra;
+            good = pread(fd, &extra, 1, (off_t)(header_bytes + want)) == 0;
+        }
+        close(fd);
+        ok[i] = good ? 1 : 0;
+    }
+}
+
+extern "C" int fq_read_npy_batch_f32(const char* const* paths, int n, const void* header, size_t header_bytes, float* dst,
+                                     size_t elems_per_file, int threads, int* ok_out) {
+    if (n < 0 || (n && (!paths || !dst || !ok_out)) || (header_bytes && !header)) return FQ_ERR_INVALID_ARG;
+    if (n == 0) return FQ_OK;
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    if (threads == 1) {
+        read_npy_range(paths, 0, n, header, header_bytes, dst, elems_per_file, ok_out);
+        return FQ_OK;
+    }
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads; ++t) {
+        const int lo = (int)((long)n * t / threads), hi = (int)((long)n * (t + 1) / threads);
+        pool.emplace_back(read_npy_range, paths, lo, hi, header, header_bytes, dst, elems_per_file, ok_out);
+    }
+    for (auto& th : pool) th.join();
+    return FQ_OK;
 }

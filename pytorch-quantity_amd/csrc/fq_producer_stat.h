@@ -16,6 +16,19 @@ struct MaxStat {
     __device__ __forceinline__ void add(float v) { m = fmaxf(m, fabsf(v)); }                  // fmaxf drops NaN
 };
 
+// TestConv / TestLinear (new_quantity_op.py:283-292, :248-256): QuanDequan(bit) of the convolution's value on its way out
+// of the accumulator -- not a statistic, a map: the stored value is map(v).  Bit for bit fq_quandequan_f32's expression.
+struct QdStat {
+    float scale, inv, lo, hi;                                 // 2^bit, 2^-bit, the integer range of the bit width
+    __device__ __forceinline__ void add(float) {}
+    __device__ __forceinline__ float map(float v) const {
+        const float q = rintf(v * scale);
+        return (q < lo ? lo : (q > hi ? hi : q)) * inv;       // NaN fails both compares and passes through
+    }
+};
+template <typename S> __device__ __forceinline__ float stat_map(const S&, float v) { return v; }
+__device__ __forceinline__ float stat_map(const QdStat& s, float v) { return s.map(v); }
+
 template <bool kFast>
 struct HistStat {
     unsigned int* bins;                                       // 2048 LDS counters of this workgroup

@@ -17,7 +17,8 @@ import torch
 
 from . import _native
 
-__all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "state", "is_verified", "is_off", "forget", "TOL"]
+__all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "call_qd", "state", "is_verified", "is_off", "forget",
+           "TOL"]
 
 TOL = 1e-5                                      # |own - torch| <= TOL * (|W| * |x| + |b|): summation order only
 # module -> {"verified": the own kernel agreed with torch here, "off": it disagreed (the module keeps torch's convolution),
@@ -157,3 +158,28 @@ def call(m, x):
         return m(x)
     finally:
         del m.forward
+
+
+def _hooked(m):
+    """Does anybody watch this module's input or output?  (Forward hooks of the module, or torch's global module hooks.)"""
+    import torch.nn.modules.module as _mod
+    return bool(m._forward_hooks or m._forward_pre_hooks or getattr(m, "_forward_hooks_with_kwargs", None)
+                or _mod._global_forward_hooks or _mod._global_forward_pre_hooks)
+
+
+def call_qd(m, x, bit, bitwidth):
+    """QuanDequan(m(x), bit) for an nn.Conv2d in ONE kernel (fq_conv1x1_qd_f32 / fq_conv_kxk_qd_f32 / fq_conv_stem_qd_f32: the
+    fake-quantisation applied where the value leaves the accumulator, reference new_quantity_op.py:283-292), or None when
+    the call does not qualify and the caller runs the two passes.  It qualifies when the own kernel takes the layer
+    (kind()), the module has passed its once-per-process check against torch, and nobody observes the un-quantised
+    convolution output -- a forward hook on m must see what the reference's hook would see, so hooked modules keep the
+    two-pass form.  The result equals fq_quandequan_f32 of the own kernel's plain output bit for bit (same sum, same map)."""
+    if not (enabled() and not torch.is_grad_enabled() and "forward" not in m.__dict__) or _hooked(m):
+        return None
+    k = kind(m, x)
+    if k is None:
+        return None
+    run = runner(m, k, x)
+    if not is_verified(m) and verified(m, run, x) is not None:
+        return None                                             # the module just failed its check: two passes, torch's convolution
+    return run(qd=(int(bit), 8 if bitwidth == 8 else 16))

@@ -104,6 +104,14 @@ def lib():
     L.fq_conv_stem_f32_packed_rows.argtypes = [ci, ci, ci]
     L.fq_conv_stem_f32.restype = ci
     L.fq_conv_stem_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [vp, vp, vp, vp]
+    L.fq_read_npy_batch_f32.restype = ci
+    L.fq_read_npy_batch_f32.argtypes = [vp, ci, ctypes.c_char_p, ctypes.c_size_t, vp, ctypes.c_size_t, ci, vp]
+    L.fq_conv1x1_qd_f32.restype = ci
+    L.fq_conv1x1_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 8 + [vp]
+    L.fq_conv_kxk_qd_f32.restype = ci
+    L.fq_conv_kxk_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 11 + [vp]
+    L.fq_conv_stem_qd_f32.restype = ci
+    L.fq_conv_stem_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 11 + [vp]
     L.fq_maxpool2d_f32.restype = ci
     L.fq_maxpool2d_f32.argtypes = [vp, vp] + [ci] * 9 + [vp]
     L.fq_avgpool_global_f32.restype = ci
@@ -338,10 +346,19 @@ def add_hist(x, y, interval_dev, hist_dev, row, out=None, relu_out=None):
     return z
 
 
-def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None, out=None):
+def _qd_args(qd, max_dev, hist_dev, relu_out, name):
+    """(bit, bitwidth) of a fused QuanDequan epilogue; it excludes the statistic epilogues and the ReLU copy."""
+    bit, bitwidth = (int(qd[0]), int(qd[1])) if isinstance(qd, (tuple, list)) else (int(qd), 8)
+    if max_dev is not None or hist_dev is not None or relu_out is not None:
+        raise FqError(name + ": the QuanDequan epilogue takes no statistic and no ReLU copy")
+    return bit, bitwidth
+
+
+def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None, out=None, qd=None):
     """fq_conv1x1_f32: the float 1x1 convolution (padding 0, groups 1) of x [N, Cin, H, W] with the TRANSPOSED weights
     wt [Cin, Cout] on the fp32 matrix cores; max_dev/row: abs-max of the output folded into max_dev[row]; interval_dev/
-    hist_dev/row: the output histogrammed into hist_dev[row]; relu_out: also receives max(y, 0).  Returns y."""
+    hist_dev/row: the output histogrammed into hist_dev[row]; relu_out: also receives max(y, 0).  qd = bit or (bit, bitwidth):
+    fq_conv1x1_qd_f32 instead -- QuanDequan(bit) applied in the epilogue (TestConv.forward in one kernel).  Returns y."""
     _need_cuda(x, torch.float32, "fq_conv1x1_f32")
     _need_cuda(wt, torch.float32, "fq_conv1x1_f32")
     assert x.dim() == 4 and x.is_contiguous() and wt.dim() == 2 and wt.is_contiguous() and wt.shape[0] == x.shape[1]
@@ -353,6 +370,11 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
     if bias is not None:
         _need_cuda(bias, torch.float32, "fq_conv1x1_f32")
         assert bias.is_contiguous() and bias.numel() == Cout
+    if qd is not None:
+        bit, bw = _qd_args(qd, max_dev, hist_dev, relu_out, "fq_conv1x1_qd_f32")
+        _check(lib().fq_conv1x1_qd_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                       N, Cin, H, W, Cout, s, bit, bw, _stream(x)), "fq_conv1x1_qd_f32")
+        return y
     mp = ivp = hp = None
     if hist_dev is not None:
         ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
@@ -372,7 +394,7 @@ def pack_kxk_weight(weight):
 
 
 def conv_kxk_f32(x, wt, bias, kernel, stride, pad, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None,
-                 out=None):
+                 out=None, qd=None):
     """fq_conv_kxk_f32: the float R x S convolution (zero padding `pad`, dilation 1, groups 1) of x [N, Cin, H, W] with the
     weights packed by pack_kxk_weight; statistics / relu_out / out as in conv1x1_f32.  Returns y."""
     _need_cuda(x, torch.float32, "fq_conv_kxk_f32")
@@ -387,6 +409,11 @@ def conv_kxk_f32(x, wt, bias, kernel, stride, pad, max_dev=None, interval_dev=No
     if bias is not None:
         _need_cuda(bias, torch.float32, "fq_conv_kxk_f32")
         assert bias.is_contiguous() and bias.numel() == Cout
+    if qd is not None:
+        bit, bw = _qd_args(qd, max_dev, hist_dev, relu_out, "fq_conv_kxk_qd_f32")
+        _check(lib().fq_conv_kxk_qd_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                        N, Cin, H, W, Cout, R, S, st, pd, bit, bw, _stream(x)), "fq_conv_kxk_qd_f32")
+        return y
     mp = ivp = hp = None
     if hist_dev is not None:
         ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
@@ -417,7 +444,7 @@ def pack_stem_weight(weight):
 
 
 def conv_stem_f32(x, wp, bias, cout, kernel, stride, pad, max_dev=None, interval_dev=None, hist_dev=None, row=None,
-                  relu_out=None, out=None):
+                  relu_out=None, out=None, qd=None):
     """fq_conv_stem_f32: the float stem convolution (kernel = (R, S), e.g. 7x7 stride 2) of x [N, Cin, H, W] with the packed
     weights wp (pack_stem_weight); statistics / relu_out / out as in conv1x1_f32.  Returns y."""
     _need_cuda(x, torch.float32, "fq_conv_stem_f32")
@@ -431,6 +458,12 @@ def conv_stem_f32(x, wp, bias, cout, kernel, stride, pad, max_dev=None, interval
     if bias is not None:
         _need_cuda(bias, torch.float32, "fq_conv_stem_f32")
         assert bias.is_contiguous() and bias.numel() == cout
+    if qd is not None:
+        bit, bw = _qd_args(qd, max_dev, hist_dev, relu_out, "fq_conv_stem_qd_f32")
+        _check(lib().fq_conv_stem_qd_f32(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                         N, Cin, H, W, int(cout), R, S, int(stride), int(pad), bit, bw, _stream(x)),
+               "fq_conv_stem_qd_f32")
+        return y
     mp = ivp = hp = None
     if hist_dev is not None:
         ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
@@ -781,3 +814,19 @@ def pack_weight_unfold_w(w, cpad2):
     out = torch.zeros(K, R, 1, cpad2, dtype=torch.int8, device=w.device)
     out[:, :, 0, :S * C] = w.permute(0, 2, 3, 1).reshape(K, R, S * C).to(torch.int8)
     return out.contiguous()
+
+
+def read_npy_batch(paths, header, dst, threads=4):
+    """fq_read_npy_batch_f32: the payloads of the .npy files `paths` (all with the header bytes `header`) into dst[i]
+    (a float32 HOST tensor [len(paths), ...], contiguous -- pinned if an asynchronous upload follows).  Returns the list of
+    per-file success flags.  One foreign call: the interpreter lock is released for all the reads."""
+    n = len(paths)
+    if n == 0:
+        return []
+    assert dst.device.type == "cpu" and dst.dtype == torch.float32 and dst.is_contiguous() and dst.shape[0] == n
+    arr = (ctypes.c_char_p * n)(*[os.fsencode(p) for p in paths])
+    ok = (ctypes.c_int * n)()
+    elems = dst[0].numel()
+    _check(lib().fq_read_npy_batch_f32(ctypes.cast(arr, ctypes.c_void_p), n, header, len(header), dst.data_ptr(), elems,
+                                       int(threads), ctypes.cast(ok, ctypes.c_void_p)), "fq_read_npy_batch_f32")
+    return [bool(v) for v in ok]

@@ -61,6 +61,10 @@ class _StopForward(Exception):
     when the deeper activations were kept from pass 1)."""
 
 
+class _FileGroup(list):
+    """Consecutive calibration files of one rank that go through the model as one batch (Quantity.file_batch)."""
+
+
 def _dist_on():
     import torch.distributed as dist
     return dist.is_available() and dist.is_initialized()
@@ -302,6 +306,8 @@ class Quantity(object):
         (SCALE is read and never applied there, and is not applied here).  Decoding uses Pillow;
         the resize is half-pixel bilinear rounded back to uint8, OpenCV's INTER_LINEAR convention."""
         mode = int(self.user_config["PRE_PROCESS"]["IMG"])
+        if isinstance(image, _FileGroup):
+            return self._preprocess_group(image, mode)
         if mode == 1:
             img, _ = image
             return img
@@ -324,6 +330,156 @@ class Quantity(object):
             return bgr - mean
         print("input option set wrong:", mode)
         return None
+
+    # File inputs (PRE_PROCESS.IMG 0 / 2): the reference feeds ONE file per forward (pytorch_quantizer.py:252-284,
+    # 288-296).  Maxima and integer histograms do not depend on how the images are grouped, and this library's float
+    # kernels compute every output element with a fixed summation order whatever the batch size, so `file_batch`
+    # consecutive files of a rank go through the model as one batch -- same tables, bit for bit (tests/test_gpu_file_inputs.py)
+    # -- decoded by `decode_workers` threads straight into one pinned staging tensor.  file_batch = 1: the reference's form.
+    file_batch = int(os.environ.get("FQ_FILE_BATCH", "64"))
+    decode_workers = int(os.environ.get("FQ_DECODE_WORKERS", str(min(16, os.cpu_count() or 8))))
+    # pass 2 reads the inputs again: file batches already uploaded in pass 1 stay on the device up to this many bytes
+    # (5 120 ResNet images are 3.1 GB) instead of being decoded a second time
+    file_keep_bytes = int(float(os.environ.get("FQ_FILE_KEEP_GB", "16")) * (1 << 30))
+
+    def _file_batching(self):
+        return (int(self.user_config["PRE_PROCESS"]["IMG"]) in (0, 2) and self.file_batch > 1 and self.device == "gpu"
+                and torch.cuda.is_available())
+
+    @staticmethod
+    def _npy_header(path):
+        """(header bytes up to the data, shape) of an fp32 C-order .npy file, or None."""
+        with open(path, "rb") as fh:
+            try:
+                version = np.lib.format.read_magic(fh)
+                shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if version == (1, 0)
+                                         else np.lib.format.read_array_header_2_0(fh))
+            except ValueError:
+                return None
+            if fortran or dtype != np.float32:
+                return None
+            n = fh.tell()
+            fh.seek(0)
+            return fh.read(n), tuple(shape)
+
+    @staticmethod
+    def _read_npy_into(path, dst, header=None):
+        """One .npy file (fp32, C order, dst's shape) read straight into `dst` (a numpy view of the pinned batch): no
+        intermediate array.  `header`: the header bytes of a file of the same form (Quantity._npy_header) -- files written by
+        one np.save loop share them, and comparing bytes is all the parsing the other files need.  False when the file is
+        not of that form (the caller falls back to np.load)."""
+        if header is None:
+            h = Quantity._npy_header(path)
+            if h is None or h[1] != tuple(dst.shape):
+                return False
+            header = h[0]
+        with open(path, "rb", buffering=0) as fh:
+            if fh.read(len(header)) != header:
+                return False
+            return fh.readinto(memoryview(dst.reshape(-1)).cast("B")) == dst.size * 4
+
+    def _staging(self, shape):
+        """A pinned host tensor of `shape` out of a ring of six staging buffers owned by this calibration (allocated on
+        first use, as large as the largest batch so far).  Page-locking 150 MB costs 15-40 ms, and torch's caching host
+        allocator hands a block back only once the copies out of it are known to be done -- with a batch decoded ahead,
+        one being copied and one just consumed it kept allocating new ones.  A slot is reused only after the copy out of it
+        has completed (its event, set by _device_items)."""
+        ring = self.__dict__.setdefault("_pinned_ring", {"slots": [], "next": 0, "lock": __import__("threading").Lock()})
+        with ring["lock"]:
+            return self._staging_locked(ring, shape)
+
+    def _staging_locked(self, ring, shape):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        if len(ring["slots"]) < 6:
+            ring["slots"].append({"buf": torch.empty(n, dtype=torch.float32, pin_memory=True), "event": None})
+            slot = ring["slots"][-1]
+        else:
+            slot = ring["slots"][ring["next"] % 6]
+            ring["next"] += 1
+            # (three groups are decoded ahead and one is being handed over: at most four slots are out without an event)
+            assert slot["event"] is not None or not slot.get("out"), "staging ring too small for the look-ahead"
+            if slot["event"] is not None:
+                slot["event"].synchronize()
+                slot["event"] = None
+            if slot["buf"].numel() < n:
+                slot["buf"] = torch.empty(n, dtype=torch.float32, pin_memory=True)
+        out = slot["buf"][:n].view(shape)
+        out._fq_slot = slot
+        slot["out"] = True
+        return out
+
+    def _preprocess_group(self, group, mode):
+        """[G, C, H, W] pinned host tensor of the files in `group` (unreadable image files are dropped, as a crash on one
+        would be the reference's only alternative); None when nothing was readable."""
+        from concurrent.futures import ThreadPoolExecutor
+        if getattr(self, "_decode_pool", None) is None:
+            self._decode_pool = ThreadPoolExecutor(max_workers=max(1, self.decode_workers))
+        paths = list(group)
+        stage = self.__dict__.setdefault("input_wait_s", {})
+        t_0 = time.perf_counter()
+        if mode == 2:
+            h = self._npy_header(paths[0])
+            if h is not None:                                   # the whole group through the native reader
+                batch = self._staging((len(paths),) + h[1])
+                t_1 = time.perf_counter()
+                flags = _native.read_npy_batch(paths, h[0], batch, threads=min(4, max(1, self.decode_workers)))
+                for j, f in enumerate(flags):
+                    if not f:                                   # another header: the general reader, which also checks the shape
+                        one = self.preprocess(paths[j])
+                        if tuple(one.shape[1:]) != tuple(batch.shape[1:]):
+                            raise ValueError("calibration files of one batch have different shapes; set Quantity.file_batch = 1")
+                        batch[j].copy_(one[0])
+                t_2 = time.perf_counter()
+                stage["group_setup"] = stage.get("group_setup", 0.0) + (t_1 - t_0)      # (helper-thread seconds: diagnostics)
+                stage["group_read"] = stage.get("group_read", 0.0) + (t_2 - t_1)
+                return batch
+        first = self.preprocess(paths[0])
+        k = 1
+        while first is False and k < len(paths):                # (mode 0: skip unreadable files at the head)
+            first = self.preprocess(paths[k])
+            k += 1
+        if first is False or first is None:
+            return None
+        rest = paths[k:]
+        batch = self._staging((1 + len(rest),) + tuple(first.shape[1:]))
+        batch[0].copy_(first[0])
+        view = batch.numpy()
+        t_1 = time.perf_counter()
+        header = None
+        if mode == 2:
+            h = self._npy_header(paths[k - 1])
+            header = h[0] if h is not None and h[1] == tuple(view.shape[1:]) else None
+
+        def load(j):
+            dst = view[1 + j]
+            one = self.preprocess(rest[j])
+            if one is False or one is None:
+                return False
+            if tuple(one.shape[1:]) != tuple(dst.shape):
+                return None
+            dst[...] = one[0].numpy()
+            return True
+        # .npy files: one foreign call reads the whole group (fq_read_npy_batch_f32: open / header compare / pread per
+        # file on a few host threads, the interpreter lock released throughout).  The same loop in Python measured 17 000-
+        # 22 000 files/s alone and 5 500 next to the thread that launches the kernels -- three lock hand-offs per file
+        # (scripts/_dbg/file_decode_probe.py); a Python thread pool was slower still.  Files the native reader refuses
+        # (another header) and image files (PIL decode + resize: milliseconds each, outside the lock) take load().
+        if header is not None and rest:
+            flags = _native.read_npy_batch(rest, header, batch[1:], threads=min(4, max(1, self.decode_workers)))
+            ok = [True if f else load(j) for j, f in enumerate(flags)]
+        elif header is not None:
+            ok = []
+        else:
+            ok = list(self._decode_pool.map(load, range(len(rest))))
+        t_2 = time.perf_counter()
+        stage["group_setup"] = stage.get("group_setup", 0.0) + (t_1 - t_0)      # (helper-thread seconds: diagnostics)
+        stage["group_read"] = stage.get("group_read", 0.0) + (t_2 - t_1)
+        if any(r is None for r in ok):
+            raise ValueError("calibration files of one batch have different shapes; set Quantity.file_batch = 1")
+        keep = [0] + [1 + j for j, r in enumerate(ok) if r]
+        return batch if len(keep) == batch.shape[0] else batch[keep].contiguous().pin_memory()
 
     def net_forward(self, net, image_path):
         img = image_path if torch.is_tensor(image_path) else self.preprocess(image_path)
@@ -352,29 +508,76 @@ class Quantity(object):
         a loader that refills one pinned staging buffer per batch would otherwise overwrite a batch still in flight."""
         use_side = (self.prefetch_inputs and self.device == "gpu" and torch.cuda.is_available())
         in_flight = None                                      # event of a copy whose pinned source is still being read
-        items = iter(self._calibration_items(images_files))
+        items = self._decoded_items(self._calibration_items(images_files))
+        kept = getattr(self, "_file_kept", None)
+        waits = self.__dict__.setdefault("input_wait_s", {"copy_done": 0.0, "decode": 0.0, "copy_issue": 0.0})
         while True:
+            t_a = time.perf_counter()
             if in_flight is not None:
                 in_flight.synchronize()
                 in_flight = None
+            t_b = time.perf_counter()
             try:
-                i, item = next(items)
+                i, img, is_group = next(items)
             except StopIteration:
                 return
-            img = self.preprocess(item)
+            t_c = time.perf_counter()
+            waits["copy_done"] += t_b - t_a                   # (host seconds this loop spent waiting: diagnostics, Quantity.input_wait_s)
+            waits["decode"] += t_c - t_b
+            if img is None:                                   # a group of unreadable files
+                continue
             if use_side and torch.is_tensor(img) and img.device.type != "cuda":
                 if getattr(self, "_copy_stream", None) is None:
                     self._copy_stream = torch.cuda.Stream()
                 main = torch.cuda.current_stream()
                 with torch.cuda.stream(self._copy_stream):
                     dev = img.cuda(non_blocking=True)
-                    if img.is_pinned():
+                    slot = getattr(img, "_fq_slot", None)
+                    if slot is not None:                      # a staging buffer of this calibration: reused after this event
+                        slot["event"] = torch.cuda.Event()
+                        slot["event"].record(self._copy_stream)
+                        slot["out"] = False
+                    elif img.is_pinned():
                         in_flight = torch.cuda.Event()
                         in_flight.record(self._copy_stream)
                 main.wait_stream(self._copy_stream)
                 dev.record_stream(main)
                 img = dev
+                waits["copy_issue"] += time.perf_counter() - t_c
+                if is_group and kept is not None and i not in kept:
+                    nbytes = img.numel() * img.element_size()
+                    if self._file_kept_bytes + nbytes <= self.file_keep_bytes:
+                        kept[i] = img                         # pass 2 takes the batch from here instead of the files
+                        self._file_kept_bytes += nbytes
             yield i, img
+
+    def _decoded_items(self, items):
+        """(index, decoded input, is a file group) for every calibration item.  File groups are decoded ONE GROUP AHEAD on
+        a helper thread (which fans the files out to the decode pool), so that reading the next batch's files runs beside
+        this thread's kernel launches for the current one; a group whose upload was kept in pass 1 is not read again."""
+        if not self._file_batching():
+            for i, item in items:
+                yield i, self.preprocess(item), False
+            return
+        import collections
+        from concurrent.futures import ThreadPoolExecutor
+        if getattr(self, "_group_pool", None) is None:
+            self._group_pool = ThreadPoolExecutor(max_workers=2)       # two groups in the making: their file reads overlap
+        kept = getattr(self, "_file_kept", None) or {}
+        pending = collections.deque()
+        it = iter(items)
+
+        def refill():
+            for i, item in it:
+                pending.append((i, None if i in kept else self._group_pool.submit(self.preprocess, item)))
+                return
+        refill()
+        refill()
+        refill()
+        while pending:
+            i, fut = pending.popleft()
+            refill()
+            yield i, (kept[i] if fut is None else fut.result()), True
 
     # ------------------------------------------------------------------------------------------
     # merge groups
@@ -653,6 +856,14 @@ class Quantity(object):
         output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))
         return False
 
+    def _training_state_modules(self):
+        """Modules whose forward in training mode changes state or draws random numbers: anything in training mode that owns
+        buffers (BatchNorm's running statistics) or is a dropout layer.  (A parameter-free module left in training mode --
+        e.g. the Identity that merge_bn puts in a BatchNorm's place -- does not count.)"""
+        from torch.nn.modules.dropout import _DropoutNd
+        return [m for m in self.model.modules()
+                if m.training and (isinstance(m, _DropoutNd) or next(m.buffers(recurse=False), None) is not None)]
+
     def _probe_forward(self, own_plain):
         """One forward of the model on a random input of INPUT_SHAPE with the hooks watching for in-place consumers; returns
         whether a hooked tensor was written to after its hook ran.  The reference feeds its models random input exactly
@@ -777,12 +988,29 @@ class Quantity(object):
         """Yield the calibration items this rank owns.  Batches 0..MAX_CALI_IMG_NUM are used
         (i > MAX breaks: N+1 batches, pytorch_quantizer.py:381); with W ranks, batch i goes to
         rank i % W.  Sequences are indexed so that other ranks' batches are never materialised."""
-        rank, world = _dist_state()
-        last = self._max_img_num
         if getattr(images_files, "_fq_indexed", False):            # already (index, item) pairs of this rank
             for pair in images_files:
                 yield pair
             return
+        if not self._file_batching():
+            for pair in self._owned_items(images_files):
+                yield pair
+            return
+        # file inputs: file_batch consecutive files of this rank form one item, named by its first file's index
+        group, first = _FileGroup(), None
+        for i, item in self._owned_items(images_files):
+            if not group:
+                first = i
+            group.append(item)
+            if len(group) == self.file_batch:
+                yield first, group
+                group = _FileGroup()
+        if group:
+            yield first, group
+
+    def _owned_items(self, images_files):
+        rank, world = _dist_state()
+        last = self._max_img_num
         if hasattr(images_files, "__getitem__") and hasattr(images_files, "__len__"):
             for i in range(rank, min(len(images_files), last + 1), world):
                 yield i, images_files[i]
@@ -818,6 +1046,7 @@ class Quantity(object):
         quantizer = self.quantizer_cls(top_feat_names, worker_num=settings["WORKER_NUM"], debug=False)
         named_feats, hooks = self.regist_hook_outfeature(self.model)
         self._collector, self._quantizer = collector, quantizer
+        self._file_kept, self._file_kept_bytes = {}, 0
         patched = self._patch_fused_convs(self.model) if getattr(collector, "supports_partial", False) else []
         try:
             return self._calibrate(images_files, collector, quantizer, named_feats, merge_groups, top_feat_names,
@@ -828,6 +1057,8 @@ class Quantity(object):
             for h in hooks:                 # (the reference never removes its hooks)
                 h.remove()
             named_feats.clear()
+            self._file_kept, self._file_kept_bytes = {}, 0
+            self.__dict__.pop("_pinned_ring", None)
 
     def _calibrate(self, images_files, collector, quantizer, named_feats, merge_groups, top_feat_names, table_file):
         rank, world = _dist_state()
@@ -841,12 +1072,14 @@ class Quantity(object):
         n_owned = None
         if hasattr(images_files, "__len__") and hasattr(images_files, "__getitem__"):
             n_owned = len(range(rank, min(len(images_files), self._max_img_num + 1), world))
+            if self._file_batching():
+                n_owned = (n_owned + self.file_batch - 1) // self.file_batch
         ctl = self._hook_ctl
         plan = None
         cached, cached_ids, used = {}, set(), 0
         step_ms = []
         inplace = None                          # does a later module overwrite a hooked tensor?
-        if eager_ok and any(m.training for m in self.model.modules()):
+        if eager_ok and self._training_state_modules():
             # a model in training mode (BatchNorm statistics, dropout): nothing but calibration data may pass through it, so
             # no probe -- one launch per tensor from inside the hooks (always correct), nothing cached, pass 2 not fused
             budget = 0
@@ -1021,7 +1254,7 @@ class Quantity(object):
             # channel counts and whether later modules overwrite hooked tensors -- on EVERY rank, also one that owns
             # no calibration batch and must still take part in the two all-reduces.  A model in training mode is probed
             # in eval mode (no BatchNorm statistic sees the noise) and then takes one launch per tensor, always correct.
-            was_training = [m for m in self.model.modules() if m.training]
+            was_training = self._training_state_modules()
             for m in was_training:
                 m.training = False
             try:

@@ -259,8 +259,10 @@ def test_a_module_that_disagrees_keeps_the_library_convolution(monkeypatch):
         q2 = Quantity(cases.seed_model(_bottleneck_net(), base_seed=5).eval().cuda())
         assert dict(q2.activation_quantize(cases.calib_batches(5, (8, 3, 16, 16), seed=77))) == bits
         import pickle
-        blob = pickle.dumps(q2.model)                   # what Reconstruction's torch.save(self.model) would write
-        assert b"_fq_" not in blob and not any(k.startswith("_fq") for m in q2.model.modules() for k in m.__dict__)
+        # what Reconstruction's torch.save(self.model) would write: nothing of this package rides on the modules
+        assert not any(k.startswith("_fq") for m in q2.model.modules() for k in m.__dict__)
+        for m in (q2.model.c1, q2.model.c3, q2.model.down):
+            assert b"_fq_" not in pickle.dumps(m) and "forward" not in m.__dict__
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -463,10 +465,11 @@ def test_testconv_runs_its_1x1_layers_on_the_own_kernel_and_hooks_still_fire():
     with product_workdir(device="gpu") as tmp:
         layer = TestConv("c", conv, {"weight_bit": 6, "bias_bit": 5, "input_bit": 4, "output_bit": 4}, tmp + "/test/workdir/rt.pth")
         seen = []
-        layer.Conv.register_forward_hook(lambda m, i, o: seen.append(o.clone()))
+        handle = layer.Conv.register_forward_hook(lambda m, i, o: seen.append(o.clone()))
         x = torch.randn(4, 32, 14, 14, device="cuda")
         with torch.no_grad():
             out = layer(x)
+            handle.remove()
             assert _float_conv.is_verified(layer.Conv) and "forward" not in layer.Conv.__dict__ and len(seen) == 1
             assert not any(k.startswith("_fq") for k in layer.Conv.__dict__)
             assert torch.equal(out, _native.quandequan(seen[0], 4))
@@ -474,6 +477,69 @@ def test_testconv_runs_its_1x1_layers_on_the_own_kernel_and_hooks_still_fire():
             assert float((seen[0] - ref).abs().max()) <= 1e-4
         pickle.dumps(layer.Conv.state_dict())
         assert b"_fq_" not in pickle.dumps(layer)                   # the whole-module pickle carries no packed copy / flag
+
+
+@pytest.mark.parametrize("bit,bitwidth", [(4, 8), (-1, 8), (9, 16)])
+def test_quandequan_epilogue_equals_the_two_pass_form(nat, bit, bitwidth):
+    """fq_conv1x1_qd_f32 / fq_conv_kxk_qd_f32 / fq_conv_stem_qd_f32 (TestConv.forward in one kernel) == fq_quandequan_f32 of
+    the plain kernel's output, bit for bit, on Gaussian data with saturating, tie and zero cases; ragged shapes (K tail,
+    partial tiles, stride 2, Cout not a multiple of the tile)."""
+    g = torch.Generator(device="cuda").manual_seed(31 + bit)
+    for (N, Cin, H, W, Cout, s) in ((3, 40, 13, 9, 36, 1), (2, 64, 28, 28, 256, 2), (5, 256, 7, 7, 64, 1)):
+        x = torch.randn(N, Cin, H, W, device="cuda", generator=g) * 3
+        x[0, 0, 0, :3] = torch.tensor([1e6, -1e6, 0.0], device="cuda")
+        wt = torch.randn(Cin, Cout, device="cuda", generator=g) * Cin ** -0.5
+        b = torch.randn(Cout, device="cuda", generator=g)
+        want = nat.quandequan(nat.conv1x1_f32(x, wt, b, s), bit, bitwidth)
+        assert torch.equal(nat.conv1x1_f32(x, wt, b, s, qd=(bit, bitwidth)), want)
+        assert torch.equal(nat.conv1x1_f32(x, wt, None, s, qd=(bit, bitwidth)), nat.quandequan(nat.conv1x1_f32(x, wt, None, s), bit, bitwidth))
+    for (N, Cin, H, W, Cout, k, s, p) in ((2, 32, 14, 11, 48, 3, 1, 1), (3, 64, 15, 15, 128, 3, 2, 1), (1, 16, 9, 9, 20, 5, 1, 2)):
+        x = torch.randn(N, Cin, H, W, device="cuda", generator=g) * 2
+        w = torch.randn(Cout, Cin, k, k, device="cuda", generator=g) * (Cin * k * k) ** -0.5
+        b = torch.randn(Cout, device="cuda", generator=g)
+        wt = nat.pack_kxk_weight(w)
+        want = nat.quandequan(nat.conv_kxk_f32(x, wt, b, (k, k), s, p), bit, bitwidth)
+        assert torch.equal(nat.conv_kxk_f32(x, wt, b, (k, k), s, p, qd=(bit, bitwidth)), want)
+    for shape in STEM_SHAPES[:3]:
+        x, w, b, pad = _stem_case(shape, 33, integer=False)
+        want = nat.quandequan(_stem(nat, x, w, b, pad), bit, bitwidth)
+        assert torch.equal(_stem(nat, x, w, b, pad, qd=(bit, bitwidth)), want)
+    with pytest.raises(nat.FqError):
+        nat.conv1x1_f32(x[:, :, :4, :4].contiguous(), torch.zeros(3, 4, device="cuda"), None, 1, qd=4, relu_out=torch.zeros(1, device="cuda"))
+
+
+def test_testconv_runs_as_one_kernel_unless_its_convolution_is_hooked():
+    """TestConv.forward: no forward hook on the inner nn.Conv2d -> one kernel (QuanDequan in the convolution's epilogue), the
+    standalone fq_quandequan_f32 pass is not launched; with a hook on the inner module the two-pass form runs (the hook sees
+    the un-quantised output, as the reference's would) -- and both give the same bits."""
+    from torch import nn
+    from common.quantity import TestConv, _float_conv, _native
+    convs = [nn.Conv2d(32, 64, 1), nn.Conv2d(16, 32, 3, padding=1), nn.Conv2d(3, 64, 7, stride=2, padding=3)]
+    with product_workdir(device="gpu") as tmp:
+        for i, conv in enumerate(convs):
+            conv = conv.cuda().eval()
+            layer = TestConv("c%d" % i, conv, {"weight_bit": 6, "bias_bit": 5, "input_bit": 4, "output_bit": 4},
+                             tmp + "/test/workdir/rt%d.pth" % i)
+            x = torch.randn(4, conv.in_channels, 30, 26, device="cuda")
+            calls, real = {"n": 0}, _native.quandequan
+
+            def counted(*a, **k):
+                calls["n"] += 1
+                return real(*a, **k)
+            _native.quandequan = counted
+            try:
+                with torch.no_grad():
+                    fused = layer(x)
+                    assert calls["n"] == 0 and _float_conv.is_verified(layer.Conv)
+                    seen = []
+                    h = layer.Conv.register_forward_hook(lambda m, inp, o: seen.append(o.clone()))
+                    two_pass = layer(x)
+                    h.remove()
+                    assert calls["n"] == 1 and len(seen) == 1
+            finally:
+                _native.quandequan = real
+            assert torch.equal(fused, two_pass) and torch.equal(fused, _native.quandequan(seen[0], 4))
+            assert not any(k.startswith("_fq") for k in layer.Conv.__dict__)
 
 
 def test_pool_modules_are_served_and_tables_do_not_change():

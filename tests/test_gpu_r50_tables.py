@@ -194,8 +194,9 @@ def test_config5_recontest_r101_at_512_every_layer_output_equals_the_oracle(orac
     """BASELINE config 5's second half: the fake-quant evaluation model (ReconTest) of ResNet-101 @3x512x512.  There is no
     reference capture at this size (the reference's Python histogram loop needs minutes per image), so the check is per
     layer and exact: for each of the 105 TestConv / TestLinear modules the output the model hands on must be the CPU
-    oracle's QuanDequan of the float convolution's own result -- i.e. the fused in-place kernel on every real activation
-    of the model, from 16 M-element planes down to the classifier -- and the fake-quantised parameters must be the
+    oracle's QuanDequan of the float convolution's own result (the same kernel run without the epilogue on the same
+    input) -- i.e. the QuanDequan epilogue of fq_conv1x1_qd_f32 / fq_conv_kxk_qd_f32 / fq_conv_stem_qd_f32 on every real
+    activation of the model, from 16 M-element planes down to 16 x 16 -- and the fake-quantised parameters must be the
     oracle's QuanDequan of the folded ones."""
     from common.quantity import merge_bn
     from model.resnet.ResNet_fabu import ResNet101
@@ -210,17 +211,28 @@ def test_config5_recontest_r101_at_512_every_layer_output_equals_the_oracle(orac
         rec = Reconstruction(float_model.cuda())
         info = rec.get_quantity_information()
         net = rec.ReconTest(info, "./workdir/recontest.pth")
-        checked = {"n": 0, "elems": 0}
-        raw = {}
+        from common.quantity import _float_conv, _native
+        checked = {"n": 0, "elems": 0, "fused": 0}
+        calls = {"qd": 0}
+        real_qd = _native.quandequan
 
-        def grab(name):
-            def hook(mod, inputs, out):
-                raw[name] = out.detach().clone()              # the float result, before QuanDequan overwrites it in place
-            return hook
+        def counted_qd(*a, **k):
+            calls["qd"] += 1
+            return real_qd(*a, **k)
 
-        def check(name, bit):
+        def check(name, inner, bit):
+            # (hooks on the OUTER TestConv / TestLinear only: a hook on the inner nn.Conv2d would -- rightly -- switch the
+            #  layer back to the two-pass form, because such a hook must see the un-quantised convolution output)
             def hook(mod, inputs, out):
-                want = oracle.quandequan(raw.pop(name).cpu().numpy(), bit)
+                x = inputs[0]
+                if isinstance(inner, torch.nn.Conv2d):
+                    k = _float_conv.kind(inner, x)
+                    assert k is not None, name                 # every convolution of the model is this library's
+                    raw = _float_conv.plain(inner, k, x, check=False)
+                    checked["fused"] += 1
+                else:
+                    raw = inner(x)
+                want = oracle.quandequan(raw.cpu().numpy(), bit)
                 assert np.array_equal(out.detach().cpu().numpy(), want), name
                 checked["n"] += 1
                 checked["elems"] += want.size
@@ -229,15 +241,20 @@ def test_config5_recontest_r101_at_512_every_layer_output_equals_the_oracle(orac
         for name, m in net.named_modules():
             if type(m).__name__ in ("TestConv", "TestLinear"):
                 inner = m.Conv if hasattr(m, "Conv") else m.linear
-                inner.register_forward_hook(grab(name))
-                m.register_forward_hook(check(name, m.output_bit))
+                m.register_forward_hook(check(name, inner, m.output_bit))
                 w = inner.weight.detach().cpu().numpy()
                 assert np.array_equal(w, oracle.quandequan(folded[name + ".weight"].numpy(), m.weight_bit)), name
                 assert np.array_equal(inner.bias.detach().cpu().numpy(),
                                       oracle.quandequan(folded[name + ".bias"].numpy(), m.bias_bit)), name
-        with torch.no_grad():
-            logits = net(cases.fixed_input((1, 3, 512, 512), seed=5).cuda())
+        _native.quandequan = counted_qd
+        try:
+            with torch.no_grad():
+                logits = net(cases.fixed_input((1, 3, 512, 512), seed=5).cuda())
+        finally:
+            _native.quandequan = real_qd
         assert checked["n"] == 105 and checked["elems"] > 60_000_000, checked
+        # the 104 convolutions ran as ONE kernel each (QuanDequan in the epilogue): the standalone pass is left to the classifier
+        assert checked["fused"] == 104 and calls["qd"] == 1, (checked, calls)
         assert torch.isfinite(logits).all()
 
 
