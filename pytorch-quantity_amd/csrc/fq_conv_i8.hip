@@ -639,6 +639,202 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     TR(4);
 }
 
+// ---- 3 x 3, stride 1, padding 1, C % 128 == 0: the activation operand as a RESIDENT HALO ---------------------------
+// In the kernel above every K-step (one filter tap of one 128-channel slice) fetches its activation tile again: 128 pixel
+// rows x 128 bytes by LDS-DMA, gathered by tap -- 9 fetches of (almost) the same pixels per slice, half of the 32 KB a
+// step moves into LDS, and with them half of the DMA issues (~45 cycles each for the issuing wave) and of the L2 -> LDS
+// traffic that, at 64 bytes per clock and CU, costs as many cycles as the step's 64 MFMAs.
+// With stride 1 and padding 1 the input pixel of (output pixel m, tap (r, s)) is pixel m + (r - 1) W + (s - 1) of the SAME
+// flat N x H x W order (where it exists): the 128 output pixels of a tile need the contiguous run of input pixels
+// [m0 - W - 1, m0 + 128 + W] -- 130 + 2 W rows of 128 bytes per channel slice.  That slab is fetched ONCE per slice,
+// a tap is a row offset r W + s into it, and taps that fall outside
+// the image (padding; the slab holds a neighbouring row's pixel there) read a 128-byte zero row instead.  Per step: the
+// weight tile only (16 KB, half the DMA issues), 12 vector instructions of tap addressing per lane, same epilogue.
+// Reduction order: slices outer, taps inner -- integer accumulation, any order gives the same bits.
+struct HaloParams {
+    int slab_rows;                         // rows of one slab buffer (130 + 2 W rounded up to 8)
+    int total_pixels;                      // N * H * W
+};
+
+// NP: pixel sub-tiles of 32 per wave (1: 128-pixel tile as above; 2: 256-pixel tile, each wave multiplies two sub-tiles
+// against every weight fragment it reads -- 6 LDS fragment reads per 8 MFMAs instead of 5 per 4, and 32 MFMAs per wave
+// between two barriers instead of 16, which is what the counters asked for: at NP = 1 the matrix pipe is 27 % busy while
+// no other unit passes 45 %, the waves simply spend two thirds of their time in waits and issue stalls around 16 MFMAs).
+// Sub-tile u of wave w is pixels m0 + 128 u + 32 w + lane: each 128-pixel half of the tile is a tile of the shared epilogue.
+template <int TK, int kOut, int ST, int NP>
+__global__ __launch_bounds__(kConvBlock) void conv3x3_i8_halo_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                                     const float* __restrict__ qbias, float* __restrict__ y,
+                                                                     int8_t* __restrict__ q, const ConvParams p, const HaloParams hp) {
+    constexpr int BKB = 128;
+    constexpr int MT = TK / 32;
+    constexpr int A_LOADS = TK / 32;
+    constexpr int TPX = kTP * NP;                             // pixels per workgroup tile
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    // [weights: ST x TK x 128][bias f32: TK][bias i32: TK][zero row: 128][slab: slab_rows x 128]
+    static_assert(ST == 2 || ST == 3, "weight ring of two or three steps");
+    int8_t* const sA = smem;
+    float* const sBias = reinterpret_cast<float*>(smem + ST * TK * BKB);
+    int* const sBiasI = reinterpret_cast<int*>(smem + ST * TK * BKB + TK * 4);
+    int8_t* const sZero = smem + ST * TK * BKB + TK * 8;
+    int8_t* const sSlab = sZero + BKB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    int tile_x, tile_y;
+    if (!conv_tile_of(p, tile_x, tile_y)) return;
+    const int m0 = tile_x * TPX;
+    const int k0 = tile_y * TK;
+    const int PQ = p.P * p.Q;
+    if (tid < TK) {
+        const float b = qbias[k0 + tid];
+        sBias[tid] = b;
+        sBiasI[tid] = (int)b;
+    }
+    if (tid < BKB / 4) reinterpret_cast<int*>(sZero)[tid] = 0;
+
+    // this lane's output pixels (one per sub-tile) and which of their nine taps exist
+    bool m_ok[NP];
+    int n_img[NP], pq[NP];
+    unsigned tap_mask[NP];
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        const int m = m0 + kTP * u + wave * 32 + (lane & 31);
+        m_ok[u] = m < p.M;
+        const int mm = m_ok[u] ? m : 0;
+        n_img[u] = mm / PQ; pq[u] = mm - n_img[u] * PQ;
+        const int oh = pq[u] / p.Q, ow = pq[u] - oh * p.Q;
+        tap_mask[u] = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const bool ok = m_ok[u] && (unsigned)(oh + r - 1) < (unsigned)p.H && (unsigned)(ow + s_ - 1) < (unsigned)p.W;
+                tap_mask[u] |= ok ? 1u << (3 * r + s_) : 0u;
+            }
+    }
+
+    // slab fetch: DMA instruction i covers slab rows 8 i .. 8 i + 7 (input pixels m0 - W - 1 + row), one 128-byte row per 8 lanes
+    const rsrc_words xr = make_rsrc_words(x, p.x_bytes);
+    const int n_slab_dma = hp.slab_rows >> 3;
+    auto slab_dma = [&](int slice) {
+        for (int i = wave; i < n_slab_dma; i += 4) {
+            const int row = 8 * i + (lane >> 3);
+            const int g = m0 - p.W - 1 + row;                 // input pixel (flat N x H x W index); outside the tensor: zeros
+            const unsigned vo = (unsigned)g < (unsigned)hp.total_pixels
+                                    ? (unsigned)g * (unsigned)p.C + (unsigned)(((lane & 7) ^ swz(row, 0)) * 16) : kOutOfRange;
+            dma_to_lds(xr, lds_offset(sSlab + i * 1024), vo, slice * BKB);
+        }
+    };
+    // weight fetch, as in the kernel above: load j of wave v covers tile rows 32 j + 8 v .. + 7
+    const rsrc_words wr = make_rsrc_words(w, p.w_bytes);
+    unsigned aoff[A_LOADS];
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+        const int row = 32 * j + 8 * wave + (lane >> 3);
+        aoff[j] = (unsigned)(k0 + row) * ((unsigned)p.chunks * 16u) + (unsigned)(((lane & 7) ^ swz(row, 0)) * 16);
+    }
+    auto weight_dma = [&](int slice, int tap, int buf, bool live) {
+        const int so = tap * p.C + slice * BKB;               // [K][3][3][C]: tap (r, s) of channel slice `slice`
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j)
+            dma_to_lds(wr, lds_offset(sA + buf * TK * BKB + (32 * j + 8 * wave) * BKB), live ? aoff[j] : kOutOfRange, so);
+    };
+
+    v16i acc[NP][MT];
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][a][r] = 0;
+    int a_off[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) a_off[a] = (a * 32 + (lane & 31)) * BKB;
+    int swz_a[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) swz_a[ks] = ((ks * 2 + half) ^ (((lane & 31) >> 1) & 7)) * 16;
+    const int p_row = wave * 32 + (lane & 31);                // this lane's pixel inside a 128-pixel half of the tile
+    const unsigned zero_off = (unsigned)(sZero - smem);
+    const unsigned slab_off0 = (unsigned)(sSlab - smem);
+
+    // Weights: ring of ST steps.  With three, the tile requested during step s is the one of step s + 2, so the wait at the
+    // end of a step (vmcnt(A_LOADS): everything but the newest request) is for data that had a whole step to arrive.  The
+    // slab has ONE buffer: between two channel slices every wave finishes the last tap, the slab is fetched again and
+    // waited for in the open -- once per nine steps.
+    const int nslices = p.C >> 7;
+    const int nsteps = 9 * nslices;
+    auto step_of = [&](int st, int& sl, int& tp) { sl = st / 9; tp = st - 9 * sl; };
+    slab_dma(0);
+    weight_dma(0, 0, 0, true);
+    if (ST == 3) weight_dma(0, 1, 1, nsteps > 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int slice = 0, tap = 0, cur = 0, nxt2 = ST - 1;
+    for (int step = 0; step < nsteps; ++step) {
+        // this tap's activation fragments out of the resident slab: row = pixel + r W + s, or the zero row
+        const int r = tap / 3, s_ = tap - 3 * r;
+        v4i fb[NP][4], fa[2][MT];
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const int j = kTP * u + p_row + r * p.W + s_;
+            const bool ok = (tap_mask[u] >> tap) & 1u;
+            const unsigned rowb = ok ? slab_off0 + (unsigned)(j * BKB) : zero_off;
+            const int sw = ok ? (j >> 1) & 7 : 0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fb[u][ks] = *reinterpret_cast<const v4i*>(smem + rowb + (unsigned)((((ks * 2 + half) ^ sw)) * 16));
+        }
+        const int8_t* const sAc = sA + cur * TK * BKB;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) fa[0][a] = *reinterpret_cast<const v4i*>(sAc + a_off[a] + swz_a[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a) fa[(ks + 1) & 1][a] = *reinterpret_cast<const v4i*>(sAc + a_off[a] + swz_a[ks + 1]);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a)
+#pragma unroll
+                for (int u = 0; u < NP; ++u)
+                    acc[u][a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[u][ks], acc[u][a], 0, 0, 0);
+            if (ks == 0) {
+                // the weight tile of step + ST - 1, requested behind the first MFMAs of this step (the matrix pipe has work
+                // queued while the wave sits in the DMA issues); it goes where step - 1 was read from
+                int sl2, tp2;
+                step_of(step + ST - 1, sl2, tp2);
+                __builtin_amdgcn_sched_barrier(0);
+                weight_dma(sl2, tp2, nxt2, step + ST - 1 < nsteps);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS) : "memory");     // step + 1's weights have landed (mine) ...
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                     // ... and everybody's; everybody is done with this step
+        cur = cur + 1 == ST ? 0 : cur + 1;
+        nxt2 = nxt2 + 1 == ST ? 0 : nxt2 + 1;
+        if (++tap == 9) {
+            tap = 0;
+            if (++slice < nslices) {                          // next channel slice: the slab again, in the open
+                slab_dma(slice);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // nothing of this wave may still land in LDS: the epilogue reuses it
+    __syncthreads();
+
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+        if (u) __syncthreads();                               // the epilogue stages its int8 tile in sA: one half after the other
+        if (p.rs) conv_epilogue<TK, kOut, true>(acc[u], p, y, q, sA, sBias, sBiasI, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u]);
+        else conv_epilogue<TK, kOut, false>(acc[u], p, y, q, sA, sBias, sBiasI, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u]);
+    }
+}
+
 // ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
 // q8 (one element): fq_int_tail.h
 
@@ -924,6 +1120,49 @@ static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const i
         hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutF32>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
 }
 
+// the halo form of the 3 x 3 layers; false when the layer is not of that shape
+template <int TK>
+static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y, int8_t* q,
+                             const ConvParams& p0) {
+    static const bool on = [] { const char* e = getenv("FQ_CONV_HALO"); return !(e && e[0] == '0'); }();
+    if (!on || p0.R != 3 || p0.S != 3 || p0.stride_h != 1 || p0.stride_w != 1 || p0.pad_h != 1 || p0.pad_w != 1 || p0.dil_h != 1 ||
+        p0.dil_w != 1 || (p0.C & 127) || (p0.K % TK) || p0.res)
+        return false;
+    static const int st_env = [] { const char* e = getenv("FQ_HALO_STAGES"); return e ? atoi(e) : 0; }();
+    static const int np_env = [] { const char* e = getenv("FQ_HALO_NP"); return e ? atoi(e) : 0; }();
+    // 128-pixel tiles.  (FQ_HALO_NP=2: 256-pixel tiles, two sub-tiles per wave -- bit-exact, fewer LDS reads and barriers per
+    // MFMA, and 20-35 % SLOWER on ResNet-50's layers at 256 images: 48.7 vs 39.9 us on 256 -> 256 @14x14.)
+    const int np = np_env ? np_env : 1;
+    HaloParams hp;
+    hp.slab_rows = (128 * np + 2 + 2 * p0.W + 7) & ~7;
+    hp.total_pixels = p0.N * p0.H * p0.W;
+    const size_t fixed = (size_t)TK * 8 + 128 + (size_t)hp.slab_rows * 128;
+    const int stages = st_env ? st_env : ((size_t)3 * TK * 128 + fixed <= 80 * 1024 - 64 ? 3 : 2);
+    const size_t lds = (size_t)stages * TK * 128 + fixed;
+    if (lds > 80 * 1024 - 64 || (stages != 2 && stages != 3) || (np != 1 && np != 2)) return false;   // two workgroups per CU
+    dim3 grid((unsigned)(((long)p0.M + 128 * np - 1) / (128 * np)), (unsigned)(p0.K / TK));
+    const ConvParams p = xcd_order(grid, p0);
+#define FQ_HALO_K(OUT, STG, NPX)                                                                                         \
+    do {                                                                                                                 \
+        auto k = conv3x3_i8_halo_kernel<TK, OUT, STG, NPX>;                                                              \
+        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                       80 * 1024);                                                       \
+        if (ok != (int)hipSuccess) return false;                                                                         \
+        hipLaunchKernelGGL(k, grid, dim3(kConvBlock), lds, st, x, w, qbias, y, q, p, hp);                                \
+    } while (0)
+#define FQ_HALO(OUT)                                                                                                     \
+    do {                                                                                                                 \
+        if (np == 2) { if (stages == 3) FQ_HALO_K(OUT, 3, 2); else FQ_HALO_K(OUT, 2, 2); }                               \
+        else { if (stages == 3) FQ_HALO_K(OUT, 3, 1); else FQ_HALO_K(OUT, 2, 1); }                                      \
+    } while (0)
+    if (y && q) FQ_HALO(kOutF32 | kOutI8);
+    else if (q) FQ_HALO(kOutI8);
+    else FQ_HALO(kOutF32);
+#undef FQ_HALO
+#undef FQ_HALO_K
+    return true;
+}
+
 struct FusedAdd {                        // residual operand and outputs of a fused NewAdd (res == nullptr: none)
     const void* res = nullptr;
     int res_bytes = 0;
@@ -988,7 +1227,9 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     static const int force_tk = [] { const char* e = getenv("FQ_CONV_TK"); return e ? atoi(e) : 0; }();
     static const bool use_c64 = [] { const char* e = getenv("FQ_CONV_C64"); return !(e && e[0] == '0'); }();
     if ((K <= 64 || wg128 < kCUs || force_tk == 64) && force_tk != 128) {
-        if (C % 128 == 0 && K % 64 == 0 && use_dma)
+        if (C % 128 == 0 && K % 64 == 0 && use_dma && launch_conv_halo<64>(st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p))
+            ;
+        else if (C % 128 == 0 && K % 64 == 0 && use_dma)
             launch_conv_dma<64>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else if (C % 128 == 0 && K % 64 == 0)
             launch_conv_tile<64, kPathC128>(dim3(gx, K / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
@@ -997,7 +1238,9 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
         else
             launch_conv_tile<64, kPathGeneral>(dim3(gx, (K + 63) / 64), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
     } else {
-        if (C % 128 == 0 && K % 128 == 0 && use_dma)
+        if (C % 128 == 0 && K % 128 == 0 && use_dma && launch_conv_halo<128>(st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p))
+            ;
+        else if (C % 128 == 0 && K % 128 == 0 && use_dma)
             launch_conv_dma<128>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);
         else if (C % 128 == 0 && K % 128 == 0)
             launch_conv_tile<128, kPathC128>(dim3(gx, K / 128), st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p);

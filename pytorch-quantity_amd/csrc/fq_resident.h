@@ -2,6 +2,7 @@
 // that fuses the residual add (fq_conv_i8.hip).
 #pragma once
 #include <cstdlib>
+#include <type_traits>
 #include "fq_common.h"
 #include "fq_int_tail.h"
 
@@ -19,6 +20,10 @@ struct AddResParams {
     int shx, shy;          // g - gx, g - gy: operand -> grid g
     int ilo, ihi;          // Sp range on grid g
     int k, half_m1;        // narrow = S * 2^(ib - g): k = g - ib; k > 0: round-half-even right shift with 2^(k-1) - 1
+    // the integer form on PAIRS of int16 (v_pk_*_i16: two elements per instruction) where every intermediate fits 16 bits:
+    // pk_ok8 / pk_ok16 for an int8 / int16 operand y; the constants below are the ones above, replicated in both halves
+    int pk_ok8, pk_ok16;
+    unsigned shx2, shy2, k2, ilo2, ihi2, half2;
 };
 
 template <typename T> struct Vec16;                       // 16 consecutive channels of one pixel
@@ -86,11 +91,70 @@ __device__ __forceinline__ Add16Out add_resident_16_int(const VX& vx, const VY& 
     return o;
 }
 
+// ---- the same integers two at a time.  With g <= 8 the clamped sum S lies in [-128 * 2^g, 127 * 2^g], inside int16; with
+// shx, shy <= 8 so do the shifted operands of an int8 x / y (|.| <= 128 * 256), and an int16 y is taken unshifted (shy = 0:
+// the residual chain on one grid, the usual case); their sum is formed with a SATURATING add (v_pk_add_i16 clamp), and
+// saturation to [-32768, 32767] followed by the clamp to [ilo, ihi] inside that range equals the clamp of the exact sum.
+// For 1 <= k <= 8 the rounding term S + 2^(k-1) - 1 + bit stays below 32512 + 128 and above -32768: no wrap.  17 vector
+// instructions per 4 elements (unpacking the int8 operand included) instead of 45; the int16 sum leaves as it stands.
+typedef short v2s_r __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2s_r pk_of(unsigned u) { return __builtin_bit_cast(v2s_r, u); }
+__device__ __forceinline__ unsigned u_of(v2s_r v) { return __builtin_bit_cast(unsigned, v); }
+// bytes (0, 1) / (2, 3) of a dword as two sign-extended int16
+__device__ __forceinline__ v2s_r pk_bytes_lo(unsigned d) { return pk_of(__builtin_amdgcn_perm(0u, d, 0x010c000cu)) >> (short)8; }
+__device__ __forceinline__ v2s_r pk_bytes_hi(unsigned d) { return pk_of(__builtin_amdgcn_perm(0u, d, 0x030c020cu)) >> (short)8; }
+
+template <typename VY>
+__device__ __forceinline__ Add16Out add_resident_16_pk(const Vec16<int8_t>& vx, const VY& vy, bool want_wide, bool want_narrow,
+                                                       const AddResParams& p) {
+    Add16Out o = {};
+    const v2s_r sx = pk_of(p.shx2), sy = pk_of(p.shy2), kk = pk_of(p.k2), lo = pk_of(p.ilo2), hi = pk_of(p.ihi2);
+    v2s_r s[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {                         // dword d of x: elements 4 d .. 4 d + 3
+        const unsigned xb = (unsigned)vx.a[d];
+        v2s_r y0, y1;
+        if constexpr (std::is_same<VY, Vec16<int16_t>>::value) {
+            y0 = pk_of((unsigned)(d < 2 ? vy.a[2 * d] : vy.b[2 * d - 4]));
+            y1 = pk_of((unsigned)(d < 2 ? vy.a[2 * d + 1] : vy.b[2 * d - 3]));
+        } else {
+            y0 = pk_bytes_lo((unsigned)vy.a[d]) << sy;
+            y1 = pk_bytes_hi((unsigned)vy.a[d]) << sy;
+        }
+        const v2s_r a0 = __builtin_elementwise_add_sat(pk_bytes_lo(xb) << sx, y0);
+        const v2s_r a1 = __builtin_elementwise_add_sat(pk_bytes_hi(xb) << sx, y1);
+        s[2 * d] = __builtin_elementwise_min(__builtin_elementwise_max(a0, lo), hi);
+        s[2 * d + 1] = __builtin_elementwise_min(__builtin_elementwise_max(a1, lo), hi);
+    }
+    if (want_wide) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            if (d < 4) o.w0[d] = (int)u_of(s[d]); else o.w1[d - 4] = (int)u_of(s[d]);
+        }
+    }
+    if (want_narrow) {
+        const v2s_r one = {1, 1}, m128 = {-128, -128}, p127 = {127, 127}, hm1 = pk_of(p.half2);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            v2s_r t0 = (s[2 * d] + hm1 + ((s[2 * d] >> kk) & one)) >> kk;
+            v2s_r t1 = (s[2 * d + 1] + hm1 + ((s[2 * d + 1] >> kk) & one)) >> kk;
+            t0 = __builtin_elementwise_min(__builtin_elementwise_max(t0, m128), p127);
+            t1 = __builtin_elementwise_min(__builtin_elementwise_max(t1, m128), p127);
+            o.n[d] = (int)__builtin_amdgcn_perm(u_of(t1), u_of(t0), 0x06040200u);      // the low bytes of the four int16
+        }
+    }
+    return o;
+}
+
 // The sum of 16 elements in registers (the callers store it: plain pointers in fq_resident.hip / the general conv epilogue,
 // buffer stores in fq_conv1x1_i8.hip)
 template <typename VX, typename VY>
 __device__ __forceinline__ Add16Out add_resident_16_regs(const VX& vx, const VY& vy, bool want_wide, bool want_narrow,
                                                          const AddResParams& p) {
+    if constexpr (std::is_same<VX, Vec16<int8_t>>::value) {
+        if (std::is_same<VY, Vec16<int16_t>>::value ? p.pk_ok16 : p.pk_ok8)     // uniform
+            return add_resident_16_pk(vx, vy, want_wide, want_narrow, p);
+    }
     if (p.int_ok) {                                       // uniform
         if (p.k > 0) return add_resident_16_int<true>(vx, vy, want_wide, want_narrow, p);
         return add_resident_16_int<false>(vx, vy, want_wide, want_narrow, p);
@@ -157,6 +221,14 @@ inline int make_add_params(int gx, int gy, int g_wide, bool want_wide, int ib, i
     p->half_m1 = p->k > 0 ? (1 << (p->k - 1)) - 1 : 0;
     p->ilo = relu ? 0 : -(128 << g); p->ihi = 127 << g;
     if (!p->int_ok) { p->shx = p->shy = 0; p->k = 0; }
+    // packed int16 form: every intermediate inside 16 bits (see add_resident_16_pk).  FQ_ADD_PACKED=0 keeps the 32-bit form.
+    static const bool no_pk = [] { const char* e = getenv("FQ_ADD_PACKED"); return e && e[0] == '0'; }();
+    const bool pk = p->int_ok && !no_pk && p->k >= 1 && p->k <= 8 && p->shx >= 0 && p->shx <= 8;
+    p->pk_ok8 = pk && p->shy >= 0 && p->shy <= 8;
+    p->pk_ok16 = pk && p->shy == 0;
+    auto rep = [](int v) { return ((unsigned)v & 0xffffu) * 0x10001u; };
+    p->shx2 = rep(p->shx); p->shy2 = rep(p->shy); p->k2 = rep(p->k); p->ilo2 = rep(p->ilo); p->ihi2 = rep(p->ihi);
+    p->half2 = rep(p->half_m1);
     return FQ_OK;
 }
 

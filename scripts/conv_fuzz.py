@@ -130,6 +130,42 @@ def run_stream(cases, seed, verbose=True):
     return failures
 
 
+def run_halo(cases, seed, verbose=True):
+    """The resident-halo form of the 3 x 3 / stride 1 / padding 1 layers (conv3x3_i8_halo_kernel in csrc/fq_conv_i8.hip): C a
+    multiple of 128, every plane size from 1 x 1 up (tiles that start and end inside an image row, span several images, or
+    lie past the end), one and several channel slices, fp32 / int8 / both outputs."""
+    rng = np.random.default_rng(seed)
+    failures = []
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for it in range(cases):
+        C = int(rng.choice([128, 128, 256, 384, 512])); K = int(rng.choice([64, 128, 192, 256]))
+        N = int(rng.integers(1, 6)); H = int(rng.integers(1, 31)); W = int(rng.integers(1, 31))
+        if rng.random() < 0.25:
+            H, W = int(rng.choice([7, 14, 28])), int(rng.choice([7, 14, 28]))
+        x = rng.integers(-128, 128, size=(N, C, H, W)).astype(np.int32)
+        w = rng.integers(-128, 128, size=(K, C, 3, 3)).astype(np.int32)
+        qb = rng.integers(-128, 128, size=K).astype(np.float32)
+        rs = int(rng.integers(0, 19)); ob = int(rng.integers(-2, 7)); relu = bool(rng.integers(0, 2))
+        acc = orc.conv2d_int(x, w, (1, 1), (1, 1), (1, 1))
+        ref = orc.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+        xd, wd, bd = dev(x.transpose(0, 2, 3, 1).astype(np.int8)), nat.pack_weight_krsc(dev(w.astype(np.float32))), dev(qb)
+        msg = "halo %d: N%d C%d H%d W%d K%d rs%d ob%d relu%d" % (it, N, C, H, W, K, rs, ob, relu)
+        try:
+            y = nat.conv2d_i8(xd, wd, bd, (1, 1), (1, 1), (1, 1), rs, ob).cpu().numpy()
+            assert np.array_equal(y, ref), "fp32 output"
+            refr = np.maximum(ref, np.float32(0)) if relu else ref
+            y2, q2 = nat.conv2d_i8_resident(xd, wd, bd, (1, 1), (1, 1), (1, 1), rs, ob, True, True, relu)
+            assert np.array_equal(y2.cpu().numpy(), refr), "resident fp32"
+            assert np.array_equal(q2.cpu().numpy().transpose(0, 3, 1, 2), orc.quantity(refr, ob).astype(np.int8)), "resident int8"
+            _, q3 = nat.conv2d_i8_resident(xd, wd, bd, (1, 1), (1, 1), (1, 1), rs, ob, False, True, relu)
+            assert np.array_equal(q3.cpu().numpy(), q2.cpu().numpy()), "int8-only output"
+        except AssertionError as ex:
+            failures.append("%s -> %s" % (msg, ex))
+            if verbose:
+                print("MISMATCH", msg, "->", ex)
+    return failures
+
+
 def run_stem(cases, seed, verbose=True):
     """fq_conv2d_i8_stem against the oracle chain (Quantity -> integer conv -> tail -> ReLU -> next Quantity) on random
     stem-shaped layers: 1-4 input channels, kernels up to 8x8, strides 1-3, ragged images, K <= 64."""
@@ -186,6 +222,9 @@ if __name__ == "__main__":
     n_stem = max(20, n // 4)
     stem_fails = run_stem(n_stem, seed + 1)
     print("stem_fuzz: %d cases, %d mismatches" % (n_stem, len(stem_fails)))
+    halo_fails = run_halo(max(20, n // 3), seed + 3)
+    print("halo_fuzz: %d cases, %d mismatches" % (max(20, n // 3), len(halo_fails)))
+    fails = fails + halo_fails
     n_stream = max(30, n // 2)
     stream_fails = run_stream(n_stream, seed + 2)
     print("stream_fuzz: %d cases, %d mismatches (FQ_STREAM_GROUPS=%s)" % (n_stream, len(stream_fails), os.environ.get("FQ_STREAM_GROUPS", "")))

@@ -9,7 +9,7 @@ from common.quantity import _native as nat
 C, H, K, R, st, pd = [int(v) for v in sys.argv[1:7]]
 mode = sys.argv[7] if len(sys.argv) > 7 else "i8"
 iters = int(sys.argv[8]) if len(sys.argv) > 8 else 20
-B = 128
+B = int(os.environ.get("FQ_CONV_ONE_BATCH", "128"))
 x = torch.randn(B, C, H, H, device="cuda") * 2
 w = torch.randint(-127, 128, (K, C, R, R), device="cuda").float()
 qb = torch.randint(-100, 100, (K,), device="cuda").float()

@@ -29,7 +29,7 @@ out = sys.argv[1]
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv2d_i8" not in r["Kernel_Name"]: continue
+        if "conv2d_i8" not in r["Kernel_Name"] and "conv3x3_i8" not in r["Kernel_Name"] and "conv1x1_i8" not in r["Kernel_Name"]: continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 for k in sorted(tot): print("%-28s %16.0f per launch (%d launches)" % (k, tot[k] / n[k], n[k]))
 PY

@@ -20,6 +20,9 @@
           2 batches of 128 with MAX_CALI_IMG_NUM = 1, WORKER_NUM 4 as shipped) -> tests/golden/ref_timing_r18.json
           (recorded in BASELINE.md; a measurement, not a parity fixture).
 
+  time101 wall time of the reference's Python path on BASELINE config 5's shape (ResNet-101 @3x512x512), ONE image
+          (MAX_CALI_IMG_NUM 0) -> tests/golden/ref_timing_r101_512.json (recorded in BASELINE.md; a measurement).
+
 Fixtures hold input recipes (seeds) and the reference's outputs only; no reference source enters the repo.
 matplotlib's hist() is replaced by a no-op while ReconTest is constructed (the reference's TestConv constructor draws
 four 2048-bin PNG histograms per layer; they are not part of any output compared here).
@@ -242,6 +245,28 @@ def time_r18(cq, tl):
     print(json.dumps(rec, indent=1))
 
 
+def time_r101_512(cq, tl):
+    import torch
+    sys.path.append(OURS)
+    from model.resnet.ResNet_fabu import ResNet101
+    torch.set_num_threads(8)
+    rec = {"config": "BASELINE configs[4] shape: fabu ResNet-101 @3x512x512, ONE synthetic image (MAX_CALI_IMG_NUM 0), WORKER_NUM 4, "
+                     "INTERVAL_NUM 2048, CPU; 139 histogram rows, 132.25 M cared elements",
+           "host": {"cpus": os.cpu_count(), "python": sys.version.split()[0], "numpy": np.__version__, "torch": torch.__version__}}
+    with _refenv.reference_workdir(input_shape="1,3,512,512", max_cali_img_num=0):
+        model = cq.merge_bn(cases.seed_model(ResNet101(input_size=512), gamma_scale=0.5).eval(), "cpu")
+        t0 = time.perf_counter()
+        q = tl.Quantity(model)
+        rec["graph_discovery_s"] = round(time.perf_counter() - t0, 3)
+        t0 = time.perf_counter()
+        q.activation_quantize(cases.calib_batches(1, (1, 3, 512, 512), seed=512))
+        rec["activation_quantize_s"] = round(time.perf_counter() - t0, 3)
+    rec["calibration_images_per_s"] = round(1.0 / rec["activation_quantize_s"], 5)
+    with open(os.path.join(HERE, "ref_timing_r101_512.json"), "w") as fh:
+        json.dump(rec, fh, indent=1, sort_keys=True)
+    print(json.dumps(rec, indent=1))
+
+
 def main():
     which = sys.argv[1:] or ["h6", "r50"]
     cq, tl = _refenv.import_reference()
@@ -253,6 +278,8 @@ def main():
         time_r18(cq, tl)
     if "r50" in which:
         capture_r50(cq, tl)
+    if "time101" in which:
+        time_r101_512(cq, tl)
     if "r50stats" in which:
         capture_r50_stats(cq, tl)
 

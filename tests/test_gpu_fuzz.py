@@ -17,6 +17,8 @@ def test_random_shapes_match_the_oracle():
     assert not failures, failures[:5]
     failures = mod.run_stem(40, 102, verbose=False)          # fq_conv2d_i8_stem on random stem-shaped layers
     assert not failures, failures[:5]
+    failures = mod.run_halo(50, 103, verbose=False)          # the resident-halo form of the 3x3 / stride 1 / padding 1 layers
+    assert not failures, failures[:5]
 
 
 @pytest.mark.parametrize("groups", ["", "1"])
