@@ -406,35 +406,43 @@ def cpu_baseline(model_cpu_ctor, hw, n_images_full, q, log):
         if type(m).__name__ in q._all_op_type:
             hooks.append(m.register_forward_hook(hook))
 
-    def measure(cores, sample_images):
+    def measure(cores, sample_images, chunk=8):
+        """The two-pass calibration of `sample_images` images on `cores` threads, `chunk` images per forward: pass 1 (forward +
+        abs-max of every row), intervals, pass 2 (forward again + 2048-bin histograms), then one KL sweep of all rows."""
         torch.set_num_threads(cores)
         pool = ThreadPoolExecutor(cores)
         x = torch.randn(sample_images, 3, hw, hw, generator=torch.Generator().manual_seed(1234))
         with torch.no_grad():
             model(x[:1])                                                 # untimed: oneDNN primitive creation
         t0 = time.perf_counter()
-        with torch.no_grad():
-            model(x)                                                     # pass 1 forward
-        arrs = {n: feats[n].numpy().ravel() for n in names}
-        maxs = dict(zip(names, pool.map(lambda n: orc.absmax(arrs[n]), names)))
+        maxs = {n: 0.0 for n in names}
+        for c0 in range(0, sample_images, chunk):                        # pass 1
+            with torch.no_grad():
+                model(x[c0:c0 + chunk])
+            arrs = {n: feats[n].numpy().ravel() for n in names}
+            for n, v in zip(names, pool.map(lambda n: orc.absmax(arrs[n]), names)):
+                maxs[n] = max(maxs[n], v)
         ivs = {n: orc.interval(maxs[n]) for n in names}
-        with torch.no_grad():
-            model(x)                                                     # pass 2 forward
-        arrs = {n: feats[n].numpy().ravel() for n in names}
-        hists = dict(zip(names, pool.map(lambda n: orc.hist2048(arrs[n], ivs[n]), names)))
+        hists = {}
+        for c0 in range(0, sample_images, chunk):                        # pass 2
+            with torch.no_grad():
+                model(x[c0:c0 + chunk])
+            arrs = {n: feats[n].numpy().ravel() for n in names}
+            for n, h in zip(names, pool.map(lambda n: orc.hist2048(arrs[n], ivs[n]), names)):
+                hists[n] = h if n not in hists else hists[n] + h
         t_img = (time.perf_counter() - t0) / sample_images
         t1 = time.perf_counter()
         list(pool.map(lambda n: orc.kl_threshold(orc.normalize(hists[n])), names))
         t_kl = time.perf_counter() - t1
         pool.shutdown()
-        log("cpu_baseline[%d threads]: %.3f s/image (2 forwards + absmax + hist), KL %.2f s for %d tensors"
-            % (cores, t_img, t_kl, len(names)))
+        log("cpu_baseline[%d threads]: %.3f s/image over %d images (2 forwards + absmax + hist), KL %.2f s for %d tensors"
+            % (cores, t_img, sample_images, t_kl, len(names)))
         return {"value": round(n_images_full / (n_images_full * t_img + t_kl), 3), "cores": cores,
                 "s_per_image": round(t_img, 4), "kl_sweep_s": round(t_kl, 3), "sample_images": sample_images}
 
     many = min(os.cpu_count() or 1, 32)          # beyond one socket's worth oneDNN only gets slower
     one = measure(1, 2)
-    full = measure(many, 8)
+    full = measure(many, 32)
     for h in hooks:
         h.remove()
     return {"value": full["value"], "unit": "images/s", "cores": full["cores"], "kind": "port",

@@ -341,16 +341,17 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
     }
 }
 
-// (4 waves per SIMD = four workgroups per CU: <= 128 registers with the 64 accumulators)
+// (4 waves per SIMD = four workgroups per CU: <= 128 registers with the 64 accumulators; the K-tail form -- Cin not a multiple
+//  of 16, no ResNet layer -- needs 130 and takes 3 waves instead of spilling)
 template <int WM, int WN, int kTailK>
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_kernel(const C1Args a) {
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(kTailK == 1 ? 3 : 4))) void conv1x1_f32_kernel(const C1Args a) {
     __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
     NoStat st;
     conv1x1_tiles<WM, WN, step_of<WM>(), kTailK>(a, st, smem);
 }
 
 template <int WM, int WN, int kTailK>
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(kTailK == 1 ? 3 : 4))) void conv1x1_f32_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
     __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
     MaxStat st;
     conv1x1_tiles<WM, WN, step_of<WM>(), kTailK>(a, st, smem);
@@ -359,7 +360,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void co
 
 // TestConv / TestLinear's forward in one kernel: convolution + bias, then QuanDequan on the accumulator's way out
 template <int WM, int WN, int kTailK>
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_qd_kernel(const C1Args a, const QdStat qd) {
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(kTailK == 1 ? 3 : 4))) void conv1x1_f32_qd_kernel(const C1Args a, const QdStat qd) {
     __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
     QdStat st = qd;
     conv1x1_tiles<WM, WN, step_of<WM>(), kTailK>(a, st, smem);

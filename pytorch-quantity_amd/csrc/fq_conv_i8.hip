@@ -442,6 +442,9 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
 // Each wave stages the activation rows it multiplies itself and a quarter of the weight tile; one
 // vmcnt(0) + workgroup barrier per K-step orders the DMA writes before the next step's reads.
 // What bounds it now is operand delivery: ~16 bytes per clock per CU at 128 ops per loaded byte.
+// (accumulators in VGPRs: this file is compiled with -mllvm -amdgpu-mfma-vgpr-form=1, csrc/Makefile -- left alone hipcc keeps
+//  them in AGPRs and every one crosses v_accvgpr_write at tile start and v_accvgpr_read on its way into the tail: 192 vector
+//  instructions per wave and tile)
 template <int TK, int kOut, int STAGES>
 __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
                                                                    const float* __restrict__ qbias, float* __restrict__ y,
@@ -835,6 +838,117 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_halo_kernel(const int8_
     }
 }
 
+// ---- 3 x 3, stride 1, padding 1, C == 64, K <= 64 (the first stage of a ResNet): weights stationary, persistent -------
+// 64 x 3 x 3 x 64 weights are 36 KB: they are fetched ONCE per workgroup and stay in LDS; the workgroup then walks over
+// 128-pixel tiles (tile t, t + grid, ...), each of which needs one slab of 130 + 2 W input pixels x 64 bytes -- requested
+// for the NEXT tile while this one is multiplied (two slab buffers).  A tile is 9 taps x 2 sub-steps x 2 MFMAs per wave with
+// no barrier and no global request in between; at 256 images these layers carry as many bytes as matrix cycles (12.8 us of
+// HBM, 11.8 us of MFMA each), so the general kernel's per-tile prologue, weight re-fetch and six barriers were most of it.
+struct C64Params {
+    int slab_rows;                         // 130 + 2 W rounded up to 16
+    int total_pixels;                      // N * H * W
+    int tiles;                             // 128-pixel tiles
+};
+
+template <int kOut>
+__global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                                    const float* __restrict__ qbias, float* __restrict__ y,
+                                                                    int8_t* __restrict__ q, const ConvParams p, const C64Params cp) {
+    constexpr int TK = 64, MT = 2, RB = 64;                   // output channels per tile, 32-row MFMA tiles, bytes per LDS row
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    // [weights: 9 taps x 64 rows x 64][bias f32: 64][bias i32: 64][zero row: 64][epilogue staging: 128 x 80][slabs: 2 x rows x 64]
+    int8_t* const sW = smem;
+    float* const sBias = reinterpret_cast<float*>(smem + 9 * TK * RB);
+    int* const sBiasI = reinterpret_cast<int*>(smem + 9 * TK * RB + TK * 4);
+    int8_t* const sZero = smem + 9 * TK * RB + TK * 8;
+    int8_t* const sO = sZero + RB;
+    int8_t* const sSlab = sO + kTP * (TK + 16);
+    const int slab_bytes = cp.slab_rows * RB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int PQ = p.P * p.Q;
+    if (tid < TK) {
+        const float b = tid < p.K ? qbias[tid] : 0.0f;
+        sBias[tid] = b;
+        sBiasI[tid] = (int)b;
+    }
+    if (tid < RB / 4) reinterpret_cast<int*>(sZero)[tid] = 0;
+
+    // 64-byte rows hold 4 chunks of 16 bytes; position c of row r holds chunk c ^ ((r >> 2) & 3) (conflict-free ds_read_b128
+    // of 32 consecutive rows, as for the 128-byte rows: the lane groups of a read cover all 16 slots of the bank row)
+    auto swz64 = [](int row) { return (row >> 2) & 3; };
+    const rsrc_words wr = make_rsrc_words(w, p.w_bytes);
+    for (int i = wave; i < 9 * (TK / 16); i += 4) {           // one DMA instruction: 16 weight rows x 64 bytes of one tap
+        const int tap = i / (TK / 16), blk = i - tap * (TK / 16), row = blk * 16 + (lane >> 2);
+        const unsigned vo = row < p.K ? (unsigned)row * (unsigned)(9 * RB) + (unsigned)(((lane & 3) ^ swz64(row)) * 16) : kOutOfRange;
+        dma_to_lds(wr, lds_offset(sW + (tap * TK + blk * 16) * RB), vo, tap * RB);
+    }
+    const rsrc_words xr = make_rsrc_words(x, p.x_bytes);
+    const int n_slab_dma = cp.slab_rows >> 4;
+    auto slab_dma = [&](int tile, int buf) {                  // 16 slab rows per instruction
+        const int m0 = tile * kTP;
+        const bool live = tile < cp.tiles;
+        for (int i = wave; i < n_slab_dma; i += 4) {
+            const int row = 16 * i + (lane >> 2);
+            const int g = m0 - p.W - 1 + row;
+            const unsigned vo = live && (unsigned)g < (unsigned)cp.total_pixels
+                                    ? (unsigned)g * (unsigned)RB + (unsigned)(((lane & 3) ^ swz64(row)) * 16) : kOutOfRange;
+            dma_to_lds(xr, lds_offset(sSlab + buf * slab_bytes + i * 1024), vo, 0);
+        }
+    };
+    int a_off[MT], swz_a[2];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) a_off[a] = (a * 32 + (lane & 31)) * RB;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) swz_a[ks] = ((ks * 2 + half) ^ swz64(lane & 31)) * 16;
+    const int p_row = wave * 32 + (lane & 31);
+    const unsigned zero_off = (unsigned)(sZero - smem), slab_off0 = (unsigned)(sSlab - smem);
+
+    int tile = blockIdx.x, buf = 0;
+    slab_dma(tile, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (; tile < cp.tiles; tile += gridDim.x) {
+        slab_dma(tile + gridDim.x, buf ^ 1);                  // the next tile's slab flies under this tile's arithmetic
+        const int m0 = tile * kTP;
+        const int m = m0 + p_row;
+        const bool m_ok = m < p.M;
+        const int mm = m_ok ? m : 0;
+        const int n_img = mm / PQ, pq = mm - n_img * PQ;
+        const int oh = pq / p.Q, ow = pq - oh * p.Q;
+        v16i acc[MT];
+#pragma unroll
+        for (int a = 0; a < MT; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][r] = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int r = tap / 3, s_ = tap - 3 * r;          // compile-time after unrolling
+            const int j = p_row + r * p.W + s_;
+            const bool ok = m_ok && (unsigned)(oh + r - 1) < (unsigned)p.H && (unsigned)(ow + s_ - 1) < (unsigned)p.W;
+            const unsigned rowb = ok ? slab_off0 + (unsigned)(buf * slab_bytes + j * RB) : zero_off;
+            const int sw = ok ? swz64(j) : 0;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const v4i fb = *reinterpret_cast<const v4i*>(smem + rowb + (unsigned)((((ks * 2 + half) ^ sw)) * 16));
+#pragma unroll
+                for (int a = 0; a < MT; ++a) {
+                    const v4i fa = *reinterpret_cast<const v4i*>(sW + tap * TK * RB + a_off[a] + swz_a[ks]);
+                    acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc[a], 0, 0, 0);
+                }
+            }
+        }
+        if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok);
+        else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next slab has landed (mine) ...
+        __syncthreads();                                      // ... and everybody's; everybody is done with this tile's slab and staging
+        buf ^= 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 // ---- fp32 NCHW -> int8 NHWC with Quantity fused (new_quantity_op.py:52-58) -----------------------
 // q8 (one element): fq_int_tail.h
 
@@ -1163,6 +1277,38 @@ static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, c
     return true;
 }
 
+static bool launch_conv_c64(hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y, int8_t* q,
+                            const ConvParams& p0) {
+    static const bool on = [] { const char* e = getenv("FQ_CONV_C64_HALO"); return !(e && e[0] == '0'); }();
+    if (!on || p0.R != 3 || p0.S != 3 || p0.stride_h != 1 || p0.stride_w != 1 || p0.pad_h != 1 || p0.pad_w != 1 || p0.dil_h != 1 ||
+        p0.dil_w != 1 || p0.C != 64 || p0.K > 64 || p0.res)
+        return false;
+    C64Params cp;
+    cp.slab_rows = (130 + 2 * p0.W + 15) & ~15;
+    cp.total_pixels = p0.N * p0.H * p0.W;
+    cp.tiles = (p0.M + kTP - 1) / kTP;
+    const size_t lds = (size_t)9 * 64 * 64 + 64 * 8 + 64 + (size_t)kTP * 80 + (size_t)2 * cp.slab_rows * 64;
+    if (lds > 80 * 1024 - 64) return false;               // two workgroups per CU
+    ConvParams p = p0;
+    p.xcd_kt = 0; p.tiles_m = cp.tiles;
+    static const int per_cu = [] { const char* e = getenv("FQ_C64_WG_PER_CU"); return e ? atoi(e) : 2; }();
+    unsigned grid = (unsigned)(kCUs * per_cu);
+    if ((long)grid > cp.tiles) grid = (unsigned)cp.tiles;
+#define FQ_C64(OUT)                                                                                                      \
+    do {                                                                                                                 \
+        auto k = conv3x3_i8_c64_kernel<OUT>;                                                                             \
+        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                       80 * 1024);                                                       \
+        if (ok != (int)hipSuccess) return false;                                                                         \
+        hipLaunchKernelGGL(k, dim3(grid), dim3(kConvBlock), lds, st, x, w, qbias, y, q, p, cp);                          \
+    } while (0)
+    if (y && q) FQ_C64(kOutF32 | kOutI8);
+    else if (q) FQ_C64(kOutI8);
+    else FQ_C64(kOutF32);
+#undef FQ_C64
+    return true;
+}
+
 struct FusedAdd {                        // residual operand and outputs of a fused NewAdd (res == nullptr: none)
     const void* res = nullptr;
     int res_bytes = 0;
@@ -1210,6 +1356,11 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     p.x_bytes = (unsigned)((long)N * H * W * C);
     p.w_bytes = (unsigned)((long)K * R * S * C);
     hipStream_t st = as_stream(stream);
+    // the 64 -> 64 3x3 layers: stationary weights, persistent workgroups
+    if (launch_conv_c64(st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p)) {
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    }
     // 1x1 layers with an int8 output: the streaming kernel with stationary weights (fq_conv1x1_i8.hip) where it applies
     if (launch_conv1x1_stream(st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p)) {
         FQ_LAUNCH_CHECK();
