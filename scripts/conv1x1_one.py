@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU: fq_conv1x1_f32 on one layer shape, for rocprofv3.  usage: conv1x1_one.py Cin Cout H stride batch [max|hist|none] [reps]"""
+"""GPU: fq_conv1x1_f32 (FQ_ONE_KIND=kxk: fq_conv_kxk_f32 3x3 padding 1; =stem: fq_conv_stem_f32 7x7 stride 2 on 3 channels) on
+one layer shape, for rocprofv3.  usage: conv1x1_one.py Cin Cout H stride batch [max|hist|none] [reps]"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -8,20 +9,35 @@ from common.quantity import _native
 cin, cout, h, s, B = (int(v) for v in sys.argv[1:6])
 mode = sys.argv[6] if len(sys.argv) > 6 else "max"
 reps = int(sys.argv[7]) if len(sys.argv) > 7 else 5
+kind = os.environ.get("FQ_ONE_KIND", "c1")
 x = torch.randn(B, cin, h, h, device="cuda")
 wt = (torch.randn(cin, cout, device="cuda") * cin ** -0.5).contiguous()
+if kind == "kxk":
+    wt = _native.pack_kxk_weight(torch.randn(cout, cin, 3, 3, device="cuda") * (9 * cin) ** -0.5)
+elif kind == "stem":
+    wt = _native.pack_stem_weight(torch.randn(cout, 3, 7, 7, device="cuda") * 147 ** -0.5)
 bias = torch.randn(cout, device="cuda")
-ho = (h - 1) // s + 1
+ho = (h - 1) // s + 1 if kind == "c1" else ((h + 2 - 3) // s + 1 if kind == "kxk" else (h + 6 - 7) // 2 + 1)
+
+
+def conv(**kw):
+    if kind == "kxk":
+        return _native.conv_kxk_f32(x, wt, bias, (3, 3), s, 1, **kw)
+    if kind == "stem":
+        return _native.conv_stem_f32(x, wt, bias, cout, (7, 7), 2, 3, **kw)
+    return _native.conv1x1_f32(x, wt, bias, s, **kw)
+
+
 y = torch.empty(B, cout, ho, ho, device="cuda")
 mx = torch.zeros(1, device="cuda")
 iv = torch.full((1,), 8.0 / 2048, device="cuda")
 hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
 for _ in range(reps):
     if mode == "max":
-        _native.conv1x1_f32(x, wt, bias, s, max_dev=mx, row=0, out=y)
+        conv(max_dev=mx, row=0, out=y)
     elif mode == "hist":
-        _native.conv1x1_f32(x, wt, bias, s, interval_dev=iv, hist_dev=hist, row=0, out=y)
+        conv(interval_dev=iv, hist_dev=hist, row=0, out=y)
     else:
-        _native.conv1x1_f32(x, wt, bias, s, out=y)
+        conv(out=y)
 torch.cuda.synchronize()
 print("done", float(mx[0]))
