@@ -244,6 +244,17 @@ int fq_conv_kxk_qd_f32(const float* x, const float* wt, const float* bias, float
 int fq_conv_stem_qd_f32(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int H, int W,
                         int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream);
 
+/* The last 1x1 convolution of a residual block together with the `Eltwise` that consumes it and the ReLU behind that
+ * (fabu_layer.py:5-11 called from the model the reference runs at pytorch_quantizer.py:288-296), calibration pass 1, in ONE
+ * kernel:  v = conv1x1(x) + bias  (abs-max folded into *max_y; stored to y unless y is NULL),  s = v + res  (abs-max folded
+ * into *max_sum; stored to sum unless sum is NULL),  relu_out = max(s, 0)  (NaN stays NaN).  res, y, sum, relu_out: fp32
+ * [N][Cout][Hout][Wout].  Bit for bit what fq_conv1x1_f32 (max form) followed by fq_add_absmax_f32 leave; it exists because
+ * those two move 20 bytes per element and this moves 8 when neither v nor s is kept for pass 2.
+ * FQ_ERR_UNSUPPORTED unless Cin % 16 == 0 and Cout % 128 == 0 (callers keep the two kernels there). */
+int fq_conv1x1_add_f32(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
+                       float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y, float* max_sum,
+                       fq_stream_t stream);
+
 /* The pooling layers of the float calibration forward (nn.MaxPool2d / a global nn.AvgPool2d inside the model the
  * reference runs at pytorch_quantizer.py:288-296), bit for bit what torch computes:
  * fq_maxpool2d_f32: y[plane][oy][ox] = max over the window clipped to the image (NaN propagates); x fp32 [planes][H][W],

@@ -46,6 +46,9 @@ struct C1Args {
     const float* bias;        // [Cout] or null
     float* y;
     float* relu;              // or null
+    const float* res;         // the add form (fq_conv1x1_add_f32): the other operand of the Eltwise that consumes y, y's shape
+    float* sum;               //   where y + res goes, or null (nobody reads it: only its ReLU is handed on)
+    int store_y;              //   0: y itself is not written either (only its statistic is wanted)
     unsigned Cin, Cout, HWin, HWout, Win, Wout, stride;
     int Hin, R, S, pad;       // (R x S taps, zero padding: the K x K form; 1, 1, 0 for the 1x1 form)
     unsigned x_bytes, w_bytes, y_bytes;
@@ -66,6 +69,13 @@ struct C1Args {
 struct NoStat {
     __device__ __forceinline__ void add(float) {}
 };
+
+// the add form's pair of statistics: the convolution output's and the sum's running abs-max
+struct AddStat {
+    MaxStat c, s;
+};
+template <typename T> struct is_add_stat { static constexpr bool value = false; };
+template <> struct is_add_stat<AddStat> { static constexpr bool value = true; };
 
 template <int I>
 struct Stage {
@@ -120,6 +130,52 @@ __device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1A
                                                                   row4, aux);
                         stat.add(val);
                     }
+                }
+            }
+        }
+    }
+}
+
+// Epilogue of the add form (conv3 + Eltwise + ReLU of a bottleneck in one kernel, fabu_layer.py:5-11 behind nn.Conv2d): per value
+// v = acc + bias (rounded: "the convolution's output", whose abs-max goes to the first statistic and which is stored only when
+// somebody keeps it), s = v + res (the Eltwise's output: second statistic, stored only when kept), max(s, 0) to a.relu.
+// Separately the two kernels move 20 bytes per element (4 written, 8 read, 8 written); this moves 8 when nothing is kept.
+template <int WM, int WN, bool kStoreY, bool kStoreSum, bool kStream>
+__device__ __forceinline__ void c1_epilogue_add(const f16v (&acc)[WM][WN], const C1Args& a, AddStat& stat, const float* s_bias,
+                                                unsigned jbase, unsigned mbase, unsigned m0, unsigned n0, unsigned r, unsigned h) {
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(kStoreY ? a.y : a.relu, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(kStoreSum ? a.sum : a.relu, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(a.relu, 0, a.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ers = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res), 0, a.y_bytes, 0x00020000);
+    constexpr int aux = kStream ? 2 : 0;                      // nt
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni) {
+        const unsigned jn = jbase + n0 + 32u * ni + r;
+        if (jn < a.cols) {
+            const unsigned n = jn / a.HWout, p = jn - n * a.HWout;
+            const unsigned col4 = (n * a.Cout * a.HWout + p + (mbase + m0 + 4u * h) * a.HWout) * 4u;   // < 2^32 (host check)
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi) {
+                float rv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned dm = 32u * mi + (e & 3) + 8u * (e >> 2);
+                    rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ers, (int)col4, (int)(dm * a.HWout * 4u), aux));
+                }
+                f4v b4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const f4v*>(s_bias + m0 + 32u * mi + 8u * q + 4u * h);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const unsigned dm = 32u * mi + (e & 3) + 8u * (e >> 2);
+                    const int row4 = (int)(dm * a.HWout * 4u);                         // uniform
+                    const float val = acc[mi][ni][e] + b4[e >> 2][e & 3];
+                    stat.c.add(val);
+                    if (kStoreY) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yrs, (int)col4, row4, aux);
+                    const float sm = val + rv[e];
+                    stat.s.add(sm);
+                    if (kStoreSum) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sm), srs, (int)col4, row4, aux);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(sm)), rrs, (int)col4, row4, aux);
                 }
             }
         }
@@ -328,6 +384,16 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
             } else
 #endif
 #define FQ_C1_EPI(R, S, F) c1_epilogue<WM, WN, R, S, F>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
+#define FQ_C1_ADD(Y, S, N) c1_epilogue_add<WM, WN, Y, S, N>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
+            if constexpr (is_add_stat<Stat>::value) {         // (whole row tiles only: host check)
+                if (a.stream_stores) {
+                    if (a.store_y) { if (a.sum) FQ_C1_ADD(true, true, true); else FQ_C1_ADD(true, false, true); }
+                    else { if (a.sum) FQ_C1_ADD(false, true, true); else FQ_C1_ADD(false, false, true); }
+                } else {
+                    if (a.store_y) { if (a.sum) FQ_C1_ADD(true, true, false); else FQ_C1_ADD(true, false, false); }
+                    else { if (a.sum) FQ_C1_ADD(false, true, false); else FQ_C1_ADD(false, false, false); }
+                }
+            } else
             if (a.relu) {
                 if (a.stream_stores) { if (full_m) FQ_C1_EPI(true, true, true); else FQ_C1_EPI(true, true, false); }
                 else { if (full_m) FQ_C1_EPI(true, false, true); else FQ_C1_EPI(true, false, false); }
@@ -336,6 +402,7 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
                 else { if (full_m) FQ_C1_EPI(false, false, true); else FQ_C1_EPI(false, false, false); }
             }
 #undef FQ_C1_EPI
+#undef FQ_C1_ADD
         }
         __syncthreads();                                      // the next tile overwrites s_bias and stage 0
     }
@@ -356,6 +423,18 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(kTailK == 1 
     MaxStat st;
     conv1x1_tiles<WM, WN, step_of<WM>(), kTailK>(a, st, smem);
     publish_max<kT>(st.m, max_bits);
+}
+
+// conv3 + Eltwise + ReLU of a bottleneck in one kernel (pass 1: both tensors' abs-max)
+template <int WM, int WN>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_add_absmax_kernel(
+    const C1Args a, unsigned int* __restrict__ max_y_bits, unsigned int* __restrict__ max_sum_bits) {
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
+    AddStat st;
+    conv1x1_tiles<WM, WN, step_of<WM>(), 0>(a, st, smem);
+    publish_max<kT>(st.c.m, max_y_bits);
+    __syncthreads();                                          // (publish_max's LDS slots are about to be reused)
+    publish_max<kT>(st.s.m, max_sum_bits);
 }
 
 // TestConv / TestLinear's forward in one kernel: convolution + bias, then QuanDequan on the accumulator's way out
@@ -446,7 +525,7 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || w_elems >= (1ULL << 30) || out_elems >= (1ULL << 30))
         return FQ_ERR_UNSUPPORTED;
     C1Args a;
-    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out;
+    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out; a.res = nullptr; a.sum = nullptr; a.store_y = 1;
     a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.HWin = (unsigned)(Hin * Win); a.HWout = (unsigned)(Hout * Wout);
     a.Win = (unsigned)Win; a.Wout = (unsigned)Wout; a.stride = (unsigned)stride;
     a.Hin = Hin; a.R = R; a.S = S; a.pad = pad;
@@ -495,6 +574,52 @@ extern "C" int fq_conv_kxk_f32(const float* x, const float* wt, const float* bia
                                int Hin, int Win, int Cout, int R, int S, int stride, int pad, float* max_inout,
                                const float* interval, int64_t* hist_row, fq_stream_t stream) {
     return conv_f32_launch(x, wt, bias, y, relu_out, N, Cin, Hin, Win, Cout, R, S, stride, pad, max_inout, interval, hist_row, stream);
+}
+
+// The last 1x1 convolution of a residual block together with the Eltwise (fabu_layer.py:5-11) and the ReLU behind it:
+// y = conv(x) + bias (abs-max -> *max_y; written to y unless y is null), sum = y + res (abs-max -> *max_sum; written unless
+// sum is null), relu_out = max(sum, 0).  Bit for bit what fq_conv1x1_f32 followed by fq_add_absmax_f32 leave.
+extern "C" int fq_conv1x1_add_f32(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
+                                  float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y,
+                                  float* max_sum, fq_stream_t stream) {
+    if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1) return FQ_ERR_INVALID_ARG;
+    if (N == 0) return FQ_OK;
+    if (!x || !wt || !res || !relu_out || !max_y || !max_sum) return FQ_ERR_INVALID_ARG;
+    if ((Cin % kBK) != 0 || (Cout % 128) != 0 || (reinterpret_cast<uintptr_t>(wt) & 15u)) return FQ_ERR_UNSUPPORTED;
+    const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
+    const size_t cols = (size_t)N * Hout * Wout;
+    const size_t in_elems = (size_t)N * Cin * Hin * Win, out_elems = cols * Cout, w_elems = (size_t)Cin * Cout;
+    if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || w_elems >= (1ULL << 30) || out_elems >= (1ULL << 30))
+        return FQ_ERR_UNSUPPORTED;
+    C1Args a;
+    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out; a.res = res; a.sum = sum; a.store_y = y != nullptr;
+    a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.HWin = (unsigned)(Hin * Win); a.HWout = (unsigned)(Hout * Wout);
+    a.Win = (unsigned)Win; a.Wout = (unsigned)Wout; a.stride = (unsigned)stride;
+    a.Hin = Hin; a.R = 1; a.S = 1; a.pad = 0;
+    a.cols = (unsigned)cols;
+    a.x_bytes = (unsigned)(in_elems * 4); a.w_bytes = (unsigned)(w_elems * 4); a.y_bytes = (unsigned)(out_elems * 4);
+    a.stream_stores = out_elems * (size_t)(8 + (y ? 4 : 0) + (sum ? 4 : 0)) > ((size_t)256 << 20);      // beyond the Infinity Cache
+    { const char* e = getenv("FQ_CONV_ADD_STREAM"); if (e && e[0]) a.stream_stores = atoi(e); }
+#ifdef FQ_C1_ABLATE
+    a.ablate = 0;
+#endif
+    static const int forced = env_int("FQ_CONV1X1_SHAPE", 0);
+    const size_t tiles22 = ((cols + 127) / 128) * (size_t)(Cout / 128);
+    const bool narrow = forced ? forced == 12 : tiles22 <= (size_t)kCUs * 4;
+    hipStream_t st = as_stream(stream);
+    if (narrow) {
+        a.tiles_m = (unsigned)Cout / 64u;
+        a.tiles = (unsigned)((cols + 127) / 128) * a.tiles_m;
+        hipLaunchKernelGGL((conv1x1_f32_add_absmax_kernel<1, 2>), dim3(a.tiles), dim3(kT), 0, st, a,
+                           reinterpret_cast<unsigned int*>(max_y), reinterpret_cast<unsigned int*>(max_sum));
+    } else {
+        a.tiles_m = (unsigned)Cout / 128u;
+        a.tiles = (unsigned)((cols + 127) / 128) * a.tiles_m;
+        hipLaunchKernelGGL((conv1x1_f32_add_absmax_kernel<2, 2>), dim3(a.tiles), dim3(kT), 0, st, a,
+                           reinterpret_cast<unsigned int*>(max_y), reinterpret_cast<unsigned int*>(max_sum));
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
 }
 
 // TestConv.forward (new_quantity_op.py:283-292) / TestLinear.forward (:248-256 on the classifier seen as a 1x1 layer) in one

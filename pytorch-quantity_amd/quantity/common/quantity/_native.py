@@ -106,6 +106,8 @@ def lib():
     L.fq_conv_stem_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [vp, vp, vp, vp]
     L.fq_read_npy_batch_f32.restype = ci
     L.fq_read_npy_batch_f32.argtypes = [vp, ci, ctypes.c_char_p, ctypes.c_size_t, vp, ctypes.c_size_t, ci, vp]
+    L.fq_conv1x1_add_f32.restype = ci
+    L.fq_conv1x1_add_f32.argtypes = [vp] * 7 + [ci] * 6 + [vp, vp, vp]
     L.fq_conv1x1_qd_f32.restype = ci
     L.fq_conv1x1_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 8 + [vp]
     L.fq_conv_kxk_qd_f32.restype = ci
@@ -385,6 +387,31 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
     _check(lib().fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
                                 _relu_ptr(relu_out, y), N, Cin, H, W, Cout, s, mp, ivp, hp, _stream(x)), "fq_conv1x1_f32")
     return y
+
+
+def conv1x1_add_f32(x, wt, bias, stride, res, max_dev, row_y, row_sum, relu_out, out=None, sum_out=None):
+    """fq_conv1x1_add_f32: the 1x1 convolution of conv1x1_f32, the Eltwise that consumes it and the ReLU behind that in one
+    kernel (pass 1).  v = conv(x) + bias: abs-max folded into max_dev[row_y], written to `out` when given; s = v + res: abs-max
+    into max_dev[row_sum], written to `sum_out` when given; relu_out receives max(s, 0).  Returns relu_out."""
+    for t in (x, wt, bias, res, max_dev, relu_out):
+        _need_cuda(t, torch.float32, "fq_conv1x1_add_f32")
+    assert x.dim() == 4 and x.is_contiguous() and wt.dim() == 2 and wt.is_contiguous() and wt.shape[0] == x.shape[1]
+    N, Cin, H, W = (int(v) for v in x.shape)
+    Cout, s = int(wt.shape[1]), int(stride)
+    shape = (N, Cout, (H - 1) // s + 1, (W - 1) // s + 1)
+    assert bias.is_contiguous() and bias.numel() == Cout and max_dev.is_contiguous()
+    assert 0 <= row_y < max_dev.numel() and 0 <= row_sum < max_dev.numel() and row_y != row_sum
+    for t in (res, relu_out, out, sum_out):
+        assert t is None or (tuple(t.shape) == shape and t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda)
+    _check(lib().fq_conv1x1_add_f32(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(),
+                                    None if out is None else out.data_ptr(), None if sum_out is None else sum_out.data_ptr(),
+                                    relu_out.data_ptr(), N, Cin, H, W, Cout, s, max_dev.data_ptr() + 4 * int(row_y),
+                                    max_dev.data_ptr() + 4 * int(row_sum), _stream(x)), "fq_conv1x1_add_f32")
+    return relu_out
+
+
+def conv1x1_add_f32_supported(cin, cout):
+    return cin % 16 == 0 and cout % 128 == 0
 
 
 def pack_kxk_weight(weight):

@@ -141,6 +141,113 @@ class _EagerStats(object):
         return any(t._version != v for (_k, t, v) in self.seen)
 
 
+class _DeferralProbe(object):
+    """The proof that a convolution's output may stay un-materialised until the Eltwise that adds it (Quantity.fuse_conv_add).
+
+    The reference's model code is arbitrary Python: `y = self.conv3(x)` may be read by anything before `self.Eltwise(y, r)`.
+    Two probe forwards on the same random input settle it for the model at hand.  The first (mode "learn", the in-place
+    probe that runs anyway) records which own 1x1 convolution's output OBJECT arrives at which Eltwise, and which nn.ReLU
+    consumes that Eltwise's output.  The second (mode "poison") hands the model a NaN-filled tensor in place of each such
+    convolution output and of each such sum, while the real values travel privately from the convolution to its Eltwise to
+    its ReLU.  If every hooked tensor outside those pairs and the model's output come out bit for bit as in the first forward,
+    nothing but the designated Eltwise read the convolution's output and nothing but the designated ReLU read the sum: NaN
+    poisons everything it touches.  (Control flow that depends on the data is not covered by a probe; the production path
+    therefore also refuses to end a forward with a convolution still waiting.)"""
+
+    def __init__(self):
+        self.mode = "learn"
+        self.conv_out = {}          # learn: id(output) -> (output, conv module)
+        self.pairs = {}             # learn: Eltwise module -> the conv module whose output it received
+        self.keys = {}              # module -> its hook key of this forward
+        self.candidates = {}        # conv module -> (Eltwise module, nn.ReLU module)
+        self.private = {}           # poison: id(poisoned tensor) -> (poisoned tensor, real tensor, the one module that may read it)
+
+    def conv_done(self, m, y):
+        if self.mode == "learn":
+            self.conv_out[id(y)] = (y, m)
+            return y
+        pair = self.candidates.get(m)
+        if pair is None:
+            return y
+        bad = torch.full_like(y, float("nan"))
+        self.private[id(bad)] = (bad, y, pair[0])
+        return bad
+
+    def real(self, t, reader):
+        e = self.private.get(id(t)) if torch.is_tensor(t) else None
+        return e[1] if e is not None and e[0] is t and e[2] is reader else None
+
+    def eltwise(self, m, x, y):
+        """The Eltwise's result for this probe forward, or None (its own forward runs)."""
+        if self.mode == "learn":
+            for t in (x, y):
+                e = self.conv_out.get(id(t)) if torch.is_tensor(t) else None
+                if e is not None and e[0] is t:
+                    self.pairs.setdefault(m, e[1])
+                    break
+            return None
+        rx, ry = self.real(x, m), self.real(y, m)
+        if rx is None and ry is None:
+            return None
+        conv = self.pairs[m]
+        s = torch.add(x if rx is None else rx, y if ry is None else ry)
+        bad = torch.full_like(s, float("nan"))
+        self.private[id(bad)] = (bad, s, self.candidates[conv][1])
+        return bad
+
+    def relu(self, m, x):
+        r = self.real(x, m) if self.mode == "poison" else None
+        return None if r is None else torch.nn.functional.relu(r)
+
+    def poisoned_keys(self):
+        mods = set(self.candidates) | set(e for e, _r in self.candidates.values())
+        return set(k for mod, k in self.keys.items() if mod in mods)
+
+
+class _HookState(object):
+    """What the forward hooks, the patched forwards (_patch_fused_convs) and the calibration loop tell each other during
+    ONE calibration (created by regist_hook_outfeature, dropped with the hooks).  Three groups:
+
+    the pass          which statistic the producers fold in (`fuse_stat`), into which engine (`fuse_collector`; None: no
+                      producer fusion), whether it was switched off by a failed check (`fuse_off`), which modules passed
+                      theirs (`fuse_verified`; `fuse_warm`: library convolutions that have had their first, unfused call),
+                      and what the cache wants kept (`keep_feats`, `keep_names`);
+    the forward       where it ends early (`stop_after`), its time stamps for the cache plan (`events`), the statistics
+                      gatherer of this forward (`eager`), the plain-kernel mode of the per-channel path (`own_plain`);
+    module to module  work a patched forward left for the hook of the very same call (`fuse_bias`), the last hooked output
+                      (`last_out`) and which ReLU consumes which producer (`relu_after`), a ReLU result a producer has already
+                      written (`relu_ready`), a convolution waiting for the Eltwise that consumes it (`deferred`, `defer_ok`).
+    The rest are counters for Quantity.timings."""
+    __slots__ = ("stop_after", "events", "eager", "fuse_bias", "fuse_collector", "fuse_off", "fuse_verified", "fuse_warm",
+                 "relu_after", "relu_ready", "last_out", "fused_relus", "fuse_stat", "hist_fused", "keep_feats", "keep_names",
+                 "own_plain", "own_conv1x1", "deferred", "defer_ok", "deferred_adds", "poison")
+
+    def __init__(self):
+        self.stop_after = None          # ordinal of the last module pass 2 needs (the hook raises _StopForward there)
+        self.events = None              # [(ordinal, event)] while the first forward of pass 1 is being timed
+        self.eager = None               # _EagerStats of the running forward
+        self.fuse_bias = None           # (module, operands): the hook of this very call finishes the module's work
+        self.fuse_collector = None
+        self.fuse_off = False
+        self.fuse_verified = set()
+        self.fuse_warm = set()
+        self.relu_after = {}            # producer module -> the out-of-place nn.ReLU that consumed its output last time
+        self.relu_ready = None          # (producer's output, its ReLU, the nn.ReLU module, version): served by the patched ReLU
+        self.last_out = None
+        self.fused_relus = set()
+        self.fuse_stat = "max"          # "max": pass 1, "hist": pass 2
+        self.hist_fused = 0
+        self.keep_feats = True          # False: nothing will be cached, producers' tensors need not outlive their hook
+        self.keep_names = None          # names of the tensors pass 2 wants kept from THIS forward (None: all of them)
+        self.own_plain = False          # per-channel calibration: convolutions on the own kernels without statistics
+        self.own_conv1x1 = 0
+        self.deferred = {}              # id(output) -> (output, conv, x, key, row, version): convolutions whose kernel has not
+        #                                 run yet -- each runs inside the launch of the Eltwise that consumes it
+        self.defer_ok = {}              # conv module -> its Eltwise, proven by the poison probe (_prove_deferral)
+        self.deferred_adds = 0
+        self.poison = None              # the _DeferralProbe of a running probe forward
+
+
 class Quantity(object):
 
     # the statistics engine; tests substitute oracle-backed doubles to exercise the host logic on CPU
@@ -180,6 +287,14 @@ class Quantity(object):
     # nn.MaxPool2d and a global nn.AvgPool2d of the model run on fq_maxpool2d_f32 / fq_avgpool_global_f32 during a GPU
     # calibration: the same bits as torch (checked once per module, torch.equal), at 2-7x torch's rate.
     own_pools = os.environ.get("FQ_OWN_POOLS", "1") != "0"
+    # Pass 1: the last 1x1 convolution of a residual block, the Eltwise that adds its output to the shortcut and the ReLU behind
+    # it run as ONE kernel (fq_conv1x1_add_f32) -- the convolution's output and the sum are written to HBM only if pass 2's
+    # cache wants them: 8 bytes per element instead of 20.  A convolution is deferred to its Eltwise only after the poison
+    # probe (_DeferralProbe) has shown that nothing else reads its output.
+    fuse_conv_add = os.environ.get("FQ_FUSE_CONV_ADD", "1") != "0"
+    # True: every hooked tensor is written to HBM even when nothing of this calibration will read it again (for observers that
+    # tape the hooked tensors: the oracle-replay tests)
+    materialize_all = False
     own_conv1x1 = _float_conv.enabled()                              # FQ_OWN_CONV1X1=0: A/B against the library convolutions
 
     def __init__(self, model):
@@ -649,26 +764,29 @@ class Quantity(object):
                 if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or m.weight.dtype != torch.float32
                         or torch.is_grad_enabled()):
                     return torch.nn.Conv2d.forward(m, x)
-                if ctl.get("own_plain"):                    # per-channel calibration: the convolution only, statistics by its hooks
+                if ctl.own_plain:                    # per-channel calibration: the convolution only, statistics by its hooks
                     own = _float_conv.kind(m, x) if self.own_conv1x1 else None
                     if own is None:
                         return torch.nn.Conv2d.forward(m, x)
-                    return _float_conv.plain(m, own, x, check=ctl["own_plain"] != "unchecked")
-                if ctl["fuse_collector"] is None or ctl["fuse_off"]:
+                    y = _float_conv.plain(m, own, x, check=ctl.own_plain != "unchecked")
+                    if ctl.poison is not None and own == "c1":
+                        y = ctl.poison.conv_done(m, y)
+                    return y
+                if ctl.fuse_collector is None or ctl.fuse_off:
                     return torch.nn.Conv2d.forward(m, x)
-                if ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"]:
+                if ctl.fuse_stat == "hist" and m not in ctl.fuse_verified:
                     return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
                 own = _float_conv.kind(m, x) if self.own_conv1x1 else None
-                if own is None and m not in ctl["fuse_warm"] and not _flag(m, _FUSION_VERIFIED):
-                    ctl["fuse_warm"].add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
+                if own is None and m not in ctl.fuse_warm and not _flag(m, _FUSION_VERIFIED):
+                    ctl.fuse_warm.add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
                     return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
                 if own is not None:
-                    ctl["fuse_bias"] = (m, (own, x))        # the hook of this very call runs the whole convolution
+                    ctl.fuse_bias = (m, (own, x))        # the hook of this very call runs the whole convolution
                     s, p, k = m.stride[0], m.padding[0], m.kernel_size
                     return torch.empty((x.shape[0], m.out_channels, (x.shape[2] + 2 * p - k[0]) // s + 1,
                                         (x.shape[3] + 2 * p - k[1]) // s + 1), dtype=torch.float32, device=x.device)
                 y = m._conv_forward(x, m.weight, None)
-                ctl["fuse_bias"] = (m, x)                   # the hook of this very call adds the bias
+                ctl.fuse_bias = (m, x)                   # the hook of this very call adds the bias
                 return y
             m.forward = forward
             patched.append(m)
@@ -679,12 +797,21 @@ class Quantity(object):
                     continue
 
                 def forward(x, y, m=m):
-                    if (ctl["fuse_collector"] is None or ctl["fuse_off"] or torch.is_grad_enabled() or not torch.is_tensor(x)
+                    if ctl.poison is not None:
+                        z = ctl.poison.eltwise(m, x, y)
+                        if z is not None:
+                            return z
+                    if (ctl.fuse_collector is None or ctl.fuse_off or torch.is_grad_enabled() or not torch.is_tensor(x)
                             or not torch.is_tensor(y) or not x.is_cuda or x.dtype != torch.float32 or y.dtype != torch.float32
                             or x.shape != y.shape or not x.is_contiguous() or not y.is_contiguous() or y.device != x.device
-                            or (ctl["fuse_stat"] == "hist" and m not in ctl["fuse_verified"])):
+                            or (ctl.fuse_stat == "hist" and m not in ctl.fuse_verified)):
+                        for t in (x, y):                        # (an operand whose convolution was left for this call)
+                            d = ctl.deferred.get(id(t)) if ctl.deferred else None
+                            if d is not None and d[0] is t:
+                                del ctl.deferred[id(t)]
+                                self._run_deferred(d)
                         return Eltwise.forward(m, x, y)
-                    ctl["fuse_bias"] = (m, (x, y))          # the hook of this very call computes the sum (+ its abs-max)
+                    ctl.fuse_bias = (m, (x, y))          # the hook of this very call computes the sum (+ its abs-max)
                     return torch.empty_like(x)
                 m.forward = forward
                 patched.append(m)
@@ -693,7 +820,7 @@ class Quantity(object):
                 return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
 
             def pool_active(x):
-                return ((ctl.get("own_plain") or (ctl["fuse_collector"] is not None and not ctl["fuse_off"])) and torch.is_tensor(x)
+                return ((ctl.own_plain or (ctl.fuse_collector is not None and not ctl.fuse_off)) and torch.is_tensor(x)
                         and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
                         and not torch.is_grad_enabled() and x.numel() < 2 ** 32 - 1)
 
@@ -733,11 +860,15 @@ class Quantity(object):
                 continue
 
             def forward(x, m=m):
-                last, ready = ctl["last_out"], ctl["relu_ready"]
+                last, ready = ctl.last_out, ctl.relu_ready
                 if last is not None and last[1] is x:
-                    ctl["relu_after"][last[0]] = m           # (re)learned on every call: who feeds this ReLU
+                    ctl.relu_after[last[0]] = m           # (re)learned on every call: who feeds this ReLU
+                if ctl.poison is not None:
+                    z = ctl.poison.relu(m, x)
+                    if z is not None:
+                        return z
                 if ready is not None and ready[0] is x and ready[2] is m and ready[3] == x._version:
-                    ctl["relu_ready"] = None                 # (same tensor object, not written to since)
+                    ctl.relu_ready = None                 # (same tensor object, not written to since)
                     return ready[1]
                 return torch.nn.functional.relu(x)
             m.forward = forward
@@ -748,32 +879,91 @@ class Quantity(object):
         """Forward-hook half of a convolution that runs on fq_conv1x1_f32 / fq_conv_stem_f32: `output` is the empty tensor
         the patched forward returned.  Returns True when the statistic of `output` is done."""
         ctl = self._hook_ctl
-        coll = ctl["fuse_collector"]
+        coll = ctl.fuse_collector
         run = _float_conv.runner(m, kind, x)
         if module is not m or coll is None or key is None:     # not a cared tensor: the convolution only
             run(out=output)
             return False
         row = coll.row_of(key)
-        if ctl["fuse_stat"] == "hist":                         # pass 2 (verified in pass 1)
+        if ctl.fuse_stat == "hist":                         # pass 2 (verified in pass 1)
             self._run_with_relu(m, output, lambda r: run(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row,
                                                          relu_out=r, out=output))
-            ctl["hist_fused"] += 1
+            ctl.hist_fused += 1
             return True
         ref = _float_conv.verified(m, run, x)                  # first use: against torch, once per process
         if ref is not None:
             output.copy_(ref)                                  # this module keeps the library convolution from now on
             return False
-        ctl["fuse_verified"].add(m)
+        ctl.fuse_verified.add(m)
+        if kind == "c1" and self.fuse_conv_add and ctl.defer_ok.get(m) is not None and ctl.eager is not None:
+            # its kernel runs inside the launch of the Eltwise that adds this tensor (_finish_deferred); until then `output`
+            # is an allocation nobody reads -- which the poison probe has shown for this model
+            ctl.deferred[id(output)] = (output, m, x, key, row, output._version)
+            return True
         self._run_with_relu(m, output, lambda r: run(max_dev=coll.max_device, row=row, relu_out=r, out=output))
         coll.note_max_refreshed()
-        ctl["own_conv1x1"] = ctl.get("own_conv1x1", 0) + 1
+        ctl.own_conv1x1 = ctl.own_conv1x1 + 1
+        return True
+
+    def _run_deferred(self, d):
+        """A deferred convolution on its own after all (what its hook would have launched)."""
+        output, m, x, _key, row, _v = d
+        ctl = self._hook_ctl
+        coll = ctl.fuse_collector
+        if coll is None:
+            _float_conv.runner(m, "c1", x)(out=output)
+            return
+        _float_conv.runner(m, "c1", x)(max_dev=coll.max_device, row=row, out=output)
+        coll.note_max_refreshed()
+        ctl.own_conv1x1 = ctl.own_conv1x1 + 1
+        if ctl.eager is not None:
+            ctl.eager.note(_key, output)
+
+    def _finish_deferred(self, module, m, a, b, key, output):
+        """Hook half of an Eltwise one of whose operands is a deferred convolution: convolution + bias, that tensor's abs-max,
+        the sum, its abs-max and the ReLU behind it in one launch.  Returns True when done; False after running the
+        convolution alone (the Eltwise then takes its usual path)."""
+        ctl = self._hook_ctl
+        d = None
+        for t in (a, b):
+            e = ctl.deferred.get(id(t))
+            if e is not None and e[0] is t:
+                d = e
+                break
+        if d is None:
+            return False
+        del ctl.deferred[id(d[0])]
+        t3, conv, x, conv_key, conv_row, version = d
+        coll = ctl.fuse_collector
+        other = b if t3 is a else a
+        relu = ctl.relu_after.get(m) if self.fuse_relu else None
+        keep = lambda name: self.materialize_all or (ctl.keep_feats and (ctl.keep_names is None or name in ctl.keep_names))
+        keep_y, keep_s = keep(conv_key), keep(key) if key is not None else True
+        # (small planes with BOTH tensors kept: three store streams of partial lines make the one kernel slower than the two,
+        #  scripts/conv_add_bench.py: 356 vs 340 us at 14 x 14, 283 vs 276 at 7 x 7)
+        small = t3.shape[2] * t3.shape[3] < 28 * 28
+        if (module is not m or coll is None or key is None or ctl.fuse_stat != "max" or ctl.defer_ok.get(conv) is not m
+                or relu is None or not _flag(m, _FUSION_VERIFIED) or not _flag(m, _RELU_VERIFIED) or t3._version != version
+                or other is t3 or other.shape != t3.shape or (keep_y and keep_s and small)):
+            self._run_deferred(d)
+            return False
+        r = torch.empty_like(t3)
+        _native.conv1x1_add_f32(x, _float_conv.weight(conv, "c1"), conv.bias, conv.stride[0], other, coll.max_device, conv_row,
+                                coll.row_of(key), r, out=t3 if keep_y else None, sum_out=output if keep_s else None)
+        coll.note_max_refreshed()
+        if keep_y and ctl.eager is not None:
+            ctl.eager.note(conv_key, t3)                        # (what its own hook left out: the tensor exists only now)
+        ctl.fuse_verified.add(m)
+        ctl.relu_ready = (output, r, relu, output._version)
+        ctl.fused_relus.add(relu)
+        ctl.deferred_adds += 1
         return True
 
     def _run_with_relu(self, m, output, run):
         """run(relu_out) launches m's fused kernel.  When an out-of-place nn.ReLU is known to consume `output` directly,
         the kernel writes that ReLU's result as well and the patched ReLU.forward hands it out instead of launching."""
         ctl = self._hook_ctl
-        relu = ctl["relu_after"].get(m) if self.fuse_relu else None
+        relu = ctl.relu_after.get(m) if self.fuse_relu else None
         if relu is None:
             run(None)
             return
@@ -784,38 +974,40 @@ class Quantity(object):
                 self.fuse_relu = False
                 return
             _set_flag(m, _RELU_VERIFIED)
-        ctl["relu_ready"] = (output, r, relu, output._version)      # holds the tensor itself: identity, not a reusable id
-        ctl["fused_relus"].add(relu)
+        ctl.relu_ready = (output, r, relu, output._version)      # holds the tensor itself: identity, not a reusable id
+        ctl.fused_relus.add(relu)
 
     def _finish_fused_conv(self, module, pending, key, output):
         """Forward-hook half of the fused conv: add the bias (and take the abs-max when the tensor is a cared one).
         Returns True when the statistics of `output` are done."""
         m, x = pending
         ctl = self._hook_ctl
-        coll = ctl["fuse_collector"]
+        coll = ctl.fuse_collector
         if isinstance(x, tuple) and isinstance(x[0], str):  # a convolution on fq_conv1x1_f32 / fq_conv_stem_f32: output is still empty
             return self._finish_own_conv(module, m, x[0], x[1], key, output)
         if isinstance(x, tuple):                            # Eltwise: output is an empty tensor waiting for x + y
             a, b = x
+            if ctl.deferred and self._finish_deferred(module, m, a, b, key, output):
+                return True
             if module is not m or coll is None or key is None:
                 torch.add(a, b, out=output)
                 return False
             row = coll.row_of(key)
-            if ctl["fuse_stat"] == "hist":                  # pass 2 (verified in pass 1): the sum, histogrammed on the way out
+            if ctl.fuse_stat == "hist":                  # pass 2 (verified in pass 1): the sum, histogrammed on the way out
                 self._run_with_relu(m, output, lambda r: _native.add_hist(a, b, coll.interval_device, coll.hist_device, row,
                                                                           out=output, relu_out=r))
-                ctl["hist_fused"] += 1
+                ctl.hist_fused += 1
                 return True
             if not _flag(m, _FUSION_VERIFIED):        # first use: the kernel against torch.add, once per process
                 scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
                 z = _native.add_absmax(a, b, scratch, 0)
                 want = torch.add(a, b)
                 if not (torch.equal(z, want) and float(scratch[0]) == float(want.abs().max())):
-                    ctl["fuse_off"] = True
+                    ctl.fuse_off = True
                     output.copy_(want)
                     return False
                 _set_flag(m, _FUSION_VERIFIED)
-            ctl["fuse_verified"].add(m)
+            ctl.fuse_verified.add(m)
             self._run_with_relu(m, output, lambda r: _native.add_absmax(a, b, coll.max_device, row, out=output, relu_out=r))
             coll.note_max_refreshed()
             return True
@@ -823,13 +1015,13 @@ class Quantity(object):
             output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))     # what torch does
             return False
         row = coll.row_of(key)
-        if ctl["fuse_stat"] == "hist":                      # pass 2 (verified in pass 1)
+        if ctl.fuse_stat == "hist":                      # pass 2 (verified in pass 1)
             self._run_with_relu(m, output, lambda r: _native.bias_add_hist(output, m.bias, coll.interval_device,
                                                                            coll.hist_device, row, relu_out=r))
-            ctl["hist_fused"] += 1
+            ctl.hist_fused += 1
             return True
-        if m in ctl["fuse_verified"] or _flag(m, _FUSION_VERIFIED):
-            ctl["fuse_verified"].add(m)
+        if m in ctl.fuse_verified or _flag(m, _FUSION_VERIFIED):
+            ctl.fuse_verified.add(m)
             self._run_with_relu(m, output, lambda r: _native.bias_add_absmax(output, m.bias, coll.max_device, row, relu_out=r))
             coll.note_max_refreshed()
             return True
@@ -847,12 +1039,12 @@ class Quantity(object):
         kernel_ok = torch.equal(raw, want) and float(scratch[0]) == float(want.abs().max())
         reproducible = torch.equal(ref, torch.nn.Conv2d.forward(m, x))
         if kernel_ok and (torch.equal(raw, ref) or not reproducible):
-            ctl["fuse_verified"].add(m)
+            ctl.fuse_verified.add(m)
             _set_flag(m, _FUSION_VERIFIED)             # a property of (module, MIOpen, this library): checked once per process
             _native.bias_add_absmax(output, m.bias, coll.max_device, row)
             coll.note_max_refreshed()
             return True
-        ctl["fuse_off"] = True                              # never silently different: torch's add, statistics as usual
+        ctl.fuse_off = True                              # never silently different: torch's add, statistics as usual
         output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))
         return False
 
@@ -864,25 +1056,71 @@ class Quantity(object):
         return [m for m in self.model.modules()
                 if m.training and (isinstance(m, _DropoutNd) or next(m.buffers(recurse=False), None) is not None)]
 
-    def _probe_forward(self, own_plain):
+    def _probe_forward(self, own_plain, deferral=None):
         """One forward of the model on a random input of INPUT_SHAPE with the hooks watching for in-place consumers; returns
         whether a hooked tensor was written to after its hook ran.  The reference feeds its models random input exactly
         once, in build_net_structure (pytorch_quantizer.py:21-62); this additional draw comes from a generator of its own,
         so the global RNG stream a user script sees afterwards is the reference's."""
         ctl = self._hook_ctl
         probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
-        saved = ctl.get("own_plain", False)
-        ctl["eager"], ctl["own_plain"] = probe, own_plain
+        saved = ctl.own_plain
+        ctl.eager, ctl.own_plain, ctl.poison = probe, own_plain, deferral
+        self._probe_out = None
         try:
             dev = self._model_device(self.model)
             gen = torch.Generator(device=dev)
             gen.manual_seed(0x5eed)
             shapes = [self.input_size] if isinstance(self.input_size, tuple) else list(self.input_size)
             with torch.no_grad():
-                self.model(*[torch.rand(*s_, device=dev, generator=gen) for s_ in shapes])
+                self._probe_out = self.model(*[torch.rand(*s_, device=dev, generator=gen) for s_ in shapes])
         finally:
-            ctl["eager"], ctl["own_plain"] = None, saved
+            ctl.eager, ctl.own_plain, ctl.poison = None, saved, None
         return bool(probe.modified())
+
+    @staticmethod
+    def _only_our_hook(m):
+        """Nobody but this calibration's own forward hook watches module m."""
+        import torch.nn.modules.module as _mod
+        return (len(m._forward_hooks) <= 1 and not m._forward_pre_hooks and not _mod._global_forward_hooks
+                and not _mod._global_forward_pre_hooks)
+
+    def _prove_deferral(self, probe, first_feats, first_out):
+        """After the learning probe forward: pick the (1x1 convolution, Eltwise, ReLU) chains fq_conv1x1_add_f32 can take, run
+        the poison forward (_DeferralProbe) and return {conv: Eltwise} when it changes nothing, else {}."""
+        ctl = self._hook_ctl
+        cared = set(self.net_info.keys())
+        for elt, conv in probe.pairs.items():
+            relu = ctl.relu_after.get(elt)
+            if (relu is None or probe.keys.get(conv) not in cared or probe.keys.get(elt) not in cared
+                    or not _native.conv1x1_add_f32_supported(conv.in_channels, conv.out_channels)
+                    or not (self._only_our_hook(conv) and self._only_our_hook(elt) and self._only_our_hook(relu))
+                    or conv in probe.candidates):
+                continue
+            probe.candidates[conv] = (elt, relu)
+        if not probe.candidates:
+            return {}
+        probe.mode = "poison"
+        named = self._probe_feats
+        named.clear()
+        self._probe_forward("unchecked", probe)
+        skip = probe.poisoned_keys()
+
+        def same(u, v):
+            if not (torch.is_tensor(u) and torch.is_tensor(v)) or u.shape != v.shape or u.dtype != v.dtype:
+                return False
+            if u.dtype == torch.float32:
+                return torch.equal(u.contiguous().view(torch.int32), v.contiguous().view(torch.int32))
+            return torch.equal(u, v)
+        ok = set(first_feats) == set(named)
+        for k, t in first_feats.items():
+            if not ok:
+                break
+            if k not in skip:
+                ok = same(t, named[k])
+        if ok and torch.is_tensor(first_out):
+            ok = same(first_out, self._probe_out)
+        self._probe_out = None
+        return {conv: pair[0] for conv, pair in probe.candidates.items()} if ok else {}
 
     def _forward_with_stats(self, item, fn, named_feats, extra=None):
         """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced and
@@ -896,12 +1134,18 @@ class Quantity(object):
             self._on_stat_stream(fn, feats)
             return None
         eager = _EagerStats(fn, limit)
-        eager.retain = self._hook_ctl.get("keep_feats", True)
-        self._hook_ctl["eager"] = eager
+        eager.retain = self._hook_ctl.keep_feats
+        self._hook_ctl.eager = eager
         try:
             self.net_forward(self.model, item)
         finally:
-            self._hook_ctl["eager"] = None
+            self._hook_ctl.eager = None
+            waiting, self._hook_ctl.deferred = self._hook_ctl.deferred, {}
+        if waiting:
+            # the forward took a path the probe did not see: whatever read these tensors read memory nobody had written
+            self._hook_ctl.defer_ok = {}
+            raise RuntimeError("a convolution deferred to its Eltwise (Quantity.fuse_conv_add) was never consumed by it: this "
+                               "model's control flow depends on its data; set Quantity.fuse_conv_add = False")
         eager.flush(extra)
         return eager
 
@@ -1091,7 +1335,16 @@ class Quantity(object):
             # (its values are not used, so the convolutions the own kernels take run on them here too, unchecked: a
             # calibration then never enters the convolution library, whose first-use solver search is most of what a
             # fresh process used to wait for; every module is still checked on the first real batch)
-            inplace = self._probe_forward("unchecked")
+            deferral = (_DeferralProbe() if self.fuse_conv_add and self.fuse_bias_absmax and self.fuse_relu and self.own_conv1x1
+                        and self._stat_stream() is None else None)
+            inplace = self._probe_forward("unchecked", deferral)
+            if deferral is not None and not inplace and deferral.pairs:
+                self._probe_feats = named_feats
+                try:
+                    ctl.defer_ok = self._prove_deferral(deferral, dict(named_feats), self._probe_out)
+                finally:
+                    self._probe_feats = None
+            self._probe_out = None
             named_feats.clear()
             if inplace:
                 budget = 0                      # kept tensors would hold overwritten values: no cache, per-tensor launches
@@ -1099,14 +1352,23 @@ class Quantity(object):
             else:
                 self._stats_limit = _AFTER_FORWARD if self.stats_group_bytes is None else int(self.stats_group_bytes)
                 if not budget:
-                    ctl["keep_feats"] = False   # nothing will be cached: producers' tensors need not outlive their hook
-        ctl["fuse_collector"] = collector if eager_ok and self.fuse_bias_absmax else None
+                    ctl.keep_feats = False   # nothing will be cached: producers' tensors need not outlive their hook
+        ctl.fuse_collector = collector if eager_ok and self.fuse_bias_absmax else None
         for i, item in self._device_items(images_files):
             ts = time.perf_counter()
             if budget and plan is None and self.device == "gpu" and torch.cuda.is_available():
                 start = torch.cuda.Event(enable_timing=True)
                 start.record()
-                ctl["events"] = []
+                ctl.events = []
+            # what pass 2 will want kept of THIS forward (a deferred convolution writes its output and the sum only then)
+            if not budget:
+                ctl.keep_names = set()
+            elif plan is None:
+                ctl.keep_names = None
+            elif plan["kind"] == "A":
+                ctl.keep_names = None if len(cached) < plan["whole_batches"] else set()
+            else:
+                ctl.keep_names = plan["keep"]
             self._forward_with_stats(item, collector.refresh_max_val, named_feats)
             if os.environ.get("FQ_DEBUG_STEP_TIMES"):
                 self._sync()
@@ -1115,10 +1377,10 @@ class Quantity(object):
                 continue
             if plan is None:
                 cum_ms = {}
-                if ctl["events"]:
+                if ctl.events:
                     self._sync()
-                    cum_ms = {o: start.elapsed_time(ev) for o, ev in ctl["events"]}
-                ctl["events"] = None
+                    cum_ms = {o: start.elapsed_time(ev) for o, ev in ctl.events}
+                ctl.events = None
                 plan = self._plan_cache(budget, n_owned, named_feats, cum_ms)
             need_all = sum(t.numel() * t.element_size() for t in named_feats.values())
             if plan["kind"] == "A":
@@ -1130,7 +1392,7 @@ class Quantity(object):
                 kept = {n: t for n, t in named_feats.items() if n in plan["keep"]}
                 cached[i] = kept
                 used += sum(t.numel() * t.element_size() for t in kept.values())
-        ctl["fuse_collector"] = None
+        ctl.fuse_collector = None
         self._join_stat_stream()
         if _dist_on():                      # also at world size 1: same code path, trivial cost
             collector.all_reduce_max()
@@ -1151,12 +1413,12 @@ class Quantity(object):
 
         # pass 2: histograms with the final intervals
         print("Collect histograms of activations:")
-        if (eager_ok and self.fuse_bias_absmax and self.fuse_hist and not ctl["fuse_off"] and ctl["fuse_verified"]
+        if (eager_ok and self.fuse_bias_absmax and self.fuse_hist and not ctl.fuse_off and ctl.fuse_verified
                 and inplace is False and hasattr(collector, "prepare_distributions")):
             collector.prepare_distributions()
-            ctl["fuse_collector"], ctl["fuse_stat"] = collector, "hist"
+            ctl.fuse_collector, ctl.fuse_stat = collector, "hist"
         if plan is not None and plan["kind"] == "B":
-            ctl["stop_after"] = plan["stop_after"] if plan["stop_after"] else None
+            ctl.stop_after = plan["stop_after"] if plan["stop_after"] else None
             try:
                 for i, item in self._device_items(images_files):
                     if plan["stop_after"]:
@@ -1169,7 +1431,7 @@ class Quantity(object):
                     feats.update(cached.pop(i))
                     self._on_stat_stream(collector.add_to_distributions, feats)
             finally:
-                ctl["stop_after"] = None
+                ctl.stop_after = None
         else:
             for i in sorted(cached):
                 self._on_stat_stream(collector.add_to_distributions, cached[i])
@@ -1177,7 +1439,7 @@ class Quantity(object):
                 self._forward_with_stats(item, collector.add_to_distributions, named_feats)
         self._join_stat_stream()
         del cached
-        ctl["fuse_collector"], ctl["fuse_stat"] = None, "max"
+        ctl.fuse_collector, ctl.fuse_stat = None, "max"
         if _dist_on():
             collector.all_reduce_hist()
         if self.profile_phases:
@@ -1223,11 +1485,12 @@ class Quantity(object):
                     fh.write(line + "\n")
         self.timings = {"pass1_s": t1 - t0, "pass2_s": t2 - t1, "kl_s": t3 - t2, "total_s": time.perf_counter() - t0,
                         "cached_batches": len(cached_ids), "cache_bytes": used, "inplace_consumers": inplace,
-                        "fused_bias_absmax_convs": 0 if ctl["fuse_off"] else sum(1 for m in ctl["fuse_verified"] if isinstance(m, torch.nn.Conv2d)),
-                        "fused_relus": len(ctl["fused_relus"]),
-                        "fused_add_absmax_eltwise": 0 if ctl["fuse_off"] else sum(1 for m in ctl["fuse_verified"] if not isinstance(m, torch.nn.Conv2d)),
-                        "fused_hist_launches": ctl["hist_fused"],
-                        "own_conv1x1_launches": ctl.get("own_conv1x1", 0),
+                        "fused_bias_absmax_convs": 0 if ctl.fuse_off else sum(1 for m in ctl.fuse_verified if isinstance(m, torch.nn.Conv2d)),
+                        "fused_relus": len(ctl.fused_relus),
+                        "fused_add_absmax_eltwise": 0 if ctl.fuse_off else sum(1 for m in ctl.fuse_verified if not isinstance(m, torch.nn.Conv2d)),
+                        "fused_hist_launches": ctl.hist_fused,
+                        "own_conv1x1_launches": ctl.own_conv1x1,
+                        "conv_add_chains_proven": len(ctl.defer_ok), "conv_add_launches": ctl.deferred_adds,
                         "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}
@@ -1248,7 +1511,7 @@ class Quantity(object):
         # the forward's 1x1 convolutions and stem on the own fp32 MFMA kernels (convolution + bias only: the per-channel
         # statistics are taken from the finished tensors)
         patched = self._patch_fused_convs(self.model) if self.device == "gpu" and torch.cuda.is_available() else []
-        ctl["own_plain"] = bool(patched)
+        ctl.own_plain = bool(patched)
         try:
             # One probe forward on a random input of INPUT_SHAPE (what build_net_structure traces with) tells the
             # channel counts and whether later modules overwrite hooked tensors -- on EVERY rank, also one that owns
@@ -1258,7 +1521,7 @@ class Quantity(object):
             for m in was_training:
                 m.training = False
             try:
-                modified = self._probe_forward(ctl["own_plain"])
+                modified = self._probe_forward(ctl.own_plain)
             finally:
                 for m in was_training:
                     m.training = True
@@ -1290,7 +1553,7 @@ class Quantity(object):
             bits = collector.quantize()
             self.timings = {"per_channel_cache_bytes": used, "per_channel_kl_s": getattr(collector, "kl_seconds", None)}
         finally:
-            ctl["own_plain"] = False
+            ctl.own_plain = False
             for m in patched:
                 del m.forward
             for h in hooks:
@@ -1317,13 +1580,10 @@ class Quantity(object):
         cared = set(self.net_info.keys())
         state = {"n": 0}
         total = int(self.layers_num)
-        ctl = self._hook_ctl = {"stop_after": None, "events": None, "eager": None, "fuse_bias": None, "fuse_collector": None,
-                                "fuse_off": False, "fuse_verified": set(), "fuse_warm": set(),
-                                "relu_after": {}, "relu_ready": None, "last_out": None, "fused_relus": set(),
-                                "fuse_stat": "max", "hist_fused": 0, "keep_feats": True}
+        ctl = self._hook_ctl = _HookState()
 
         def on_forward(module, inputs, output):
-            eager = ctl["eager"]
+            eager = ctl.eager
             if state["n"] == 0:
                 out_feat.clear()
                 out_feat["image"] = inputs[0].detach()
@@ -1331,31 +1591,37 @@ class Quantity(object):
                     eager.add("image", out_feat["image"])
             state["n"] += 1
             key = "%s_%i" % (type(module).__name__, state["n"])
-            ctl["relu_ready"] = None        # a ReLU result prepared by the previous module is for the very next forward only
-            pending_bias, ctl["fuse_bias"] = ctl.get("fuse_bias"), None
+            if ctl.poison is not None:
+                ctl.poison.keys[module] = key
+            ctl.relu_ready = None        # a ReLU result prepared by the previous module is for the very next forward only
+            pending_bias, ctl.fuse_bias = ctl.fuse_bias, None
             fused = pending_bias is not None and self._finish_fused_conv(module, pending_bias, key if key in cared else None, output)
-            ctl["last_out"] = (module, output) if torch.is_tensor(output) else None
+            ctl.last_out = (module, output) if torch.is_tensor(output) else None
+            waiting = fused and bool(ctl.deferred) and id(output) in ctl.deferred     # its kernel runs with its Eltwise: noted there
             if key in cared:
-                if fused and eager is not None and not ctl["keep_feats"]:
+                if fused and eager is not None and not ctl.keep_feats:
                     # its statistic is taken and nothing will be cached: do not keep the tensor alive until the end of the
                     # forward (17 GB of references per batch of 256 ResNet-50 images -- in a fresh process that is 30 GB
                     # of allocator pool the forward would not otherwise need, up to a second of hipMalloc)
                     out_feat.pop(key, None)
-                    eager.note(key, output)
+                    if not waiting:
+                        eager.note(key, output)
                 else:
                     out_feat[key] = output.detach()
                     if eager is not None:
-                        if fused:
+                        if waiting:
+                            pass
+                        elif fused:
                             eager.note(key, out_feat[key])
                         else:
                             eager.add(key, out_feat[key])
-                if ctl["events"] is not None:                 # time stamps of one forward, for the cache plan
+                if ctl.events is not None:                 # time stamps of one forward, for the cache plan
                     ev = torch.cuda.Event(enable_timing=True)
                     ev.record()
-                    ctl["events"].append((state["n"], ev))
+                    ctl.events.append((state["n"], ev))
             if state["n"] >= total:
                 state["n"] = 0
-            elif ctl["stop_after"] is not None and state["n"] >= ctl["stop_after"]:
+            elif ctl.stop_after is not None and state["n"] >= ctl.stop_after:
                 state["n"] = 0
                 raise _StopForward()
 

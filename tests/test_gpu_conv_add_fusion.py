@@ -1,0 +1,168 @@
+"""Calibration pass 1 with the last 1x1 convolution of a residual block, the Eltwise that adds it to the shortcut and the ReLU
+behind it as ONE kernel (Quantity.fuse_conv_add, fq_conv1x1_add_f32): which chains are taken is PROVEN per model by the poison
+probe (tools.pytorch_quantizer._DeferralProbe), the tables do not depend on it, and whether the two intermediate tensors reach
+HBM follows what pass 2's cache wants.  Reference: the forward at pytorch_quantizer.py:288-296 through fabu_layer.py:5-11."""
+import os
+
+import pytest
+import torch
+
+import cases
+from workdir_util import product_workdir
+
+pytestmark = pytest.mark.gpu
+
+
+def _block_net(variant="plain", hw=64):
+    """stem -> 2 x [1x1 -> ReLU -> 3x3 -> ReLU -> 1x1 (128 channels)] + shortcut -> Eltwise -> ReLU -> pool -> fc.
+    variant "peek": block 1's convolution output is ALSO read by something else before its Eltwise;
+    variant "inplace_relu": the ReLU behind the Eltwise works in place."""
+    from torch import nn
+    from common.quantity import Eltwise, View
+
+    class Block(nn.Module):
+        def __init__(self, cin, mid, cout, stride, peek):
+            super().__init__()
+            self.c1, self.r1 = nn.Conv2d(cin, mid, 1), nn.ReLU()
+            self.c2, self.r2 = nn.Conv2d(mid, mid, 3, stride=stride, padding=1), nn.ReLU()
+            self.c3 = nn.Conv2d(mid, cout, 1)
+            self.down = nn.Conv2d(cin, cout, 1, stride=stride) if (stride != 1 or cin != cout) else None
+            self.add = Eltwise()
+            self.r3 = nn.ReLU(variant == "inplace_relu")
+            self.peek = (nn.ReLU(), Eltwise()) if peek else None
+            if peek:
+                self.peek_relu, self.peek_add = self.peek
+
+        def forward(self, x):
+            y = self.c3(self.r2(self.c2(self.r1(self.c1(x)))))
+            side = self.peek_relu(y) if self.peek else None                    # a second reader of the convolution's output
+            z = self.r3(self.add(y, x if self.down is None else self.down(x)))
+            return z if side is None else self.peek_add(z, side)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem, self.relu0 = nn.Conv2d(3, 32, 3, padding=1), nn.ReLU()
+            self.b1 = Block(32, 16, 128, 2, peek=False)
+            self.b2 = Block(128, 32, 128, 1, peek=variant == "peek")
+            self.pool, self.view, self.fc = nn.AvgPool2d(hw // 2), View(), nn.Linear(128, 10)
+
+        def forward(self, x):
+            return self.fc(self.view(self.pool(self.b2(self.b1(self.relu0(self.stem(x)))))))
+    return Net()
+
+
+def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None, hw=64):
+    from tools import Quantity
+    if monkeypatch is not None and cache_gb is not None:
+        monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
+        monkeypatch.setenv("FQ_CACHE_PLAN", plan)
+    with product_workdir(input_shape="1,3,%d,%d" % (hw, hw), device="gpu", max_cali_img_num=batches - 1) as tmp:
+        q = Quantity(model)
+        q.fuse_conv_add = fuse
+        bits = q.activation_quantize(cases.calib_batches(batches, (8, 3, hw, hw), seed=91))
+        table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
+        return dict(bits), table, dict(q._collector.max_vals), q._collector.hist_device.clone(), dict(q.timings)
+
+
+@pytest.mark.parametrize("cache_gb,plan", [("0", ""), ("1", "A"), ("0.07", "A"), ("1", "B"), ("0.05", "B")])
+def test_tables_do_not_depend_on_the_fusion_nor_on_what_the_cache_keeps(monkeypatch, cache_gb, plan):
+    """32 x 32 planes behind the blocks: the one-kernel form is taken whatever the cache keeps -- nothing (no cache), both
+    tensors of every batch (1 GB), whole batches until the budget is spent (plan A), the deepest tensors of every batch (B)."""
+    model = cases.seed_model(_block_net(), base_seed=8).eval().cuda()
+    want = _calibrate(model, False, cache_gb, plan, monkeypatch=monkeypatch)
+    got = _calibrate(model, True, cache_gb, plan, monkeypatch=monkeypatch)
+    assert got[1] == want[1] and got[0] == want[0]
+    assert got[2] == want[2]                                   # every abs-max, bit for bit
+    assert torch.equal(got[3], want[3])                        # every histogram
+    assert want[4]["conv_add_chains_proven"] == 0 and want[4]["conv_add_launches"] == 0
+    assert got[4]["conv_add_chains_proven"] == 2               # both blocks' (c3, add, r3)
+    # every forward of pass 1 takes both chains, except the one in which the Eltwise modules have their first, checked use
+    assert got[4]["conv_add_launches"] in (2 * 4, 2 * 5)
+    if plan:
+        assert got[4]["cache_plan"]["kind"] == plan and got[4]["cache_bytes"] > 0
+        assert (got[4]["cache_bytes"] < 100e6) == (cache_gb != "1")      # (a batch's hooked tensors are 30 MB: partial caches are partial)
+
+
+def test_small_planes_with_both_tensors_kept_stay_on_the_two_kernels(monkeypatch):
+    """8 x 8 planes and a cache that keeps everything: three store streams of partial lines make the one kernel slower than
+    the two (scripts/conv_add_bench.py), so the convolution is launched on its own after all -- same tables; without a cache
+    the same planes take the one kernel."""
+    model = cases.seed_model(_block_net(hw=16), base_seed=8).eval().cuda()
+    want = _calibrate(model, False, "1", "A", monkeypatch=monkeypatch, hw=16)
+    got = _calibrate(model, True, "1", "A", monkeypatch=monkeypatch, hw=16)
+    assert got[4]["conv_add_chains_proven"] == 2 and got[4]["conv_add_launches"] == 0
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+    cold = _calibrate(model, True, "0", "", monkeypatch=monkeypatch, hw=16)
+    assert cold[4]["conv_add_launches"] == 2 * 5
+    assert cold[1] == want[1] and cold[2] == want[2] and torch.equal(cold[3], want[3])
+
+
+def test_a_convolution_output_with_a_second_reader_is_not_deferred():
+    """Block 2's convolution output is also read by an expression outside any module: the poison forward differs from the
+    clean one, so no chain of this model is deferred -- and the tables are those of the unfused run."""
+    model = cases.seed_model(_block_net("peek"), base_seed=8).eval().cuda()
+    want = _calibrate(model, False)
+    got = _calibrate(model, True)
+    assert got[4]["conv_add_chains_proven"] == 0 and got[4]["conv_add_launches"] == 0
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+
+
+def test_an_inplace_relu_behind_the_eltwise_is_left_alone():
+    model = cases.seed_model(_block_net("inplace_relu"), base_seed=8).eval().cuda()
+    want = _calibrate(model, False)
+    got = _calibrate(model, True)
+    assert got[4]["conv_add_chains_proven"] == 0 and got[4]["inplace_consumers"] is True
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+
+
+def test_a_foreign_hook_on_the_convolution_keeps_its_output_materialised():
+    """Somebody else's forward hook on the block's last convolution must see the convolution's output, as the reference's
+    hook would: that chain is not deferred (the other one still is)."""
+    model = cases.seed_model(_block_net(), base_seed=8).eval().cuda()
+    want = _calibrate(model, False)
+    seen = []
+    h = model.b2.c3.register_forward_hook(lambda m, i, o: seen.append(float(o.abs().max())))
+    try:
+        got = _calibrate(model, True)
+    finally:
+        h.remove()
+    assert got[4]["conv_add_chains_proven"] == 1
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+    assert seen and all(v == v and 0.0 < v < 1e6 for v in seen)      # the foreign hook saw real tensors in every forward
+
+
+def test_a_forward_that_leaves_the_proven_path_is_refused():
+    """Data-dependent control flow the probe cannot see: a calibration batch takes a branch in which the convolution's output
+    never reaches its Eltwise.  The forward is refused instead of calibrating on memory nobody wrote."""
+    from tools import Quantity
+    model = cases.seed_model(_block_net(), base_seed=8).eval().cuda()
+    block = model.b2
+    plain = type(block).forward
+
+    def moody(self, x):
+        if float(x.flatten()[0]) == 12345.0:                  # never on the probe's input
+            y = self.c3(self.r2(self.c2(self.r1(self.c1(x)))))
+            return self.r3(y)                                 # (no Eltwise)
+        return plain(self, x)
+    batches = cases.calib_batches(3, (8, 3, 64, 64), seed=91)
+    with product_workdir(input_shape="1,3,64,64", device="gpu", max_cali_img_num=2):
+        q = Quantity(model)
+        block.forward = moody.__get__(block)
+        try:
+            calls = {"n": 0}
+            b1 = model.b1
+            real_b1 = b1.forward
+
+            def tagged(x):
+                out = real_b1(x)
+                calls["n"] += 1
+                if calls["n"] == 4:                           # probe, poison probe, batch 0, then batch 1: the other branch
+                    out = out.clone()
+                    out.flatten()[0] = 12345.0
+                return out
+            b1.forward = tagged
+            with pytest.raises(RuntimeError, match="fuse_conv_add"):
+                q.activation_quantize(batches)
+        finally:
+            del block.forward, b1.forward

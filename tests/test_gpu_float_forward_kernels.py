@@ -508,6 +508,61 @@ def test_quandequan_epilogue_equals_the_two_pass_form(nat, bit, bitwidth):
         nat.conv1x1_f32(x[:, :, :4, :4].contiguous(), torch.zeros(3, 4, device="cuda"), None, 1, qd=4, relu_out=torch.zeros(1, device="cuda"))
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 13, 9, 256, 1), (2, 32, 28, 28, 128, 1), (5, 256, 7, 7, 1024, 1), (2, 64, 15, 15, 128, 2),
+                                   (40, 64, 56, 56, 256, 1)], ids=lambda s: "x".join(map(str, s)))
+def test_conv_add_relu_in_one_kernel_equals_the_two_kernels(nat, shape):
+    """fq_conv1x1_add_f32 (conv3 + Eltwise + ReLU of a residual block, pass 1) leaves bit for bit what fq_conv1x1_f32 (max
+    form) followed by fq_add_absmax_f32 leave -- both maxima, the ReLU output, and each of the two intermediate tensors
+    exactly when it is asked for (the others' destinations stay untouched); NaN / Inf / -0.0 included; both tile shapes,
+    partial column tiles, stride 2, the streaming (non-temporal) form."""
+    N, Cin, H, W, Cout, s = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g) * 2
+    wt = torch.randn(Cin, Cout, device="cuda", generator=g) * Cin ** -0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    ho, wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(N, Cout, ho, wo, device="cuda", generator=g) * 3
+    res[0, 0, 0, :4] = torch.tensor([float("nan"), float("inf"), -0.0, -1e30], device="cuda")
+    x[-1, :, -1, -1] = 0.0
+    m2 = torch.zeros(4, device="cuda")
+    v = nat.conv1x1_f32(x, wt, b, s, max_dev=m2, row=1)
+    r2 = torch.empty_like(v)
+    sm = nat.add_absmax(v, res, m2, 3, relu_out=r2)
+    for keep_y in (False, True):
+        for keep_s in (False, True):
+            m1 = torch.zeros(4, device="cuda")
+            mark = 12345.0
+            y = torch.full_like(v, mark) if keep_y else None
+            so = torch.full_like(v, mark) if keep_s else None
+            r1 = torch.full_like(v, mark)
+            out = nat.conv1x1_add_f32(x, wt, b, s, res, m1, 1, 3, r1, out=y, sum_out=so)
+            assert out is r1
+            assert torch.equal(m1, m2), (m1, m2)
+            assert torch.equal(r1.view(torch.int32), r2.view(torch.int32))          # (bit patterns: NaN == NaN, -0.0 != 0.0)
+            if keep_y:
+                assert torch.equal(y.view(torch.int32), v.view(torch.int32))
+            if keep_s:
+                assert torch.equal(so.view(torch.int32), sm.view(torch.int32))
+    # maxima fold into what the rows already hold
+    m1 = torch.tensor([0.0, 1e9, 0.0, 0.5], device="cuda")
+    nat.conv1x1_add_f32(x, wt, b, s, res, m1, 1, 3, torch.empty_like(v))
+    assert float(m1[1]) == 1e9 and float(m1[3]) == float(m2[3]) and float(m1[0]) == 0.0 and float(m1[2]) == 0.0
+
+
+def test_conv_add_argument_errors(nat):
+    x = torch.zeros(1, 16, 4, 4, device="cuda")
+    r = torch.zeros(1, 128, 4, 4, device="cuda")
+    m = torch.zeros(2, device="cuda")
+    with pytest.raises(nat.FqError):            # Cout not a multiple of 128
+        nat.conv1x1_add_f32(x, torch.zeros(16, 64, device="cuda"), torch.zeros(64, device="cuda"), 1, r[:, :64].contiguous(), m, 0, 1,
+                            torch.zeros(1, 64, 4, 4, device="cuda"))
+    with pytest.raises(nat.FqError):            # Cin not a multiple of 16
+        nat.conv1x1_add_f32(x[:, :8].contiguous(), torch.zeros(8, 128, device="cuda"), torch.zeros(128, device="cuda"), 1, r, m, 0, 1,
+                            torch.empty_like(r))
+    assert not nat.conv1x1_add_f32_supported(8, 128) and not nat.conv1x1_add_f32_supported(16, 64)
+    assert nat.conv1x1_add_f32_supported(64, 256)
+
+
 def test_testconv_runs_as_one_kernel_unless_its_convolution_is_hooked():
     """TestConv.forward: no forward hook on the inner nn.Conv2d -> one kernel (QuanDequan in the convolution's epilogue), the
     standalone fq_quandequan_f32 pass is not launched; with a hook on the inner module the two-pass form runs (the hook sees

@@ -87,6 +87,7 @@ def _hip_vs_oracle(oracle, model, batches, input_shape, rows, fused, monkeypatch
         collector_cls = RecordingCollector
         fuse_bias_absmax = fused
         fuse_relu = fused
+        materialize_all = True        # (conv3 + Eltwise in one kernel: both tensors must exist in HBM to be taped)
 
     class CpuQuantity(Quantity):
         collector_cls = ReplayCollector
