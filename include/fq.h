@@ -254,6 +254,12 @@ int fq_conv_stem_qd_f32(const float* x, const float* wp, const float* bias, floa
 int fq_conv1x1_add_f32(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
                        float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y, float* max_sum,
                        fq_stream_t stream);
+/* ... and in pass 2: v and s are counted into the 2048-bin rows hist_y / hist_sum (bin widths *interval_y / *interval_sum,
+ * the rule of fq_hist2048_seg) while they pass through the registers and are not written at all; relu_out = max(s, 0).
+ * Bit for bit the rows fq_conv1x1_f32 (histogram form) followed by fq_add_hist_f32 leave. */
+int fq_conv1x1_add_hist_f32(const float* x, const float* wt, const float* bias, const float* res, float* relu_out, int N, int Cin,
+                            int Hin, int Win, int Cout, int stride, const float* interval_y, int64_t* hist_y,
+                            const float* interval_sum, int64_t* hist_sum, fq_stream_t stream);
 
 /* The pooling layers of the float calibration forward (nn.MaxPool2d / a global nn.AvgPool2d inside the model the
  * reference runs at pytorch_quantizer.py:288-296), bit for bit what torch computes:

@@ -71,11 +71,15 @@ struct NoStat {
 };
 
 // the add form's pair of statistics: the convolution output's and the sum's running abs-max
+// (kMayStore = false: the form that never writes the two tensors themselves -- pass 2, where nothing is kept)
+template <typename SC, typename SS, bool kStores>
 struct AddStat {
-    MaxStat c, s;
+    static constexpr bool kMayStore = kStores;
+    SC c;
+    SS s;
 };
 template <typename T> struct is_add_stat { static constexpr bool value = false; };
-template <> struct is_add_stat<AddStat> { static constexpr bool value = true; };
+template <typename SC, typename SS, bool K> struct is_add_stat<AddStat<SC, SS, K>> { static constexpr bool value = true; };
 
 template <int I>
 struct Stage {
@@ -140,8 +144,8 @@ __device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1A
 // v = acc + bias (rounded: "the convolution's output", whose abs-max goes to the first statistic and which is stored only when
 // somebody keeps it), s = v + res (the Eltwise's output: second statistic, stored only when kept), max(s, 0) to a.relu.
 // Separately the two kernels move 20 bytes per element (4 written, 8 read, 8 written); this moves 8 when nothing is kept.
-template <int WM, int WN, bool kStoreY, bool kStoreSum, bool kStream>
-__device__ __forceinline__ void c1_epilogue_add(const f16v (&acc)[WM][WN], const C1Args& a, AddStat& stat, const float* s_bias,
+template <int WM, int WN, bool kStoreY, bool kStoreSum, bool kStream, typename Stat>
+__device__ __forceinline__ void c1_epilogue_add(const f16v (&acc)[WM][WN], const C1Args& a, Stat& stat, const float* s_bias,
                                                 unsigned jbase, unsigned mbase, unsigned m0, unsigned n0, unsigned r, unsigned h) {
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(kStoreY ? a.y : a.relu, 0, a.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(kStoreSum ? a.sum : a.relu, 0, a.y_bytes, 0x00020000);
@@ -386,6 +390,9 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
 #define FQ_C1_EPI(R, S, F) c1_epilogue<WM, WN, R, S, F>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
 #define FQ_C1_ADD(Y, S, N) c1_epilogue_add<WM, WN, Y, S, N>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
             if constexpr (is_add_stat<Stat>::value) {         // (whole row tiles only: host check)
+                if constexpr (!Stat::kMayStore) {
+                    if (a.stream_stores) FQ_C1_ADD(false, false, true); else FQ_C1_ADD(false, false, false);
+                } else
                 if (a.stream_stores) {
                     if (a.store_y) { if (a.sum) FQ_C1_ADD(true, true, true); else FQ_C1_ADD(true, false, true); }
                     else { if (a.sum) FQ_C1_ADD(false, true, true); else FQ_C1_ADD(false, false, true); }
@@ -430,11 +437,35 @@ template <int WM, int WN>
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(4))) void conv1x1_f32_add_absmax_kernel(
     const C1Args a, unsigned int* __restrict__ max_y_bits, unsigned int* __restrict__ max_sum_bits) {
     __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
-    AddStat st;
+    AddStat<MaxStat, MaxStat, true> st;
     conv1x1_tiles<WM, WN, step_of<WM>(), 0>(a, st, smem);
     publish_max<kT>(st.c.m, max_y_bits);
     __syncthreads();                                          // (publish_max's LDS slots are about to be reused)
     publish_max<kT>(st.s.m, max_sum_bits);
+}
+
+// ... and in pass 2: both tensors histogrammed on their way through the registers, neither written (nothing is kept in pass 2);
+// two 8 KB sets of LDS bins on top of the stages, a persistent grid for the flushes as in conv1x1_f32_hist_kernel
+template <int WM, int WN>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void conv1x1_f32_add_hist_kernel(
+    const C1Args a, const float* __restrict__ interval_y, unsigned long long* __restrict__ hist_y,
+    const float* __restrict__ interval_sum, unsigned long long* __restrict__ hist_sum, const int allow_fast) {
+    __shared__ __attribute__((aligned(16))) float smem[Shape<WM, WN, step_of<WM>()>::kFloats];
+    __shared__ unsigned int s_bins[2][FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < 2 * (FQ_BINS + kWave); b += kT) (&s_bins[0][0])[b] = 0u;
+    __syncthreads();
+    const float ivy = *interval_y, ivs = *interval_sum;
+    unsigned int* park0 = s_bins[0] + FQ_BINS + (threadIdx.x & (kWave - 1));
+    unsigned int* park1 = s_bins[1] + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (allow_fast && fast_quotient_ok(ivy) && fast_quotient_ok(ivs)) {
+        AddStat<HistStat<true>, HistStat<true>, false> st{{s_bins[0], park0, ivy, 1.0f / ivy}, {s_bins[1], park1, ivs, 1.0f / ivs}};
+        conv1x1_tiles<WM, WN, step_of<WM>(), 0>(a, st, smem);
+    } else {
+        AddStat<HistStat<false>, HistStat<false>, false> st{{s_bins[0], park0, ivy, 1.0f / ivy}, {s_bins[1], park1, ivs, 1.0f / ivs}};
+        conv1x1_tiles<WM, WN, step_of<WM>(), 0>(a, st, smem);
+    }
+    hist_flush<kT>(s_bins[0], hist_y);
+    hist_flush<kT>(s_bins[1], hist_sum);
 }
 
 // TestConv / TestLinear's forward in one kernel: convolution + bias, then QuanDequan on the accumulator's way out
@@ -579,12 +610,15 @@ extern "C" int fq_conv_kxk_f32(const float* x, const float* wt, const float* bia
 // The last 1x1 convolution of a residual block together with the Eltwise (fabu_layer.py:5-11) and the ReLU behind it:
 // y = conv(x) + bias (abs-max -> *max_y; written to y unless y is null), sum = y + res (abs-max -> *max_sum; written unless
 // sum is null), relu_out = max(sum, 0).  Bit for bit what fq_conv1x1_f32 followed by fq_add_absmax_f32 leave.
-extern "C" int fq_conv1x1_add_f32(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
-                                  float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y,
-                                  float* max_sum, fq_stream_t stream) {
+static int conv_add_launch(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
+                           float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y, float* max_sum,
+                           const float* interval_y, int64_t* hist_y, const float* interval_sum, int64_t* hist_sum,
+                           fq_stream_t stream) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1) return FQ_ERR_INVALID_ARG;
     if (N == 0) return FQ_OK;
-    if (!x || !wt || !res || !relu_out || !max_y || !max_sum) return FQ_ERR_INVALID_ARG;
+    const bool hist = hist_y != nullptr;
+    if (!x || !wt || !res || !relu_out) return FQ_ERR_INVALID_ARG;
+    if (hist ? (!hist_sum || !interval_y || !interval_sum || hist_y == hist_sum) : (!max_y || !max_sum)) return FQ_ERR_INVALID_ARG;
     if ((Cin % kBK) != 0 || (Cout % 128) != 0 || (reinterpret_cast<uintptr_t>(wt) & 15u)) return FQ_ERR_UNSUPPORTED;
     const int Hout = (Hin - 1) / stride + 1, Wout = (Win - 1) / stride + 1;
     const size_t cols = (size_t)N * Hout * Wout;
@@ -598,7 +632,10 @@ extern "C" int fq_conv1x1_add_f32(const float* x, const float* wt, const float* 
     a.Hin = Hin; a.R = 1; a.S = 1; a.pad = 0;
     a.cols = (unsigned)cols;
     a.x_bytes = (unsigned)(in_elems * 4); a.w_bytes = (unsigned)(w_elems * 4); a.y_bytes = (unsigned)(out_elems * 4);
-    a.stream_stores = out_elems * (size_t)(8 + (y ? 4 : 0) + (sum ? 4 : 0)) > ((size_t)256 << 20);      // beyond the Infinity Cache
+    // non-temporal accesses beyond the Infinity Cache -- but only where a plane is a whole number of 64-byte blocks: the runs of
+    // 128 bytes a wave stores are then whole blocks, and anything else streamed past the L2 becomes partial writes
+    // (scripts/conv_add_bench.py: 256 -> 1024 @14x14, both tensors kept, 356 us with default stores, 486 with nt)
+    a.stream_stores = out_elems * (size_t)(8 + (y ? 4 : 0) + (sum ? 4 : 0)) > ((size_t)256 << 20) && (a.HWout % 16u) == 0;
     { const char* e = getenv("FQ_CONV_ADD_STREAM"); if (e && e[0]) a.stream_stores = atoi(e); }
 #ifdef FQ_C1_ABLATE
     a.ablate = 0;
@@ -607,19 +644,54 @@ extern "C" int fq_conv1x1_add_f32(const float* x, const float* wt, const float* 
     const size_t tiles22 = ((cols + 127) / 128) * (size_t)(Cout / 128);
     const bool narrow = forced ? forced == 12 : tiles22 <= (size_t)kCUs * 4;
     hipStream_t st = as_stream(stream);
-    if (narrow) {
-        a.tiles_m = (unsigned)Cout / 64u;
-        a.tiles = (unsigned)((cols + 127) / 128) * a.tiles_m;
+    a.tiles_m = (unsigned)Cout / (narrow ? 64u : 128u);
+    a.tiles = (unsigned)((cols + 127) / 128) * a.tiles_m;
+    if (hist) {
+        static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
+        static const int res12 = [] {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_f32_add_hist_kernel<1, 2>, kT, 0) != hipSuccess || n < 1) n = 1;
+            return n;
+        }();
+        static const int res22 = [] {
+            int n = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv1x1_f32_add_hist_kernel<2, 2>, kT, 0) != hipSuccess || n < 1) n = 1;
+            return n;
+        }();
+        unsigned grid = (unsigned)kCUs * (unsigned)(narrow ? res12 : res22);
+        if (grid > a.tiles) grid = a.tiles;
+        unsigned long long* hy = reinterpret_cast<unsigned long long*>(hist_y);
+        unsigned long long* hs = reinterpret_cast<unsigned long long*>(hist_sum);
+        if (narrow)
+            hipLaunchKernelGGL((conv1x1_f32_add_hist_kernel<1, 2>), dim3(grid), dim3(kT), 0, st, a, interval_y, hy, interval_sum, hs, fast);
+        else
+            hipLaunchKernelGGL((conv1x1_f32_add_hist_kernel<2, 2>), dim3(grid), dim3(kT), 0, st, a, interval_y, hy, interval_sum, hs, fast);
+    } else if (narrow) {
         hipLaunchKernelGGL((conv1x1_f32_add_absmax_kernel<1, 2>), dim3(a.tiles), dim3(kT), 0, st, a,
                            reinterpret_cast<unsigned int*>(max_y), reinterpret_cast<unsigned int*>(max_sum));
     } else {
-        a.tiles_m = (unsigned)Cout / 128u;
-        a.tiles = (unsigned)((cols + 127) / 128) * a.tiles_m;
         hipLaunchKernelGGL((conv1x1_f32_add_absmax_kernel<2, 2>), dim3(a.tiles), dim3(kT), 0, st, a,
                            reinterpret_cast<unsigned int*>(max_y), reinterpret_cast<unsigned int*>(max_sum));
     }
     FQ_LAUNCH_CHECK();
     return FQ_OK;
+}
+
+extern "C" int fq_conv1x1_add_f32(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
+                                  float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y,
+                                  float* max_sum, fq_stream_t stream) {
+    return conv_add_launch(x, wt, bias, res, y, sum, relu_out, N, Cin, Hin, Win, Cout, stride, max_y, max_sum, nullptr, nullptr,
+                           nullptr, nullptr, stream);
+}
+
+// The same chain in calibration pass 2: the convolution's output and the sum are histogrammed (2048 bins each, rows hist_y and
+// hist_sum with their interval widths) while they pass through the registers and are not written at all; relu_out = max(sum, 0).
+extern "C" int fq_conv1x1_add_hist_f32(const float* x, const float* wt, const float* bias, const float* res, float* relu_out,
+                                       int N, int Cin, int Hin, int Win, int Cout, int stride, const float* interval_y,
+                                       int64_t* hist_y, const float* interval_sum, int64_t* hist_sum, fq_stream_t stream) {
+    if (!hist_y) return FQ_ERR_INVALID_ARG;
+    return conv_add_launch(x, wt, bias, res, nullptr, nullptr, relu_out, N, Cin, Hin, Win, Cout, stride, nullptr, nullptr, interval_y,
+                           hist_y, interval_sum, hist_sum, stream);
 }
 
 // TestConv.forward (new_quantity_op.py:283-292) / TestLinear.forward (:248-256 on the classifier seen as a 1x1 layer) in one

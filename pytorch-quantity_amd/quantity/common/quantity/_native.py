@@ -108,6 +108,8 @@ def lib():
     L.fq_read_npy_batch_f32.argtypes = [vp, ci, ctypes.c_char_p, ctypes.c_size_t, vp, ctypes.c_size_t, ci, vp]
     L.fq_conv1x1_add_f32.restype = ci
     L.fq_conv1x1_add_f32.argtypes = [vp] * 7 + [ci] * 6 + [vp, vp, vp]
+    L.fq_conv1x1_add_hist_f32.restype = ci
+    L.fq_conv1x1_add_hist_f32.argtypes = [vp] * 5 + [ci] * 6 + [vp, vp, vp, vp, vp]
     L.fq_conv1x1_qd_f32.restype = ci
     L.fq_conv1x1_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 8 + [vp]
     L.fq_conv_kxk_qd_f32.restype = ci
@@ -407,6 +409,25 @@ def conv1x1_add_f32(x, wt, bias, stride, res, max_dev, row_y, row_sum, relu_out,
                                     None if out is None else out.data_ptr(), None if sum_out is None else sum_out.data_ptr(),
                                     relu_out.data_ptr(), N, Cin, H, W, Cout, s, max_dev.data_ptr() + 4 * int(row_y),
                                     max_dev.data_ptr() + 4 * int(row_sum), _stream(x)), "fq_conv1x1_add_f32")
+    return relu_out
+
+
+def conv1x1_add_hist_f32(x, wt, bias, stride, res, interval_dev, hist_dev, row_y, row_sum, relu_out):
+    """fq_conv1x1_add_hist_f32: the chain of conv1x1_add_f32 in pass 2 -- v = conv(x) + bias counted into hist_dev[row_y], s = v + res
+    into hist_dev[row_sum] (bin widths interval_dev[row]); neither is written; relu_out receives max(s, 0).  Returns relu_out."""
+    for t in (x, wt, bias, res, relu_out):
+        _need_cuda(t, torch.float32, "fq_conv1x1_add_hist_f32")
+    assert x.dim() == 4 and x.is_contiguous() and wt.dim() == 2 and wt.is_contiguous() and wt.shape[0] == x.shape[1]
+    N, Cin, H, W = (int(v) for v in x.shape)
+    Cout, s = int(wt.shape[1]), int(stride)
+    shape = (N, Cout, (H - 1) // s + 1, (W - 1) // s + 1)
+    assert bias.is_contiguous() and bias.numel() == Cout and row_y != row_sum
+    for t in (res, relu_out):
+        assert tuple(t.shape) == shape and t.is_contiguous()
+    ivy, hy = _hist_row_ptrs(interval_dev, hist_dev, row_y)
+    ivs, hs = _hist_row_ptrs(interval_dev, hist_dev, row_sum)
+    _check(lib().fq_conv1x1_add_hist_f32(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(), relu_out.data_ptr(),
+                                         N, Cin, H, W, Cout, s, ivy, hy, ivs, hs, _stream(x)), "fq_conv1x1_add_hist_f32")
     return relu_out
 
 

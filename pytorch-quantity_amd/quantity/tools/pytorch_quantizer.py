@@ -220,7 +220,7 @@ class _HookState(object):
     The rest are counters for Quantity.timings."""
     __slots__ = ("stop_after", "events", "eager", "fuse_bias", "fuse_collector", "fuse_off", "fuse_verified", "fuse_warm",
                  "relu_after", "relu_ready", "last_out", "fused_relus", "fuse_stat", "hist_fused", "keep_feats", "keep_names",
-                 "own_plain", "own_conv1x1", "deferred", "defer_ok", "deferred_adds", "poison")
+                 "own_plain", "own_conv1x1", "deferred", "defer_ok", "deferred_adds", "deferred_hists", "poison")
 
     def __init__(self):
         self.stop_after = None          # ordinal of the last module pass 2 needs (the hook raises _StopForward there)
@@ -244,7 +244,8 @@ class _HookState(object):
         self.deferred = {}              # id(output) -> (output, conv, x, key, row, version): convolutions whose kernel has not
         #                                 run yet -- each runs inside the launch of the Eltwise that consumes it
         self.defer_ok = {}              # conv module -> its Eltwise, proven by the poison probe (_prove_deferral)
-        self.deferred_adds = 0
+        self.deferred_adds = 0          # launches of fq_conv1x1_add_f32 (pass 1)
+        self.deferred_hists = 0         # launches of fq_conv1x1_add_hist_f32 (pass 2)
         self.poison = None              # the _DeferralProbe of a running probe forward
 
 
@@ -886,6 +887,10 @@ class Quantity(object):
             return False
         row = coll.row_of(key)
         if ctl.fuse_stat == "hist":                         # pass 2 (verified in pass 1)
+            if (kind == "c1" and self.fuse_conv_add and not self.materialize_all and ctl.defer_ok.get(m) is not None
+                    and ctl.eager is not None):
+                ctl.deferred[id(output)] = (output, m, x, key, row, output._version)       # (see below)
+                return True
             self._run_with_relu(m, output, lambda r: run(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row,
                                                          relu_out=r, out=output))
             ctl.hist_fused += 1
@@ -913,9 +918,13 @@ class Quantity(object):
         if coll is None:
             _float_conv.runner(m, "c1", x)(out=output)
             return
-        _float_conv.runner(m, "c1", x)(max_dev=coll.max_device, row=row, out=output)
-        coll.note_max_refreshed()
-        ctl.own_conv1x1 = ctl.own_conv1x1 + 1
+        if ctl.fuse_stat == "hist":
+            _float_conv.runner(m, "c1", x)(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row, out=output)
+            ctl.hist_fused += 1
+        else:
+            _float_conv.runner(m, "c1", x)(max_dev=coll.max_device, row=row, out=output)
+            coll.note_max_refreshed()
+            ctl.own_conv1x1 = ctl.own_conv1x1 + 1
         if ctl.eager is not None:
             ctl.eager.note(_key, output)
 
@@ -942,12 +951,22 @@ class Quantity(object):
         # (small planes with BOTH tensors kept: three store streams of partial lines make the one kernel slower than the two,
         #  scripts/conv_add_bench.py: 356 vs 340 us at 14 x 14, 283 vs 276 at 7 x 7)
         small = t3.shape[2] * t3.shape[3] < 28 * 28
-        if (module is not m or coll is None or key is None or ctl.fuse_stat != "max" or ctl.defer_ok.get(conv) is not m
+        hist = ctl.fuse_stat == "hist"
+        if (module is not m or coll is None or key is None or ctl.defer_ok.get(conv) is not m
                 or relu is None or not _flag(m, _FUSION_VERIFIED) or not _flag(m, _RELU_VERIFIED) or t3._version != version
-                or other is t3 or other.shape != t3.shape or (keep_y and keep_s and small)):
+                or other is t3 or other.shape != t3.shape or not other.is_contiguous()
+                or (m not in ctl.fuse_verified if hist else (keep_y and keep_s and small))):
             self._run_deferred(d)
             return False
         r = torch.empty_like(t3)
+        if hist:                                                # pass 2: both histograms, neither tensor written
+            _native.conv1x1_add_hist_f32(x, _float_conv.weight(conv, "c1"), conv.bias, conv.stride[0], other, coll.interval_device,
+                                         coll.hist_device, conv_row, coll.row_of(key), r)
+            ctl.hist_fused += 2
+            ctl.relu_ready = (output, r, relu, output._version)
+            ctl.fused_relus.add(relu)
+            ctl.deferred_hists += 1
+            return True
         _native.conv1x1_add_f32(x, _float_conv.weight(conv, "c1"), conv.bias, conv.stride[0], other, coll.max_device, conv_row,
                                 coll.row_of(key), r, out=t3 if keep_y else None, sum_out=output if keep_s else None)
         coll.note_max_refreshed()
@@ -1491,6 +1510,7 @@ class Quantity(object):
                         "fused_hist_launches": ctl.hist_fused,
                         "own_conv1x1_launches": ctl.own_conv1x1,
                         "conv_add_chains_proven": len(ctl.defer_ok), "conv_add_launches": ctl.deferred_adds,
+                        "conv_add_hist_launches": ctl.deferred_hists,
                         "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}
@@ -1623,6 +1643,9 @@ class Quantity(object):
                 state["n"] = 0
             elif ctl.stop_after is not None and state["n"] >= ctl.stop_after:
                 state["n"] = 0
+                waiting_convs, ctl.deferred = ctl.deferred, {}
+                for d in waiting_convs.values():               # (the forward ends between a convolution and its Eltwise)
+                    self._run_deferred(d)
                 raise _StopForward()
 
         for m in model.modules():

@@ -79,6 +79,11 @@ def test_tables_do_not_depend_on_the_fusion_nor_on_what_the_cache_keeps(monkeypa
     assert got[4]["conv_add_chains_proven"] == 2               # both blocks' (c3, add, r3)
     # every forward of pass 1 takes both chains, except the one in which the Eltwise modules have their first, checked use
     assert got[4]["conv_add_launches"] in (2 * 4, 2 * 5)
+    # pass 2: both chains of every forward it re-runs in full (no cache: all five; plan A with 70 MB: the batches that did not
+    # fit; everything kept: no forward at all); plan B re-runs a prefix, which may end inside a block
+    redo = {("0", ""): (10,), ("1", "A"): (0,), ("0.07", "A"): (6,), ("1", "B"): (0,), ("0.05", "B"): (0, 5, 10)}[(cache_gb, plan)]
+    assert got[4]["conv_add_hist_launches"] in redo, got[4]
+    assert want[4]["conv_add_hist_launches"] == 0
     if plan:
         assert got[4]["cache_plan"]["kind"] == plan and got[4]["cache_bytes"] > 0
         assert (got[4]["cache_bytes"] < 100e6) == (cache_gb != "1")      # (a batch's hooked tensors are 30 MB: partial caches are partial)
@@ -94,7 +99,7 @@ def test_small_planes_with_both_tensors_kept_stay_on_the_two_kernels(monkeypatch
     assert got[4]["conv_add_chains_proven"] == 2 and got[4]["conv_add_launches"] == 0
     assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
     cold = _calibrate(model, True, "0", "", monkeypatch=monkeypatch, hw=16)
-    assert cold[4]["conv_add_launches"] == 2 * 5
+    assert cold[4]["conv_add_launches"] == 2 * 5 and cold[4]["conv_add_hist_launches"] == 2 * 5
     assert cold[1] == want[1] and cold[2] == want[2] and torch.equal(cold[3], want[3])
 
 

@@ -549,6 +549,35 @@ def test_conv_add_relu_in_one_kernel_equals_the_two_kernels(nat, shape):
     assert float(m1[1]) == 1e9 and float(m1[3]) == float(m2[3]) and float(m1[0]) == 0.0 and float(m1[2]) == 0.0
 
 
+@pytest.mark.parametrize("shape", [(3, 64, 13, 9, 256, 1), (2, 32, 28, 28, 128, 1), (5, 256, 7, 7, 1024, 1), (2, 64, 15, 15, 128, 2),
+                                   (40, 64, 56, 56, 256, 1)], ids=lambda s: "x".join(map(str, s)))
+def test_conv_add_relu_histogram_form_equals_the_two_kernels(nat, shape):
+    """fq_conv1x1_add_hist_f32 (pass 2) leaves the two histogram rows and the ReLU output that fq_conv1x1_f32 (histogram form)
+    followed by fq_add_hist_f32 leave, bit for bit -- on top of counts the rows already hold; intervals inside and outside the
+    fast-quotient range; values beyond the last bin, exact zeros, NaN / Inf."""
+    N, Cin, H, W, Cout, s = shape
+    g = torch.Generator(device="cuda").manual_seed(7 + sum(shape))
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g) * 2
+    x[0, :, 0, 0] = 0.0
+    wt = torch.randn(Cin, Cout, device="cuda", generator=g) * Cin ** -0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    b[0] = 0.0                                                     # (exact zeros in the convolution's output)
+    ho, wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(N, Cout, ho, wo, device="cuda", generator=g) * 3
+    res[0, 0, 0, :4] = torch.tensor([float("nan"), float("inf"), -0.0, -1e30], device="cuda")
+    for ivs in ((0.004, 0.0061), (3e-39, 0.0061), (0.004, 1e-3)):
+        iv = torch.tensor([1.0, ivs[0], 1.0, ivs[1]], device="cuda")
+        h2 = torch.arange(4 * 2048, device="cuda", dtype=torch.int64).view(4, 2048) % 7
+        h1 = h2.clone()
+        v = nat.conv1x1_f32(x, wt, b, s, interval_dev=iv, hist_dev=h2, row=1)
+        r2 = torch.empty_like(v)
+        nat.add_hist(v, res, iv, h2, 3, relu_out=r2)
+        r1 = torch.full_like(v, 777.0)
+        assert nat.conv1x1_add_hist_f32(x, wt, b, s, res, iv, h1, 1, 3, r1) is r1
+        assert torch.equal(h1, h2)
+        assert torch.equal(r1.view(torch.int32), r2.view(torch.int32))
+
+
 def test_conv_add_argument_errors(nat):
     x = torch.zeros(1, 16, 4, 4, device="cuda")
     r = torch.zeros(1, 128, 4, 4, device="cuda")
