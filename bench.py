@@ -178,8 +178,8 @@ class CallTimer(object):
     """Wraps a _native entry point and brackets every call with HIP events on the launch stream (torch's current
     stream is the stream the C ABI is handed).  bytes_fn(args, kwargs) -> algorithmic bytes of that launch."""
 
-    def __init__(self, native, name, bytes_fn, flops_fn=None):
-        self.native, self.name, self.bytes_fn, self.flops_fn = native, name, bytes_fn, flops_fn
+    def __init__(self, native, name, bytes_fn, flops_fn=None, form=None):
+        self.native, self.name, self.bytes_fn, self.flops_fn, self.form = native, name, bytes_fn, flops_fn, form
         self.orig = getattr(native, name)
         self.events, self.bytes, self.flops, self.forms = [], [], [], []
         self.enabled = False
@@ -196,7 +196,8 @@ class CallTimer(object):
             self.bytes.append(float(self.bytes_fn(a, k)))
             if self.flops_fn is not None:
                 self.flops.append(float(self.flops_fn(a, k)))
-                self.forms.append("hist" if k.get("hist_dev") is not None else ("absmax" if k.get("max_dev") is not None else "plain"))
+                self.forms.append(self.form or ("hist" if k.get("hist_dev") is not None else
+                                                ("absmax" if k.get("max_dev") is not None else "plain")))
             return r
         setattr(self.native, self.name, wrapped)
         return self
@@ -241,6 +242,12 @@ def _c1_flops(a, k):                # conv1x1_f32(x, wt, bias, stride, ...): 2 x
 def _c1_bytes(a, k):                # x read once, Wt, y written (+ the ReLU copy)
     n, cin, cout, ho, wo = _c1_shape(a, k)
     return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
+
+
+def _c1_add_bytes(a, k):            # conv1x1_add_f32(x, wt, bias, stride, res, ...): x, Wt and the shortcut read, the ReLU output
+    n, cin, cout, ho, wo = _c1_shape(a, k)          # written, the convolution's output and the sum only when they are kept
+    kept = (1 if k.get("out") is not None else 0) + (1 if k.get("sum_out") is not None else 0)
+    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 + kept))
 
 
 def _stem_shape(a, k):              # conv_stem_f32(x, wp, bias, cout, kernel, stride, pad, ...)
@@ -721,12 +728,15 @@ def main():
                 CallTimer(_native, "bias_add_hist", _bias_add_bytes) as kt_bh, CallTimer(_native, "add_hist", _add_bytes) as kt_ah, \
                 CallTimer(_native, "conv1x1_f32", _c1_bytes, _c1_flops) as kt_c1, \
                 CallTimer(_native, "conv_stem_f32", _stem_bytes, _stem_flops) as kt_st, \
-                CallTimer(_native, "conv_kxk_f32", _kxk_bytes, _kxk_flops) as kt_kk:
+                CallTimer(_native, "conv_kxk_f32", _kxk_bytes, _kxk_flops) as kt_kk, \
+                CallTimer(_native, "conv1x1_add_f32", _c1_add_bytes, _c1_flops, "absmax") as kt_ca, \
+                CallTimer(_native, "conv1x1_add_hist_f32", _c1_add_bytes, _c1_flops, "hist") as kt_cah:
             make_workdir(3 * world - 1, shape, dev_index)
             extra = DeviceBatches(3 * world, B, HW, rank, world, device)
             eq = Quantity(model)
             eq._activation_cache_budget = lambda: 0          # every batch through the second forward: all 69 producers fused
             kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = kt_c1.enabled = kt_st.enabled = kt_kk.enabled = True
+            kt_ca.enabled = kt_cah.enabled = True
             eq.activation_quantize(extra)
             torch.cuda.synchronize()
             del extra, eq
@@ -757,6 +767,16 @@ def main():
                     c1["pass1_absmax_form" if form == "absmax" else "pass2_hist_form"] = {
                         k: part[k] for k in ("achieved", "frac", "launches", "mean_launch_ms", "frac_of_bound")}
             result["roofline_conv1x1_f32"] = c1
+        for key, kt, kernel in (("roofline_conv1x1_add_f32", kt_ca, "conv1x1_f32_add_absmax_kernel"),
+                                ("roofline_conv1x1_add_hist_f32", kt_cah, "conv1x1_f32_add_hist_kernel")):
+            ca = mfma_f32_roofline(
+                kernel, kt,
+                "the last 1x1 convolution of each of the 16 residual blocks with the Eltwise that adds the shortcut and the ReLU behind "
+                "it in the same kernel (both tensors' statistic in the epilogue; neither written when pass 2 keeps neither): 8 bytes "
+                "per output element instead of the 20 the two kernels move; most of these launches are HBM bound even at the "
+                "matrix peak, so read frac_of_bound and hbm_gbs, not frac")
+            if ca:
+                result[key] = ca
         stem = mfma_f32_roofline(
             "conv_stem_f32_absmax_kernel / conv_stem_f32_hist_kernel", kt_st,
             "the float forward's 7x7 stride-2 stem (0.118 GMAC per image) as an implicit GEMM on v_mfma_f32_32x32x2_f32, taps padded "

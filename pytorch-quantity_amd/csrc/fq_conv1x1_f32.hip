@@ -30,6 +30,9 @@
 #include "fq_common.h"
 #include "fq_producer_stat.h"
 
+#include <map>
+#include <mutex>
+
 namespace fq {
 namespace {
 
@@ -55,6 +58,12 @@ struct C1Args {
     unsigned cols;            // N * HWout
     unsigned tiles_m, tiles;
     int stream_stores;
+    // The tail split (plan_split): tiles >= split_first are computed by split_s workgroups each, one K slice per workgroup;
+    // the partial accumulators meet in `ws` and the workgroup that arrives last (ws_count) sums them in slice order and
+    // runs the epilogue.  work = split_first + (tiles - split_first) * split_s items; no split: split_first = tiles.
+    unsigned split_first, split_s, work;
+    float* ws;
+    unsigned* ws_count;
 #ifdef FQ_C1_ABLATE
     int ablate;               // debug build only (scripts/conv1x1_ablate.py): 1 no stores, 2 global loads of the first K step only, 4 no barriers (wrong results)
 #endif
@@ -200,7 +209,8 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
     const unsigned m0 = (wave >> 1) * (32u * WM), n0 = (wave & 1u) * (32u * WN);
     // Workgroup g runs on XCD g % 8, each with its own L2: give an XCD a contiguous run of tiles, so the m-tiles that
     // share one x tile (and the column tiles that share one W tile) meet in the same L2.
-    const unsigned G = gridDim.x, G8 = G & ~7u, g = blockIdx.x;
+    // (the K slices of the tail split keep their launch order: they are the last workgroups to start, spread over all XCDs)
+    const unsigned G = gridDim.x, G8 = (G < a.split_first ? G : a.split_first) & ~7u, g = blockIdx.x;
     const unsigned v0 = g < G8 ? (g & 7u) * (G8 >> 3) + (g >> 3) : g;
     const unsigned xc = tid % BN, xk = tid / BN;              // x tile: this thread's column, rows xk + kXStep * i
     const unsigned wr = tid / (BM / 4), wc = (tid % (BM / 4)) * 4u;   // W tile: rows wr + kWRowStep * i, columns wc .. wc + 3
@@ -234,7 +244,16 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
     float* const ww0 = Ws + wr * BM + wc;                     // W tile stores:   + (stage * BK + kWRowStep * i) * BM
     float* const xw0 = Xs + xk * BN + xc;                     // x tile stores:   + (stage * BK + kXStep * i) * BN
 
-    for (unsigned t = v0; t < a.tiles; t += G) {
+    for (unsigned wi = v0; wi < a.work; wi += G) {
+        unsigned t = wi, ks_begin = 0, ks_end = nk, slice = 0;
+        const bool split = wi >= a.split_first;                // uniform
+        if (split) {
+            const unsigned rr = (wi - a.split_first) / a.split_s;
+            slice = (wi - a.split_first) - rr * a.split_s;
+            t = a.split_first + rr;
+            ks_begin = slice * nk / a.split_s;
+            ks_end = (slice + 1u) * nk / a.split_s;
+        }
         const unsigned ct = t / a.tiles_m, mt = t - ct * a.tiles_m;
         const unsigned mbase = mt * BM, jbase = ct * BN;
         // Loads never leave the tensors: a column past the end re-reads the last one, a W column past Cout the last four
@@ -260,6 +279,12 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
                 iy0 = (int)(oh * a.stride) - a.pad;
                 ix0 = (int)(ow * a.stride) - a.pad;
                 nbase = n * a.Cin * a.HWin;
+                if (ks_begin) {                               // a K slice starts inside the tap sequence
+                    const unsigned per_tap = a.Cin / BK, tap = ks_begin / per_tap;
+                    ld_r = (int)(tap / (unsigned)a.S);
+                    ld_s = (int)(tap - (unsigned)ld_r * (unsigned)a.S);
+                    ld_kb = (ks_begin - tap * per_tap) * BK;
+                }
                 tap_offsets();
             } else {
                 unsigned pin = p;
@@ -332,10 +357,10 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
         // had finished before it could pass the barrier of step s - 1; and what is read at the start of step s + 1 was
         // complete half a step earlier.  So no wave waits for data at a step boundary: the first operands of the next
         // step are fetched under the last MFMAs of this one, and the MFMA stream of a wave does not stop between steps.
-        gload(0);
+        gload(ks_begin * BK);
         if (tid < (unsigned)BM) s_bias[tid] = (a.bias && mbase + tid < a.Cout) ? a.bias[mbase + tid] : 0.0f;
         lstore(Stage<0>{});
-        if (nk > 1) gload(BK);
+        if (ks_begin + 1 < ks_end) gload((ks_begin + 1) * BK);
         __syncthreads();
         float fa[2][WM], fb[2][WN];                           // operands of this and of the next k pair
 #pragma unroll
@@ -344,13 +369,13 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
         for (int ni = 0; ni < WN; ++ni) fb[0][ni] = xrd[ni][0];
         auto kstep = [&](auto stage, unsigned ks) {
             constexpr int cur = decltype(stage)::value, nxt = (cur + 1) % 3;
-            const bool more = ks + 1 < nk;
+            const bool more = ks + 1 < ks_end;
 #pragma unroll
             for (int kk = 0; kk < BK; kk += 2) {
                 const int c = (kk >> 1) & 1, nx = c ^ 1;
                 if (kk == BK / 2 && more) {
                     lstore(Stage<nxt>{});
-                    if (ks + 2 < nk && !FQ_C1_OFF(2)) gload((ks + 2) * BK);
+                    if (ks + 2 < ks_end && !FQ_C1_OFF(2)) gload((ks + 2) * BK);
                     if (!FQ_C1_OFF(4)) __syncthreads();
                 }
                 if (kk + 2 < BK) {
@@ -373,15 +398,77 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
             }
         };
         static_assert((BK / 2) % 2 == 0, "a K step must hold an even number of k pairs: the operand double buffer starts each step at 0");
-        for (unsigned ks = 0;;) {
+        for (unsigned ks = ks_begin;;) {
             kstep(Stage<0>{}, ks);
-            if (++ks >= nk) break;
+            if (++ks >= ks_end) break;
             kstep(Stage<1>{}, ks);
-            if (++ks >= nk) break;
+            if (++ks >= ks_end) break;
             kstep(Stage<2>{}, ks);
-            if (++ks >= nk) break;
+            if (++ks >= ks_end) break;
         }
-        {
+        bool finish = true;
+        if (split) {
+            // This workgroup holds one K slice of the tile.  Its accumulators go to the workspace; the workgroup of the tile
+            // that gets there last adds all slices up IN SLICE ORDER (so the result does not depend on who was last) and
+            // carries on with the epilogue.  Release / acquire at agent scope as MI355X_MICROARCH.md prescribes for a
+            // counter hand-off: every storing wave waits for its stores, a barrier, one lane releases and adds; the lane
+            // whose add completes the count acquires, a barrier, then plain loads.
+            const unsigned rr = t - a.split_first;
+            constexpr unsigned kTileFloats = (unsigned)(BM * BN);
+            float* const mine = a.ws + ((size_t)rr * a.split_s + slice) * kTileFloats;
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f4v v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                        *reinterpret_cast<f4v*>(mine + ((((mi * WN + ni) * 4 + q) * kT) + tid) * 4u) = v;
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            __shared__ unsigned s_last;
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned prev = __hip_atomic_fetch_add(a.ws_count + rr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned last = prev + 1u == a.split_s;
+                if (last) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(a.ws_count + rr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                }
+                s_last = last;
+            }
+            __syncthreads();
+            finish = s_last != 0u;                            // uniform
+            if (finish) {
+                if (wave != 0) {                              // (wave 0's lane 0 made the acquire: its L1 is this CU's L1 -- one
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   //  invalidate per CU would do, one per wave is cheap here)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+                for (unsigned sl = 0; sl < a.split_s; ++sl) {
+                    const float* part = a.ws + ((size_t)rr * a.split_s + sl) * kTileFloats;
+#pragma unroll
+                    for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f4v v = *reinterpret_cast<const f4v*>(part + ((((mi * WN + ni) * 4 + q) * kT) + tid) * 4u);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) acc[mi][ni][4 * q + c] += v[c];
+                            }
+                }
+            }
+        }
+        if (finish) {
             const bool full_m = mbase + BM <= a.Cout;
 #ifdef FQ_C1_ABLATE
             if (FQ_C1_OFF(1)) {
@@ -496,14 +583,67 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(3))) void co
     hist_flush<kT>(s_bins, hist_row);
 }
 
+int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return (e && e[0]) ? atoi(e) : dflt;
+}
+
+// The tail split.  A launch of T tiles on 256 CUs takes ceil(T / 256) tile times on the busiest CU: 784 tiles (3.06 per CU) cost
+// what 1 024 would (scripts/_dbg/conv_balance_probe.py: 512 -> 512 3x3 @7x7 takes 449 us at 250 images = 3.00 tiles per CU and
+// 568 us at 252 = 3.03).  So the T mod 256 tiles of the last, partly filled round are cut along K into 256 / (T mod 256)
+// slices each: the tail becomes one more FULL round of short workgroups, 3.06 tile times instead of 4.  The slices meet in
+// a workspace (conv1x1_tiles); the summation order is fixed, and which tiles are split is a function of the layer's shape
+// alone, the same for every form of the kernel -- so a value does not depend on the statistic that rides on it.
+struct SplitWs {
+    float* ws = nullptr;
+    unsigned* count = nullptr;
+};
+constexpr unsigned kSplitMaxItems = 256, kSplitMaxSlices = 16;
+
+SplitWs split_workspace(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<hipStream_t, SplitWs> per_stream;         // (launches on different streams may overlap)
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = per_stream.find(st);
+    if (it != per_stream.end()) return it->second;
+    SplitWs w;
+    void* p = nullptr;
+    const size_t bytes = (size_t)kSplitMaxItems * 128 * 128 * sizeof(float);
+    if (hipMalloc(&p, bytes + kSplitMaxItems * sizeof(unsigned)) == hipSuccess) {
+        w.ws = static_cast<float*>(p);
+        w.count = reinterpret_cast<unsigned*>(static_cast<char*>(p) + bytes);
+        if (hipMemsetAsync(w.count, 0, kSplitMaxItems * sizeof(unsigned), st) != hipSuccess) w = SplitWs();
+    } else {
+        (void)hipGetLastError();
+    }
+    per_stream[st] = w;
+    return w;
+}
+
+void plan_split(C1Args& a, unsigned nk, hipStream_t st) {
+    a.split_first = a.tiles; a.split_s = 1; a.work = a.tiles; a.ws = nullptr; a.ws_count = nullptr;
+    static const int on = env_int("FQ_CONV_TAIL_SPLIT", 1);
+    const unsigned rounds = a.tiles / (unsigned)kCUs, rem = a.tiles % (unsigned)kCUs;
+    if (!on || rounds == 0 || rounds >= 16 || rem == 0 || rem > (unsigned)kCUs / 2) return;
+    unsigned s = (unsigned)kCUs / rem;
+    if (s > kSplitMaxSlices) s = kSplitMaxSlices;
+    if (s > nk / 8) s = nk / 8;                               // at least 8 K steps per slice
+    if (s < 2) return;
+    const SplitWs w = split_workspace(st);
+    if (!w.ws) return;
+    a.split_first = a.tiles - rem; a.split_s = s; a.work = a.split_first + rem * s; a.ws = w.ws; a.ws_count = w.count;
+}
+
 template <int WM, int WN, int kTailK>
 void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, int64_t* hist_row, int hist_per_cu, int fast,
             const QdStat* qd, hipStream_t st) {
     typedef Shape<WM, WN> S;
     a.tiles_m = (a.Cout + S::BM - 1) / S::BM;
     a.tiles = ((cols + S::BN - 1) / S::BN) * a.tiles_m;
+    constexpr unsigned BK = (unsigned)step_of<WM>();
+    plan_split(a, kTailK == 2 ? (unsigned)(a.R * a.S) * (a.Cin / BK) : (a.Cin + BK - 1) / BK, st);
     if (qd) {
-        hipLaunchKernelGGL((conv1x1_f32_qd_kernel<WM, WN, kTailK>), dim3(a.tiles), dim3(kT), 0, st, a, *qd);
+        hipLaunchKernelGGL((conv1x1_f32_qd_kernel<WM, WN, kTailK>), dim3(a.work), dim3(kT), 0, st, a, *qd);
     } else if (hist_row) {
         // every workgroup flushes up to 2048 bins with 64-bit atomics at its end: a persistent grid of exactly the
         // workgroups the chip holds at once (LDS: three stages + 8 KB of bins), each taking every grid-th tile
@@ -513,20 +653,15 @@ void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, in
             return n;
         }();
         unsigned grid = (unsigned)kCUs * (unsigned)(hist_per_cu > 0 ? hist_per_cu : resident);
-        if (grid > a.tiles) grid = a.tiles;
+        if (grid > a.work) grid = a.work;
         hipLaunchKernelGGL((conv1x1_f32_hist_kernel<WM, WN, step_of<WM>(), kTailK>), dim3(grid), dim3(kT), 0, st, a, interval,
                            reinterpret_cast<unsigned long long*>(hist_row), fast);
     } else if (max_inout) {
-        hipLaunchKernelGGL((conv1x1_f32_absmax_kernel<WM, WN, kTailK>), dim3(a.tiles), dim3(kT), 0, st, a,
+        hipLaunchKernelGGL((conv1x1_f32_absmax_kernel<WM, WN, kTailK>), dim3(a.work), dim3(kT), 0, st, a,
                            reinterpret_cast<unsigned int*>(max_inout));
     } else {
-        hipLaunchKernelGGL((conv1x1_f32_kernel<WM, WN, kTailK>), dim3(a.tiles), dim3(kT), 0, st, a);
+        hipLaunchKernelGGL((conv1x1_f32_kernel<WM, WN, kTailK>), dim3(a.work), dim3(kT), 0, st, a);
     }
-}
-
-int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return (e && e[0]) ? atoi(e) : dflt;
 }
 
 }  // namespace
@@ -565,6 +700,7 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     a.w_bytes = (unsigned)(w_elems * 4);
     a.y_bytes = (unsigned)(out_elems * 4);
     a.tiles_m = a.tiles = 0;
+    a.split_first = a.split_s = a.work = 0; a.ws = nullptr; a.ws_count = nullptr;
     a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);       // beyond the Infinity Cache
 #ifdef FQ_C1_ABLATE
     a.ablate = env_int("FQ_C1_ABLATE", 0);
@@ -646,6 +782,7 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
     hipStream_t st = as_stream(stream);
     a.tiles_m = (unsigned)Cout / (narrow ? 64u : 128u);
     a.tiles = (unsigned)((cols + 127) / 128) * a.tiles_m;
+    plan_split(a, (unsigned)Cin / (unsigned)(narrow ? step_of<1>() : step_of<2>()), st);
     if (hist) {
         static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
         static const int res12 = [] {
@@ -659,7 +796,7 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
             return n;
         }();
         unsigned grid = (unsigned)kCUs * (unsigned)(narrow ? res12 : res22);
-        if (grid > a.tiles) grid = a.tiles;
+        if (grid > a.work) grid = a.work;
         unsigned long long* hy = reinterpret_cast<unsigned long long*>(hist_y);
         unsigned long long* hs = reinterpret_cast<unsigned long long*>(hist_sum);
         if (narrow)
@@ -667,10 +804,10 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
         else
             hipLaunchKernelGGL((conv1x1_f32_add_hist_kernel<2, 2>), dim3(grid), dim3(kT), 0, st, a, interval_y, hy, interval_sum, hs, fast);
     } else if (narrow) {
-        hipLaunchKernelGGL((conv1x1_f32_add_absmax_kernel<1, 2>), dim3(a.tiles), dim3(kT), 0, st, a,
+        hipLaunchKernelGGL((conv1x1_f32_add_absmax_kernel<1, 2>), dim3(a.work), dim3(kT), 0, st, a,
                            reinterpret_cast<unsigned int*>(max_y), reinterpret_cast<unsigned int*>(max_sum));
     } else {
-        hipLaunchKernelGGL((conv1x1_f32_add_absmax_kernel<2, 2>), dim3(a.tiles), dim3(kT), 0, st, a,
+        hipLaunchKernelGGL((conv1x1_f32_add_absmax_kernel<2, 2>), dim3(a.work), dim3(kT), 0, st, a,
                            reinterpret_cast<unsigned int*>(max_y), reinterpret_cast<unsigned int*>(max_sum));
     }
     FQ_LAUNCH_CHECK();

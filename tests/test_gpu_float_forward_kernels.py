@@ -19,6 +19,9 @@ pytestmark = pytest.mark.gpu
 
 # N, Cin, Cout, H, W, stride
 SHAPES = [
+    (9, 256, 640, 28, 28, 1),     # tail split: 560 narrow tiles = 2 rounds of 256 + 48, each of the 48 cut into 2 K slices
+    (130, 256, 1024, 8, 16, 1),   # tail split: 1 040 tiles of 128 x 128, the last 16 cut into 4 K slices
+    (256, 2048, 512, 7, 7, 1),    # ResNet-50 layer4 conv1 at the bench's batch: 784 tiles, the last 16 in 16 slices
     (2, 64, 64, 56, 56, 1),       # the narrow 64 x 256 tile
     (3, 64, 256, 28, 28, 1),      # 128 x 128 tiles, 2352 columns = 18.4 tiles
     (5, 256, 64, 14, 14, 1),
@@ -268,6 +271,8 @@ def test_a_module_that_disagrees_keeps_the_library_convolution(monkeypatch):
 # ---------------------------------------------------------------------------------------------------------------------
 # fq_conv_kxk_f32: R x S taps with zero padding through the same kernel (ResNet's 3x3 layers)
 KXK_SHAPES = [  # N, Cin, Cout, H, W, R, S, stride, pad
+    (11, 64, 256, 28, 28, 3, 3, 1, 1),   # tail split: 272 narrow tiles, the last 16 cut into 4 K slices (a slice starts inside a tap)
+    (256, 512, 512, 7, 7, 3, 3, 1, 1),   # ResNet-50 layer4 conv2 at the bench's batch: 784 tiles, 16 x 16 slices of 18 K steps
     (2, 64, 64, 56, 56, 3, 3, 1, 1),
     (3, 128, 128, 28, 28, 3, 3, 2, 1),
     (4, 256, 256, 14, 14, 3, 3, 1, 1),
@@ -509,7 +514,8 @@ def test_quandequan_epilogue_equals_the_two_pass_form(nat, bit, bitwidth):
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 13, 9, 256, 1), (2, 32, 28, 28, 128, 1), (5, 256, 7, 7, 1024, 1), (2, 64, 15, 15, 128, 2),
-                                   (40, 64, 56, 56, 256, 1)], ids=lambda s: "x".join(map(str, s)))
+                                   (40, 64, 56, 56, 256, 1), (9, 256, 28, 28, 640, 1), (130, 256, 8, 16, 1024, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
 def test_conv_add_relu_in_one_kernel_equals_the_two_kernels(nat, shape):
     """fq_conv1x1_add_f32 (conv3 + Eltwise + ReLU of a residual block, pass 1) leaves bit for bit what fq_conv1x1_f32 (max
     form) followed by fq_add_absmax_f32 leave -- both maxima, the ReLU output, and each of the two intermediate tensors
@@ -550,7 +556,8 @@ def test_conv_add_relu_in_one_kernel_equals_the_two_kernels(nat, shape):
 
 
 @pytest.mark.parametrize("shape", [(3, 64, 13, 9, 256, 1), (2, 32, 28, 28, 128, 1), (5, 256, 7, 7, 1024, 1), (2, 64, 15, 15, 128, 2),
-                                   (40, 64, 56, 56, 256, 1)], ids=lambda s: "x".join(map(str, s)))
+                                   (40, 64, 56, 56, 256, 1), (9, 256, 28, 28, 640, 1), (130, 256, 8, 16, 1024, 1)],
+                         ids=lambda s: "x".join(map(str, s)))
 def test_conv_add_relu_histogram_form_equals_the_two_kernels(nat, shape):
     """fq_conv1x1_add_hist_f32 (pass 2) leaves the two histogram rows and the ReLU output that fq_conv1x1_f32 (histogram form)
     followed by fq_add_hist_f32 leave, bit for bit -- on top of counts the rows already hold; intervals inside and outside the
