@@ -228,6 +228,10 @@ def _add_bytes(a, k):               # z = x + y (8 B read + 4 B written) (+ 4 B 
     return (12.0 + (4.0 if relu is not None else 0.0)) * int(a[0].numel())
 
 
+def _out_copies(k):                 # y and the ReLU copy; y itself is not written when only its ReLU is read (out=False)
+    return (1 if k.get("out") is not False else 0) + (1 if k.get("relu_out") is not None else 0)
+
+
 def _c1_shape(a, k):
     x, wt = a[0], a[1]
     s = int(k.get("stride", a[3] if len(a) > 3 else 1))
@@ -241,7 +245,7 @@ def _c1_flops(a, k):                # conv1x1_f32(x, wt, bias, stride, ...): 2 x
 
 def _c1_bytes(a, k):                # x read once, Wt, y written (+ the ReLU copy)
     n, cin, cout, ho, wo = _c1_shape(a, k)
-    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
+    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * _out_copies(k))
 
 
 def _c1_add_bytes(a, k):            # conv1x1_add_f32(x, wt, bias, stride, res, ...): x, Wt and the shortcut read, the ReLU output
@@ -263,7 +267,7 @@ def _stem_flops(a, k):
 
 def _stem_bytes(a, k):
     n, cin, cout, ho, wo, taps = _stem_shape(a, k)
-    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
+    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * _out_copies(k))
 
 
 def _kxk_shape(a, k):               # conv_kxk_f32(x, wt, bias, kernel, stride, pad, ...)
@@ -279,7 +283,7 @@ def _kxk_flops(a, k):
 
 def _kxk_bytes(a, k):
     n, cin, cout, ho, wo, taps = _kxk_shape(a, k)
-    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * (2 if k.get("relu_out") is not None else 1))
+    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * _out_copies(k))
 
 
 def mfma_f32_roofline(kernel, kt, note, form=None):

@@ -198,7 +198,9 @@ int fq_add_hist_f32(const float* x, const float* y, float* z, size_t n, const fl
  * wt: the weights TRANSPOSED, fp32 [Cin][Cout], 16-byte aligned, Cout % 4 == 0; bias: fp32 [Cout] or NULL;
  * x: fp32 [N][Cin][Hin][Win] contiguous, < 2^30 elements (FQ_ERR_UNSUPPORTED beyond); y: fp32 [N][Cout][Hout][Wout],
  * Hout = (Hin-1)/stride + 1, < 2^30 elements;
- * relu_out (may be NULL): max(y, 0) as well (the nn.ReLU behind the convolution);
+ * relu_out (may be NULL): max(y, 0) as well (the nn.ReLU behind the convolution); with relu_out given y may be NULL: y is then
+ *   not written (its statistic is still taken) -- for callers that know nothing but that ReLU reads the convolution's output
+ *   (the same holds for fq_conv_kxk_f32 and fq_conv_stem_f32);
  * exactly one of {max_inout, hist_row} may be given (both NULL: plain convolution):
  *   max_inout: *max_inout = max(*max_inout, max |y|)                 (distribution_collector.py:70-78)
  *   hist_row + interval: y counted into int64[2048] with bin width *interval   (distribution_collector.py:127-135)

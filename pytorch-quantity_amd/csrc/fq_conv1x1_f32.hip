@@ -32,6 +32,7 @@
 
 #include <map>
 #include <mutex>
+#include <utility>
 
 namespace fq {
 namespace {
@@ -117,7 +118,9 @@ __device__ __forceinline__ void c1_epilogue(const f16v (&acc)[WM][WN], const C1A
                                             unsigned jbase, unsigned mbase, unsigned m0, unsigned n0, unsigned r, unsigned h) {
     // stores through buffer descriptors too: per-lane byte offset of (column, first row of the lane) once per column
     // block, the row advance as the scalar offset -- a value costs its bias add, the ReLU select and the statistic
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    // (y == null with a ReLU copy: only the ReLU's output is wanted -- a descriptor of zero records drops every store of y in
+    //  the address unit, the loop below stays as it is)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y ? a.y : a.relu, 0, a.y ? a.y_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(kRelu ? a.relu : a.y, 0, a.y_bytes, 0x00020000);
     constexpr int aux = kStream ? 2 : 0;                      // nt
 #pragma unroll
@@ -602,9 +605,12 @@ constexpr unsigned kSplitMaxItems = 256, kSplitMaxSlices = 16;
 
 SplitWs split_workspace(hipStream_t st) {
     static std::mutex mu;
-    static std::map<hipStream_t, SplitWs> per_stream;         // (launches on different streams may overlap)
+    static std::map<std::pair<int, hipStream_t>, SplitWs> per_stream;   // (device, stream): launches on different streams may overlap
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return SplitWs();
+    const std::pair<int, hipStream_t> key(dev, st);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = per_stream.find(st);
+    auto it = per_stream.find(key);
     if (it != per_stream.end()) return it->second;
     SplitWs w;
     void* p = nullptr;
@@ -615,8 +621,9 @@ SplitWs split_workspace(hipStream_t st) {
         if (hipMemsetAsync(w.count, 0, kSplitMaxItems * sizeof(unsigned), st) != hipSuccess) w = SplitWs();
     } else {
         (void)hipGetLastError();
+        return w;                                             // (not remembered: the next launch asks again)
     }
-    per_stream[st] = w;
+    per_stream[key] = w;
     return w;
 }
 
@@ -680,7 +687,7 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
     if (hist_row && !interval) return FQ_ERR_INVALID_ARG;
     if (N == 0) return FQ_OK;
-    if (!x || !wt || !y) return FQ_ERR_INVALID_ARG;
+    if (!x || !wt || (!y && (!relu_out || qd))) return FQ_ERR_INVALID_ARG;                   // (y may be null when only its ReLU is wanted)
     if ((Cout & 3) || (reinterpret_cast<uintptr_t>(wt) & 15u)) return FQ_ERR_UNSUPPORTED;       // float4 loads of Wt rows
     const bool taps = R * S > 1 || pad > 0;
     if (taps && (Cin % 16) != 0) return FQ_ERR_UNSUPPORTED;                                   // whole K steps per tap
@@ -701,7 +708,7 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     a.y_bytes = (unsigned)(out_elems * 4);
     a.tiles_m = a.tiles = 0;
     a.split_first = a.split_s = a.work = 0; a.ws = nullptr; a.ws_count = nullptr;
-    a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);       // beyond the Infinity Cache
+    a.stream_stores = out_elems * (relu_out && y ? 8 : 4) > ((size_t)256 << 20);  // beyond the Infinity Cache
 #ifdef FQ_C1_ABLATE
     a.ablate = env_int("FQ_C1_ABLATE", 0);
 #endif

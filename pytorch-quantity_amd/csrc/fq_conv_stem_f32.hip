@@ -71,7 +71,8 @@ __device__ __forceinline__ void stem_epilogue(const f16v& acc0, const f16v& acc1
     // buffer stores: per-lane byte offset of (pixel, channel 4 h) + the channel advance as the scalar offset: a value costs its
     // bias add, the ReLU select and the statistic (a vector instruction of any wave takes issue cycles from the matrix pipe)
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, a.y_bytes, 0x00020000);
+    // (y == null with a ReLU copy: a descriptor of zero records drops every store of y in the address unit)
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y ? a.y : a.relu, 0, a.y ? a.y_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(kRelu ? a.relu : a.y, 0, a.y_bytes, 0x00020000);
     constexpr int aux = kStream ? 2 : 0;                      // nt
 #pragma unroll
@@ -318,7 +319,7 @@ static int stem_launch(const float* x, const float* wp, const float* bias, float
     if (!(Cin == 3 && R == 7 && S == 7 && stride == 2) || Cout > 64) return FQ_ERR_UNSUPPORTED;
     if (H + 2 * pad < R || W + 2 * pad < S) return FQ_ERR_INVALID_ARG;
     if (N == 0) return FQ_OK;
-    if (!x || !wp || !y) return FQ_ERR_INVALID_ARG;
+    if (!x || !wp || (!y && (!relu_out || qd))) return FQ_ERR_INVALID_ARG;                   // (y may be null when only its ReLU is wanted)
     if (reinterpret_cast<uintptr_t>(wp) & 15u) return FQ_ERR_INVALID_ARG;
     StemArgs a;
     a.x = x; a.wp = wp; a.bias = bias; a.y = y; a.relu = relu_out;
@@ -334,7 +335,7 @@ static int stem_launch(const float* x, const float* wp, const float* bias, float
     if (out_elems >= (1ULL << 30) || in_elems >= (1ULL << 30)) return FQ_ERR_UNSUPPORTED;          // 32-bit byte offsets
     a.x_bytes = (unsigned)(in_elems * 4);
     a.y_bytes = (unsigned)(out_elems * 4);
-    a.stream_stores = out_elems * (relu_out ? 8 : 4) > ((size_t)256 << 20);
+    a.stream_stores = out_elems * (relu_out && y ? 8 : 4) > ((size_t)256 << 20);
     static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
     const int rc = launch_stem<3, 7, 7>(a, max_inout, interval, hist_row, fast, qd, as_stream(stream));
     if (rc != FQ_OK) return rc;

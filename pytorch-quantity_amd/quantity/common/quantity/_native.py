@@ -369,8 +369,12 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
     N, Cin, H, W = (int(v) for v in x.shape)
     Cout, s = int(wt.shape[1]), int(stride)
     shape = (N, Cout, (H - 1) // s + 1, (W - 1) // s + 1)
-    y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
-    assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
+    if out is False:                                            # only the ReLU's output is wanted: y is not written
+        assert relu_out is not None and qd is None and tuple(relu_out.shape) == shape
+        y = None
+    else:
+        y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+        assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
     if bias is not None:
         _need_cuda(bias, torch.float32, "fq_conv1x1_f32")
         assert bias.is_contiguous() and bias.numel() == Cout
@@ -386,8 +390,9 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
         _need_cuda(max_dev, torch.float32, "fq_conv1x1_f32")
         assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
         mp = max_dev.data_ptr() + 4 * int(row)
-    _check(lib().fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                _relu_ptr(relu_out, y), N, Cin, H, W, Cout, s, mp, ivp, hp, _stream(x)), "fq_conv1x1_f32")
+    _check(lib().fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(),
+                                None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin, H, W,
+                                Cout, s, mp, ivp, hp, _stream(x)), "fq_conv1x1_f32")
     return y
 
 
@@ -452,8 +457,12 @@ def conv_kxk_f32(x, wt, bias, kernel, stride, pad, max_dev=None, interval_dev=No
     N, Cin, H, W = (int(v) for v in x.shape)
     Cout, st, pd = int(wt.shape[1]), int(stride), int(pad)
     shape = (N, Cout, (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1)
-    y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
-    assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
+    if out is False:                                            # only the ReLU's output is wanted: y is not written
+        assert relu_out is not None and qd is None and tuple(relu_out.shape) == shape
+        y = None
+    else:
+        y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+        assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
     if bias is not None:
         _need_cuda(bias, torch.float32, "fq_conv_kxk_f32")
         assert bias.is_contiguous() and bias.numel() == Cout
@@ -469,9 +478,9 @@ def conv_kxk_f32(x, wt, bias, kernel, stride, pad, max_dev=None, interval_dev=No
         _need_cuda(max_dev, torch.float32, "fq_conv_kxk_f32")
         assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
         mp = max_dev.data_ptr() + 4 * int(row)
-    _check(lib().fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                 _relu_ptr(relu_out, y), N, Cin, H, W, Cout, R, S, st, pd, mp, ivp, hp, _stream(x)),
-           "fq_conv_kxk_f32")
+    _check(lib().fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(),
+                                 None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin, H, W,
+                                 Cout, R, S, st, pd, mp, ivp, hp, _stream(x)), "fq_conv_kxk_f32")
     return y
 
 
@@ -501,8 +510,12 @@ def conv_stem_f32(x, wp, bias, cout, kernel, stride, pad, max_dev=None, interval
     N, Cin, H, W = (int(v) for v in x.shape)
     R, S = int(kernel[0]), int(kernel[1])
     shape = (N, int(cout), (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1)
-    y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
-    assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
+    if out is False:                                            # only the ReLU's output is wanted: y is not written
+        assert relu_out is not None and qd is None and tuple(relu_out.shape) == shape
+        y = None
+    else:
+        y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+        assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
     if bias is not None:
         _need_cuda(bias, torch.float32, "fq_conv_stem_f32")
         assert bias.is_contiguous() and bias.numel() == cout
@@ -519,9 +532,9 @@ def conv_stem_f32(x, wp, bias, cout, kernel, stride, pad, max_dev=None, interval
         _need_cuda(max_dev, torch.float32, "fq_conv_stem_f32")
         assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
         mp = max_dev.data_ptr() + 4 * int(row)
-    _check(lib().fq_conv_stem_f32(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                  _relu_ptr(relu_out, y), N, Cin, H, W, int(cout), R, S, int(stride), int(pad), mp, ivp, hp,
-                                  _stream(x)), "fq_conv_stem_f32")
+    _check(lib().fq_conv_stem_f32(x.data_ptr(), wp.data_ptr(), None if bias is None else bias.data_ptr(),
+                                  None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin, H, W,
+                                  int(cout), R, S, int(stride), int(pad), mp, ivp, hp, _stream(x)), "fq_conv_stem_f32")
     return y
 
 

@@ -152,7 +152,9 @@ class _DeferralProbe(object):
     its ReLU.  If every hooked tensor outside those pairs and the model's output come out bit for bit as in the first forward,
     nothing but the designated Eltwise read the convolution's output and nothing but the designated ReLU read the sum: NaN
     poisons everything it touches.  (Control flow that depends on the data is not covered by a probe; the production path
-    therefore also refuses to end a forward with a convolution still waiting.)"""
+    therefore also refuses to end a forward with a convolution still waiting.)
+    The same forward proves the simpler chain convolution -> out-of-place nn.ReLU (`relu_only`): when nothing but that ReLU reads
+    a convolution's output, and pass 2 does not want the tensor kept, the kernel writes the ReLU's result only."""
 
     def __init__(self):
         self.mode = "learn"
@@ -160,6 +162,7 @@ class _DeferralProbe(object):
         self.pairs = {}             # learn: Eltwise module -> the conv module whose output it received
         self.keys = {}              # module -> its hook key of this forward
         self.candidates = {}        # conv module -> (Eltwise module, nn.ReLU module)
+        self.relu_only = {}         # conv module -> the nn.ReLU that is the only reader of its output (skip_unread_outputs)
         self.private = {}           # poison: id(poisoned tensor) -> (poisoned tensor, real tensor, the one module that may read it)
 
     def conv_done(self, m, y):
@@ -167,10 +170,11 @@ class _DeferralProbe(object):
             self.conv_out[id(y)] = (y, m)
             return y
         pair = self.candidates.get(m)
-        if pair is None:
+        reader = pair[0] if pair is not None else self.relu_only.get(m)
+        if reader is None:
             return y
         bad = torch.full_like(y, float("nan"))
-        self.private[id(bad)] = (bad, y, pair[0])
+        self.private[id(bad)] = (bad, y, reader)
         return bad
 
     def real(self, t, reader):
@@ -200,7 +204,7 @@ class _DeferralProbe(object):
         return None if r is None else torch.nn.functional.relu(r)
 
     def poisoned_keys(self):
-        mods = set(self.candidates) | set(e for e, _r in self.candidates.values())
+        mods = set(self.candidates) | set(e for e, _r in self.candidates.values()) | set(self.relu_only)
         return set(k for mod, k in self.keys.items() if mod in mods)
 
 
@@ -220,7 +224,7 @@ class _HookState(object):
     The rest are counters for Quantity.timings."""
     __slots__ = ("stop_after", "events", "eager", "fuse_bias", "fuse_collector", "fuse_off", "fuse_verified", "fuse_warm",
                  "relu_after", "relu_ready", "last_out", "fused_relus", "fuse_stat", "hist_fused", "keep_feats", "keep_names",
-                 "own_plain", "own_conv1x1", "deferred", "defer_ok", "deferred_adds", "deferred_hists", "poison")
+                 "own_plain", "own_conv1x1", "deferred", "defer_ok", "deferred_adds", "deferred_hists", "poison", "relu_only_ok", "skipped_outputs")
 
     def __init__(self):
         self.stop_after = None          # ordinal of the last module pass 2 needs (the hook raises _StopForward there)
@@ -247,6 +251,8 @@ class _HookState(object):
         self.deferred_adds = 0          # launches of fq_conv1x1_add_f32 (pass 1)
         self.deferred_hists = 0         # launches of fq_conv1x1_add_hist_f32 (pass 2)
         self.poison = None              # the _DeferralProbe of a running probe forward
+        self.relu_only_ok = set()       # convolutions whose output only their nn.ReLU reads (same proof)
+        self.skipped_outputs = 0        # launches that did not write the convolution's own output
 
 
 class Quantity(object):
@@ -293,6 +299,9 @@ class Quantity(object):
     # cache wants them: 8 bytes per element instead of 20.  A convolution is deferred to its Eltwise only after the poison
     # probe (_DeferralProbe) has shown that nothing else reads its output.
     fuse_conv_add = os.environ.get("FQ_FUSE_CONV_ADD", "1") != "0"
+    # A convolution whose output only an out-of-place nn.ReLU reads (same proof) writes that ReLU's result and not its own
+    # output, unless pass 2's cache wants the tensor: 4 bytes per element instead of 8.
+    skip_unread_outputs = os.environ.get("FQ_SKIP_UNREAD", "1") != "0"
     # True: every hooked tensor is written to HBM even when nothing of this calibration will read it again (for observers that
     # tape the hooked tensors: the oracle-replay tests)
     materialize_all = False
@@ -770,7 +779,7 @@ class Quantity(object):
                     if own is None:
                         return torch.nn.Conv2d.forward(m, x)
                     y = _float_conv.plain(m, own, x, check=ctl.own_plain != "unchecked")
-                    if ctl.poison is not None and own == "c1":
+                    if ctl.poison is not None:
                         y = ctl.poison.conv_done(m, y)
                     return y
                 if ctl.fuse_collector is None or ctl.fuse_off:
@@ -891,8 +900,8 @@ class Quantity(object):
                     and ctl.eager is not None):
                 ctl.deferred[id(output)] = (output, m, x, key, row, output._version)       # (see below)
                 return True
-            self._run_with_relu(m, output, lambda r: run(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row,
-                                                         relu_out=r, out=output))
+            self._run_with_relu(m, output, lambda r, o: run(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row,
+                                                            relu_out=r, out=o), key)
             ctl.hist_fused += 1
             return True
         ref = _float_conv.verified(m, run, x)                  # first use: against torch, once per process
@@ -905,7 +914,7 @@ class Quantity(object):
             # is an allocation nobody reads -- which the poison probe has shown for this model
             ctl.deferred[id(output)] = (output, m, x, key, row, output._version)
             return True
-        self._run_with_relu(m, output, lambda r: run(max_dev=coll.max_device, row=row, relu_out=r, out=output))
+        self._run_with_relu(m, output, lambda r, o: run(max_dev=coll.max_device, row=row, relu_out=r, out=o), key)
         coll.note_max_refreshed()
         ctl.own_conv1x1 = ctl.own_conv1x1 + 1
         return True
@@ -978,16 +987,32 @@ class Quantity(object):
         ctl.deferred_adds += 1
         return True
 
-    def _run_with_relu(self, m, output, run):
-        """run(relu_out) launches m's fused kernel.  When an out-of-place nn.ReLU is known to consume `output` directly,
-        the kernel writes that ReLU's result as well and the patched ReLU.forward hands it out instead of launching."""
+    def _wanted(self, key):
+        """Does anything of this calibration read the hooked tensor `key` of the running forward from HBM again?  (Pass 1: what
+        pass 2's cache keeps; pass 2: nothing.)"""
+        ctl = self._hook_ctl
+        if self.materialize_all:
+            return True
+        if ctl.fuse_stat == "hist":
+            return False
+        return ctl.keep_feats and (ctl.keep_names is None or key in ctl.keep_names)
+
+    def _run_with_relu(self, m, output, run, key=None):
+        """run(relu_out, out) launches m's fused kernel (out: where the module's own output goes).  When an out-of-place
+        nn.ReLU is known to consume `output` directly, the kernel writes that ReLU's result as well and the patched ReLU.forward
+        hands it out instead of launching -- and when that ReLU is PROVEN to be the only reader of `output` (relu_only_ok) and
+        pass 2 does not want the tensor, `output` itself is not written (out = False)."""
         ctl = self._hook_ctl
         relu = ctl.relu_after.get(m) if self.fuse_relu else None
         if relu is None:
-            run(None)
+            run(None, output)
             return
         r = torch.empty_like(output)
-        run(r)
+        skip = (key is not None and self.skip_unread_outputs and m in ctl.relu_only_ok and _flag(m, _RELU_VERIFIED)
+                and ctl.eager is not None and not self._wanted(key))
+        run(r, False if skip else output)
+        if skip:
+            ctl.skipped_outputs += 1
         if not _flag(m, _RELU_VERIFIED):              # once per process: the same bits as torch's ReLU?
             if not torch.equal(r, torch.nn.functional.relu(output)):
                 self.fuse_relu = False
@@ -1013,8 +1038,8 @@ class Quantity(object):
                 return False
             row = coll.row_of(key)
             if ctl.fuse_stat == "hist":                  # pass 2 (verified in pass 1): the sum, histogrammed on the way out
-                self._run_with_relu(m, output, lambda r: _native.add_hist(a, b, coll.interval_device, coll.hist_device, row,
-                                                                          out=output, relu_out=r))
+                self._run_with_relu(m, output, lambda r, _o: _native.add_hist(a, b, coll.interval_device, coll.hist_device, row,
+                                                                              out=output, relu_out=r))
                 ctl.hist_fused += 1
                 return True
             if not _flag(m, _FUSION_VERIFIED):        # first use: the kernel against torch.add, once per process
@@ -1027,7 +1052,7 @@ class Quantity(object):
                     return False
                 _set_flag(m, _FUSION_VERIFIED)
             ctl.fuse_verified.add(m)
-            self._run_with_relu(m, output, lambda r: _native.add_absmax(a, b, coll.max_device, row, out=output, relu_out=r))
+            self._run_with_relu(m, output, lambda r, _o: _native.add_absmax(a, b, coll.max_device, row, out=output, relu_out=r))
             coll.note_max_refreshed()
             return True
         if module is not m or coll is None or key is None or not output.is_contiguous() or output.dim() < 2:
@@ -1035,13 +1060,13 @@ class Quantity(object):
             return False
         row = coll.row_of(key)
         if ctl.fuse_stat == "hist":                      # pass 2 (verified in pass 1)
-            self._run_with_relu(m, output, lambda r: _native.bias_add_hist(output, m.bias, coll.interval_device,
-                                                                           coll.hist_device, row, relu_out=r))
+            self._run_with_relu(m, output, lambda r, _o: _native.bias_add_hist(output, m.bias, coll.interval_device,
+                                                                               coll.hist_device, row, relu_out=r))
             ctl.hist_fused += 1
             return True
         if m in ctl.fuse_verified or _flag(m, _FUSION_VERIFIED):
             ctl.fuse_verified.add(m)
-            self._run_with_relu(m, output, lambda r: _native.bias_add_absmax(output, m.bias, coll.max_device, row, relu_out=r))
+            self._run_with_relu(m, output, lambda r, _o: _native.bias_add_absmax(output, m.bias, coll.max_device, row, relu_out=r))
             coll.note_max_refreshed()
             return True
         # First fused use of this module (its second batch).  Two things are checked once per module:
@@ -1104,20 +1129,28 @@ class Quantity(object):
                 and not _mod._global_forward_pre_hooks)
 
     def _prove_deferral(self, probe, first_feats, first_out):
-        """After the learning probe forward: pick the (1x1 convolution, Eltwise, ReLU) chains fq_conv1x1_add_f32 can take, run
-        the poison forward (_DeferralProbe) and return {conv: Eltwise} when it changes nothing, else {}."""
+        """After the learning probe forward: pick the (1x1 convolution, Eltwise, ReLU) chains fq_conv1x1_add_f32 can take and the
+        (convolution, ReLU) chains whose convolution output nobody else reads, run the poison forward (_DeferralProbe) and
+        return ({conv: Eltwise}, {conv}) when it changes nothing, else ({}, set())."""
         ctl = self._hook_ctl
         cared = set(self.net_info.keys())
-        for elt, conv in probe.pairs.items():
+        for elt, conv in (probe.pairs.items() if self.fuse_conv_add else ()):
             relu = ctl.relu_after.get(elt)
             if (relu is None or probe.keys.get(conv) not in cared or probe.keys.get(elt) not in cared
+                    or conv.kernel_size != (1, 1) or conv.padding != (0, 0)
                     or not _native.conv1x1_add_f32_supported(conv.in_channels, conv.out_channels)
                     or not (self._only_our_hook(conv) and self._only_our_hook(elt) and self._only_our_hook(relu))
                     or conv in probe.candidates):
                 continue
             probe.candidates[conv] = (elt, relu)
-        if not probe.candidates:
-            return {}
+        for (_y, conv) in (probe.conv_out.values() if self.skip_unread_outputs else ()):
+            relu = ctl.relu_after.get(conv)
+            if (relu is None or conv in probe.candidates or probe.keys.get(conv) not in cared
+                    or not (self._only_our_hook(conv) and self._only_our_hook(relu))):
+                continue
+            probe.relu_only[conv] = relu
+        if not probe.candidates and not probe.relu_only:
+            return {}, set()
         probe.mode = "poison"
         named = self._probe_feats
         named.clear()
@@ -1139,7 +1172,9 @@ class Quantity(object):
         if ok and torch.is_tensor(first_out):
             ok = same(first_out, self._probe_out)
         self._probe_out = None
-        return {conv: pair[0] for conv, pair in probe.candidates.items()} if ok else {}
+        if not ok:
+            return {}, set()
+        return {conv: pair[0] for conv, pair in probe.candidates.items()}, set(probe.relu_only)
 
     def _forward_with_stats(self, item, fn, named_feats, extra=None):
         """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced and
@@ -1354,13 +1389,13 @@ class Quantity(object):
             # (its values are not used, so the convolutions the own kernels take run on them here too, unchecked: a
             # calibration then never enters the convolution library, whose first-use solver search is most of what a
             # fresh process used to wait for; every module is still checked on the first real batch)
-            deferral = (_DeferralProbe() if self.fuse_conv_add and self.fuse_bias_absmax and self.fuse_relu and self.own_conv1x1
-                        and self._stat_stream() is None else None)
+            deferral = (_DeferralProbe() if (self.fuse_conv_add or self.skip_unread_outputs) and self.fuse_bias_absmax and self.fuse_relu
+                        and self.own_conv1x1 and self._stat_stream() is None else None)
             inplace = self._probe_forward("unchecked", deferral)
-            if deferral is not None and not inplace and deferral.pairs:
+            if deferral is not None and not inplace and (deferral.pairs or deferral.conv_out):
                 self._probe_feats = named_feats
                 try:
-                    ctl.defer_ok = self._prove_deferral(deferral, dict(named_feats), self._probe_out)
+                    ctl.defer_ok, ctl.relu_only_ok = self._prove_deferral(deferral, dict(named_feats), self._probe_out)
                 finally:
                     self._probe_feats = None
             self._probe_out = None
@@ -1511,6 +1546,7 @@ class Quantity(object):
                         "own_conv1x1_launches": ctl.own_conv1x1,
                         "conv_add_chains_proven": len(ctl.defer_ok), "conv_add_launches": ctl.deferred_adds,
                         "conv_add_hist_launches": ctl.deferred_hists,
+                        "relu_only_chains_proven": len(ctl.relu_only_ok), "launches_without_own_output": ctl.skipped_outputs,
                         "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}

@@ -52,7 +52,7 @@ def _block_net(variant="plain", hw=64):
     return Net()
 
 
-def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None, hw=64):
+def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None, hw=64, skip=None):
     from tools import Quantity
     if monkeypatch is not None and cache_gb is not None:
         monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
@@ -60,6 +60,7 @@ def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None,
     with product_workdir(input_shape="1,3,%d,%d" % (hw, hw), device="gpu", max_cali_img_num=batches - 1) as tmp:
         q = Quantity(model)
         q.fuse_conv_add = fuse
+        q.skip_unread_outputs = fuse if skip is None else skip
         bits = q.activation_quantize(cases.calib_batches(batches, (8, 3, hw, hw), seed=91))
         table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
         return dict(bits), table, dict(q._collector.max_vals), q._collector.hist_device.clone(), dict(q.timings)
@@ -87,6 +88,27 @@ def test_tables_do_not_depend_on_the_fusion_nor_on_what_the_cache_keeps(monkeypa
     if plan:
         assert got[4]["cache_plan"]["kind"] == plan and got[4]["cache_bytes"] > 0
         assert (got[4]["cache_bytes"] < 100e6) == (cache_gb != "1")      # (a batch's hooked tensors are 30 MB: partial caches are partial)
+
+
+@pytest.mark.parametrize("cache_gb,plan", [("0", ""), ("1", "A"), ("0.05", "B")])
+def test_convolution_outputs_only_their_relu_reads_are_not_written(monkeypatch, cache_gb, plan):
+    """skip_unread_outputs alone (the conv + Eltwise fusion off): the two inner convolutions of each block run on the own kernels
+    and are followed by an out-of-place nn.ReLU that the poison probe proves to be the only reader -- 4 chains (the 3-channel
+    3x3 stem stays with the library); their own output reaches HBM only when pass 2's cache keeps it.  Tables, maxima and
+    histograms are those of the plain run."""
+    model = cases.seed_model(_block_net(), base_seed=8).eval().cuda()
+    want = _calibrate(model, False, cache_gb, plan, monkeypatch=monkeypatch)
+    got = _calibrate(model, False, cache_gb, plan, monkeypatch=monkeypatch, skip=True)
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+    assert want[4]["relu_only_chains_proven"] == 0 and want[4]["launches_without_own_output"] == 0
+    assert got[4]["relu_only_chains_proven"] == 4 and got[4]["conv_add_chains_proven"] == 0
+    n = got[4]["launches_without_own_output"]
+    if cache_gb == "0":
+        assert n >= 4 * 4 + 4 * 5              # pass 1 (all but the modules' first, checked use) + every forward of pass 2
+    elif plan == "A":
+        assert n == 0                          # every batch is kept whole, pass 2 runs no forward
+    else:
+        assert 0 < n < 4 * 5 + 4 * 5           # the early tensors are not kept, the deep ones are
 
 
 def test_small_planes_with_both_tensors_kept_stay_on_the_two_kernels(monkeypatch):

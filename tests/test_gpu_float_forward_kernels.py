@@ -585,6 +585,42 @@ def test_conv_add_relu_histogram_form_equals_the_two_kernels(nat, shape):
         assert torch.equal(r1.view(torch.int32), r2.view(torch.int32))
 
 
+def test_relu_only_form_writes_the_relu_and_not_the_convolution_output(nat):
+    """y = NULL with relu_out (out=False): the ReLU copy and the statistic (abs-max or histogram) are those of the ordinary call,
+    for the 1x1, the R x S and the stem kernel; without relu_out a missing y is an argument error."""
+    g = torch.Generator(device="cuda").manual_seed(404)
+    iv = torch.tensor([0.003, 1.0], device="cuda")
+    cases_ = []
+    x = torch.randn(5, 64, 28, 28, device="cuda", generator=g)
+    wt = torch.randn(64, 128, device="cuda", generator=g) * 0.125
+    b = torch.randn(128, device="cuda", generator=g)
+    cases_.append(lambda **kw: nat.conv1x1_f32(x, wt, b, 1, **kw))
+    w3 = torch.randn(64, 64, 3, 3, device="cuda", generator=g) * 0.05
+    b3 = torch.randn(64, device="cuda", generator=g)
+    wk = nat.pack_kxk_weight(w3)
+    cases_.append(lambda **kw: nat.conv_kxk_f32(x, wk, b3, (3, 3), 1, 1, **kw))
+    xs, ws, bs, pad = _stem_case(STEM_SHAPES[0], 35, integer=False)
+    cases_.append(lambda **kw: _stem(nat, xs, ws, bs, pad, **kw))
+    for run in cases_:
+        for stat in ("max", "hist"):
+            m2, m1 = torch.zeros(2, device="cuda"), torch.zeros(2, device="cuda")
+            h2 = torch.zeros(2, 2048, dtype=torch.int64, device="cuda")
+            h1 = h2.clone()
+            kw2 = dict(max_dev=m2, row=0) if stat == "max" else dict(interval_dev=iv, hist_dev=h2, row=0)
+            kw1 = dict(max_dev=m1, row=0) if stat == "max" else dict(interval_dev=iv, hist_dev=h1, row=0)
+            y = run(**kw2)
+            r2 = torch.empty_like(y)
+            run(relu_out=r2, **kw2)
+            m2.zero_(), h2.zero_()
+            run(relu_out=r2, **kw2)
+            r1 = torch.full_like(y, 5.5)
+            assert run(relu_out=r1, out=False, **kw1) is None
+            assert torch.equal(r1, r2) and torch.equal(r1, torch.relu(y))
+            assert torch.equal(m1, m2) and torch.equal(h1, h2)
+    with pytest.raises((nat.FqError, AssertionError)):
+        nat.conv1x1_f32(x, wt, b, 1, out=False)
+
+
 def test_conv_add_argument_errors(nat):
     x = torch.zeros(1, 16, 4, 4, device="cuda")
     r = torch.zeros(1, 128, 4, 4, device="cuda")
