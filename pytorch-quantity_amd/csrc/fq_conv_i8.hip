@@ -108,9 +108,10 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
 template <int TK, int kOut, bool kIntTail>
 __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvParams& p, float* __restrict__ y,
                                               int8_t* __restrict__ q, int8_t* sO, const float* sBias, const int* sBiasI, int m0,
-                                              int k0, int n_img, int pq, bool m_ok) {
+                                              int k0, int n_img, int pq, bool m_ok, int tid_base = 0) {
     constexpr int MT = TK / 32;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
+    // (tid_base: a 512-thread workgroup runs this once per 256-thread half, each on its own 128-pixel tile and its own sO)
+    const int tid = (int)threadIdx.x - tid_base, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
     const int PQ = p.P * p.Q;
     if ((kOut & kOutF32) && m_ok) {
         // For a fixed register the 32 lanes of a half-wave write 32 consecutive pixels of one channel
@@ -838,6 +839,171 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_halo_kernel(const int8_
     }
 }
 
+// ---- the same with 256-pixel tiles and EIGHT waves ---------------------------------------------------------------------
+// What bounds the kernel above is operand delivery into LDS (a round of tiles moves its operands at 11-13 bytes
+// per clock and CU, the LDS-DMA fill rate of the chip, and a 128 x 128 tile needs a byte per 128 MACs).  Here one weight tile
+// feeds 256 pixels: waves 0-3 own the first 128 pixels of the tile, waves 4-7 the second 128, every wave as in the kernel
+// above (32 pixels x TK channels, the same fragments, the same 16 MFMAs per step) -- so the bytes per MAC halve while the
+// waves per SIMD do not (the four-wave NP = 2 form paid for the same halving with half the resident waves and lost).
+// Weights in a ring of two (32 KB) + one slab of 258 + 2 W rows: 70 KB at W = 14, two workgroups = 16 waves per CU.
+template <int TK, int kOut, int ST>
+__global__ __launch_bounds__(2 * kConvBlock) void conv3x3_i8_halo8_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                                          const float* __restrict__ qbias, float* __restrict__ y,
+                                                                          int8_t* __restrict__ q, const ConvParams p, const HaloParams hp) {
+    constexpr int BKB = 128;
+    constexpr int MT = TK / 32;
+    constexpr int A_LOADS = TK / 64;                          // 8 waves x 8 rows per DMA instruction
+    constexpr int TPX = 2 * kTP;
+    extern __shared__ __attribute__((aligned(16))) int8_t smem[];
+    // [weights: ST x TK x 128][bias f32: TK][bias i32: TK][zero row: 128][slab: slab_rows x 128]
+    static_assert(ST == 2 || ST == 3, "weight ring of two or three steps");
+    static_assert(TK == 64 || TK == 128, "one or two DMA instructions per wave and weight tile");
+    int8_t* const sA = smem;
+    float* const sBias = reinterpret_cast<float*>(smem + ST * TK * BKB);
+    int* const sBiasI = reinterpret_cast<int*>(smem + ST * TK * BKB + TK * 4);
+    int8_t* const sZero = smem + ST * TK * BKB + TK * 8;
+    int8_t* const sSlab = sZero + BKB;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0 .. 7
+    const int u = wave >> 2, wq = wave & 3;                   // which 128-pixel half, which 32 pixels of it
+    const int half = lane >> 5;
+    int tile_x, tile_y;
+    if (!conv_tile_of(p, tile_x, tile_y)) return;
+    const int m0 = tile_x * TPX;
+    const int k0 = tile_y * TK;
+    const int PQ = p.P * p.Q;
+    if (tid < TK) {
+        const float b = qbias[k0 + tid];
+        sBias[tid] = b;
+        sBiasI[tid] = (int)b;
+    }
+    if (tid < BKB / 4) reinterpret_cast<int*>(sZero)[tid] = 0;
+
+    const int m = m0 + kTP * u + wq * 32 + (lane & 31);
+    const bool m_ok = m < p.M;
+    const int mm = m_ok ? m : 0;
+    const int n_img = mm / PQ, pq = mm - n_img * PQ;
+    unsigned tap_mask = 0;
+    {
+        const int oh = pq / p.Q, ow = pq - oh * p.Q;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s_ = 0; s_ < 3; ++s_) {
+                const bool ok = m_ok && (unsigned)(oh + r - 1) < (unsigned)p.H && (unsigned)(ow + s_ - 1) < (unsigned)p.W;
+                tap_mask |= ok ? 1u << (3 * r + s_) : 0u;
+            }
+    }
+
+    const rsrc_words xr = make_rsrc_words(x, p.x_bytes);
+    const int n_slab_dma = hp.slab_rows >> 3;
+    auto slab_dma = [&](int slice) {
+        for (int i = wave; i < n_slab_dma; i += 8) {
+            const int row = 8 * i + (lane >> 3);
+            const int g = m0 - p.W - 1 + row;                 // input pixel (flat N x H x W index); outside the tensor: zeros
+            const unsigned vo = (unsigned)g < (unsigned)hp.total_pixels
+                                    ? (unsigned)g * (unsigned)p.C + (unsigned)(((lane & 7) ^ swz(row, 0)) * 16) : kOutOfRange;
+            dma_to_lds(xr, lds_offset(sSlab + i * 1024), vo, slice * BKB);
+        }
+    };
+    // weight fetch: load j of wave v covers tile rows 64 j + 8 v .. + 7
+    const rsrc_words wr = make_rsrc_words(w, p.w_bytes);
+    unsigned aoff[A_LOADS];
+#pragma unroll
+    for (int j = 0; j < A_LOADS; ++j) {
+        const int row = 64 * j + 8 * wave + (lane >> 3);
+        aoff[j] = (unsigned)(k0 + row) * ((unsigned)p.chunks * 16u) + (unsigned)(((lane & 7) ^ swz(row, 0)) * 16);
+    }
+    auto weight_dma = [&](int slice, int tap, int buf, bool live) {
+        const int so = tap * p.C + slice * BKB;
+#pragma unroll
+        for (int j = 0; j < A_LOADS; ++j)
+            dma_to_lds(wr, lds_offset(sA + buf * TK * BKB + (64 * j + 8 * wave) * BKB), live ? aoff[j] : kOutOfRange, so);
+    };
+
+    v16i acc[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0;
+    int a_off[MT];
+#pragma unroll
+    for (int a = 0; a < MT; ++a) a_off[a] = (a * 32 + (lane & 31)) * BKB;
+    int swz_a[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) swz_a[ks] = ((ks * 2 + half) ^ (((lane & 31) >> 1) & 7)) * 16;
+    const int p_row = kTP * u + wq * 32 + (lane & 31);        // this lane's pixel inside the 256-pixel tile
+    const unsigned zero_off = (unsigned)(sZero - smem);
+    const unsigned slab_off0 = (unsigned)(sSlab - smem);
+
+    const int nslices = p.C >> 7;
+    const int nsteps = 9 * nslices;
+    auto step_of = [&](int st, int& sl, int& tp) { sl = st / 9; tp = st - 9 * sl; };
+    slab_dma(0);
+    weight_dma(0, 0, 0, true);
+    if (ST == 3) weight_dma(0, 1, 1, nsteps > 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int slice = 0, tap = 0, cur = 0, nxt2 = ST - 1;
+    for (int step = 0; step < nsteps; ++step) {
+        const int r = tap / 3, s_ = tap - 3 * r;
+        v4i fb[4], fa[2][MT];
+        {
+            const int j = p_row + r * p.W + s_;
+            const bool ok = (tap_mask >> tap) & 1u;
+            const unsigned rowb = ok ? slab_off0 + (unsigned)(j * BKB) : zero_off;
+            const int sw = ok ? (j >> 1) & 7 : 0;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                fb[ks] = *reinterpret_cast<const v4i*>(smem + rowb + (unsigned)((((ks * 2 + half) ^ sw)) * 16));
+        }
+        const int8_t* const sAc = sA + cur * TK * BKB;
+#pragma unroll
+        for (int a = 0; a < MT; ++a) fa[0][a] = *reinterpret_cast<const v4i*>(sAc + a_off[a] + swz_a[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) {
+#pragma unroll
+                for (int a = 0; a < MT; ++a) fa[(ks + 1) & 1][a] = *reinterpret_cast<const v4i*>(sAc + a_off[a] + swz_a[ks + 1]);
+            }
+#pragma unroll
+            for (int a = 0; a < MT; ++a) acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[ks & 1][a], fb[ks], acc[a], 0, 0, 0);
+            if (ks == 0) {
+                // the weight tile of step + ST - 1, requested behind the first MFMAs of this step; it goes where step - 1 was
+                // read from (free since the barrier that ended that step)
+                int sl2, tp2;
+                step_of(step + ST - 1, sl2, tp2);
+                __builtin_amdgcn_sched_barrier(0);
+                weight_dma(sl2, tp2, nxt2, step + ST - 1 < nsteps);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ST == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LOADS) : "memory");     // step + 1's weights have landed (mine) ...
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                                     // ... and everybody's; everybody is done with this step
+        cur = cur + 1 == ST ? 0 : cur + 1;
+        nxt2 = nxt2 + 1 == ST ? 0 : nxt2 + 1;
+        if (++tap == 9) {
+            tap = 0;
+            if (++slice < nslices) {                          // next channel slice: the slab again, in the open
+                slab_dma(slice);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // each half stages its int8 tile in its own LDS: the first in the weight buffers, the second in the slab
+    static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the first half's int8 tile is staged in the weight buffers");
+    int8_t* const sO = u ? sSlab : sA;
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, m0 + kTP * u, k0, n_img, pq, m_ok, u * kConvBlock);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, m0 + kTP * u, k0, n_img, pq, m_ok, u * kConvBlock);
+}
+
 // ---- 3 x 3, stride 1, padding 1, C == 64, K <= 64 (the first stage of a ResNet): weights stationary, persistent -------
 // 64 x 3 x 3 x 64 weights are 36 KB: they are fetched ONCE per workgroup and stay in LDS; the workgroup then walks over
 // 128-pixel tiles (tile t, t + grid, ...), each of which needs one slab of 130 + 2 W input pixels x 64 bytes -- requested
@@ -1244,6 +1410,35 @@ static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, c
         return false;
     static const int st_env = [] { const char* e = getenv("FQ_HALO_STAGES"); return e ? atoi(e) : 0; }();
     static const int np_env = [] { const char* e = getenv("FQ_HALO_NP"); return e ? atoi(e) : 0; }();
+    // 256-pixel tiles on eight waves (conv3x3_i8_halo8_kernel): FQ_HALO8=0 keeps the 128-pixel form
+    static const int eight = [] { const char* e = getenv("FQ_HALO8"); return e ? atoi(e) : 1; }();
+    if (eight && !np_env && (eight > 1 || (long)((p0.M + 255) / 256) * (p0.K / TK) >= kCUs)) {
+        HaloParams hp8;
+        hp8.slab_rows = (2 * 128 + 2 + 2 * p0.W + 7) & ~7;
+        hp8.total_pixels = p0.N * p0.H * p0.W;
+        const size_t fixed8 = (size_t)TK * 8 + 128 + (size_t)hp8.slab_rows * 128;
+        const int stages8 = st_env ? st_env : 2;
+        const size_t lds8 = (size_t)stages8 * TK * 128 + fixed8;
+        if (lds8 <= 80 * 1024 - 64 && (stages8 == 2 || stages8 == 3)) {
+            dim3 grid8((unsigned)(((long)p0.M + 255) / 256), (unsigned)(p0.K / TK));
+            const ConvParams p8 = xcd_order(grid8, p0);
+#define FQ_HALO8_K(OUT, STG)                                                                                             \
+    do {                                                                                                                 \
+        auto k = conv3x3_i8_halo8_kernel<TK, OUT, STG>;                                                                  \
+        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                                       80 * 1024);                                                       \
+        if (ok != (int)hipSuccess) return false;                                                                         \
+        hipLaunchKernelGGL(k, grid8, dim3(2 * kConvBlock), lds8, st, x, w, qbias, y, q, p8, hp8);                        \
+    } while (0)
+#define FQ_HALO8(OUT) do { if (stages8 == 3) FQ_HALO8_K(OUT, 3); else FQ_HALO8_K(OUT, 2); } while (0)
+            if (y && q) FQ_HALO8(kOutF32 | kOutI8);
+            else if (q) FQ_HALO8(kOutI8);
+            else FQ_HALO8(kOutF32);
+#undef FQ_HALO8
+#undef FQ_HALO8_K
+            return true;
+        }
+    }
     // 128-pixel tiles.  (FQ_HALO_NP=2: 256-pixel tiles, two sub-tiles per wave -- bit-exact, fewer LDS reads and barriers per
     // MFMA, and 20-35 % SLOWER on ResNet-50's layers at 256 images: 48.7 vs 39.9 us on 256 -> 256 @14x14.)
     const int np = np_env ? np_env : 1;

@@ -217,6 +217,11 @@ def run_stem(cases, seed, verbose=True):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 150
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 7
+    if len(sys.argv) > 3 and sys.argv[3] == "halo":            # only the 3x3 halo kernels (FQ_HALO8=2: the eight-wave form everywhere)
+        halo_fails = run_halo(n, seed)
+        print("halo_fuzz: %d cases, %d mismatches (FQ_HALO8=%s FQ_HALO_STAGES=%s)"
+              % (n, len(halo_fails), os.environ.get("FQ_HALO8", ""), os.environ.get("FQ_HALO_STAGES", "")))
+        sys.exit(1 if halo_fails else 0)
     if len(sys.argv) > 3 and sys.argv[3] == "stream":          # only the streaming 1x1 kernel (run with FQ_CONV_STREAM=1)
         stream_fails = run_stream(n, seed)
         print("stream_fuzz: %d cases, %d mismatches (FQ_CONV_STREAM=%s FQ_STREAM_GROUPS=%s)"

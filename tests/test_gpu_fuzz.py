@@ -36,6 +36,22 @@ def test_streaming_1x1_kernel_matches_the_oracle(groups):
     assert r.returncode == 0 and "40 cases, 0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("stages", ["", "3"])
+def test_eight_wave_halo_kernel_matches_the_oracle(stages):
+    """conv3x3_i8_halo8_kernel (256-pixel tiles on eight waves; by default only launches that fill the chip take it, FQ_HALO8=2
+    forces it for every 3x3 / stride 1 / padding 1 layer; read once per process, hence the child process): every plane size
+    from 1 x 1, tiles spanning images and lying past the end, 1-4 channel slices, fp32 / int8 / both outputs, ring of two and
+    of three, against the CPU oracle."""
+    import subprocess
+    import sys
+    env = dict(os.environ, FQ_HALO8="2")
+    if stages:
+        env["FQ_HALO_STAGES"] = stages
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "conv_fuzz.py"), "60", "404", "halo"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "60 cases, 0 mismatches" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_random_histograms_kl_sweep_matches_the_oracle_bit_for_bit():
     """scripts/kl_fuzz.py: 96 random histograms of eight families; thresholds and KL curves (same include/fq_log.h on
     both sides) must agree bit for bit."""
