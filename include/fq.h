@@ -205,7 +205,10 @@ int fq_add_hist_f32(const float* x, const float* y, float* z, size_t n, const fl
  *   max_inout: *max_inout = max(*max_inout, max |y|)                 (distribution_collector.py:70-78)
  *   hist_row + interval: y counted into int64[2048] with bin width *interval   (distribution_collector.py:127-135)
  * Replaces, inside the float forward the reference runs at pytorch_quantizer.py:288-296, torch's Conv2d for these layers;
- * not bit-identical to the library's convolution (different, fixed summation order), deterministic from run to run. */
+ * not bit-identical to the library's convolution (different, fixed summation order), deterministic from run to run.
+ * Device memory: launches whose tile count leaves a partly filled last round over the CUs (the tail split)
+ * use a 16 MB workspace that the first such launch on a (device, stream) allocates and the library keeps; FQ_CONV_TAIL_SPLIT=0
+ * in the environment turns the split off.  This is the only allocation any entry point of this header makes. */
 int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin,
                    int Win, int Cout, int stride, float* max_inout, const float* interval, int64_t* hist_row,
                    fq_stream_t stream);

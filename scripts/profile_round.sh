@@ -14,8 +14,8 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 ARGS="--steps 20 --warmup 5 --no-cold"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench_line.json 2> $OUT/trace_err.log
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS --no-cpu-baseline --no-recon > $OUT/bench_line_pmc.json 2> $OUT/pmc_fetch_err.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS --no-cpu-baseline --no-recon > /dev/null 2> $OUT/pmc_write_err.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $ARGS --no-cpu-baseline --no-recon --no-file-input > $OUT/bench_line_pmc.json 2> $OUT/pmc_fetch_err.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $ARGS --no-cpu-baseline --no-recon --no-file-input > /dev/null 2> $OUT/pmc_write_err.log
 python3 $R/scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 # the raw traces are large: keep stats + counter rows of our kernels only
