@@ -22,7 +22,12 @@ The JSON line also carries
   roofline     : the dominant hand-written kernel (hist2048_seg), algorithmic bytes (4 B x elements per launch) / its
                  mean launch duration measured with HIP events on the launch stream inside the timed region;
                  `traffic` is STATIC (PMC counters of the committed profile of this configuration), and says so;
-  roofline_bias_add_absmax / roofline_add_absmax : the two kernels pass 1's maxima ride on;
+  roofline_bias_add_absmax / roofline_add_absmax : the two kernels pass 1's maxima ride on where the convolution itself
+                 (fq_conv*_f32) or the one-kernel residual tail (below) does not take the statistic -- absent when none ran;
+  roofline_conv1x1_add_f32 / roofline_conv1x1_add_hist_f32 : the last 1x1 convolution of a residual block + Eltwise + ReLU
+                 in one kernel (pass 1 / pass 2): matrix work and algorithmic bytes (x, Wt, the shortcut, the ReLU output and
+                 whichever of the two intermediate tensors is kept), frac_of_bound against max(matrix, bytes) per launch;
+  file_input   : the same images as .npy files through PRE_PROCESS.IMG = 2 (--input-mode npy|both), beside `value`, never it;
   roofline_conv_stem_f32 / roofline_conv_kxk_f32 : the same for the 7x7 stride-2 stem (fq_conv_stem_f32) and the 3x3 layers
                  (fq_conv_kxk_f32);
   roofline_conv1x1_f32 : the float forward's 1x1 convolutions on the fp32 matrix cores (fq_conv1x1_f32, statistic in the
