@@ -612,6 +612,11 @@ SplitWs split_workspace(hipStream_t st) {
     std::lock_guard<std::mutex> lock(mu);
     auto it = per_stream.find(key);
     if (it != per_stream.end()) return it->second;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;  // no allocation inside a stream capture: that launch runs unsplit
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return SplitWs();
+    }
     SplitWs w;
     void* p = nullptr;
     const size_t bytes = (size_t)kSplitMaxItems * 128 * 128 * sizeof(float);
