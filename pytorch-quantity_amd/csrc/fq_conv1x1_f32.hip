@@ -623,7 +623,11 @@ SplitWs split_workspace(hipStream_t st) {
     if (hipMalloc(&p, bytes + kSplitMaxItems * sizeof(unsigned)) == hipSuccess) {
         w.ws = static_cast<float*>(p);
         w.count = reinterpret_cast<unsigned*>(static_cast<char*>(p) + bytes);
-        if (hipMemsetAsync(w.count, 0, kSplitMaxItems * sizeof(unsigned), st) != hipSuccess) w = SplitWs();
+        if (hipMemsetAsync(w.count, 0, kSplitMaxItems * sizeof(unsigned), st) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(p);
+            return SplitWs();
+        }
     } else {
         (void)hipGetLastError();
         return w;                                             // (not remembered: the next launch asks again)
@@ -784,7 +788,8 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
     // 128 bytes a wave stores are then whole blocks, and anything else streamed past the L2 becomes partial writes
     // (scripts/conv_add_bench.py: 256 -> 1024 @14x14, both tensors kept, 356 us with default stores, 486 with nt)
     a.stream_stores = out_elems * (size_t)(8 + (y ? 4 : 0) + (sum ? 4 : 0)) > ((size_t)256 << 20) && (a.HWout % 16u) == 0;
-    { const char* e = getenv("FQ_CONV_ADD_STREAM"); if (e && e[0]) a.stream_stores = atoi(e); }
+    static const int stream_env = env_int("FQ_CONV_ADD_STREAM", -1);      // 0 / 1: force default / non-temporal accesses (A/B)
+    if (stream_env >= 0) a.stream_stores = stream_env;
 #ifdef FQ_C1_ABLATE
     a.ablate = 0;
 #endif
