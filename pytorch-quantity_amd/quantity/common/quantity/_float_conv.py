@@ -104,8 +104,9 @@ def verified(m, run, x):
     if is_verified(m):
         return None
     # The reference result comes from an independent implementation of the same fp32 mathematics that is NOT the convolution
-    # library wherever that is cheap: asking that library for a layer it will never run again would put its first-use solver
-    # search (tens of milliseconds to seconds per configuration) into a one-shot calibration for nothing.
+    # library: asking that library for a layer it will never run again would put its first-use solver search (tens of
+    # milliseconds to seconds per configuration; 0.4 s for the 7x7 stem alone, scripts/_dbg/one_shot_probe.py) into a one-shot
+    # calibration for nothing.
     head = None                                                 # compare only the first `head` images (None: all)
     if m.kernel_size == (1, 1):                                 # 1x1: a GEMM (rocBLAS through torch.matmul)
         s = m.stride[0]
@@ -114,7 +115,7 @@ def verified(m, run, x):
         shape = (x.shape[0], m.out_channels, (x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1)
         ref = (torch.matmul(w2, xs) + m.bias.view(1, -1, 1)).view(shape)
         bound = (torch.matmul(w2.abs(), xs.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
-    elif m.in_channels >= 16:                                   # R x S: im2col (unfold) + GEMM on the first images
+    else:                                                       # R x S (the stem included): im2col (unfold) + GEMM on the first images
         head = max(1, min(x.shape[0], (1 << 28) // max(x[0].numel() * m.kernel_size[0] * m.kernel_size[1], 1)))
         xh = x[:head]
         cols = torch.nn.functional.unfold(xh, m.kernel_size, padding=m.padding, stride=m.stride)
@@ -124,9 +125,6 @@ def verified(m, run, x):
         ref = (torch.matmul(w2, cols) + m.bias.view(1, -1, 1)).view(shape)
         bound = (torch.matmul(w2.abs(), cols.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
         del cols
-    else:                                                       # the stem: torch's own convolution (one configuration)
-        ref = torch.nn.Conv2d.forward(m, x)
-        bound = torch.nn.functional.conv2d(x.abs(), m.weight.abs(), m.bias.abs(), stride=m.stride, padding=m.padding)
     scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
     own = run(max_dev=scratch, row=0)
     cmp = own if head is None else own[:head]
