@@ -508,8 +508,8 @@ def parse_args():
 
 
 def cold_child(args):
-    """Fresh process, N = 1: (1) the very first activation_quantize() of the process, nothing warmed up at all (MIOpen's
-    first-use solver search and code loading inside the clock): `one_shot_images_per_s`; (2) the allocator pool handed
+    """Fresh process, N = 1: (1) the very first activation_quantize() of the process, nothing warmed up at all (code loading and
+    the once-per-module checks inside the clock): `one_shot_images_per_s`; (2) the allocator pool handed
     back to the driver (empty_cache), then the same workload again: every hipMalloc inside the clock, no activation
     cache (the engine never grows its pool for one), code and MIOpen warm: `value_cold`.  Prints one JSON line."""
     sys.stdout.flush()
@@ -701,9 +701,10 @@ def main():
         if "cold" in cold:
             result["value_cold"] = cold["cold"]["images_per_s"]
             result["cold_process"] = {"what": "fresh process, N=1, same workload; value_cold: allocator pool empty when the clock "
-                                              "starts (code + MIOpen warm from the process's first run), no activation cache; "
-                                              "one_shot: the process's very first call, nothing warmed (MIOpen first-use solver "
-                                              "search, code load and allocation inside the clock)",
+                                              "starts (code warm from the process's first run), no activation cache; "
+                                              "one_shot: the process's very first call, nothing warmed (code load, the once-per-module "
+                                              "checks and allocation inside the clock; a calibration does not enter the convolution "
+                                              "library)",
                                       "cold": cold["cold"], "one_shot": cold.get("one_shot"),
                                       "process_wall_s": cold.get("process_wall_s")}
         else:
