@@ -5,6 +5,11 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: the bare form (no RANK in the environment) starts the second one as a CHILD process before anything
+touches the GPU (spawn_ranks: free master port on 127.0.0.1, rank 0's JSON line relayed, the child's exit code returned; nothing
+is re-exec'ed).  The line says what the collectives saw: `ranks_seen` (dist.get_world_size()), `backend`, and `devices`, one
+(rank, device index, device name) entry per rank.
+
 WORKLOAD.  `--images` (default 5120 = BASELINE configs[1]'s "5k") calibration images PER GPU; --steps only decides how
 they are cut into batches (batch = images / steps: 256 at the driver's 20 steps, 128 at 40), never how many there are.
 `--total-images T` instead fixes the WHOLE job (strong scaling: T / N images per GPU, "scaling": "strong";
@@ -497,6 +502,9 @@ def parse_args():
                     help="tensor: device-resident batches only (the headline); npy / both: also the same images as one .npy file "
                          "each through PRE_PROCESS.IMG = 2 (reported as file_input, never the headline)")
     ap.add_argument("--no-file-input", action="store_true")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launch plumbing only (no GPU needed): every rank joins a gloo group and rank 0 prints a JSON line with "
+                         "ranks_seen / devices / the workload split -- what tests/test_bench_launch_cpu.py runs")
     args = ap.parse_args()
     world = max(args.gpus, 1)
     per_gpu = args.images if not args.total_images else -(-args.total_images // world)
@@ -567,10 +575,70 @@ def run_cold_child(args, log):
         return {"error": repr(e)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (the form the driver uses for N = 1): start
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a CHILD process on a free
+    port of 127.0.0.1, relay rank 0's JSON line and return the child's exit code.  This parent never touches the GPU
+    (torch.cuda.device_count() does not initialise HIP on this stack) and nothing is exec'ed over a process that did."""
+    import socket
+    backend = os.environ.get("FQ_BENCH_BACKEND", "nccl")
+    if not args.dry_launch and backend == "nccl" and torch.cuda.device_count() < args.gpus:
+        print("bench.py --gpus %d: this node shows %d GPU(s).  (A dry run of the %d-rank flow on fewer devices: "
+              "FQ_BENCH_BACKEND=gloo -- ranks then share devices and the number is not a scaling measurement.)"
+              % (args.gpus, torch.cuda.device_count(), args.gpus), file=sys.stderr, flush=True)
+        return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)          # stderr is inherited: the ranks' logs stay visible
+    lines = [ln for ln in r.stdout.split("\n") if ln.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif r.returncode == 0:
+        print("bench.py: the ranks exited with 0 but printed no JSON line", file=sys.stderr, flush=True)
+        return 1
+    return r.returncode
+
+
+def dry_launch(args):
+    """--dry-launch: the launch plumbing without a GPU.  Every rank joins a gloo group, the ranks gather what each of them
+    would bind to, and rank 0 prints the one JSON line -- same keys as the real line where they do not need a measurement."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    devices = [(rank, None, "cpu (dry launch)")]
+    if "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, devices[0])
+        devices, world = gathered, dist.get_world_size()
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": BASELINE_METRIC, "dry_launch": True, "value": None, "unit": "images/s", "n_gpus": args.gpus,
+                          "ranks_seen": world, "backend": "gloo", "devices": [list(d) for d in devices], "steps": args.steps,
+                          "warmup": args.warmup, "scaling": args.scaling,
+                          "config": {"batch": args.batch, "images_per_gpu": args.images_per_gpu,
+                                     "images_total": args.images_per_gpu * world, "parallelism": "dp%d" % world}}), flush=True)
+    if "RANK" in os.environ:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     args = parse_args()
     if args.cold_child:
         return cold_child(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return spawn_ranks(args)
+    if args.dry_launch:
+        return dry_launch(args)
 
     # stdout carries exactly ONE line, the JSON.  Native libraries write there too (RCCL prints a version
     # banner on init), so file descriptor 1 itself is parked on /dev/null until the result is ready.
@@ -582,7 +650,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)" % (args.gpus, world), file=sys.stderr, flush=True)
+        return 2
 
     def log(*a):
         if rank == 0:
@@ -608,6 +678,15 @@ def main():
             dist.init_process_group("nccl", device_id=device)              # backend nccl = RCCL on ROCm
         else:
             dist.init_process_group(backend)
+
+    # what the collectives see (the driver's scaling run reads these: RCCL must have seen N ranks on N different devices)
+    ranks_seen = dist.get_world_size() if distributed else 1
+    devices = [(rank, dev_index, torch.cuda.get_device_name(dev_index))]
+    if distributed:
+        gathered = [None] * ranks_seen
+        dist.all_gather_object(gathered, devices[0])
+        devices = gathered
+    sharing = max(sum(1 for d in devices if d[1] == dev_index), 1)            # ranks on this device (> 1 only in the gloo dry run)
 
     def barrier():
         torch.cuda.synchronize()
@@ -642,7 +721,7 @@ def main():
         if "FQ_ACT_CACHE_GB" not in os.environ:
             free_b, total_b = torch.cuda.mem_get_info()
             pooled_b = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
-            frac = float(os.environ.get("FQ_BENCH_POOL_FRAC", "0.80"))
+            frac = float(os.environ.get("FQ_BENCH_POOL_FRAC", "%.4f" % (0.80 / sharing if sharing == 1 else 0.40 / sharing)))
             grow = min(int(total_b * frac) - torch.cuda.memory_allocated(), free_b + pooled_b - (8 << 30))
             if grow > 0:
                 pool = torch.empty(grow, dtype=torch.uint8, device=device)
@@ -682,7 +761,9 @@ def main():
                        "warm allocator pool; value_cold = the same workload in a fresh process (allocation inside the clock); "
                        "int8-sim images/s is reported beside it as int8_sim_images_per_s (resident integer activations, logits "
                        "bit-identical to int8_sim_fp32_boundary_images_per_s, the reference's module-boundary form)",
-        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": W,
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "ranks_seen": ranks_seen,
+        "backend": (backend + (" (RCCL)" if backend == "nccl" else " (dry run: not RCCL)")) if distributed else "none (one process)",
+        "devices": [list(d) for d in devices], "steps": K, "warmup": W,
         "ms_per_step": round(elapsed / K * 1e3, 3), "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": "f32", "data": "synthetic" + (" (host-resident, PCIe inclusive)" if args.host_inputs else ""),
         "config": {"workload": "fabu ResNet-%s per-tensor KL calibration, %d synthetic 3x%dx%d images per GPU "
@@ -1033,4 +1114,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
