@@ -12,7 +12,8 @@
  *     parameter is documented "host".  The caller owns every buffer.
  *   - All device work is enqueued on the passed hipStream_t (as void*; NULL = the null stream) and is
  *     asynchronous; there is no hidden global state, so calls are thread-safe per stream and
- *     capturable into a hipGraph.  No function allocates device memory.
+ *     capturable into a hipGraph.  No function allocates device memory: scratch a kernel needs is a `workspace`
+ *     argument sized by a fq_*_workspace_bytes() query (fq_kl_threshold, the float convolutions), owned by the caller.
  *   - "row" = one histogram row.  Parity mode uses one row per hooked tensor (the reference's
  *     calibrator is per tensor: distribution_collector.py:40-42); row = tensor x channel is the
  *     same kernels with more rows.
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FQ_VERSION 100            /* 0.1.0 */
+#define FQ_VERSION 101            /* 0.1.1: caller-owned workspace of the float convolutions */
 #define FQ_BINS 2048              /* INTERVAL_NUM, tools/configs.yml:24 */
 #define FQ_KL_TARGET_BINS 128     /* quantizer.py:98 target_bin */
 #define FQ_KL_CANDIDATES 1920     /* thresholds 128..2047, quantizer.py:103 */
@@ -206,12 +207,19 @@ int fq_add_hist_f32(const float* x, const float* y, float* z, size_t n, const fl
  *   hist_row + interval: y counted into int64[2048] with bin width *interval   (distribution_collector.py:127-135)
  * Replaces, inside the float forward the reference runs at pytorch_quantizer.py:288-296, torch's Conv2d for these layers;
  * not bit-identical to the library's convolution (different, fixed summation order), deterministic from run to run.
- * Device memory: launches whose tile count leaves a partly filled last round over the CUs (the tail split)
- * use a 16 MB workspace that the first such launch on a (device, stream) allocates and the library keeps; FQ_CONV_TAIL_SPLIT=0
- * in the environment turns the split off.  This is the only allocation any entry point of this header makes. */
+ * workspace / workspace_bytes (all six entry points of this family; may be NULL / 0): device scratch of
+ *   fq_conv_f32_workspace_bytes() bytes, 16-byte aligned, ZERO-FILLED ONCE by the caller before its first use (the kernels
+ *   leave its counters at zero, so it can be handed to launch after launch); one workspace per stream whose launches may
+ *   overlap.  With it, a launch whose tile count leaves a partly filled last round over the 256 CUs cuts the tiles of that
+ *   round along the reduction into slices that meet in the workspace (the tail split, DESIGN.md section 3: 784-tile launches
+ *   18-20 % faster).  A split tile's value is the sum of <= 16 partial fma chains added in slice order instead of one chain:
+ *   deterministic, but WHICH tiles are split depends on the tile count, i.e. on the batch size N -- the same images pushed
+ *   through in different batch sizes may differ in the last bit of those outputs.  NULL (or FQ_CONV_TAIL_SPLIT=0 in the
+ *   environment): never split; every output is one chain over ci = 0 .. Cin-1 whatever N is. */
+size_t fq_conv_f32_workspace_bytes(void);
 int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin,
                    int Win, int Cout, int stride, float* max_inout, const float* interval, int64_t* hist_row,
-                   fq_stream_t stream);
+                   void* workspace, size_t workspace_bytes, fq_stream_t stream);
 
 /* The same kernel for R x S convolutions with zero padding (ResNet's 3x3 layers, stride 1 and 2): the reduction runs tap by
  * tap over the same x rows, shifted -- a 1x1 convolution per tap whose per-thread pixel offset (or "outside the image:
@@ -222,7 +230,7 @@ int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y,
  * (the convolution library's Winograd kernels are not reproducible from call to call) and does not touch that library. */
 int fq_conv_kxk_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin,
                     int Win, int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval,
-                    int64_t* hist_row, fq_stream_t stream);
+                    int64_t* hist_row, void* workspace, size_t workspace_bytes, fq_stream_t stream);
 
 /* The float stem convolution of the calibration forward (ResNet-50/101's conv1: 7x7, stride 2, 3 -> Cout <= 64 channels,
  * any padding) on the fp32 matrix cores, same epilogue contract as fq_conv1x1_f32 (bias, relu_out, and exactly one of
@@ -243,9 +251,10 @@ int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* 
  * QuanDequan sees is exactly what fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32 would have stored, so the result equals
  * fq_quandequan_f32 of their output bit for bit.  Same operand contracts as the plain entry points. */
 int fq_conv1x1_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
-                      int Cout, int stride, int bit, int bitwidth, fq_stream_t stream);
+                      int Cout, int stride, int bit, int bitwidth, void* workspace, size_t workspace_bytes, fq_stream_t stream);
 int fq_conv_kxk_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
-                       int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream);
+                       int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, void* workspace,
+                       size_t workspace_bytes, fq_stream_t stream);
 int fq_conv_stem_qd_f32(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int H, int W,
                         int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream);
 
@@ -258,13 +267,14 @@ int fq_conv_stem_qd_f32(const float* x, const float* wp, const float* bias, floa
  * FQ_ERR_UNSUPPORTED unless Cin % 16 == 0 and Cout % 128 == 0 (callers keep the two kernels there). */
 int fq_conv1x1_add_f32(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
                        float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y, float* max_sum,
-                       fq_stream_t stream);
+                       void* workspace, size_t workspace_bytes, fq_stream_t stream);
 /* ... and in pass 2: v and s are counted into the 2048-bin rows hist_y / hist_sum (bin widths *interval_y / *interval_sum,
  * the rule of fq_hist2048_seg) while they pass through the registers and are not written at all; relu_out = max(s, 0).
  * Bit for bit the rows fq_conv1x1_f32 (histogram form) followed by fq_add_hist_f32 leave. */
 int fq_conv1x1_add_hist_f32(const float* x, const float* wt, const float* bias, const float* res, float* relu_out, int N, int Cin,
                             int Hin, int Win, int Cout, int stride, const float* interval_y, int64_t* hist_y,
-                            const float* interval_sum, int64_t* hist_sum, fq_stream_t stream);
+                            const float* interval_sum, int64_t* hist_sum, void* workspace, size_t workspace_bytes,
+                            fq_stream_t stream);
 
 /* The pooling layers of the float calibration forward (nn.MaxPool2d / a global nn.AvgPool2d inside the model the
  * reference runs at pytorch_quantizer.py:288-296), bit for bit what torch computes:

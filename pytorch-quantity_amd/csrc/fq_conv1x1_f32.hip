@@ -30,8 +30,6 @@
 #include "fq_common.h"
 #include "fq_producer_stat.h"
 
-#include <map>
-#include <mutex>
 #include <utility>
 
 namespace fq {
@@ -597,67 +595,37 @@ int env_int(const char* name, int dflt) {
 // slices each: the tail becomes one more FULL round of short workgroups, 3.06 tile times instead of 4.  The slices meet in
 // a workspace (conv1x1_tiles); the summation order is fixed, and which tiles are split is a function of the layer's shape
 // alone, the same for every form of the kernel -- so a value does not depend on the statistic that rides on it.
-struct SplitWs {
-    float* ws = nullptr;
-    unsigned* count = nullptr;
-};
 constexpr unsigned kSplitMaxItems = 256, kSplitMaxSlices = 16;
+// The workspace belongs to the CALLER (include/fq.h: fq_conv_f32_workspace_bytes): [kSplitMaxItems partial tiles of 128 x 128
+// floats -- (split tiles) x (slices per tile) never exceeds 256][kSplitMaxItems arrival counters, one per split tile].  The
+// counters must be zero when a launch starts; the workgroup that arrives last at a tile puts its counter back to zero, so a
+// workspace zero-filled once stays usable launch after launch on one stream.  NULL (or too small): the launch runs unsplit.
+constexpr size_t kSplitWsFloatBytes = (size_t)kSplitMaxItems * 128 * 128 * sizeof(float);
+constexpr size_t kSplitWsBytes = kSplitWsFloatBytes + kSplitMaxItems * sizeof(unsigned);
 
-SplitWs split_workspace(hipStream_t st) {
-    static std::mutex mu;
-    static std::map<std::pair<int, hipStream_t>, SplitWs> per_stream;   // (device, stream): launches on different streams may overlap
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return SplitWs();
-    const std::pair<int, hipStream_t> key(dev, st);
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = per_stream.find(key);
-    if (it != per_stream.end()) return it->second;
-    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;  // no allocation inside a stream capture: that launch runs unsplit
-    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return SplitWs();
-    }
-    SplitWs w;
-    void* p = nullptr;
-    const size_t bytes = (size_t)kSplitMaxItems * 128 * 128 * sizeof(float);
-    if (hipMalloc(&p, bytes + kSplitMaxItems * sizeof(unsigned)) == hipSuccess) {
-        w.ws = static_cast<float*>(p);
-        w.count = reinterpret_cast<unsigned*>(static_cast<char*>(p) + bytes);
-        if (hipMemsetAsync(w.count, 0, kSplitMaxItems * sizeof(unsigned), st) != hipSuccess) {
-            (void)hipGetLastError();
-            (void)hipFree(p);
-            return SplitWs();
-        }
-    } else {
-        (void)hipGetLastError();
-        return w;                                             // (not remembered: the next launch asks again)
-    }
-    per_stream[key] = w;
-    return w;
-}
-
-void plan_split(C1Args& a, unsigned nk, hipStream_t st) {
+void plan_split(C1Args& a, unsigned nk, void* workspace, size_t workspace_bytes) {
     a.split_first = a.tiles; a.split_s = 1; a.work = a.tiles; a.ws = nullptr; a.ws_count = nullptr;
     static const int on = env_int("FQ_CONV_TAIL_SPLIT", 1);
+    if (!workspace || workspace_bytes < kSplitWsBytes || (reinterpret_cast<uintptr_t>(workspace) & 15u)) return;
     const unsigned rounds = a.tiles / (unsigned)kCUs, rem = a.tiles % (unsigned)kCUs;
     if (!on || rounds == 0 || rounds >= 16 || rem == 0 || rem > (unsigned)kCUs / 2) return;
     unsigned s = (unsigned)kCUs / rem;
     if (s > kSplitMaxSlices) s = kSplitMaxSlices;
     if (s > nk / 8) s = nk / 8;                               // at least 8 K steps per slice
     if (s < 2) return;
-    const SplitWs w = split_workspace(st);
-    if (!w.ws) return;
-    a.split_first = a.tiles - rem; a.split_s = s; a.work = a.split_first + rem * s; a.ws = w.ws; a.ws_count = w.count;
+    a.split_first = a.tiles - rem; a.split_s = s; a.work = a.split_first + rem * s;
+    a.ws = static_cast<float*>(workspace);
+    a.ws_count = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + kSplitWsFloatBytes);
 }
 
 template <int WM, int WN, int kTailK>
 void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, int64_t* hist_row, int hist_per_cu, int fast,
-            const QdStat* qd, hipStream_t st) {
+            const QdStat* qd, void* workspace, size_t workspace_bytes, hipStream_t st) {
     typedef Shape<WM, WN> S;
     a.tiles_m = (a.Cout + S::BM - 1) / S::BM;
     a.tiles = ((cols + S::BN - 1) / S::BN) * a.tiles_m;
     constexpr unsigned BK = (unsigned)step_of<WM>();
-    plan_split(a, kTailK == 2 ? (unsigned)(a.R * a.S) * (a.Cin / BK) : (a.Cin + BK - 1) / BK, st);
+    plan_split(a, kTailK == 2 ? (unsigned)(a.R * a.S) * (a.Cin / BK) : (a.Cin + BK - 1) / BK, workspace, workspace_bytes);
     if (qd) {
         hipLaunchKernelGGL((conv1x1_f32_qd_kernel<WM, WN, kTailK>), dim3(a.work), dim3(kT), 0, st, a, *qd);
     } else if (hist_row) {
@@ -690,7 +658,7 @@ namespace {
 // the common host side of fq_conv1x1_f32 (R = S = 1, pad = 0) and fq_conv_kxk_f32
 int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin, int Win,
                     int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval, int64_t* hist_row,
-                    fq_stream_t stream, const QdStat* qd = nullptr) {
+                    void* workspace, size_t workspace_bytes, fq_stream_t stream, const QdStat* qd = nullptr) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1 || R < 1 || S < 1 || pad < 0) return FQ_ERR_INVALID_ARG;
     if (Hin + 2 * pad < R || Win + 2 * pad < S) return FQ_ERR_INVALID_ARG;
     if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
@@ -734,9 +702,9 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     const int shape = forced ? forced : ((Cout <= 64 || tiles22 <= (size_t)kCUs * 4) ? 12 : 22);
 #define FQ_C1_LAUNCH(WM, WN)                                                                                       \
     do {                                                                                                           \
-        if (mode == 2) launch<WM, WN, 2>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, st);     \
-        else if (mode == 1) launch<WM, WN, 1>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, st); \
-        else launch<WM, WN, 0>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, st);               \
+        if (mode == 2) launch<WM, WN, 2>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, workspace, workspace_bytes, st);     \
+        else if (mode == 1) launch<WM, WN, 1>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, workspace, workspace_bytes, st); \
+        else launch<WM, WN, 0>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, workspace, workspace_bytes, st);               \
     } while (0)
     if (shape == 12) FQ_C1_LAUNCH(1, 2);
     else FQ_C1_LAUNCH(2, 2);
@@ -747,16 +715,21 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
 
 }  // namespace
 
+extern "C" size_t fq_conv_f32_workspace_bytes(void) { return kSplitWsBytes; }
+
 extern "C" int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin,
                               int Hin, int Win, int Cout, int stride, float* max_inout, const float* interval,
-                              int64_t* hist_row, fq_stream_t stream) {
-    return conv_f32_launch(x, wt, bias, y, relu_out, N, Cin, Hin, Win, Cout, 1, 1, stride, 0, max_inout, interval, hist_row, stream);
+                              int64_t* hist_row, void* workspace, size_t workspace_bytes, fq_stream_t stream) {
+    return conv_f32_launch(x, wt, bias, y, relu_out, N, Cin, Hin, Win, Cout, 1, 1, stride, 0, max_inout, interval, hist_row,
+                           workspace, workspace_bytes, stream);
 }
 
 extern "C" int fq_conv_kxk_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin,
                                int Hin, int Win, int Cout, int R, int S, int stride, int pad, float* max_inout,
-                               const float* interval, int64_t* hist_row, fq_stream_t stream) {
-    return conv_f32_launch(x, wt, bias, y, relu_out, N, Cin, Hin, Win, Cout, R, S, stride, pad, max_inout, interval, hist_row, stream);
+                               const float* interval, int64_t* hist_row, void* workspace, size_t workspace_bytes,
+                               fq_stream_t stream) {
+    return conv_f32_launch(x, wt, bias, y, relu_out, N, Cin, Hin, Win, Cout, R, S, stride, pad, max_inout, interval, hist_row,
+                           workspace, workspace_bytes, stream);
 }
 
 // The last 1x1 convolution of a residual block together with the Eltwise (fabu_layer.py:5-11) and the ReLU behind it:
@@ -765,7 +738,7 @@ extern "C" int fq_conv_kxk_f32(const float* x, const float* wt, const float* bia
 static int conv_add_launch(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
                            float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y, float* max_sum,
                            const float* interval_y, int64_t* hist_y, const float* interval_sum, int64_t* hist_sum,
-                           fq_stream_t stream) {
+                           void* workspace, size_t workspace_bytes, fq_stream_t stream) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1) return FQ_ERR_INVALID_ARG;
     if (N == 0) return FQ_OK;
     const bool hist = hist_y != nullptr;
@@ -799,7 +772,7 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
     hipStream_t st = as_stream(stream);
     a.tiles_m = (unsigned)Cout / (narrow ? 64u : 128u);
     a.tiles = (unsigned)((cols + 127) / 128) * a.tiles_m;
-    plan_split(a, (unsigned)Cin / (unsigned)(narrow ? step_of<1>() : step_of<2>()), st);
+    plan_split(a, (unsigned)Cin / (unsigned)(narrow ? step_of<1>() : step_of<2>()), workspace, workspace_bytes);
     if (hist) {
         static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
         static const int res12 = [] {
@@ -833,19 +806,20 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
 
 extern "C" int fq_conv1x1_add_f32(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
                                   float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y,
-                                  float* max_sum, fq_stream_t stream) {
+                                  float* max_sum, void* workspace, size_t workspace_bytes, fq_stream_t stream) {
     return conv_add_launch(x, wt, bias, res, y, sum, relu_out, N, Cin, Hin, Win, Cout, stride, max_y, max_sum, nullptr, nullptr,
-                           nullptr, nullptr, stream);
+                           nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
 // The same chain in calibration pass 2: the convolution's output and the sum are histogrammed (2048 bins each, rows hist_y and
 // hist_sum with their interval widths) while they pass through the registers and are not written at all; relu_out = max(sum, 0).
 extern "C" int fq_conv1x1_add_hist_f32(const float* x, const float* wt, const float* bias, const float* res, float* relu_out,
                                        int N, int Cin, int Hin, int Win, int Cout, int stride, const float* interval_y,
-                                       int64_t* hist_y, const float* interval_sum, int64_t* hist_sum, fq_stream_t stream) {
+                                       int64_t* hist_y, const float* interval_sum, int64_t* hist_sum, void* workspace,
+                                       size_t workspace_bytes, fq_stream_t stream) {
     if (!hist_y) return FQ_ERR_INVALID_ARG;
     return conv_add_launch(x, wt, bias, res, nullptr, nullptr, relu_out, N, Cin, Hin, Win, Cout, stride, nullptr, nullptr, interval_y,
-                           hist_y, interval_sum, hist_sum, stream);
+                           hist_y, interval_sum, hist_sum, workspace, workspace_bytes, stream);
 }
 
 // TestConv.forward (new_quantity_op.py:283-292) / TestLinear.forward (:248-256 on the classifier seen as a 1x1 layer) in one
@@ -859,15 +833,19 @@ static bool qd_params(int bit, int bitwidth, QdStat* qd) {
 }
 
 extern "C" int fq_conv1x1_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
-                                 int Cout, int stride, int bit, int bitwidth, fq_stream_t stream) {
+                                 int Cout, int stride, int bit, int bitwidth, void* workspace, size_t workspace_bytes,
+                                 fq_stream_t stream) {
     QdStat qd;
     if (!qd_params(bit, bitwidth, &qd)) return FQ_ERR_INVALID_ARG;
-    return conv_f32_launch(x, wt, bias, y, nullptr, N, Cin, Hin, Win, Cout, 1, 1, stride, 0, nullptr, nullptr, nullptr, stream, &qd);
+    return conv_f32_launch(x, wt, bias, y, nullptr, N, Cin, Hin, Win, Cout, 1, 1, stride, 0, nullptr, nullptr, nullptr, workspace,
+                           workspace_bytes, stream, &qd);
 }
 
 extern "C" int fq_conv_kxk_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
-                                  int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream) {
+                                  int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, void* workspace,
+                                  size_t workspace_bytes, fq_stream_t stream) {
     QdStat qd;
     if (!qd_params(bit, bitwidth, &qd)) return FQ_ERR_INVALID_ARG;
-    return conv_f32_launch(x, wt, bias, y, nullptr, N, Cin, Hin, Win, Cout, R, S, stride, pad, nullptr, nullptr, nullptr, stream, &qd);
+    return conv_f32_launch(x, wt, bias, y, nullptr, N, Cin, Hin, Win, Cout, R, S, stride, pad, nullptr, nullptr, nullptr, workspace,
+                           workspace_bytes, stream, &qd);
 }

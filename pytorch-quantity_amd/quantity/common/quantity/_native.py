@@ -97,9 +97,11 @@ def lib():
     L.fq_add_hist_f32.restype = ci
     L.fq_add_hist_f32.argtypes = [vp, vp, vp, sz, vp, vp, vp, vp]
     L.fq_conv1x1_f32.restype = ci
-    L.fq_conv1x1_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [vp, vp, vp, vp]
+    L.fq_conv_f32_workspace_bytes.restype = sz
+    L.fq_conv_f32_workspace_bytes.argtypes = []
+    L.fq_conv1x1_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [vp, vp, vp, vp, sz, vp]
     L.fq_conv_kxk_f32.restype = ci
-    L.fq_conv_kxk_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [vp, vp, vp, vp]
+    L.fq_conv_kxk_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [vp, vp, vp, vp, sz, vp]
     L.fq_conv_stem_f32_packed_rows.restype = ci
     L.fq_conv_stem_f32_packed_rows.argtypes = [ci, ci, ci]
     L.fq_conv_stem_f32.restype = ci
@@ -107,13 +109,13 @@ def lib():
     L.fq_read_npy_batch_f32.restype = ci
     L.fq_read_npy_batch_f32.argtypes = [vp, ci, ctypes.c_char_p, ctypes.c_size_t, vp, ctypes.c_size_t, ci, vp]
     L.fq_conv1x1_add_f32.restype = ci
-    L.fq_conv1x1_add_f32.argtypes = [vp] * 7 + [ci] * 6 + [vp, vp, vp]
+    L.fq_conv1x1_add_f32.argtypes = [vp] * 7 + [ci] * 6 + [vp, vp, vp, sz, vp]
     L.fq_conv1x1_add_hist_f32.restype = ci
-    L.fq_conv1x1_add_hist_f32.argtypes = [vp] * 5 + [ci] * 6 + [vp, vp, vp, vp, vp]
+    L.fq_conv1x1_add_hist_f32.argtypes = [vp] * 5 + [ci] * 6 + [vp, vp, vp, vp, vp, sz, vp]
     L.fq_conv1x1_qd_f32.restype = ci
-    L.fq_conv1x1_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 8 + [vp]
+    L.fq_conv1x1_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 8 + [vp, sz, vp]
     L.fq_conv_kxk_qd_f32.restype = ci
-    L.fq_conv_kxk_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 11 + [vp]
+    L.fq_conv_kxk_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 11 + [vp, sz, vp]
     L.fq_conv_stem_qd_f32.restype = ci
     L.fq_conv_stem_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 11 + [vp]
     L.fq_maxpool2d_f32.restype = ci
@@ -358,6 +360,30 @@ def _qd_args(qd, max_dev, hist_dev, relu_out, name):
     return bit, bitwidth
 
 
+# The tail split of the float convolutions (include/fq.h, fq_conv_f32_workspace_bytes): the CALLER owns the 16 MB scratch.  Here
+# that is one zero-filled tensor from torch's allocator per (device, stream) -- launches of one stream run one after the
+# other, launches of different streams may overlap and must not share counters.  conv_tail_split = False (or
+# FQ_CONV_TAIL_SPLIT=0) hands the kernels no workspace at all: every output is then ONE fma chain whatever the batch size is
+# (with the split, which tiles are cut depends on the launch's tile count, i.e. on N).
+conv_tail_split = os.environ.get("FQ_CONV_TAIL_SPLIT", "1") != "0"
+_conv_ws = {}
+
+
+def conv_workspace(x):
+    """(pointer, bytes) of this stream's tail-split workspace, or (None, 0): split switched off, or the first use of a stream
+    falls inside a graph capture (an allocation made there would belong to the graph's private pool)."""
+    if not conv_tail_split:
+        return None, 0
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _conv_ws.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None, 0
+        ws = torch.zeros(int(lib().fq_conv_f32_workspace_bytes()), dtype=torch.uint8, device=x.device)
+        _conv_ws[key] = ws
+    return ws.data_ptr(), ws.numel()
+
+
 def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None, out=None, qd=None):
     """fq_conv1x1_f32: the float 1x1 convolution (padding 0, groups 1) of x [N, Cin, H, W] with the TRANSPOSED weights
     wt [Cin, Cout] on the fp32 matrix cores; max_dev/row: abs-max of the output folded into max_dev[row]; interval_dev/
@@ -381,7 +407,7 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
     if qd is not None:
         bit, bw = _qd_args(qd, max_dev, hist_dev, relu_out, "fq_conv1x1_qd_f32")
         _check(lib().fq_conv1x1_qd_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                       N, Cin, H, W, Cout, s, bit, bw, _stream(x)), "fq_conv1x1_qd_f32")
+                                       N, Cin, H, W, Cout, s, bit, bw, *conv_workspace(x), _stream(x)), "fq_conv1x1_qd_f32")
         return y
     mp = ivp = hp = None
     if hist_dev is not None:
@@ -392,7 +418,7 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
         mp = max_dev.data_ptr() + 4 * int(row)
     _check(lib().fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(),
                                 None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin, H, W,
-                                Cout, s, mp, ivp, hp, _stream(x)), "fq_conv1x1_f32")
+                                Cout, s, mp, ivp, hp, *conv_workspace(x), _stream(x)), "fq_conv1x1_f32")
     return y
 
 
@@ -413,7 +439,7 @@ def conv1x1_add_f32(x, wt, bias, stride, res, max_dev, row_y, row_sum, relu_out,
     _check(lib().fq_conv1x1_add_f32(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(),
                                     None if out is None else out.data_ptr(), None if sum_out is None else sum_out.data_ptr(),
                                     relu_out.data_ptr(), N, Cin, H, W, Cout, s, max_dev.data_ptr() + 4 * int(row_y),
-                                    max_dev.data_ptr() + 4 * int(row_sum), _stream(x)), "fq_conv1x1_add_f32")
+                                    max_dev.data_ptr() + 4 * int(row_sum), *conv_workspace(x), _stream(x)), "fq_conv1x1_add_f32")
     return relu_out
 
 
@@ -432,7 +458,8 @@ def conv1x1_add_hist_f32(x, wt, bias, stride, res, interval_dev, hist_dev, row_y
     ivy, hy = _hist_row_ptrs(interval_dev, hist_dev, row_y)
     ivs, hs = _hist_row_ptrs(interval_dev, hist_dev, row_sum)
     _check(lib().fq_conv1x1_add_hist_f32(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(), relu_out.data_ptr(),
-                                         N, Cin, H, W, Cout, s, ivy, hy, ivs, hs, _stream(x)), "fq_conv1x1_add_hist_f32")
+                                         N, Cin, H, W, Cout, s, ivy, hy, ivs, hs, *conv_workspace(x), _stream(x)),
+           "fq_conv1x1_add_hist_f32")
     return relu_out
 
 
@@ -469,7 +496,7 @@ def conv_kxk_f32(x, wt, bias, kernel, stride, pad, max_dev=None, interval_dev=No
     if qd is not None:
         bit, bw = _qd_args(qd, max_dev, hist_dev, relu_out, "fq_conv_kxk_qd_f32")
         _check(lib().fq_conv_kxk_qd_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                        N, Cin, H, W, Cout, R, S, st, pd, bit, bw, _stream(x)), "fq_conv_kxk_qd_f32")
+                                        N, Cin, H, W, Cout, R, S, st, pd, bit, bw, *conv_workspace(x), _stream(x)), "fq_conv_kxk_qd_f32")
         return y
     mp = ivp = hp = None
     if hist_dev is not None:
@@ -480,7 +507,7 @@ def conv_kxk_f32(x, wt, bias, kernel, stride, pad, max_dev=None, interval_dev=No
         mp = max_dev.data_ptr() + 4 * int(row)
     _check(lib().fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(),
                                  None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin, H, W,
-                                 Cout, R, S, st, pd, mp, ivp, hp, _stream(x)), "fq_conv_kxk_f32")
+                                 Cout, R, S, st, pd, mp, ivp, hp, *conv_workspace(x), _stream(x)), "fq_conv_kxk_f32")
     return y
 
 

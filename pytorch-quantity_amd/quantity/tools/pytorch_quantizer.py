@@ -291,10 +291,14 @@ class Quantity(object):
         return None
 
     # File inputs (PRE_PROCESS.IMG 0 / 2): the reference feeds ONE file per forward (pytorch_quantizer.py:252-284,
-    # 288-296).  Maxima and integer histograms do not depend on how the images are grouped, and this library's float
-    # kernels compute every output element with a fixed summation order whatever the batch size, so `file_batch`
-    # consecutive files of a rank go through the model as one batch -- same tables, bit for bit (tests/test_gpu_file_inputs.py)
-    # -- decoded by `decode_workers` threads straight into one pinned staging tensor.  file_batch = 1: the reference's form.
+    # 288-296).  Maxima and integer histograms do not depend on how the images are grouped, so `file_batch` consecutive
+    # files of a rank go through the model as one batch, decoded by `decode_workers` threads straight into one pinned staging
+    # tensor (file_batch = 1: the reference's form).  What the grouping CAN touch is the last bit of some activations: this
+    # library's float kernels compute an output element as one fma chain whatever the batch size -- except in the tiles of a
+    # launch's partly filled last round, which the tail split (include/fq.h, fq_conv_f32_workspace_bytes) cuts along K, and
+    # which tiles those are depends on the launch's tile count.  With _native.conv_tail_split = False (FQ_CONV_TAIL_SPLIT=0)
+    # any grouping gives the same histograms bit for bit; with it (default, +3 % images/s) the same feat.table and
+    # histograms that differ in a few counts of neighbouring bins (tests/test_gpu_file_inputs.py runs both).
     file_batch = int(os.environ.get("FQ_FILE_BATCH", "64"))
     decode_workers = int(os.environ.get("FQ_DECODE_WORKERS", str(min(16, os.cpu_count() or 8))))
     # pass 2 reads the inputs again: file batches already uploaded in pass 1 stay on the device up to this many bytes

@@ -1,8 +1,10 @@
 """SURVEY 8f-3, file inputs at speed (reference quantity/tools/pytorch_quantizer.py:252-284: PRE_PROCESS.IMG = 2 / 0, one
 file per calibration item, one forward per file).  On the GPU the drop-in groups `Quantity.file_batch` consecutive files of a
 rank into one forward, decoded by a thread pool straight into a pinned staging tensor: the tables must not depend on the
-grouping -- maxima and integer histograms are order independent, and the float kernels compute every output element in a
-fixed summation order whatever the batch size.   pytest -m gpu"""
+grouping -- maxima and integer histograms are order independent, and the float kernels compute every output element as one
+fma chain whatever the batch size, EXCEPT in the tiles the tail split cuts (launches of more than 256 tiles whose last round
+over the CUs is partly filled: which tiles those are depends on the batch size).  So: bit-identical histograms for any
+grouping with the split off, the same table and histograms within a stated distance with it on (last test).   pytest -m gpu"""
 import os
 
 import numpy as np
@@ -86,3 +88,67 @@ def test_npy_reader_fills_the_pinned_batch_without_an_intermediate_array(tmp_pat
     assert not Quantity._read_npy_into(str(tmp_path / "f.npy"), dst)          # Fortran order / another dtype / another shape:
     assert not Quantity._read_npy_into(str(tmp_path / "d.npy"), dst)          # the caller falls back to np.load
     assert not Quantity._read_npy_into(str(tmp_path / "a.npy"), np.zeros((3, 5, 8), dtype=np.float32))
+
+
+def _calibrate_net(net, items, mode, file_batch, max_cali, shape):
+    from tools import Quantity
+
+    class Q(Quantity):
+        pass
+    Q.file_batch = file_batch
+    with product_workdir(device="gpu", max_cali_img_num=max_cali, input_shape=shape) as tmp:
+        _set_mode(tmp, mode)
+        q = Q(net)
+        q.activation_quantize(items)
+        table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
+        return table, q._collector.hist_device.cpu().numpy(), q._collector.max_device.cpu().numpy()
+
+
+@pytest.mark.timeout(900)
+def test_grouping_on_launches_of_more_than_256_tiles_with_the_tail_split_on_and_off(tmp_path):
+    """one file per forward against 64 files per forward where a launch has MORE than 256 tiles (the earlier tests
+    stay below that and never reach the tail split).  A 128 -> 256 1x1 convolution on 40 x 40 planes: 64 images are 102 400
+    columns = 1 600 tiles of 128 x 128 (6 rounds of 256 + 64: the last 64 tiles are cut into 4 K slices each), one image is
+    26 tiles (never split).  Split OFF: every output is one fma chain whatever N -- maxima and histograms bit-identical.
+    Split ON (the default): the 64-file launch computes 4 % of its outputs as sums of four partial chains, so a few values
+    may land in a neighbouring bin -- same feat.table, maxima within 4 ulp, histograms within 1e-4 of their mass in L1."""
+    from torch import nn
+    from common.quantity import _native, View
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c0 = nn.Conv2d(3, 128, 3, padding=1)
+            self.r0 = nn.ReLU()
+            self.c1 = nn.Conv2d(128, 256, 1)
+            self.r1 = nn.ReLU()
+            self.pool = nn.AvgPool2d(40)
+            self.view = View()
+            self.fc = nn.Linear(256, 10)
+
+        def forward(self, x):
+            return self.fc(self.view(self.pool(self.r1(self.c1(self.r0(self.c0(x)))))))
+
+    torch.manual_seed(5)
+    net = Net().eval().cuda()
+    paths = []
+    for i in range(65):                                                       # items 0 .. 64 are used: 64 + 1 files
+        paths.append(str(tmp_path / ("im%02d.npy" % i)))
+        np.save(paths[-1], cases.fixed_input((3, 40, 40), seed=300 + i).numpy())
+    old = _native.conv_tail_split
+    got = {}
+    try:
+        for split in (False, True):
+            _native.conv_tail_split = split
+            got[split] = (_calibrate_net(net, paths, 2, 1, 64, "1,3,40,40"), _calibrate_net(net, paths, 2, 64, 64, "1,3,40,40"))
+    finally:
+        _native.conv_tail_split = old
+    (t1, h1, m1), (t64, h64, m64) = got[False]
+    assert t1 == t64 and np.array_equal(h1, h64) and np.array_equal(m1, m64)
+    (s1, g1, n1), (s64, g64, n64) = got[True]
+    assert s1 == s64 == t1                                                    # the table does not move
+    assert np.array_equal(g1, h1) and np.array_equal(n1, m1)                  # one image per forward never splits
+    assert np.allclose(n64, m1, rtol=4 * 2.0 ** -23, atol=0)
+    mass = h1.sum(axis=1).astype(np.float64)
+    dist = np.abs(g64.astype(np.int64) - h1.astype(np.int64)).sum(axis=1)
+    assert np.array_equal(g64.sum(axis=1), h1.sum(axis=1)) and float((dist / np.maximum(mass, 1)).max()) <= 1e-4

@@ -158,6 +158,64 @@ def test_streaming_form_beyond_the_infinity_cache(nat):
     assert torch.equal(y, ref) and torch.equal(r, torch.relu(ref)) and float(mx[0]) == float(ref.abs().max())
 
 
+def test_tail_split_workspace_is_the_callers(nat):
+    """include/fq.h: the float convolutions allocate nothing.  The tail split's scratch is a `workspace` argument
+    (fq_conv_f32_workspace_bytes), zero-filled once by the caller; the kernels leave its counters at zero.  NULL, a workspace
+    that is too small or FQ_CONV_TAIL_SPLIT=0 run the launch UNSPLIT: on integer-valued data (every partial sum exact) the
+    split and the unsplit launch must agree bit for bit, and the unsplit launch is one fma chain per output whatever the
+    batch size -- the same images in two halves give the same bits, which the split form does not promise."""
+    L = nat.lib()
+    shape = (130, 256, 1024, 8, 16, 1)                                       # 1 040 tiles: the last 16 are cut into 4 K slices
+    N, cin, cout, H, W, s = shape
+    nbytes = int(L.fq_conv_f32_workspace_bytes())
+    assert nbytes == 256 * 128 * 128 * 4 + 256 * 4
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device="cuda")
+
+    def run(x, wt, b, wsp, wsb, n=N):
+        y = torch.empty(n, cout, H, W, device="cuda")
+        rc = L.fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), b.data_ptr(), y.data_ptr(), None, n, cin, H, W, cout, s, None, None, None,
+                              wsp, wsb, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return y
+
+    x, w, b, wt, _ = _case(shape, 41, integer=True)
+    ref = torch.nn.functional.conv2d(x, w, b)
+    y_split = run(x, wt, b, ws.data_ptr(), nbytes)
+    assert torch.equal(y_split, ref)
+    assert int(ws[256 * 128 * 128 * 4:].view(torch.int32).abs().sum()) == 0           # counters back at zero ...
+    assert int(ws[:256 * 128 * 128 * 4].view(torch.int32).ne(0).sum()) > 0            # ... and the slices did meet here
+    assert torch.equal(run(x, wt, b, ws.data_ptr(), nbytes), ref)                      # the same workspace, launch after launch
+    assert torch.equal(run(x, wt, b, None, 0), ref)                                    # no workspace: unsplit
+    small = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+    assert torch.equal(run(x, wt, b, small.data_ptr(), 4096), ref) and int(small.sum()) == 0   # too small: unsplit, untouched
+
+    xg, wg, bg, wtg, _ = _case(shape, 42, integer=False)
+    y_un = run(xg, wtg, bg, None, 0)
+    halves = torch.cat([run(xg[:65].contiguous(), wtg, bg, None, 0, 65), run(xg[65:].contiguous(), wtg, bg, None, 0, 65)])
+    assert torch.equal(y_un, halves)                                                   # one chain per output, whatever N
+    y_sp = run(xg, wtg, bg, ws.data_ptr(), nbytes)
+    tol = 1e-5 * (torch.nn.functional.conv2d(xg.abs(), wg.abs()) + bg.abs().view(1, -1, 1, 1))
+    assert bool(((y_sp - y_un).abs() <= tol).all())
+    diff = (y_sp != y_un).flatten(1).any(1)                                            # only images inside the 16 split tiles differ
+    assert int(diff.sum()) <= 17 and not bool(diff[:100].any())
+    # the binding: one workspace per (device, stream) from torch's allocator, none when the split is switched off
+    p1, n1 = nat.conv_workspace(x)
+    assert n1 == nbytes and nat.conv_workspace(x) == (p1, n1)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        p2, _ = nat.conv_workspace(x)
+    assert p2 != p1
+    old = nat.conv_tail_split
+    nat.conv_tail_split = False
+    try:
+        assert nat.conv_workspace(x) == (None, 0)
+        assert torch.equal(nat.conv1x1_f32(xg, wtg, bg, s), y_un)
+    finally:
+        nat.conv_tail_split = old
+    assert torch.equal(nat.conv1x1_f32(xg, wtg, bg, s), y_sp)
+
+
 def test_argument_errors(nat):
     L = nat.lib()
     x = torch.zeros(1, 4, 2, 2, device="cuda")
@@ -166,13 +224,13 @@ def test_argument_errors(nat):
     one = torch.zeros(1, device="cuda")
     h = torch.zeros(2048, dtype=torch.int64, device="cuda")
     call = lambda *a: L.fq_conv1x1_f32(*a)
-    assert call(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 6, 1, None, None, None, None) == -4
+    assert call(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 6, 1, None, None, None, None, 0, None) == -4
     wt8 = torch.zeros(4, 8, device="cuda")
     assert call(x.data_ptr(), wt8.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 8, 1, one.data_ptr(), one.data_ptr(),
-                h.data_ptr(), None) == -1                                    # both statistics at once
-    assert call(x.data_ptr(), wt8.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 8, 1, None, None, h.data_ptr(), None) == -1
-    assert call(x.data_ptr(), wt8.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 8, 0, None, None, None, None) == -1
-    assert call(None, None, None, None, None, 0, 4, 2, 2, 8, 1, None, None, None, None) == 0        # no images: nothing to do
+                h.data_ptr(), None, 0, None) == -1                           # both statistics at once
+    assert call(x.data_ptr(), wt8.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 8, 1, None, None, h.data_ptr(), None, 0, None) == -1
+    assert call(x.data_ptr(), wt8.data_ptr(), None, y.data_ptr(), None, 1, 4, 2, 2, 8, 0, None, None, None, None, 0, None) == -1
+    assert call(None, None, None, None, None, 0, 4, 2, 2, 8, 1, None, None, None, None, 0, None) == 0   # no images: nothing to do
 
 
 def _bottleneck_net():
@@ -337,8 +395,8 @@ def test_kxk_argument_errors_and_oracle(nat, oracle):
     x = torch.zeros(1, 8, 4, 4, device="cuda")                               # Cin = 8: not a multiple of 16
     wt = torch.zeros(72, 8, device="cuda")
     y = torch.zeros(1, 8, 4, 4, device="cuda")
-    assert L.fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 8, 4, 4, 8, 3, 3, 1, 1, None, None, None, None) == -4
-    assert L.fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 16, 2, 2, 8, 5, 5, 1, 1, None, None, None, None) == -1
+    assert L.fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 8, 4, 4, 8, 3, 3, 1, 1, None, None, None, None, 0, None) == -4
+    assert L.fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None, y.data_ptr(), None, 1, 16, 2, 2, 8, 5, 5, 1, 1, None, None, None, None, 0, None) == -1
     rng = np.random.default_rng(6)
     xi = rng.integers(-8, 9, (2, 32, 9, 8)).astype(np.int32)
     wi = rng.integers(-8, 9, (40, 32, 3, 3)).astype(np.int32)
