@@ -35,4 +35,21 @@ constexpr int kCUs = 256;          // MI355X
 
 inline bool valid_bitwidth(int bw) { return bw == 8 || bw == 16; }
 
+// More than 64 KB of dynamic LDS needs hipFuncAttributeMaxDynamicSharedMemorySize, and that attribute is PER DEVICE: a
+// process that drives a second GPU must opt in there too (a function-local "done once" flag, what round 3 had, made the launch
+// on the second device fail after the dispatch had already committed to the kernel).  One flag per kernel AND device; the
+// call is cheap, a racing second thread merely repeats it.
+constexpr int kMaxDevices = 64;
+inline bool ensure_dynamic_lds(const void* kernel, int bytes, bool (&done)[kMaxDevices]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) return false;
+    if (dev < kMaxDevices && done[dev]) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (dev < kMaxDevices) done[dev] = true;
+    return true;
+}
+
 }  // namespace fq

@@ -379,12 +379,8 @@ bool launch_variant(hipStream_t st, const int8_t* x, const int8_t* w, const floa
     const size_t lds = stream_lds_bytes<SB, MT, NW, D>(sp.nsteps);
     if (lds > kLdsPerCU) return false;
     auto kern = conv1x1_i8_stream_kernel<SB, MT, NW, D, kAdd, kRes16, kGather>;
-    static bool attr_set = false;                         // > 64 KB of dynamic LDS needs the attribute once per kernel
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsPerCU) != hipSuccess)
-            return false;
-        attr_set = true;
-    }
+    static bool lds_ok[kMaxDevices] = {};                 // > 64 KB of dynamic LDS needs the attribute once per kernel and device
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(kern), (int)kLdsPerCU, lds_ok)) return false;
     // workgroups resident per CU: LDS, and 8 waves per CU (two per SIMD: the register budget of the add epilogue)
     int per_cu = (int)(kLdsPerCU / lds);
     const int by_waves = (MT == 2 ? 16 : 8) / NW;          // registers: the 128-channel add epilogue fits two waves per SIMD, the 64-channel one four

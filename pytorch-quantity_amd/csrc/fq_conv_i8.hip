@@ -1425,9 +1425,8 @@ static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, c
 #define FQ_HALO8_K(OUT, STG)                                                                                             \
     do {                                                                                                                 \
         auto k = conv3x3_i8_halo8_kernel<TK, OUT, STG>;                                                                  \
-        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                       80 * 1024);                                                       \
-        if (ok != (int)hipSuccess) return false;                                                                         \
+        static bool lds_ok[kMaxDevices] = {};                                                                            \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), 80 * 1024, lds_ok)) return false;                      \
         hipLaunchKernelGGL(k, grid8, dim3(2 * kConvBlock), lds8, st, x, w, qbias, y, q, p8, hp8);                        \
     } while (0)
 #define FQ_HALO8(OUT) do { if (stages8 == 3) FQ_HALO8_K(OUT, 3); else FQ_HALO8_K(OUT, 2); } while (0)
@@ -1454,9 +1453,8 @@ static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, c
 #define FQ_HALO_K(OUT, STG, NPX)                                                                                         \
     do {                                                                                                                 \
         auto k = conv3x3_i8_halo_kernel<TK, OUT, STG, NPX>;                                                              \
-        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                       80 * 1024);                                                       \
-        if (ok != (int)hipSuccess) return false;                                                                         \
+        static bool lds_ok[kMaxDevices] = {};                                                                            \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), 80 * 1024, lds_ok)) return false;                      \
         hipLaunchKernelGGL(k, grid, dim3(kConvBlock), lds, st, x, w, qbias, y, q, p, hp);                                \
     } while (0)
 #define FQ_HALO(OUT)                                                                                                     \
@@ -1492,9 +1490,8 @@ static bool launch_conv_c64(hipStream_t st, const int8_t* x, const int8_t* w, co
 #define FQ_C64(OUT)                                                                                                      \
     do {                                                                                                                 \
         auto k = conv3x3_i8_c64_kernel<OUT>;                                                                             \
-        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                                       80 * 1024);                                                       \
-        if (ok != (int)hipSuccess) return false;                                                                         \
+        static bool lds_ok[kMaxDevices] = {};                                                                            \
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), 80 * 1024, lds_ok)) return false;                      \
         hipLaunchKernelGGL(k, dim3(grid), dim3(kConvBlock), lds, st, x, w, qbias, y, q, p, cp);                          \
     } while (0)
     if (y && q) FQ_C64(kOutF32 | kOutI8);

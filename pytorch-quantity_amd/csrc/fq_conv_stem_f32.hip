@@ -266,32 +266,32 @@ int launch_stem(StemArgs a, float* max_inout, const float* interval, int64_t* hi
     // persistent: every workgroup loads the 43 KB weight matrix once and walks over tiles
     if (qd) {
         auto k = conv_stem_f32_qd_kernel<CIN, R, S>;
-        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+        static bool lds_ok[kMaxDevices] = {};
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), (int)dyn, lds_ok)) return hip_fail(hipErrorInvalidValue);
         static const int per_cu = resident_per_cu(k, dyn);
         unsigned grid = (unsigned)(kCUs * per_cu);
         if (grid > a.tiles) grid = a.tiles;
         hipLaunchKernelGGL(k, dim3(grid), dim3(kT), dyn, st, a, *qd);
     } else if (hist_row) {
         auto k = conv_stem_f32_hist_kernel<CIN, R, S>;
-        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+        static bool lds_ok[kMaxDevices] = {};
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), (int)dyn, lds_ok)) return hip_fail(hipErrorInvalidValue);
         static const int per_cu = resident_per_cu(k, dyn);
         unsigned grid = (unsigned)(kCUs * per_cu);
         if (grid > a.tiles) grid = a.tiles;
         hipLaunchKernelGGL(k, dim3(grid), dim3(kT), dyn, st, a, interval, reinterpret_cast<unsigned long long*>(hist_row), fast);
     } else if (max_inout) {
         auto k = conv_stem_f32_absmax_kernel<CIN, R, S>;
-        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+        static bool lds_ok[kMaxDevices] = {};
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), (int)dyn, lds_ok)) return hip_fail(hipErrorInvalidValue);
         static const int per_cu = resident_per_cu(k, dyn);
         unsigned grid = (unsigned)(kCUs * per_cu);
         if (grid > a.tiles) grid = a.tiles;
         hipLaunchKernelGGL(k, dim3(grid), dim3(kT), dyn, st, a, reinterpret_cast<unsigned int*>(max_inout));
     } else {
         auto k = conv_stem_f32_kernel<CIN, R, S>;
-        static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-        if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+        static bool lds_ok[kMaxDevices] = {};
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(k), (int)dyn, lds_ok)) return hip_fail(hipErrorInvalidValue);
         static const int per_cu = resident_per_cu(k, dyn);
         unsigned grid = (unsigned)(kCUs * per_cu);
         if (grid > a.tiles) grid = a.tiles;

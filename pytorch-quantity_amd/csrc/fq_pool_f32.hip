@@ -121,9 +121,9 @@ extern "C" int fq_avgpool_global_f32(const float* x, float* y, int planes, int H
     if (planes == 0) return FQ_OK;
     if (!x || !y) return FQ_ERR_INVALID_ARG;
     const size_t dyn = (size_t)kPoolBlock * HW * sizeof(float);
-    static const int ok = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(avgpool_global_f32_kernel),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 144 * kPoolBlock * (int)sizeof(float));
-    if (ok != (int)hipSuccess) return hip_fail((hipError_t)ok);
+    static bool lds_ok[kMaxDevices] = {};
+    if (!ensure_dynamic_lds(reinterpret_cast<const void*>(avgpool_global_f32_kernel), 144 * kPoolBlock * (int)sizeof(float), lds_ok))
+        return hip_fail(hipErrorInvalidValue);
     const unsigned blocks = ((unsigned)planes + kPoolBlock - 1) / kPoolBlock;
     hipLaunchKernelGGL(avgpool_global_f32_kernel, dim3(blocks), dim3(kPoolBlock), dyn, as_stream(stream), x, y, (unsigned)planes, HW);
     FQ_LAUNCH_CHECK();

@@ -481,7 +481,10 @@ class TestConv(_FakeQuantLayer):
     def forward(self, x):
         # One kernel where the convolution is this library's (1x1, R x S with zero padding, the 7x7 stem) and nobody hooks
         # the inner nn.Conv2d: QuanDequan rides in the epilogue, the reference's second 8 B/element pass disappears.
-        fused = _float_conv.call_qd(self.Conv, x, self.output_bit, self.output_qdp.bitwidth)
+        # (the reference calls output_qdp as a module, new_quantity_op.py:284: a hook on it must fire, and its own `bit` /
+        # `bitwidth` -- not a copy taken at construction -- decide the map; either keeps the two-pass form or feeds the kernel)
+        qdp = self.output_qdp
+        fused = None if _float_conv._hooked(qdp) else _float_conv.call_qd(self.Conv, x, qdp.bit, qdp.bitwidth)
         if fused is not None:
             return fused
         out = _float_conv.call(self.Conv, x)

@@ -442,7 +442,18 @@ class Quantity(object):
         if any(r is None for r in ok):
             raise ValueError("calibration files of one batch have different shapes; set Quantity.file_batch = 1")
         keep = [0] + [1 + j for j, r in enumerate(ok) if r]
-        return batch if len(keep) == batch.shape[0] else batch[keep].contiguous().pin_memory()
+        if len(keep) == batch.shape[0]:
+            return batch
+        # unreadable files inside the group: close the gaps IN the staging slot (keep is ascending, so row i <= keep[i] and a
+        # front-to-back copy never overwrites a row it still needs) and hand out the head of the same slot.  The view must carry
+        # the slot: _device_items records the copy's event on it, and a compacted COPY (what this returned until round 4) left
+        # the slot marked "out" with no event -- the ring's seventh group then tripped the look-ahead assertion.
+        for i, k_ in enumerate(keep):
+            if i != k_:
+                batch[i].copy_(batch[k_])
+        out = batch[:len(keep)]
+        out._fq_slot = batch._fq_slot
+        return out
 
     def net_forward(self, net, image_path):
         img = image_path if torch.is_tensor(image_path) else self.preprocess(image_path)
@@ -736,7 +747,7 @@ class Quantity(object):
         if ctl.fuse_stat == "hist":                         # pass 2 (verified in pass 1)
             if (kind == "c1" and self.fuse_conv_add and not self.materialize_all and ctl.defer_ok.get(m) is not None
                     and ctl.eager is not None):
-                ctl.deferred[id(output)] = (output, m, x, key, row, output._version)       # (see below)
+                ctl.deferred[id(output)] = (output, m, x, key, row, output._version, x._version)       # (see below)
                 return True
             self._run_with_relu(m, output, lambda r, o: run(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row,
                                                             relu_out=r, out=o), key)
@@ -750,7 +761,7 @@ class Quantity(object):
         if kind == "c1" and self.fuse_conv_add and ctl.defer_ok.get(m) is not None and ctl.eager is not None:
             # its kernel runs inside the launch of the Eltwise that adds this tensor (_finish_deferred); until then `output`
             # is an allocation nobody reads -- which the poison probe has shown for this model
-            ctl.deferred[id(output)] = (output, m, x, key, row, output._version)
+            ctl.deferred[id(output)] = (output, m, x, key, row, output._version, x._version)
             return True
         self._run_with_relu(m, output, lambda r, o: run(max_dev=coll.max_device, row=row, relu_out=r, out=o), key)
         coll.note_max_refreshed()
@@ -759,7 +770,8 @@ class Quantity(object):
 
     def _run_deferred(self, d):
         """A deferred convolution on its own after all (what its hook would have launched)."""
-        output, m, x, _key, row, _v = d
+        output, m, x, _key, row, _v, x_version = d
+        self._deferred_input_intact(x, x_version)
         ctl = self._hook_ctl
         coll = ctl.fuse_collector
         if coll is None:
@@ -775,6 +787,16 @@ class Quantity(object):
         if ctl.eager is not None:
             ctl.eager.note(_key, output)
 
+    @staticmethod
+    def _deferred_input_intact(x, x_version):
+        """A deferred convolution runs LATER than the model called it, on the input tensor it was called with.  The poison probe
+        runs the convolution at its own position, so a model that writes that input in place between the convolution and its
+        Eltwise is invisible to it -- the version counter is not: such a forward cannot be calibrated with the deferral."""
+        if x._version != x_version:
+            raise _native.FqError("the input of a 1x1 convolution was written in place between the convolution and the Eltwise "
+                                  "that consumes its output; the one-kernel residual tail cannot run on it: set "
+                                  "Quantity.fuse_conv_add = False (FQ_FUSE_CONV_ADD=0)")
+
     def _finish_deferred(self, module, m, a, b, key, output):
         """Hook half of an Eltwise one of whose operands is a deferred convolution: convolution + bias, that tensor's abs-max,
         the sum, its abs-max and the ReLU behind it in one launch.  Returns True when done; False after running the
@@ -789,7 +811,8 @@ class Quantity(object):
         if d is None:
             return False
         del ctl.deferred[id(d[0])]
-        t3, conv, x, conv_key, conv_row, version = d
+        t3, conv, x, conv_key, conv_row, version, x_version = d
+        self._deferred_input_intact(x, x_version)
         coll = ctl.fuse_collector
         other = b if t3 is a else a
         relu = ctl.relu_after.get(m) if self.fuse_relu else None
