@@ -974,13 +974,22 @@ def main():
                     with torch.no_grad():
                         ref_logits = int8_net(batches[0])
                     plan = resident.enable(int8_net, batches[0])
-                    with torch.no_grad():
-                        same = bool(torch.equal(int8_net(batches[0]), ref_logits))
+                    _native.conv_variant_log = kernels = {}          # which integer-convolution kernels this forward launches
+                    try:
+                        with torch.no_grad():
+                            same = bool(torch.equal(int8_net(batches[0]), ref_logits))
+                    finally:
+                        _native.conv_variant_log = None
+                    plan = dict(plan, kernels=kernels)
                     return ref_logits, plan, same
                 ok_r, res, err_r = run_section(go_resident, device)
                 same_everywhere = ok_r and all_ok(res[2], device)
                 if ok_r:
-                    result["int8_sim_resident"] = {"bit_identical_logits": bool(res[2]), "plan": res[1], "images_per_forward": FB}
+                    result["int8_sim_resident"] = {"bit_identical_logits": bool(res[2]), "plan": res[1], "images_per_forward": FB,
+                                                   "checked_against": "the fp32-module-boundary form of the same model on the timed batch "
+                                                                      "(torch.equal); the same dispatch (plan.kernels) against the reference's "
+                                                                      "CPU logits: tests/test_gpu_r50_tables.py::test_r50_reconmodel_at_the_"
+                                                                      "batch_the_bench_times_equals_the_reference"}
                 if same_everywhere:                        # never report a rate for a model that computes something else
                     result["int8_sim_images_per_s"] = fwd_rate(int8_net, 8)
                     if rank == 0:

@@ -23,6 +23,7 @@
 namespace fq {
 
 thread_local int g_last_hip_error = 0;
+thread_local int g_last_conv_variant = 0;
 
 constexpr int kSegChunk = 96;          // segments per launch (kernarg block stays < 4 KB)
 constexpr int kBlock = 256;            // abs-max: 4 waves per workgroup

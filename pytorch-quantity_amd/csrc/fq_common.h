@@ -9,6 +9,13 @@
 namespace fq {
 
 extern thread_local int g_last_hip_error;
+// Which kernel the last fq_conv2d_i8* call of this thread launched (fq_conv2d_i8_last_variant, include/fq.h): a diagnostic
+// of the same kind as the error code above -- thread-local, written by the dispatch, read by tests and bench.py so that
+// "the kernels the bench times were the ones the golden check ran" is an assertion and not a belief.
+extern thread_local int g_last_conv_variant;
+enum ConvVariant { kVarNone = 0, kVarC64Halo = 1, kVarStream = 2, kVarHalo8 = 3, kVarHalo = 4, kVarDma2 = 5, kVarDma3 = 6,
+                   kVarTileC128 = 7, kVarTileC64 = 8, kVarTileGeneral = 9, kVarStem = 10 };
+inline void note_conv_variant(int variant, int tk) { g_last_conv_variant = variant | (tk << 8); }
 
 inline int hip_fail(hipError_t e) {
     g_last_hip_error = (int)e;

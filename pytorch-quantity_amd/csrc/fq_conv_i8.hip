@@ -1384,12 +1384,14 @@ static void launch_conv_dma(dim3 grid, hipStream_t st, const int8_t* x, const in
     const bool three = stages_env ? stages_env == 3 : (long)grid.x * grid.y <= kCUs;
     if (three) launch_conv_dma_stages<TK, 3>(grid, st, x, w, qbias, y, q, p);
     else launch_conv_dma_stages<TK, 2>(grid, st, x, w, qbias, y, q, p);
+    note_conv_variant(three ? kVarDma3 : kVarDma2, TK);
 }
 
 template <int TK, int kPath>
 static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y,
                              int8_t* q, const ConvParams& p0) {
     const ConvParams p = xcd_order(grid, p0);
+    note_conv_variant(kPath == kPathC128 ? kVarTileC128 : (kPath == kPathC64 ? kVarTileC64 : kVarTileGeneral), TK);
     if (p.res)
         hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutI8 | kOutAdd>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else if (y && q)
@@ -1435,6 +1437,7 @@ static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, c
             else FQ_HALO8(kOutF32);
 #undef FQ_HALO8
 #undef FQ_HALO8_K
+            note_conv_variant(kVarHalo8, TK);
             return true;
         }
     }
@@ -1467,6 +1470,7 @@ static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, c
     else FQ_HALO(kOutF32);
 #undef FQ_HALO
 #undef FQ_HALO_K
+    note_conv_variant(kVarHalo, TK);
     return true;
 }
 
@@ -1498,6 +1502,7 @@ static bool launch_conv_c64(hipStream_t st, const int8_t* x, const int8_t* w, co
     else if (q) FQ_C64(kOutI8);
     else FQ_C64(kOutF32);
 #undef FQ_C64
+    note_conv_variant(kVarC64Halo, 64);
     return true;
 }
 
@@ -1521,6 +1526,7 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     const int P = (H + 2 * pad_h - dil_h * (R - 1) - 1) / stride_h + 1;
     const int Q = (W + 2 * pad_w - dil_w * (S - 1) - 1) / stride_w + 1;
     if (P <= 0 || Q <= 0) return FQ_ERR_INVALID_ARG;
+    g_last_conv_variant = kVarNone;
     if (N == 0) return FQ_OK;
     if (!x_nhwc || !w_krsc || !qbias || (!y_nchw && !q_nhwc && !fa.res)) return FQ_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w_krsc) | reinterpret_cast<uintptr_t>(q_nhwc) |
@@ -1555,6 +1561,7 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     }
     // 1x1 layers with an int8 output: the streaming kernel with stationary weights (fq_conv1x1_i8.hip) where it applies
     if (launch_conv1x1_stream(st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p)) {
+        note_conv_variant(kVarStream, 0);
         FQ_LAUNCH_CHECK();
         return FQ_OK;
     }

@@ -24,6 +24,7 @@ extern "C" const char* fq_status_string(int status) {
 }
 
 extern "C" int fq_last_hip_error(void) { return fq::g_last_hip_error; }
+extern "C" int fq_conv2d_i8_last_variant(void) { return fq::g_last_conv_variant; }
 
 // quantizer.py:86-90.  (threshold_bin + 0.5) is a Python float, interval an np.float32: the product
 // is fp32.  math.log(x, 2) is log(x)/log(2) in float64 on the C library's log.

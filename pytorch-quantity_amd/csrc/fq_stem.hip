@@ -224,6 +224,7 @@ extern "C" int fq_conv2d_i8_stem(const float* x_nchw, const int8_t* w_stem, cons
         case 3: hipLaunchKernelGGL(stem_conv_i8_kernel<3>, g, b, 0, st, p); break;
         default: hipLaunchKernelGGL(stem_conv_i8_kernel<4>, g, b, 0, st, p); break;
     }
+    note_conv_variant(kVarStem, 64);
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }

@@ -49,6 +49,8 @@ def lib():
     L.fq_status_string.restype = ctypes.c_char_p
     L.fq_status_string.argtypes = [ci]
     L.fq_last_hip_error.restype = ci
+    L.fq_conv2d_i8_last_variant.restype = ci
+    L.fq_conv2d_i8_last_variant.argtypes = []
     L.fq_absmax_seg.restype = ci
     L.fq_absmax_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp]
     L.fq_hist2048_seg.restype = ci
@@ -720,6 +722,21 @@ def pack_weight_krsc(w, cpad=None):
     return out.contiguous()
 
 
+# Which integer-convolution kernels ran (fq_conv2d_i8_last_variant): set conv_variant_log = {} and every call below counts its
+# kernel there by name -- tests and bench.py assert with it that the dispatch they checked is the dispatch they time.
+CONV_VARIANTS = {0: "none", 1: "c64_halo", 2: "stream", 3: "halo8", 4: "halo", 5: "dma2", 6: "dma3", 7: "tile_c128", 8: "tile_c64",
+                 9: "tile_general", 10: "stem", 11: "block_tail"}
+conv_variant_log = None
+
+
+def _note_variant():
+    log = conv_variant_log
+    if log is not None:
+        v = int(lib().fq_conv2d_i8_last_variant())
+        name = CONV_VARIANTS.get(v & 0xff, "?") + ("" if (v >> 8) == 0 else "/%d" % (v >> 8))
+        log[name] = log.get(name, 0) + 1
+
+
 def conv2d_i8(xq, wq, qbias, stride, padding, dilation, rs, ob, bitwidth=8):
     """xq int8 [N,H,W,C] (or [N,C] for Linear), wq int8 [K,R,S,C]; returns fp32 [N,K,P,Q] (or [N,K])."""
     _need_cuda(xq, torch.int8, "fq_conv2d_i8")
@@ -737,6 +754,7 @@ def conv2d_i8(xq, wq, qbias, stride, padding, dilation, rs, ob, bitwidth=8):
     _check(lib().fq_conv2d_i8(xq.data_ptr(), wq.data_ptr(), qbias.contiguous().data_ptr(), y.data_ptr(), N, H, W, C, K, R, S,
                               stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1], int(rs), int(ob),
                               int(bitwidth), _stream(xq)), "fq_conv2d_i8")
+    _note_variant()
     return y.view(N, K) if linear else y
 
 
@@ -758,6 +776,7 @@ def conv2d_i8_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, want_f3
                                        y.data_ptr() if want_f32 else None, q.data_ptr() if want_i8 else None, kpad,
                                        1 if relu else 0, N, H, W, C, K, R, S, stride[0], stride[1], padding[0], padding[1],
                                        dilation[0], dilation[1], int(rs), int(ob), _stream(xq)), "fq_conv2d_i8_resident")
+    _note_variant()
     return y, q
 
 
@@ -796,6 +815,7 @@ def conv2d_i8_stem(x, w_stem, qbias, K, S, stride, padding, ib, rs, ob, relu):
     _check(lib().fq_conv2d_i8_stem(x.data_ptr(), w_stem.data_ptr(), qbias.contiguous().data_ptr(), q.data_ptr(), kpad,
                                    1 if relu else 0, N, C, H, W, K, R, S, stride[0], stride[1], padding[0], padding[1],
                                    int(ib), int(rs), int(ob), _stream(x)), "fq_conv2d_i8_stem")
+    _note_variant()
     return q
 
 
@@ -824,6 +844,7 @@ def conv2d_i8_add_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, res
                                            narrow.data_ptr() if want_narrow else None, int(ib), 1 if relu else 0, kpad, N, H, W, C,
                                            K, R, S, stride[0], stride[1], padding[0], padding[1], dilation[0], dilation[1],
                                            int(rs), int(ob), _stream(xq)), "fq_conv2d_i8_add_resident")
+    _note_variant()
     return wide, narrow
 
 

@@ -75,6 +75,9 @@ class _DeferralProbe(object):
     nothing but the designated Eltwise read the convolution's output and nothing but the designated ReLU read the sum: NaN
     poisons everything it touches.  (Control flow that depends on the data is not covered by a probe; the production path
     therefore also refuses to end a forward with a convolution still waiting.)
+    What poisoning cannot see is a KEEPER -- code that stores the tensor and reads it after the forward; `holders()` finds those
+    after the learning forward (whoever still refers to the tensor then is not a frame of the model), and a chain with one is
+    not taken.
     The same forward proves the simpler chain convolution -> out-of-place nn.ReLU (`relu_only`): when nothing but that ReLU reads
     a convolution's output, and pass 2 does not want the tensor kept, the kernel writes the ReLU's result only."""
 
@@ -124,6 +127,36 @@ class _DeferralProbe(object):
     def relu(self, m, x):
         r = self.real(x, m) if self.mode == "poison" else None
         return None if r is None else torch.nn.functional.relu(r)
+
+    @staticmethod
+    def holders(t, ours):
+        """Who, besides this calibration, still holds tensor `t` (or its memory) once the learning forward has RETURNED.  NaN
+        poisoning finds every reader whose result reaches a hooked tensor or the model's output; it cannot find one that merely
+        KEEPS the tensor -- `self.feat = y`, a list a user hook appends to, a view or `.detach()` alias parked somewhere -- and
+        reads it after the forward: in production that reader would hold memory no kernel ever wrote.  After the forward the
+        model's frames are gone, so whatever still refers to the tensor object is either one of `ours` (containers of this
+        calibration, by identity) or such a keeper.  Returns a list of descriptions, empty when nobody does.
+          * Python references: gc.get_referrers (module __dict__s, lists, tuples, closures are all gc-tracked);
+          * other tensor objects on the same memory: the TensorImpl's use count (a view keeps its base alive) and the
+            storage's (an alias made by detach() / .data shares the storage but not the tensor)."""
+        import gc
+        import types
+        mine = set(id(o) for o in ours)
+        found = []
+        for r in gc.get_referrers(t):
+            if id(r) in mine or isinstance(r, types.FrameType):
+                continue
+            if isinstance(r, tuple) and any(id(rr) in mine for rr in gc.get_referrers(r)):
+                continue                                    # a tuple inside one of our containers
+            found.append("a %s" % type(r).__name__)
+        if t._use_count() > 1:
+            found.append("a view of it")
+        use = getattr(torch._C, "_storage_Use_Count", None)
+        if use is not None:
+            # (the tensor itself + the UntypedStorage wrapper this very expression creates = 2)
+            if use(t.untyped_storage()._cdata) > 2:
+                found.append("an alias of its storage")
+        return found
 
     def poisoned_keys(self):
         mods = set(self.candidates) | set(e for e, _r in self.candidates.values()) | set(self.relu_only)

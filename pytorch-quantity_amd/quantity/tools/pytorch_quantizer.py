@@ -1010,6 +1010,21 @@ class Quantity(object):
                     or not (self._only_our_hook(conv) and self._only_our_hook(relu))):
                 continue
             probe.relu_only[conv] = relu
+        # keepers (code that stores one of these tensors and reads it after the forward: invisible to the poison): whoever still
+        # refers to a convolution's output or to a sum now that the learning forward has returned, and is not this calibration
+        ours = [probe.conv_out, first_feats, self._probe_feats, ctl.last_out, ctl.relu_ready] + list(probe.conv_out.values())
+        out_of = dict((conv, y) for (y, conv) in probe.conv_out.values())
+        self.deferral_refused = {}
+        for conv in list(probe.candidates) + list(probe.relu_only):
+            watched = [out_of.get(conv)]
+            if conv in probe.candidates:
+                watched.append(first_feats.get(probe.keys.get(probe.candidates[conv][0])))
+            kept = [h for t in watched if torch.is_tensor(t) for h in probe.holders(t, ours)]
+            if kept:
+                self.deferral_refused[probe.keys.get(conv)] = kept
+                probe.candidates.pop(conv, None)
+                probe.relu_only.pop(conv, None)
+        del out_of
         if not probe.candidates and not probe.relu_only:
             return {}, set()
         probe.mode = "poison"

@@ -193,3 +193,112 @@ def test_a_forward_that_leaves_the_proven_path_is_refused():
                 q.activation_quantize(batches)
         finally:
             del block.forward, b1.forward
+
+
+# ---- what NaN poisoning cannot see: code that KEEPS a tensor -------------------------------------------
+def _keeper_net(kind):
+    """_block_net() whose second block does something else with its last convolution's output y (or with the sum s):
+      "compare"  a comparison reader: mask = (y > 0) gates the block's result -- NaN > 0 is False everywhere, so the poisoned
+                 forward differs and the poison probe itself refuses the chain;
+      "stash"    self.feat = y: nothing in the forward depends on it, the owner reads it AFTER the forward;
+      "alias"    self.feat = y.detach(): the same, through another tensor object on the same memory;
+      "view"     self.feat = y[:, :4]: the same, through a view;
+      "sum"      self.feat = s, the Eltwise's result before the ReLU."""
+    net = _block_net()
+    block = net.b2
+
+    def forward(self, x):
+        y = self.c3(self.r2(self.c2(self.r1(self.c1(x)))))
+        if kind == "stash":
+            self.feat = y
+        elif kind == "alias":
+            self.feat = y.detach()
+        elif kind == "view":
+            self.feat = y[:, :4]
+        s = self.add(y, x if self.down is None else self.down(x))
+        if kind == "sum":
+            self.feat = s
+        z = self.r3(s)
+        if kind == "compare":
+            z = z * (y > 0).float()
+        return z
+    block.forward = forward.__get__(block)
+    return net
+
+
+@pytest.mark.parametrize("kind", ["compare", "stash", "alias", "view", "sum"])
+def test_readers_the_poison_cannot_see_are_found_and_their_chain_is_not_deferred(kind):
+    """A comparison reader is caught by the poison forward itself; a KEEPER (attribute stash, detach() alias, view) influences
+    nothing the probe compares, so `_DeferralProbe.holders` looks for whoever still refers to the tensor after the learning
+    forward.  Either way block 2's chain keeps its own kernels -- the kept tensor holds what the convolution computed, in every
+    forward -- block 1's chain is still fused, and the tables are the unfused run's."""
+    plain = cases.seed_model(_block_net(), base_seed=8).eval().cuda()
+    want = _calibrate(plain, False)
+    model = cases.seed_model(_keeper_net(kind), base_seed=8).eval().cuda()
+    got = _calibrate(model, True)
+    if kind == "compare":
+        ref = _calibrate(cases.seed_model(_keeper_net(kind), base_seed=8).eval().cuda(), False)
+        assert got[4]["conv_add_chains_proven"] == 0                     # the poison forward differed: nothing is deferred
+        assert got[1] == ref[1] and got[2] == ref[2] and torch.equal(got[3], ref[3])
+        return
+    assert got[4]["conv_add_chains_proven"] == 1, got[4]                  # block 1 only
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+    # the keeper's tensor after the LAST forward of the calibration: real values, the ones an unfused run leaves
+    kept = model.b2.feat
+    assert bool(torch.isfinite(kept).all()) and float(kept.abs().max()) > 0
+    ref_model = cases.seed_model(_keeper_net(kind), base_seed=8).eval().cuda()
+    _calibrate(ref_model, False)
+    assert torch.equal(kept, ref_model.b2.feat)
+
+
+def test_a_list_collector_hooked_on_the_parent_block_sees_what_the_unfused_run_shows_it():
+    """register_forward_hook on the BLOCK (not on a module of the chain): it receives the block's input and its result -- the
+    ReLU's output, which the one-kernel tail does write -- and keeps them in a list.  The chain stays fused (nothing it keeps is
+    a skipped tensor), and every kept tensor equals the unfused run's."""
+    def run(fuse):
+        model = cases.seed_model(_block_net(), base_seed=8).eval().cuda()
+        seen = []
+        h = model.b2.register_forward_hook(lambda m, i, o: seen.append((i[0], o)))
+        try:
+            out = _calibrate(model, fuse)
+        finally:
+            h.remove()
+        return out, seen
+    want, seen_w = run(False)
+    got, seen_g = run(True)
+    assert got[4]["conv_add_chains_proven"] == 2
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+    assert len(seen_g) >= 10 and all(torch.equal(a[1], b[1]) for a, b in zip(seen_g[-10:], seen_w[-10:]))
+
+
+def test_an_input_written_in_place_before_the_eltwise_is_refused():
+    """a deferred convolution runs later, on the input tensor object it was called with.  A model that writes that
+    input in place between the convolution and the Eltwise is invisible to the probes (both run the convolution at its own
+    position); the version counter is not, and such a forward raises instead of calibrating on the overwritten input."""
+    from tools import Quantity
+    net = _block_net()
+    block = net.b2
+
+    def forward(self, x):
+        t = self.r2(self.c2(self.r1(self.c1(x))))
+        y = self.c3(t)
+        if getattr(self, "scribble", False):
+            t.mul_(2.0)                                       # the convolution's INPUT, after the convolution
+        return self.r3(self.add(y, x if self.down is None else self.down(x)))
+    block.forward = forward.__get__(block)
+    model = cases.seed_model(net, base_seed=8).eval().cuda()
+    with product_workdir(input_shape="1,3,64,64", device="gpu", max_cali_img_num=2):
+        q = Quantity(model)
+        calls = {"n": 0}
+        real = model.b1.forward
+
+        def counted(x):
+            calls["n"] += 1
+            block.scribble = calls["n"] >= 4                  # probe, poison probe, batch 0 clean; from batch 1 on it scribbles
+            return real(x)
+        model.b1.forward = counted
+        try:
+            with pytest.raises(Exception, match="written in place"):
+                q.activation_quantize(cases.calib_batches(3, (8, 3, 64, 64), seed=91))
+        finally:
+            del model.b1.forward

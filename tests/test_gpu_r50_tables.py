@@ -341,6 +341,53 @@ def test_r50_reconmodel_logits_equal_the_reference(g4r50):
         np.testing.assert_array_equal(graphed(torch.flip(x, dims=[0])).cpu().numpy(), g4["logits_recon"][::-1])
 
 
+@pytest.mark.timeout(1200)
+def test_r50_reconmodel_at_the_batch_the_bench_times_equals_the_reference(g4r50):
+    """bench.py times the integer-simulation forward at 256 images, where the dispatch differs from the
+    2- and 6-image forwards of the test above -- launches of >= 256 workgroups take the eight-wave conv3x3_i8_halo8 kernel, the
+    64-channel 3x3 layers the persistent c64 kernel, the 7x7 layers other tile shapes.  The reference's golden input (2 images)
+    tiled to 256: every pair of rows of the logits must be the reference's CPU logits, with fp32 module boundaries, resident,
+    as one HIP graph and as two graphs on two streams -- and the kernels that ran are the ones the bench's plan records
+    (fq_conv2d_i8_last_variant through _native.conv_variant_log: an assertion, not a belief)."""
+    from common.quantity import _native, resident
+    tables, g4 = g4r50
+    x = cases.fixed_input(tuple(tables["input"]["shape"]), seed=tables["input"]["seed"]).cuda()
+    big = x.repeat(128, 1, 1, 1).contiguous()
+    want = np.tile(g4["logits_recon"], (128, 1))
+    with product_workdir(input_shape="1,3,224,224", device="gpu") as tmp:
+        rec, wd = _r50_rec(tables, tmp)
+        net = rec.ReconModel(rec.get_quantity_information(), os.path.join(wd, "recon.pth")).cuda()
+        with torch.no_grad():
+            np.testing.assert_array_equal(net(big).cpu().numpy(), want)                  # the reference's module boundaries
+        resident.enable(net, big)
+        _native.conv_variant_log = log = {}
+        try:
+            with torch.no_grad():
+                got = net(big).cpu().numpy()
+        finally:
+            _native.conv_variant_log = None
+        np.testing.assert_array_equal(got, want)
+        # 54 launches: the stem, 16 3x3 layers (three 64-channel ones on the stationary-weight kernel, the chip-filling ones on
+        # the eight-wave halo kernel), the 1x1 layers and the block tails on their kernels, the classifier
+        assert sum(log.values()) == 54, log
+        assert log.get("stem/64") == 1 and log.get("c64_halo/64") == 3, log
+        assert sum(v for k, v in log.items() if k.startswith("halo8")) >= 7, log
+        assert sum(v for k, v in log.items() if k.startswith(("halo", "c64_halo"))) == 16, log      # every 3x3 layer
+        small = {}
+        _native.conv_variant_log = small
+        try:
+            with torch.no_grad():
+                np.testing.assert_array_equal(net(x).cpu().numpy(), g4["logits_recon"])
+        finally:
+            _native.conv_variant_log = None
+        assert not any(k.startswith("halo8") for k in small), small                      # (what the 2-image test never reached)
+        graphed = resident.capture(net, big)
+        np.testing.assert_array_equal(graphed(big).cpu().numpy(), want)
+        np.testing.assert_array_equal(graphed(torch.flip(big, dims=[0])).cpu().numpy(), want[::-1])
+        dual = resident.capture(net, big, streams=2)
+        np.testing.assert_array_equal(dual(big).cpu().numpy(), want)
+
+
 def test_r50_recontest_logits_match_the_reference(g4r50):
     """Fake-quant ResNet-50: float convolutions followed by QuanDequan.  The convolutions are this library's fp32 MFMA
     kernels (fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32: a fixed k-ordered fma chain), the reference's are oneDNN's
