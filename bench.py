@@ -342,7 +342,7 @@ def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
         float_model(batch)
     for h in hooks:
         h.remove()
-    names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8")
+    names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8", "block_tail_i8")
     events, saved = [], {n: getattr(_native, n) for n in names}
     bytes_of, macs_of = [], []
 
@@ -358,12 +358,14 @@ def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
             events.append((e0, e1))
             outs = r if isinstance(r, tuple) else (r,)
             # algorithmic traffic of the launch: activation operand + weights + (fused add) residual + everything written
-            res = a[8] if name == "conv2d_i8_add_resident" else None
-            bytes_of.append(nbytes(a[0], a[1], res, *outs))
+            res = a[8] if name == "conv2d_i8_add_resident" else (a[5] if name == "block_tail_i8" else None)
+            # fq_block_tail_i8 also runs the next block's 1x1 reduction: its weights, its matrix work, its int8 output
+            w_next = (a[12] if len(a) > 12 else k.get("w1q")) if name == "block_tail_i8" else None
+            bytes_of.append(nbytes(a[0], a[1], res, w_next, *outs))
             first = next(t for t in outs if isinstance(t, torch.Tensor))
             pixels = first.numel() // first.shape[1 if first.dtype == torch.float32 else -1]
             wq = a[1]                                              # [K][R][S][Cpad] (stem: [R][64][32])
-            macs_of.append(pixels * int(wq.numel()))
+            macs_of.append(pixels * (int(wq.numel()) + (int(w_next.numel()) if w_next is not None else 0)))
             return r
         return wrapper
     try:
@@ -385,7 +387,8 @@ def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
     t_mfma = [2.0 * m / (INT8_PEAK_TOPS * 1e12) * 1e3 for m in macs_of[:n_l]]
     t_hbm = [b / (HBM_PEAK_GBS * 1e9) * 1e3 for b in bytes_of[:n_l]]
     bound_ms = sum(max(a, b) for a, b in zip(t_mfma, t_hbm))
-    return {"bound": "mfma", "kernel": "conv2d_i8 / conv2d_i8_dma / stem_conv_i8 (all integer conv + linear launches of one forward)",
+    return {"bound": "mfma", "kernel": "conv2d_i8 / conv2d_i8_dma / conv3x3_i8_halo* / block_tail_i8 / stem_conv_i8 (all integer conv + linear "
+                                       "launches of one forward)",
             "achieved": round(achieved, 1), "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(achieved / INT8_PEAK_TOPS, 4),
             "launches_per_forward": n_l, "ms_per_forward": round(ms, 4), "images_per_forward": int(batch.shape[0]),
             "gmac_per_image": round(macs[0] / int(batch.shape[0]) / 1e9, 3),

@@ -362,6 +362,25 @@ int fq_conv2d_i8_add_resident(const int8_t* x_nhwc, const int8_t* w_krsc, const 
                               int stride_w, int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob,
                               fq_stream_t stream);
 
+/* The tail of a bottleneck block and the head of the next one in ONE kernel (round 4):
+ *   NewConv2d.forward of conv3 (1x1, C -> K3; new_quantity_op.py:124-133)  ->  NewAdd.forward with the shortcut (:166-174)
+ *   -> nn.ReLU -> the next block's conv1: NewConv2d.forward again (1x1, K3 -> C2, Quantity(ib) on the sum, its own tail and
+ *   ReLU) -- what fq_conv2d_i8_add_resident followed by fq_conv2d_i8_resident compute, bit for bit, without the int8
+ *   re-quantisation of the sum ever reaching HBM (it is the second convolution's operand, staged in LDS).
+ * x_nhwc int8 [M][C]; w3_krsc int8 [K3][C]; qbias3 fp32 [K3] integer valued; rs3 / ob3 as in fq_conv2d_i8_resident;
+ * res / res_bytes / g_res / wide / g_wide / narrow / ib / relu exactly as in fq_conv2d_i8_add_resident ([M][K3] tensors;
+ *   narrow may be NULL when nothing but the fused conv1 reads it; wide may be NULL);
+ * w1_krsc int8 [C2][K3], qbias1 fp32 [C2], rs1, relu1, q1_nhwc int8 [M][C2]: the next conv1 (its input bit is `ib`);
+ *   C2 = 0 (w1 / qbias1 / q1 NULL): conv3 + NewAdd alone.
+ * 1x1, stride 1, no padding: spatial shape does not matter, M = N * H * W pixels.
+ * fq_block_tail_i8_supported: 1 for C in {64, 128}, K3 in {128 .. 512} a multiple of 128, C2 in {0, 64, 128}, shifts in
+ * 1 .. 16 (the integer tails); fq_block_tail_i8 returns FQ_ERR_UNSUPPORTED otherwise and callers keep the two launches. */
+int fq_block_tail_i8_supported(int C, int K3, int C2, int rs3, int rs1);
+int fq_block_tail_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, const float* qbias3, int rs3, int ob3, const void* res,
+                     int res_bytes, int g_res, int16_t* wide, int g_wide, int8_t* narrow, int ib, int relu,
+                     const int8_t* w1_krsc, const float* qbias1, int rs1, int relu1, int8_t* q1_nhwc, long M, int C, int K3,
+                     int C2, fq_stream_t stream);
+
 /* NewAdd.forward (new_quantity_op.py:171-174) on resident operands, with the nn.ReLU and the Quantity of
  * the consumers fused.  x, y: int8 (x_bytes = 1) or int16 (x_bytes = 2) arrays of n elements in the same
  * flat NHWC layout, standing for x * 2^-gx and y * 2^-gy.

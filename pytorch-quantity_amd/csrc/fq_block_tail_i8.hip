@@ -1,0 +1,347 @@
+// fq_block_tail_i8.hip -- the tail of a bottleneck block of the integer-simulation model AND the head of the next one in ONE
+// kernel:   conv3 (1x1 expand, C -> K3 = 4 C channels)  ->  NewAdd with the shortcut (+ the nn.ReLU behind it)  ->  the next
+// block's conv1 (1x1 reduce, K3 -> C2 channels, + its nn.ReLU).
+//
+// Reference: new_quantity_op.py:124-133 (NewConv2d.forward, twice) and :166-174 (NewAdd.forward) run this chain as
+// Quantity -> conv -> RightShift -> BiasAdd -> Sp -> DeQuantity, add, clamp, ReLU, Quantity -> conv -> ... on fp32 NCHW tensors.
+// With resident integer activations (fq_resident.h) the chain was two launches: fq_conv2d_i8_add_resident (reads the int16
+// shortcut, writes the exact int16 sum AND its int8 re-quantisation, 5.25 B per element) and fq_conv2d_i8_resident for the next
+// conv1, which reads that int8 tensor straight back (1.25 B per element).  At 256 images the 56 x 56 and 28 x 28 stages are
+// bound by exactly those bytes.  Here the re-quantised sum never leaves the CU: a workgroup owns 128 pixels and ALL K3 channels
+// of them, walks over the channels in slices of 128, and after the add of a slice multiplies the slice's int8 values -- staged
+// in LDS in MFMA operand layout -- into the next conv1's accumulators (32 pixels x C2 channels per wave, kept in registers
+// across the slices).  Per element of the sum: 2 B read (shortcut) + 2 B written (sum) + C2 / K3 B (the next conv1's output)
+// instead of 6.5, and one launch instead of two.
+//
+// Layout of a workgroup (256 threads = 4 waves, wave w owns pixels [32 w, 32 w + 32) of the tile and everything about them):
+//   x fragments        lane = pixel, 16 bytes per 32-channel sub-step, straight from the int8 NHWC tensor into registers, once
+//   conv3 weights      one 128-row slice at a time in LDS (XOR-swizzled rows), fetched global -> registers one slice ahead
+//   conv3 epilogue     RightShift + bias + Sp in integer arithmetic, int8 through the wave's OWN 32 rows of an LDS tile
+//                      (row = pixel, 128 bytes = the slice's channels), read back 16 channels per lane, NewAdd with the
+//                      shortcut (fq_resident.h), 16-byte stores of the sum; the re-quantised int8 goes back to the SAME 16
+//                      bytes of the tile, which is then the B operand of ...
+//   the next conv1     C2 x 128-byte slice of its weights in LDS, 4 MFMA sub-steps per slice and accumulator tile
+// LDS instructions of one wave execute in order and a wave only touches its own 32 rows of the tile, so the whole epilogue has
+// NO workgroup barrier; the two barriers per slice order the weight slices' hand-over only.
+//
+// Same integers, bit for bit, as the two launches (tests/test_gpu_block_tail.py runs both against the CPU oracle).
+#include <utility>
+
+#include "fq_conv_i8_common.h"
+
+namespace fq {
+namespace {
+
+struct TailParams {                      // what conv_tail_i (fq_int_tail.h) reads
+    int rs, half_rs, ilo, ihi, slo, shi;
+};
+
+struct BtParams {
+    int M;                               // pixels (N * H * W)
+    int K3;                              // conv3 output channels = channel stride of the shortcut / sum / narrow tensors
+    unsigned x_bytes;                    // M * C
+    TailParams t3, t1;
+    const void* res;                     // shortcut: int8 / int16 [M][K3]
+    int res_bytes;
+    int16_t* wide;                       // exact sum (may be null)
+    int8_t* narrow;                      // its re-quantisation (may be null: nobody but the fused conv1 reads it)
+    AddResParams ap;
+};
+
+// LDS rows of RB bytes hold RB / 16 chunks of 16 bytes; position c of row r holds chunk c ^ swz_of(r), chosen so that the 16 lanes
+// of every ds_read_b128 lane group ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...) reading chunk c of 16 different rows land in
+// 16 different 16-byte slots of the 256-byte bank row
+template <int RB> __device__ __forceinline__ int swz_of(int row) {
+    return RB == 256 ? row & 15 : (RB == 128 ? (row >> 1) & 7 : (row >> 2) & 3);
+}
+
+// C: conv3's input channels (64 / 128).  C2: the fused next conv1's output channels (64 / 128; 0: no next conv -- the kernel is
+// then conv3 + NewAdd alone, in the barrier-free form).  kRes16: the shortcut is int16 (a previous sum) or int8 (a projection).
+#ifndef FQ_BT_WAVES
+#define FQ_BT_WAVES 2
+#endif
+template <int C, int C2, bool kRes16>
+__global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_BT_WAVES))) void block_tail_i8_kernel(
+    const int8_t* __restrict__ x, const int8_t* __restrict__ w3, const float* __restrict__ qbias3,
+    const int8_t* __restrict__ w1, const float* __restrict__ qbias1, int8_t* __restrict__ q1, const BtParams p) {
+    constexpr int KS3 = C / 32;                          // MFMA sub-steps of conv3 (its whole reduction)
+    constexpr int W3_LOADS = (128 * (C / 16)) / kConvBlock;      // 16-byte chunks of a conv3 weight slice per thread
+    constexpr int MT1 = C2 / 32;                         // accumulator tiles of the next conv1 per wave
+    constexpr int W1_LOADS = C2 ? (C2 * 8) / kConvBlock : 1;
+    constexpr bool kNext = C2 != 0;
+    __shared__ __attribute__((aligned(16))) int8_t sW3[128 * C];
+    __shared__ __attribute__((aligned(16))) int8_t sW1[kNext ? C2 * 128 : 16];
+    __shared__ __attribute__((aligned(16))) int8_t sN[kTP * 128];
+    __shared__ int sBias3[1024];
+    __shared__ int sBias1[kNext ? C2 : 1];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, prow = wave * 32 + (lane & 31);
+    const int m0 = blockIdx.x * kTP;
+    const int KT = p.K3 >> 7;
+
+    for (int i = tid; i < p.K3; i += kConvBlock) sBias3[i] = (int)qbias3[i];          // integer valued by contract
+    if (kNext && tid < C2) sBias1[tid] = (int)qbias1[tid];
+
+    // ---- x: this lane's pixel, 16 bytes per sub-step, for the whole tile's life
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(x), 0, p.x_bytes, 0x00020000);
+    v4i fb[KS3];
+    {
+        const int m = m0 + prow;
+        const unsigned off = m < p.M ? (unsigned)m * (unsigned)C + (unsigned)(half * 16) : kOutOfRange;
+#pragma unroll
+        for (int ks = 0; ks < KS3; ++ks) fb[ks] = load_act(xr, off + (unsigned)(ks * 32));
+    }
+
+    // ---- weight slices: global -> registers (one slice ahead) -> LDS
+    v4i r3[W3_LOADS], r1[W1_LOADS];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < W3_LOADS; ++j) {
+            const int i = tid + kConvBlock * j, row = i / (C / 16), c = i % (C / 16);
+            r3[j] = *reinterpret_cast<const v4i*>(w3 + ((long)(kt * 128 + row) * C + c * 16));
+        }
+        if constexpr (kNext) {
+#pragma unroll
+            for (int j = 0; j < W1_LOADS; ++j) {
+                const int i = tid + kConvBlock * j, row = i >> 3, c = i & 7;
+                r1[j] = *reinterpret_cast<const v4i*>(w1 + ((long)row * p.K3 + kt * 128 + c * 16));
+            }
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < W3_LOADS; ++j) {
+            const int i = tid + kConvBlock * j, row = i / (C / 16), c = i % (C / 16);
+            *reinterpret_cast<v4i*>(&sW3[row * C + ((c ^ swz_of<C>(row)) * 16)]) = r3[j];
+        }
+        if constexpr (kNext) {
+#pragma unroll
+            for (int j = 0; j < W1_LOADS; ++j) {
+                const int i = tid + kConvBlock * j, row = i >> 3, c = i & 7;
+                *reinterpret_cast<v4i*>(&sW1[row * 128 + ((c ^ swz_of<128>(row)) * 16)]) = r1[j];
+            }
+        }
+    };
+    fetch(0);
+    stage();
+    __syncthreads();
+
+    // operand-fragment offsets: row (lane & 31) of a 32-row block, chunk 2 ks + half, swizzled by the row
+    int a3_off[KS3], a1_off[4];
+#pragma unroll
+    for (int ks = 0; ks < KS3; ++ks) a3_off[ks] = (lane & 31) * C + (((2 * ks + half) ^ swz_of<C>(lane & 31)) * 16);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) a1_off[ks] = (lane & 31) * 128 + (((2 * ks + half) ^ swz_of<128>(lane & 31)) * 16);
+    int8_t* const my_row = sN + prow * 128;
+    const int my_swz = swz_of<128>(prow);
+
+    // store layout of the epilogue: instruction j of a wave covers its pixels 8 j .. 8 j + 7, lane -> (pixel, 16-channel group)
+    const int s_pix = wave * 32 + (lane >> 3), s_ch = lane & 7;            // (+ 8 j)
+
+    v16i acc1[kNext ? MT1 : 1];
+    if constexpr (kNext) {
+#pragma unroll
+        for (int a = 0; a < MT1; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[a][r] = 0;
+    }
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int k0 = kt * 128;
+        // the shortcut of this slice (16 channels x 4 pixels per lane), requested before the matrix work
+        v4i_r res_lo[4], res_hi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + s_pix + 8 * j;
+            const long off = m < p.M ? (long)m * p.K3 + k0 + 16 * s_ch : 0;
+            if constexpr (kRes16) {
+                res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
+                res_hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
+            } else {
+                res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+
+        // ---- conv3, this slice: 32 pixels x 128 channels per wave, 64 channels (two accumulator tiles) at a time -- RightShift +
+        // BiasAdd + Sp of the first half runs while the second half's accumulators do not exist yet (32 registers fewer)
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            v16i acc[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][r] = 0;
+#pragma unroll
+            for (int ks = 0; ks < KS3; ++ks) {
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const v4i fa = *reinterpret_cast<const v4i*>(&sW3[(2 * hs + a) * 32 * C + a3_off[ks]]);
+                    acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[ks], acc[a], 0, 0, 0);
+                }
+            }
+            // 4 channels = one dword into this lane's own row of the tile
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int kl = (2 * hs + a) * 32 + e + 8 * g + 4 * half;
+                        v[e] = conv_tail_i(acc[a][4 * g + e], sBias3[k0 + kl], p.t3);
+                    }
+                    const int byte = (2 * hs + a) * 32 + 8 * g + 4 * half;          // channel of v[0] inside the slice
+                    *reinterpret_cast<unsigned*>(my_row + (((byte >> 4) ^ my_swz) * 16) + (byte & 15)) = pack4(v[0], v[1], v[2], v[3]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- NewAdd (+ ReLU + the consumers' Quantity) on 16 channels of one pixel per lane; rows of this wave only
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pix = s_pix + 8 * j;
+            int8_t* const cell = sN + pix * 128 + ((s_ch ^ swz_of<128>(pix)) * 16);
+            Vec16<int8_t> cv;
+            cv.a = *reinterpret_cast<const v4i_r*>(cell);
+            Add16Out o;
+            if constexpr (kRes16) {
+                Vec16<int16_t> rv;
+                rv.a = res_lo[j]; rv.b = res_hi[j];
+                o = add_resident_16_regs(cv, rv, p.wide != nullptr, true, p.ap);
+            } else {
+                Vec16<int8_t> rv;
+                rv.a = res_lo[j];
+                o = add_resident_16_regs(cv, rv, p.wide != nullptr, true, p.ap);
+            }
+            const int m = m0 + pix;
+            if (m < p.M) {
+                const long off = (long)m * p.K3 + k0 + 16 * s_ch;
+                if (p.wide) {
+                    *reinterpret_cast<v4i_r*>(p.wide + off) = o.w0;
+                    *reinterpret_cast<v4i_r*>(p.wide + off + 8) = o.w1;
+                }
+                if (p.narrow) *reinterpret_cast<v4i_r*>(p.narrow + off) = o.n;
+            }
+            if constexpr (kNext) *reinterpret_cast<v4i_r*>(cell) = o.n;
+            __builtin_amdgcn_sched_barrier(0);                // one pixel group at a time: interleaving the four inflates the live set
+        }
+        // the next slice's weights are requested only now -- the shortcut registers are free again -- and land under the matrix
+        // work below; they come from L2 (a slice is 8-32 KB that every workgroup reads)
+        if (kt + 1 < KT) fetch(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- the next conv1, this slice of its reduction: B = the re-quantised sums of this wave's pixels
+        if constexpr (kNext) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const v4i fn = *reinterpret_cast<const v4i*>(sN + wave * 32 * 128 + a1_off[ks]);
+#pragma unroll
+                for (int a = 0; a < MT1; ++a) {
+                    const v4i fa = *reinterpret_cast<const v4i*>(&sW1[a * 32 * 128 + a1_off[ks]]);
+                    acc1[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fn, acc1[a], 0, 0, 0);
+                }
+            }
+        }
+        if (kt + 1 < KT) {
+            __syncthreads();                                  // everybody is done reading this slice's weights
+            stage();
+            __syncthreads();
+        }
+    }
+
+    // ---- the next conv1's tail (+ its ReLU): int8 through the wave's own rows, 16-byte stores of C2 contiguous bytes per pixel
+    if constexpr (kNext) {
+#pragma unroll
+        for (int a = 0; a < MT1; ++a) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int kl = a * 32 + e + 8 * g + 4 * half;
+                    v[e] = conv_tail_i(acc1[a][4 * g + e], sBias1[kl], p.t1);
+                }
+                const int byte = a * 32 + 8 * g + 4 * half;
+                *reinterpret_cast<unsigned*>(my_row + (((byte >> 4) ^ my_swz) * 16) + (byte & 15)) = pack4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        constexpr int CPP = C2 / 16, PPI = 64 / CPP;          // 16-byte groups per pixel, pixels per store instruction
+#pragma unroll
+        for (int j = 0; j < 32 / PPI; ++j) {
+            const int pix = wave * 32 + PPI * j + lane / CPP, ch = lane % CPP;
+            const v4i_r o = *reinterpret_cast<const v4i_r*>(sN + pix * 128 + ((ch ^ swz_of<128>(pix)) * 16));
+            const int m = m0 + pix;
+            if (m < p.M) *reinterpret_cast<v4i_r*>(q1 + (long)m * C2 + 16 * ch) = o;
+        }
+    }
+}
+
+TailParams tail_params(int rs, int relu) {
+    TailParams t;
+    t.rs = rs; t.half_rs = 1 << (rs - 1);
+    t.ilo = -128; t.ihi = 127;
+    t.slo = relu ? 0 : -128; t.shi = 127;
+    return t;
+}
+
+template <int C, int C2>
+void launch_bt(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w3, const float* qb3, const int8_t* w1, const float* qb1,
+               int8_t* q1, const BtParams& p) {
+    if (p.res_bytes == 2)
+        hipLaunchKernelGGL((block_tail_i8_kernel<C, C2, true>), grid, dim3(kConvBlock), 0, st, x, w3, qb3, w1, qb1, q1, p);
+    else
+        hipLaunchKernelGGL((block_tail_i8_kernel<C, C2, false>), grid, dim3(kConvBlock), 0, st, x, w3, qb3, w1, qb1, q1, p);
+}
+
+}  // namespace
+}  // namespace fq
+
+using namespace fq;
+
+extern "C" int fq_block_tail_i8_supported(int C, int K3, int C2, int rs3, int rs1) {
+    if (!(C == 64 || C == 128 || C == 256) || K3 < 128 || K3 > 1024 || (K3 & 127)) return 0;
+    if (!(C2 == 0 || C2 == 64 || C2 == 128) || (C == 256 && C2 != 0)) return 0;
+    if (rs3 < 1 || rs3 > 16 || (C2 && (rs1 < 1 || rs1 > 16))) return 0;
+    return 1;
+}
+
+extern "C" int fq_block_tail_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, const float* qbias3, int rs3, int ob3, const void* res,
+                                int res_bytes, int g_res, int16_t* wide, int g_wide, int8_t* narrow, int ib, int relu,
+                                const int8_t* w1_krsc, const float* qbias1, int rs1, int relu1, int8_t* q1_nhwc, long M, int C,
+                                int K3, int C2, fq_stream_t stream) {
+    if (M < 0 || !fq_block_tail_i8_supported(C, K3, C2, rs3, rs1)) return FQ_ERR_UNSUPPORTED;
+    if (!res || (res_bytes != 1 && res_bytes != 2)) return FQ_ERR_INVALID_ARG;
+    if (M == 0) return FQ_OK;
+    if (!x_nhwc || !w3_krsc || !qbias3 || (C2 && (!w1_krsc || !qbias1 || !q1_nhwc)) || (!C2 && !wide && !narrow)) return FQ_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w3_krsc) | reinterpret_cast<uintptr_t>(res) |
+         reinterpret_cast<uintptr_t>(wide) | reinterpret_cast<uintptr_t>(narrow) | reinterpret_cast<uintptr_t>(w1_krsc) |
+         reinterpret_cast<uintptr_t>(q1_nhwc)) & 15u)
+        return FQ_ERR_INVALID_ARG;
+    if (M * (long)K3 >= 0x3fffffffL || M * (long)C >= 0x7fffffffL) return FQ_ERR_UNSUPPORTED;
+    BtParams p;
+    p.M = (int)M; p.K3 = K3; p.x_bytes = (unsigned)(M * C);
+    p.t3 = tail_params(rs3, 0);
+    p.t1 = tail_params(C2 ? rs1 : 1, relu1);
+    p.res = res; p.res_bytes = res_bytes; p.wide = wide; p.narrow = narrow;
+    const int rc = make_add_params(ob3, g_res, g_wide, wide != nullptr, ib, relu, &p.ap);
+    if (rc != FQ_OK) return rc;
+    // the integer tail of conv3 is only the reference's fp32 chain while |acc| + 2^15 < 2^31: C * 127 * 128 is far below
+    const dim3 grid((unsigned)((M + kTP - 1) / kTP));
+    hipStream_t st = as_stream(stream);
+    if (C == 64) {
+        if (C2 == 64) launch_bt<64, 64>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+        else if (C2 == 128) launch_bt<64, 128>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+        else launch_bt<64, 0>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+    } else if (C == 128) {
+        if (C2 == 64) launch_bt<128, 64>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+        else if (C2 == 128) launch_bt<128, 128>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+        else launch_bt<128, 0>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+    } else {
+        launch_bt<256, 0>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+    }
+    note_conv_variant(11, 128);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}

@@ -128,6 +128,10 @@ def lib():
     L.fq_conv2d_i8_stem.argtypes = [vp, vp, vp, vp] + [ci] * 16 + [vp]
     L.fq_conv2d_i8_add_resident.restype = ci
     L.fq_conv2d_i8_add_resident.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, vp, ci, ci, ci] + [ci] * 15 + [vp]
+    L.fq_block_tail_i8_supported.restype = ci
+    L.fq_block_tail_i8_supported.argtypes = [ci] * 5
+    L.fq_block_tail_i8.restype = ci
+    L.fq_block_tail_i8.argtypes = [vp, vp, vp, ci, ci, vp, ci, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, ctypes.c_long, ci, ci, ci, vp]
     L.fq_add_resident.restype = ci
     L.fq_add_resident.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, vp, ci, ci, sz, vp]
     L.fq_dequant_nhwc_to_nchw.restype = ci
@@ -846,6 +850,44 @@ def conv2d_i8_add_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, res
                                            int(rs), int(ob), _stream(xq)), "fq_conv2d_i8_add_resident")
     _note_variant()
     return wide, narrow
+
+
+def block_tail_supported(C, K3, C2, rs3, rs1):
+    return bool(lib().fq_block_tail_i8_supported(int(C), int(K3), int(C2), int(rs3), int(rs1)))
+
+
+def block_tail_i8(xq, w3q, qbias3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1q=None, qbias1=None, rs1=0,
+                  relu1=False):
+    """fq_block_tail_i8: conv3 (1x1) + NewAdd with the shortcut `res` (+ ReLU) + the next block's conv1 (1x1, + ReLU) in one
+    kernel.  xq int8 [N,H,W,C], w3q int8 [K3,1,1,C], res int8 / int16 [N,H,W,K3], w1q int8 [C2,1,1,K3] or None.
+    Returns (wide int16 or None, narrow int8 or None, q1 int8 [N,H,W,C2] or None)."""
+    for t, n in ((xq, "x"), (w3q, "w3")):
+        _need_cuda(t, torch.int8, "fq_block_tail_i8")
+    _need_cuda(qbias3, torch.float32, "fq_block_tail_i8")
+    if not isinstance(res, torch.Tensor) or res.device.type != "cuda" or res.dtype not in _INT_BYTES:
+        raise FqError("fq_block_tail_i8: the shortcut must be an int8 / int16 torch.cuda tensor")
+    N, H, W, C = xq.shape
+    K3 = int(w3q.shape[0])
+    assert tuple(w3q.shape[1:]) == (1, 1, C) and xq.is_contiguous() and w3q.is_contiguous() and res.is_contiguous()
+    assert tuple(res.shape) == (N, H, W, K3) and qbias3.numel() == K3
+    C2 = 0
+    if w1q is not None:
+        _need_cuda(w1q, torch.int8, "fq_block_tail_i8")
+        _need_cuda(qbias1, torch.float32, "fq_block_tail_i8")
+        C2 = int(w1q.shape[0])
+        assert tuple(w1q.shape[1:]) == (1, 1, K3) and w1q.is_contiguous() and qbias1.numel() == C2
+    assert C2 or want_wide or want_narrow
+    wide = torch.empty(N, H, W, K3, dtype=torch.int16, device=xq.device) if want_wide else None
+    narrow = torch.empty(N, H, W, K3, dtype=torch.int8, device=xq.device) if want_narrow else None
+    q1 = torch.empty(N, H, W, C2, dtype=torch.int8, device=xq.device) if C2 else None
+    _check(lib().fq_block_tail_i8(xq.data_ptr(), w3q.data_ptr(), qbias3.contiguous().data_ptr(), int(rs3), int(ob3), res.data_ptr(),
+                                  _INT_BYTES[res.dtype], int(g_res), wide.data_ptr() if want_wide else None, int(g_wide),
+                                  narrow.data_ptr() if want_narrow else None, int(ib), 1 if relu else 0,
+                                  w1q.data_ptr() if C2 else None, qbias1.contiguous().data_ptr() if C2 else None, int(rs1),
+                                  1 if relu1 else 0, q1.data_ptr() if C2 else None, N * H * W, C, K3, C2, _stream(xq)),
+           "fq_block_tail_i8")
+    _note_variant()
+    return wide, narrow, q1
 
 
 def add_resident(x, gx, y, gy, want_wide, g_wide, want_narrow, ib, relu):

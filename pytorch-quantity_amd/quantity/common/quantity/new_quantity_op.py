@@ -238,6 +238,9 @@ class NewConv2d(_IntegerSimLayer):
 
     def forward(self, input):
         conv = self.Conv
+        ready = getattr(input, "next_out", None) if type(input) is QHandle else None
+        if ready is not None and ready[0] is self:        # the NewAdd that produced `input` ran this convolution in its kernel
+            return ready[1]
         if self._int8_ok(conv):
             wq = self._packed_weight(conv)
             plan = self.__dict__.get("_resident")         # set by common.quantity.resident.enable()
@@ -352,6 +355,10 @@ class NewAdd(nn.Module):
         return out
 
 
+def _block_tail_on():
+    return os.environ.get("FQ_BLOCK_TAIL", "1") != "0"
+
+
 def _newadd_fused_conv_add(self, plan, x, y):
     """conv -> add in one kernel when one operand is a DeferredConv and the other a resident activation."""
     d, other = (x, y) if type(x) is DeferredConv else ((y, x) if type(y) is DeferredConv else (None, None))
@@ -365,6 +372,32 @@ def _newadd_fused_conv_add(self, plan, x, y):
     want_wide = plan.want_wide or not want_narrow
     if h.exact.shape[0] != d.xq.shape[0] or h.exact.shape[-1] != _native.pad16(L.Conv.out_channels):
         return None
+    nxt = plan.fuse_next
+    one = tuple(tuple(int(v) for v in g) for g in d.geom) == ((1, 1), (0, 0), (1, 1)) and tuple(d.wq.shape[1:3]) == (1, 1)
+    if (nxt is None and one and tuple(h.exact.shape[:3]) == tuple(d.xq.shape[:3]) and _block_tail_on()
+            and _native.block_tail_supported(d.xq.shape[-1], L.Conv.out_channels, 0, L.rs_bit, 0)
+            and L.Conv.out_channels == d.wq.shape[0]):
+        # conv3 + NewAdd alone on the same kernel (no next convolution to fuse): its barrier-free, wave-local epilogue streams the
+        # shortcut and the sum 1.5-1.6 x faster than the general kernel's
+        wide, narrow, _ = _native.block_tail_i8(d.xq, d.wq, L.quantized_bias, L.rs_bit, L.output_bit, h.exact, h.grid, want_wide,
+                                                plan.grid, want_narrow, plan.narrow_bit if want_narrow else 0, plan.relu)
+        ref = wide if wide is not None else narrow
+        return QHandle((ref.shape[0], L.Conv.out_channels, ref.shape[1], ref.shape[2]), wide, plan.grid, narrow, plan.narrow_bit,
+                       plan.relu)
+    if nxt is not None and want_narrow and want_wide and tuple(h.exact.shape[:3]) == tuple(d.xq.shape[:3]):
+        # conv3 + NewAdd + the next block's conv1 in one kernel (fq_block_tail_i8): the re-quantised sum is that convolution's
+        # operand, staged in LDS, and reaches HBM only if somebody else reads it too
+        np_ = nxt.__dict__.get("_resident")
+        w1 = nxt._packed_weight(nxt.Conv)
+        if np_ is not None and w1.shape[-1] == L.Conv.out_channels:
+            wide, narrow, q1 = _native.block_tail_i8(d.xq, d.wq, L.quantized_bias, L.rs_bit, L.output_bit, h.exact, h.grid, True,
+                                                     plan.grid, plan.narrow_to_hbm, plan.narrow_bit, plan.relu, w1,
+                                                     nxt.quantized_bias, nxt.rs_bit, np_.relu)
+            out = QHandle((wide.shape[0], L.Conv.out_channels, wide.shape[1], wide.shape[2]), wide, plan.grid, narrow,
+                          plan.narrow_bit, plan.relu)
+            out.next_out = (nxt, QHandle((q1.shape[0], nxt.Conv.out_channels, q1.shape[1], q1.shape[2]), q1, nxt.output_bit, q1,
+                                         nxt.output_bit, np_.relu))
+            return out
     wide, narrow = _native.conv2d_i8_add_resident(d.xq, d.wq, L.quantized_bias, d.geom[0], d.geom[1], d.geom[2], L.rs_bit,
                                                   L.output_bit, h.exact, h.grid, want_wide, plan.grid, want_narrow,
                                                   plan.narrow_bit if want_narrow else 0, plan.relu)

@@ -38,10 +38,13 @@ class QHandle(object):
     exact : int8 / int16 NHWC tensor, value = exact * 2^-grid (the reference's fp32 value, exactly)
     narrow: int8 NHWC tensor = Quantity(value, bit) for the next conv (conv outputs: the same tensor)
     """
-    __slots__ = ("shape", "exact", "grid", "narrow", "bit", "relu_done")
+    __slots__ = ("shape", "exact", "grid", "narrow", "bit", "relu_done", "next_out")
 
     def __init__(self, shape, exact, grid, narrow, bit, relu_done):
         self.shape, self.exact, self.grid, self.narrow, self.bit, self.relu_done = shape, exact, grid, narrow, bit, relu_done
+        # (consumer NewConv2d, its finished output handle): set by a NewAdd that ran that consumer inside its own kernel
+        # (fq_block_tail_i8, Plan.fuse_next) -- the consumer hands it out instead of launching
+        self.next_out = None
 
     def to_f32(self):
         """The fp32 NCHW tensor this handle stands for (DeQuantity + layout change, one kernel)."""
@@ -77,6 +80,12 @@ class DeferredConv(object):
         return self.materialise().to_f32()
 
 
+def block_tail_enabled():
+    """FQ_BLOCK_TAIL=0: keep conv3 + add and the next conv1 as two launches (A/B timing)."""
+    import os
+    return os.environ.get("FQ_BLOCK_TAIL", "1") != "0"
+
+
 def resident_of(x):
     """The integer form of an activation, if it has one (a handle, or an fp32 tensor carrying one)."""
     if type(x) is QHandle:
@@ -92,7 +101,8 @@ def as_f32(x):
 
 class Plan(object):
     """What one producer emits.  Plain data (pickles with the module)."""
-    __slots__ = ("relu", "emit_f32", "emit_int", "narrow_bit", "want_wide", "grid", "resident_add", "defer", "fuse_arg")
+    __slots__ = ("relu", "emit_f32", "emit_int", "narrow_bit", "want_wide", "grid", "resident_add", "defer", "fuse_arg",
+                 "fuse_next", "narrow_to_hbm")
 
     def __init__(self):
         self.relu = False            # the nn.ReLU that consumes this output is fused
@@ -104,6 +114,8 @@ class Plan(object):
         self.resident_add = False    # NewAdd: operands arrive as integers
         self.defer = False           # NewConv2d: only consumer is a resident NewAdd, which runs this conv itself
         self.fuse_arg = None         # NewAdd: operand position (0 / 1) that arrives as a DeferredConv
+        self.fuse_next = None        # NewAdd: the 1x1 NewConv2d consuming this sum that runs inside the add's kernel too
+        self.narrow_to_hbm = True    # NewAdd with fuse_next: somebody besides that convolution reads the int8 re-quantisation
 
     def __getstate__(self):
         return {k: getattr(self, k) for k in self.__slots__}
@@ -456,6 +468,34 @@ def enable(model, example_input, verify=True):
                 add_mod.__dict__["_resident"].fuse_arg = pos
                 summary["fused_conv_adds"] += 1
                 break
+    # ... and when the re-quantised sum of such an add feeds a 1x1 convolution (the next bottleneck's conv1), that convolution
+    # runs inside the same kernel (fq_block_tail_i8): its operand is staged in LDS and, if nobody else reads it, never written
+    summary["fused_block_tails"] = 0
+    for v in tracer.produced:
+        add_mod = v.producer
+        plan = add_mod.__dict__.get("_resident")
+        if v.kind != "add" or plan is None or plan.fuse_arg is None or plan.emit_f32 or not plan.want_wide or not block_tail_enabled():
+            continue
+        e, _relu = eff_of[id(v)]
+        conv3 = operands[add_mod][plan.fuse_arg].producer
+        readers = [c for (c, _pos) in e.consumers if conv_can_read(c)]
+        nxt = None
+        for c in readers:
+            cp = c.__dict__.get("_resident")
+            k = c.Conv
+            if (cp is not None and not cp.defer and cp.emit_int and not cp.emit_f32 and tracer.calls.get(c, 0) == 1
+                    and tuple(k.kernel_size) == (1, 1) and tuple(k.stride) == (1, 1) and tuple(k.padding) == (0, 0)
+                    and tuple(conv3.Conv.kernel_size) == (1, 1) and tuple(conv3.Conv.stride) == (1, 1)
+                    and tuple(conv3.Conv.padding) == (0, 0) and c.input_bit == plan.narrow_bit
+                    and conv3.Conv.out_channels == k.in_channels
+                    and _native.block_tail_supported(conv3.Conv.in_channels, conv3.Conv.out_channels, k.out_channels,
+                                                     conv3.rs_bit, c.rs_bit)):
+                nxt = c
+                break
+        if nxt is not None:
+            plan.fuse_next = nxt
+            plan.narrow_to_hbm = len(readers) > 1
+            summary["fused_block_tails"] += 1
     for m in tracer.avgpool_shapes:
         if avg_can_read(m):
             m.__dict__["forward"] = _AvgPoolResident(m)

@@ -86,6 +86,7 @@ class _DeferralProbe(object):
         self.conv_out = {}          # learn: id(output) -> (output, conv module)
         self.pairs = {}             # learn: Eltwise module -> the conv module whose output it received
         self.keys = {}              # module -> its hook key of this forward
+        self.outputs = {}           # learn: module -> the output OBJECT its forward returned (what model code may have kept)
         self.candidates = {}        # conv module -> (Eltwise module, nn.ReLU module)
         self.relu_only = {}         # conv module -> the nn.ReLU that is the only reader of its output (skip_unread_outputs)
         self.private = {}           # poison: id(poisoned tensor) -> (poisoned tensor, real tensor, the one module that may read it)
@@ -137,8 +138,9 @@ class _DeferralProbe(object):
         model's frames are gone, so whatever still refers to the tensor object is either one of `ours` (containers of this
         calibration, by identity) or such a keeper.  Returns a list of descriptions, empty when nobody does.
           * Python references: gc.get_referrers (module __dict__s, lists, tuples, closures are all gc-tracked);
-          * other tensor objects on the same memory: the TensorImpl's use count (a view keeps its base alive) and the
-            storage's (an alias made by detach() / .data shares the storage but not the tensor)."""
+          * views: the TensorImpl's use count (a view keeps its base alive).
+        NOT found: a detach() / .data alias (another tensor object on the same storage; torch exposes no dependable count of a
+        storage's users -- torch._C._storage_Use_Count moved by itself between two looks at an untouched tensor on this stack)."""
         import gc
         import types
         mine = set(id(o) for o in ours)
@@ -151,11 +153,6 @@ class _DeferralProbe(object):
             found.append("a %s" % type(r).__name__)
         if t._use_count() > 1:
             found.append("a view of it")
-        use = getattr(torch._C, "_storage_Use_Count", None)
-        if use is not None:
-            # (the tensor itself + the UntypedStorage wrapper this very expression creates = 2)
-            if use(t.untyped_storage()._cdata) > 2:
-                found.append("an alias of its storage")
         return found
 
     def poisoned_keys(self):

@@ -1012,14 +1012,15 @@ class Quantity(object):
             probe.relu_only[conv] = relu
         # keepers (code that stores one of these tensors and reads it after the forward: invisible to the poison): whoever still
         # refers to a convolution's output or to a sum now that the learning forward has returned, and is not this calibration
-        ours = [probe.conv_out, first_feats, self._probe_feats, ctl.last_out, ctl.relu_ready] + list(probe.conv_out.values())
+        ours = [probe.conv_out, probe.outputs, first_feats, self._probe_feats, ctl.last_out, ctl.relu_ready] + list(probe.conv_out.values())
         out_of = dict((conv, y) for (y, conv) in probe.conv_out.values())
         self.deferral_refused = {}
         for conv in list(probe.candidates) + list(probe.relu_only):
             watched = [out_of.get(conv)]
             if conv in probe.candidates:
-                watched.append(first_feats.get(probe.keys.get(probe.candidates[conv][0])))
-            kept = [h for t in watched if torch.is_tensor(t) for h in probe.holders(t, ours)]
+                watched.append(probe.outputs.get(probe.candidates[conv][0]))           # the sum, as the model's code holds it
+            kept = [h for t in watched if torch.is_tensor(t) for h in probe.holders(t, ours + [out_of, watched])]
+
             if kept:
                 self.deferral_refused[probe.keys.get(conv)] = kept
                 probe.candidates.pop(conv, None)
@@ -1423,6 +1424,7 @@ class Quantity(object):
                         "conv_add_chains_proven": len(ctl.defer_ok), "conv_add_launches": ctl.deferred_adds,
                         "conv_add_hist_launches": ctl.deferred_hists,
                         "relu_only_chains_proven": len(ctl.relu_only_ok), "launches_without_own_output": ctl.skipped_outputs,
+                        "chains_refused_for_keepers": dict(getattr(self, "deferral_refused", None) or {}),
                         "stats_group_bytes": self._stats_limit,
                         "cache_plan": {k: (sorted(v) if isinstance(v, set) else v) for k, v in (plan or {}).items()
                                        if k != "keep"} if plan else None}
@@ -1525,6 +1527,8 @@ class Quantity(object):
             key = "%s_%i" % (type(module).__name__, state["n"])
             if ctl.poison is not None:
                 ctl.poison.keys[module] = key
+                if ctl.poison.mode == "learn" and torch.is_tensor(output):
+                    ctl.poison.outputs[module] = output       # the object the model code holds (out_feat keeps a detach() alias)
             ctl.relu_ready = None        # a ReLU result prepared by the previous module is for the very next forward only
             pending_bias, ctl.fuse_bias = ctl.fuse_bias, None
             fused = pending_bias is not None and self._finish_fused_conv(module, pending_bias, key if key in cared else None, output)

@@ -25,7 +25,7 @@ sys.stdout = out
 x = data[0][0]
 resident.enable(net, x)
 
-names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8")
+names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8", "block_tail_i8")
 saved = {n: getattr(_native, n) for n in names}
 rows, events = [], []
 
@@ -39,13 +39,16 @@ def timed(fn, name):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); r = fn(*a, **k); e1.record()
         outs = r if isinstance(r, tuple) else (r,)
-        res = a[8] if name == "conv2d_i8_add_resident" else None
+        res = a[8] if name == "conv2d_i8_add_resident" else (a[5] if name == "block_tail_i8" else None)
         first = next(t for t in outs if isinstance(t, torch.Tensor))
         pixels = first.numel() // first.shape[1 if first.dtype == torch.float32 else -1]
         wq = a[1]
+        w_next = (a[12] if len(a) > 12 else k.get("w1q")) if name == "block_tail_i8" else None      # the fused next conv1
         events.append((e0, e1))
-        rows.append((name.replace("conv2d_i8_", ""), tuple(a[0].shape), tuple(wq.shape), pixels, pixels * int(wq.numel()),
-                     nbytes(a[0], a[1], res, *outs)))
+        label = name.replace("conv2d_i8_", "") if name != "block_tail_i8" else ("tail+conv1" if w_next is not None else "block_tail")
+        wshape = tuple(wq.shape) if w_next is None else tuple(wq.shape[:1]) + (int(w_next.shape[0]),) + tuple(wq.shape[3:])
+        rows.append((label, tuple(a[0].shape), wshape, pixels, pixels * (int(wq.numel()) + (int(w_next.numel()) if w_next is not None else 0)),
+                     nbytes(a[0], a[1], res, w_next, *outs)))
         return r
     return wrapper
 

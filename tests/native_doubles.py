@@ -129,6 +129,17 @@ def conv2d_i8_add_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, res
     return _add_chain(y_nhwc, _deq(res, g_res), g_wide, want_wide, ib, want_narrow, relu)
 
 
+def block_tail_i8(xq, w3q, qbias3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1q=None, qbias1=None, rs1=0,
+                  relu1=False):
+    """conv3 + NewAdd (+ ReLU) + the next conv1 (+ ReLU): the reference's chain, one op after the other."""
+    one = ((1, 1), (0, 0), (1, 1))
+    wide, narrow = conv2d_i8_add_resident(xq, w3q, qbias3, one[0], one[1], one[2], rs3, ob3, res, g_res, want_wide, g_wide, True, ib, relu)
+    q1 = None
+    if w1q is not None:
+        _, q1 = conv2d_i8_resident(narrow, w1q, qbias1, one[0], one[1], one[2], rs1, 0, False, True, relu1)
+    return wide, (narrow if want_narrow else None), q1
+
+
 def dequant_nhwc_to_nchw(q, g, channels):
     return torch.from_numpy(np.ascontiguousarray(np.moveaxis(_deq(q, g, channels), -1, 1)))
 
@@ -154,7 +165,7 @@ def quantity(x, ib, bitwidth=8, out=None):
 
 _DOUBLES = dict(quantize_i8_nhwc=quantize_i8_nhwc, quantize_i8_unfold_w=quantize_i8_unfold_w, conv2d_i8=conv2d_i8,
                 conv2d_i8_resident=conv2d_i8_resident, conv2d_i8_stem=conv2d_i8_stem,
-                conv2d_i8_add_resident=conv2d_i8_add_resident, add_resident=add_resident,
+                conv2d_i8_add_resident=conv2d_i8_add_resident, add_resident=add_resident, block_tail_i8=block_tail_i8,
                 dequant_nhwc_to_nchw=dequant_nhwc_to_nchw, maxpool_i8_nhwc=maxpool_i8_nhwc, avgpool_global_nhwc=avgpool_global_nhwc,
                 add_sat=add_sat, quantity=quantity)
 

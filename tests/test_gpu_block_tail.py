@@ -1,0 +1,116 @@
+"""fq_block_tail_i8: conv3 (1x1 expand) + NewAdd with the shortcut (+ ReLU) + the next block's conv1 (1x1 reduce + ReLU) as ONE
+kernel (reference: new_quantity_op.py:124-133 twice and :166-174).  It must leave bit for bit what the two launches it
+replaces leave -- fq_conv2d_i8_add_resident (itself pinned to the CPU oracle's fp32 chain in tests/test_gpu_resident.py) followed
+by fq_conv2d_i8_resident -- and, independently, what the oracle's chain gives on the same integers: ragged pixel counts, int8
+and int16 shortcuts, every subset of {sum, re-quantisation} outputs, with and without the fused next convolution, all grids
+the integer add takes (packed int16, 32-bit) and the float fallback.   pytest -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nat():
+    assert torch.cuda.is_available()
+    from common.quantity import _native
+    _native.lib()
+    return _native
+
+
+def _operands(nat, N, H, W, C, K3, C2, res_dtype, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.randint(-128, 128, (N, H, W, C), dtype=torch.int8, device="cuda", generator=g)
+    w3 = nat.pack_weight_krsc(torch.randint(-127, 128, (K3, C, 1, 1), device="cuda", generator=g).float())
+    b3 = torch.randint(-100, 101, (K3,), device="cuda", generator=g).float()
+    lim = 3000 if res_dtype == torch.int16 else 128
+    res = torch.randint(-lim, lim, (N, H, W, K3), dtype=res_dtype, device="cuda", generator=g)
+    w1 = b1 = None
+    if C2:
+        w1 = nat.pack_weight_krsc(torch.randint(-127, 128, (C2, K3, 1, 1), device="cuda", generator=g).float())
+        b1 = torch.randint(-100, 101, (C2,), device="cuda", generator=g).float()
+    return x, w3, b3, res, w1, b1
+
+
+def _two_launches(nat, x, w3, b3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1, relu1):
+    wide, narrow = nat.conv2d_i8_add_resident(x, w3, b3, (1, 1), (0, 0), (1, 1), rs3, ob3, res, g_res, want_wide, g_wide,
+                                              True, ib, relu)
+    q1 = None
+    if w1 is not None:
+        _, q1 = nat.conv2d_i8_resident(narrow, w1, b1, (1, 1), (0, 0), (1, 1), rs1, ib, False, True, relu1)
+    return wide, (narrow if want_narrow else None), q1
+
+
+CASES = [
+    # N, H, W, C, K3, C2, shortcut, (ob3, g_res, ib), rs3, rs1, relu, relu1, want_wide, want_narrow
+    (3, 9, 7, 64, 256, 64, torch.int16, (4, 5, 4), 9, 10, True, True, True, False),      # stage-1 shape, 189 pixels (ragged tile)
+    (2, 12, 12, 64, 256, 64, torch.int8, (4, 4, 4), 9, 10, True, True, True, False),     # a stage's first block: int8 shortcut
+    (2, 8, 8, 128, 512, 128, torch.int16, (4, 5, 4), 10, 11, True, True, True, False),   # stage-2 shape: four slices
+    (1, 16, 16, 128, 512, 128, torch.int8, (3, 5, 4), 10, 11, True, True, True, True),
+    (2, 7, 9, 64, 256, 128, torch.int16, (4, 5, 3), 8, 9, True, False, True, True),
+    (2, 7, 9, 128, 384, 64, torch.int16, (5, 5, 5), 9, 9, False, True, False, True),     # k = 0: the 32-bit integer add, no ReLU
+    (2, 10, 10, 64, 256, 0, torch.int16, (4, 5, 4), 9, 0, True, False, True, True),      # conv3 + NewAdd alone
+    (2, 10, 10, 128, 128, 0, torch.int8, (4, 5, 4), 9, 0, True, False, False, True),
+    (5, 14, 14, 64, 256, 64, torch.int16, (4, 6, 2), 9, 10, True, True, True, False),    # k = 4
+    (1, 1, 1, 64, 128, 64, torch.int16, (4, 5, 4), 9, 10, True, True, True, True),       # one pixel
+    (3, 7, 7, 256, 1024, 0, torch.int16, (4, 5, 4), 10, 0, True, False, True, True),     # stage-3 shape: eight slices, 256-byte weight rows
+    (2, 5, 5, 256, 384, 0, torch.int8, (3, 4, 4), 11, 0, False, False, True, False),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%dx%d_%dto%dto%d_%s" % (c[0], c[1], c[2], c[3], c[4], c[5], str(c[6])[-5:]))
+def test_block_tail_equals_the_two_launches_it_replaces(nat, case):
+    N, H, W, C, K3, C2, res_dtype, (ob3, g_res, ib), rs3, rs1, relu, relu1, want_wide, want_narrow = case
+    x, w3, b3, res, w1, b1 = _operands(nat, N, H, W, C, K3, C2, res_dtype, seed=N * 1000 + K3 + C2)
+    g_wide = max(0, ob3, g_res)
+    assert nat.block_tail_supported(C, K3, C2, rs3, rs1)
+    ref = _two_launches(nat, x, w3, b3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1, relu1)
+    nat.conv_variant_log = log = {}
+    try:
+        got = nat.block_tail_i8(x, w3, b3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1, relu1)
+    finally:
+        nat.conv_variant_log = None
+    assert log == {"block_tail/128": 1}
+    for name, a, b in zip(("wide", "narrow", "q1"), got, ref):
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert torch.equal(a, b), "%s differs in %d of %d" % (name, int((a != b).sum()), a.numel())
+    if C2:
+        assert int((got[2] != 0).sum()) > 0                       # (not a vacuous comparison)
+
+
+def test_block_tail_against_the_oracle_chain(nat, oracle):
+    """The same chain through the CPU oracle's element-wise ops on the exact integer convolution (no GPU kernel involved in the
+    expected values): conv -> RightShift -> + bias -> Sp -> DeQuantity | add | clamp | ReLU | Quantity -> conv -> tail -> ReLU."""
+    N, H, W, C, K3, C2 = 2, 6, 5, 64, 256, 64
+    ob3, g_res, ib, rs3, rs1 = 4, 5, 4, 9, 10
+    x, w3, b3, res, w1, b1 = _operands(nat, N, H, W, C, K3, C2, torch.int16, seed=77)
+    wide, narrow, q1 = nat.block_tail_i8(x, w3, b3, rs3, ob3, res, g_res, True, 5, True, ib, True, w1, b1, rs1, True)
+    xi = x.cpu().numpy().astype(np.int32).transpose(0, 3, 1, 2)
+    w3i = w3.cpu().numpy().astype(np.int32).reshape(K3, C, 1, 1)
+    acc = oracle.conv2d_int(xi, w3i).astype(np.float32)                              # [N, K3, H, W]
+    conv_val = oracle.recon_epilogue(acc, b3.cpu().numpy(), rs3, ob3, 8)            # RightShift + bias + Sp + DeQuantity
+    res_val = res.cpu().numpy().astype(np.float32).transpose(0, 3, 1, 2) * np.float32(2.0 ** -g_res)
+    s = np.maximum(oracle.add_sat(conv_val.ravel(), res_val.ravel(), 8), 0).astype(np.float32)        # NewAdd, then nn.ReLU
+    want_wide = (s * np.float32(2.0 ** 5)).reshape(N, K3, H, W).transpose(0, 2, 3, 1)
+    assert np.array_equal(wide.cpu().numpy().astype(np.float32), want_wide)
+    qn = oracle.quantity(s, ib, 8).reshape(N, K3, H, W)                              # the next layer's Quantity(ib)
+    assert np.array_equal(narrow.cpu().numpy().astype(np.float32), qn.transpose(0, 2, 3, 1))
+    acc1 = oracle.conv2d_int(qn.astype(np.int32), w1.cpu().numpy().astype(np.int32).reshape(C2, K3, 1, 1)).astype(np.float32)
+    t1 = np.maximum(oracle.recon_epilogue(acc1, b1.cpu().numpy(), rs1, 0, 8), 0)     # ob = 0: the integers in front of DeQuantity
+    assert np.array_equal(q1.cpu().numpy().astype(np.float32), t1.transpose(0, 2, 3, 1))
+
+
+def test_block_tail_argument_errors(nat):
+    L = nat.lib()
+    assert L.fq_block_tail_i8_supported(64, 256, 64, 9, 10) == 1
+    assert L.fq_block_tail_i8_supported(256, 1024, 256, 9, 10) == 0          # no fused next conv behind 256 -> 1024
+    assert L.fq_block_tail_i8_supported(256, 1024, 0, 9, 0) == 1 and L.fq_block_tail_i8_supported(512, 2048, 0, 9, 0) == 0
+    assert L.fq_block_tail_i8_supported(64, 192, 64, 9, 10) == 0             # K3 not a multiple of 128
+    assert L.fq_block_tail_i8_supported(64, 256, 64, 0, 10) == 0             # no integer tail
+    x = torch.zeros(1, 1, 1, 64, dtype=torch.int8, device="cuda")
+    assert L.fq_block_tail_i8(x.data_ptr(), x.data_ptr(), x.data_ptr(), 9, 4, None, 2, 5, None, 5, None, 4, 1, None, None, 0, 0, None,
+                              1, 64, 256, 0, None) == -1                      # no shortcut
+    assert L.fq_block_tail_i8(None, None, None, 9, 4, x.data_ptr(), 2, 5, None, 5, None, 4, 1, None, None, 0, 0, None, 0, 64, 256, 0,
+                              None) == 0                                      # no pixels: nothing to do

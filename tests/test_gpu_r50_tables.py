@@ -372,7 +372,9 @@ def test_r50_reconmodel_at_the_batch_the_bench_times_equals_the_reference(g4r50)
         assert sum(log.values()) == 54, log
         assert log.get("stem/64") == 1 and log.get("c64_halo/64") == 3, log
         assert sum(v for k, v in log.items() if k.startswith("halo8")) >= 7, log
-        assert sum(v for k, v in log.items() if k.startswith(("halo", "c64_halo"))) == 16, log      # every 3x3 layer
+        # all 13 stride-1 3x3 layers on the resident-halo kernels; the three stride-2 ones and the deep 1x1 reductions on LDS-DMA
+        assert sum(v for k, v in log.items() if k.startswith(("halo", "c64_halo"))) == 13, log
+        assert sum(v for k, v in log.items() if k.startswith("dma")) >= 3, log
         small = {}
         _native.conv_variant_log = small
         try:

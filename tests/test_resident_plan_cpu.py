@@ -73,7 +73,7 @@ def test_plan_of_a_mini_resnet_and_bit_identical_outputs():
             plain = net(x)
         summary = resident.enable(net, x)                      # verify=True: compares with the traced forward itself
         assert summary == {"resident_convs": 8, "resident_adds": 2, "resident_pools": 2, "fused_relus": 7, "fp32_outputs": 0,
-                           "int_only_outputs": 11, "fused_conv_adds": 2}, summary
+                           "int_only_outputs": 11, "fused_conv_adds": 2, "fused_block_tails": 0}, summary   # (16 / 32 channels: too thin)
         plans = resident.describe(net)
         assert plans["conv1"].relu and plans["conv1"].emit_int and not plans["conv1"].emit_f32          # stem -> int8 max-pool
         assert plans["maxpool"].emit_int and not plans["maxpool"].emit_f32 and plans["maxpool"].narrow_bit == 4
@@ -99,6 +99,78 @@ def test_plan_of_a_mini_resnet_and_bit_identical_outputs():
         assert not resident.describe(net) and "forward" not in net.relu.__dict__ and "forward" not in net.maxpool.__dict__
         with torch.no_grad():
             assert torch.equal(net(x), plain)
+
+
+class _WideNet(nn.Module):
+    """Three bottlenecks at ResNet-50's first-stage widths (64 -> 256) behind a 3x3 stem."""
+
+    def __init__(self):
+        from common.quantity import NewConv2d
+        super(_WideNet, self).__init__()
+        torch.manual_seed(5)
+        self.conv1 = NewConv2d(nn.Conv2d(3, 64, 3, padding=1, bias=True), _info(5, 4))
+        self.relu = nn.ReLU(False)
+        self.block1 = _Block(64, 64, 256, (4, 4, 3, 3, 4, 3), True)
+        self.block2 = _Block(256, 64, 256, (3, 4, 4, 2, None, 2), False)
+        self.block3 = _Block(256, 64, 256, (2, 4, 4, 2, None, 2), False)
+        self.avgpool = nn.AvgPool2d(4)
+
+    def forward(self, x):
+        x = self.relu(self.conv1(x))
+        x = self.block3(self.block2(self.block1(x)))
+        return self.avgpool(x)
+
+
+def test_block_tail_plan_runs_the_next_conv1_inside_the_add():
+    """Two bottlenecks at ResNet-50's first-stage widths (64 -> 256): block 1's conv3 is deferred into its NewAdd, and that add's
+    re-quantised sum feeds block 2's conv1 and nothing else -- so the add also runs THAT convolution (fq_block_tail_i8,
+    Plan.fuse_next) and the int8 sum is not written; block 1's own conv1 / projection read the stem's int8 output (two readers:
+    no fusion there).  Same outputs, bit for bit; the plan survives pickling; FQ_BLOCK_TAIL=0 keeps the two launches."""
+    from common.quantity import resident
+    with native_doubles.installed() as nat:
+        net = _WideNet().eval()
+        x = torch.randn(1, 3, 4, 4)
+        with torch.no_grad():
+            plain = net(x)
+        calls = {"bt": 0, "add": 0}
+        real_bt, real_add = nat.block_tail_i8, nat.conv2d_i8_add_resident
+
+        def bt(*a, **k):
+            calls["bt"] += 1
+            return real_bt(*a, **k)
+
+        def add(*a, **k):
+            calls["add"] += 1
+            return real_add(*a, **k)
+        nat.block_tail_i8, nat.conv2d_i8_add_resident = bt, add
+        try:
+            summary = resident.enable(net, x)
+            assert summary["fused_conv_adds"] == 3 and summary["fused_block_tails"] == 2, summary
+            plans = resident.describe(net)
+            assert plans["block1.Eltwise"].fuse_next is net.block2.conv1 and not plans["block1.Eltwise"].narrow_to_hbm
+            assert plans["block2.Eltwise"].fuse_next is net.block3.conv1
+            assert plans["block3.Eltwise"].fuse_next is None                 # its sum goes to the average pool
+            calls["bt"] = calls["add"] = 0
+            with torch.no_grad():
+                assert torch.equal(net(x), plain)
+            # blocks 1 and 2 run their tails AND the next conv1 through fq_block_tail_i8, block 3 its tail alone (same kernel)
+            assert calls["bt"] == 3 and calls["add"] == 0
+            with torch.no_grad():
+                mid = net.block1(net.relu(net.conv1(x)))
+            assert type(mid).__name__ == "QHandle" and mid.narrow is None and mid.next_out[0] is net.block2.conv1
+            again = pickle.loads(pickle.dumps(net))
+            with torch.no_grad():
+                assert torch.equal(again(x), plain)
+        finally:
+            nat.block_tail_i8, nat.conv2d_i8_add_resident = real_bt, real_add
+
+
+def test_block_tail_can_be_switched_off(monkeypatch):
+    from common.quantity import resident
+    monkeypatch.setenv("FQ_BLOCK_TAIL", "0")
+    with native_doubles.installed():
+        net = _mini_resnet()
+        assert resident.enable(net, torch.randn(1, 3, 8, 8))["fused_block_tails"] == 0
 
 
 def test_values_with_foreign_consumers_keep_their_fp32_form():
