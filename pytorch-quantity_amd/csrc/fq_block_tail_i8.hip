@@ -148,19 +148,24 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
             for (int r = 0; r < 16; ++r) acc1[a][r] = 0;
     }
 
+    // the shortcut of a slice: 16 channels x 4 pixels per lane, requested at the head of the slice -- in front of ~700 vector
+    // instructions of matrix work and tail.  (Measured and rejected, round 4, in the network at 256 images: a second register set
+    // holding the NEXT slice's shortcut one slice ahead -- 174 / 188 / 135 us became 177 / 196 / 151 on the three 56 x 56 tails; and
+    // a persistent form with every weight stationary in LDS, no barrier at all and the next tile's operands requested a slice
+    // ahead: 171 / 193 / 148.  These launches run within 20-35 % of what HBM delivers; what is left is not request latency.)
+    struct Res { v4i_r lo[4], hi[kRes16 ? 4 : 1]; };
+    Res res;
     for (int kt = 0; kt < KT; ++kt) {
         const int k0 = kt * 128;
-        // the shortcut of this slice (16 channels x 4 pixels per lane), requested before the matrix work
-        v4i_r res_lo[4], res_hi[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + s_pix + 8 * j;
             const long off = m < p.M ? (long)m * p.K3 + k0 + 16 * s_ch : 0;
             if constexpr (kRes16) {
-                res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
-                res_hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
+                res.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
+                res.hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
             } else {
-                res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
+                res.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -209,11 +214,11 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
             Add16Out o;
             if constexpr (kRes16) {
                 Vec16<int16_t> rv;
-                rv.a = res_lo[j]; rv.b = res_hi[j];
+                rv.a = res.lo[j]; rv.b = res.hi[j];
                 o = add_resident_16_regs(cv, rv, p.wide != nullptr, true, p.ap);
             } else {
                 Vec16<int8_t> rv;
-                rv.a = res_lo[j];
+                rv.a = res.lo[j];
                 o = add_resident_16_regs(cv, rv, p.wide != nullptr, true, p.ap);
             }
             const int m = m0 + pix;

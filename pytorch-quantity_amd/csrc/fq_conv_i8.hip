@@ -105,39 +105,10 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
 // (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel (wave*32 + lane&31 of the 128-pixel tile).  The tail
 // runs in integer arithmetic when the host proved it equivalent (kIntTail), else as the reference's fp32
 // chain.  sO: >= kTP * (TK + 16) bytes of LDS that no wave reads any more (the weight buffers).
-// The residual operand of a fused NewAdd for one thread of the store layout (thread -> pixel idx / CPP, 16-channel group idx % CPP,
-// idx = tid + 256 j): requested either at the head of the epilogue, or -- register-staged kernel, FQ_RES_EARLY -- right behind
-// the first K-step's operand loads, so that its latency runs beside the operand fetch, the LDS staging and the MFMAs instead of
-// starting when they are over (a conv3 + add workgroup is one or two K-steps of matrix work and 32 KB of residual).
-template <int TK>
-struct ResRegs {
-    static constexpr int NJ = (kTP * (TK / 16)) / kConvBlock;
-    v4i_r lo[NJ], hi[NJ];
-};
-template <int TK>
-__device__ __forceinline__ void load_residual(ResRegs<TK>& r, const ConvParams& p, int tid, int m0, int k0) {
-    constexpr int CPP = TK / 16;
-#pragma unroll
-    for (int j = 0; j < ResRegs<TK>::NJ; ++j) {
-        const int idx = tid + kConvBlock * j;
-        const int pix = idx / CPP, ch = idx - pix * CPP;
-        const int mm = m0 + pix, kk = k0 + 16 * ch;
-        const bool live = mm < p.M && kk < p.Kpad;
-        const long off = live ? (long)mm * p.Kpad + kk : 0;
-        if (p.res_bytes == 1) {
-            r.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
-        } else {
-            r.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
-            r.hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
-        }
-    }
-}
-
 template <int TK, int kOut, bool kIntTail>
 __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvParams& p, float* __restrict__ y,
                                               int8_t* __restrict__ q, int8_t* sO, const float* sBias, const int* sBiasI, int m0,
-                                              int k0, int n_img, int pq, bool m_ok, int tid_base = 0,
-                                              ResRegs<TK>* early = nullptr) {
+                                              int k0, int n_img, int pq, bool m_ok, int tid_base = 0) {
     constexpr int MT = TK / 32;
     // (tid_base: a 512-thread workgroup runs this once per 256-thread half, each on its own 128-pixel tile and its own sO)
     const int tid = (int)threadIdx.x - tid_base, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -170,10 +141,23 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
         // fused NewAdd: the residual groups this thread will need are requested FIRST, so that their latency
         // hides under the tail arithmetic and the LDS transpose below instead of sitting in front of the stores
         // (the operand-fragment registers are dead here, so this costs no occupancy)
-        static_assert(NJ == ResRegs<TK>::NJ, "store layout");
-        ResRegs<TK> res_late;
-        if ((kOut & kOutAdd) && early == nullptr) load_residual<TK>(res_late, p, tid, m0, k0);
-        ResRegs<TK>& res = early ? *early : res_late;
+        v4i_r res_lo[NJ], res_hi[NJ];
+        if (kOut & kOutAdd) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int idx = tid + kConvBlock * j;
+                const int pix = idx / CPP, ch = idx - pix * CPP;
+                const int mm = m0 + pix, kk = k0 + 16 * ch;
+                const bool live = mm < p.M && kk < p.Kpad;
+                const long off = live ? (long)mm * p.Kpad + kk : 0;
+                if (p.res_bytes == 1) {
+                    res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
+                } else {
+                    res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
+                    res_hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
+                }
+            }
+        }
         __syncthreads();                                  // every wave is done reading the operand tiles
         const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
 #pragma unroll
@@ -207,11 +191,11 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
                     int8_t* nd = q ? q + off : nullptr;
                     if (p.res_bytes == 1) {
                         Vec16<int8_t> rv;
-                        rv.a = res.lo[j];
+                        rv.a = res_lo[j];
                         add_resident_16(cv, rv, wd, nd, p.ap);
                     } else {
                         Vec16<int16_t> rv;
-                        rv.a = res.lo[j]; rv.b = res.hi[j];
+                        rv.a = res_lo[j]; rv.b = res_hi[j];
                         add_resident_16(cv, rv, wd, nd, p.ap);
                     }
                 } else {
@@ -396,15 +380,6 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
 
     const int nsteps = (p.chunks + 7) >> 3;
     load_step();
-    // fused NewAdd: the residual tile (32 KB per workgroup at TK = 128) is requested HERE, behind the first K-step's operand
-    // loads and in front of everything that waits for them -- vmcnt retires in issue order, so the operands are not held up,
-    // and the residual's latency runs beside the LDS staging, the barrier and the MFMAs (FQ_RES_EARLY=0: at the head of the
-    // epilogue, as until round 4)
-    ResRegs<TK> res_early;
-    if ((kOut & kOutAdd) && p.res_early) {
-        load_residual<TK>(res_early, p, tid, m0, k0);
-        __builtin_amdgcn_sched_barrier(0);
-    }
     store_a(0);
     v4i fb[4];
 #pragma unroll
@@ -440,9 +415,10 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
     }
 
     static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the int8 output tile is staged in the weight buffers");
-    ResRegs<TK>* const early = ((kOut & kOutAdd) && p.res_early) ? &res_early : nullptr;
-    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, 0, early);
-    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, 0, early);
+    // (measured and rejected, round 4: the fused add's residual requested behind the first K-step's operand loads instead of at
+    //  the head of the epilogue: 333 -> 374 us on 64 -> 256 @56x56 from HBM, 170 -> 190 on 128 -> 512 @28x28)
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
 }
 
 // ---- C % 128 == 0, K % TK == 0: both operands by LDS-DMA ----------------------------------------------
@@ -1577,10 +1553,6 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     p.slo = (int)p.lo; p.shi = (int)p.hi;
     p.Kpad = (q_nhwc || fa.res) ? Kpad : 0;
     p.res = fa.res; p.res_bytes = fa.res_bytes; p.wide = fa.wide; p.ap = fa.ap;
-    // (measured and rejected, round 4: requesting the residual behind the first K-step's operand loads instead of at the head of
-    //  the epilogue -- 333 -> 374 us on 64 -> 256 @56x56 from HBM, and twice the time inside the network; FQ_RES_EARLY=1 to see it)
-    static const int res_early = [] { const char* e = getenv("FQ_RES_EARLY"); return e ? atoi(e) : 0; }();
-    p.res_early = res_early;
     p.x_bytes = (unsigned)((long)N * H * W * C);
     p.w_bytes = (unsigned)((long)K * R * S * C);
     hipStream_t st = as_stream(stream);

@@ -29,7 +29,6 @@ struct ConvParams {
     // fused residual add (kOutAdd): the conv output is operand x of NewAdd, `res` is operand y
     const void* res;                     // int8 / int16 NHWC [N][P][Q][Kpad], same layout as the int8 output
     int res_bytes;
-    int res_early;                       // request the residual behind the first K-step's operand loads (conv2d_i8_kernel)
     int16_t* wide;                       // exact int16 sum (may be null); the int8 output pointer receives `narrow`
     AddResParams ap;
     // XCD-aware workgroup order (0 = plain 2-D grid): see conv_tile_of()

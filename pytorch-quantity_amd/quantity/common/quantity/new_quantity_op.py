@@ -375,10 +375,12 @@ def _newadd_fused_conv_add(self, plan, x, y):
     nxt = plan.fuse_next
     one = tuple(tuple(int(v) for v in g) for g in d.geom) == ((1, 1), (0, 0), (1, 1)) and tuple(d.wq.shape[1:3]) == (1, 1)
     if (nxt is None and one and tuple(h.exact.shape[:3]) == tuple(d.xq.shape[:3]) and _block_tail_on()
-            and _native.block_tail_supported(d.xq.shape[-1], L.Conv.out_channels, 0, L.rs_bit, 0)
+            and d.xq.shape[-1] == 64 and _native.block_tail_supported(64, L.Conv.out_channels, 0, L.rs_bit, 0)
             and L.Conv.out_channels == d.wq.shape[0]):
-        # conv3 + NewAdd alone on the same kernel (no next convolution to fuse): its barrier-free, wave-local epilogue streams the
-        # shortcut and the sum 1.5-1.6 x faster than the general kernel's
+        # conv3 + NewAdd alone on the same kernel (no next convolution to fuse) for the 64-channel stage, whose tensors come from
+        # HBM: its barrier-free, wave-local epilogue streams them 1.5-1.6 x faster than the general kernel's when nothing is
+        # cache resident (scripts/block_tail_probe.py), 6 % faster inside the network.  Deeper stages live in the Infinity
+        # Cache at these sizes and the general kernel's 3 workgroups per CU win there.
         wide, narrow, _ = _native.block_tail_i8(d.xq, d.wq, L.quantized_bias, L.rs_bit, L.output_bit, h.exact, h.grid, want_wide,
                                                 plan.grid, want_narrow, plan.narrow_bit if want_narrow else 0, plan.relu)
         ref = wide if wide is not None else narrow

@@ -56,40 +56,13 @@ def _dist_state():
     return 0, 1
 
 
-class _StopForward(Exception):
-    """Raised by the feature hook to end a forward pass early (pass 2 only needs a prefix of the net
-    when the deeper activations were kept from pass 1)."""
-
-
-class _FileGroup(list):
-    """Consecutive calibration files of one rank that go through the model as one batch (Quantity.file_batch)."""
-
-
-def _dist_on():
-    import torch.distributed as dist
-    return dist.is_available() and dist.is_initialized()
-
-
-# Once-per-process check results, per module.  Kept in _float_conv's WeakKeyDictionary, never on the module: the reference
-# pickles whole models (reconstruction.py:107-140) and nothing of this package may travel into that file.
-_RELU_VERIFIED = "relu_fusion_verified"
-_POOL_VERIFIED = "pool_verified"                  # the own pooling kernel gave torch's bits here
-_POOL_OFF = "pool_off"
-_FUSION_VERIFIED = "bias_fusion_verified"         # conv-without-bias + fq_bias_add_absmax_f32 == its forward
-
-
-def _flag(m, name):
-    return bool(_float_conv.state(m).get(name))
-
-
-def _set_flag(m, name):
-    _float_conv.state(m)[name] = True
-
-
+from ._fused_forward import (_FusedForward, _StopForward, _flag, _set_flag, _RELU_VERIFIED, _POOL_VERIFIED, _POOL_OFF,  # noqa: E402,F401
+                             _FUSION_VERIFIED)
+from ._file_inputs import _FileInputs, _FileGroup, _dist_on  # noqa: E402,F401
 from ._hook_state import _AFTER_FORWARD, _DeferralProbe, _EagerStats, _HookState  # noqa: E402,F401
 
 
-class Quantity(object):
+class Quantity(_FusedForward, _FileInputs):
 
     # the statistics engine; tests substitute oracle-backed doubles to exercise the host logic on CPU
     collector_cls = DistributionCollector
@@ -290,171 +263,6 @@ class Quantity(object):
         print("input option set wrong:", mode)
         return None
 
-    # File inputs (PRE_PROCESS.IMG 0 / 2): the reference feeds ONE file per forward (pytorch_quantizer.py:252-284,
-    # 288-296).  Maxima and integer histograms do not depend on how the images are grouped, so `file_batch` consecutive
-    # files of a rank go through the model as one batch, decoded by `decode_workers` threads straight into one pinned staging
-    # tensor (file_batch = 1: the reference's form).  What the grouping CAN touch is the last bit of some activations: this
-    # library's float kernels compute an output element as one fma chain whatever the batch size -- except in the tiles of a
-    # launch's partly filled last round, which the tail split (include/fq.h, fq_conv_f32_workspace_bytes) cuts along K, and
-    # which tiles those are depends on the launch's tile count.  With _native.conv_tail_split = False (FQ_CONV_TAIL_SPLIT=0)
-    # any grouping gives the same histograms bit for bit; with it (default, +3 % images/s) the same feat.table and
-    # histograms that differ in a few counts of neighbouring bins (tests/test_gpu_file_inputs.py runs both).
-    file_batch = int(os.environ.get("FQ_FILE_BATCH", "64"))
-    decode_workers = int(os.environ.get("FQ_DECODE_WORKERS", str(min(16, os.cpu_count() or 8))))
-    # pass 2 reads the inputs again: file batches already uploaded in pass 1 stay on the device up to this many bytes
-    # (5 120 ResNet images are 3.1 GB) instead of being decoded a second time
-    file_keep_bytes = int(float(os.environ.get("FQ_FILE_KEEP_GB", "16")) * (1 << 30))
-
-    def _file_batching(self):
-        return (int(self.user_config["PRE_PROCESS"]["IMG"]) in (0, 2) and self.file_batch > 1 and self.device == "gpu"
-                and torch.cuda.is_available())
-
-    @staticmethod
-    def _npy_header(path):
-        """(header bytes up to the data, shape) of an fp32 C-order .npy file, or None."""
-        with open(path, "rb") as fh:
-            try:
-                version = np.lib.format.read_magic(fh)
-                shape, fortran, dtype = (np.lib.format.read_array_header_1_0(fh) if version == (1, 0)
-                                         else np.lib.format.read_array_header_2_0(fh))
-            except ValueError:
-                return None
-            if fortran or dtype != np.float32:
-                return None
-            n = fh.tell()
-            fh.seek(0)
-            return fh.read(n), tuple(shape)
-
-    @staticmethod
-    def _read_npy_into(path, dst, header=None):
-        """One .npy file (fp32, C order, dst's shape) read straight into `dst` (a numpy view of the pinned batch): no
-        intermediate array.  `header`: the header bytes of a file of the same form (Quantity._npy_header) -- files written by
-        one np.save loop share them, and comparing bytes is all the parsing the other files need.  False when the file is
-        not of that form (the caller falls back to np.load)."""
-        if header is None:
-            h = Quantity._npy_header(path)
-            if h is None or h[1] != tuple(dst.shape):
-                return False
-            header = h[0]
-        with open(path, "rb", buffering=0) as fh:
-            if fh.read(len(header)) != header:
-                return False
-            return fh.readinto(memoryview(dst.reshape(-1)).cast("B")) == dst.size * 4
-
-    def _staging(self, shape):
-        """A pinned host tensor of `shape` out of a ring of six staging buffers owned by this calibration (allocated on
-        first use, as large as the largest batch so far).  Page-locking 150 MB costs 15-40 ms, and torch's caching host
-        allocator hands a block back only once the copies out of it are known to be done -- with a batch decoded ahead,
-        one being copied and one just consumed it kept allocating new ones.  A slot is reused only after the copy out of it
-        has completed (its event, set by _device_items)."""
-        ring = self.__dict__.setdefault("_pinned_ring", {"slots": [], "next": 0, "lock": __import__("threading").Lock()})
-        with ring["lock"]:
-            return self._staging_locked(ring, shape)
-
-    def _staging_locked(self, ring, shape):
-        n = 1
-        for v in shape:
-            n *= int(v)
-        if len(ring["slots"]) < 6:
-            ring["slots"].append({"buf": torch.empty(n, dtype=torch.float32, pin_memory=True), "event": None})
-            slot = ring["slots"][-1]
-        else:
-            slot = ring["slots"][ring["next"] % 6]
-            ring["next"] += 1
-            # (three groups are decoded ahead and one is being handed over: at most four slots are out without an event)
-            assert slot["event"] is not None or not slot.get("out"), "staging ring too small for the look-ahead"
-            if slot["event"] is not None:
-                slot["event"].synchronize()
-                slot["event"] = None
-            if slot["buf"].numel() < n:
-                slot["buf"] = torch.empty(n, dtype=torch.float32, pin_memory=True)
-        out = slot["buf"][:n].view(shape)
-        out._fq_slot = slot
-        slot["out"] = True
-        return out
-
-    def _preprocess_group(self, group, mode):
-        """[G, C, H, W] pinned host tensor of the files in `group` (unreadable image files are dropped, as a crash on one
-        would be the reference's only alternative); None when nothing was readable."""
-        from concurrent.futures import ThreadPoolExecutor
-        if getattr(self, "_decode_pool", None) is None:
-            self._decode_pool = ThreadPoolExecutor(max_workers=max(1, self.decode_workers))
-        paths = list(group)
-        stage = self.__dict__.setdefault("input_wait_s", {})
-        t_0 = time.perf_counter()
-        if mode == 2:
-            h = self._npy_header(paths[0])
-            if h is not None:                                   # the whole group through the native reader
-                batch = self._staging((len(paths),) + h[1])
-                t_1 = time.perf_counter()
-                flags = _native.read_npy_batch(paths, h[0], batch, threads=min(4, max(1, self.decode_workers)))
-                for j, f in enumerate(flags):
-                    if not f:                                   # another header: the general reader, which also checks the shape
-                        one = self.preprocess(paths[j])
-                        if tuple(one.shape[1:]) != tuple(batch.shape[1:]):
-                            raise ValueError("calibration files of one batch have different shapes; set Quantity.file_batch = 1")
-                        batch[j].copy_(one[0])
-                t_2 = time.perf_counter()
-                stage["group_setup"] = stage.get("group_setup", 0.0) + (t_1 - t_0)      # (helper-thread seconds: diagnostics)
-                stage["group_read"] = stage.get("group_read", 0.0) + (t_2 - t_1)
-                return batch
-        first = self.preprocess(paths[0])
-        k = 1
-        while first is False and k < len(paths):                # (mode 0: skip unreadable files at the head)
-            first = self.preprocess(paths[k])
-            k += 1
-        if first is False or first is None:
-            return None
-        rest = paths[k:]
-        batch = self._staging((1 + len(rest),) + tuple(first.shape[1:]))
-        batch[0].copy_(first[0])
-        view = batch.numpy()
-        t_1 = time.perf_counter()
-        header = None
-        if mode == 2:
-            h = self._npy_header(paths[k - 1])
-            header = h[0] if h is not None and h[1] == tuple(view.shape[1:]) else None
-
-        def load(j):
-            dst = view[1 + j]
-            one = self.preprocess(rest[j])
-            if one is False or one is None:
-                return False
-            if tuple(one.shape[1:]) != tuple(dst.shape):
-                return None
-            dst[...] = one[0].numpy()
-            return True
-        # .npy files: one foreign call reads the whole group (fq_read_npy_batch_f32: open / header compare / pread per
-        # file on a few host threads, the interpreter lock released throughout).  The same loop in Python measured 17 000-
-        # 22 000 files/s alone and 5 500 next to the thread that launches the kernels -- three lock hand-offs per file
-        # (scripts/_dbg/file_decode_probe.py); a Python thread pool was slower still.  Files the native reader refuses
-        # (another header) and image files (PIL decode + resize: milliseconds each, outside the lock) take load().
-        if header is not None and rest:
-            flags = _native.read_npy_batch(rest, header, batch[1:], threads=min(4, max(1, self.decode_workers)))
-            ok = [True if f else load(j) for j, f in enumerate(flags)]
-        elif header is not None:
-            ok = []
-        else:
-            ok = list(self._decode_pool.map(load, range(len(rest))))
-        t_2 = time.perf_counter()
-        stage["group_setup"] = stage.get("group_setup", 0.0) + (t_1 - t_0)      # (helper-thread seconds: diagnostics)
-        stage["group_read"] = stage.get("group_read", 0.0) + (t_2 - t_1)
-        if any(r is None for r in ok):
-            raise ValueError("calibration files of one batch have different shapes; set Quantity.file_batch = 1")
-        keep = [0] + [1 + j for j, r in enumerate(ok) if r]
-        if len(keep) == batch.shape[0]:
-            return batch
-        # unreadable files inside the group: close the gaps IN the staging slot (keep is ascending, so row i <= keep[i] and a
-        # front-to-back copy never overwrites a row it still needs) and hand out the head of the same slot.  The view must carry
-        # the slot: _device_items records the copy's event on it, and a compacted COPY (what this returned until round 4) left
-        # the slot marked "out" with no event -- the ring's seventh group then tripped the look-ahead assertion.
-        for i, k_ in enumerate(keep):
-            if i != k_:
-                batch[i].copy_(batch[k_])
-        out = batch[:len(keep)]
-        out._fq_slot = batch._fq_slot
-        return out
-
     def net_forward(self, net, image_path):
         img = image_path if torch.is_tensor(image_path) else self.preprocess(image_path)
         if self.device == "gpu" and img.device.type != "cuda":
@@ -464,94 +272,6 @@ class Quantity(object):
                 net(img)
             except _StopForward:
                 pass
-
-    # Host-resident batches (a DataLoader): the H2D copy of a batch is issued on a side stream from the generator below,
-    # i.e. when the loop asks for the NEXT item -- at which point the kernels of the current batch are enqueued but still
-    # running -- and the compute stream only waits for the copy's event.  False: plain `.cuda()` on the compute stream.
-    prefetch_inputs = True
-
-    def _device_items(self, images_files):
-        """(index, network input) for this rank's calibration items; host tensors are copied to the device ahead of the
-        compute stream (see prefetch_inputs).  Round 1 measured a helper-THREAD prefetcher with pinned staging buffers as
-        slower than a plain `.cuda()` (3 077-3 287 vs 4 232 images/s: the extra host memcpy and GIL traffic outweigh the
-        PCIe copy they hide); a side stream needs neither.
-
-        The copy only overlaps the previous batch's kernels for PINNED host tensors (a pageable source makes the copy
-        host-synchronous whatever the flag says).  For those nothing on the host waits for the DMA, so the source must
-        stay untouched until it is done: the copy's event is waited for before the iterable is asked for its next item --
-        a loader that refills one pinned staging buffer per batch would otherwise overwrite a batch still in flight."""
-        use_side = (self.prefetch_inputs and self.device == "gpu" and torch.cuda.is_available())
-        in_flight = None                                      # event of a copy whose pinned source is still being read
-        items = self._decoded_items(self._calibration_items(images_files))
-        kept = getattr(self, "_file_kept", None)
-        waits = self.__dict__.setdefault("input_wait_s", {"copy_done": 0.0, "decode": 0.0, "copy_issue": 0.0})
-        while True:
-            t_a = time.perf_counter()
-            if in_flight is not None:
-                in_flight.synchronize()
-                in_flight = None
-            t_b = time.perf_counter()
-            try:
-                i, img, is_group = next(items)
-            except StopIteration:
-                return
-            t_c = time.perf_counter()
-            waits["copy_done"] += t_b - t_a                   # (host seconds this loop spent waiting: diagnostics, Quantity.input_wait_s)
-            waits["decode"] += t_c - t_b
-            if img is None:                                   # a group of unreadable files
-                continue
-            if use_side and torch.is_tensor(img) and img.device.type != "cuda":
-                if getattr(self, "_copy_stream", None) is None:
-                    self._copy_stream = torch.cuda.Stream()
-                main = torch.cuda.current_stream()
-                with torch.cuda.stream(self._copy_stream):
-                    dev = img.cuda(non_blocking=True)
-                    slot = getattr(img, "_fq_slot", None)
-                    if slot is not None:                      # a staging buffer of this calibration: reused after this event
-                        slot["event"] = torch.cuda.Event()
-                        slot["event"].record(self._copy_stream)
-                        slot["out"] = False
-                    elif img.is_pinned():
-                        in_flight = torch.cuda.Event()
-                        in_flight.record(self._copy_stream)
-                main.wait_stream(self._copy_stream)
-                dev.record_stream(main)
-                img = dev
-                waits["copy_issue"] += time.perf_counter() - t_c
-                if is_group and kept is not None and i not in kept:
-                    nbytes = img.numel() * img.element_size()
-                    if self._file_kept_bytes + nbytes <= self.file_keep_bytes:
-                        kept[i] = img                         # pass 2 takes the batch from here instead of the files
-                        self._file_kept_bytes += nbytes
-            yield i, img
-
-    def _decoded_items(self, items):
-        """(index, decoded input, is a file group) for every calibration item.  File groups are decoded ONE GROUP AHEAD on
-        a helper thread (which fans the files out to the decode pool), so that reading the next batch's files runs beside
-        this thread's kernel launches for the current one; a group whose upload was kept in pass 1 is not read again."""
-        if not self._file_batching():
-            for i, item in items:
-                yield i, self.preprocess(item), False
-            return
-        import collections
-        from concurrent.futures import ThreadPoolExecutor
-        if getattr(self, "_group_pool", None) is None:
-            self._group_pool = ThreadPoolExecutor(max_workers=2)       # two groups in the making: their file reads overlap
-        kept = getattr(self, "_file_kept", None) or {}
-        pending = collections.deque()
-        it = iter(items)
-
-        def refill():
-            for i, item in it:
-                pending.append((i, None if i in kept else self._group_pool.submit(self.preprocess, item)))
-                return
-        refill()
-        refill()
-        refill()
-        while pending:
-            i, fut = pending.popleft()
-            refill()
-            yield i, (kept[i] if fut is None else fut.result()), True
 
     # ------------------------------------------------------------------------------------------
     # merge groups
@@ -603,455 +323,6 @@ class Quantity(object):
         # part of HBM the pool does not cover absorbs anything beyond that).
         warm = pooled - (total >> 4)
         return max(warm, 0)
-
-    def _patch_fused_convs(self, model):
-        """Instance-level forwards for the duration of a GPU calibration (undo: del module.forward; returns the patched modules):
-        every hooked nn.Conv2d with a bias leaves its work to its forward hook -- the whole convolution with the statistic in
-        the epilogue where common.quantity._float_conv takes the layer (1x1, R x S with zero padding, the 7x7/2 stem), else
-        convolution-without-bias here and fq_bias_add_absmax_f32 / fq_bias_add_hist_f32 in the hook; `Eltwise` likewise
-        (fq_add_absmax_f32 / fq_add_hist_f32); nn.MaxPool2d / a global nn.AvgPool2d run on fq_maxpool2d_f32 /
-        fq_avgpool_global_f32; an out-of-place nn.ReLU fed by one of the producers hands out the copy that producer wrote."""
-        patched = []
-        if not self.fuse_bias_absmax or "Conv2d" not in self._all_op_type or "Conv2d" not in self._cared_op_type:
-            return patched
-        ctl = self._hook_ctl
-        for m in model.modules():
-            if type(m) is not torch.nn.Conv2d or m.bias is None or m.padding_mode != "zeros" or "forward" in m.__dict__:
-                continue
-
-            def forward(x, m=m):
-                if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or m.weight.dtype != torch.float32
-                        or torch.is_grad_enabled()):
-                    return torch.nn.Conv2d.forward(m, x)
-                if ctl.own_plain:                    # per-channel calibration: the convolution only, statistics by its hooks
-                    own = _float_conv.kind(m, x) if self.own_conv1x1 else None
-                    if own is None:
-                        return torch.nn.Conv2d.forward(m, x)
-                    y = _float_conv.plain(m, own, x, check=ctl.own_plain != "unchecked")
-                    if ctl.poison is not None:
-                        y = ctl.poison.conv_done(m, y)
-                    return y
-                if ctl.fuse_collector is None or ctl.fuse_off:
-                    return torch.nn.Conv2d.forward(m, x)
-                if ctl.fuse_stat == "hist" and m not in ctl.fuse_verified:
-                    return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
-                own = _float_conv.kind(m, x) if self.own_conv1x1 else None
-                if own is None and m not in ctl.fuse_warm and not _flag(m, _FUSION_VERIFIED):
-                    ctl.fuse_warm.add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
-                    return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch
-                if own is not None:
-                    ctl.fuse_bias = (m, (own, x))        # the hook of this very call runs the whole convolution
-                    s, p, k = m.stride[0], m.padding[0], m.kernel_size
-                    return torch.empty((x.shape[0], m.out_channels, (x.shape[2] + 2 * p - k[0]) // s + 1,
-                                        (x.shape[3] + 2 * p - k[1]) // s + 1), dtype=torch.float32, device=x.device)
-                y = m._conv_forward(x, m.weight, None)
-                ctl.fuse_bias = (m, x)                   # the hook of this very call adds the bias
-                return y
-            m.forward = forward
-            patched.append(m)
-        if "Eltwise" in self._all_op_type and "Eltwise" in self._cared_op_type:
-            from common.quantity.fabu_layer import Eltwise
-            for m in model.modules():
-                if type(m) is not Eltwise or "forward" in m.__dict__:
-                    continue
-
-                def forward(x, y, m=m):
-                    if ctl.poison is not None:
-                        z = ctl.poison.eltwise(m, x, y)
-                        if z is not None:
-                            return z
-                    if (ctl.fuse_collector is None or ctl.fuse_off or torch.is_grad_enabled() or not torch.is_tensor(x)
-                            or not torch.is_tensor(y) or not x.is_cuda or x.dtype != torch.float32 or y.dtype != torch.float32
-                            or x.shape != y.shape or not x.is_contiguous() or not y.is_contiguous() or y.device != x.device
-                            or (ctl.fuse_stat == "hist" and m not in ctl.fuse_verified)):
-                        for t in (x, y):                        # (an operand whose convolution was left for this call)
-                            d = ctl.deferred.get(id(t)) if ctl.deferred else None
-                            if d is not None and d[0] is t:
-                                del ctl.deferred[id(t)]
-                                self._run_deferred(d)
-                        return Eltwise.forward(m, x, y)
-                    ctl.fuse_bias = (m, (x, y))          # the hook of this very call computes the sum (+ its abs-max)
-                    return torch.empty_like(x)
-                m.forward = forward
-                patched.append(m)
-        if self.own_pools:
-            def pair(v):
-                return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
-
-            def pool_active(x):
-                return ((ctl.own_plain or (ctl.fuse_collector is not None and not ctl.fuse_off)) and torch.is_tensor(x)
-                        and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
-                        and not torch.is_grad_enabled() and x.numel() < 2 ** 32 - 1)
-
-            def checked(m, cls, x, y):
-                if not _flag(m, _POOL_VERIFIED):           # once per process: the same bits as torch's kernel?
-                    ref = cls.forward(m, x)
-                    if not torch.equal(y, ref):
-                        _set_flag(m, _POOL_OFF)
-                        return ref
-                    _set_flag(m, _POOL_VERIFIED)
-                return y
-            for m in model.modules():
-                if "forward" in m.__dict__:
-                    continue
-                if type(m) is torch.nn.MaxPool2d:
-                    def forward(x, m=m):
-                        if (_flag(m, _POOL_OFF) or not pool_active(x) or pair(m.dilation) != (1, 1) or m.ceil_mode
-                                or m.return_indices):
-                            return torch.nn.MaxPool2d.forward(m, x)
-                        k, p = pair(m.kernel_size), pair(m.padding)
-                        st = pair(m.stride if m.stride is not None else m.kernel_size)
-                        return checked(m, torch.nn.MaxPool2d, x, _native.maxpool2d_f32(x, k, st, p))
-                    m.forward = forward
-                    patched.append(m)
-                elif type(m) is torch.nn.AvgPool2d:
-                    def forward(x, m=m):
-                        if (_flag(m, _POOL_OFF) or not pool_active(x) or pair(m.kernel_size) != tuple(x.shape[2:])
-                                or pair(m.padding) != (0, 0) or m.ceil_mode or m.divisor_override is not None
-                                or x.shape[2] * x.shape[3] > 144):
-                            return torch.nn.AvgPool2d.forward(m, x)
-                        return checked(m, torch.nn.AvgPool2d, x, _native.avgpool_global_f32(x))
-                    m.forward = forward
-                    patched.append(m)
-        # an out-of-place nn.ReLU fed directly by one of the modules above is served by that module's kernel
-        for m in model.modules():
-            if type(m) is not torch.nn.ReLU or m.inplace or "forward" in m.__dict__:
-                continue
-
-            def forward(x, m=m):
-                last, ready = ctl.last_out, ctl.relu_ready
-                if last is not None and last[1] is x:
-                    ctl.relu_after[last[0]] = m           # (re)learned on every call: who feeds this ReLU
-                if ctl.poison is not None:
-                    z = ctl.poison.relu(m, x)
-                    if z is not None:
-                        return z
-                if ready is not None and ready[0] is x and ready[2] is m and ready[3] == x._version:
-                    ctl.relu_ready = None                 # (same tensor object, not written to since)
-                    return ready[1]
-                return torch.nn.functional.relu(x)
-            m.forward = forward
-            patched.append(m)
-        return patched
-
-    def _finish_own_conv(self, module, m, kind, x, key, output):
-        """Forward-hook half of a convolution that runs on fq_conv1x1_f32 / fq_conv_stem_f32: `output` is the empty tensor
-        the patched forward returned.  Returns True when the statistic of `output` is done."""
-        ctl = self._hook_ctl
-        coll = ctl.fuse_collector
-        run = _float_conv.runner(m, kind, x)
-        if module is not m or coll is None or key is None:     # not a cared tensor: the convolution only
-            run(out=output)
-            return False
-        row = coll.row_of(key)
-        if ctl.fuse_stat == "hist":                         # pass 2 (verified in pass 1)
-            if (kind == "c1" and self.fuse_conv_add and not self.materialize_all and ctl.defer_ok.get(m) is not None
-                    and ctl.eager is not None):
-                ctl.deferred[id(output)] = (output, m, x, key, row, output._version, x._version)       # (see below)
-                return True
-            self._run_with_relu(m, output, lambda r, o: run(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row,
-                                                            relu_out=r, out=o), key)
-            ctl.hist_fused += 1
-            return True
-        ref = _float_conv.verified(m, run, x)                  # first use: against torch, once per process
-        if ref is not None:
-            output.copy_(ref)                                  # this module keeps the library convolution from now on
-            return False
-        ctl.fuse_verified.add(m)
-        if kind == "c1" and self.fuse_conv_add and ctl.defer_ok.get(m) is not None and ctl.eager is not None:
-            # its kernel runs inside the launch of the Eltwise that adds this tensor (_finish_deferred); until then `output`
-            # is an allocation nobody reads -- which the poison probe has shown for this model
-            ctl.deferred[id(output)] = (output, m, x, key, row, output._version, x._version)
-            return True
-        self._run_with_relu(m, output, lambda r, o: run(max_dev=coll.max_device, row=row, relu_out=r, out=o), key)
-        coll.note_max_refreshed()
-        ctl.own_conv1x1 = ctl.own_conv1x1 + 1
-        return True
-
-    def _run_deferred(self, d):
-        """A deferred convolution on its own after all (what its hook would have launched)."""
-        output, m, x, _key, row, _v, x_version = d
-        self._deferred_input_intact(x, x_version)
-        ctl = self._hook_ctl
-        coll = ctl.fuse_collector
-        if coll is None:
-            _float_conv.runner(m, "c1", x)(out=output)
-            return
-        if ctl.fuse_stat == "hist":
-            _float_conv.runner(m, "c1", x)(interval_dev=coll.interval_device, hist_dev=coll.hist_device, row=row, out=output)
-            ctl.hist_fused += 1
-        else:
-            _float_conv.runner(m, "c1", x)(max_dev=coll.max_device, row=row, out=output)
-            coll.note_max_refreshed()
-            ctl.own_conv1x1 = ctl.own_conv1x1 + 1
-        if ctl.eager is not None:
-            ctl.eager.note(_key, output)
-
-    @staticmethod
-    def _deferred_input_intact(x, x_version):
-        """A deferred convolution runs LATER than the model called it, on the input tensor it was called with.  The poison probe
-        runs the convolution at its own position, so a model that writes that input in place between the convolution and its
-        Eltwise is invisible to it -- the version counter is not: such a forward cannot be calibrated with the deferral."""
-        if x._version != x_version:
-            raise _native.FqError("the input of a 1x1 convolution was written in place between the convolution and the Eltwise "
-                                  "that consumes its output; the one-kernel residual tail cannot run on it: set "
-                                  "Quantity.fuse_conv_add = False (FQ_FUSE_CONV_ADD=0)")
-
-    def _finish_deferred(self, module, m, a, b, key, output):
-        """Hook half of an Eltwise one of whose operands is a deferred convolution: convolution + bias, that tensor's abs-max,
-        the sum, its abs-max and the ReLU behind it in one launch.  Returns True when done; False after running the
-        convolution alone (the Eltwise then takes its usual path)."""
-        ctl = self._hook_ctl
-        d = None
-        for t in (a, b):
-            e = ctl.deferred.get(id(t))
-            if e is not None and e[0] is t:
-                d = e
-                break
-        if d is None:
-            return False
-        del ctl.deferred[id(d[0])]
-        t3, conv, x, conv_key, conv_row, version, x_version = d
-        self._deferred_input_intact(x, x_version)
-        coll = ctl.fuse_collector
-        other = b if t3 is a else a
-        relu = ctl.relu_after.get(m) if self.fuse_relu else None
-        keep = lambda name: self.materialize_all or (ctl.keep_feats and (ctl.keep_names is None or name in ctl.keep_names))
-        keep_y, keep_s = keep(conv_key), keep(key) if key is not None else True
-        # (small planes with BOTH tensors kept: three store streams of partial lines make the one kernel slower than the two,
-        #  scripts/conv_add_bench.py: 356 vs 340 us at 14 x 14, 283 vs 276 at 7 x 7)
-        small = t3.shape[2] * t3.shape[3] < 28 * 28
-        hist = ctl.fuse_stat == "hist"
-        if (module is not m or coll is None or key is None or ctl.defer_ok.get(conv) is not m
-                or relu is None or not _flag(m, _FUSION_VERIFIED) or not _flag(m, _RELU_VERIFIED) or t3._version != version
-                or other is t3 or other.shape != t3.shape or not other.is_contiguous()
-                or (m not in ctl.fuse_verified if hist else (keep_y and keep_s and small))):
-            self._run_deferred(d)
-            return False
-        r = torch.empty_like(t3)
-        if hist:                                                # pass 2: both histograms, neither tensor written
-            _native.conv1x1_add_hist_f32(x, _float_conv.weight(conv, "c1"), conv.bias, conv.stride[0], other, coll.interval_device,
-                                         coll.hist_device, conv_row, coll.row_of(key), r)
-            ctl.hist_fused += 2
-            ctl.relu_ready = (output, r, relu, output._version)
-            ctl.fused_relus.add(relu)
-            ctl.deferred_hists += 1
-            return True
-        _native.conv1x1_add_f32(x, _float_conv.weight(conv, "c1"), conv.bias, conv.stride[0], other, coll.max_device, conv_row,
-                                coll.row_of(key), r, out=t3 if keep_y else None, sum_out=output if keep_s else None)
-        coll.note_max_refreshed()
-        if keep_y and ctl.eager is not None:
-            ctl.eager.note(conv_key, t3)                        # (what its own hook left out: the tensor exists only now)
-        ctl.fuse_verified.add(m)
-        ctl.relu_ready = (output, r, relu, output._version)
-        ctl.fused_relus.add(relu)
-        ctl.deferred_adds += 1
-        return True
-
-    def _wanted(self, key):
-        """Does anything of this calibration read the hooked tensor `key` of the running forward from HBM again?  (Pass 1: what
-        pass 2's cache keeps; pass 2: nothing.)"""
-        ctl = self._hook_ctl
-        if self.materialize_all:
-            return True
-        if ctl.fuse_stat == "hist":
-            return False
-        return ctl.keep_feats and (ctl.keep_names is None or key in ctl.keep_names)
-
-    def _run_with_relu(self, m, output, run, key=None):
-        """run(relu_out, out) launches m's fused kernel (out: where the module's own output goes).  When an out-of-place
-        nn.ReLU is known to consume `output` directly, the kernel writes that ReLU's result as well and the patched ReLU.forward
-        hands it out instead of launching -- and when that ReLU is PROVEN to be the only reader of `output` (relu_only_ok) and
-        pass 2 does not want the tensor, `output` itself is not written (out = False)."""
-        ctl = self._hook_ctl
-        relu = ctl.relu_after.get(m) if self.fuse_relu else None
-        if relu is None:
-            run(None, output)
-            return
-        r = torch.empty_like(output)
-        skip = (key is not None and self.skip_unread_outputs and m in ctl.relu_only_ok and _flag(m, _RELU_VERIFIED)
-                and ctl.eager is not None and not self._wanted(key))
-        run(r, False if skip else output)
-        if skip:
-            ctl.skipped_outputs += 1
-        if not _flag(m, _RELU_VERIFIED):              # once per process: the same bits as torch's ReLU?
-            if not torch.equal(r, torch.nn.functional.relu(output)):
-                self.fuse_relu = False
-                return
-            _set_flag(m, _RELU_VERIFIED)
-        ctl.relu_ready = (output, r, relu, output._version)      # holds the tensor itself: identity, not a reusable id
-        ctl.fused_relus.add(relu)
-
-    def _finish_fused_conv(self, module, pending, key, output):
-        """Forward-hook half of the fused conv: add the bias (and take the abs-max when the tensor is a cared one).
-        Returns True when the statistics of `output` are done."""
-        m, x = pending
-        ctl = self._hook_ctl
-        coll = ctl.fuse_collector
-        if isinstance(x, tuple) and isinstance(x[0], str):  # a convolution on fq_conv1x1_f32 / fq_conv_stem_f32: output is still empty
-            return self._finish_own_conv(module, m, x[0], x[1], key, output)
-        if isinstance(x, tuple):                            # Eltwise: output is an empty tensor waiting for x + y
-            a, b = x
-            if ctl.deferred and self._finish_deferred(module, m, a, b, key, output):
-                return True
-            if module is not m or coll is None or key is None:
-                torch.add(a, b, out=output)
-                return False
-            row = coll.row_of(key)
-            if ctl.fuse_stat == "hist":                  # pass 2 (verified in pass 1): the sum, histogrammed on the way out
-                self._run_with_relu(m, output, lambda r, _o: _native.add_hist(a, b, coll.interval_device, coll.hist_device, row,
-                                                                              out=output, relu_out=r))
-                ctl.hist_fused += 1
-                return True
-            if not _flag(m, _FUSION_VERIFIED):        # first use: the kernel against torch.add, once per process
-                scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
-                z = _native.add_absmax(a, b, scratch, 0)
-                want = torch.add(a, b)
-                if not (torch.equal(z, want) and float(scratch[0]) == float(want.abs().max())):
-                    ctl.fuse_off = True
-                    output.copy_(want)
-                    return False
-                _set_flag(m, _FUSION_VERIFIED)
-            ctl.fuse_verified.add(m)
-            self._run_with_relu(m, output, lambda r, _o: _native.add_absmax(a, b, coll.max_device, row, out=output, relu_out=r))
-            coll.note_max_refreshed()
-            return True
-        if module is not m or coll is None or key is None or not output.is_contiguous() or output.dim() < 2:
-            output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))     # what torch does
-            return False
-        row = coll.row_of(key)
-        if ctl.fuse_stat == "hist":                      # pass 2 (verified in pass 1)
-            self._run_with_relu(m, output, lambda r, _o: _native.bias_add_hist(output, m.bias, coll.interval_device,
-                                                                               coll.hist_device, row, relu_out=r))
-            ctl.hist_fused += 1
-            return True
-        if m in ctl.fuse_verified or _flag(m, _FUSION_VERIFIED):
-            ctl.fuse_verified.add(m)
-            self._run_with_relu(m, output, lambda r, _o: _native.bias_add_absmax(output, m.bias, coll.max_device, row, relu_out=r))
-            coll.note_max_refreshed()
-            return True
-        # First fused use of this module (its second batch).  Two things are checked once per module:
-        #   * the kernel itself: on the same convolution result it must leave exactly torch's `raw + bias` and that
-        #     tensor's maximum;
-        #   * the decomposition: torch's own forward must equal convolution-without-bias + bias bit for bit -- on layers
-        #     where torch's forward is reproducible at all (MIOpen's Winograd kernels for some 3x3 shapes are not: two
-        #     identical calls differ in the last bit, so there is nothing bitwise to compare against).
-        ref = torch.nn.Conv2d.forward(m, x)
-        raw = m._conv_forward(x, m.weight, None)
-        want = raw + m.bias.view(1, -1, *([1] * (raw.dim() - 2)))
-        scratch = torch.zeros(1, dtype=torch.float32, device=output.device)
-        _native.bias_add_absmax(raw, m.bias, scratch, 0)
-        kernel_ok = torch.equal(raw, want) and float(scratch[0]) == float(want.abs().max())
-        reproducible = torch.equal(ref, torch.nn.Conv2d.forward(m, x))
-        if kernel_ok and (torch.equal(raw, ref) or not reproducible):
-            ctl.fuse_verified.add(m)
-            _set_flag(m, _FUSION_VERIFIED)             # a property of (module, MIOpen, this library): checked once per process
-            _native.bias_add_absmax(output, m.bias, coll.max_device, row)
-            coll.note_max_refreshed()
-            return True
-        ctl.fuse_off = True                              # never silently different: torch's add, statistics as usual
-        output.add_(m.bias.view(1, -1, *([1] * (output.dim() - 2))))
-        return False
-
-    def _training_state_modules(self):
-        """Modules whose forward in training mode changes state or draws random numbers: anything in training mode that owns
-        buffers (BatchNorm's running statistics) or is a dropout layer.  (A parameter-free module left in training mode --
-        e.g. the Identity that merge_bn puts in a BatchNorm's place -- does not count.)"""
-        from torch.nn.modules.dropout import _DropoutNd
-        return [m for m in self.model.modules()
-                if m.training and (isinstance(m, _DropoutNd) or next(m.buffers(recurse=False), None) is not None)]
-
-    def _probe_forward(self, own_plain, deferral=None):
-        """One forward of the model on a random input of INPUT_SHAPE with the hooks watching for in-place consumers; returns
-        whether a hooked tensor was written to after its hook ran.  The reference feeds its models random input exactly
-        once, in build_net_structure (pytorch_quantizer.py:21-62); this additional draw comes from a generator of its own,
-        so the global RNG stream a user script sees afterwards is the reference's."""
-        ctl = self._hook_ctl
-        probe = _EagerStats(lambda tensors: None, _AFTER_FORWARD)
-        saved = ctl.own_plain
-        ctl.eager, ctl.own_plain, ctl.poison = probe, own_plain, deferral
-        self._probe_out = None
-        try:
-            dev = self._model_device(self.model)
-            gen = torch.Generator(device=dev)
-            gen.manual_seed(0x5eed)
-            shapes = [self.input_size] if isinstance(self.input_size, tuple) else list(self.input_size)
-            with torch.no_grad():
-                self._probe_out = self.model(*[torch.rand(*s_, device=dev, generator=gen) for s_ in shapes])
-        finally:
-            ctl.eager, ctl.own_plain, ctl.poison = None, saved, None
-        return bool(probe.modified())
-
-    @staticmethod
-    def _only_our_hook(m):
-        """Nobody but this calibration's own forward hook watches module m."""
-        import torch.nn.modules.module as _mod
-        return (len(m._forward_hooks) <= 1 and not m._forward_pre_hooks and not _mod._global_forward_hooks
-                and not _mod._global_forward_pre_hooks)
-
-    def _prove_deferral(self, probe, first_feats, first_out):
-        """After the learning probe forward: pick the (1x1 convolution, Eltwise, ReLU) chains fq_conv1x1_add_f32 can take and the
-        (convolution, ReLU) chains whose convolution output nobody else reads, run the poison forward (_DeferralProbe) and
-        return ({conv: Eltwise}, {conv}) when it changes nothing, else ({}, set())."""
-        ctl = self._hook_ctl
-        cared = set(self.net_info.keys())
-        for elt, conv in (probe.pairs.items() if self.fuse_conv_add else ()):
-            relu = ctl.relu_after.get(elt)
-            if (relu is None or probe.keys.get(conv) not in cared or probe.keys.get(elt) not in cared
-                    or conv.kernel_size != (1, 1) or conv.padding != (0, 0)
-                    or not _native.conv1x1_add_f32_supported(conv.in_channels, conv.out_channels)
-                    or not (self._only_our_hook(conv) and self._only_our_hook(elt) and self._only_our_hook(relu))
-                    or conv in probe.candidates):
-                continue
-            probe.candidates[conv] = (elt, relu)
-        for (_y, conv) in (probe.conv_out.values() if self.skip_unread_outputs else ()):
-            relu = ctl.relu_after.get(conv)
-            if (relu is None or conv in probe.candidates or probe.keys.get(conv) not in cared
-                    or not (self._only_our_hook(conv) and self._only_our_hook(relu))):
-                continue
-            probe.relu_only[conv] = relu
-        # keepers (code that stores one of these tensors and reads it after the forward: invisible to the poison): whoever still
-        # refers to a convolution's output or to a sum now that the learning forward has returned, and is not this calibration
-        ours = [probe.conv_out, probe.outputs, first_feats, self._probe_feats, ctl.last_out, ctl.relu_ready] + list(probe.conv_out.values())
-        out_of = dict((conv, y) for (y, conv) in probe.conv_out.values())
-        self.deferral_refused = {}
-        for conv in list(probe.candidates) + list(probe.relu_only):
-            watched = [out_of.get(conv)]
-            if conv in probe.candidates:
-                watched.append(probe.outputs.get(probe.candidates[conv][0]))           # the sum, as the model's code holds it
-            kept = [h for t in watched if torch.is_tensor(t) for h in probe.holders(t, ours + [out_of, watched])]
-
-            if kept:
-                self.deferral_refused[probe.keys.get(conv)] = kept
-                probe.candidates.pop(conv, None)
-                probe.relu_only.pop(conv, None)
-        del out_of
-        if not probe.candidates and not probe.relu_only:
-            return {}, set()
-        probe.mode = "poison"
-        named = self._probe_feats
-        named.clear()
-        self._probe_forward("unchecked", probe)
-        skip = probe.poisoned_keys()
-
-        def same(u, v):
-            if not (torch.is_tensor(u) and torch.is_tensor(v)) or u.shape != v.shape or u.dtype != v.dtype:
-                return False
-            if u.dtype == torch.float32:
-                return torch.equal(u.contiguous().view(torch.int32), v.contiguous().view(torch.int32))
-            return torch.equal(u, v)
-        ok = set(first_feats) == set(named)
-        for k, t in first_feats.items():
-            if not ok:
-                break
-            if k not in skip:
-                ok = same(t, named[k])
-        if ok and torch.is_tensor(first_out):
-            ok = same(first_out, self._probe_out)
-        self._probe_out = None
-        if not ok:
-            return {}, set()
-        return {conv: pair[0] for conv, pair in probe.candidates.items()}, set(probe.relu_only)
 
     def _forward_with_stats(self, item, fn, named_feats, extra=None):
         """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced and

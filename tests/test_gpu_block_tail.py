@@ -56,6 +56,9 @@ CASES = [
     (1, 1, 1, 64, 128, 64, torch.int16, (4, 5, 4), 9, 10, True, True, True, True),       # one pixel
     (3, 7, 7, 256, 1024, 0, torch.int16, (4, 5, 4), 10, 0, True, False, True, True),     # stage-3 shape: eight slices, 256-byte weight rows
     (2, 5, 5, 256, 384, 0, torch.int8, (3, 4, 4), 11, 0, False, False, True, False),
+    (23, 56, 56, 64, 256, 64, torch.int16, (4, 5, 4), 9, 10, True, True, True, False),   # 564 tiles: more than two per CU
+    (9, 56, 56, 64, 256, 0, torch.int8, (4, 4, 4), 9, 0, True, False, True, True),
+    (5, 33, 31, 64, 128, 64, torch.int16, (4, 5, 4), 9, 10, True, True, True, True),     # K3 = 128: one slice per tile
 ]
 
 

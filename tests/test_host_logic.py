@@ -284,7 +284,7 @@ def test_image_file_input_mode(tmp_path):
 def test_eager_stats_groups_launches_and_notices_inplace_consumers():
     """tools.pytorch_quantizer._EagerStats (host logic of the in-hook statistics launches) on CPU tensors."""
     import torch
-    from tools.pytorch_quantizer import _AFTER_FORWARD, _EagerStats
+    from tools._hook_state import _AFTER_FORWARD, _EagerStats
     calls = []
     fn = lambda tensors: calls.append(list(tensors))
     a, b, c = torch.ones(100), torch.ones(100), torch.ones(100)
