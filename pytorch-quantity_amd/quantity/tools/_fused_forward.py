@@ -462,17 +462,20 @@ class _FusedForward(object):
         ours = [probe.conv_out, probe.outputs, first_feats, self._probe_feats, ctl.last_out, ctl.relu_ready] + list(probe.conv_out.values())
         out_of = dict((conv, y) for (y, conv) in probe.conv_out.values())
         self.deferral_refused = {}
+        watch = {}                                             # conv -> the tensors of its chain that would stay un-written
         for conv in list(probe.candidates) + list(probe.relu_only):
-            watched = [out_of.get(conv)]
+            watch[conv] = [out_of.get(conv)]
             if conv in probe.candidates:
-                watched.append(probe.outputs.get(probe.candidates[conv][0]))           # the sum, as the model's code holds it
-            kept = [h for t in watched if torch.is_tensor(t) for h in probe.holders(t, ours + [out_of, watched])]
-
+                watch[conv].append(probe.outputs.get(probe.candidates[conv][0]))           # the sum, as the model's code holds it
+        every = [t for ts in watch.values() for t in ts]
+        held = probe.holders(every, ours + [out_of, watch, every] + list(watch.values()))
+        for conv, ts in watch.items():
+            kept = [h for t in ts if torch.is_tensor(t) for h in held.get(id(t), ())]
             if kept:
                 self.deferral_refused[probe.keys.get(conv)] = kept
                 probe.candidates.pop(conv, None)
                 probe.relu_only.pop(conv, None)
-        del out_of
+        del out_of, watch, every
         if not probe.candidates and not probe.relu_only:
             return {}, set()
         probe.mode = "poison"

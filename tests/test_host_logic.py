@@ -330,3 +330,34 @@ def test_float_conv_dispatch_declines_what_the_kernels_do_not_take():
             assert torch.equal(_float_conv.call(conv, x), conv(x))
         h.remove()
         assert len(seen) == 2 and "forward" not in conv.__dict__ and not _float_conv.is_verified(conv)
+
+
+def test_deferral_probe_finds_keepers_of_a_tensor_in_one_heap_pass():
+    """tools._hook_state._DeferralProbe.holders (host logic, CPU tensors): whoever still refers to a watched tensor and is not one
+    of the calibration's own containers -- a module attribute, a user's list, a view -- is reported against that tensor; clean
+    tensors are not; and the scan is ONE gc pass for all tensors (a pass per tensor cost 0.4 s of a 0.5 s calibration)."""
+    import time
+    import torch
+    from tools._hook_state import _DeferralProbe
+
+    class Holder(object):
+        pass
+    clean, stashed, listed, viewed = (torch.zeros(4, 4) for _ in range(4))
+    ours = {"a": clean, "b": stashed, "c": listed, "d": viewed}         # what the calibration itself keeps
+    user, user_list = Holder(), []
+    user.feat = stashed
+    user_list.append(listed)
+    view = viewed[:2]
+    every = [clean, stashed, listed, viewed]
+    got = _DeferralProbe.holders(every, [ours, every])
+    assert id(clean) not in got
+    assert got[id(stashed)] == ["a dict"] and got[id(listed)] == ["a list"] and got[id(viewed)] == ["a view of it"]
+    del view
+    many = [torch.zeros(2) for _ in range(64)]
+    t0 = time.perf_counter()
+    assert _DeferralProbe.holders(many, [many]) == {}
+    one_pass = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for t in many[:8]:
+        _DeferralProbe.holders([t], [many])
+    assert one_pass < (time.perf_counter() - t0) * 2                     # 64 tensors in one pass: cheaper than 16 single scans
