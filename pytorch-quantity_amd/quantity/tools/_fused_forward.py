@@ -459,23 +459,39 @@ class _FusedForward(object):
             probe.relu_only[conv] = relu
         # keepers (code that stores one of these tensors and reads it after the forward: invisible to the poison): whoever still
         # refers to a convolution's output or to a sum now that the learning forward has returned, and is not this calibration
-        ours = [probe.conv_out, probe.outputs, first_feats, self._probe_feats, ctl.last_out, ctl.relu_ready] + list(probe.conv_out.values())
+        # (cheap first: a tensor nobody else holds has exactly the reference count of a CONTROL tensor put into the same containers
+        #  of this calibration; only tensors that exceed it -- normally none -- are looked up in the heap, which costs tens of ms)
+        import sys
+        ctl.last_out = ctl.relu_ready = None                   # stale after the forward; they would count as holders
         out_of = dict((conv, y) for (y, conv) in probe.conv_out.values())
+        c_conv, c_sum = torch.empty(1), torch.empty(1)
+        probe.conv_out[id(c_conv)] = (c_conv, None)             # a convolution's output sits in these three containers ...
+        probe.outputs["control conv"], out_of["control conv"] = c_conv, c_conv
+        probe.outputs["control sum"] = c_sum                    # ... an Eltwise's in this one
+        base_conv, base_sum = sys.getrefcount(c_conv), sys.getrefcount(c_sum)
+        del probe.conv_out[id(c_conv)], probe.outputs["control conv"], out_of["control conv"], probe.outputs["control sum"]
         self.deferral_refused = {}
-        watch = {}                                             # conv -> the tensors of its chain that would stay un-written
+        watch, suspects = {}, []                               # conv -> the tensors of its chain that would stay un-written
         for conv in list(probe.candidates) + list(probe.relu_only):
-            watch[conv] = [out_of.get(conv)]
-            if conv in probe.candidates:
-                watch[conv].append(probe.outputs.get(probe.candidates[conv][0]))           # the sum, as the model's code holds it
-        every = [t for ts in watch.values() for t in ts]
-        held = probe.holders(every, ours + [out_of, watch, every] + list(watch.values()))
+            y = out_of.get(conv)
+            s_ = probe.outputs.get(probe.candidates[conv][0]) if conv in probe.candidates else None     # the sum, as the model holds it
+            watch[conv] = (y, s_)
+            if torch.is_tensor(y) and (sys.getrefcount(y) - 1 > base_conv or y._use_count() > 1):       # (- 1: `watch` holds it too)
+                suspects.append(y)
+            if torch.is_tensor(s_) and (sys.getrefcount(s_) - 1 > base_sum or s_._use_count() > 1):
+                suspects.append(s_)
+        held = {}
+        if suspects:
+            ours = [probe.conv_out, probe.outputs, first_feats, self._probe_feats, out_of, watch, suspects]
+            ours += list(probe.conv_out.values()) + list(watch.values())
+            held = probe.holders(suspects, ours)
         for conv, ts in watch.items():
             kept = [h for t in ts if torch.is_tensor(t) for h in held.get(id(t), ())]
             if kept:
                 self.deferral_refused[probe.keys.get(conv)] = kept
                 probe.candidates.pop(conv, None)
                 probe.relu_only.pop(conv, None)
-        del out_of, watch, every
+        del out_of, watch, suspects
         if not probe.candidates and not probe.relu_only:
             return {}, set()
         probe.mode = "poison"
