@@ -141,12 +141,17 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
         // fused NewAdd: the residual groups this thread will need are requested FIRST, so that their latency
         // hides under the tail arithmetic and the LDS transpose below instead of sitting in front of the stores
         // (the operand-fragment registers are dead here, so this costs no occupancy)
+        // Store layout: WAVE-LOCAL since round 4 -- item j of a lane is (pixel wave * 32 + (lane + 64 j) / CPP, 16-channel group
+        // (lane + 64 j) % CPP), i.e. a wave reads back only the 32 rows of sO it wrote itself.  LDS instructions of one wave execute
+        // in order, so the barrier that used to separate the tail's writes from these reads is gone.  (Measured neutral here:
+        // 2.831 vs 2.843 ms per 256-image forward, profiles/r04_int8_layer_table_b256*.txt -- the barrier in front of the tail,
+        // which the aliasing of sO with the operand tiles needs, still keeps a workgroup's waves in step.)
         v4i_r res_lo[NJ], res_hi[NJ];
         if (kOut & kOutAdd) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int idx = tid + kConvBlock * j;
-                const int pix = idx / CPP, ch = idx - pix * CPP;
+                const int idx = lane + 64 * j;
+                const int pix = wave * 32 + idx / CPP, ch = idx % CPP;
                 const int mm = m0 + pix, kk = k0 + 16 * ch;
                 const bool live = mm < p.M && kk < p.Kpad;
                 const long off = live ? (long)mm * p.Kpad + kk : 0;
@@ -174,11 +179,10 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
                 *reinterpret_cast<unsigned*>(&sO[prow + a * 32 + 8 * g]) = pack4(v[0], v[1], v[2], v[3]);
             }
         }
-        __syncthreads();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int idx = tid + kConvBlock * j;
-            const int pix = idx / CPP, ch = idx - pix * CPP;
+            const int idx = lane + 64 * j;
+            const int pix = wave * 32 + idx / CPP, ch = idx % CPP;
             const int mm = m0 + pix, kk = k0 + 16 * ch;
             if (mm < p.M && kk < p.Kpad) {
                 const long off = (long)mm * p.Kpad + kk;
