@@ -105,10 +105,37 @@ __device__ __forceinline__ void red_advance(RedPos& q, int delta, int c16, int S
 // (r&3) + 8*(r>>2) + 4*half, D col = this lane's pixel (wave*32 + lane&31 of the 128-pixel tile).  The tail
 // runs in integer arithmetic when the host proved it equivalent (kIntTail), else as the reference's fp32
 // chain.  sO: >= kTP * (TK + 16) bytes of LDS that no wave reads any more (the weight buffers).
+// The residual operand of a fused NewAdd for one thread of the store layout (16 channels of NJ pixels).  Plain registers handed
+// around BY REFERENCE (a first attempt at requesting them early passed a pointer chosen at run time between two such structs,
+// which put both into scratch memory and doubled the launch times).
+template <int TK>
+struct ResRegs {
+    static constexpr int NJ = (kTP * (TK / 16)) / kConvBlock;
+    v4i_r lo[NJ], hi[NJ];
+};
+template <int TK>
+__device__ __forceinline__ void load_residual(ResRegs<TK>& r, const ConvParams& p, int lane, int wave, int m0, int k0) {
+    constexpr int CPP = TK / 16;
+#pragma unroll
+    for (int j = 0; j < ResRegs<TK>::NJ; ++j) {
+        const int idx = lane + 64 * j;
+        const int pix = wave * 32 + idx / CPP, ch = idx % CPP;
+        const int mm = m0 + pix, kk = k0 + 16 * ch;
+        const bool live = mm < p.M && kk < p.Kpad;
+        const long off = live ? (long)mm * p.Kpad + kk : 0;
+        if (p.res_bytes == 1) {
+            r.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
+        } else {
+            r.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
+            r.hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
+        }
+    }
+}
+
 template <int TK, int kOut, bool kIntTail>
 __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvParams& p, float* __restrict__ y,
                                               int8_t* __restrict__ q, int8_t* sO, const float* sBias, const int* sBiasI, int m0,
-                                              int k0, int n_img, int pq, bool m_ok, int tid_base = 0) {
+                                              int k0, int n_img, int pq, bool m_ok, ResRegs<TK>& res, int tid_base = 0) {
     constexpr int MT = TK / 32;
     // (tid_base: a 512-thread workgroup runs this once per 256-thread half, each on its own 128-pixel tile and its own sO)
     const int tid = (int)threadIdx.x - tid_base, lane = tid & 63, wave = tid >> 6, half = lane >> 5;
@@ -146,23 +173,8 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
         // in order, so the barrier that used to separate the tail's writes from these reads is gone.  (Measured neutral here:
         // 2.831 vs 2.843 ms per 256-image forward, profiles/r04_int8_layer_table_b256*.txt -- the barrier in front of the tail,
         // which the aliasing of sO with the operand tiles needs, still keeps a workgroup's waves in step.)
-        v4i_r res_lo[NJ], res_hi[NJ];
-        if (kOut & kOutAdd) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int idx = lane + 64 * j;
-                const int pix = wave * 32 + idx / CPP, ch = idx % CPP;
-                const int mm = m0 + pix, kk = k0 + 16 * ch;
-                const bool live = mm < p.M && kk < p.Kpad;
-                const long off = live ? (long)mm * p.Kpad + kk : 0;
-                if (p.res_bytes == 1) {
-                    res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
-                } else {
-                    res_lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
-                    res_hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
-                }
-            }
-        }
+        static_assert(NJ == ResRegs<TK>::NJ, "store layout");
+        if constexpr ((kOut & kOutAdd) != 0 && (kOut & kOutResEarly) == 0) load_residual<TK>(res, p, lane, wave, m0, k0);
         __syncthreads();                                  // every wave is done reading the operand tiles
         const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
 #pragma unroll
@@ -195,11 +207,11 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
                     int8_t* nd = q ? q + off : nullptr;
                     if (p.res_bytes == 1) {
                         Vec16<int8_t> rv;
-                        rv.a = res_lo[j];
+                        rv.a = res.lo[j];
                         add_resident_16(cv, rv, wd, nd, p.ap);
                     } else {
                         Vec16<int16_t> rv;
-                        rv.a = res_lo[j]; rv.b = res_hi[j];
+                        rv.a = res.lo[j]; rv.b = res.hi[j];
                         add_resident_16(cv, rv, wd, nd, p.ap);
                     }
                 } else {
@@ -384,6 +396,13 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
 
     const int nsteps = (p.chunks + 7) >> 3;
     load_step();
+    ResRegs<TK> res;
+    if constexpr ((kOut & kOutResEarly) != 0) {
+        // the fused NewAdd's residual tile (32 KB per workgroup) requested behind the first K-step's operand loads -- vmcnt retires
+        // in issue order, so the operands are not held up -- its latency then runs beside the LDS staging and the MFMAs
+        load_residual<TK>(res, p, lane, wave, m0, k0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     store_a(0);
     v4i fb[4];
 #pragma unroll
@@ -419,10 +438,8 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
     }
 
     static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the int8 output tile is staged in the weight buffers");
-    // (measured and rejected, round 4: the fused add's residual requested behind the first K-step's operand loads instead of at
-    //  the head of the epilogue: 333 -> 374 us on 64 -> 256 @56x56 from HBM, 170 -> 190 on 128 -> 512 @28x28)
-    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
-    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, res);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, res);
 }
 
 // ---- C % 128 == 0, K % TK == 0: both operands by LDS-DMA ----------------------------------------------
@@ -644,8 +661,9 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     TR(3);
 
     static_assert(kTP * (TK + 16) <= STAGES * TK * BKB, "the int8 output tile is staged in the weight buffers");
-    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
-    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok);
+    ResRegs<TK> res;
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, res);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, res);
     TR(4);
 }
 
@@ -840,8 +858,9 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_halo_kernel(const int8_
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
         if (u) __syncthreads();                               // the epilogue stages its int8 tile in sA: one half after the other
-        if (p.rs) conv_epilogue<TK, kOut, true>(acc[u], p, y, q, sA, sBias, sBiasI, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u]);
-        else conv_epilogue<TK, kOut, false>(acc[u], p, y, q, sA, sBias, sBiasI, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u]);
+        ResRegs<TK> res;
+        if (p.rs) conv_epilogue<TK, kOut, true>(acc[u], p, y, q, sA, sBias, sBiasI, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u], res);
+        else conv_epilogue<TK, kOut, false>(acc[u], p, y, q, sA, sBias, sBiasI, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u], res);
     }
 }
 
@@ -1006,8 +1025,9 @@ __global__ __launch_bounds__(2 * kConvBlock) void conv3x3_i8_halo8_kernel(const 
     // each half stages its int8 tile in its own LDS: the first in the weight buffers, the second in the slab
     static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the first half's int8 tile is staged in the weight buffers");
     int8_t* const sO = u ? sSlab : sA;
-    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, m0 + kTP * u, k0, n_img, pq, m_ok, u * kConvBlock);
-    else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, m0 + kTP * u, k0, n_img, pq, m_ok, u * kConvBlock);
+    ResRegs<TK> res;
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, m0 + kTP * u, k0, n_img, pq, m_ok, res, u * kConvBlock);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, m0 + kTP * u, k0, n_img, pq, m_ok, res, u * kConvBlock);
 }
 
 // ---- 3 x 3, stride 1, padding 1, C == 64, K <= 64 (the first stage of a ResNet): weights stationary, persistent -------
@@ -1112,8 +1132,9 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
                 }
             }
         }
-        if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok);
-        else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok);
+        ResRegs<TK> res;
+        if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok, res);
+        else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok, res);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next slab has landed (mine) ...
         __syncthreads();                                      // ... and everybody's; everybody is done with this tile's slab and staging
         buf ^= 1;
@@ -1398,6 +1419,11 @@ static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const i
                              int8_t* q, const ConvParams& p0) {
     const ConvParams p = xcd_order(grid, p0);
     note_conv_variant(kPath == kPathC128 ? kVarTileC128 : (kPath == kPathC64 ? kVarTileC64 : kVarTileGeneral), TK);
+    // (kOutResEarly -- the residual requested behind the first K-step's operand loads -- is kept in the kernel as a template flag
+    //  and NOT instantiated: measured twice in round 4, the second time without the scratch traffic that spoilt the first, it is
+    //  slower everywhere inside the network at 256 images: 86 -> 97 us on the 28 x 28 tail, 63.6 -> 74.5 on the 14 x 14 ones,
+    //  38.8 -> 41.6 at 7 x 7; 333 -> 374 us on the 56 x 56 tail from HBM.  The burst of 32 KB per workgroup ahead of the other
+    //  resident workgroups' operand requests delays THEIR matrix work by more than it saves this one.)
     if (p.res)
         hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutI8 | kOutAdd>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
     else if (y && q)

@@ -79,6 +79,7 @@ __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >>
 // kOut: bit 0 = fp32 NCHW output y (the module-boundary format), bit 1 = int8 NHWC output q (the
 // resident hand-off to the next integer layer: 1 byte per element instead of 4 written + 4 read + 1).
 constexpr int kOutF32 = 1, kOutI8 = 2, kOutAdd = 4;      // kOutAdd: with kOutI8, NewAdd fused into the store
+constexpr int kOutResEarly = 8;                          // with kOutAdd (register-staged kernel): the residual is requested behind the first K-step's operand loads
 
 // fq_conv1x1_i8.hip: true when the streaming kernel took the launch (p is complete except xcd_kt / tiles_m)
 bool launch_conv1x1_stream(hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y, int8_t* q,
