@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """GPU: fq_conv1x1_f32 (FQ_ONE_KIND=kxk: fq_conv_kxk_f32 3x3 padding 1; =stem: fq_conv_stem_f32 7x7 stride 2 on 3 channels) on
-one layer shape, for rocprofv3.  usage: conv1x1_one.py Cin Cout H stride batch [max|hist|none] [reps]"""
+one layer shape, for rocprofv3.  usage: conv1x1_one.py Cin Cout H stride batch [max|hist|none|add|addhist|addkeep] [reps]
+(add / addhist: fq_conv1x1_add_f32 / fq_conv1x1_add_hist_f32, the residual tail in one kernel, nothing kept; addkeep: both tensors kept)"""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,8 +33,20 @@ y = torch.empty(B, cout, ho, ho, device="cuda")
 mx = torch.zeros(1, device="cuda")
 iv = torch.full((1,), 8.0 / 2048, device="cuda")
 hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
+res = torch.randn(B, cout, ho, ho, device="cuda") if mode.startswith("add") else None
+relu = torch.empty(B, cout, ho, ho, device="cuda") if mode.startswith("add") else None
+mx2 = torch.zeros(2, device="cuda")
+iv2 = torch.full((2,), 8.0 / 2048, device="cuda")
+hist2 = torch.zeros(2, 2048, dtype=torch.int64, device="cuda")
+ysum = torch.empty(B, cout, ho, ho, device="cuda") if mode == "addkeep" else None
 for _ in range(reps):
-    if mode == "max":
+    if mode == "add":
+        _native.conv1x1_add_f32(x, wt, bias, s, res, mx2, 0, 1, relu)
+    elif mode == "addkeep":
+        _native.conv1x1_add_f32(x, wt, bias, s, res, mx2, 0, 1, relu, out=y, sum_out=ysum)
+    elif mode == "addhist":
+        _native.conv1x1_add_hist_f32(x, wt, bias, s, res, iv2, hist2, 0, 1, relu)
+    elif mode == "max":
         conv(max_dev=mx, row=0, out=y)
     elif mode == "hist":
         conv(interval_dev=iv, hist_dev=hist, row=0, out=y)
