@@ -373,9 +373,11 @@ int fq_conv2d_i8_add_resident(const int8_t* x_nhwc, const int8_t* w_krsc, const 
  * w1_krsc int8 [C2][K3], qbias1 fp32 [C2], rs1, relu1, q1_nhwc int8 [M][C2]: the next conv1 (its input bit is `ib`);
  *   C2 = 0 (w1 / qbias1 / q1 NULL): conv3 + NewAdd alone.
  * 1x1, stride 1, no padding: spatial shape does not matter, M = N * H * W pixels.
- * fq_block_tail_i8_supported: 1 for C in {64, 128}, K3 in {128 .. 512} a multiple of 128, C2 in {0, 64, 128}, shifts in
- * 1 .. 16 (the integer tails); fq_block_tail_i8 returns FQ_ERR_UNSUPPORTED otherwise and callers keep the two launches. */
-int fq_block_tail_i8_supported(int C, int K3, int C2, int rs3, int rs1);
+ * fq_block_tail_i8_supported: 1 for C in {64, 128, 256}, K3 in {128 .. 1024} a multiple of 128, C2 in {0, 64, 128} (0 only behind
+ * C = 256) and shifts in 1 .. 16 (the integer tails); the grids (ob3, g_res, res_bytes, ib) are part of the query so that a later
+ * kernel may specialise on them -- today every grid fq_conv2d_i8_add_resident takes is taken.  fq_block_tail_i8 returns
+ * FQ_ERR_UNSUPPORTED otherwise and callers keep the two launches. */
+int fq_block_tail_i8_supported(int C, int K3, int C2, int rs3, int rs1, int ob3, int g_res, int res_bytes, int ib);
 int fq_block_tail_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, const float* qbias3, int rs3, int ob3, const void* res,
                      int res_bytes, int g_res, int16_t* wide, int g_wide, int8_t* narrow, int ib, int relu,
                      const int8_t* w1_krsc, const float* qbias1, int rs1, int relu1, int8_t* q1_nhwc, long M, int C, int K3,

@@ -95,18 +95,23 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
     }
 
     // ---- weight slices: global -> registers (one slice ahead) -> LDS
+    // (everything below addresses memory through buffer descriptors: a 32-bit per-lane offset that is fixed for the tile's life plus
+    //  a scalar slice offset -- 64-bit per-lane pointers for three output streams, the shortcut and two weight matrices were 40
+    //  registers of loop invariants, and with the next conv1's 64 accumulators alive that meant spills)
+    const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(w3), 0, (unsigned)(p.K3 * C), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(w1), 0, (unsigned)(C2 * p.K3), 0x00020000);
     v4i r3[W3_LOADS], r1[W1_LOADS];
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < W3_LOADS; ++j) {
             const int i = tid + kConvBlock * j, row = i / (C / 16), c = i % (C / 16);
-            r3[j] = *reinterpret_cast<const v4i*>(w3 + ((long)(kt * 128 + row) * C + c * 16));
+            r3[j] = load_act(w3r, (unsigned)(row * C + c * 16) + (unsigned)(kt * 128 * C));
         }
         if constexpr (kNext) {
 #pragma unroll
             for (int j = 0; j < W1_LOADS; ++j) {
                 const int i = tid + kConvBlock * j, row = i >> 3, c = i & 7;
-                r1[j] = *reinterpret_cast<const v4i*>(w1 + ((long)row * p.K3 + kt * 128 + c * 16));
+                r1[j] = load_act(w1r, (unsigned)(row * p.K3 + c * 16) + (unsigned)(kt * 128));
             }
         }
     };
@@ -155,54 +160,67 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
     // ahead: 171 / 193 / 148.  These launches run within 20-35 % of what HBM delivers; what is left is not request latency.)
     struct Res { v4i_r lo[4], hi[kRes16 ? 4 : 1]; };
     Res res;
+    // element offset of (pixel of store item j, first channel of this lane's 16-channel group) in an [M][K3] tensor; beyond the last
+    // pixel: out of range for every descriptor below (loads give zeros, stores are dropped)
+    const unsigned total = (unsigned)p.M * (unsigned)p.K3;
+    unsigned o_el[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + s_pix + 8 * j;
+        // (0x40000000: beyond M x K3 < 2^30 elements -- host check -- and still beyond the int16 tensors' byte count when doubled)
+        o_el[j] = m < p.M ? (unsigned)m * (unsigned)p.K3 + (unsigned)(16 * s_ch) : 0x40000000u;
+    }
+    const __amdgpu_buffer_rsrc_t resr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, total * (kRes16 ? 2u : 1u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t wider = __builtin_amdgcn_make_buffer_rsrc(p.wide, 0, p.wide ? 2u * total : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t narr = __builtin_amdgcn_make_buffer_rsrc(p.narrow, 0, p.narrow ? total : 0u, 0x00020000);
+#pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
         const int k0 = kt * 128;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = m0 + s_pix + 8 * j;
-            const long off = m < p.M ? (long)m * p.K3 + k0 + 16 * s_ch : 0;
             if constexpr (kRes16) {
-                res.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
-                res.hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
+                res.lo[j] = (v4i_r)load_act(resr, 2u * o_el[j] + (unsigned)(2 * k0));
+                res.hi[j] = (v4i_r)load_act(resr, 2u * o_el[j] + (unsigned)(2 * k0 + 16));
             } else {
-                res.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
+                res.lo[j] = (v4i_r)load_act(resr, o_el[j] + (unsigned)k0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
 
         // ---- conv3, this slice: 32 pixels x 128 channels per wave, 64 channels (two accumulator tiles) at a time -- RightShift +
         // BiasAdd + Sp of the first half runs while the second half's accumulators do not exist yet (32 registers fewer)
+        constexpr int PT = 2;
 #pragma unroll
-        for (int hs = 0; hs < 2; ++hs) {
-            v16i acc[2];
+        for (int hs = 0; hs < 4 / PT; ++hs) {
+            v16i acc[PT];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < PT; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][r] = 0;
 #pragma unroll
             for (int ks = 0; ks < KS3; ++ks) {
 #pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    const v4i fa = *reinterpret_cast<const v4i*>(&sW3[(2 * hs + a) * 32 * C + a3_off[ks]]);
+                for (int a = 0; a < PT; ++a) {
+                    const v4i fa = *reinterpret_cast<const v4i*>(&sW3[(PT * hs + a) * 32 * C + a3_off[ks]]);
                     acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[ks], acc[a], 0, 0, 0);
                 }
             }
             // 4 channels = one dword into this lane's own row of the tile
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < PT; ++a) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     int v[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const int kl = (2 * hs + a) * 32 + e + 8 * g + 4 * half;
+                        const int kl = (PT * hs + a) * 32 + e + 8 * g + 4 * half;
                         v[e] = conv_tail_i(acc[a][4 * g + e], sBias3[k0 + kl], p.t3);
                     }
-                    const int byte = (2 * hs + a) * 32 + 8 * g + 4 * half;          // channel of v[0] inside the slice
+                    const int byte = (PT * hs + a) * 32 + 8 * g + 4 * half;          // channel of v[0] inside the slice
                     *reinterpret_cast<unsigned*>(my_row + (((byte >> 4) ^ my_swz) * 16) + (byte & 15)) = pack4(v[0], v[1], v[2], v[3]);
+                    __builtin_amdgcn_sched_barrier(0);        // four values at a time: left alone the scheduler runs all 32 tails abreast
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
         // ---- NewAdd (+ ReLU + the consumers' Quantity) on 16 channels of one pixel per lane; rows of this wave only
 #pragma unroll
@@ -221,15 +239,13 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
                 rv.a = res.lo[j];
                 o = add_resident_16_regs(cv, rv, p.wide != nullptr, true, p.ap);
             }
-            const int m = m0 + pix;
-            if (m < p.M) {
-                const long off = (long)m * p.K3 + k0 + 16 * s_ch;
-                if (p.wide) {
-                    *reinterpret_cast<v4i_r*>(p.wide + off) = o.w0;
-                    *reinterpret_cast<v4i_r*>(p.wide + off + 8) = o.w1;
-                }
-                if (p.narrow) *reinterpret_cast<v4i_r*>(p.narrow + off) = o.n;
-            }
+            // (an output nobody wants has a descriptor of zero records: its stores are dropped in the address unit.  The slice offset
+            //  rides in the VECTOR offset: a 16-byte buffer store with a scalar-offset register is the store hipcc does not pad against
+            //  a write of its data registers on gfx950)
+            const unsigned ov = o_el[j] + (unsigned)k0;
+            __builtin_amdgcn_raw_buffer_store_b128((v4u)o.w0, wider, (int)(2u * ov), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((v4u)o.w1, wider, (int)(2u * ov + 16u), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128((v4u)o.n, narr, (int)ov, 0, 0);
             if constexpr (kNext) *reinterpret_cast<v4i_r*>(cell) = o.n;
             __builtin_amdgcn_sched_barrier(0);                // one pixel group at a time: interleaving the four inflates the live set
         }
@@ -273,12 +289,13 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
             }
         }
         constexpr int CPP = C2 / 16, PPI = 64 / CPP;          // 16-byte groups per pixel, pixels per store instruction
+        const __amdgpu_buffer_rsrc_t q1r = __builtin_amdgcn_make_buffer_rsrc(q1, 0, (unsigned)p.M * (unsigned)C2, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 32 / PPI; ++j) {
             const int pix = wave * 32 + PPI * j + lane / CPP, ch = lane % CPP;
             const v4i_r o = *reinterpret_cast<const v4i_r*>(sN + pix * 128 + ((ch ^ swz_of<128>(pix)) * 16));
             const int m = m0 + pix;
-            if (m < p.M) *reinterpret_cast<v4i_r*>(q1 + (long)m * C2 + 16 * ch) = o;
+            __builtin_amdgcn_raw_buffer_store_b128((v4u)o, q1r, m < p.M ? (int)((unsigned)m * (unsigned)C2 + (unsigned)(16 * ch)) : (int)kOutOfRange, 0, 0);
         }
     }
 }
@@ -305,19 +322,20 @@ void launch_bt(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w3, con
 
 using namespace fq;
 
-extern "C" int fq_block_tail_i8_supported(int C, int K3, int C2, int rs3, int rs1) {
+extern "C" int fq_block_tail_i8_supported(int C, int K3, int C2, int rs3, int rs1, int ob3, int g_res, int res_bytes, int ib) {
     if (!(C == 64 || C == 128 || C == 256) || K3 < 128 || K3 > 1024 || (K3 & 127)) return 0;
     if (!(C2 == 0 || C2 == 64 || C2 == 128) || (C == 256 && C2 != 0)) return 0;
     if (rs3 < 1 || rs3 > 16 || (C2 && (rs1 < 1 || rs1 > 16))) return 0;
-    return 1;
+    (void)ob3; (void)g_res; (void)ib;                     // every grid fq_conv2d_i8_add_resident takes (packed, 32-bit and fp32 forms of NewAdd)
+    return (res_bytes == 1 || res_bytes == 2) ? 1 : 0;
 }
 
 extern "C" int fq_block_tail_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, const float* qbias3, int rs3, int ob3, const void* res,
                                 int res_bytes, int g_res, int16_t* wide, int g_wide, int8_t* narrow, int ib, int relu,
                                 const int8_t* w1_krsc, const float* qbias1, int rs1, int relu1, int8_t* q1_nhwc, long M, int C,
                                 int K3, int C2, fq_stream_t stream) {
-    if (M < 0 || !fq_block_tail_i8_supported(C, K3, C2, rs3, rs1)) return FQ_ERR_UNSUPPORTED;
     if (!res || (res_bytes != 1 && res_bytes != 2)) return FQ_ERR_INVALID_ARG;
+    if (M < 0 || !fq_block_tail_i8_supported(C, K3, C2, rs3, rs1, ob3, g_res, res_bytes, ib)) return FQ_ERR_UNSUPPORTED;
     if (M == 0) return FQ_OK;
     if (!x_nhwc || !w3_krsc || !qbias3 || (C2 && (!w1_krsc || !qbias1 || !q1_nhwc)) || (!C2 && !wide && !narrow)) return FQ_ERR_INVALID_ARG;
     if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w3_krsc) | reinterpret_cast<uintptr_t>(res) |

@@ -129,7 +129,7 @@ def lib():
     L.fq_conv2d_i8_add_resident.restype = ci
     L.fq_conv2d_i8_add_resident.argtypes = [vp, vp, vp, vp, ci, ci, vp, ci, vp, ci, ci, ci] + [ci] * 15 + [vp]
     L.fq_block_tail_i8_supported.restype = ci
-    L.fq_block_tail_i8_supported.argtypes = [ci] * 5
+    L.fq_block_tail_i8_supported.argtypes = [ci] * 9
     L.fq_block_tail_i8.restype = ci
     L.fq_block_tail_i8.argtypes = [vp, vp, vp, ci, ci, vp, ci, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, ctypes.c_long, ci, ci, ci, vp]
     L.fq_add_resident.restype = ci
@@ -852,8 +852,10 @@ def conv2d_i8_add_resident(xq, wq, qbias, stride, padding, dilation, rs, ob, res
     return wide, narrow
 
 
-def block_tail_supported(C, K3, C2, rs3, rs1):
-    return bool(lib().fq_block_tail_i8_supported(int(C), int(K3), int(C2), int(rs3), int(rs1)))
+def block_tail_supported(C, K3, C2, rs3, rs1, ob3, g_res, res_bytes, ib):
+    """Does fq_block_tail_i8 take this chain?  (shapes, integer tails, and grids for which NewAdd's packed-int16 form holds)"""
+    return bool(lib().fq_block_tail_i8_supported(int(C), int(K3), int(C2), int(rs3), int(rs1), int(ob3), int(g_res), int(res_bytes),
+                                                 int(ib)))
 
 
 def block_tail_i8(xq, w3q, qbias3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1q=None, qbias1=None, rs1=0,

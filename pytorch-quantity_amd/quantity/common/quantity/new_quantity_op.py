@@ -355,6 +355,9 @@ class NewAdd(nn.Module):
         return out
 
 
+_BT_ALONE_MAX_C = int(os.environ.get("FQ_BT_ALONE_MAX_C", "64"))     # conv3 + NewAdd WITHOUT a next conv1 on fq_block_tail_i8 up to this width
+
+
 def _block_tail_on():
     return os.environ.get("FQ_BLOCK_TAIL", "1") != "0"
 
@@ -375,8 +378,9 @@ def _newadd_fused_conv_add(self, plan, x, y):
     nxt = plan.fuse_next
     one = tuple(tuple(int(v) for v in g) for g in d.geom) == ((1, 1), (0, 0), (1, 1)) and tuple(d.wq.shape[1:3]) == (1, 1)
     if (nxt is None and one and tuple(h.exact.shape[:3]) == tuple(d.xq.shape[:3]) and _block_tail_on()
-            and d.xq.shape[-1] == 64 and _native.block_tail_supported(64, L.Conv.out_channels, 0, L.rs_bit, 0)
-            and L.Conv.out_channels == d.wq.shape[0]):
+            and d.xq.shape[-1] <= _BT_ALONE_MAX_C and L.Conv.out_channels == d.wq.shape[0]
+            and _native.block_tail_supported(d.xq.shape[-1], L.Conv.out_channels, 0, L.rs_bit, 0, L.output_bit, h.grid, h.exact.element_size(),
+                                             plan.narrow_bit if want_narrow else plan.grid - 1)):
         # conv3 + NewAdd alone on the same kernel (no next convolution to fuse) for the 64-channel stage, whose tensors come from
         # HBM: its barrier-free, wave-local epilogue streams them 1.5-1.6 x faster than the general kernel's when nothing is
         # cache resident (scripts/block_tail_probe.py), 6 % faster inside the network.  Deeper stages live in the Infinity
@@ -391,7 +395,9 @@ def _newadd_fused_conv_add(self, plan, x, y):
         # operand, staged in LDS, and reaches HBM only if somebody else reads it too
         np_ = nxt.__dict__.get("_resident")
         w1 = nxt._packed_weight(nxt.Conv)
-        if np_ is not None and w1.shape[-1] == L.Conv.out_channels:
+        if (np_ is not None and w1.shape[-1] == L.Conv.out_channels
+                and _native.block_tail_supported(d.xq.shape[-1], L.Conv.out_channels, nxt.Conv.out_channels, L.rs_bit, nxt.rs_bit,
+                                                 L.output_bit, h.grid, h.exact.element_size(), plan.narrow_bit)):
             wide, narrow, q1 = _native.block_tail_i8(d.xq, d.wq, L.quantized_bias, L.rs_bit, L.output_bit, h.exact, h.grid, True,
                                                      plan.grid, plan.narrow_to_hbm, plan.narrow_bit, plan.relu, w1,
                                                      nxt.quantized_bias, nxt.rs_bit, np_.relu)

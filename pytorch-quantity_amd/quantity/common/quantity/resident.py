@@ -478,6 +478,9 @@ def enable(model, example_input, verify=True):
             continue
         e, _relu = eff_of[id(v)]
         conv3 = operands[add_mod][plan.fuse_arg].producer
+        other = fmt.get(id(operands[add_mod][1 - plan.fuse_arg]))            # (bytes, grid) of the shortcut
+        if other is None:
+            continue
         readers = [c for (c, _pos) in e.consumers if conv_can_read(c)]
         nxt = None
         for c in readers:
@@ -489,7 +492,8 @@ def enable(model, example_input, verify=True):
                     and tuple(conv3.Conv.padding) == (0, 0) and c.input_bit == plan.narrow_bit
                     and conv3.Conv.out_channels == k.in_channels
                     and _native.block_tail_supported(conv3.Conv.in_channels, conv3.Conv.out_channels, k.out_channels,
-                                                     conv3.rs_bit, c.rs_bit)):
+                                                     conv3.rs_bit, c.rs_bit, conv3.output_bit, other[1], other[0],
+                                                     plan.narrow_bit)):
                 nxt = c
                 break
         if nxt is not None:

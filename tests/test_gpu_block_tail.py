@@ -62,13 +62,23 @@ CASES = [
 ]
 
 
+UNSUPPORTED_GRIDS = []          # (every grid the two launches take is taken: packed, 32-bit and fp32 forms of NewAdd)
+
+
 @pytest.mark.parametrize("case", CASES, ids=lambda c: "%dx%dx%d_%dto%dto%d_%s" % (c[0], c[1], c[2], c[3], c[4], c[5], str(c[6])[-5:]))
 def test_block_tail_equals_the_two_launches_it_replaces(nat, case):
     N, H, W, C, K3, C2, res_dtype, (ob3, g_res, ib), rs3, rs1, relu, relu1, want_wide, want_narrow = case
     x, w3, b3, res, w1, b1 = _operands(nat, N, H, W, C, K3, C2, res_dtype, seed=N * 1000 + K3 + C2)
     g_wide = max(0, ob3, g_res)
-    assert nat.block_tail_supported(C, K3, C2, rs3, rs1)
+    rb = 2 if res_dtype == torch.int16 else 1
     ref = _two_launches(nat, x, w3, b3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1, relu1)
+    if not nat.block_tail_supported(C, K3, C2, rs3, rs1, ob3, g_res, rb, ib):
+        # grids outside NewAdd's packed-int16 form: the kernel refuses, callers keep the two launches (which take every grid)
+        assert case in UNSUPPORTED_GRIDS
+        with pytest.raises(nat.FqError):
+            nat.block_tail_i8(x, w3, b3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1, relu1)
+        return
+    assert case not in UNSUPPORTED_GRIDS
     nat.conv_variant_log = log = {}
     try:
         got = nat.block_tail_i8(x, w3, b3, rs3, ob3, res, g_res, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1, relu1)
@@ -107,11 +117,14 @@ def test_block_tail_against_the_oracle_chain(nat, oracle):
 
 def test_block_tail_argument_errors(nat):
     L = nat.lib()
-    assert L.fq_block_tail_i8_supported(64, 256, 64, 9, 10) == 1
-    assert L.fq_block_tail_i8_supported(256, 1024, 256, 9, 10) == 0          # no fused next conv behind 256 -> 1024
-    assert L.fq_block_tail_i8_supported(256, 1024, 0, 9, 0) == 1 and L.fq_block_tail_i8_supported(512, 2048, 0, 9, 0) == 0
-    assert L.fq_block_tail_i8_supported(64, 192, 64, 9, 10) == 0             # K3 not a multiple of 128
-    assert L.fq_block_tail_i8_supported(64, 256, 64, 0, 10) == 0             # no integer tail
+    ok = (4, 5, 2, 4)                                                        # ob3, g_res, int16 shortcut, ib: the packed add's grids
+    assert L.fq_block_tail_i8_supported(64, 256, 64, 9, 10, *ok) == 1
+    assert L.fq_block_tail_i8_supported(256, 1024, 256, 9, 10, *ok) == 0     # no fused next conv behind 256 -> 1024
+    assert L.fq_block_tail_i8_supported(256, 1024, 0, 9, 0, *ok) == 1 and L.fq_block_tail_i8_supported(512, 2048, 0, 9, 0, *ok) == 0
+    assert L.fq_block_tail_i8_supported(64, 192, 64, 9, 10, *ok) == 0        # K3 not a multiple of 128
+    assert L.fq_block_tail_i8_supported(64, 256, 64, 0, 10, *ok) == 0        # no integer tail
+    assert L.fq_block_tail_i8_supported(64, 256, 64, 9, 10, 5, 5, 2, 5) == 1  # k = 0: the 32-bit form of the add
+    assert L.fq_block_tail_i8_supported(64, 256, 64, 9, 10, 5, 4, 3, 4) == 0  # a 3-byte shortcut
     x = torch.zeros(1, 1, 1, 64, dtype=torch.int8, device="cuda")
     assert L.fq_block_tail_i8(x.data_ptr(), x.data_ptr(), x.data_ptr(), 9, 4, None, 2, 5, None, 5, None, 4, 1, None, None, 0, 0, None,
                               1, 64, 256, 0, None) == -1                      # no shortcut
