@@ -116,19 +116,20 @@ struct ResRegs {
 template <int TK>
 __device__ __forceinline__ void load_residual(ResRegs<TK>& r, const ConvParams& p, int lane, int wave, int m0, int k0) {
     constexpr int CPP = TK / 16;
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.res), 0, p.out_elems * (unsigned)p.res_bytes, 0x00020000);
 #pragma unroll
     for (int j = 0; j < ResRegs<TK>::NJ; ++j) {
         const int idx = lane + 64 * j;
         const int pix = wave * 32 + idx / CPP, ch = idx % CPP;
         const int mm = m0 + pix, kk = k0 + 16 * ch;
-        const bool live = mm < p.M && kk < p.Kpad;
-        const long off = live ? (long)mm * p.Kpad + kk : 0;
-        if (p.res_bytes == 1) {
-            r.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int8_t*>(p.res) + off);
-        } else {
-            r.lo[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off);
-            r.hi[j] = *reinterpret_cast<const v4i_r*>(static_cast<const int16_t*>(p.res) + off + 8);
-        }
+        // (element offset in the [M][Kpad] tensors, 32 bits -- M x Kpad < 2^30, host check; 0x40000000 is out of range for the
+        //  int8 descriptor and, doubled, for the int16 ones: such loads give zeros, such stores are dropped)
+        const unsigned o = (mm < p.M && kk < p.Kpad) ? (unsigned)mm * (unsigned)p.Kpad + (unsigned)kk : 0x40000000u;
+        // (both halves always: for an int8 shortcut the second request is out of range -- zeros, no traffic -- so that the struct is
+        //  fully defined on every path and stays in registers)
+        const bool wide_res = p.res_bytes != 1;
+        r.lo[j] = (v4i_r)load_act(rr, wide_res ? 2u * o : o);
+        r.hi[j] = (v4i_r)load_act(rr, wide_res ? 2u * o + 16u : kOutOfRange);
     }
 }
 
@@ -189,34 +190,41 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
                                     : (int)conv_tail_int(acc[a][4 * g + e], sBias[kl], p);
                 }
                 *reinterpret_cast<unsigned*>(&sO[prow + a * 32 + 8 * g]) = pack4(v[0], v[1], v[2], v[3]);
+                if (kOut & kOutAdd) __builtin_amdgcn_sched_barrier(0);   // four tails at a time beside the residual registers (fq_block_tail_i8.hip)
             }
         }
+        // outputs through buffer descriptors (an output nobody wants: zero records, its stores are dropped); the 16-byte stores keep
+        // the scalar offset the immediate 0 (the store hazard hipcc does not pad on gfx950)
+        const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(q, 0, q ? p.out_elems : 0u, 0x00020000);
+        const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(p.wide, 0, ((kOut & kOutAdd) && p.wide) ? 2u * p.out_elems : 0u, 0x00020000);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int idx = lane + 64 * j;
             const int pix = wave * 32 + idx / CPP, ch = idx % CPP;
             const int mm = m0 + pix, kk = k0 + 16 * ch;
-            if (mm < p.M && kk < p.Kpad) {
-                const long off = (long)mm * p.Kpad + kk;
-                if (kOut & kOutAdd) {
-                    // NewAdd (+ ReLU + the consumers' Quantity) on the tile while it is in flight: the conv's
-                    // int8 result never reaches HBM; 16 channels per thread
-                    Vec16<int8_t> cv;
-                    cv.a = *reinterpret_cast<const v4i_r*>(&sO[pix * OS + 16 * ch]);
-                    int16_t* wd = p.wide ? p.wide + off : nullptr;
-                    int8_t* nd = q ? q + off : nullptr;
-                    if (p.res_bytes == 1) {
-                        Vec16<int8_t> rv;
-                        rv.a = res.lo[j];
-                        add_resident_16(cv, rv, wd, nd, p.ap);
-                    } else {
-                        Vec16<int16_t> rv;
-                        rv.a = res.lo[j]; rv.b = res.hi[j];
-                        add_resident_16(cv, rv, wd, nd, p.ap);
-                    }
+            const unsigned o = (mm < p.M && kk < p.Kpad) ? (unsigned)mm * (unsigned)p.Kpad + (unsigned)kk : 0x40000000u;
+            if (kOut & kOutAdd) {
+                // NewAdd (+ ReLU + the consumers' Quantity) on the tile while it is in flight: the conv's
+                // int8 result never reaches HBM; 16 channels per thread
+                Vec16<int8_t> cv;
+                cv.a = *reinterpret_cast<const v4i_r*>(&sO[pix * OS + 16 * ch]);
+                auto emit = [&](const Add16Out& out) {
+                    __builtin_amdgcn_raw_buffer_store_b128((v4u)out.w0, wr, (int)(2u * o), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((v4u)out.w1, wr, (int)(2u * o + 16u), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128((v4u)out.n, qr, (int)o, 0, 0);
+                };
+                if (p.res_bytes == 1) {
+                    Vec16<int8_t> rv;
+                    rv.a = res.lo[j];
+                    emit(add_resident_16_regs(cv, rv, p.wide != nullptr, q != nullptr, p.ap));
                 } else {
-                    *reinterpret_cast<v4i*>(q + off) = *reinterpret_cast<const v4i*>(&sO[pix * OS + 16 * ch]);
+                    Vec16<int16_t> rv;
+                    rv.a = res.lo[j]; rv.b = res.hi[j];
+                    emit(add_resident_16_regs(cv, rv, p.wide != nullptr, q != nullptr, p.ap));
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const v4u*>(&sO[pix * OS + 16 * ch]), qr, (int)o, 0, 0);
             }
         }
     }
@@ -1583,6 +1591,8 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     p.slo = (int)p.lo; p.shi = (int)p.hi;
     p.Kpad = (q_nhwc || fa.res) ? Kpad : 0;
     p.res = fa.res; p.res_bytes = fa.res_bytes; p.wide = fa.wide; p.ap = fa.ap;
+    if ((q_nhwc || fa.res) && (long)M * Kpad >= 0x3fffffffL) return FQ_ERR_UNSUPPORTED;     // 32-bit element offsets into the [M][Kpad] tensors
+    p.out_elems = (q_nhwc || fa.res) ? (unsigned)((long)M * Kpad) : 0u;
     p.x_bytes = (unsigned)((long)N * H * W * C);
     p.w_bytes = (unsigned)((long)K * R * S * C);
     hipStream_t st = as_stream(stream);

@@ -23,6 +23,7 @@ struct ConvParams {
     float inv_rs, inv_ob, lo, hi;        // 2^-rs, 2^-ob, clamp range (lo = 0 when a ReLU is fused)
     int ilo, ihi;
     int Kpad;                            // channel stride of the int8 NHWC output (>= K, multiple of 16)
+    unsigned out_elems;                  // M * Kpad: elements of the int8 output / the fused add's residual and sum tensors
     unsigned x_bytes;                    // N * H * W * C: num_records of the activation buffer descriptor
     int rs, half_rs, slo, shi;           // integer tail: shift, 2^(rs-1), Sp range; rs = 0 selects the fp32 tail
     unsigned w_bytes;                    // K * R * S * C: num_records of the weight buffer descriptor
