@@ -344,7 +344,9 @@ int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias,
  *   y_nchw (may be NULL): fp32 [N][K][P][Q] as fq_conv2d_i8
  *   q_nhwc (may be NULL): int8 [N][P][Q][Kpad], the integer BEFORE DeQuantity,
  *                         clamp(RightShift(acc, rs) + qbias[k]) = Quantity(y, ib = ob); channels [K, Kpad) = 0;
- *                         Kpad >= K, Kpad % 16 == 0, 16-byte aligned
+ *                         Kpad >= K, Kpad % 16 == 0, 16-byte aligned; N * P * Q * Kpad < 2^30 elements (32-bit offsets
+ *                         into the integer tensors, also for the residual / sum of fq_conv2d_i8_add_resident:
+ *                         FQ_ERR_UNSUPPORTED beyond)
  *   relu != 0: a following nn.ReLU is fused into both outputs (max(., 0) commutes with the scale 2^-ob).
  * bitwidth is 8.  At least one output must be given. */
 int fq_conv2d_i8_resident(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw,
