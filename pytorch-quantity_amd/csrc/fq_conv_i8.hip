@@ -133,7 +133,7 @@ __device__ __forceinline__ void load_residual(ResRegs<TK>& r, const ConvParams& 
     }
 }
 
-template <int TK, int kOut, bool kIntTail>
+template <int TK, int kOut, bool kIntTail, bool kStageAliased = true>
 __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvParams& p, float* __restrict__ y,
                                               int8_t* __restrict__ q, int8_t* sO, const float* sBias, const int* sBiasI, int m0,
                                               int k0, int n_img, int pq, bool m_ok, ResRegs<TK>& res, int tid_base = 0) {
@@ -176,7 +176,9 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
         // which the aliasing of sO with the operand tiles needs, still keeps a workgroup's waves in step.)
         static_assert(NJ == ResRegs<TK>::NJ, "store layout");
         if constexpr ((kOut & kOutAdd) != 0 && (kOut & kOutResEarly) == 0) load_residual<TK>(res, p, lane, wave, m0, k0);
-        __syncthreads();                                  // every wave is done reading the operand tiles
+        // sO aliases the operand tiles in every kernel but the stationary-weight one: every wave must be done reading them.
+        // (kStageAliased = false: sO is the caller's own region, a wave only ever touches its own 32 rows of it -- no barrier)
+        if constexpr (kStageAliased) __syncthreads();
         const int prow = (wave * 32 + (lane & 31)) * OS + 4 * half;
 #pragma unroll
         for (int a = 0; a < MT; ++a) {
@@ -1141,8 +1143,8 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
             }
         }
         ResRegs<TK> res;
-        if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok, res);
-        else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok, res);
+        if (p.rs) conv_epilogue<TK, kOut, true, false>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok, res);
+        else conv_epilogue<TK, kOut, false, false>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok, res);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next slab has landed (mine) ...
         __syncthreads();                                      // ... and everybody's; everybody is done with this tile's slab and staging
         buf ^= 1;
