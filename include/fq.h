@@ -238,6 +238,25 @@ int fq_conv_kxk_f32(const float* x, const float* wt, const float* bias, float* y
                     int Win, int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval,
                     int64_t* hist_row, void* workspace, size_t workspace_bytes, fq_stream_t stream);
 
+/* The stride-1, pad-1 3x3 convolutions of the same forward as Winograd F(2x2, 3x3) on the fp32 matrix cores: 16 products per
+ * 2x2 output tile, input channel and output channel instead of 36 (fq_conv_kxk_f32's direct sum), the transforms fused into
+ * the kernel, same epilogue contract as fq_conv1x1_f32 (bias, relu_out, y may be NULL with relu_out given, exactly one of
+ * {max_inout, hist_row + interval} or neither).  Replaces, inside the float forward the reference runs at
+ * pytorch_quantizer.py:288-296, torch's Conv2d for these layers (whose library kernels are Winograd forms as well).
+ * u: the weights transformed and packed by fq_conv3x3_wino_f32_pack -- fq_conv3x3_wino_f32_packed_floats(Cin, Cout) floats,
+ *   16-byte aligned, U = G g Gt computed in fp64 and rounded once, laid out [ci / 8][position 0..15][ci % 2][co][ci % 8 / 2];
+ *   w_kcrs: fp32 [Cout][Cin][3][3] on the device.
+ * x: fp32 [N][Cin][H][W], y / relu_out: fp32 [N][Cout][H][W]; Cin % 8 == 0, Cout % 64 == 0, x and y below 2^31 BYTES
+ *   (fq_conv3x3_wino_f32_supported; FQ_ERR_UNSUPPORTED otherwise: callers keep fq_conv_kxk_f32 there).
+ * Numerics: per output an fmaf chain over ci = 0 .. Cin-1 for each of the 16 positions, the fixed additions of the output
+ *   transform, then the bias: deterministic, independent of N (no tail split, no workspace), NOT the direct sum -- it differs
+ *   from fq_conv_kxk_f32 by a few units in the last place of the LARGEST term (tests/test_gpu_conv_wino.py states the bound). */
+int fq_conv3x3_wino_f32_supported(int N, int Cin, int Hin, int Win, int Cout);
+size_t fq_conv3x3_wino_f32_packed_floats(int Cin, int Cout);
+int fq_conv3x3_wino_f32_pack(const float* w_kcrs, float* u, int Cin, int Cout, fq_stream_t stream);
+int fq_conv3x3_wino_f32(const float* x, const float* u, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin,
+                        int Win, int Cout, float* max_inout, const float* interval, int64_t* hist_row, fq_stream_t stream);
+
 /* The float stem convolution of the calibration forward (ResNet-50/101's conv1: 7x7, stride 2, 3 -> Cout <= 64 channels,
  * any padding) on the fp32 matrix cores, same epilogue contract as fq_conv1x1_f32 (bias, relu_out, and exactly one of
  * {max_inout, hist_row + interval} or neither).  wp: the weights PACKED as fp32 [fq_conv_stem_f32_packed_rows()][64],

@@ -1,0 +1,438 @@
+// fq_conv_wino_f32.hip -- the stride-1 3x3 convolutions of the float calibration forward as Winograd F(2x2, 3x3) on the
+// fp32 matrix cores, with the calibration's statistic taken in the epilogue (the contract of fq_conv_kxk_f32).
+//
+// Why.  The 3x3 layers are 7.9 of the 18.8 ms of a pass-1 forward of ResNet-50 at 256 images, and the direct kernel
+// (fq_conv1x1_f32.hip, R x S form) already runs them at 117-127 of the 157 TFLOP/s the fp32 MFMA has: what is left is
+// the number of multiplications.  F(2x2, 3x3) computes a 2x2 output tile from a 4x4 input tile with 16 multiplications
+// per (input channel, output channel) instead of 36:
+//     Y = At [ sum_c (G g_c Gt) .* (Bt d_c B) ] A
+// -- 16 independent GEMMs  M_e[k][t] = sum_c U_e[c][k] V_e[c][t]  (e = the 16 positions of the transformed tile, k = output
+// channel, t = tile), between an input transform (32 additions per tile and channel) and an output transform (24 per
+// tile and output channel).
+//
+// Mapping.  Workgroup = 4 waves = 64 output channels x 64 tiles (tiles are numbered through the whole batch:
+// t = (n * TH + ty) * TW + tx, so a 7x7 plane costs its 4x4 tiles and nothing else); a wave owns 32 x 32 of it for ALL
+// 16 positions: 16 accumulator tiles of v_mfma_f32_32x32x2_f32 = 256 registers -- one wave per SIMD, by construction.
+// With nobody else on the SIMD to cover a stall the K loop is a software pipeline over input channels in steps of 8:
+//   * U (the transformed weights) never touches LDS: the host packs it (fq_conv3x3_wino_f32_pack) as
+//     [c / 8][e][c % 2][k][c % 8 / 2], so that the A operands of the four MFMAs of (step, e) are ONE 16-byte load per lane
+//     straight from L2 into the registers the MFMAs read; the load of step s + 1 is issued as soon as (step s, e) has
+//     issued its MFMAs -- a whole step (4 096 matrix cycles) of latency cover, no double buffer.  Work items are ordered
+//     k-block major, so the workgroups an XCD runs at one time share one 64-channel slice of U (<= 2 MB: its L2).
+//   * V is made in the kernel: thread = (tile, two input channels); 2 x 16 dword loads of the 4x4 input tile through a
+//     buffer descriptor (per-thread byte offsets computed once per work item, "outside the image" = an out-of-range
+//     offset that the address unit answers with zero; the channel is the scalar offset), the transform as 32 packed
+//     additions (v_pk_add_f32: the two channels ride in one instruction), 16 ds_write_b64 into the stage of step s + 1;
+//     the loads of step s + 2 follow at once.  Three 32 KB stages and one barrier per step, in the middle of it (the
+//     scheme of conv1x1_tiles): nothing is waited for at a step boundary.  B operands: one ds_read_b128 per (step, e).
+//   * Epilogue: the output transform in registers (the 16 positions of a (k, tile) pair sit in the same lane and the
+//     same register index of the 16 accumulator tiles), + bias, statistic, ReLU copy, 8-byte stores of the two pixels
+//     of a tile row (4-byte stores with per-pixel "exists" for odd H or W: 7x7).
+//
+// Numerics.  fp32 throughout; U is computed from the weights in fp64 and rounded once.  Per output: an fmaf chain over
+// c = 0 .. Cin-1 per position, then the fixed additions of the two transforms, then the bias.  Deterministic, batch-size
+// independent (no K split).  It is NOT the direct sum: |error| is about twice the direct kernel's (DESIGN.md section 4
+// states the measured bound) -- the reference's own GPU forward goes through the convolution library's Winograd kernels
+// for these layers, so no table ever depended on the direct order.
+#include "fq_common.h"
+#include "fq_producer_stat.h"
+
+#ifndef FQ_WINO_ABLATE
+#define FQ_WINO_ABLATE 0      // debug builds only (make wino_ablate): 1 no x loads in the loop, 2 no U loads, 4 no transform, 8 no epilogue, 16 no MFMAs -- wrong results, timing only
+#endif
+#define FQ_WINO_OFF(bit) ((FQ_WINO_ABLATE) & (bit))
+
+namespace fq {
+namespace {
+
+constexpr int kT = 256;
+constexpr unsigned kBT = 64;                                  // tiles per workgroup
+constexpr unsigned kBK = 64;                                  // output channels per workgroup
+constexpr unsigned kCS = 8;                                   // input channels per step
+// One stage of V: 16 positions of [c % 2][c % 8 / 2][tile 0..63] floats; the c % 2 = 1 half sits 128 bytes (32 banks) further
+// on, so that the two halves of a wave (lanes 0..31: c % 2 = 0, lanes 32..63: 1) read different banks, and a position takes a
+// whole number of 256-byte units (the offset unit of ds_read2st64_b32 / ds_write2st64_b32).
+constexpr unsigned kKkBytes = 4u * 256u + 128u;
+constexpr unsigned kPlane = 2304u;
+constexpr unsigned kStageBytes = 16u * kPlane;                // 36 KB
+constexpr unsigned kOob = 0x80000000u;                        // a byte offset no tensor of <= 2^31 bytes contains
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+typedef unsigned u2v __attribute__((__vector_size__(2 * sizeof(unsigned))));
+
+struct WArgs {
+    const float* x;
+    const float* u;           // packed by wino_pack_kernel
+    const float* bias;        // [Cout] or null
+    float* y;                 // or null (only the ReLU copy is wanted)
+    float* relu;              // or null
+    unsigned Cin, Cout, H, W, HW, TH, TW, tiles_img, tiles, tiles_t, work;
+    unsigned x_bytes, u_bytes, y_bytes;
+    int stream_stores;
+};
+
+struct NoStat {
+    __device__ __forceinline__ void add(float) {}
+};
+
+__device__ __forceinline__ void stat_add_if(NoStat&, bool, float) {}
+__device__ __forceinline__ void stat_add_if(MaxStat& s, bool ok, float v) { s.add(ok ? v : 0.0f); }
+template <bool kFast>
+__device__ __forceinline__ void stat_add_if(HistStat<kFast>& s, bool ok, float v) { if (ok) s.add(v); }
+
+// The output transform of one (k, tile) pair and what the epilogue contract asks for its four pixels.
+// kEven: H and W even -- both pixels of a tile row exist together and the pair is 8-byte aligned.
+template <bool kEven, bool kRelu, bool kStream, typename Stat>
+__device__ __forceinline__ void wino_epilogue(const f16v (&acc)[16], const WArgs& a, Stat& stat, unsigned kbase, unsigned tbase,
+                                              unsigned r, unsigned h) {
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y ? a.y : a.relu, 0, a.y ? a.y_bytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(kRelu ? a.relu : a.y, 0, a.y_bytes, 0x00020000);
+    constexpr int aux = kStream ? 2 : 0;                      // nt
+    const unsigned t = tbase + r;
+    const bool tile_ok = t < a.tiles;
+    const unsigned tc = tile_ok ? t : 0u;
+    const unsigned n = tc / a.tiles_img, rem = tc - n * a.tiles_img, ty = rem / a.TW, tx = rem - ty * a.TW;
+    const unsigned oy = 2u * ty, ox = 2u * tx;
+    const unsigned off00 = (((n * a.Cout + kbase + 4u * h) * a.H + oy) * a.W + ox) * 4u;    // < 2^31 (host check)
+    const bool ok01 = tile_ok && (kEven || ox + 1u < a.W), ok10 = tile_ok && (kEven || oy + 1u < a.H), ok11 = ok01 && ok10;
+    const unsigned v00 = tile_ok ? off00 : kOob, v01 = ok01 ? off00 + 4u : kOob;
+    const unsigned v10 = ok10 ? off00 + a.W * 4u : kOob, v11 = ok11 ? off00 + a.W * 4u + 4u : kOob;
+    f4v b4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        b4[q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + kbase + 8u * q + 4u * h) : f4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const unsigned dm = (e & 3) + 8u * (e >> 2);          // row of this register within the wave's 32 (+ 4 h: in off00)
+        const int row4 = (int)(dm * a.HW * 4u);               // uniform
+        // At M A,  At = [1 1 1 0; 0 1 -1 -1]: rows first, then columns
+        float t0[4], t1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t0[c] = (acc[c][e] + acc[4 + c][e]) + acc[8 + c][e];
+            t1[c] = (acc[4 + c][e] - acc[8 + c][e]) - acc[12 + c][e];
+        }
+        const float bias = b4[e >> 2][e & 3];
+        float o[4];
+        o[0] = ((t0[0] + t0[1]) + t0[2]) + bias;
+        o[1] = ((t0[1] - t0[2]) - t0[3]) + bias;
+        o[2] = ((t1[0] + t1[1]) + t1[2]) + bias;
+        o[3] = ((t1[1] - t1[2]) - t1[3]) + bias;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = stat_map(stat, o[i]);
+        if (kEven) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{o[0], o[1]}), yrs, (int)v00, row4, aux);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{o[2], o[3]}), yrs, (int)v10, row4, aux);
+            if (kRelu) {
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    __builtin_bit_cast(u2v, f2v{relu_like_torch(o[0]), relu_like_torch(o[1])}), rrs, (int)v00, row4, aux);
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    __builtin_bit_cast(u2v, f2v{relu_like_torch(o[2]), relu_like_torch(o[3])}), rrs, (int)v10, row4, aux);
+            }
+        } else {
+            const unsigned vo[4] = {v00, v01, v10, v11};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[i]), yrs, (int)vo[i], row4, aux);
+                if (kRelu)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(o[i])), rrs, (int)vo[i], row4, aux);
+            }
+        }
+        stat_add_if(stat, tile_ok, o[0]);
+        stat_add_if(stat, ok01, o[1]);
+        stat_add_if(stat, ok10, o[2]);
+        stat_add_if(stat, ok11, o[3]);
+    }
+}
+
+template <typename Stat>
+__device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* smem) {
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const unsigned r = lane & 31u, h = lane >> 5;
+    const unsigned wk = wave >> 1, wt = wave & 1u;            // the MFMA role: which 32 channels x 32 tiles
+    const unsigned tkk = wave & 1u, thalf = wave >> 1;        // the transform role: channels tkk + 4 thalf and + 2 of a step
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
+    const unsigned vrd = h * kKkBytes + (wt * 32u + r) * 4u;  // B operand reads:  + stage + e * kPlane + ks * 256
+    const unsigned vwr = tkk * kKkBytes + 2u * thalf * 256u + lane * 4u;   // transform writes: + stage + e * kPlane (+ 256: the second channel)
+    const unsigned nsteps = a.Cin / kCS;
+    const unsigned upos = 2u * a.Cout * 16u;                  // bytes of one position's slice of a step of U
+    const bool oddw = (a.W & 1u) != 0u;                       // uniform
+    // Workgroup g runs on XCD g % 8: give an XCD a contiguous run of work items (k-block major: one slice of U per XCD at a time)
+    const unsigned G = gridDim.x, G8 = G & ~7u, g = blockIdx.x;
+    const unsigned v0 = g < G8 ? (g & 7u) * (G8 >> 3) + (g >> 3) : g;
+
+    for (unsigned wi = v0; wi < a.work; wi += G) {
+        const unsigned kb = wi / a.tiles_t, tb = wi - kb * a.tiles_t;
+        // The transform role's tile: byte offset of the first pixel of each of its four input rows in channel 0 of its image
+        // (a whole row in one 16-byte load; "row outside the image" = an out-of-range offset, answered with zeros), and
+        // which columns exist.  Column -1 of a tile at the left edge is the pixel in front of the row: it is loaded and
+        // dropped -- except in front of the tensor's very first pixel, where that row is loaded from column 0 and shifted.
+        unsigned xo[4];
+        bool c0ok, c2ok, c3ok, shift1;
+        {
+            const unsigned t = tb * kBT + lane;
+            const bool tile_ok = t < a.tiles;
+            const unsigned tc = tile_ok ? t : 0u;
+            const unsigned n = tc / a.tiles_img, rem = tc - n * a.tiles_img, ty = rem / a.TW, tx = rem - ty * a.TW;
+            const int iy0 = (int)(2u * ty) - 1;
+            const unsigned nb = n * a.Cin * a.HW;
+            c0ok = tx != 0u; c2ok = 2u * tx + 1u < a.W; c3ok = 2u * tx + 2u < a.W;
+            shift1 = tile_ok && tc == 0u;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = iy0 + i;
+                const bool ok = tile_ok && (unsigned)iy < a.H;
+                xo[i] = ok ? (nb + (unsigned)iy * a.W + 2u * tx - 1u) * 4u : kOob;
+            }
+            if (shift1) xo[1] = 0u;
+        }
+        const unsigned uvo = (h * a.Cout + kb * kBK + wk * 32u + r) * 16u;
+        f4v d0[4], d1[4];                                     // the two channels' input tiles of the step being loaded, row by row
+        auto xload = [&](unsigned s) {
+            const unsigned c0 = s * kCS + tkk + 4u * thalf;
+            const int s0 = (int)(c0 * a.HW * 4u), s1 = (int)((c0 + 2u) * a.HW * 4u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d0[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)xo[i], s0, 0));
+                d1[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)xo[i], s1, 0));
+            }
+        };
+        // Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
+        auto transform = [&](f4v (&d)[4], float (&v)[16]) {
+            d[1] = shift1 ? f4v{0.0f, d[1][0], d[1][1], d[1][2]} : d[1];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i][0] = c0ok ? d[i][0] : 0.0f;
+                d[i][3] = c3ok ? d[i][3] : 0.0f;
+            }
+            if (oddw) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) d[i][2] = c2ok ? d[i][2] : 0.0f;
+            }
+            const f4v t0 = d[0] - d[2], t1 = d[1] + d[2], t2 = d[2] - d[1], t3 = d[1] - d[3];
+            const f4v t[4] = {t0, t1, t2, t3};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[4 * i] = t[i][0] - t[i][2];
+                v[4 * i + 1] = t[i][1] + t[i][2];
+                v[4 * i + 2] = t[i][2] - t[i][1];
+                v[4 * i + 3] = t[i][1] - t[i][3];
+            }
+        };
+        auto transform_store = [&](unsigned stage_off) {
+            float va[16], vb[16];
+            transform(d0, va);
+            transform(d1, vb);
+            char* const w = smem + stage_off + vwr;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                *reinterpret_cast<float*>(w + (unsigned)e * kPlane) = va[e];
+                *reinterpret_cast<float*>(w + (unsigned)e * kPlane + 256u) = vb[e];
+            }
+        };
+        f4v ua[16];                                           // A operands of the current step: [e][k pair of the step]
+        auto uload = [&](int e, unsigned s) {
+            ua[e] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(urs, (int)uvo, (int)((s * 16u + (unsigned)e) * upos), 0));
+        };
+        float bq[2][8][4];                                    // B operands: [half of the step][e % 8][k pair]
+        auto bload = [&](int half, unsigned stage_off, int e0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    bq[half][e][k] = *reinterpret_cast<const float*>(smem + stage_off + vrd + (unsigned)(e0 + e) * kPlane + (unsigned)k * 256u);
+        };
+        f16v acc[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[e][i] = 0.0f;
+        auto mfma_half = [&](int half, int e0, unsigned sn) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (!FQ_WINO_OFF(16)) acc[e0 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e0 + e][k], bq[half][e][k], acc[e0 + e], 0, 0, 0);
+                    else acc[e0 + e][k] += ua[e0 + e][k] * bq[half][e][k];
+                }
+            if (!FQ_WINO_OFF(2)) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) uload(e0 + e, sn);
+            }
+        };
+
+        // (the loads are issued in the order a step of the loop leaves them in -- x, then U: the wait counts the compiler puts
+        //  into the loop are the minimum over both ways into it, and a prologue that issued x last made every step wait for all)
+        xload(0);
+        transform_store(0);
+        xload(nsteps > 1 ? 1u : 0u);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) uload(e, 0);
+        __syncthreads();
+        bload(0, 0u, 0);
+        unsigned cur = 0;                                     // byte offset of the stage step s multiplies out of
+        for (unsigned s = 0; s < nsteps; ++s) {
+            const unsigned nxt = cur == 2u * kStageBytes ? 0u : cur + kStageBytes;
+            const unsigned sn = s + 1 < nsteps ? s + 1 : s;   // (the last step re-reads its own slice of U and re-transforms a step nobody
+                                                              //  reads: no branch in the loop -- a branch makes every s_waitcnt behind it
+                                                              //  assume the shorter path and wait for loads that were only just issued)
+            bload(1, cur, 8);                                 // the second half's B operands, under the first half's MFMAs
+            mfma_half(0, 0, sn);
+            if (!FQ_WINO_OFF(4)) transform_store(nxt);
+            if (!FQ_WINO_OFF(1)) xload(s + 2 < nsteps ? s + 2 : s);
+            __syncthreads();
+            bload(0, nxt, 0);                                 // the next step's first half, under this step's second
+            mfma_half(1, 8, sn);
+            cur = nxt;
+        }
+        const unsigned kbase = kb * kBK + wk * 32u, tbase = tb * kBT + wt * 32u;
+        const bool even = ((a.H | a.W) & 1u) == 0u;           // uniform
+#define FQ_WINO_EPI(E, R, S) wino_epilogue<E, R, S>(acc, a, stat, kbase, tbase, r, h)
+        if (FQ_WINO_OFF(8)) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum += acc[e][i];
+            if (sum == 12345.678f) a.y[0] = sum;
+        } else if (even) {
+            if (a.relu) { if (a.stream_stores) FQ_WINO_EPI(true, true, true); else FQ_WINO_EPI(true, true, false); }
+            else { if (a.stream_stores) FQ_WINO_EPI(true, false, true); else FQ_WINO_EPI(true, false, false); }
+        } else {
+            if (a.relu) FQ_WINO_EPI(false, true, false); else FQ_WINO_EPI(false, false, false);
+        }
+#undef FQ_WINO_EPI
+        __syncthreads();                                      // the next work item overwrites stage 0
+    }
+}
+
+constexpr unsigned kLdsBytes = 3u * kStageBytes;
+
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_kernel(const WArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char wino_smem[];
+    NoStat st;
+    wino_tiles(a, st, wino_smem);
+}
+
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_absmax_kernel(const WArgs a, unsigned int* __restrict__ max_bits) {
+    extern __shared__ __attribute__((aligned(16))) char wino_smem[];
+    MaxStat st;
+    wino_tiles(a, st, wino_smem);
+    publish_max<kT>(st.m, max_bits);
+}
+
+// (a persistent grid, one workgroup per CU: every workgroup flushes its 2048 LDS bins with 64-bit atomics at its end)
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_hist_kernel(
+    const WArgs a, const float* __restrict__ interval, unsigned long long* __restrict__ hist_row, const int allow_fast) {
+    extern __shared__ __attribute__((aligned(16))) char wino_smem[];
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kT) s_bins[b] = 0u;
+    __syncthreads();
+    const float iv = *interval;
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (allow_fast && fast_quotient_ok(iv)) {
+        HistStat<true> st{s_bins, park, iv, 1.0f / iv};
+        wino_tiles(a, st, wino_smem);
+    } else {
+        HistStat<false> st{s_bins, park, iv, 1.0f / iv};
+        wino_tiles(a, st, wino_smem);
+    }
+    hist_flush<kT>(s_bins, hist_row);
+}
+
+// U = G g Gt,  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in fp64, rounded once; written where the kernel's A operand loads
+// find it: [c / 8][e][c % 2][k][c % 8 / 2].  One thread per (k, c).
+__global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, unsigned Cin, unsigned Cout) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= Cin * Cout) return;
+    const unsigned k = i / Cin, c = i - k * Cin;
+    const float* g = w + (size_t)i * 9u;
+    double gg[3][3], t[4][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) gg[a][b] = (double)g[3 * a + b];
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = gg[0][b];
+        t[1][b] = 0.5 * (gg[0][b] + gg[1][b] + gg[2][b]);
+        t[2][b] = 0.5 * (gg[0][b] - gg[1][b] + gg[2][b]);
+        t[3][b] = gg[2][b];
+    }
+    const unsigned cb = c / kCS, kk = c & 1u, ks = (c % kCS) >> 1;
+    for (int a = 0; a < 4; ++a) {
+        const double o[4] = {t[a][0], 0.5 * (t[a][0] + t[a][1] + t[a][2]), 0.5 * (t[a][0] - t[a][1] + t[a][2]), t[a][2]};
+        for (int b = 0; b < 4; ++b) {
+            const unsigned e = 4u * (unsigned)a + (unsigned)b;
+            u[((((size_t)cb * 16u + e) * 2u + kk) * Cout + k) * 4u + ks] = (float)o[b];
+        }
+    }
+}
+
+bool wino_shape_ok(int N, int Cin, int Hin, int Win, int Cout) {
+    if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0) return false;
+    if ((Cin % (int)kCS) != 0 || (Cout % (int)kBK) != 0) return false;
+    const size_t in_bytes = (size_t)N * Cin * Hin * Win * 4, out_bytes = (size_t)N * Cout * Hin * Win * 4;
+    const size_t tiles = (size_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2);
+    return in_bytes < (1ULL << 31) && out_bytes < (1ULL << 31) && (size_t)Cin * Cout * 64 < (1ULL << 31) && tiles < (1ULL << 30);
+}
+
+}  // namespace
+}  // namespace fq
+
+using namespace fq;
+
+extern "C" int fq_conv3x3_wino_f32_supported(int N, int Cin, int Hin, int Win, int Cout) { return wino_shape_ok(N, Cin, Hin, Win, Cout) ? 1 : 0; }
+
+extern "C" size_t fq_conv3x3_wino_f32_packed_floats(int Cin, int Cout) {
+    return (Cin > 0 && Cout > 0) ? (size_t)16 * (size_t)Cin * (size_t)Cout : 0;
+}
+
+extern "C" int fq_conv3x3_wino_f32_pack(const float* w_kcrs, float* u, int Cin, int Cout, fq_stream_t stream) {
+    if (!w_kcrs || !u || Cin <= 0 || Cout <= 0) return FQ_ERR_INVALID_ARG;
+    if ((Cin % (int)kCS) != 0 || (size_t)Cin * Cout * 64 >= (1ULL << 31)) return FQ_ERR_UNSUPPORTED;
+    const unsigned n = (unsigned)Cin * (unsigned)Cout;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((n + 255u) / 256u), dim3(256), 0, as_stream(stream), w_kcrs, u, (unsigned)Cin, (unsigned)Cout);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_conv3x3_wino_f32(const float* x, const float* u, const float* bias, float* y, float* relu_out, int N, int Cin,
+                                   int Hin, int Win, int Cout, float* max_inout, const float* interval, int64_t* hist_row,
+                                   fq_stream_t stream) {
+    if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0) return FQ_ERR_INVALID_ARG;
+    if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
+    if (hist_row && !interval) return FQ_ERR_INVALID_ARG;
+    if (N == 0) return FQ_OK;
+    if (!x || !u || (!y && !relu_out)) return FQ_ERR_INVALID_ARG;
+    if (!wino_shape_ok(N, Cin, Hin, Win, Cout) || (reinterpret_cast<uintptr_t>(u) & 15u) ||
+        (bias && (reinterpret_cast<uintptr_t>(bias) & 15u)))
+        return FQ_ERR_UNSUPPORTED;
+    WArgs a;
+    a.x = x; a.u = u; a.bias = bias; a.y = y; a.relu = relu_out;
+    a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.H = (unsigned)Hin; a.W = (unsigned)Win; a.HW = a.H * a.W;
+    a.TH = (a.H + 1u) / 2u; a.TW = (a.W + 1u) / 2u; a.tiles_img = a.TH * a.TW; a.tiles = (unsigned)N * a.tiles_img;
+    a.tiles_t = (a.tiles + kBT - 1u) / kBT;
+    a.work = a.tiles_t * (a.Cout / kBK);
+    a.x_bytes = (unsigned)((size_t)N * Cin * a.HW * 4); a.y_bytes = (unsigned)((size_t)N * Cout * a.HW * 4);
+    a.u_bytes = (unsigned)((size_t)16 * Cin * Cout * 4);
+    // non-temporal stores beyond the Infinity Cache, where a plane is a whole number of 64-byte blocks (fq_conv1x1_f32.hip)
+    a.stream_stores = (size_t)a.y_bytes * (relu_out && y ? 2 : 1) > ((size_t)256 << 20) && (a.HW % 16u) == 0;
+    hipStream_t st = as_stream(stream);
+    static bool done_plain[kMaxDevices], done_max[kMaxDevices], done_hist[kMaxDevices];
+    if (hist_row) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_hist_kernel), (int)kLdsBytes, done_hist)) return FQ_ERR_HIP;
+        static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
+        const unsigned grid = a.work < (unsigned)kCUs ? a.work : (unsigned)kCUs;
+        hipLaunchKernelGGL(wino_f32_hist_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a, interval,
+                           reinterpret_cast<unsigned long long*>(hist_row), fast);
+    } else if (max_inout) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_absmax_kernel), (int)kLdsBytes, done_max)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL(wino_f32_absmax_kernel, dim3(a.work), dim3(kT), kLdsBytes, st, a, reinterpret_cast<unsigned int*>(max_inout));
+    } else {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_kernel), (int)kLdsBytes, done_plain)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL(wino_f32_kernel, dim3(a.work), dim3(kT), kLdsBytes, st, a);
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}

@@ -53,9 +53,11 @@ def enabled():
     return os.environ.get("FQ_OWN_CONV1X1", "1") != "0"
 
 
-def kind(m, x):
-    """"c1" (fq_conv1x1_f32), "kxk" (fq_conv_kxk_f32), "stem" (fq_conv_stem_f32) or None: which own kernel takes this call of
-    the nn.Conv2d m."""
+def kind(m, x, wino=False):
+    """"c1" (fq_conv1x1_f32), "kxk" (fq_conv_kxk_f32), "wino" (fq_conv3x3_wino_f32), "stem" (fq_conv_stem_f32) or None: which
+    own kernel takes this call of the nn.Conv2d m.  "wino" -- the Winograd form of the stride-1 3x3 layers -- is handed out only
+    to callers that ask for it (the calibration forward): TestConv's two forms (fused with QuanDequan, or not when somebody
+    watches the module) must agree bit for bit, and only the direct kernel has both."""
     if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or m.weight.dtype != torch.float32 or m.bias is None
             or is_off(m) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
             or not x.is_contiguous() or isinstance(m.padding, str) or m.padding[0] != m.padding[1] or m.padding_mode != "zeros"
@@ -69,22 +71,26 @@ def kind(m, x):
     if (m.kernel_size != (1, 1) and m.in_channels % 16 == 0 and m.out_channels % 4 == 0
             and x.shape[2] + 2 * m.padding[0] >= m.kernel_size[0] and x.shape[3] + 2 * m.padding[1] >= m.kernel_size[1]
             and m.kernel_size[0] * m.kernel_size[1] * m.in_channels * m.out_channels < 2 ** 30):
+        if (wino and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and _native.conv_wino_enabled()
+                and _native.conv_wino_supported(x.shape[0], m.in_channels, x.shape[2], x.shape[3], m.out_channels)):
+            return "wino"
         return "kxk"
     return None
 
 
 def weight(m, k):
-    """The weights in the layout the kernel reads (Wt [Cin][Cout] / the packed stem matrix), rebuilt when the parameter
-    was written to or replaced."""
+    """The weights in the layout the kernel reads (Wt [Cin][Cout] / the packed stem matrix / the transformed Winograd
+    weights), one entry per kind, rebuilt when the parameter was written to or replaced."""
     w = m.weight
-    tag = (k, w._version, w.data_ptr(), w.device)
-    st = state(m)
-    cached = st.get("wt")
+    tag = (w._version, w.data_ptr(), w.device)
+    by_kind = state(m).setdefault("wt", {})
+    cached = by_kind.get(k)
     if cached is None or cached[0] != tag:
         packed = (w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1"
-                  else _native.pack_kxk_weight(w) if k == "kxk" else _native.pack_stem_weight(w))
+                  else _native.pack_kxk_weight(w) if k == "kxk"
+                  else _native.pack_wino_weight(w) if k == "wino" else _native.pack_stem_weight(w))
         cached = (tag, packed)
-        st["wt"] = cached
+        by_kind[k] = cached
     return cached[1]
 
 
@@ -95,6 +101,8 @@ def runner(m, k, x):
         return lambda **kw: _native.conv1x1_f32(x, wq, m.bias, s, **kw)
     if k == "kxk":
         return lambda **kw: _native.conv_kxk_f32(x, wq, m.bias, m.kernel_size, s, m.padding[0], **kw)
+    if k == "wino":
+        return lambda **kw: _native.conv_wino_f32(x, wq, m.bias, m.out_channels, **kw)
     return lambda **kw: _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
 
 

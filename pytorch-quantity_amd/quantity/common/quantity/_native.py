@@ -104,6 +104,14 @@ def lib():
     L.fq_conv1x1_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 6 + [vp, vp, vp, vp, sz, vp]
     L.fq_conv_kxk_f32.restype = ci
     L.fq_conv_kxk_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 9 + [vp, vp, vp, vp, sz, vp]
+    L.fq_conv3x3_wino_f32_supported.restype = ci
+    L.fq_conv3x3_wino_f32_supported.argtypes = [ci] * 5
+    L.fq_conv3x3_wino_f32_packed_floats.restype = sz
+    L.fq_conv3x3_wino_f32_packed_floats.argtypes = [ci, ci]
+    L.fq_conv3x3_wino_f32_pack.restype = ci
+    L.fq_conv3x3_wino_f32_pack.argtypes = [vp, vp, ci, ci, vp]
+    L.fq_conv3x3_wino_f32.restype = ci
+    L.fq_conv3x3_wino_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 5 + [vp, vp, vp, vp]
     L.fq_conv_stem_f32_packed_rows.restype = ci
     L.fq_conv_stem_f32_packed_rows.argtypes = [ci, ci, ci]
     L.fq_conv_stem_f32.restype = ci
@@ -514,6 +522,59 @@ def conv_kxk_f32(x, wt, bias, kernel, stride, pad, max_dev=None, interval_dev=No
     _check(lib().fq_conv_kxk_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(),
                                  None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin, H, W,
                                  Cout, R, S, st, pd, mp, ivp, hp, *conv_workspace(x), _stream(x)), "fq_conv_kxk_f32")
+    return y
+
+
+def conv_wino_enabled():
+    """FQ_CONV_WINO=0 keeps the stride-1 3x3 layers of the float forward on the direct kernel (fq_conv_kxk_f32)."""
+    return os.environ.get("FQ_CONV_WINO", "1") != "0"
+
+
+def conv_wino_supported(n, cin, h, w, cout):
+    """True when fq_conv3x3_wino_f32 takes a stride-1, pad-1 3x3 convolution of x [n, cin, h, w] to cout channels."""
+    return bool(lib().fq_conv3x3_wino_f32_supported(int(n), int(cin), int(h), int(w), int(cout)))
+
+
+def pack_wino_weight(weight):
+    """[Cout, Cin, 3, 3] (device, fp32) -> the transformed, packed weights fq_conv3x3_wino_f32 reads."""
+    _need_cuda(weight, torch.float32, "fq_conv3x3_wino_f32_pack")
+    cout, cin, r, s = (int(v) for v in weight.shape)
+    assert r == 3 and s == 3
+    w = weight.detach().contiguous()
+    u = torch.empty(int(lib().fq_conv3x3_wino_f32_packed_floats(cin, cout)), dtype=torch.float32, device=w.device)
+    _check(lib().fq_conv3x3_wino_f32_pack(w.data_ptr(), u.data_ptr(), cin, cout, _stream(w)), "fq_conv3x3_wino_f32_pack")
+    return u
+
+
+def conv_wino_f32(x, u, bias, cout, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None, out=None):
+    """fq_conv3x3_wino_f32: the stride-1, pad-1 3x3 float convolution of x [N, Cin, H, W] with the weights packed by
+    pack_wino_weight; statistics / relu_out / out as in conv1x1_f32.  Returns y."""
+    _need_cuda(x, torch.float32, "fq_conv3x3_wino_f32")
+    _need_cuda(u, torch.float32, "fq_conv3x3_wino_f32")
+    assert x.dim() == 4 and x.is_contiguous() and u.is_contiguous()
+    N, Cin, H, W = (int(v) for v in x.shape)
+    Cout = int(cout)
+    assert u.numel() == 16 * Cin * Cout
+    shape = (N, Cout, H, W)
+    if out is False:                                            # only the ReLU's output is wanted: y is not written
+        assert relu_out is not None and tuple(relu_out.shape) == shape
+        y = None
+    else:
+        y = torch.empty(shape, dtype=torch.float32, device=x.device) if out is None else out
+        assert tuple(y.shape) == shape and y.is_contiguous() and y.dtype == torch.float32 and y.is_cuda
+    if bias is not None:
+        _need_cuda(bias, torch.float32, "fq_conv3x3_wino_f32")
+        assert bias.is_contiguous() and bias.numel() == Cout
+    mp = ivp = hp = None
+    if hist_dev is not None:
+        ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)
+    elif max_dev is not None:
+        _need_cuda(max_dev, torch.float32, "fq_conv3x3_wino_f32")
+        assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
+        mp = max_dev.data_ptr() + 4 * int(row)
+    _check(lib().fq_conv3x3_wino_f32(x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(),
+                                     None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin,
+                                     H, W, Cout, mp, ivp, hp, _stream(x)), "fq_conv3x3_wino_f32")
     return y
 
 
