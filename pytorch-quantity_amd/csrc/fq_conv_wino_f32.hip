@@ -107,11 +107,16 @@ __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[16], const WArgs
         const unsigned dm = (e & 3) + 8u * (e >> 2);          // row of this register within the wave's 32 (+ 4 h: in off00)
         const int row4 = (int)(dm * a.HW * 4u);               // uniform
         // At M A,  At = [1 1 1 0; 0 1 -1 -1]: rows first, then columns
+        // (the accumulators live in AGPRs; they are copied out HERE, sixteen at a time -- left to itself the compiler copies all
+        //  256 at the end of the K loop, in front of the branch that picks the epilogue, and spills to make room)
+        float m[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[q]) : "a"(acc[q][e]));
         float t0[4], t1[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            t0[c] = (acc[c][e] + acc[4 + c][e]) + acc[8 + c][e];
-            t1[c] = (acc[4 + c][e] - acc[8 + c][e]) - acc[12 + c][e];
+            t0[c] = (m[c] + m[4 + c]) + m[8 + c];
+            t1[c] = (m[4 + c] - m[8 + c]) - m[12 + c];
         }
         const float bias = b4[e >> 2][e & 3];
         float o[4];
@@ -143,10 +148,50 @@ __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[16], const WArgs
         stat_add_if(stat, ok01, o[1]);
         stat_add_if(stat, ok10, o[2]);
         stat_add_if(stat, ok11, o[3]);
-    }
+        __builtin_amdgcn_sched_barrier(0);                    // (one register index at a time: left alone the compiler copies all 256
+    }                                                         //  accumulators out of the AGPRs first and spills to make room)
 }
 
-template <typename Stat>
+// What the transform role needs to know about its tile of one work item: the byte offset of the first pixel of each of its
+// four input rows in channel 0 of its image (a whole row is one 16-byte load; "row outside the image" = an out-of-range
+// offset, answered with zeros) and which columns exist.  Column -1 of a tile at the left edge is the pixel in front of the
+// row: it is loaded and dropped -- except in front of the tensor's very first pixel, where that row is loaded from column 0
+// and shifted.
+struct TileIn {
+    unsigned xo[4];
+    bool c0ok, c2ok, c3ok, shift1;
+};
+
+__device__ __forceinline__ TileIn tile_in(const WArgs& a, unsigned tb, unsigned lane) {
+    TileIn t;
+    const unsigned ti = tb * kBT + lane;
+    const bool tile_ok = ti < a.tiles;
+    const unsigned tc = tile_ok ? ti : 0u;
+    const unsigned n = tc / a.tiles_img, rem = tc - n * a.tiles_img, ty = rem / a.TW, tx = rem - ty * a.TW;
+    const int iy0 = (int)(2u * ty) - 1;
+    const unsigned nb = n * a.Cin * a.HW;
+    t.c0ok = tx != 0u; t.c2ok = 2u * tx + 1u < a.W; t.c3ok = 2u * tx + 2u < a.W;
+    t.shift1 = tile_ok && tc == 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int iy = iy0 + i;
+        const bool ok = tile_ok && (unsigned)iy < a.H;
+        t.xo[i] = ok ? (nb + (unsigned)iy * a.W + 2u * tx - 1u) * 4u : kOob;
+    }
+    if (t.shift1) t.xo[1] = 0u;
+    return t;
+}
+
+__device__ __forceinline__ TileIn pick(bool second, const TileIn& a, const TileIn& b) {   // (second is uniform)
+    TileIn t;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.xo[i] = second ? b.xo[i] : a.xo[i];
+    t.c0ok = second ? b.c0ok : a.c0ok; t.c2ok = second ? b.c2ok : a.c2ok; t.c3ok = second ? b.c3ok : a.c3ok;
+    t.shift1 = second ? b.shift1 : a.shift1;
+    return t;
+}
+
+template <bool kOddW, typename Stat>
 __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* smem) {
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -157,138 +202,150 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
     const unsigned vrd = h * kKkBytes + (wt * 32u + r) * 4u;  // B operand reads:  + stage + e * kPlane + ks * 256
     const unsigned vwr = tkk * kKkBytes + 2u * thalf * 256u + lane * 4u;   // transform writes: + stage + e * kPlane (+ 256: the second channel)
-    const unsigned nsteps = a.Cin / kCS;
+    const unsigned nsteps = a.Cin / kCS;                      // >= 2 (host check): the pipeline looks two steps ahead, at most into the next item
     const unsigned upos = 2u * a.Cout * 16u;                  // bytes of one position's slice of a step of U
-    const bool oddw = (a.W & 1u) != 0u;                       // uniform
+    const unsigned uvo = (h * a.Cout + wk * 32u + r) * 16u;   // + kb * 64 * 16 (in the scalar offset)
     // Workgroup g runs on XCD g % 8: give an XCD a contiguous run of work items (k-block major: one slice of U per XCD at a time)
     const unsigned G = gridDim.x, G8 = G & ~7u, g = blockIdx.x;
     const unsigned v0 = g < G8 ? (g & 7u) * (G8 >> 3) + (g >> 3) : g;
+    if (v0 >= a.work) return;
 
-    for (unsigned wi = v0; wi < a.work; wi += G) {
-        const unsigned kb = wi / a.tiles_t, tb = wi - kb * a.tiles_t;
-        // The transform role's tile: byte offset of the first pixel of each of its four input rows in channel 0 of its image
-        // (a whole row in one 16-byte load; "row outside the image" = an out-of-range offset, answered with zeros), and
-        // which columns exist.  Column -1 of a tile at the left edge is the pixel in front of the row: it is loaded and
-        // dropped -- except in front of the tensor's very first pixel, where that row is loaded from column 0 and shifted.
-        unsigned xo[4];
-        bool c0ok, c2ok, c3ok, shift1;
-        {
-            const unsigned t = tb * kBT + lane;
-            const bool tile_ok = t < a.tiles;
-            const unsigned tc = tile_ok ? t : 0u;
-            const unsigned n = tc / a.tiles_img, rem = tc - n * a.tiles_img, ty = rem / a.TW, tx = rem - ty * a.TW;
-            const int iy0 = (int)(2u * ty) - 1;
-            const unsigned nb = n * a.Cin * a.HW;
-            c0ok = tx != 0u; c2ok = 2u * tx + 1u < a.W; c3ok = 2u * tx + 2u < a.W;
-            shift1 = tile_ok && tc == 0u;
+    f4v d0[4], d1[4];                                         // the two channels' input tiles of the step being loaded, row by row
+    auto xload = [&](const TileIn& t, unsigned s) {
+        const unsigned c0 = s * kCS + tkk + 4u * thalf;
+        const int s0 = (int)(c0 * a.HW * 4u), s1 = (int)((c0 + 2u) * a.HW * 4u);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int iy = iy0 + i;
-                const bool ok = tile_ok && (unsigned)iy < a.H;
-                xo[i] = ok ? (nb + (unsigned)iy * a.W + 2u * tx - 1u) * 4u : kOob;
-            }
-            if (shift1) xo[1] = 0u;
+        for (int i = 0; i < 4; ++i) {
+            d0[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)t.xo[i], s0, 0));
+            d1[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)t.xo[i], s1, 0));
         }
-        const unsigned uvo = (h * a.Cout + kb * kBK + wk * 32u + r) * 16u;
-        f4v d0[4], d1[4];                                     // the two channels' input tiles of the step being loaded, row by row
-        auto xload = [&](unsigned s) {
-            const unsigned c0 = s * kCS + tkk + 4u * thalf;
-            const int s0 = (int)(c0 * a.HW * 4u), s1 = (int)((c0 + 2u) * a.HW * 4u);
+    };
+    // Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
+    auto transform = [&](const TileIn& ti, f4v (&d)[4], float (&v)[16]) {
+        d[1] = ti.shift1 ? f4v{0.0f, d[1][0], d[1][1], d[1][2]} : d[1];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d0[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)xo[i], s0, 0));
-                d1[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)xo[i], s1, 0));
+        for (int i = 0; i < 4; ++i) {
+            d[i][0] = ti.c0ok ? d[i][0] : 0.0f;
+            d[i][3] = ti.c3ok ? d[i][3] : 0.0f;
+        }
+        if (kOddW) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d[i][2] = ti.c2ok ? d[i][2] : 0.0f;
+        }
+        const f4v t0 = d[0] - d[2], t1 = d[1] + d[2], t2 = d[2] - d[1], t3 = d[1] - d[3];
+        const f4v t[4] = {t0, t1, t2, t3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[4 * i] = t[i][0] - t[i][2];
+            v[4 * i + 1] = t[i][1] + t[i][2];
+            v[4 * i + 2] = t[i][2] - t[i][1];
+            v[4 * i + 3] = t[i][1] - t[i][3];
+        }
+    };
+    auto transform_store = [&](const TileIn& ti, unsigned stage_off) {
+        float va[16], vb[16];
+        transform(ti, d0, va);
+        transform(ti, d1, vb);
+        char* const w = smem + stage_off + vwr;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            *reinterpret_cast<float*>(w + (unsigned)e * kPlane) = va[e];
+            *reinterpret_cast<float*>(w + (unsigned)e * kPlane + 256u) = vb[e];
+        }
+    };
+    f4v ua[16];                                               // A operands of the current step: [e][k pair of the step]
+    auto uload = [&](int e, unsigned s, unsigned kb) {
+        ua[e] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(urs, (int)uvo, (int)((s * 16u + (unsigned)e) * upos + kb * (kBK * 16u)), 0));
+    };
+    float bq[2][8][4];                                        // B operands: [half of the step][e % 8][k pair]
+    auto bload = [&](int half, unsigned stage_off, int e0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                bq[half][e][k] = *reinterpret_cast<const float*>(smem + stage_off + vrd + (unsigned)(e0 + e) * kPlane + (unsigned)k * 256u);
+    };
+    f16v acc[16];
+    auto mfma_half = [&](int half, int e0, unsigned sn, unsigned kbn) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (!FQ_WINO_OFF(16)) acc[e0 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e0 + e][k], bq[half][e][k], acc[e0 + e], 0, 0, 0);
+                else acc[e0 + e][k] += ua[e0 + e][k] * bq[half][e][k];
             }
-        };
-        // Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
-        auto transform = [&](f4v (&d)[4], float (&v)[16]) {
-            d[1] = shift1 ? f4v{0.0f, d[1][0], d[1][1], d[1][2]} : d[1];
+        if (!FQ_WINO_OFF(2)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d[i][0] = c0ok ? d[i][0] : 0.0f;
-                d[i][3] = c3ok ? d[i][3] : 0.0f;
-            }
-            if (oddw) {
+            for (int e = 0; e < 8; ++e) uload(e0 + e, sn, kbn);
+        }
+    };
+
+    // ONE pipeline over all (work item, step) pairs of this workgroup: in step s of an item the U operands of the following
+    // step are loaded, the x tile of the step after that, and the tile in between is transformed -- and "the following step"
+    // of an item's last step is step 0 of the workgroup's NEXT item, so the matrix pipe goes from the last MFMA of one item
+    // into the epilogue and from there straight into the first MFMA of the next, whose operands are already there: its loads
+    // were issued before the epilogue's stores (on this architecture a load issued behind a store cannot be waited for without
+    // waiting for the store).  The loads are issued in the same order everywhere -- x, then U -- because the wait counts the
+    // compiler puts into the loop are the minimum over all ways into it.  The last item of a workgroup "looks ahead" into
+    // itself: loads and a transform nobody uses, instead of a branch (a branch makes every s_waitcnt behind it assume the
+    // shorter path).
+    unsigned wi = v0;
+    unsigned kb = wi / a.tiles_t, tb = wi - kb * a.tiles_t;
+    TileIn tcur = tile_in(a, tb, lane);
+    xload(tcur, 0);
+    transform_store(tcur, 0u);
+    xload(tcur, 1);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) d[i][2] = c2ok ? d[i][2] : 0.0f;
-            }
-            const f4v t0 = d[0] - d[2], t1 = d[1] + d[2], t2 = d[2] - d[1], t3 = d[1] - d[3];
-            const f4v t[4] = {t0, t1, t2, t3};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[4 * i] = t[i][0] - t[i][2];
-                v[4 * i + 1] = t[i][1] + t[i][2];
-                v[4 * i + 2] = t[i][2] - t[i][1];
-                v[4 * i + 3] = t[i][1] - t[i][3];
-            }
-        };
-        auto transform_store = [&](unsigned stage_off) {
-            float va[16], vb[16];
-            transform(d0, va);
-            transform(d1, vb);
-            char* const w = smem + stage_off + vwr;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                *reinterpret_cast<float*>(w + (unsigned)e * kPlane) = va[e];
-                *reinterpret_cast<float*>(w + (unsigned)e * kPlane + 256u) = vb[e];
-            }
-        };
-        f4v ua[16];                                           // A operands of the current step: [e][k pair of the step]
-        auto uload = [&](int e, unsigned s) {
-            ua[e] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(urs, (int)uvo, (int)((s * 16u + (unsigned)e) * upos), 0));
-        };
-        float bq[2][8][4];                                    // B operands: [half of the step][e % 8][k pair]
-        auto bload = [&](int half, unsigned stage_off, int e0) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    bq[half][e][k] = *reinterpret_cast<const float*>(smem + stage_off + vrd + (unsigned)(e0 + e) * kPlane + (unsigned)k * 256u);
-        };
-        f16v acc[16];
+    for (int e = 0; e < 16; ++e) uload(e, 0, kb);
+    __syncthreads();
+    bload(0, 0u, 0);
+    unsigned cur = 0;                                         // byte offset of the stage the current step multiplies out of
+    for (;;) {
+        const unsigned wn = wi + G;
+        const bool has_next = wn < a.work;                    // uniform
+        const unsigned wnc = has_next ? wn : wi;
+        const unsigned kbn = wnc / a.tiles_t, tbn = wnc - kbn * a.tiles_t;
+        const TileIn tnext = tile_in(a, tbn, lane);
 #pragma unroll
         for (int e = 0; e < 16; ++e)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[e][i] = 0.0f;
-        auto mfma_half = [&](int half, int e0, unsigned sn) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    if (!FQ_WINO_OFF(16)) acc[e0 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e0 + e][k], bq[half][e][k], acc[e0 + e], 0, 0, 0);
-                    else acc[e0 + e][k] += ua[e0 + e][k] * bq[half][e][k];
-                }
-            if (!FQ_WINO_OFF(2)) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) uload(e0 + e, sn);
-            }
-        };
-
-        // (the loads are issued in the order a step of the loop leaves them in -- x, then U: the wait counts the compiler puts
-        //  into the loop are the minimum over both ways into it, and a prologue that issued x last made every step wait for all)
-        xload(0);
-        transform_store(0);
-        xload(nsteps > 1 ? 1u : 0u);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) uload(e, 0);
-        __syncthreads();
-        bload(0, 0u, 0);
-        unsigned cur = 0;                                     // byte offset of the stage step s multiplies out of
         for (unsigned s = 0; s < nsteps; ++s) {
             const unsigned nxt = cur == 2u * kStageBytes ? 0u : cur + kStageBytes;
-            const unsigned sn = s + 1 < nsteps ? s + 1 : s;   // (the last step re-reads its own slice of U and re-transforms a step nobody
-                                                              //  reads: no branch in the loop -- a branch makes every s_waitcnt behind it
-                                                              //  assume the shorter path and wait for loads that were only just issued)
+            const bool last1 = s + 1 >= nsteps, last2 = s + 2 >= nsteps;          // uniform
+            const unsigned s1 = last1 ? 0u : s + 1, s2 = last2 ? s + 2 - nsteps : s + 2;
+            const unsigned kb1 = last1 ? kbn : kb;
             bload(1, cur, 8);                                 // the second half's B operands, under the first half's MFMAs
-            mfma_half(0, 0, sn);
-            if (!FQ_WINO_OFF(4)) transform_store(nxt);
-            if (!FQ_WINO_OFF(1)) xload(s + 2 < nsteps ? s + 2 : s);
+            mfma_half(0, 0, s1, kb1);
+            if (!FQ_WINO_OFF(4)) transform_store(pick(last1, tcur, tnext), nxt);
+            if (!FQ_WINO_OFF(1)) xload(pick(last2, tcur, tnext), s2);
+            // The wave is alone on its SIMD and issues in order: whatever stands between two MFMAs for longer than an MFMA runs
+            // (64 cycles) leaves the matrix pipe idle.  Left alone the compiler puts the ~100 vector instructions of the transform
+            // in one lump with four MFMAs in it; this asks for one MFMA, then at most four vector instructions and one LDS / one
+            // memory instruction, 32 times.
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (i & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
             __syncthreads();
-            bload(0, nxt, 0);                                 // the next step's first half, under this step's second
-            mfma_half(1, 8, sn);
+            bload(0, nxt, 0);                                 // the following step's first half, under this step's second
+            mfma_half(1, 8, s1, kb1);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
             cur = nxt;
         }
         const unsigned kbase = kb * kBK + wk * 32u, tbase = tb * kBT + wt * 32u;
+        // (the epilogue copies the accumulators out with v_accvgpr_read in inline assembly, which the compiler's hazard
+        //  recogniser does not see into: the wait states between the last MFMA and the first copy are put here by hand)
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         const bool even = ((a.H | a.W) & 1u) == 0u;           // uniform
 #define FQ_WINO_EPI(E, R, S) wino_epilogue<E, R, S>(acc, a, stat, kbase, tbase, r, h)
         if (FQ_WINO_OFF(8)) {
@@ -305,7 +362,8 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
             if (a.relu) FQ_WINO_EPI(false, true, false); else FQ_WINO_EPI(false, false, false);
         }
 #undef FQ_WINO_EPI
-        __syncthreads();                                      // the next work item overwrites stage 0
+        if (!has_next) break;
+        wi = wn; kb = kbn; tb = tbn; tcur = tnext;
     }
 }
 
@@ -314,17 +372,17 @@ constexpr unsigned kLdsBytes = 3u * kStageBytes;
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_kernel(const WArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     NoStat st;
-    wino_tiles(a, st, wino_smem);
+    if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
 }
 
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_absmax_kernel(const WArgs a, unsigned int* __restrict__ max_bits) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     MaxStat st;
-    wino_tiles(a, st, wino_smem);
+    if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
     publish_max<kT>(st.m, max_bits);
 }
 
-// (a persistent grid, one workgroup per CU: every workgroup flushes its 2048 LDS bins with 64-bit atomics at its end)
+// (every workgroup flushes its 2048 LDS bins with 64-bit atomics at its end)
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_hist_kernel(
     const WArgs a, const float* __restrict__ interval, unsigned long long* __restrict__ hist_row, const int allow_fast) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
@@ -335,10 +393,10 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
     if (allow_fast && fast_quotient_ok(iv)) {
         HistStat<true> st{s_bins, park, iv, 1.0f / iv};
-        wino_tiles(a, st, wino_smem);
+        if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
     } else {
         HistStat<false> st{s_bins, park, iv, 1.0f / iv};
-        wino_tiles(a, st, wino_smem);
+        if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
     }
     hist_flush<kT>(s_bins, hist_row);
 }
@@ -371,7 +429,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 
 bool wino_shape_ok(int N, int Cin, int Hin, int Win, int Cout) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0) return false;
-    if ((Cin % (int)kCS) != 0 || (Cout % (int)kBK) != 0) return false;
+    if ((Cin % (int)kCS) != 0 || Cin < 2 * (int)kCS || (Cout % (int)kBK) != 0) return false;
     const size_t in_bytes = (size_t)N * Cin * Hin * Win * 4, out_bytes = (size_t)N * Cout * Hin * Win * 4;
     const size_t tiles = (size_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2);
     return in_bytes < (1ULL << 31) && out_bytes < (1ULL << 31) && (size_t)Cin * Cout * 64 < (1ULL << 31) && tiles < (1ULL << 30);
@@ -419,19 +477,21 @@ extern "C" int fq_conv3x3_wino_f32(const float* x, const float* u, const float* 
     // non-temporal stores beyond the Infinity Cache, where a plane is a whole number of 64-byte blocks (fq_conv1x1_f32.hip)
     a.stream_stores = (size_t)a.y_bytes * (relu_out && y ? 2 : 1) > ((size_t)256 << 20) && (a.HW % 16u) == 0;
     hipStream_t st = as_stream(stream);
+    // A persistent grid, one workgroup per CU (that is all the registers allow), each taking every 256th work item: measured
+    // 5 % faster than one workgroup per item at 784 items, and the histogram form needs it anyway (one flush per workgroup).
+    const unsigned grid = a.work < (unsigned)kCUs ? a.work : (unsigned)kCUs;
     static bool done_plain[kMaxDevices], done_max[kMaxDevices], done_hist[kMaxDevices];
     if (hist_row) {
         if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_hist_kernel), (int)kLdsBytes, done_hist)) return FQ_ERR_HIP;
         static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
-        const unsigned grid = a.work < (unsigned)kCUs ? a.work : (unsigned)kCUs;
         hipLaunchKernelGGL(wino_f32_hist_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a, interval,
                            reinterpret_cast<unsigned long long*>(hist_row), fast);
     } else if (max_inout) {
         if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_absmax_kernel), (int)kLdsBytes, done_max)) return FQ_ERR_HIP;
-        hipLaunchKernelGGL(wino_f32_absmax_kernel, dim3(a.work), dim3(kT), kLdsBytes, st, a, reinterpret_cast<unsigned int*>(max_inout));
+        hipLaunchKernelGGL(wino_f32_absmax_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a, reinterpret_cast<unsigned int*>(max_inout));
     } else {
         if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_kernel), (int)kLdsBytes, done_plain)) return FQ_ERR_HIP;
-        hipLaunchKernelGGL(wino_f32_kernel, dim3(a.work), dim3(kT), kLdsBytes, st, a);
+        hipLaunchKernelGGL(wino_f32_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a);
     }
     FQ_LAUNCH_CHECK();
     return FQ_OK;

@@ -20,9 +20,9 @@ SHAPES = [
     (3, 128, 128, 28, 28),        # layer2: two k-blocks
     (5, 256, 256, 14, 14),        # layer3: 7x7 tiles per image, 245 tiles = 3.8 blocks
     (4, 512, 512, 7, 7),          # layer4: odd plane, 4x4 tiles with a missing row and column; 64 tiles = one block
-    (3, 8, 64, 5, 9),             # one step; odd both ways
+    (3, 16, 64, 5, 9),            # two steps (the fewest the pipeline takes); odd both ways
     (70, 16, 128, 1, 1),          # 1x1 planes: one tile per image, three of its four pixels missing, eight taps padding
-    (1, 8, 64, 2, 3),             # a single partial block
+    (1, 16, 64, 2, 3),            # a single partial block
     (7, 24, 64, 13, 6),           # three steps, odd height
     (33, 16, 192, 10, 10),        # 825 tiles = 12.9 blocks x 3 k-blocks: more work items than one round of a persistent grid
     (2, 40, 64, 6, 20),           # wide plane
@@ -138,27 +138,29 @@ def test_packed_weights_are_g_gt_in_fp64_rounded_once(nat):
 
 def test_argument_errors(nat):
     L = nat.lib()
-    x = torch.zeros(1, 8, 4, 4, device="cuda")
-    u = torch.zeros(16 * 8 * 64, device="cuda")
+    x = torch.zeros(1, 16, 4, 4, device="cuda")
+    u = torch.zeros(16 * 16 * 64, device="cuda")
     y = torch.zeros(1, 64, 4, 4, device="cuda")
     mx = torch.zeros(1, device="cuda")
     hist = torch.zeros(2048, dtype=torch.int64, device="cuda")
     P = lambda t: t.data_ptr()
     ok = lambda *a: L.fq_conv3x3_wino_f32(*a)
-    assert ok(P(x), P(u), None, P(y), None, 1, 8, 4, 4, 64, None, None, None, None) == 0
-    assert ok(P(x), P(u), None, P(y), None, 0, 8, 4, 4, 64, None, None, None, None) == 0           # no images: nothing to do
-    assert ok(P(x), P(u), None, P(y), None, 1, 4, 4, 4, 64, None, None, None, None) == -4          # Cin % 8
-    assert ok(P(x), P(u), None, P(y), None, 1, 8, 4, 4, 32, None, None, None, None) == -4          # Cout % 64
-    assert ok(P(x), P(u) + 4, None, P(y), None, 1, 8, 4, 4, 64, None, None, None, None) == -4      # u not 16-byte aligned
-    assert ok(P(x), P(u), None, None, None, 1, 8, 4, 4, 64, None, None, None, None) == -1          # neither y nor relu_out
-    assert ok(None, P(u), None, P(y), None, 1, 8, 4, 4, 64, None, None, None, None) == -1
-    assert ok(P(x), P(u), None, P(y), None, 1, 8, 4, 4, 64, P(mx), P(mx), P(hist), None) == -1     # both statistics
-    assert ok(P(x), P(u), None, P(y), None, 1, 8, 4, 4, 64, None, None, P(hist), None) == -1       # histogram without its interval
-    assert ok(P(x), P(u), None, P(y), None, 1, 8, 0, 4, 64, None, None, None, None) == -1
+    assert ok(P(x), P(u), None, P(y), None, 1, 16, 4, 4, 64, None, None, None, None) == 0
+    assert ok(P(x), P(u), None, P(y), None, 0, 16, 4, 4, 64, None, None, None, None) == 0          # no images: nothing to do
+    assert ok(P(x), P(u), None, P(y), None, 1, 12, 4, 4, 64, None, None, None, None) == -4         # Cin % 8
+    assert ok(P(x), P(u), None, P(y), None, 1, 8, 4, 4, 64, None, None, None, None) == -4          # Cin < 16: the pipeline needs two steps
+    assert ok(P(x), P(u), None, P(y), None, 1, 16, 4, 4, 32, None, None, None, None) == -4         # Cout % 64
+    assert ok(P(x), P(u) + 4, None, P(y), None, 1, 16, 4, 4, 64, None, None, None, None) == -4     # u not 16-byte aligned
+    assert ok(P(x), P(u), None, None, None, 1, 16, 4, 4, 64, None, None, None, None) == -1         # neither y nor relu_out
+    assert ok(None, P(u), None, P(y), None, 1, 16, 4, 4, 64, None, None, None, None) == -1
+    assert ok(P(x), P(u), None, P(y), None, 1, 16, 4, 4, 64, P(mx), P(mx), P(hist), None) == -1    # both statistics
+    assert ok(P(x), P(u), None, P(y), None, 1, 16, 4, 4, 64, None, None, P(hist), None) == -1      # histogram without its interval
+    assert ok(P(x), P(u), None, P(y), None, 1, 16, 0, 4, 64, None, None, None, None) == -1
     assert L.fq_conv3x3_wino_f32_supported(256, 64, 56, 56, 64) == 1
     assert L.fq_conv3x3_wino_f32_supported(1024, 256, 56, 56, 256) == 0                            # x beyond 2^31 bytes
     assert L.fq_conv3x3_wino_f32_pack(None, P(u), 8, 64, None) == -1
     assert L.fq_conv3x3_wino_f32_pack(P(x), P(u), 4, 64, None) == -4
+    assert L.fq_conv3x3_wino_f32_supported(4, 8, 8, 8, 64) == 0 and L.fq_conv3x3_wino_f32_supported(4, 16, 8, 8, 64) == 1
 
 
 def test_resnet50_tables_do_not_depend_on_the_3x3_kernel(monkeypatch):
