@@ -33,8 +33,8 @@ The JSON line also carries
                  in one kernel (pass 1 / pass 2): matrix work and algorithmic bytes (x, Wt, the shortcut, the ReLU output and
                  whichever of the two intermediate tensors is kept), frac_of_bound against max(matrix, bytes) per launch;
   file_input   : the same images as .npy files through PRE_PROCESS.IMG = 2 (--input-mode npy|both), beside `value`, never it;
-  roofline_conv_stem_f32 / roofline_conv_kxk_f32 : the same for the 7x7 stride-2 stem (fq_conv_stem_f32) and the 3x3 layers
-                 (fq_conv_kxk_f32);
+  roofline_conv_stem_f32 / roofline_conv_kxk_f32 : the same for the 7x7 stride-2 stem (fq_conv_stem_f32) and the stride-2 3x3
+                 layers (fq_conv_kxk_f32); roofline_conv_wino_f32: the stride-1 3x3 layers (fq_conv3x3_wino_f32, Winograd);
   roofline_conv1x1_f32 : the float forward's 1x1 convolutions on the fp32 matrix cores (fq_conv1x1_f32, statistic in the
                  epilogue): 2 x MAC / summed launch durations against the 157.3 TFLOP/s dense fp32 MFMA peak;
   cpu_baseline : the CPU oracle (oracle/fq_oracle.c, "port") + torch-CPU forwards timed on a bounded sample on this
@@ -294,6 +294,28 @@ def _kxk_flops(a, k):
 def _kxk_bytes(a, k):
     n, cin, cout, ho, wo, taps = _kxk_shape(a, k)
     return 4.0 * (a[0].numel() + a[1].numel() + n * cout * ho * wo * _out_copies(k))
+
+
+def _wino_shape(a, k):              # conv_wino_f32(x, u, bias, cout, ...): stride 1, pad 1, 3x3
+    x = a[0]
+    return int(x.shape[0]), int(x.shape[1]), int(a[3]), int(x.shape[2]), int(x.shape[3])
+
+
+def _wino_flops(a, k):
+    """The multiply-adds the kernel ISSUES: 16 per 2x2 output tile, input channel and output channel (a 7x7 plane has 4x4
+    tiles).  The direct sum of the same layer is 2.25 x that on even planes (_wino_direct_flops)."""
+    n, cin, cout, h, w = _wino_shape(a, k)
+    return 2.0 * 16 * n * ((h + 1) // 2) * ((w + 1) // 2) * cin * cout
+
+
+def _wino_direct_flops(a, k):
+    n, cin, cout, h, w = _wino_shape(a, k)
+    return 2.0 * n * cout * h * w * cin * 9
+
+
+def _wino_bytes(a, k):
+    n, cin, cout, h, w = _wino_shape(a, k)
+    return 4.0 * (a[0].numel() + a[1].numel() + n * cout * h * w * _out_copies(k))
 
 
 def mfma_f32_roofline(kernel, kt, note, form=None):
@@ -823,6 +845,8 @@ def main():
                 CallTimer(_native, "conv1x1_f32", _c1_bytes, _c1_flops) as kt_c1, \
                 CallTimer(_native, "conv_stem_f32", _stem_bytes, _stem_flops) as kt_st, \
                 CallTimer(_native, "conv_kxk_f32", _kxk_bytes, _kxk_flops) as kt_kk, \
+                CallTimer(_native, "conv_wino_f32", _wino_bytes, _wino_flops) as kt_wi, \
+                CallTimer(_native, "conv_wino_f32", _wino_bytes, _wino_direct_flops) as kt_wd, \
                 CallTimer(_native, "conv1x1_add_f32", _c1_add_bytes, _c1_flops, "absmax") as kt_ca, \
                 CallTimer(_native, "conv1x1_add_hist_f32", _c1_add_bytes, _c1_flops, "hist") as kt_cah:
             make_workdir(3 * world - 1, shape, dev_index)
@@ -830,6 +854,7 @@ def main():
             eq = Quantity(model)
             eq._activation_cache_budget = lambda: 0          # every batch through the second forward: all 69 producers fused
             kt_b.enabled = kt_a.enabled = kt_bh.enabled = kt_ah.enabled = kt_c1.enabled = kt_st.enabled = kt_kk.enabled = True
+            kt_wi.enabled = kt_wd.enabled = True
             kt_ca.enabled = kt_cah.enabled = True
             eq.activation_quantize(extra)
             torch.cuda.synchronize()
@@ -888,6 +913,22 @@ def main():
                     kk["pass1_absmax_form" if form == "absmax" else "pass2_hist_form"] = {
                         k: part[k] for k in ("achieved", "frac", "launches", "mean_launch_ms", "frac_of_bound")}
             result["roofline_conv_kxk_f32"] = kk
+        wi = mfma_f32_roofline(
+            "wino_f32_absmax_kernel / wino_f32_hist_kernel", kt_wi,
+            "the float forward's 13 stride-1 3x3 convolutions as Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32 (fq_conv3x3_wino_f32): "
+            "16 products per 2x2 tile instead of 36, input and output transforms in the kernel.  achieved / frac count the "
+            "multiply-adds the kernel issues (a 7x7 plane pays for 4x4 tiles); direct_equivalent_tflops is the direct sum's flop "
+            "count over the same time -- what fq_conv_kxk_f32 would have to reach -- and may exceed the matrix peak")
+        if wi:
+            for form in ("absmax", "hist"):
+                part = mfma_f32_roofline("", kt_wi, None, form)
+                if part:
+                    wi["pass1_absmax_form" if form == "absmax" else "pass2_hist_form"] = {
+                        k: part[k] for k in ("achieved", "frac", "launches", "mean_launch_ms", "frac_of_bound")}
+            wd = mfma_f32_roofline("", kt_wd, None)
+            if wd:
+                wi["direct_equivalent_tflops"] = wd["achieved"]
+            result["roofline_conv_wino_f32"] = wi
     except Exception as e:
         if world == 1:
             result["roofline_bias_add_absmax"] = {"error": repr(e)}

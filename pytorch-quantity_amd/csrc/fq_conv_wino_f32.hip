@@ -10,51 +10,59 @@
 // channel, t = tile), between an input transform (32 additions per tile and channel) and an output transform (24 per
 // tile and output channel).
 //
-// Mapping.  Workgroup = 4 waves = 64 output channels x 64 tiles (tiles are numbered through the whole batch:
-// t = (n * TH + ty) * TW + tx, so a 7x7 plane costs its 4x4 tiles and nothing else); a wave owns 32 x 32 of it for ALL
-// 16 positions: 16 accumulator tiles of v_mfma_f32_32x32x2_f32 = 256 registers -- one wave per SIMD, by construction.
-// With nobody else on the SIMD to cover a stall the K loop is a software pipeline over input channels in steps of 8:
+// Mapping.  Workgroup = 8 waves = 64 output channels x 64 tiles (tiles are numbered through the whole batch:
+// t = (n * TH + ty) * TW + tx, so a 7x7 plane costs its 4x4 tiles and nothing else).  A (32 channels x 32 tiles) block of
+// it with all 16 positions would be 16 accumulator tiles of v_mfma_f32_32x32x2_f32 = 256 registers, i.e. one wave per SIMD
+// with nobody to cover its stalls (built first: 84 % of the matrix cycles at best, scripts/mfma_f32_probe.hip).  So TWO
+// waves share a block, eight positions (two rows of the transformed 4x4 tile) each: 128 accumulators + 105 other registers
+// -> two waves per SIMD; the two meet once per work item, in the output transform (wino_epilogue).
+// A persistent grid, one workgroup per CU, work items k-block major: the workgroups an XCD runs at one time share one
+// 64-channel slice of U (<= 2 MB: its L2).  The K loop runs over input channels in steps of 8:
 //   * U (the transformed weights) never touches LDS: the host packs it (fq_conv3x3_wino_f32_pack) as
 //     [c / 8][e][c % 2][k][c % 8 / 2], so that the A operands of the four MFMAs of (step, e) are ONE 16-byte load per lane
 //     straight from L2 into the registers the MFMAs read; the load of step s + 1 is issued as soon as (step s, e) has
-//     issued its MFMAs -- a whole step (4 096 matrix cycles) of latency cover, no double buffer.  Work items are ordered
-//     k-block major, so the workgroups an XCD runs at one time share one 64-channel slice of U (<= 2 MB: its L2).
-//   * V is made in the kernel: thread = (tile, two input channels); 2 x 16 dword loads of the 4x4 input tile through a
-//     buffer descriptor (per-thread byte offsets computed once per work item, "outside the image" = an out-of-range
-//     offset that the address unit answers with zero; the channel is the scalar offset), the transform as 32 packed
-//     additions (v_pk_add_f32: the two channels ride in one instruction), 16 ds_write_b64 into the stage of step s + 1;
-//     the loads of step s + 2 follow at once.  Three 32 KB stages and one barrier per step, in the middle of it (the
-//     scheme of conv1x1_tiles): nothing is waited for at a step boundary.  B operands: one ds_read_b128 per (step, e).
-//   * Epilogue: the output transform in registers (the 16 positions of a (k, tile) pair sit in the same lane and the
-//     same register index of the 16 accumulator tiles), + bias, statistic, ReLU copy, 8-byte stores of the two pixels
-//     of a tile row (4-byte stores with per-pixel "exists" for odd H or W: 7x7).
+//     issued its MFMAs -- a whole step of latency cover, no double buffer.
+//   * V is made in the kernel: thread = (tile, input channel = its wave's number); four 16-byte loads of the rows of the
+//     4x4 input tile through a buffer descriptor (per-thread byte offsets computed once per work item; "row outside the
+//     image" = an out-of-range offset that the address unit answers with zero; the two edge columns are dropped by select;
+//     the channel is the scalar offset), 32 additions, 16 LDS writes into the stage of step s + 1; the loads of step s + 2
+//     follow at once.  Three 32 KB stages and one barrier per step, in the middle of it (the scheme of conv1x1_tiles):
+//     nothing is waited for at a step boundary.  B operands: one ds_read_b128 per (step, e).
+//   * Epilogue: the two waves of a block exchange one row of M through LDS and each makes one row of every 2x2 output
+//     tile: + bias, statistic, ReLU copy, one 8-byte store per tile row (4-byte stores with per-pixel "exists" for odd H or
+//     W: 7x7).
+// What was measured on the way (profiles/r04_conv_wino_*): every vector instruction between two MFMAs costs the matrix
+// pipe ~7 cycles whatever it does, so the input rows come as whole 16-byte loads (16 dword loads per tile and channel: 23 %
+// slower), the B operands as one read per (step, e), and the accumulators are copied out of the AGPRs where they are used.
 //
 // Numerics.  fp32 throughout; U is computed from the weights in fp64 and rounded once.  Per output: an fmaf chain over
-// c = 0 .. Cin-1 per position, then the fixed additions of the two transforms, then the bias.  Deterministic, batch-size
-// independent (no K split).  It is NOT the direct sum: |error| is about twice the direct kernel's (DESIGN.md section 4
-// states the measured bound) -- the reference's own GPU forward goes through the convolution library's Winograd kernels
-// for these layers, so no table ever depended on the direct order.
+// c = 0 .. Cin-1 per position, then the fixed additions of the two transforms, then the bias.  Deterministic and
+// batch-size independent (no K split, no workspace: an image computes the same bits wherever it sits in whatever batch).
+// It is NOT the direct sum: measured |error| <= 1.8e-7 of sum |w||x| on Gaussian data against 3.5e-7 for the direct kernel
+// (fewer terms per chain) -- the reference's own GPU forward goes through the convolution library's Winograd kernels for
+// these layers, so no table ever depended on the direct order.
 #include "fq_common.h"
 #include "fq_producer_stat.h"
 
 #ifndef FQ_WINO_ABLATE
-#define FQ_WINO_ABLATE 0      // debug builds only (make wino_ablate): 1 no x loads in the loop, 2 no U loads, 4 no transform, 8 no epilogue, 16 no MFMAs -- wrong results, timing only
+#define FQ_WINO_ABLATE 0      // debug builds only (make wino_ablate): 1 no x loads in the loop, 2 no U loads, 4 no transform, 8 no epilogue, 16 no MFMAs, 32 no barrier in the loop, 64 no B operand reads in the loop -- wrong results, timing only
 #endif
 #define FQ_WINO_OFF(bit) ((FQ_WINO_ABLATE) & (bit))
 
 namespace fq {
 namespace {
 
-constexpr int kT = 256;
+constexpr int kT = 512;                                      // 8 waves: two per SIMD
 constexpr unsigned kBT = 64;                                  // tiles per workgroup
 constexpr unsigned kBK = 64;                                  // output channels per workgroup
 constexpr unsigned kCS = 8;                                   // input channels per step
-// One stage of V: 16 positions of [c % 2][c % 8 / 2][tile 0..63] floats; the c % 2 = 1 half sits 128 bytes (32 banks) further
-// on, so that the two halves of a wave (lanes 0..31: c % 2 = 0, lanes 32..63: 1) read different banks, and a position takes a
-// whole number of 256-byte units (the offset unit of ds_read2st64_b32 / ds_write2st64_b32).
-constexpr unsigned kKkBytes = 4u * 256u + 128u;
-constexpr unsigned kPlane = 2304u;
-constexpr unsigned kStageBytes = 16u * kPlane;                // 36 KB
+// One stage of V: 16 positions of [c % 2][tile 0..63][c % 8 / 2] floats = 2 KB each: the B operands of the four MFMAs of a
+// (step, position) are ONE 16-byte LDS read per lane (lanes 0..31: c % 2 = 0, consecutive tiles; lanes 32..63: c % 2 = 1).
+// The transform's 4-byte writes go 16 bytes apart across the lanes of a wave (four lanes per bank): the LDS pipe has the time,
+// the instruction stream does not -- every vector instruction, whatever it does, takes ~7 cycles from the matrix pipe.
+constexpr unsigned kKkBytes = kBT * 16u;
+constexpr unsigned kPlane = 2u * kKkBytes;
+constexpr unsigned kStageBytes = 16u * kPlane;                // 32 KB
 constexpr unsigned kOob = 0x80000000u;                        // a byte offset no tensor of <= 2^31 bytes contains
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -81,11 +89,16 @@ __device__ __forceinline__ void stat_add_if(MaxStat& s, bool ok, float v) { s.ad
 template <bool kFast>
 __device__ __forceinline__ void stat_add_if(HistStat<kFast>& s, bool ok, float v) { if (ok) s.add(v); }
 
-// The output transform of one (k, tile) pair and what the epilogue contract asks for its four pixels.
+// The output transform  Y = At M A,  At = [1 1 1 0; 0 1 -1 -1]  (rows first, then columns), split between the two waves that
+// hold one (32 channels x 32 tiles) block: the wave with rows 0 and 1 of M (positions 0..7) makes output row 0 of every tile and
+// needs row 2 for it; the wave with rows 2 and 3 makes output row 1 and needs row 1.  So each hands ONE row of M (4 values per
+// (channel, tile) pair, 64 registers per lane, 16 bytes at a time) to the other through LDS -- in two rounds of 64 KB, in the
+// stages the K loop has finished with -- and each does half of the transform, the bias, the statistic and the stores.  The order of the additions
+// is that of the undivided transform: (m0 + m1) + m2 and (m1 - m2) - m3.
 // kEven: H and W even -- both pixels of a tile row exist together and the pair is 8-byte aligned.
 template <bool kEven, bool kRelu, bool kStream, typename Stat>
-__device__ __forceinline__ void wino_epilogue(const f16v (&acc)[16], const WArgs& a, Stat& stat, unsigned kbase, unsigned tbase,
-                                              unsigned r, unsigned h) {
+__device__ __forceinline__ void wino_epilogue(const f16v (&acc)[8], unsigned ph, unsigned wave, unsigned lane, char* smem, const WArgs& a,
+                                              Stat& stat, unsigned kbase, unsigned tbase, unsigned r, unsigned h) {
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y ? a.y : a.relu, 0, a.y ? a.y_bytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(kRelu ? a.relu : a.y, 0, a.y_bytes, 0x00020000);
     constexpr int aux = kStream ? 2 : 0;                      // nt
@@ -93,63 +106,65 @@ __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[16], const WArgs
     const bool tile_ok = t < a.tiles;
     const unsigned tc = tile_ok ? t : 0u;
     const unsigned n = tc / a.tiles_img, rem = tc - n * a.tiles_img, ty = rem / a.TW, tx = rem - ty * a.TW;
-    const unsigned oy = 2u * ty, ox = 2u * tx;
-    const unsigned off00 = (((n * a.Cout + kbase + 4u * h) * a.H + oy) * a.W + ox) * 4u;    // < 2^31 (host check)
-    const bool ok01 = tile_ok && (kEven || ox + 1u < a.W), ok10 = tile_ok && (kEven || oy + 1u < a.H), ok11 = ok01 && ok10;
-    const unsigned v00 = tile_ok ? off00 : kOob, v01 = ok01 ? off00 + 4u : kOob;
-    const unsigned v10 = ok10 ? off00 + a.W * 4u : kOob, v11 = ok11 ? off00 + a.W * 4u + 4u : kOob;
+    const unsigned oy = 2u * ty + ph, ox = 2u * tx;           // this wave's output row of the tile
+    const bool row_ok = tile_ok && (kEven || oy < a.H), px1_ok = row_ok && (kEven || ox + 1u < a.W);
+    const unsigned off0 = (((n * a.Cout + kbase + 4u * h) * a.H + oy) * a.W + ox) * 4u;     // < 2^31 (host check)
+    const unsigned v0 = row_ok ? off0 : kOob, v1 = px1_ok ? off0 + 4u : kOob;
     f4v b4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         b4[q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + kbase + 8u * q + 4u * h) : f4v{0.f, 0.f, 0.f, 0.f};
+    f4v* const mine = reinterpret_cast<f4v*>(smem) + wave * 64u + lane;                 // + slot * 512: [slot][wave][lane], 16 bytes each
+    const f4v* const theirs = reinterpret_cast<const f4v*>(smem) + (wave ^ 4u) * 64u + lane;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const unsigned dm = (e & 3) + 8u * (e >> 2);          // row of this register within the wave's 32 (+ 4 h: in off00)
-        const int row4 = (int)(dm * a.HW * 4u);               // uniform
-        // At M A,  At = [1 1 1 0; 0 1 -1 -1]: rows first, then columns
-        // (the accumulators live in AGPRs; they are copied out HERE, sixteen at a time -- left to itself the compiler copies all
-        //  256 at the end of the K loop, in front of the branch that picks the epilogue, and spills to make room)
-        float m[16];
+    for (int pass = 0; pass < 2; ++pass) {
+        // (the accumulators live in AGPRs and are copied out where they are used -- left to itself the compiler copies all of
+        //  them at the end of the K loop, in front of the branch that picks the epilogue, and spills to make room)
+        __syncthreads();                                      // the K loop / the previous round is done with this memory
 #pragma unroll
-        for (int q = 0; q < 16; ++q) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(m[q]) : "a"(acc[q][e]));
-        float t0[4], t1[4];
+        for (int e = 0; e < 8; ++e) {
+            f4v v;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t0[c] = (m[c] + m[4 + c]) + m[8 + c];
-            t1[c] = (m[4 + c] - m[8 + c]) - m[12 + c];
-        }
-        const float bias = b4[e >> 2][e & 3];
-        float o[4];
-        o[0] = ((t0[0] + t0[1]) + t0[2]) + bias;
-        o[1] = ((t0[1] - t0[2]) - t0[3]) + bias;
-        o[2] = ((t1[0] + t1[1]) + t1[2]) + bias;
-        o[3] = ((t1[1] - t1[2]) - t1[3]) + bias;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = stat_map(stat, o[i]);
-        if (kEven) {
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{o[0], o[1]}), yrs, (int)v00, row4, aux);
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{o[2], o[3]}), yrs, (int)v10, row4, aux);
-            if (kRelu) {
-                __builtin_amdgcn_raw_buffer_store_b64(
-                    __builtin_bit_cast(u2v, f2v{relu_like_torch(o[0]), relu_like_torch(o[1])}), rrs, (int)v00, row4, aux);
-                __builtin_amdgcn_raw_buffer_store_b64(
-                    __builtin_bit_cast(u2v, f2v{relu_like_torch(o[2]), relu_like_torch(o[3])}), rrs, (int)v10, row4, aux);
+            for (int c = 0; c < 4; ++c) {
+                if (ph == 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[4 + c][8 * pass + e]));   // row 1
+                else asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[c][8 * pass + e]));              // row 2
             }
-        } else {
-            const unsigned vo[4] = {v00, v01, v10, v11};
+            mine[e * 512] = v;
+        }
+        __syncthreads();
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[i]), yrs, (int)vo[i], row4, aux);
+        for (int e8 = 0; e8 < 8; ++e8) {
+            const int e = 8 * pass + e8;
+            const unsigned dm = (e & 3) + 8u * (e >> 2);      // row of this register within the wave's 32 (+ 4 h: in off0)
+            const int row4 = (int)(dm * a.HW * 4u);           // uniform
+            const f4v got = theirs[e8 * 512];
+            float lo[4], hi[4], tc4[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo[c]) : "a"(acc[c][e]));
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi[c]) : "a"(acc[4 + c][e]));
+                tc4[c] = ph == 0 ? (lo[c] + hi[c]) + got[c] : (got[c] - lo[c]) - hi[c];
+            }
+            const float bias = b4[e >> 2][e & 3];
+            float o0 = ((tc4[0] + tc4[1]) + tc4[2]) + bias, o1 = ((tc4[1] - tc4[2]) - tc4[3]) + bias;
+            o0 = stat_map(stat, o0); o1 = stat_map(stat, o1);
+            if (kEven) {
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{o0, o1}), yrs, (int)v0, row4, aux);
                 if (kRelu)
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(o[i])), rrs, (int)vo[i], row4, aux);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{relu_like_torch(o0), relu_like_torch(o1)}), rrs, (int)v0, row4, aux);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o0), yrs, (int)v0, row4, aux);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o1), yrs, (int)v1, row4, aux);
+                if (kRelu) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(o0)), rrs, (int)v0, row4, aux);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(o1)), rrs, (int)v1, row4, aux);
+                }
             }
+            stat_add_if(stat, row_ok, o0);
+            stat_add_if(stat, px1_ok, o1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        stat_add_if(stat, tile_ok, o[0]);
-        stat_add_if(stat, ok01, o[1]);
-        stat_add_if(stat, ok10, o[2]);
-        stat_add_if(stat, ok11, o[3]);
-        __builtin_amdgcn_sched_barrier(0);                    // (one register index at a time: left alone the compiler copies all 256
-    }                                                         //  accumulators out of the AGPRs first and spills to make room)
+    }
 }
 
 // What the transform role needs to know about its tile of one work item: the byte offset of the first pixel of each of its
@@ -182,164 +197,109 @@ __device__ __forceinline__ TileIn tile_in(const WArgs& a, unsigned tb, unsigned 
     return t;
 }
 
-__device__ __forceinline__ TileIn pick(bool second, const TileIn& a, const TileIn& b) {   // (second is uniform)
-    TileIn t;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) t.xo[i] = second ? b.xo[i] : a.xo[i];
-    t.c0ok = second ? b.c0ok : a.c0ok; t.c2ok = second ? b.c2ok : a.c2ok; t.c3ok = second ? b.c3ok : a.c3ok;
-    t.shift1 = second ? b.shift1 : a.shift1;
-    return t;
-}
-
 template <bool kOddW, typename Stat>
 __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* smem) {
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned r = lane & 31u, h = lane >> 5;
-    const unsigned wk = wave >> 1, wt = wave & 1u;            // the MFMA role: which 32 channels x 32 tiles
-    const unsigned tkk = wave & 1u, thalf = wave >> 1;        // the transform role: channels tkk + 4 thalf and + 2 of a step
+    // the MFMA role: block sp = (32 channels wk, 32 tiles wt) of the workgroup's 64 x 64, positions 8 ph .. 8 ph + 7
+    const unsigned sp = wave & 3u, ph = wave >> 2, wk = sp >> 1, wt = sp & 1u;
+    // the transform role: input channel `wave` of the step, tile `lane`
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
-    const unsigned vrd = h * kKkBytes + (wt * 32u + r) * 4u;  // B operand reads:  + stage + e * kPlane + ks * 256
-    const unsigned vwr = tkk * kKkBytes + 2u * thalf * 256u + lane * 4u;   // transform writes: + stage + e * kPlane (+ 256: the second channel)
-    const unsigned nsteps = a.Cin / kCS;                      // >= 2 (host check): the pipeline looks two steps ahead, at most into the next item
+    const unsigned vrd = h * kKkBytes + (wt * 32u + r) * 16u + ph * 8u * kPlane;       // B operand reads:  + stage + e * kPlane
+    const unsigned vwr = (wave & 1u) * kKkBytes + lane * 16u + (wave >> 1) * 4u;       // transform writes: + stage + e * kPlane
+    const unsigned nsteps = a.Cin / kCS;
     const unsigned upos = 2u * a.Cout * 16u;                  // bytes of one position's slice of a step of U
-    const unsigned uvo = (h * a.Cout + wk * 32u + r) * 16u;   // + kb * 64 * 16 (in the scalar offset)
+    const unsigned uvo = (h * a.Cout + wk * 32u + r) * 16u;   // + (step, position, k-block): the scalar offset
     // Workgroup g runs on XCD g % 8: give an XCD a contiguous run of work items (k-block major: one slice of U per XCD at a time)
     const unsigned G = gridDim.x, G8 = G & ~7u, g = blockIdx.x;
     const unsigned v0 = g < G8 ? (g & 7u) * (G8 >> 3) + (g >> 3) : g;
-    if (v0 >= a.work) return;
 
-    f4v d0[4], d1[4];                                         // the two channels' input tiles of the step being loaded, row by row
-    auto xload = [&](const TileIn& t, unsigned s) {
-        const unsigned c0 = s * kCS + tkk + 4u * thalf;
-        const int s0 = (int)(c0 * a.HW * 4u), s1 = (int)((c0 + 2u) * a.HW * 4u);
+    for (unsigned wi = v0; wi < a.work; wi += G) {
+        const unsigned kb = wi / a.tiles_t, tb = wi - kb * a.tiles_t;
+        const TileIn ti = tile_in(a, tb, lane);
+        f4v d[4];                                             // this thread's input tile of the step being loaded, row by row
+        auto xload = [&](unsigned s) {
+            const int so = (int)((s * kCS + wave) * a.HW * 4u);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            d0[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)t.xo[i], s0, 0));
-            d1[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)t.xo[i], s1, 0));
-        }
-    };
-    // Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
-    auto transform = [&](const TileIn& ti, f4v (&d)[4], float (&v)[16]) {
-        d[1] = ti.shift1 ? f4v{0.0f, d[1][0], d[1][1], d[1][2]} : d[1];
+            for (int i = 0; i < 4; ++i) d[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)ti.xo[i], so, 0));
+        };
+        // Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
+        auto transform_store = [&](unsigned stage_off) {
+            if (tb == 0u) d[1] = ti.shift1 ? f4v{0.0f, d[1][0], d[1][1], d[1][2]} : d[1];     // (uniform: the block that holds tile 0)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            d[i][0] = ti.c0ok ? d[i][0] : 0.0f;
-            d[i][3] = ti.c3ok ? d[i][3] : 0.0f;
-        }
-        if (kOddW) {
+            for (int i = 0; i < 4; ++i) {
+                d[i][0] = ti.c0ok ? d[i][0] : 0.0f;
+                d[i][3] = ti.c3ok ? d[i][3] : 0.0f;
+            }
+            if (kOddW) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) d[i][2] = ti.c2ok ? d[i][2] : 0.0f;
-        }
-        const f4v t0 = d[0] - d[2], t1 = d[1] + d[2], t2 = d[2] - d[1], t3 = d[1] - d[3];
-        const f4v t[4] = {t0, t1, t2, t3};
+                for (int i = 0; i < 4; ++i) d[i][2] = ti.c2ok ? d[i][2] : 0.0f;
+            }
+            const f4v t0 = d[0] - d[2], t1 = d[1] + d[2], t2 = d[2] - d[1], t3 = d[1] - d[3];
+            const f4v t[4] = {t0, t1, t2, t3};
+            char* const w = smem + stage_off + vwr;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[4 * i] = t[i][0] - t[i][2];
-            v[4 * i + 1] = t[i][1] + t[i][2];
-            v[4 * i + 2] = t[i][2] - t[i][1];
-            v[4 * i + 3] = t[i][1] - t[i][3];
-        }
-    };
-    auto transform_store = [&](const TileIn& ti, unsigned stage_off) {
-        float va[16], vb[16];
-        transform(ti, d0, va);
-        transform(ti, d1, vb);
-        char* const w = smem + stage_off + vwr;
+            for (int i = 0; i < 4; ++i) {
+                *reinterpret_cast<float*>(w + (unsigned)(4 * i) * kPlane) = t[i][0] - t[i][2];
+                *reinterpret_cast<float*>(w + (unsigned)(4 * i + 1) * kPlane) = t[i][1] + t[i][2];
+                *reinterpret_cast<float*>(w + (unsigned)(4 * i + 2) * kPlane) = t[i][2] - t[i][1];
+                *reinterpret_cast<float*>(w + (unsigned)(4 * i + 3) * kPlane) = t[i][1] - t[i][3];
+            }
+        };
+        f4v ua[8];                                            // A operands of the current step: [position][k pair of the step]
+        auto uload = [&](int e, unsigned s) {
+            ua[e] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(
+                urs, (int)uvo, (int)((s * 16u + 8u * ph + (unsigned)e) * upos + kb * (kBK * 16u)), 0));
+        };
+        f4v bq[2][4];                                         // B operands: [half of the step][position % 4][k pair]
+        auto bload = [&](int half, unsigned stage_off, int e0) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            *reinterpret_cast<float*>(w + (unsigned)e * kPlane) = va[e];
-            *reinterpret_cast<float*>(w + (unsigned)e * kPlane + 256u) = vb[e];
-        }
-    };
-    f4v ua[16];                                               // A operands of the current step: [e][k pair of the step]
-    auto uload = [&](int e, unsigned s, unsigned kb) {
-        ua[e] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(urs, (int)uvo, (int)((s * 16u + (unsigned)e) * upos + kb * (kBK * 16u)), 0));
-    };
-    float bq[2][8][4];                                        // B operands: [half of the step][e % 8][k pair]
-    auto bload = [&](int half, unsigned stage_off, int e0) {
+            for (int e = 0; e < 4; ++e) bq[half][e] = *reinterpret_cast<const f4v*>(smem + stage_off + vrd + (unsigned)(e0 + e) * kPlane);
+        };
+        f16v acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                bq[half][e][k] = *reinterpret_cast<const float*>(smem + stage_off + vrd + (unsigned)(e0 + e) * kPlane + (unsigned)k * 256u);
-    };
-    f16v acc[16];
-    auto mfma_half = [&](int half, int e0, unsigned sn, unsigned kbn) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                if (!FQ_WINO_OFF(16)) acc[e0 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e0 + e][k], bq[half][e][k], acc[e0 + e], 0, 0, 0);
-                else acc[e0 + e][k] += ua[e0 + e][k] * bq[half][e][k];
-            }
-        if (!FQ_WINO_OFF(2)) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) uload(e0 + e, sn, kbn);
-        }
-    };
-
-    // ONE pipeline over all (work item, step) pairs of this workgroup: in step s of an item the U operands of the following
-    // step are loaded, the x tile of the step after that, and the tile in between is transformed -- and "the following step"
-    // of an item's last step is step 0 of the workgroup's NEXT item, so the matrix pipe goes from the last MFMA of one item
-    // into the epilogue and from there straight into the first MFMA of the next, whose operands are already there: its loads
-    // were issued before the epilogue's stores (on this architecture a load issued behind a store cannot be waited for without
-    // waiting for the store).  The loads are issued in the same order everywhere -- x, then U -- because the wait counts the
-    // compiler puts into the loop are the minimum over all ways into it.  The last item of a workgroup "looks ahead" into
-    // itself: loads and a transform nobody uses, instead of a branch (a branch makes every s_waitcnt behind it assume the
-    // shorter path).
-    unsigned wi = v0;
-    unsigned kb = wi / a.tiles_t, tb = wi - kb * a.tiles_t;
-    TileIn tcur = tile_in(a, tb, lane);
-    xload(tcur, 0);
-    transform_store(tcur, 0u);
-    xload(tcur, 1);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) uload(e, 0, kb);
-    __syncthreads();
-    bload(0, 0u, 0);
-    unsigned cur = 0;                                         // byte offset of the stage the current step multiplies out of
-    for (;;) {
-        const unsigned wn = wi + G;
-        const bool has_next = wn < a.work;                    // uniform
-        const unsigned wnc = has_next ? wn : wi;
-        const unsigned kbn = wnc / a.tiles_t, tbn = wnc - kbn * a.tiles_t;
-        const TileIn tnext = tile_in(a, tbn, lane);
-#pragma unroll
-        for (int e = 0; e < 16; ++e)
-#pragma unroll
             for (int i = 0; i < 16; ++i) acc[e][i] = 0.0f;
+        auto mfma_half = [&](int half, int e0, unsigned sn) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (!FQ_WINO_OFF(16)) acc[e0 + e] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[e0 + e][k], bq[half][e][k], acc[e0 + e], 0, 0, 0);
+                    else acc[e0 + e][k] += ua[e0 + e][k] * bq[half][e][k];
+                }
+            if (!FQ_WINO_OFF(2)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) uload(e0 + e, sn);
+            }
+        };
+
+        // (the loads are issued in the order a step of the loop leaves them in -- x, then U: the wait counts the compiler puts
+        //  into the loop are the minimum over both ways into it, and a prologue that issued x last made every step wait for all)
+        xload(0);
+        transform_store(0u);
+        xload(nsteps > 1 ? 1u : 0u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) uload(e, 0);
+        __syncthreads();
+        bload(0, 0u, 0);
+        if (FQ_WINO_OFF(64)) bload(1, 0u, 4);
+        unsigned cur = 0;                                     // byte offset of the stage step s multiplies out of
         for (unsigned s = 0; s < nsteps; ++s) {
             const unsigned nxt = cur == 2u * kStageBytes ? 0u : cur + kStageBytes;
-            const bool last1 = s + 1 >= nsteps, last2 = s + 2 >= nsteps;          // uniform
-            const unsigned s1 = last1 ? 0u : s + 1, s2 = last2 ? s + 2 - nsteps : s + 2;
-            const unsigned kb1 = last1 ? kbn : kb;
-            bload(1, cur, 8);                                 // the second half's B operands, under the first half's MFMAs
-            mfma_half(0, 0, s1, kb1);
-            if (!FQ_WINO_OFF(4)) transform_store(pick(last1, tcur, tnext), nxt);
-            if (!FQ_WINO_OFF(1)) xload(pick(last2, tcur, tnext), s2);
-            // The wave is alone on its SIMD and issues in order: whatever stands between two MFMAs for longer than an MFMA runs
-            // (64 cycles) leaves the matrix pipe idle.  Left alone the compiler puts the ~100 vector instructions of the transform
-            // in one lump with four MFMAs in it; this asks for one MFMA, then at most four vector instructions and one LDS / one
-            // memory instruction, 32 times.
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-                if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-                if (i & 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-            __syncthreads();
-            bload(0, nxt, 0);                                 // the following step's first half, under this step's second
-            mfma_half(1, 8, s1, kb1);
-#pragma unroll
-            for (int i = 0; i < 32; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
+            const unsigned sn = s + 1 < nsteps ? s + 1 : s;   // (the last step re-reads its own slice of U and re-transforms a step nobody
+                                                              //  reads: no branch in the loop -- a branch makes every s_waitcnt behind it
+                                                              //  assume the shorter path and wait for loads that were only just issued)
+            if (!FQ_WINO_OFF(64)) bload(1, cur, 4);           // the second half's B operands, under the first half's MFMAs
+            mfma_half(0, 0, sn);
+            if (!FQ_WINO_OFF(4)) transform_store(nxt);
+            if (!FQ_WINO_OFF(1)) xload(s + 2 < nsteps ? s + 2 : s);
+            if (!FQ_WINO_OFF(32)) __syncthreads();
+            if (!FQ_WINO_OFF(64)) bload(0, nxt, 0);           // the next step's first half, under this step's second
+            mfma_half(1, 4, sn);
             cur = nxt;
         }
         const unsigned kbase = kb * kBK + wk * 32u, tbase = tb * kBT + wt * 32u;
@@ -347,11 +307,11 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
         //  recogniser does not see into: the wait states between the last MFMA and the first copy are put here by hand)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         const bool even = ((a.H | a.W) & 1u) == 0u;           // uniform
-#define FQ_WINO_EPI(E, R, S) wino_epilogue<E, R, S>(acc, a, stat, kbase, tbase, r, h)
+#define FQ_WINO_EPI(E, R, S) wino_epilogue<E, R, S>(acc, ph, wave, lane, smem, a, stat, kbase, tbase, r, h)
         if (FQ_WINO_OFF(8)) {
             float sum = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
+            for (int e = 0; e < 8; ++e)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) sum += acc[e][i];
             if (sum == 12345.678f) a.y[0] = sum;
@@ -362,20 +322,19 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
             if (a.relu) FQ_WINO_EPI(false, true, false); else FQ_WINO_EPI(false, false, false);
         }
 #undef FQ_WINO_EPI
-        if (!has_next) break;
-        wi = wn; kb = kbn; tb = tbn; tcur = tnext;
+        __syncthreads();                                      // the next work item overwrites stage 0 (the exchange area)
     }
 }
 
 constexpr unsigned kLdsBytes = 3u * kStageBytes;
 
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_kernel(const WArgs a) {
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_kernel(const WArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     NoStat st;
     if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
 }
 
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_absmax_kernel(const WArgs a, unsigned int* __restrict__ max_bits) {
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_absmax_kernel(const WArgs a, unsigned int* __restrict__ max_bits) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     MaxStat st;
     if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
@@ -383,7 +342,7 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 }
 
 // (every workgroup flushes its 2048 LDS bins with 64-bit atomics at its end)
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_f32_hist_kernel(
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_hist_kernel(
     const WArgs a, const float* __restrict__ interval, unsigned long long* __restrict__ hist_row, const int allow_fast) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     __shared__ unsigned int s_bins[FQ_BINS + kWave];
@@ -429,7 +388,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 
 bool wino_shape_ok(int N, int Cin, int Hin, int Win, int Cout) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0) return false;
-    if ((Cin % (int)kCS) != 0 || Cin < 2 * (int)kCS || (Cout % (int)kBK) != 0) return false;
+    if ((Cin % (int)kCS) != 0 || (Cout % (int)kBK) != 0) return false;
     const size_t in_bytes = (size_t)N * Cin * Hin * Win * 4, out_bytes = (size_t)N * Cout * Hin * Win * 4;
     const size_t tiles = (size_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2);
     return in_bytes < (1ULL << 31) && out_bytes < (1ULL << 31) && (size_t)Cin * Cout * 64 < (1ULL << 31) && tiles < (1ULL << 30);

@@ -18,7 +18,7 @@ def main():
     sys.stdout, out = open(os.devnull, "w"), sys.stdout
     model = bench.build_model("r50", 224, dev)
     sys.stdout = out
-    names = ["conv_stem_f32", "conv1x1_f32", "conv_kxk_f32", "conv1x1_add_f32", "conv1x1_add_hist_f32", "add_absmax", "add_hist",
+    names = ["conv_stem_f32", "conv1x1_f32", "conv_kxk_f32", "conv_wino_f32", "conv1x1_add_f32", "conv1x1_add_hist_f32", "add_absmax", "add_hist",
              "bias_add_absmax", "maxpool2d_f32", "avgpool_global_f32", "absmax_seg", "hist2048_seg"]
     rows, on = [], {"v": False}
 
@@ -41,6 +41,9 @@ def main():
             elif name == "conv_kxk_f32":
                 fl, by = bench._kxk_flops(a, k), bench._kxk_bytes(a, k)
                 desc = "%dx%dx%dx%d -> %d k%d s%d" % (tuple(x.shape) + (a[1].shape[1], a[3][0], a[4]))
+            elif name == "conv_wino_f32":                       # (TFLOP/s: the direct sum's flop count over the kernel's time)
+                fl, by = bench._wino_direct_flops(a, k), bench._wino_bytes(a, k)
+                desc = "%dx%dx%dx%d -> %d k3 s1 winograd" % (tuple(x.shape) + (a[3],))
             elif name == "conv_stem_f32":
                 fl, by = bench._stem_flops(a, k), bench._stem_bytes(a, k)
                 desc = "%dx%dx%dx%d -> %d" % (tuple(x.shape) + (a[3],))

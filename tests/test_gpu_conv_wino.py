@@ -20,9 +20,9 @@ SHAPES = [
     (3, 128, 128, 28, 28),        # layer2: two k-blocks
     (5, 256, 256, 14, 14),        # layer3: 7x7 tiles per image, 245 tiles = 3.8 blocks
     (4, 512, 512, 7, 7),          # layer4: odd plane, 4x4 tiles with a missing row and column; 64 tiles = one block
-    (3, 16, 64, 5, 9),            # two steps (the fewest the pipeline takes); odd both ways
+    (3, 8, 64, 5, 9),             # one step; odd both ways
     (70, 16, 128, 1, 1),          # 1x1 planes: one tile per image, three of its four pixels missing, eight taps padding
-    (1, 16, 64, 2, 3),            # a single partial block
+    (1, 8, 64, 2, 3),             # a single partial block
     (7, 24, 64, 13, 6),           # three steps, odd height
     (33, 16, 192, 10, 10),        # 825 tiles = 12.9 blocks x 3 k-blocks: more work items than one round of a persistent grid
     (2, 40, 64, 6, 20),           # wide plane
@@ -148,7 +148,6 @@ def test_argument_errors(nat):
     assert ok(P(x), P(u), None, P(y), None, 1, 16, 4, 4, 64, None, None, None, None) == 0
     assert ok(P(x), P(u), None, P(y), None, 0, 16, 4, 4, 64, None, None, None, None) == 0          # no images: nothing to do
     assert ok(P(x), P(u), None, P(y), None, 1, 12, 4, 4, 64, None, None, None, None) == -4         # Cin % 8
-    assert ok(P(x), P(u), None, P(y), None, 1, 8, 4, 4, 64, None, None, None, None) == -4          # Cin < 16: the pipeline needs two steps
     assert ok(P(x), P(u), None, P(y), None, 1, 16, 4, 4, 32, None, None, None, None) == -4         # Cout % 64
     assert ok(P(x), P(u) + 4, None, P(y), None, 1, 16, 4, 4, 64, None, None, None, None) == -4     # u not 16-byte aligned
     assert ok(P(x), P(u), None, None, None, 1, 16, 4, 4, 64, None, None, None, None) == -1         # neither y nor relu_out
@@ -160,7 +159,7 @@ def test_argument_errors(nat):
     assert L.fq_conv3x3_wino_f32_supported(1024, 256, 56, 56, 256) == 0                            # x beyond 2^31 bytes
     assert L.fq_conv3x3_wino_f32_pack(None, P(u), 8, 64, None) == -1
     assert L.fq_conv3x3_wino_f32_pack(P(x), P(u), 4, 64, None) == -4
-    assert L.fq_conv3x3_wino_f32_supported(4, 8, 8, 8, 64) == 0 and L.fq_conv3x3_wino_f32_supported(4, 16, 8, 8, 64) == 1
+    assert L.fq_conv3x3_wino_f32_supported(4, 12, 8, 8, 64) == 0 and L.fq_conv3x3_wino_f32_supported(4, 8, 8, 8, 64) == 1
 
 
 def test_resnet50_tables_do_not_depend_on_the_3x3_kernel(monkeypatch):
