@@ -273,13 +273,15 @@ int fq_conv_stem_f32(const float* x, const float* wp, const float* bias, float* 
  * with QuanDequan(bit) applied to each value as it leaves the accumulator,
  *   y = clamp(rint((conv(x) + bias) * 2^bit), lo, hi) / 2^bit,   [lo, hi] = the integer range of bitwidth (8 or 16),
  * instead of the reference's two passes (the convolution's store, then an 8 B/element read-modify-write).  The value
- * QuanDequan sees is exactly what fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32 would have stored, so the result equals
+ * QuanDequan sees is exactly what fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv3x3_wino_f32 / fq_conv_stem_f32 would have stored, so the result equals
  * fq_quandequan_f32 of their output bit for bit.  Same operand contracts as the plain entry points. */
 int fq_conv1x1_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
                       int Cout, int stride, int bit, int bitwidth, void* workspace, size_t workspace_bytes, fq_stream_t stream);
 int fq_conv_kxk_qd_f32(const float* x, const float* wt, const float* bias, float* y, int N, int Cin, int Hin, int Win,
                        int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, void* workspace,
                        size_t workspace_bytes, fq_stream_t stream);
+int fq_conv3x3_wino_qd_f32(const float* x, const float* u, const float* bias, float* y, int N, int Cin, int Hin, int Win, int Cout,
+                           int bit, int bitwidth, fq_stream_t stream);     /* (fq_conv3x3_wino_f32's operands and limits) */
 int fq_conv_stem_qd_f32(const float* x, const float* wp, const float* bias, float* y, int N, int Cin, int H, int W,
                         int Cout, int R, int S, int stride, int pad, int bit, int bitwidth, fq_stream_t stream);
 

@@ -85,6 +85,7 @@ struct NoStat {
 };
 
 __device__ __forceinline__ void stat_add_if(NoStat&, bool, float) {}
+__device__ __forceinline__ void stat_add_if(QdStat&, bool, float) {}
 __device__ __forceinline__ void stat_add_if(MaxStat& s, bool ok, float v) { s.add(ok ? v : 0.0f); }
 template <bool kFast>
 __device__ __forceinline__ void stat_add_if(HistStat<kFast>& s, bool ok, float v) { if (ok) s.add(v); }
@@ -341,6 +342,13 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     publish_max<kT>(st.m, max_bits);
 }
 
+// TestConv's forward in one kernel (new_quantity_op.py:283-292): QuanDequan where the value leaves the output transform
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_qd_kernel(const WArgs a, const QdStat qd) {
+    extern __shared__ __attribute__((aligned(16))) char wino_smem[];
+    QdStat st = qd;
+    if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
+}
+
 // (every workgroup flushes its 2048 LDS bins with 64-bit atomics at its end)
 __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_hist_kernel(
     const WArgs a, const float* __restrict__ interval, unsigned long long* __restrict__ hist_row, const int allow_fast) {
@@ -414,9 +422,8 @@ extern "C" int fq_conv3x3_wino_f32_pack(const float* w_kcrs, float* u, int Cin, 
     return FQ_OK;
 }
 
-extern "C" int fq_conv3x3_wino_f32(const float* x, const float* u, const float* bias, float* y, float* relu_out, int N, int Cin,
-                                   int Hin, int Win, int Cout, float* max_inout, const float* interval, int64_t* hist_row,
-                                   fq_stream_t stream) {
+static int wino_launch(const float* x, const float* u, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin, int Win,
+                       int Cout, float* max_inout, const float* interval, int64_t* hist_row, const QdStat* qd, fq_stream_t stream) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0) return FQ_ERR_INVALID_ARG;
     if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
     if (hist_row && !interval) return FQ_ERR_INVALID_ARG;
@@ -439,8 +446,11 @@ extern "C" int fq_conv3x3_wino_f32(const float* x, const float* u, const float* 
     // A persistent grid, one workgroup per CU (that is all the registers allow), each taking every 256th work item: measured
     // 5 % faster than one workgroup per item at 784 items, and the histogram form needs it anyway (one flush per workgroup).
     const unsigned grid = a.work < (unsigned)kCUs ? a.work : (unsigned)kCUs;
-    static bool done_plain[kMaxDevices], done_max[kMaxDevices], done_hist[kMaxDevices];
-    if (hist_row) {
+    static bool done_plain[kMaxDevices], done_max[kMaxDevices], done_hist[kMaxDevices], done_qd[kMaxDevices];
+    if (qd) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_qd_kernel), (int)kLdsBytes, done_qd)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL(wino_f32_qd_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a, *qd);
+    } else if (hist_row) {
         if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_hist_kernel), (int)kLdsBytes, done_hist)) return FQ_ERR_HIP;
         static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
         hipLaunchKernelGGL(wino_f32_hist_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a, interval,
@@ -454,4 +464,22 @@ extern "C" int fq_conv3x3_wino_f32(const float* x, const float* u, const float* 
     }
     FQ_LAUNCH_CHECK();
     return FQ_OK;
+}
+
+extern "C" int fq_conv3x3_wino_f32(const float* x, const float* u, const float* bias, float* y, float* relu_out, int N, int Cin,
+                                   int Hin, int Win, int Cout, float* max_inout, const float* interval, int64_t* hist_row,
+                                   fq_stream_t stream) {
+    return wino_launch(x, u, bias, y, relu_out, N, Cin, Hin, Win, Cout, max_inout, interval, hist_row, nullptr, stream);
+}
+
+// TestConv.forward (new_quantity_op.py:283-292) on a stride-1 3x3 layer in one kernel: y = QuanDequan(conv(x) + bias, bit).  The value
+// QuanDequan sees is the kernel's own sum -- the one fq_conv3x3_wino_f32 would have stored -- so the result equals
+// fq_quandequan_f32 of its output bit for bit.
+extern "C" int fq_conv3x3_wino_qd_f32(const float* x, const float* u, const float* bias, float* y, int N, int Cin, int Hin, int Win,
+                                      int Cout, int bit, int bitwidth, fq_stream_t stream) {
+    if ((bitwidth != 8 && bitwidth != 16) || bit < -120 || bit > 120 || !y) return FQ_ERR_INVALID_ARG;
+    QdStat qd;
+    qd.scale = ldexpf(1.0f, bit); qd.inv = ldexpf(1.0f, -bit);
+    qd.lo = bitwidth == 8 ? -128.0f : -32768.0f; qd.hi = bitwidth == 8 ? 127.0f : 32767.0f;
+    return wino_launch(x, u, bias, y, nullptr, N, Cin, Hin, Win, Cout, nullptr, nullptr, nullptr, &qd, stream);
 }

@@ -53,11 +53,11 @@ def enabled():
     return os.environ.get("FQ_OWN_CONV1X1", "1") != "0"
 
 
-def kind(m, x, wino=False):
-    """"c1" (fq_conv1x1_f32), "kxk" (fq_conv_kxk_f32), "wino" (fq_conv3x3_wino_f32), "stem" (fq_conv_stem_f32) or None: which
-    own kernel takes this call of the nn.Conv2d m.  "wino" -- the Winograd form of the stride-1 3x3 layers -- is handed out only
-    to callers that ask for it (the calibration forward): TestConv's two forms (fused with QuanDequan, or not when somebody
-    watches the module) must agree bit for bit, and only the direct kernel has both."""
+def kind(m, x, wino=True):
+    """"c1" (fq_conv1x1_f32), "kxk" (fq_conv_kxk_f32), "wino" (fq_conv3x3_wino_f32: the Winograd form of the stride-1 3x3
+    layers; wino=False or FQ_CONV_WINO=0 keeps them on "kxk"), "stem" (fq_conv_stem_f32) or None: which own kernel takes this call
+    of the nn.Conv2d m.  Every kind has the plain, the statistic and the QuanDequan form, so TestConv's two ways through a layer
+    (fused with QuanDequan, or not when somebody watches the module) see the same sums."""
     if (not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or m.weight.dtype != torch.float32 or m.bias is None
             or is_off(m) or m.groups != 1 or m.dilation != (1, 1) or m.stride[0] != m.stride[1] or x.dim() != 4
             or not x.is_contiguous() or isinstance(m.padding, str) or m.padding[0] != m.padding[1] or m.padding_mode != "zeros"

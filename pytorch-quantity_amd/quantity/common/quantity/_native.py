@@ -112,6 +112,8 @@ def lib():
     L.fq_conv3x3_wino_f32_pack.argtypes = [vp, vp, ci, ci, vp]
     L.fq_conv3x3_wino_f32.restype = ci
     L.fq_conv3x3_wino_f32.argtypes = [vp, vp, vp, vp, vp] + [ci] * 5 + [vp, vp, vp, vp]
+    L.fq_conv3x3_wino_qd_f32.restype = ci
+    L.fq_conv3x3_wino_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 7 + [vp]
     L.fq_conv_stem_f32_packed_rows.restype = ci
     L.fq_conv_stem_f32_packed_rows.argtypes = [ci, ci, ci]
     L.fq_conv_stem_f32.restype = ci
@@ -546,7 +548,7 @@ def pack_wino_weight(weight):
     return u
 
 
-def conv_wino_f32(x, u, bias, cout, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None, out=None):
+def conv_wino_f32(x, u, bias, cout, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None, out=None, qd=None):
     """fq_conv3x3_wino_f32: the stride-1, pad-1 3x3 float convolution of x [N, Cin, H, W] with the weights packed by
     pack_wino_weight; statistics / relu_out / out as in conv1x1_f32.  Returns y."""
     _need_cuda(x, torch.float32, "fq_conv3x3_wino_f32")
@@ -565,6 +567,11 @@ def conv_wino_f32(x, u, bias, cout, max_dev=None, interval_dev=None, hist_dev=No
     if bias is not None:
         _need_cuda(bias, torch.float32, "fq_conv3x3_wino_f32")
         assert bias.is_contiguous() and bias.numel() == Cout
+    if qd is not None:
+        bit, bw = _qd_args(qd, max_dev, hist_dev, relu_out, "fq_conv3x3_wino_qd_f32")
+        _check(lib().fq_conv3x3_wino_qd_f32(x.data_ptr(), u.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                                            N, Cin, H, W, Cout, bit, bw, _stream(x)), "fq_conv3x3_wino_qd_f32")
+        return y
     mp = ivp = hp = None
     if hist_dev is not None:
         ivp, hp = _hist_row_ptrs(interval_dev, hist_dev, row)

@@ -71,7 +71,7 @@ class _FusedForward(object):
                         or torch.is_grad_enabled()):
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl.own_plain:                    # per-channel calibration: the convolution only, statistics by its hooks
-                    own = _float_conv.kind(m, x, wino=True) if self.own_conv1x1 else None
+                    own = _float_conv.kind(m, x) if self.own_conv1x1 else None
                     if own is None:
                         return torch.nn.Conv2d.forward(m, x)
                     y = _float_conv.plain(m, own, x, check=ctl.own_plain != "unchecked")
@@ -82,7 +82,7 @@ class _FusedForward(object):
                     return torch.nn.Conv2d.forward(m, x)
                 if ctl.fuse_stat == "hist" and m not in ctl.fuse_verified:
                     return torch.nn.Conv2d.forward(m, x)    # pass 2 fuses verified modules only
-                own = _float_conv.kind(m, x, wino=True) if self.own_conv1x1 else None
+                own = _float_conv.kind(m, x) if self.own_conv1x1 else None
                 if own is None and m not in ctl.fuse_warm and not _flag(m, _FUSION_VERIFIED):
                     ctl.fuse_warm.add(m)                 # the first call of a shape may run a one-off MIOpen kernel:
                     return torch.nn.Conv2d.forward(m, x)    # plain forward now, verification on the next batch

@@ -97,6 +97,23 @@ def test_gaussian_data_statistics_and_relu(nat, shape):
     assert torch.equal(r2, torch.relu(y)) and float(mx2[0]) == float(y.abs().max())
 
 
+@pytest.mark.parametrize("bit,bitwidth", [(5, 8), (-2, 8), (9, 16)])
+def test_quandequan_epilogue_equals_the_two_pass_form(nat, bit, bitwidth):
+    """TestConv.forward (new_quantity_op.py:283-292) on a stride-1 3x3 layer as one kernel: the value QuanDequan sees is the
+    kernel's own sum, so the result is fq_quandequan_f32 of the plain output bit for bit -- saturation, odd planes included."""
+    for shape in ((3, 64, 64, 14, 14), (4, 24, 128, 7, 7)):
+        x, w, b = _case(shape, 57, integer=False)
+        x *= 40.0                                               # (some outputs beyond the 8-bit range at bit 5)
+        u = nat.pack_wino_weight(w)
+        plain = nat.conv_wino_f32(x, u, b, shape[2])
+        want = nat.quandequan(plain.clone(), bit, bitwidth)
+        got = nat.conv_wino_f32(x, u, b, shape[2], qd=(bit, bitwidth))
+        assert torch.equal(got, want)
+    with pytest.raises(nat.FqError):
+        nat.conv_wino_f32(x, u, b, shape[2], qd=(bit, bitwidth), relu_out=torch.empty_like(plain))
+    assert nat.lib().fq_conv3x3_wino_qd_f32(x.data_ptr(), u.data_ptr(), None, plain.data_ptr(), 4, 24, 7, 7, 128, 3, 12, None) == -1
+
+
 def test_an_image_computes_the_same_bits_in_any_batch(nat):
     """No K split, no workspace: what a pixel is does not depend on how many images ride in the launch or where in it the
     image sits (the direct kernel's tail split does make the last bit depend on the tile count -- include/fq.h)."""
