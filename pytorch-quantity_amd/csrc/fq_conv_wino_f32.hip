@@ -399,7 +399,9 @@ bool wino_shape_ok(int N, int Cin, int Hin, int Win, int Cout) {
     if ((Cin % (int)kCS) != 0 || (Cout % (int)kBK) != 0) return false;
     const size_t in_bytes = (size_t)N * Cin * Hin * Win * 4, out_bytes = (size_t)N * Cout * Hin * Win * 4;
     const size_t tiles = (size_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2);
-    return in_bytes < (1ULL << 31) && out_bytes < (1ULL << 31) && (size_t)Cin * Cout * 64 < (1ULL << 31) && tiles < (1ULL << 30);
+    const size_t work = ((tiles + kBT - 1) / kBT) * (size_t)(Cout / (int)kBK);                  // (32-bit work item numbers)
+    return in_bytes < (1ULL << 31) && out_bytes < (1ULL << 31) && (size_t)Cin * Cout * 64 < (1ULL << 31) && tiles < (1ULL << 30) &&
+           work < (1ULL << 31);
 }
 
 }  // namespace
