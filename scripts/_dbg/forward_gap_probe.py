@@ -3,7 +3,7 @@ kernels' durations (scripts/float_forward_table.py) -- what the launch gaps and 
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "pytorch-quantity_amd", "quantity"), os.path.join(ROOT, "tests")]
-os.environ.setdefault("FQ_ACT_CACHE_GB", "0")
+os.environ.setdefault("FQ_ACT_CACHE_GB", os.environ.get("GAP_CACHE_GB", "0"))
 import bench
 from tools import Quantity
 
