@@ -10,23 +10,25 @@
 // channel, t = tile), between an input transform (32 additions per tile and channel) and an output transform (24 per
 // tile and output channel).
 //
-// Mapping.  Workgroup = 8 waves = 64 output channels x 64 tiles (tiles are numbered through the whole batch:
+// Mapping.  A work item = 64 output channels x 64 (or 32) tiles (tiles are numbered through the whole batch:
 // t = (n * TH + ty) * TW + tx, so a 7x7 plane costs its 4x4 tiles and nothing else).  A (32 channels x 32 tiles) block of
 // it with all 16 positions would be 16 accumulator tiles of v_mfma_f32_32x32x2_f32 = 256 registers, i.e. one wave per SIMD
 // with nobody to cover its stalls (built first: 84 % of the matrix cycles at best, scripts/mfma_f32_probe.hip).  So TWO
 // waves share a block, eight positions (two rows of the transformed 4x4 tile) each: 128 accumulators + 105 other registers
-// -> two waves per SIMD; the two meet once per work item, in the output transform (wino_epilogue).
-// A persistent grid, one workgroup per CU, work items k-block major: the workgroups an XCD runs at one time share one
+// -> two waves per SIMD; the two meet once per work item, in the output transform (wino_epilogue).  Two shapes (Geo):
+// 8 waves on 64 x 64, one workgroup per CU, for layers with few K steps; 4 waves on 64 x 32, two workgroups per CU,
+// for the rest (half-length items: a cheaper last round over the CUs, and two workgroups that cover each other's ends).
+// A persistent grid filling the CUs once, work items k-block major: the workgroups an XCD runs at one time share one
 // 64-channel slice of U (<= 2 MB: its L2).  The K loop runs over input channels in steps of 8:
 //   * U (the transformed weights) never touches LDS: the host packs it (fq_conv3x3_wino_f32_pack) as
 //     [c / 8][e][c % 2][k][c % 8 / 2], so that the A operands of the four MFMAs of (step, e) are ONE 16-byte load per lane
 //     straight from L2 into the registers the MFMAs read; the load of step s + 1 is issued as soon as (step s, e) has
 //     issued its MFMAs -- a whole step of latency cover, no double buffer.
-//   * V is made in the kernel: thread = (tile, input channel = its wave's number); four 16-byte loads of the rows of the
+//   * V is made in the kernel: thread = (tile, one input channel of the step); four 16-byte loads of the rows of the
 //     4x4 input tile through a buffer descriptor (per-thread byte offsets computed once per work item; "row outside the
 //     image" = an out-of-range offset that the address unit answers with zero; the two edge columns are dropped by select;
 //     the channel is the scalar offset), 32 additions, 16 LDS writes into the stage of step s + 1; the loads of step s + 2
-//     follow at once.  Three 32 KB stages and one barrier per step, in the middle of it (the scheme of conv1x1_tiles):
+//     follow at once.  Three 32 (16) KB stages and one barrier per step, in the middle of it (the scheme of conv1x1_tiles):
 //     nothing is waited for at a step boundary.  B operands: one ds_read_b128 per (step, e).
 //   * Epilogue: the two waves of a block exchange one row of M through LDS and each makes one row of every 2x2 output
 //     tile: + bias, statistic, ReLU copy, one 8-byte store per tile row (4-byte stores with per-pixel "exists" for odd H or
@@ -52,17 +54,27 @@
 namespace fq {
 namespace {
 
-constexpr int kT = 512;                                      // 8 waves: two per SIMD
-constexpr unsigned kBT = 64;                                  // tiles per workgroup
 constexpr unsigned kBK = 64;                                  // output channels per workgroup
 constexpr unsigned kCS = 8;                                   // input channels per step
-// One stage of V: 16 positions of [c % 2][tile 0..63][c % 8 / 2] floats = 2 KB each: the B operands of the four MFMAs of a
-// (step, position) are ONE 16-byte LDS read per lane (lanes 0..31: c % 2 = 0, consecutive tiles; lanes 32..63: c % 2 = 1).
-// The transform's 4-byte writes go 16 bytes apart across the lanes of a wave (four lanes per bank): the LDS pipe has the time,
-// the instruction stream does not -- every vector instruction, whatever it does, takes ~7 cycles from the matrix pipe.
-constexpr unsigned kKkBytes = kBT * 16u;
-constexpr unsigned kPlane = 2u * kKkBytes;
-constexpr unsigned kStageBytes = 16u * kPlane;                // 32 KB
+// Two shapes of a work item: WT = 2: 64 channels x 64 tiles, 8 waves, one workgroup per CU; WT = 1: 64 channels x 32 tiles, 4 waves,
+// two workgroups per CU.  Either way two waves per SIMD.  The small one halves the length of a work item: the last, partly filled
+// round over the CUs costs half as much (784 equal items on 256 CUs are 4 rounds for 3.06 rounds of work; 1 568 half items on 512
+// slots are 3.06 + the tail at double speed) and two independent workgroups overlap each other's prologue and epilogue -- 15 %
+// on the 14x14 layers; a layer with few K steps (Cin = 64: 8 steps per item) pays more per item than that returns (6 % slower).
+template <int WT>
+struct Geo {
+    static constexpr int kT = 256 * WT;
+    static constexpr unsigned kWaves = 4u * WT;
+    static constexpr unsigned kBT = 32u * WT;                 // tiles per workgroup
+    // One stage of V: 16 positions of [c % 2][tile][c % 8 / 2] floats: the B operands of the four MFMAs of a (step, position) are
+    // ONE 16-byte LDS read per lane (lanes 0..31: c % 2 = 0, consecutive tiles; lanes 32..63: c % 2 = 1).  The transform's 4-byte
+    // writes go 16 bytes apart across the lanes of a wave (four lanes per bank): the LDS pipe has the time, the instruction stream
+    // does not -- every vector instruction, whatever it does, takes ~7 cycles from the matrix pipe.
+    static constexpr unsigned kKkBytes = kBT * 16u;
+    static constexpr unsigned kPlane = 2u * kKkBytes;
+    static constexpr unsigned kStageBytes = 16u * kPlane;     // 32 KB / 16 KB
+    static constexpr unsigned kLdsBytes = 3u * kStageBytes;
+};
 constexpr unsigned kOob = 0x80000000u;                        // a byte offset no tensor of <= 2^31 bytes contains
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef float f4v __attribute__((ext_vector_type(4)));
@@ -97,7 +109,7 @@ __device__ __forceinline__ void stat_add_if(HistStat<kFast>& s, bool ok, float v
 // stages the K loop has finished with -- and each does half of the transform, the bias, the statistic and the stores.  The order of the additions
 // is that of the undivided transform: (m0 + m1) + m2 and (m1 - m2) - m3.
 // kEven: H and W even -- both pixels of a tile row exist together and the pair is 8-byte aligned.
-template <bool kEven, bool kRelu, bool kStream, typename Stat>
+template <int WT, bool kEven, bool kRelu, bool kStream, typename Stat>
 __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[8], unsigned ph, unsigned wave, unsigned lane, char* smem, const WArgs& a,
                                               Stat& stat, unsigned kbase, unsigned tbase, unsigned r, unsigned h) {
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(a.y ? a.y : a.relu, 0, a.y ? a.y_bytes : 0u, 0x00020000);
@@ -115,8 +127,9 @@ __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[8], unsigned ph,
 #pragma unroll
     for (int q = 0; q < 4; ++q)
         b4[q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + kbase + 8u * q + 4u * h) : f4v{0.f, 0.f, 0.f, 0.f};
-    f4v* const mine = reinterpret_cast<f4v*>(smem) + wave * 64u + lane;                 // + slot * 512: [slot][wave][lane], 16 bytes each
-    const f4v* const theirs = reinterpret_cast<const f4v*>(smem) + (wave ^ 4u) * 64u + lane;
+    constexpr unsigned kSlot = Geo<WT>::kWaves * 64u;
+    f4v* const mine = reinterpret_cast<f4v*>(smem) + wave * 64u + lane;                 // + slot * kSlot: [slot][wave][lane], 16 bytes each
+    const f4v* const theirs = reinterpret_cast<const f4v*>(smem) + (wave ^ (2u * WT)) * 64u + lane;
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
         // (the accumulators live in AGPRs and are copied out where they are used -- left to itself the compiler copies all of
@@ -130,7 +143,7 @@ __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[8], unsigned ph,
                 if (ph == 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[4 + c][8 * pass + e]));   // row 1
                 else asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[c][8 * pass + e]));              // row 2
             }
-            mine[e * 512] = v;
+            mine[e * kSlot] = v;
         }
         __syncthreads();
 #pragma unroll
@@ -138,7 +151,7 @@ __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[8], unsigned ph,
             const int e = 8 * pass + e8;
             const unsigned dm = (e & 3) + 8u * (e >> 2);      // row of this register within the wave's 32 (+ 4 h: in off0)
             const int row4 = (int)(dm * a.HW * 4u);           // uniform
-            const f4v got = theirs[e8 * 512];
+            const f4v got = theirs[e8 * kSlot];
             float lo[4], hi[4], tc4[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -178,9 +191,10 @@ struct TileIn {
     bool c0ok, c2ok, c3ok, shift1;
 };
 
+template <int WT>
 __device__ __forceinline__ TileIn tile_in(const WArgs& a, unsigned tb, unsigned lane) {
     TileIn t;
-    const unsigned ti = tb * kBT + lane;
+    const unsigned ti = tb * Geo<WT>::kBT + (WT == 1 ? lane & 31u : lane);   // (WT = 1: lanes 32..63 are the same tiles, the wave's second channel)
     const bool tile_ok = ti < a.tiles;
     const unsigned tc = tile_ok ? ti : 0u;
     const unsigned n = tc / a.tiles_img, rem = tc - n * a.tiles_img, ty = rem / a.TW, tx = rem - ty * a.TW;
@@ -195,21 +209,28 @@ __device__ __forceinline__ TileIn tile_in(const WArgs& a, unsigned tb, unsigned 
         t.xo[i] = ok ? (nb + (unsigned)iy * a.W + 2u * tx - 1u) * 4u : kOob;
     }
     if (t.shift1) t.xo[1] = 0u;
+    const unsigned second = WT == 1 ? (lane >> 5) * a.HW * 4u : 0u;   // (an out-of-range offset stays out of range: x is below 2^31 bytes)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t.xo[i] += second;
     return t;
 }
 
-template <bool kOddW, typename Stat>
+template <int WT, bool kOddW, typename Stat>
 __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* smem) {
+    typedef Geo<WT> G_;
+    constexpr unsigned kBT = G_::kBT, kKkBytes = G_::kKkBytes, kPlane = G_::kPlane, kStageBytes = G_::kStageBytes;
     const unsigned tid = threadIdx.x, lane = tid & 63u;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned r = lane & 31u, h = lane >> 5;
-    // the MFMA role: block sp = (32 channels wk, 32 tiles wt) of the workgroup's 64 x 64, positions 8 ph .. 8 ph + 7
-    const unsigned sp = wave & 3u, ph = wave >> 2, wk = sp >> 1, wt = sp & 1u;
-    // the transform role: input channel `wave` of the step, tile `lane`
+    // the MFMA role: (32 channels wk, 32 tiles wt) of the workgroup's 64 x 32 WT, positions 8 ph .. 8 ph + 7
+    const unsigned wk = WT == 2 ? (wave & 3u) >> 1 : wave & 1u, wt = WT == 2 ? wave & 1u : 0u, ph = wave / (2u * WT);
+    // the transform role: WT = 2: tile `lane`, input channel `wave` of the step; WT = 1: tile lane % 32, channel 2 wave + lane / 32
+    const unsigned tkk = WT == 2 ? wave & 1u : h, tks = WT == 2 ? wave >> 1 : wave, ttile = WT == 2 ? lane : r;
+    const unsigned tch = WT == 2 ? wave : 2u * wave;          // (WT = 1: the odd channel of the pair is in the lanes' offsets)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.u), 0, a.u_bytes, 0x00020000);
     const unsigned vrd = h * kKkBytes + (wt * 32u + r) * 16u + ph * 8u * kPlane;       // B operand reads:  + stage + e * kPlane
-    const unsigned vwr = (wave & 1u) * kKkBytes + lane * 16u + (wave >> 1) * 4u;       // transform writes: + stage + e * kPlane
+    const unsigned vwr = tkk * kKkBytes + ttile * 16u + tks * 4u;                      // transform writes: + stage + e * kPlane
     const unsigned nsteps = a.Cin / kCS;
     const unsigned upos = 2u * a.Cout * 16u;                  // bytes of one position's slice of a step of U
     const unsigned uvo = (h * a.Cout + wk * 32u + r) * 16u;   // + (step, position, k-block): the scalar offset
@@ -219,10 +240,10 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
 
     for (unsigned wi = v0; wi < a.work; wi += G) {
         const unsigned kb = wi / a.tiles_t, tb = wi - kb * a.tiles_t;
-        const TileIn ti = tile_in(a, tb, lane);
+        const TileIn ti = tile_in<WT>(a, tb, lane);
         f4v d[4];                                             // this thread's input tile of the step being loaded, row by row
         auto xload = [&](unsigned s) {
-            const int so = (int)((s * kCS + wave) * a.HW * 4u);
+            const int so = (int)((s * kCS + tch) * a.HW * 4u);
 #pragma unroll
             for (int i = 0; i < 4; ++i) d[i] = __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(xrs, (int)ti.xo[i], so, 0));
         };
@@ -308,7 +329,7 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
         //  recogniser does not see into: the wait states between the last MFMA and the first copy are put here by hand)
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
         const bool even = ((a.H | a.W) & 1u) == 0u;           // uniform
-#define FQ_WINO_EPI(E, R, S) wino_epilogue<E, R, S>(acc, ph, wave, lane, smem, a, stat, kbase, tbase, r, h)
+#define FQ_WINO_EPI(E, R, S) wino_epilogue<WT, E, R, S>(acc, ph, wave, lane, smem, a, stat, kbase, tbase, r, h)
         if (FQ_WINO_OFF(8)) {
             float sum = 0.0f;
 #pragma unroll
@@ -327,46 +348,51 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
     }
 }
 
-constexpr unsigned kLdsBytes = 3u * kStageBytes;
+#define FQ_WINO_TILES(ST) do { if (a.W & 1u) wino_tiles<WT, true>(a, ST, wino_smem); else wino_tiles<WT, false>(a, ST, wino_smem); } while (0)
 
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_kernel(const WArgs a) {
+template <int WT>
+__global__ __launch_bounds__(Geo<WT>::kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_kernel(const WArgs a) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     NoStat st;
-    if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
+    FQ_WINO_TILES(st);
 }
 
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_absmax_kernel(const WArgs a, unsigned int* __restrict__ max_bits) {
+template <int WT>
+__global__ __launch_bounds__(Geo<WT>::kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_absmax_kernel(const WArgs a, unsigned int* __restrict__ max_bits) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     MaxStat st;
-    if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
-    publish_max<kT>(st.m, max_bits);
+    FQ_WINO_TILES(st);
+    publish_max<Geo<WT>::kT>(st.m, max_bits);
 }
 
 // TestConv's forward in one kernel (new_quantity_op.py:283-292): QuanDequan where the value leaves the output transform
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_qd_kernel(const WArgs a, const QdStat qd) {
+template <int WT>
+__global__ __launch_bounds__(Geo<WT>::kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_qd_kernel(const WArgs a, const QdStat qd) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     QdStat st = qd;
-    if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
+    FQ_WINO_TILES(st);
 }
 
 // (every workgroup flushes its 2048 LDS bins with 64-bit atomics at its end)
-__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_hist_kernel(
+template <int WT>
+__global__ __launch_bounds__(Geo<WT>::kT) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino_f32_hist_kernel(
     const WArgs a, const float* __restrict__ interval, unsigned long long* __restrict__ hist_row, const int allow_fast) {
     extern __shared__ __attribute__((aligned(16))) char wino_smem[];
     __shared__ unsigned int s_bins[FQ_BINS + kWave];
-    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kT) s_bins[b] = 0u;
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += Geo<WT>::kT) s_bins[b] = 0u;
     __syncthreads();
     const float iv = *interval;
     unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
     if (allow_fast && fast_quotient_ok(iv)) {
         HistStat<true> st{s_bins, park, iv, 1.0f / iv};
-        if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
+        FQ_WINO_TILES(st);
     } else {
         HistStat<false> st{s_bins, park, iv, 1.0f / iv};
-        if (a.W & 1u) wino_tiles<true>(a, st, wino_smem); else wino_tiles<false>(a, st, wino_smem);
+        FQ_WINO_TILES(st);
     }
-    hist_flush<kT>(s_bins, hist_row);
+    hist_flush<Geo<WT>::kT>(s_bins, hist_row);
 }
+#undef FQ_WINO_TILES
 
 // U = G g Gt,  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1], in fp64, rounded once; written where the kernel's A operand loads
 // find it: [c / 8][e][c % 2][k][c % 8 / 2].  One thread per (k, c).
@@ -399,7 +425,7 @@ bool wino_shape_ok(int N, int Cin, int Hin, int Win, int Cout) {
     if ((Cin % (int)kCS) != 0 || (Cout % (int)kBK) != 0) return false;
     const size_t in_bytes = (size_t)N * Cin * Hin * Win * 4, out_bytes = (size_t)N * Cout * Hin * Win * 4;
     const size_t tiles = (size_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2);
-    const size_t work = ((tiles + kBT - 1) / kBT) * (size_t)(Cout / (int)kBK);                  // (32-bit work item numbers)
+    const size_t work = ((tiles + 31) / 32) * (size_t)(Cout / (int)kBK);                        // (32-bit work item numbers)
     return in_bytes < (1ULL << 31) && out_bytes < (1ULL << 31) && (size_t)Cin * Cout * 64 < (1ULL << 31) && tiles < (1ULL << 30) &&
            work < (1ULL << 31);
 }
@@ -424,6 +450,36 @@ extern "C" int fq_conv3x3_wino_f32_pack(const float* w_kcrs, float* u, int Cin, 
     return FQ_OK;
 }
 
+// A persistent grid -- as many workgroups as the CUs hold (one of 8 waves or two of 4), each taking every grid-th work item:
+// measured 5 % faster than one workgroup per item at 784 items, and the histogram form needs it anyway (one flush per workgroup).
+template <int WT>
+static int wino_launch_geo(WArgs a, float* max_inout, const float* interval, int64_t* hist_row, const QdStat* qd, fq_stream_t stream) {
+    typedef Geo<WT> G;
+    a.tiles_t = (a.tiles + G::kBT - 1u) / G::kBT;
+    a.work = a.tiles_t * (a.Cout / kBK);
+    const unsigned slots = (unsigned)kCUs * (WT == 1 ? 2u : 1u);
+    const unsigned grid = a.work < slots ? a.work : slots;
+    hipStream_t st = as_stream(stream);
+    static bool done_plain[kMaxDevices], done_max[kMaxDevices], done_hist[kMaxDevices], done_qd[kMaxDevices];
+    if (qd) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_qd_kernel<WT>), (int)G::kLdsBytes, done_qd)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL(wino_f32_qd_kernel<WT>, dim3(grid), dim3(G::kT), G::kLdsBytes, st, a, *qd);
+    } else if (hist_row) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_hist_kernel<WT>), (int)G::kLdsBytes, done_hist)) return FQ_ERR_HIP;
+        static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
+        hipLaunchKernelGGL(wino_f32_hist_kernel<WT>, dim3(grid), dim3(G::kT), G::kLdsBytes, st, a, interval,
+                           reinterpret_cast<unsigned long long*>(hist_row), fast);
+    } else if (max_inout) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_absmax_kernel<WT>), (int)G::kLdsBytes, done_max)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL(wino_f32_absmax_kernel<WT>, dim3(grid), dim3(G::kT), G::kLdsBytes, st, a, reinterpret_cast<unsigned int*>(max_inout));
+    } else {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_kernel<WT>), (int)G::kLdsBytes, done_plain)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL(wino_f32_kernel<WT>, dim3(grid), dim3(G::kT), G::kLdsBytes, st, a);
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
 static int wino_launch(const float* x, const float* u, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin, int Win,
                        int Cout, float* max_inout, const float* interval, int64_t* hist_row, const QdStat* qd, fq_stream_t stream) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0) return FQ_ERR_INVALID_ARG;
@@ -438,34 +494,14 @@ static int wino_launch(const float* x, const float* u, const float* bias, float*
     a.x = x; a.u = u; a.bias = bias; a.y = y; a.relu = relu_out;
     a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.H = (unsigned)Hin; a.W = (unsigned)Win; a.HW = a.H * a.W;
     a.TH = (a.H + 1u) / 2u; a.TW = (a.W + 1u) / 2u; a.tiles_img = a.TH * a.TW; a.tiles = (unsigned)N * a.tiles_img;
-    a.tiles_t = (a.tiles + kBT - 1u) / kBT;
-    a.work = a.tiles_t * (a.Cout / kBK);
     a.x_bytes = (unsigned)((size_t)N * Cin * a.HW * 4); a.y_bytes = (unsigned)((size_t)N * Cout * a.HW * 4);
     a.u_bytes = (unsigned)((size_t)16 * Cin * Cout * 4);
     // non-temporal stores beyond the Infinity Cache, where a plane is a whole number of 64-byte blocks (fq_conv1x1_f32.hip)
     a.stream_stores = (size_t)a.y_bytes * (relu_out && y ? 2 : 1) > ((size_t)256 << 20) && (a.HW % 16u) == 0;
-    hipStream_t st = as_stream(stream);
-    // A persistent grid, one workgroup per CU (that is all the registers allow), each taking every 256th work item: measured
-    // 5 % faster than one workgroup per item at 784 items, and the histogram form needs it anyway (one flush per workgroup).
-    const unsigned grid = a.work < (unsigned)kCUs ? a.work : (unsigned)kCUs;
-    static bool done_plain[kMaxDevices], done_max[kMaxDevices], done_hist[kMaxDevices], done_qd[kMaxDevices];
-    if (qd) {
-        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_qd_kernel), (int)kLdsBytes, done_qd)) return FQ_ERR_HIP;
-        hipLaunchKernelGGL(wino_f32_qd_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a, *qd);
-    } else if (hist_row) {
-        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_hist_kernel), (int)kLdsBytes, done_hist)) return FQ_ERR_HIP;
-        static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
-        hipLaunchKernelGGL(wino_f32_hist_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a, interval,
-                           reinterpret_cast<unsigned long long*>(hist_row), fast);
-    } else if (max_inout) {
-        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_absmax_kernel), (int)kLdsBytes, done_max)) return FQ_ERR_HIP;
-        hipLaunchKernelGGL(wino_f32_absmax_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a, reinterpret_cast<unsigned int*>(max_inout));
-    } else {
-        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(wino_f32_kernel), (int)kLdsBytes, done_plain)) return FQ_ERR_HIP;
-        hipLaunchKernelGGL(wino_f32_kernel, dim3(grid), dim3(kT), kLdsBytes, st, a);
-    }
-    FQ_LAUNCH_CHECK();
-    return FQ_OK;
+    // the shape of a work item (Geo): half items unless the layer has few K steps; FQ_WINO_WT = 1 | 2 forces one (probing)
+    static const int forced = [] { const char* e = getenv("FQ_WINO_WT"); return (e && e[0]) ? atoi(e) : 0; }();
+    const int wt = (forced == 1 || forced == 2) ? forced : (Cin < 128 ? 2 : 1);
+    return wt == 2 ? wino_launch_geo<2>(a, max_inout, interval, hist_row, qd, stream) : wino_launch_geo<1>(a, max_inout, interval, hist_row, qd, stream);
 }
 
 extern "C" int fq_conv3x3_wino_f32(const float* x, const float* u, const float* bias, float* y, float* relu_out, int N, int Cin,

@@ -26,6 +26,10 @@ SHAPES = [
     (7, 24, 64, 13, 6),           # three steps, odd height
     (33, 16, 192, 10, 10),        # 825 tiles = 12.9 blocks x 3 k-blocks: more work items than one round of a persistent grid
     (2, 40, 64, 6, 20),           # wide plane
+    # (Cin >= 128: the half-size work item -- 64 channels x 32 tiles, two workgroups per CU, two channels per transform wave)
+    (3, 128, 64, 5, 9),           # odd both ways, 45 tiles = 1.4 blocks
+    (70, 128, 128, 1, 1),         # 1x1 planes
+    (1, 136, 64, 2, 3),           # a single partial block, 17 steps
 ]
 
 
