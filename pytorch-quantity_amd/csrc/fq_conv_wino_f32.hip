@@ -30,15 +30,16 @@
 //     the channel is the scalar offset), 32 additions, 16 LDS writes into the stage of step s + 1; the loads of step s + 2
 //     follow at once.  Three 32 (16) KB stages and one barrier per step, in the middle of it (the scheme of conv1x1_tiles):
 //     nothing is waited for at a step boundary.  B operands: one ds_read_b128 per (step, e).
-//   * Epilogue: the two waves of a block exchange one row of M through LDS and each makes one row of every 2x2 output
-//     tile: + bias, statistic, ReLU copy, one 8-byte store per tile row (4-byte stores with per-pixel "exists" for odd H or
+//   * Epilogue: each wave applies the column stage of the output transform to its two rows, the two waves of a block
+//     exchange one row of the result through LDS and each makes one row of every 2x2 output tile: + bias, statistic, ReLU copy, one 8-byte store per tile row (4-byte stores with per-pixel "exists" for odd H or
 //     W: 7x7).
 // What was measured on the way (profiles/r04_conv_wino_*): every vector instruction between two MFMAs costs the matrix
 // pipe ~7 cycles whatever it does, so the input rows come as whole 16-byte loads (16 dword loads per tile and channel: 23 %
 // slower), the B operands as one read per (step, e), and the accumulators are copied out of the AGPRs where they are used.
 //
 // Numerics.  fp32 throughout; U is computed from the weights in fp64 and rounded once.  Per output: an fmaf chain over
-// c = 0 .. Cin-1 per position, then the fixed additions of the two transforms, then the bias.  Deterministic and
+// c = 0 .. Cin-1 per position, then the fixed additions of the two transforms (output: along a row first, then down),
+// then the bias.  Deterministic and
 // batch-size independent (no K split, no workspace: an image computes the same bits wherever it sits in whatever batch).
 // It is NOT the direct sum: measured |error| <= 1.8e-7 of sum |w||x| on Gaussian data against 3.5e-7 for the direct kernel
 // (fewer terms per chain) -- the reference's own GPU forward goes through the convolution library's Winograd kernels for
@@ -102,12 +103,13 @@ __device__ __forceinline__ void stat_add_if(MaxStat& s, bool ok, float v) { s.ad
 template <bool kFast>
 __device__ __forceinline__ void stat_add_if(HistStat<kFast>& s, bool ok, float v) { if (ok) s.add(v); }
 
-// The output transform  Y = At M A,  At = [1 1 1 0; 0 1 -1 -1]  (rows first, then columns), split between the two waves that
-// hold one (32 channels x 32 tiles) block: the wave with rows 0 and 1 of M (positions 0..7) makes output row 0 of every tile and
-// needs row 2 for it; the wave with rows 2 and 3 makes output row 1 and needs row 1.  So each hands ONE row of M (4 values per
-// (channel, tile) pair, 64 registers per lane, 16 bytes at a time) to the other through LDS -- in two rounds of 64 KB, in the
-// stages the K loop has finished with -- and each does half of the transform, the bias, the statistic and the stores.  The order of the additions
-// is that of the undivided transform: (m0 + m1) + m2 and (m1 - m2) - m3.
+// The output transform  Y = At M A,  At = [1 1 1 0; 0 1 -1 -1], split between the two waves that hold one (32 channels x 32
+// tiles) block.  Each wave has two whole ROWS of M (positions 8 ph .. 8 ph + 7), so the column stage  N = M A  -- (m0 + m1) + m2
+// and (m1 - m2) - m3 along a row -- is its own business: two values per row.  The row stage  Y = At N  needs all four rows: the
+// wave with rows 0 and 1 makes output row 0 of every tile, (n0 + n1) + n2, and needs n2 for it; the wave with rows 2 and 3 makes
+// output row 1, (n1 - n2) - n3, and needs n1.  So each hands ONE row of N (2 values per (channel, tile) pair, 32 registers per
+// lane, 8 bytes at a time) to the other through LDS -- 64 (32) KB, once, in the stages the K loop has finished with -- and each
+// does half of the transform, the bias, the statistic and the stores.
 // kEven: H and W even -- both pixels of a tile row exist together and the pair is 8-byte aligned.
 template <int WT, bool kEven, bool kRelu, bool kStream, typename Stat>
 __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[8], unsigned ph, unsigned wave, unsigned lane, char* smem, const WArgs& a,
@@ -128,56 +130,53 @@ __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[8], unsigned ph,
     for (int q = 0; q < 4; ++q)
         b4[q] = a.bias ? *reinterpret_cast<const f4v*>(a.bias + kbase + 8u * q + 4u * h) : f4v{0.f, 0.f, 0.f, 0.f};
     constexpr unsigned kSlot = Geo<WT>::kWaves * 64u;
-    f4v* const mine = reinterpret_cast<f4v*>(smem) + wave * 64u + lane;                 // + slot * kSlot: [slot][wave][lane], 16 bytes each
-    const f4v* const theirs = reinterpret_cast<const f4v*>(smem) + (wave ^ (2u * WT)) * 64u + lane;
+    f2v* const mine = reinterpret_cast<f2v*>(smem) + wave * 64u + lane;                 // + e * kSlot: [e][wave][lane], 8 bytes each
+    const f2v* const theirs = reinterpret_cast<const f2v*>(smem) + (wave ^ (2u * WT)) * 64u + lane;
+    // (the accumulators live in AGPRs and are copied out where they are used -- left to itself the compiler copies all of
+    //  them at the end of the K loop, in front of the branch that picks the epilogue, and spills to make room)
+    float na[16][2], nb[16][2];                               // this wave's two rows of N: [e][output column]
+    __syncthreads();                                          // the K loop is done with this memory
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        // (the accumulators live in AGPRs and are copied out where they are used -- left to itself the compiler copies all of
-        //  them at the end of the K loop, in front of the branch that picks the epilogue, and spills to make room)
-        __syncthreads();                                      // the K loop / the previous round is done with this memory
+    for (int e = 0; e < 16; ++e) {
+        float lo[4], hi[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            f4v v;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (ph == 0) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[4 + c][8 * pass + e]));   // row 1
-                else asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v[c]) : "a"(acc[c][8 * pass + e]));              // row 2
-            }
-            mine[e * kSlot] = v;
+        for (int c = 0; c < 4; ++c) {
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo[c]) : "a"(acc[c][e]));
+            asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi[c]) : "a"(acc[4 + c][e]));
         }
-        __syncthreads();
+        na[e][0] = (lo[0] + lo[1]) + lo[2]; na[e][1] = (lo[1] - lo[2]) - lo[3];         // N of this wave's first row (0 or 2)
+        nb[e][0] = (hi[0] + hi[1]) + hi[2]; nb[e][1] = (hi[1] - hi[2]) - hi[3];         // ... and of its second (1 or 3)
+        mine[e * kSlot] = ph == 0 ? f2v{nb[e][0], nb[e][1]} : f2v{na[e][0], na[e][1]};  // rows 0, 1 here: hand over row 1; rows 2, 3: row 2
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
 #pragma unroll
-        for (int e8 = 0; e8 < 8; ++e8) {
-            const int e = 8 * pass + e8;
-            const unsigned dm = (e & 3) + 8u * (e >> 2);      // row of this register within the wave's 32 (+ 4 h: in off0)
-            const int row4 = (int)(dm * a.HW * 4u);           // uniform
-            const f4v got = theirs[e8 * kSlot];
-            float lo[4], hi[4], tc4[4];
+    for (int e = 0; e < 16; ++e) {
+        const unsigned dm = (e & 3) + 8u * (e >> 2);      // row of this register within the wave's 32 (+ 4 h: in off0)
+        const int row4 = (int)(dm * a.HW * 4u);           // uniform
+        const f2v got = theirs[e * kSlot];
+        float tc4[2];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo[c]) : "a"(acc[c][e]));
-                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi[c]) : "a"(acc[4 + c][e]));
-                tc4[c] = ph == 0 ? (lo[c] + hi[c]) + got[c] : (got[c] - lo[c]) - hi[c];
+        for (int c = 0; c < 2; ++c)
+            tc4[c] = ph == 0 ? (na[e][c] + nb[e][c]) + got[c] : (got[c] - na[e][c]) - nb[e][c];
+        const float bias = b4[e >> 2][e & 3];
+        float o0 = tc4[0] + bias, o1 = tc4[1] + bias;
+        o0 = stat_map(stat, o0); o1 = stat_map(stat, o1);
+        if (kEven) {
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{o0, o1}), yrs, (int)v0, row4, aux);
+            if (kRelu)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{relu_like_torch(o0), relu_like_torch(o1)}), rrs, (int)v0, row4, aux);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o0), yrs, (int)v0, row4, aux);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o1), yrs, (int)v1, row4, aux);
+            if (kRelu) {
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(o0)), rrs, (int)v0, row4, aux);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(o1)), rrs, (int)v1, row4, aux);
             }
-            const float bias = b4[e >> 2][e & 3];
-            float o0 = ((tc4[0] + tc4[1]) + tc4[2]) + bias, o1 = ((tc4[1] - tc4[2]) - tc4[3]) + bias;
-            o0 = stat_map(stat, o0); o1 = stat_map(stat, o1);
-            if (kEven) {
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{o0, o1}), yrs, (int)v0, row4, aux);
-                if (kRelu)
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2v{relu_like_torch(o0), relu_like_torch(o1)}), rrs, (int)v0, row4, aux);
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o0), yrs, (int)v0, row4, aux);
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o1), yrs, (int)v1, row4, aux);
-                if (kRelu) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(o0)), rrs, (int)v0, row4, aux);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, relu_like_torch(o1)), rrs, (int)v1, row4, aux);
-                }
-            }
-            stat_add_if(stat, row_ok, o0);
-            stat_add_if(stat, px1_ok, o1);
-            __builtin_amdgcn_sched_barrier(0);
         }
+        stat_add_if(stat, row_ok, o0);
+        stat_add_if(stat, px1_ok, o1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
