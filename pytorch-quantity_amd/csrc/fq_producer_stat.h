@@ -8,8 +8,10 @@
 
 namespace fq {
 
-// torch's clamp_min(x, 0): NaN stays NaN
-__device__ __forceinline__ float relu_like_torch(float v) { return v > 0.0f ? v : (v != v ? v : 0.0f); }
+// torch's clamp_min(x, 0): NaN stays NaN.  "not (v <= 0)" is true for v > 0 AND for NaN: one v_cmp_nle_f32 + one v_cndmask
+// (the obvious  v > 0 ? v : (v != v ? v : 0)  is two compares, a scalar or and the select -- and every vector instruction of an
+// epilogue is time the matrix pipe does not get)
+__device__ __forceinline__ float relu_like_torch(float v) { return !(v <= 0.0f) ? v : 0.0f; }
 
 struct MaxStat {
     float m = 0.0f;
