@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FQ_VERSION 101            /* 0.1.1: caller-owned workspace of the float convolutions */
+#define FQ_VERSION 102            /* 0.1.2: Winograd and split-bf16 forms of the float convolutions */
 #define FQ_BINS 2048              /* INTERVAL_NUM, tools/configs.yml:24 */
 #define FQ_KL_TARGET_BINS 128     /* quantizer.py:98 target_bin */
 #define FQ_KL_CANDIDATES 1920     /* thresholds 128..2047, quantizer.py:103 */
@@ -226,6 +226,31 @@ size_t fq_conv_f32_workspace_bytes(void);
 int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin,
                    int Win, int Cout, int stride, float* max_inout, const float* interval, int64_t* hist_row,
                    void* workspace, size_t workspace_bytes, fq_stream_t stream);
+
+/* The 1x1 convolutions above with every fp32 operand as THREE bf16 values on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16: 14 x
+ * the rate of the fp32 MFMA on this chip).  v = hi + mid + lo with hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi - mid) is exact
+ * (8 + 8 + 8 significant bits); of the nine bf16 products of w x the six largest are accumulated in fp32 (the three left out are
+ * below 2^-23 of the product).  Measured against fp64: 1.0-1.3e-7 of sum |w||x| -- the fp32 fma chain of fq_conv1x1_f32: 1.4-2.1e-7
+ * (profiles/r04_bf16x3_probe.txt; tests/test_gpu_float_forward_kernels.py holds both to the same bound); integer-valued operands
+ * below 2^8 are exact as before; a non-finite input gives NaN.  Same operands, epilogues, statistics, workspace / tail split and
+ * error codes as the entry points they shadow, except:
+ *   wsb: the weights packed by fq_conv1x1_sb_pack from fp32 [Cout][Cin] (NOT transposed) into three bf16 planes [3][Cout][Cin],
+ *        fq_conv1x1_sb_packed_bytes(Cin, Cout) bytes, 16-byte aligned;  Cin % 16 == 0, Cout % 4 == 0 (fq_conv1x1_sb_supported). */
+size_t fq_conv1x1_sb_packed_bytes(int Cin, int Cout);
+int fq_conv1x1_sb_supported(int Cin, int Cout);
+int fq_conv1x1_sb_pack(const float* w_kc, void* wsb, int Cin, int Cout, fq_stream_t stream);
+int fq_conv1x1_sb_f32(const float* x, const void* wsb, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin, int Win,
+                      int Cout, int stride, float* max_inout, const float* interval, int64_t* hist_row, void* workspace,
+                      size_t workspace_bytes, fq_stream_t stream);
+int fq_conv1x1_sb_qd_f32(const float* x, const void* wsb, const float* bias, float* y, int N, int Cin, int Hin, int Win, int Cout,
+                         int stride, int bit, int bitwidth, void* workspace, size_t workspace_bytes, fq_stream_t stream);
+int fq_conv1x1_sb_add_f32(const float* x, const void* wsb, const float* bias, const float* res, float* y, float* sum, float* relu_out,
+                          int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y, float* max_sum, void* workspace,
+                          size_t workspace_bytes, fq_stream_t stream);
+int fq_conv1x1_sb_add_hist_f32(const float* x, const void* wsb, const float* bias, const float* res, float* relu_out, int N, int Cin,
+                               int Hin, int Win, int Cout, int stride, const float* interval_y, int64_t* hist_y,
+                               const float* interval_sum, int64_t* hist_sum, void* workspace, size_t workspace_bytes,
+                               fq_stream_t stream);
 
 /* The same kernel for R x S convolutions with zero padding (ResNet's 3x3 layers, stride 1 and 2): the reduction runs tap by
  * tap over the same x rows, shifted -- a 1x1 convolution per tap whose per-thread pixel offset (or "outside the image:

@@ -45,6 +45,7 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 struct C1Args {
     const float* x;
     const float* wt;          // [Cin][Cout]
+    const unsigned short* wsb; // the split-bf16 form (conv1x1_tiles_sb): three bf16 planes [3][Cout][Cin], fq_conv1x1_sb_pack
     const float* bias;        // [Cout] or null
     float* y;
     float* relu;              // or null
@@ -193,6 +194,107 @@ __device__ __forceinline__ void c1_epilogue_add(const f16v (&acc)[WM][WN], const
                 }
             }
         }
+    }
+}
+
+// What happens to a finished accumulator tile -- shared by the fp32 and the split-bf16 K loops.  A K slice of a split tile goes to the
+// workspace and the last slice to arrive sums them in slice order; then the epilogue the launch asked for.
+template <int WM, int WN, typename Stat>
+__device__ __forceinline__ void finish_tile(f16v (&acc)[WM][WN], const C1Args& a, Stat& stat, const float* s_bias, bool split, unsigned t,
+                                            unsigned slice, unsigned jbase, unsigned mbase, unsigned m0, unsigned n0, unsigned r, unsigned h,
+                                            unsigned tid, unsigned wave) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    bool finish = true;
+    if (split) {
+        // This workgroup holds one K slice of the tile.  Its accumulators go to the workspace; the workgroup of the tile
+        // that gets there last adds all slices up IN SLICE ORDER (so the result does not depend on who was last) and
+        // carries on with the epilogue.  Release / acquire at agent scope as MI355X_MICROARCH.md prescribes for a
+        // counter hand-off: every storing wave waits for its stores, a barrier, one lane releases and adds; the lane
+        // whose add completes the count acquires, a barrier, then plain loads.
+        const unsigned rr = t - a.split_first;
+        constexpr unsigned kTileFloats = (unsigned)(BM * BN);
+        float* const mine = a.ws + ((size_t)rr * a.split_s + slice) * kTileFloats;
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4v v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
+                    *reinterpret_cast<f4v*>(mine + ((((mi * WN + ni) * 4 + q) * kT) + tid) * 4u) = v;
+                }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        __shared__ unsigned s_last;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned prev = __hip_atomic_fetch_add(a.ws_count + rr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned last = prev + 1u == a.split_s;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(a.ws_count + rr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            s_last = last;
+        }
+        __syncthreads();
+        finish = s_last != 0u;                            // uniform
+        if (finish) {
+            if (wave != 0) {                              // (wave 0's lane 0 made the acquire: its L1 is this CU's L1 -- one
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   //  invalidate per CU would do, one per wave is cheap here)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+#pragma unroll
+            for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+            for (unsigned sl = 0; sl < a.split_s; ++sl) {
+                const float* part = a.ws + ((size_t)rr * a.split_s + sl) * kTileFloats;
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f4v v = *reinterpret_cast<const f4v*>(part + ((((mi * WN + ni) * 4 + q) * kT) + tid) * 4u);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) acc[mi][ni][4 * q + c] += v[c];
+                        }
+            }
+        }
+    }
+    if (finish) {
+        const bool full_m = mbase + BM <= a.Cout;
+#ifdef FQ_C1_ABLATE
+        if (FQ_C1_OFF(1)) {
+        } else
+#endif
+#define FQ_C1_EPI(R, S, F) c1_epilogue<WM, WN, R, S, F>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
+#define FQ_C1_ADD(Y, S, N) c1_epilogue_add<WM, WN, Y, S, N>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
+        if constexpr (is_add_stat<Stat>::value) {         // (whole row tiles only: host check)
+            if constexpr (!Stat::kMayStore) {
+                if (a.stream_stores) FQ_C1_ADD(false, false, true); else FQ_C1_ADD(false, false, false);
+            } else
+            if (a.stream_stores) {
+                if (a.store_y) { if (a.sum) FQ_C1_ADD(true, true, true); else FQ_C1_ADD(true, false, true); }
+                else { if (a.sum) FQ_C1_ADD(false, true, true); else FQ_C1_ADD(false, false, true); }
+            } else {
+                if (a.store_y) { if (a.sum) FQ_C1_ADD(true, true, false); else FQ_C1_ADD(true, false, false); }
+                else { if (a.sum) FQ_C1_ADD(false, true, false); else FQ_C1_ADD(false, false, false); }
+            }
+        } else
+        if (a.relu) {
+            if (a.stream_stores) { if (full_m) FQ_C1_EPI(true, true, true); else FQ_C1_EPI(true, true, false); }
+            else { if (full_m) FQ_C1_EPI(true, false, true); else FQ_C1_EPI(true, false, false); }
+        } else {
+            if (a.stream_stores) { if (full_m) FQ_C1_EPI(false, true, true); else FQ_C1_EPI(false, true, false); }
+            else { if (full_m) FQ_C1_EPI(false, false, true); else FQ_C1_EPI(false, false, false); }
+        }
+#undef FQ_C1_EPI
+#undef FQ_C1_ADD
     }
 }
 
@@ -407,100 +509,286 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
             kstep(Stage<2>{}, ks);
             if (++ks >= ks_end) break;
         }
-        bool finish = true;
+        finish_tile<WM, WN>(acc, a, stat, s_bias, split, t, slice, jbase, mbase, m0, n0, r, h, tid, wave);
+        __syncthreads();                                      // the next tile overwrites s_bias and stage 0
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same GEMM with every fp32 operand as THREE bf16 values (conv1x1_tiles_sb, fq_conv1x1_sb_f32 and friends).
+//
+// The fp32 MFMA runs at the vector rate -- 1/16 of the bf16 rate on this chip (scripts/bf16x3_probe.hip: 145-154 TFLOP/s
+// against 2.1-2.2 PFLOP/s).  An fp32 value IS the sum of three bf16 values (hi = bf16(v), mid = bf16(v - hi), lo = bf16(v - hi -
+// mid): 8 + 8 + 8 significant bits, both residuals exact), so a product is nine bf16 products; the three smallest (mid lo, lo mid,
+// lo lo: below 2^-23 of the product) are left out and the other six accumulate in fp32 inside v_mfma_f32_32x32x16_bf16.
+// Measured against fp64 (the probe; tests/test_gpu_float_forward_kernels.py): 1.0-1.3e-7 of sum |w||x| -- the fp32 fma chain
+// of conv1x1_tiles: 1.4-2.1e-7 -- at 6 MFMAs of 32 cycles per 16 of K instead of 8 of 64.  Integer-valued operands below 2^8
+// have no mid and lo part: such data is exact, as before.  (A non-finite input gives NaN: inf - inf in its residual.)
+//
+// The weights are split once (fq_conv1x1_sb_pack: three planes [Cout][Cin], k contiguous -- the A operand of the MFMA wants a
+// row's 8 consecutive k in one lane); the activations are split by the threads that stage the x tile: thread = (column, half of
+// the K step) loads its 8 k, splits them (~5 vector instructions per value, once per 128 output channels) and writes three
+// 16-byte pieces.  LDS per stage: [plane 3][k / 8: 2][row or column][8 bf16] for both operands -- every fragment read is one
+// conflict-free ds_read_b128.  Same three-stage pipeline with one barrier in the middle of a step, same accumulator layout,
+// hence the same epilogues, statistics and tail split as the fp32 kernel.
+constexpr int kSbBK = 16;
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+template <int WM, int WN>
+struct ShapeSb {
+    static constexpr int BM = 64 * WM, BN = 64 * WN;
+    static constexpr int kABytes = 3 * 2 * BM * 16, kBBytes = 3 * 2 * BN * 16, kStage = kABytes + kBBytes;
+    static constexpr int kWVecs = (3 * 2 * BM + kT - 1) / kT;          // 16-byte pieces of the W tile per thread and K step
+    static constexpr int kBytes = 3 * kStage + BM * 4;                 // three stages + the bias slice
+    static_assert(BN == 128, "the x tile is staged by 128 columns x 2 halves of the K step = 256 threads");
+};
+
+// v -> (hi, mid, lo) as bf16 bit patterns, round to nearest even (the residuals are exact in fp32)
+__device__ __forceinline__ unsigned bf16_bits(float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void split3(float v, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = bf16_bits(v);
+    const float r1 = v - __builtin_bit_cast(float, hi << 16);
+    mid = bf16_bits(r1);
+    const float r2 = r1 - __builtin_bit_cast(float, mid << 16);
+    lo = bf16_bits(r2);
+}
+
+template <int WM, int WN, typename Stat>
+__device__ __forceinline__ void conv1x1_tiles_sb(const C1Args& a, Stat& stat, char* smem) {
+    typedef ShapeSb<WM, WN> S;
+    constexpr int BM = S::BM, BN = S::BN;
+    float* const s_bias = reinterpret_cast<float*>(smem + 3 * S::kStage);
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned r = lane & 31u, h = lane >> 5;
+    const unsigned m0 = (wave >> 1) * (32u * WM), n0 = (wave & 1u) * (32u * WN);
+    const unsigned G = gridDim.x, G8 = (G < a.split_first ? G : a.split_first) & ~7u, g = blockIdx.x;
+    const unsigned v0 = g < G8 ? (g & 7u) * (G8 >> 3) + (g >> 3) : g;
+    const unsigned xc = tid % BN, xh = tid / BN;                  // x tile: this thread's column, its half of the K step
+    const unsigned nk = a.Cin / kSbBK;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wsb), 0, a.w_bytes, 0x00020000);
+    // fragment reads: A + ((plane * 2 + h) * BM + m0 + 32 mi + r) * 16, B + ((plane * 2 + h) * BN + n0 + 32 ni + r) * 16
+    const unsigned ard = (h * BM + m0 + r) * 16u, brd = S::kABytes + (h * BN + n0 + r) * 16u;
+    const unsigned bwr = S::kABytes + (xh * BN + xc) * 16u;       // x tile stores: + stage + plane * 2 * BN * 16
+
+    for (unsigned wi = v0; wi < a.work; wi += G) {
+        unsigned t = wi, ks_begin = 0, ks_end = nk, slice = 0;
+        const bool split = wi >= a.split_first;                // uniform
         if (split) {
-            // This workgroup holds one K slice of the tile.  Its accumulators go to the workspace; the workgroup of the tile
-            // that gets there last adds all slices up IN SLICE ORDER (so the result does not depend on who was last) and
-            // carries on with the epilogue.  Release / acquire at agent scope as MI355X_MICROARCH.md prescribes for a
-            // counter hand-off: every storing wave waits for its stores, a barrier, one lane releases and adds; the lane
-            // whose add completes the count acquires, a barrier, then plain loads.
-            const unsigned rr = t - a.split_first;
-            constexpr unsigned kTileFloats = (unsigned)(BM * BN);
-            float* const mine = a.ws + ((size_t)rr * a.split_s + slice) * kTileFloats;
+            const unsigned rr = (wi - a.split_first) / a.split_s;
+            slice = (wi - a.split_first) - rr * a.split_s;
+            t = a.split_first + rr;
+            ks_begin = slice * nk / a.split_s;
+            ks_end = (slice + 1u) * nk / a.split_s;
+        }
+        const unsigned ct = t / a.tiles_m, mt = t - ct * a.tiles_m;
+        const unsigned mbase = mt * BM, jbase = ct * BN;
+        // x: byte offset of (this column, k = 8 xh) in K step 0; the 8 rows follow at HWin * 4 (scalar), the K step is scalar too
+        unsigned xo;
+        {
+            const unsigned j = min(jbase + xc, a.cols - 1u);
+            const unsigned n = j / a.HWout, p = j - n * a.HWout;
+            unsigned pin = p;
+            if (a.stride != 1) {
+                const unsigned oh = p / a.Wout, ow = p - oh * a.Wout;
+                pin = oh * a.stride * a.Win + ow * a.stride;
+            }
+            xo = (n * a.Cin * a.HWin + pin + 8u * xh * a.HWin) * 4u;
+        }
+        // W: 16-byte piece v of a K step = (plane, row, half): v = tid + kT i; rows past Cout re-read the last row (never stored)
+        unsigned wo[S::kWVecs], wl[S::kWVecs];
 #pragma unroll
-            for (int mi = 0; mi < WM; ++mi)
+        for (int i = 0; i < S::kWVecs; ++i) {
+            const unsigned v = tid + (unsigned)kT * i, plane = v / (2u * BM), rem = v - plane * (2u * BM), row = rem >> 1, half = rem & 1u;
+            const unsigned grow = min(mbase + row, a.Cout - 1u);
+            wo[i] = ((plane * a.Cout + grow) * a.Cin + 8u * half) * 2u;
+            wl[i] = ((plane * 2u + half) * BM + row) * 16u;
+        }
+        float xr[8];
+        u4v wreg[S::kWVecs];
+        auto gload = [&](unsigned ks) {                        // ks is uniform: the K advance is scalar arithmetic
+            const unsigned xs = ks * kSbBK * a.HWin * 4u, ws = ks * kSbBK * 2u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)xo, (int)(xs + (unsigned)i * a.HWin * 4u), 0));
+#pragma unroll
+            for (int i = 0; i < S::kWVecs; ++i)
+                if (S::kWVecs * kT == 3 * 2 * BM || tid + (unsigned)kT * i < 3u * 2u * BM)
+                    wreg[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)wo[i], (int)ws, 0));
+        };
+        auto lstore = [&](unsigned stage_off) {
+#pragma unroll
+            for (int i = 0; i < S::kWVecs; ++i)
+                if (S::kWVecs * kT == 3 * 2 * BM || tid + (unsigned)kT * i < 3u * 2u * BM)
+                    *reinterpret_cast<u4v*>(smem + stage_off + wl[i]) = wreg[i];
+            // two values at a time: v_cvt_pk_bf16_f32 (round to nearest even), the two halves widened again by a shift and a mask,
+            // one packed subtraction for the residuals -- 4.5 vector instructions per value
+            u4v ph, pm, pl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f2v v = {xr[2 * i], xr[2 * i + 1]};
+                const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2v));
+                const f2v r1 = v - f2v{__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
+                const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf2v));
+                const f2v r2 = r1 - f2v{__builtin_bit_cast(float, mb << 16), __builtin_bit_cast(float, mb & 0xffff0000u)};
+                ph[i] = hb; pm[i] = mb; pl[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(r2, bf2v));
+            }
+            *reinterpret_cast<u4v*>(smem + stage_off + bwr) = ph;
+            *reinterpret_cast<u4v*>(smem + stage_off + bwr + 2u * BN * 16u) = pm;
+            *reinterpret_cast<u4v*>(smem + stage_off + bwr + 4u * BN * 16u) = pl;
+        };
+        f16v acc[WM][WN];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
+
+        gload(ks_begin);
+        if (tid < (unsigned)BM) s_bias[tid] = (a.bias && mbase + tid < a.Cout) ? a.bias[mbase + tid] : 0.0f;
+        lstore(0u);
+        if (ks_begin + 1 < ks_end) gload(ks_begin + 1);
+        __syncthreads();
+        // Two sets of operand fragments: a step multiplies out of one while the other is filled, behind the step's barrier, with
+        // the fragments of the following step -- their LDS latency falls under the second half of this step's MFMAs (with one
+        // set every step began with twelve reads and an MFMA waiting for each).
+        bf8v fa[2][WM][3], fb[2][WN][3];
+        auto frags = [&](int set, unsigned stage_off) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int mi = 0; mi < WM; ++mi)
+                    fa[set][mi][pl] = *reinterpret_cast<const bf8v*>(smem + stage_off + ard + (unsigned)(pl * 2 * BM + 32 * mi) * 16u);
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f4v v = {acc[mi][ni][4 * q], acc[mi][ni][4 * q + 1], acc[mi][ni][4 * q + 2], acc[mi][ni][4 * q + 3]};
-                        *reinterpret_cast<f4v*>(mine + ((((mi * WN + ni) * 4 + q) * kT) + tid) * 4u) = v;
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            __shared__ unsigned s_last;
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned prev = __hip_atomic_fetch_add(a.ws_count + rr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned last = prev + 1u == a.split_s;
-                if (last) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_store(a.ws_count + rr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-                }
-                s_last = last;
+                    fb[set][ni][pl] = *reinterpret_cast<const bf8v*>(smem + stage_off + brd + (unsigned)(pl * 2 * BN + 32 * ni) * 16u);
             }
-            __syncthreads();
-            finish = s_last != 0u;                            // uniform
-            if (finish) {
-                if (wave != 0) {                              // (wave 0's lane 0 made the acquire: its L1 is this CU's L1 -- one
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   //  invalidate per CU would do, one per wave is cheap here)
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        unsigned cur = 0;
+        auto kstep = [&](auto set_c, unsigned ks) {
+            constexpr int set = decltype(set_c)::value;
+            const unsigned nxt = cur == 2u * S::kStage ? 0u : cur + (unsigned)S::kStage;
+            // smallest products first: (hi, lo), (lo, hi), (mid, mid), (hi, mid), (mid, hi), (hi, hi)
+            constexpr int kA[6] = {0, 2, 1, 0, 1, 0}, kB[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+            for (int q = 0; q < 6; ++q) {
+                if (q == 3) {                                   // the middle of the step: the operands of step ks + 1 go to their stage,
+                    if (ks + 1 < ks_end) {                      // the loads of step ks + 2 are issued, one barrier, then its fragments
+                        lstore(nxt);
+                        if (ks + 2 < ks_end) gload(ks + 2);
+                    }
+                    __syncthreads();
+                    if (ks + 1 < ks_end) frags(set ^ 1, nxt);
                 }
 #pragma unroll
                 for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < WN; ++ni)
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
-                for (unsigned sl = 0; sl < a.split_s; ++sl) {
-                    const float* part = a.ws + ((size_t)rr * a.split_s + sl) * kTileFloats;
-#pragma unroll
-                    for (int mi = 0; mi < WM; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < WN; ++ni)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                const f4v v = *reinterpret_cast<const f4v*>(part + ((((mi * WN + ni) * 4 + q) * kT) + tid) * 4u);
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) acc[mi][ni][4 * q + c] += v[c];
-                            }
-                }
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[set][mi][kA[q]], fb[set][ni][kB[q]], acc[mi][ni], 0, 0, 0);
             }
+            cur = nxt;
+        };
+        frags(0, 0u);
+        for (unsigned ks = ks_begin;;) {
+            kstep(Stage<0>{}, ks);
+            if (++ks >= ks_end) break;
+            kstep(Stage<1>{}, ks);
+            if (++ks >= ks_end) break;
         }
-        if (finish) {
-            const bool full_m = mbase + BM <= a.Cout;
-#ifdef FQ_C1_ABLATE
-            if (FQ_C1_OFF(1)) {
-            } else
-#endif
-#define FQ_C1_EPI(R, S, F) c1_epilogue<WM, WN, R, S, F>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
-#define FQ_C1_ADD(Y, S, N) c1_epilogue_add<WM, WN, Y, S, N>(acc, a, stat, s_bias, jbase, mbase, m0, n0, r, h)
-            if constexpr (is_add_stat<Stat>::value) {         // (whole row tiles only: host check)
-                if constexpr (!Stat::kMayStore) {
-                    if (a.stream_stores) FQ_C1_ADD(false, false, true); else FQ_C1_ADD(false, false, false);
-                } else
-                if (a.stream_stores) {
-                    if (a.store_y) { if (a.sum) FQ_C1_ADD(true, true, true); else FQ_C1_ADD(true, false, true); }
-                    else { if (a.sum) FQ_C1_ADD(false, true, true); else FQ_C1_ADD(false, false, true); }
-                } else {
-                    if (a.store_y) { if (a.sum) FQ_C1_ADD(true, true, false); else FQ_C1_ADD(true, false, false); }
-                    else { if (a.sum) FQ_C1_ADD(false, true, false); else FQ_C1_ADD(false, false, false); }
-                }
-            } else
-            if (a.relu) {
-                if (a.stream_stores) { if (full_m) FQ_C1_EPI(true, true, true); else FQ_C1_EPI(true, true, false); }
-                else { if (full_m) FQ_C1_EPI(true, false, true); else FQ_C1_EPI(true, false, false); }
-            } else {
-                if (a.stream_stores) { if (full_m) FQ_C1_EPI(false, true, true); else FQ_C1_EPI(false, true, false); }
-                else { if (full_m) FQ_C1_EPI(false, false, true); else FQ_C1_EPI(false, false, false); }
-            }
-#undef FQ_C1_EPI
-#undef FQ_C1_ADD
-        }
+        finish_tile<WM, WN>(acc, a, stat, s_bias, split, t, slice, jbase, mbase, m0, n0, r, h, tid, wave);
         __syncthreads();                                      // the next tile overwrites s_bias and stage 0
     }
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2))) void conv1x1_sb_kernel(const C1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
+    NoStat st;
+    conv1x1_tiles_sb<WM, WN>(a, st, sb_smem);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2))) void conv1x1_sb_absmax_kernel(const C1Args a, unsigned int* __restrict__ max_bits) {
+    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
+    MaxStat st;
+    conv1x1_tiles_sb<WM, WN>(a, st, sb_smem);
+    publish_max<kT>(st.m, max_bits);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2))) void conv1x1_sb_qd_kernel(const C1Args a, const QdStat qd) {
+    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
+    QdStat st = qd;
+    conv1x1_tiles_sb<WM, WN>(a, st, sb_smem);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2))) void conv1x1_sb_hist_kernel(
+    const C1Args a, const float* __restrict__ interval, unsigned long long* __restrict__ hist_row, const int allow_fast) {
+    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kT) s_bins[b] = 0u;
+    __syncthreads();
+    const float iv = *interval;
+    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (allow_fast && fast_quotient_ok(iv)) {
+        HistStat<true> st{s_bins, park, iv, 1.0f / iv};
+        conv1x1_tiles_sb<WM, WN>(a, st, sb_smem);
+    } else {
+        HistStat<false> st{s_bins, park, iv, 1.0f / iv};
+        conv1x1_tiles_sb<WM, WN>(a, st, sb_smem);
+    }
+    hist_flush<kT>(s_bins, hist_row);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2))) void conv1x1_sb_add_absmax_kernel(
+    const C1Args a, unsigned int* __restrict__ max_y_bits, unsigned int* __restrict__ max_sum_bits) {
+    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
+    AddStat<MaxStat, MaxStat, true> st;
+    conv1x1_tiles_sb<WM, WN>(a, st, sb_smem);
+    publish_max<kT>(st.c.m, max_y_bits);
+    __syncthreads();
+    publish_max<kT>(st.s.m, max_sum_bits);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2))) void conv1x1_sb_add_hist_kernel(
+    const C1Args a, const float* __restrict__ interval_y, unsigned long long* __restrict__ hist_y,
+    const float* __restrict__ interval_sum, unsigned long long* __restrict__ hist_sum, const int allow_fast) {
+    extern __shared__ __attribute__((aligned(16))) char sb_smem[];
+    __shared__ unsigned int s_bins[2][FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < 2 * (FQ_BINS + kWave); b += kT) (&s_bins[0][0])[b] = 0u;
+    __syncthreads();
+    const float ivy = *interval_y, ivs = *interval_sum;
+    unsigned int* park0 = s_bins[0] + FQ_BINS + (threadIdx.x & (kWave - 1));
+    unsigned int* park1 = s_bins[1] + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (allow_fast && fast_quotient_ok(ivy) && fast_quotient_ok(ivs)) {
+        AddStat<HistStat<true>, HistStat<true>, false> st{{s_bins[0], park0, ivy, 1.0f / ivy}, {s_bins[1], park1, ivs, 1.0f / ivs}};
+        conv1x1_tiles_sb<WM, WN>(a, st, sb_smem);
+    } else {
+        AddStat<HistStat<false>, HistStat<false>, false> st{{s_bins[0], park0, ivy, 1.0f / ivy}, {s_bins[1], park1, ivs, 1.0f / ivs}};
+        conv1x1_tiles_sb<WM, WN>(a, st, sb_smem);
+    }
+    hist_flush<kT>(s_bins[0], hist_y);
+    hist_flush<kT>(s_bins[1], hist_sum);
+}
+
+// fp32 [Cout][Cin] -> three bf16 planes [3][Cout][Cin]: hi, mid, lo of every weight
+__global__ __launch_bounds__(256) void conv1x1_sb_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, unsigned n) {
+    const unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    unsigned hi, mid, lo;
+    split3(w[i], hi, mid, lo);
+    out[i] = (unsigned short)hi; out[(size_t)n + i] = (unsigned short)mid; out[2 * (size_t)n + i] = (unsigned short)lo;
 }
 
 // (4 waves per SIMD = four workgroups per CU: <= 128 registers with the 64 accumulators; the K-tail form -- Cin not a multiple
@@ -648,6 +936,57 @@ void launch(C1Args a, unsigned cols, float* max_inout, const float* interval, in
     }
 }
 
+// the split-bf16 form: same tiling, tail split and statistics; LDS is dynamic (74 KB for the 128 x 128 tile: two workgroups per CU)
+template <int WM, int WN>
+int launch_sb(C1Args a, float* max_inout, const float* interval, int64_t* hist_row, int fast, const QdStat* qd, const float* res_interval_y,
+              int64_t* hist_y, const float* interval_sum, int64_t* hist_sum, float* max_y, float* max_sum, bool add, void* workspace,
+              size_t workspace_bytes, hipStream_t st) {
+    typedef ShapeSb<WM, WN> S;
+    a.tiles_m = (a.Cout + S::BM - 1) / S::BM;
+    a.tiles = ((a.cols + S::BN - 1) / S::BN) * a.tiles_m;
+    plan_split(a, a.Cin / (unsigned)kSbBK, workspace, workspace_bytes);
+    constexpr int lds = S::kBytes;
+    static bool d_plain[kMaxDevices], d_max[kMaxDevices], d_hist[kMaxDevices], d_qd[kMaxDevices], d_am[kMaxDevices], d_ah[kMaxDevices];
+    auto resident = [&](const void* k, int static_lds) {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, kT, (size_t)lds) != hipSuccess || n < 1) n = 1;
+        (void)static_lds;
+        return (unsigned)n;
+    };
+    if (add) {
+        if (hist_y) {
+            const void* k = reinterpret_cast<const void*>(conv1x1_sb_add_hist_kernel<WM, WN>);
+            if (!ensure_dynamic_lds(k, lds, d_ah)) return FQ_ERR_HIP;
+            unsigned grid = (unsigned)kCUs * resident(k, 0);
+            if (grid > a.work) grid = a.work;
+            hipLaunchKernelGGL((conv1x1_sb_add_hist_kernel<WM, WN>), dim3(grid), dim3(kT), lds, st, a, res_interval_y,
+                               reinterpret_cast<unsigned long long*>(hist_y), interval_sum, reinterpret_cast<unsigned long long*>(hist_sum), fast);
+        } else {
+            if (!ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_sb_add_absmax_kernel<WM, WN>), lds, d_am)) return FQ_ERR_HIP;
+            hipLaunchKernelGGL((conv1x1_sb_add_absmax_kernel<WM, WN>), dim3(a.work), dim3(kT), lds, st, a,
+                               reinterpret_cast<unsigned int*>(max_y), reinterpret_cast<unsigned int*>(max_sum));
+        }
+    } else if (qd) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_sb_qd_kernel<WM, WN>), lds, d_qd)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL((conv1x1_sb_qd_kernel<WM, WN>), dim3(a.work), dim3(kT), lds, st, a, *qd);
+    } else if (hist_row) {
+        const void* k = reinterpret_cast<const void*>(conv1x1_sb_hist_kernel<WM, WN>);
+        if (!ensure_dynamic_lds(k, lds, d_hist)) return FQ_ERR_HIP;
+        unsigned grid = (unsigned)kCUs * resident(k, 0);
+        if (grid > a.work) grid = a.work;
+        hipLaunchKernelGGL((conv1x1_sb_hist_kernel<WM, WN>), dim3(grid), dim3(kT), lds, st, a, interval,
+                           reinterpret_cast<unsigned long long*>(hist_row), fast);
+    } else if (max_inout) {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_sb_absmax_kernel<WM, WN>), lds, d_max)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL((conv1x1_sb_absmax_kernel<WM, WN>), dim3(a.work), dim3(kT), lds, st, a, reinterpret_cast<unsigned int*>(max_inout));
+    } else {
+        if (!ensure_dynamic_lds(reinterpret_cast<const void*>(conv1x1_sb_kernel<WM, WN>), lds, d_plain)) return FQ_ERR_HIP;
+        hipLaunchKernelGGL((conv1x1_sb_kernel<WM, WN>), dim3(a.work), dim3(kT), lds, st, a);
+    }
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
 }  // namespace
 }  // namespace fq
 
@@ -658,8 +997,10 @@ namespace {
 // the common host side of fq_conv1x1_f32 (R = S = 1, pad = 0) and fq_conv_kxk_f32
 int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y, float* relu_out, int N, int Cin, int Hin, int Win,
                     int Cout, int R, int S, int stride, int pad, float* max_inout, const float* interval, int64_t* hist_row,
-                    void* workspace, size_t workspace_bytes, fq_stream_t stream, const QdStat* qd = nullptr) {
+                    void* workspace, size_t workspace_bytes, fq_stream_t stream, const QdStat* qd = nullptr,
+                    const unsigned short* wsb = nullptr) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1 || R < 1 || S < 1 || pad < 0) return FQ_ERR_INVALID_ARG;
+    if (wsb) wt = reinterpret_cast<const float*>(wsb);                                        // (the checks below: non-null, 16-byte aligned)
     if (Hin + 2 * pad < R || Win + 2 * pad < S) return FQ_ERR_INVALID_ARG;
     if (max_inout && hist_row) return FQ_ERR_INVALID_ARG;
     if (hist_row && !interval) return FQ_ERR_INVALID_ARG;
@@ -668,6 +1009,7 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     if ((Cout & 3) || (reinterpret_cast<uintptr_t>(wt) & 15u)) return FQ_ERR_UNSUPPORTED;       // float4 loads of Wt rows
     const bool taps = R * S > 1 || pad > 0;
     if (taps && (Cin % 16) != 0) return FQ_ERR_UNSUPPORTED;                                   // whole K steps per tap
+    if (wsb && (taps || (Cin % kSbBK) != 0)) return FQ_ERR_UNSUPPORTED;                        // the split-bf16 form: 1x1, whole K steps of 16
     const int Hout = (Hin + 2 * pad - R) / stride + 1, Wout = (Win + 2 * pad - S) / stride + 1;
     const size_t cols = (size_t)N * Hout * Wout;
     const size_t in_elems = (size_t)N * Cin * Hin * Win, out_elems = cols * Cout, w_elems = (size_t)R * S * Cin * Cout;
@@ -675,13 +1017,13 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || w_elems >= (1ULL << 30) || out_elems >= (1ULL << 30))
         return FQ_ERR_UNSUPPORTED;
     C1Args a;
-    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out; a.res = nullptr; a.sum = nullptr; a.store_y = 1;
+    a.x = x; a.wt = wt; a.wsb = wsb; a.bias = bias; a.y = y; a.relu = relu_out; a.res = nullptr; a.sum = nullptr; a.store_y = 1;
     a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.HWin = (unsigned)(Hin * Win); a.HWout = (unsigned)(Hout * Wout);
     a.Win = (unsigned)Win; a.Wout = (unsigned)Wout; a.stride = (unsigned)stride;
     a.Hin = Hin; a.R = R; a.S = S; a.pad = pad;
     a.cols = (unsigned)cols;
     a.x_bytes = (unsigned)(in_elems * 4);
-    a.w_bytes = (unsigned)(w_elems * 4);
+    a.w_bytes = wsb ? (unsigned)(w_elems * 6) : (unsigned)(w_elems * 4);
     a.y_bytes = (unsigned)(out_elems * 4);
     a.tiles_m = a.tiles = 0;
     a.split_first = a.split_s = a.work = 0; a.ws = nullptr; a.ws_count = nullptr;
@@ -700,6 +1042,10 @@ int conv_f32_launch(const float* x, const float* wt, const float* bias, float* y
     static const int forced = env_int("FQ_CONV1X1_SHAPE", 0);
     const size_t tiles22 = ((cols + 127) / 128) * (size_t)((Cout + 127) / 128);
     const int shape = forced ? forced : ((Cout <= 64 || tiles22 <= (size_t)kCUs * 4) ? 12 : 22);
+    if (wsb) {
+        if (shape == 12) return launch_sb<1, 2>(a, max_inout, interval, hist_row, fast, qd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, workspace, workspace_bytes, st);
+        return launch_sb<2, 2>(a, max_inout, interval, hist_row, fast, qd, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, false, workspace, workspace_bytes, st);
+    }
 #define FQ_C1_LAUNCH(WM, WN)                                                                                       \
     do {                                                                                                           \
         if (mode == 2) launch<WM, WN, 2>(a, a.cols, max_inout, interval, hist_row, hist_per_cu, fast, qd, workspace, workspace_bytes, st);     \
@@ -735,10 +1081,11 @@ extern "C" int fq_conv_kxk_f32(const float* x, const float* wt, const float* bia
 // The last 1x1 convolution of a residual block together with the Eltwise (fabu_layer.py:5-11) and the ReLU behind it:
 // y = conv(x) + bias (abs-max -> *max_y; written to y unless y is null), sum = y + res (abs-max -> *max_sum; written unless
 // sum is null), relu_out = max(sum, 0).  Bit for bit what fq_conv1x1_f32 followed by fq_add_absmax_f32 leave.
-static int conv_add_launch(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
+static int conv_add_launch(const float* x, const float* wt_in, const unsigned short* wsb, const float* bias, const float* res, float* y, float* sum,
                            float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y, float* max_sum,
                            const float* interval_y, int64_t* hist_y, const float* interval_sum, int64_t* hist_sum,
                            void* workspace, size_t workspace_bytes, fq_stream_t stream) {
+    const float* wt = wsb ? reinterpret_cast<const float*>(wsb) : wt_in;
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0 || stride < 1) return FQ_ERR_INVALID_ARG;
     if (N == 0) return FQ_OK;
     const bool hist = hist_y != nullptr;
@@ -751,12 +1098,12 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
     if (cols >= 0xffffff00ULL || in_elems >= (1ULL << 30) || w_elems >= (1ULL << 30) || out_elems >= (1ULL << 30))
         return FQ_ERR_UNSUPPORTED;
     C1Args a;
-    a.x = x; a.wt = wt; a.bias = bias; a.y = y; a.relu = relu_out; a.res = res; a.sum = sum; a.store_y = y != nullptr;
+    a.x = x; a.wt = wt; a.wsb = wsb; a.bias = bias; a.y = y; a.relu = relu_out; a.res = res; a.sum = sum; a.store_y = y != nullptr;
     a.Cin = (unsigned)Cin; a.Cout = (unsigned)Cout; a.HWin = (unsigned)(Hin * Win); a.HWout = (unsigned)(Hout * Wout);
     a.Win = (unsigned)Win; a.Wout = (unsigned)Wout; a.stride = (unsigned)stride;
     a.Hin = Hin; a.R = 1; a.S = 1; a.pad = 0;
     a.cols = (unsigned)cols;
-    a.x_bytes = (unsigned)(in_elems * 4); a.w_bytes = (unsigned)(w_elems * 4); a.y_bytes = (unsigned)(out_elems * 4);
+    a.x_bytes = (unsigned)(in_elems * 4); a.w_bytes = wsb ? (unsigned)(w_elems * 6) : (unsigned)(w_elems * 4); a.y_bytes = (unsigned)(out_elems * 4);
     // non-temporal accesses beyond the Infinity Cache -- but only where a plane is a whole number of 64-byte blocks: the runs of
     // 128 bytes a wave stores are then whole blocks, and anything else streamed past the L2 becomes partial writes
     // (scripts/conv_add_bench.py: 256 -> 1024 @14x14, both tensors kept, 356 us with default stores, 486 with nt)
@@ -772,6 +1119,11 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
     hipStream_t st = as_stream(stream);
     a.tiles_m = (unsigned)Cout / (narrow ? 64u : 128u);
     a.tiles = (unsigned)((cols + 127) / 128) * a.tiles_m;
+    if (wsb) {
+        static const int fast_sb = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
+        if (narrow) return launch_sb<1, 2>(a, nullptr, nullptr, nullptr, fast_sb, nullptr, interval_y, hist_y, interval_sum, hist_sum, max_y, max_sum, true, workspace, workspace_bytes, st);
+        return launch_sb<2, 2>(a, nullptr, nullptr, nullptr, fast_sb, nullptr, interval_y, hist_y, interval_sum, hist_sum, max_y, max_sum, true, workspace, workspace_bytes, st);
+    }
     plan_split(a, (unsigned)Cin / (unsigned)(narrow ? step_of<1>() : step_of<2>()), workspace, workspace_bytes);
     if (hist) {
         static const int fast = [] { const char* e = getenv("FQ_HIST_IEEE_DIV"); return (e && e[0] && e[0] != '0') ? 0 : 1; }();
@@ -807,7 +1159,7 @@ static int conv_add_launch(const float* x, const float* wt, const float* bias, c
 extern "C" int fq_conv1x1_add_f32(const float* x, const float* wt, const float* bias, const float* res, float* y, float* sum,
                                   float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y,
                                   float* max_sum, void* workspace, size_t workspace_bytes, fq_stream_t stream) {
-    return conv_add_launch(x, wt, bias, res, y, sum, relu_out, N, Cin, Hin, Win, Cout, stride, max_y, max_sum, nullptr, nullptr,
+    return conv_add_launch(x, wt, nullptr, bias, res, y, sum, relu_out, N, Cin, Hin, Win, Cout, stride, max_y, max_sum, nullptr, nullptr,
                            nullptr, nullptr, workspace, workspace_bytes, stream);
 }
 
@@ -818,7 +1170,7 @@ extern "C" int fq_conv1x1_add_hist_f32(const float* x, const float* wt, const fl
                                        int64_t* hist_y, const float* interval_sum, int64_t* hist_sum, void* workspace,
                                        size_t workspace_bytes, fq_stream_t stream) {
     if (!hist_y) return FQ_ERR_INVALID_ARG;
-    return conv_add_launch(x, wt, bias, res, nullptr, nullptr, relu_out, N, Cin, Hin, Win, Cout, stride, nullptr, nullptr, interval_y,
+    return conv_add_launch(x, wt, nullptr, bias, res, nullptr, nullptr, relu_out, N, Cin, Hin, Win, Cout, stride, nullptr, nullptr, interval_y,
                            hist_y, interval_sum, hist_sum, workspace, workspace_bytes, stream);
 }
 
@@ -848,4 +1200,52 @@ extern "C" int fq_conv_kxk_qd_f32(const float* x, const float* wt, const float* 
     if (!qd_params(bit, bitwidth, &qd)) return FQ_ERR_INVALID_ARG;
     return conv_f32_launch(x, wt, bias, y, nullptr, N, Cin, Hin, Win, Cout, R, S, stride, pad, nullptr, nullptr, nullptr, workspace,
                            workspace_bytes, stream, &qd);
+}
+
+// ---- the split-bf16 form of the 1x1 convolutions (conv1x1_tiles_sb): same contracts, weights packed by fq_conv1x1_sb_pack
+extern "C" size_t fq_conv1x1_sb_packed_bytes(int Cin, int Cout) { return (Cin > 0 && Cout > 0) ? (size_t)6 * (size_t)Cin * (size_t)Cout : 0; }
+
+extern "C" int fq_conv1x1_sb_supported(int Cin, int Cout) { return Cin > 0 && Cout > 0 && (Cin % kSbBK) == 0 && (Cout & 3) == 0; }
+
+extern "C" int fq_conv1x1_sb_pack(const float* w_kc, void* wsb, int Cin, int Cout, fq_stream_t stream) {
+    if (!w_kc || !wsb || Cin <= 0 || Cout <= 0) return FQ_ERR_INVALID_ARG;
+    if ((size_t)Cin * Cout >= (1ULL << 30)) return FQ_ERR_UNSUPPORTED;
+    const unsigned n = (unsigned)Cin * (unsigned)Cout;
+    hipLaunchKernelGGL(conv1x1_sb_pack_kernel, dim3((n + 255u) / 256u), dim3(256), 0, as_stream(stream), w_kc, static_cast<unsigned short*>(wsb), n);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+extern "C" int fq_conv1x1_sb_f32(const float* x, const void* wsb, const float* bias, float* y, float* relu_out, int N, int Cin,
+                                 int Hin, int Win, int Cout, int stride, float* max_inout, const float* interval,
+                                 int64_t* hist_row, void* workspace, size_t workspace_bytes, fq_stream_t stream) {
+    if (!wsb) return FQ_ERR_INVALID_ARG;
+    return conv_f32_launch(x, nullptr, bias, y, relu_out, N, Cin, Hin, Win, Cout, 1, 1, stride, 0, max_inout, interval, hist_row,
+                           workspace, workspace_bytes, stream, nullptr, static_cast<const unsigned short*>(wsb));
+}
+
+extern "C" int fq_conv1x1_sb_qd_f32(const float* x, const void* wsb, const float* bias, float* y, int N, int Cin, int Hin, int Win,
+                                    int Cout, int stride, int bit, int bitwidth, void* workspace, size_t workspace_bytes,
+                                    fq_stream_t stream) {
+    QdStat qd;
+    if (!wsb || !qd_params(bit, bitwidth, &qd)) return FQ_ERR_INVALID_ARG;
+    return conv_f32_launch(x, nullptr, bias, y, nullptr, N, Cin, Hin, Win, Cout, 1, 1, stride, 0, nullptr, nullptr, nullptr, workspace,
+                           workspace_bytes, stream, &qd, static_cast<const unsigned short*>(wsb));
+}
+
+extern "C" int fq_conv1x1_sb_add_f32(const float* x, const void* wsb, const float* bias, const float* res, float* y, float* sum,
+                                     float* relu_out, int N, int Cin, int Hin, int Win, int Cout, int stride, float* max_y,
+                                     float* max_sum, void* workspace, size_t workspace_bytes, fq_stream_t stream) {
+    if (!wsb) return FQ_ERR_INVALID_ARG;
+    return conv_add_launch(x, nullptr, static_cast<const unsigned short*>(wsb), bias, res, y, sum, relu_out, N, Cin, Hin, Win, Cout, stride,
+                           max_y, max_sum, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fq_conv1x1_sb_add_hist_f32(const float* x, const void* wsb, const float* bias, const float* res, float* relu_out, int N,
+                                          int Cin, int Hin, int Win, int Cout, int stride, const float* interval_y, int64_t* hist_y,
+                                          const float* interval_sum, int64_t* hist_sum, void* workspace, size_t workspace_bytes,
+                                          fq_stream_t stream) {
+    if (!wsb || !hist_y) return FQ_ERR_INVALID_ARG;
+    return conv_add_launch(x, nullptr, static_cast<const unsigned short*>(wsb), bias, res, nullptr, nullptr, relu_out, N, Cin, Hin, Win, Cout,
+                           stride, nullptr, nullptr, interval_y, hist_y, interval_sum, hist_sum, workspace, workspace_bytes, stream);
 }

@@ -82,11 +82,13 @@ def weight(m, k):
     """The weights in the layout the kernel reads (Wt [Cin][Cout] / the packed stem matrix / the transformed Winograd
     weights), one entry per kind, rebuilt when the parameter was written to or replaced."""
     w = m.weight
-    tag = (w._version, w.data_ptr(), w.device)
+    tag = (w._version, w.data_ptr(), w.device, _native.conv_sb_enabled())
     by_kind = state(m).setdefault("wt", {})
     cached = by_kind.get(k)
     if cached is None or cached[0] != tag:
-        packed = (w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1"
+        sb = k == "c1" and _native.conv_sb_enabled() and _native.conv_sb_supported(w.shape[1], w.shape[0])
+        packed = (_native.pack_sb_weight(w) if sb                # (opt-in: the split-bf16 form of the 1x1 kernels takes this pack)
+                  else w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1"
                   else _native.pack_kxk_weight(w) if k == "kxk"
                   else _native.pack_wino_weight(w) if k == "wino" else _native.pack_stem_weight(w))
         cached = (tag, packed)

@@ -126,6 +126,20 @@ def lib():
     L.fq_conv1x1_add_hist_f32.argtypes = [vp] * 5 + [ci] * 6 + [vp, vp, vp, vp, vp, sz, vp]
     L.fq_conv1x1_qd_f32.restype = ci
     L.fq_conv1x1_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 8 + [vp, sz, vp]
+    L.fq_conv1x1_sb_packed_bytes.restype = sz
+    L.fq_conv1x1_sb_packed_bytes.argtypes = [ci, ci]
+    L.fq_conv1x1_sb_supported.restype = ci
+    L.fq_conv1x1_sb_supported.argtypes = [ci, ci]
+    L.fq_conv1x1_sb_pack.restype = ci
+    L.fq_conv1x1_sb_pack.argtypes = [vp, vp, ci, ci, vp]
+    L.fq_conv1x1_sb_f32.restype = ci
+    L.fq_conv1x1_sb_f32.argtypes = L.fq_conv1x1_f32.argtypes
+    L.fq_conv1x1_sb_qd_f32.restype = ci
+    L.fq_conv1x1_sb_qd_f32.argtypes = L.fq_conv1x1_qd_f32.argtypes
+    L.fq_conv1x1_sb_add_f32.restype = ci
+    L.fq_conv1x1_sb_add_f32.argtypes = L.fq_conv1x1_add_f32.argtypes
+    L.fq_conv1x1_sb_add_hist_f32.restype = ci
+    L.fq_conv1x1_sb_add_hist_f32.argtypes = L.fq_conv1x1_add_hist_f32.argtypes
     L.fq_conv_kxk_qd_f32.restype = ci
     L.fq_conv_kxk_qd_f32.argtypes = [vp, vp, vp, vp] + [ci] * 11 + [vp, sz, vp]
     L.fq_conv_stem_qd_f32.restype = ci
@@ -400,16 +414,49 @@ def conv_workspace(x):
     return ws.data_ptr(), ws.numel()
 
 
+def conv_sb_enabled():
+    """FQ_CONV_SPLIT_BF16=1 runs the float 1x1 convolutions on the split-bf16 kernels (fq_conv1x1_sb_f32 and its add / QuanDequan
+    forms) instead of the fp32 MFMA ones.  Off by default: as accurate, not faster yet."""
+    return os.environ.get("FQ_CONV_SPLIT_BF16", "0") == "1"
+
+
+def conv_sb_supported(cin, cout):
+    return bool(lib().fq_conv1x1_sb_supported(int(cin), int(cout)))
+
+
+def pack_sb_weight(weight):
+    """[Cout, Cin(, 1, 1)] fp32 -> int16 [3, Cout, Cin]: the hi / mid / lo bf16 planes the split-bf16 1x1 kernels read
+    (fq_conv1x1_sb_pack).  conv1x1_f32 / conv1x1_add_f32 / conv1x1_add_hist_f32 take it in place of the transposed weights."""
+    _need_cuda(weight, torch.float32, "fq_conv1x1_sb_pack")
+    cout, cin = int(weight.shape[0]), int(weight.shape[1])
+    w = weight.detach().reshape(cout, cin).contiguous()
+    out = torch.empty((3, cout, cin), dtype=torch.int16, device=w.device)
+    assert out.numel() * 2 == lib().fq_conv1x1_sb_packed_bytes(cin, cout)
+    _check(lib().fq_conv1x1_sb_pack(w.data_ptr(), out.data_ptr(), cin, cout, _stream(w)), "fq_conv1x1_sb_pack")
+    return out
+
+
+def _sb(wt):
+    """(is the weight operand a split-bf16 pack?, Cin, Cout)"""
+    if wt.dtype == torch.int16:
+        assert wt.is_cuda and wt.dim() == 3 and wt.shape[0] == 3 and wt.is_contiguous()
+        return True, int(wt.shape[2]), int(wt.shape[1])
+    _need_cuda(wt, torch.float32, "fq_conv1x1_f32")
+    assert wt.dim() == 2 and wt.is_contiguous()
+    return False, int(wt.shape[0]), int(wt.shape[1])
+
+
 def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev=None, row=None, relu_out=None, out=None, qd=None):
     """fq_conv1x1_f32: the float 1x1 convolution (padding 0, groups 1) of x [N, Cin, H, W] with the TRANSPOSED weights
     wt [Cin, Cout] on the fp32 matrix cores; max_dev/row: abs-max of the output folded into max_dev[row]; interval_dev/
     hist_dev/row: the output histogrammed into hist_dev[row]; relu_out: also receives max(y, 0).  qd = bit or (bit, bitwidth):
     fq_conv1x1_qd_f32 instead -- QuanDequan(bit) applied in the epilogue (TestConv.forward in one kernel).  Returns y."""
     _need_cuda(x, torch.float32, "fq_conv1x1_f32")
-    _need_cuda(wt, torch.float32, "fq_conv1x1_f32")
-    assert x.dim() == 4 and x.is_contiguous() and wt.dim() == 2 and wt.is_contiguous() and wt.shape[0] == x.shape[1]
+    sb, wcin, Cout = _sb(wt)                                    # (an int16 [3, Cout, Cin] pack: the split-bf16 kernels)
+    assert x.dim() == 4 and x.is_contiguous() and wcin == x.shape[1]
     N, Cin, H, W = (int(v) for v in x.shape)
-    Cout, s = int(wt.shape[1]), int(stride)
+    s = int(stride)
+    fn, fn_qd = (lib().fq_conv1x1_sb_f32, lib().fq_conv1x1_sb_qd_f32) if sb else (lib().fq_conv1x1_f32, lib().fq_conv1x1_qd_f32)
     shape = (N, Cout, (H - 1) // s + 1, (W - 1) // s + 1)
     if out is False:                                            # only the ReLU's output is wanted: y is not written
         assert relu_out is not None and qd is None and tuple(relu_out.shape) == shape
@@ -422,8 +469,8 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
         assert bias.is_contiguous() and bias.numel() == Cout
     if qd is not None:
         bit, bw = _qd_args(qd, max_dev, hist_dev, relu_out, "fq_conv1x1_qd_f32")
-        _check(lib().fq_conv1x1_qd_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
-                                       N, Cin, H, W, Cout, s, bit, bw, *conv_workspace(x), _stream(x)), "fq_conv1x1_qd_f32")
+        _check(fn_qd(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(), y.data_ptr(),
+                     N, Cin, H, W, Cout, s, bit, bw, *conv_workspace(x), _stream(x)), "fq_conv1x1_qd_f32")
         return y
     mp = ivp = hp = None
     if hist_dev is not None:
@@ -432,9 +479,9 @@ def conv1x1_f32(x, wt, bias, stride=1, max_dev=None, interval_dev=None, hist_dev
         _need_cuda(max_dev, torch.float32, "fq_conv1x1_f32")
         assert max_dev.is_contiguous() and 0 <= row < max_dev.numel()
         mp = max_dev.data_ptr() + 4 * int(row)
-    _check(lib().fq_conv1x1_f32(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(),
-                                None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin, H, W,
-                                Cout, s, mp, ivp, hp, *conv_workspace(x), _stream(x)), "fq_conv1x1_f32")
+    _check(fn(x.data_ptr(), wt.data_ptr(), None if bias is None else bias.data_ptr(),
+              None if y is None else y.data_ptr(), _relu_ptr(relu_out, relu_out if y is None else y), N, Cin, H, W,
+              Cout, s, mp, ivp, hp, *conv_workspace(x), _stream(x)), "fq_conv1x1_f32")
     return y
 
 
@@ -442,17 +489,18 @@ def conv1x1_add_f32(x, wt, bias, stride, res, max_dev, row_y, row_sum, relu_out,
     """fq_conv1x1_add_f32: the 1x1 convolution of conv1x1_f32, the Eltwise that consumes it and the ReLU behind that in one
     kernel (pass 1).  v = conv(x) + bias: abs-max folded into max_dev[row_y], written to `out` when given; s = v + res: abs-max
     into max_dev[row_sum], written to `sum_out` when given; relu_out receives max(s, 0).  Returns relu_out."""
-    for t in (x, wt, bias, res, max_dev, relu_out):
+    for t in (x, bias, res, max_dev, relu_out):
         _need_cuda(t, torch.float32, "fq_conv1x1_add_f32")
-    assert x.dim() == 4 and x.is_contiguous() and wt.dim() == 2 and wt.is_contiguous() and wt.shape[0] == x.shape[1]
+    sb, wcin, Cout = _sb(wt)
+    assert x.dim() == 4 and x.is_contiguous() and wcin == x.shape[1]
     N, Cin, H, W = (int(v) for v in x.shape)
-    Cout, s = int(wt.shape[1]), int(stride)
+    s = int(stride)
     shape = (N, Cout, (H - 1) // s + 1, (W - 1) // s + 1)
     assert bias.is_contiguous() and bias.numel() == Cout and max_dev.is_contiguous()
     assert 0 <= row_y < max_dev.numel() and 0 <= row_sum < max_dev.numel() and row_y != row_sum
     for t in (res, relu_out, out, sum_out):
         assert t is None or (tuple(t.shape) == shape and t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda)
-    _check(lib().fq_conv1x1_add_f32(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(),
+    _check((lib().fq_conv1x1_sb_add_f32 if sb else lib().fq_conv1x1_add_f32)(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(),
                                     None if out is None else out.data_ptr(), None if sum_out is None else sum_out.data_ptr(),
                                     relu_out.data_ptr(), N, Cin, H, W, Cout, s, max_dev.data_ptr() + 4 * int(row_y),
                                     max_dev.data_ptr() + 4 * int(row_sum), *conv_workspace(x), _stream(x)), "fq_conv1x1_add_f32")
@@ -462,18 +510,19 @@ def conv1x1_add_f32(x, wt, bias, stride, res, max_dev, row_y, row_sum, relu_out,
 def conv1x1_add_hist_f32(x, wt, bias, stride, res, interval_dev, hist_dev, row_y, row_sum, relu_out):
     """fq_conv1x1_add_hist_f32: the chain of conv1x1_add_f32 in pass 2 -- v = conv(x) + bias counted into hist_dev[row_y], s = v + res
     into hist_dev[row_sum] (bin widths interval_dev[row]); neither is written; relu_out receives max(s, 0).  Returns relu_out."""
-    for t in (x, wt, bias, res, relu_out):
+    for t in (x, bias, res, relu_out):
         _need_cuda(t, torch.float32, "fq_conv1x1_add_hist_f32")
-    assert x.dim() == 4 and x.is_contiguous() and wt.dim() == 2 and wt.is_contiguous() and wt.shape[0] == x.shape[1]
+    sb, wcin, Cout = _sb(wt)
+    assert x.dim() == 4 and x.is_contiguous() and wcin == x.shape[1]
     N, Cin, H, W = (int(v) for v in x.shape)
-    Cout, s = int(wt.shape[1]), int(stride)
+    s = int(stride)
     shape = (N, Cout, (H - 1) // s + 1, (W - 1) // s + 1)
     assert bias.is_contiguous() and bias.numel() == Cout and row_y != row_sum
     for t in (res, relu_out):
         assert tuple(t.shape) == shape and t.is_contiguous()
     ivy, hy = _hist_row_ptrs(interval_dev, hist_dev, row_y)
     ivs, hs = _hist_row_ptrs(interval_dev, hist_dev, row_sum)
-    _check(lib().fq_conv1x1_add_hist_f32(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(), relu_out.data_ptr(),
+    _check((lib().fq_conv1x1_sb_add_hist_f32 if sb else lib().fq_conv1x1_add_hist_f32)(x.data_ptr(), wt.data_ptr(), bias.data_ptr(), res.data_ptr(), relu_out.data_ptr(),
                                          N, Cin, H, W, Cout, s, ivy, hy, ivs, hs, *conv_workspace(x), _stream(x)),
            "fq_conv1x1_add_hist_f32")
     return relu_out

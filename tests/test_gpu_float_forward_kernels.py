@@ -758,3 +758,106 @@ def test_pool_modules_are_served_and_tables_do_not_change():
             served = [pytorch_quantizer._flag(m, pytorch_quantizer._POOL_VERIFIED) for m in (q.model.pool, q.model.avg)]
             assert served == [own, own] and "forward" not in q.model.pool.__dict__      # patched only while calibrating
     assert tables[0] == tables[1]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The split-bf16 form of the 1x1 kernels (fq_conv1x1_sb_f32 and its add / QuanDequan forms; opt-in, FQ_CONV_SPLIT_BF16=1): every fp32
+# operand as three bf16 values on the bf16 matrix cores, six of the nine products.  Same contracts as the fp32-MFMA entry points.
+SB_SHAPES = [s for s in SHAPES if s[1] % 16 == 0 and s[2] % 4 == 0]
+
+
+@pytest.mark.parametrize("shape", SB_SHAPES, ids=lambda s: "x".join(map(str, s)))
+def test_split_bf16_exact_on_integer_valued_data_and_as_accurate_as_the_fp32_chain(nat, shape):
+    x, w, b, wt, s = _case(shape, 21, integer=True)       # integers below 2^8 have no mid and lo part: exact, as on the fp32 MFMA
+    wsb = nat.pack_sb_weight(w)
+    assert torch.equal(nat.conv1x1_f32(x, wsb, b, s).double(), _ref64(x, w, b, s))
+    assert torch.equal(nat.conv1x1_f32(x, wsb, None, s).double(), _ref64(x, w, None, s))
+    x, w, b, wt, s = _case(shape, 22, integer=False)
+    wsb = nat.pack_sb_weight(w)
+    ref, bound = _ref64(x, w, b, s), _ref64(x.abs(), w.abs(), b.abs(), s)
+    y, yf = nat.conv1x1_f32(x, wsb, b, s), nat.conv1x1_f32(x, wt, b, s)
+    err, err_f = float(((y.double() - ref).abs() / bound).max()), float(((yf.double() - ref).abs() / bound).max())
+    assert err <= 1e-5 and err <= 1.5 * err_f + 1e-7, (err, err_f)            # the product's bound, and the fp32 chain's class
+    assert torch.equal(y, nat.conv1x1_f32(x, wsb, b, s))                      # same bits from run to run
+    # the statistic forms, the ReLU copy, the QuanDequan form: on the SAME output
+    mx = torch.tensor([0.0, 1e9, 0.0], device="cuda")
+    r = torch.empty_like(y)
+    assert torch.equal(nat.conv1x1_f32(x, wsb, b, s, max_dev=mx, row=2, relu_out=r), y) and torch.equal(r, torch.relu(y))
+    assert mx.tolist() == [0.0, 1e9, float(y.abs().max())]
+    iv = torch.tensor([1.0, float(y.abs().max()) / 2048 + 1e-12], device="cuda")
+    hist = torch.zeros(2, 2048, dtype=torch.int64, device="cuda")
+    hist[1, 5] = 7
+    want = hist.clone()
+    assert torch.equal(nat.conv1x1_f32(x, wsb, b, s, interval_dev=iv, hist_dev=hist, row=1, relu_out=r), y)
+    nat.hist2048_seg([y], [1], iv, want)
+    assert torch.equal(hist, want) and torch.equal(r, torch.relu(y))
+    assert torch.equal(nat.conv1x1_f32(x, wsb, b, s, qd=(4, 8)), nat.quandequan(y.clone(), 4, 8))
+    r2 = torch.full_like(y, 3.0)
+    mx2 = torch.zeros(1, device="cuda")
+    assert nat.conv1x1_f32(x, wsb, b, s, max_dev=mx2, row=0, relu_out=r2, out=False) is None
+    assert torch.equal(r2, torch.relu(y)) and float(mx2[0]) == float(y.abs().max())
+
+
+@pytest.mark.parametrize("shape", [(3, 64, 13, 9, 256, 1), (5, 256, 7, 7, 1024, 1), (2, 64, 15, 15, 128, 2), (9, 256, 28, 28, 640, 1),
+                                   (130, 256, 8, 16, 1024, 1)], ids=lambda s: "x".join(map(str, s)))
+def test_split_bf16_conv_add_forms_equal_their_two_kernels(nat, shape):
+    """fq_conv1x1_sb_add_f32 / _add_hist_f32 leave bit for bit what fq_conv1x1_sb_f32 followed by the Eltwise kernels leave (the
+    contract of the fp32 pair), tail split included (the last two shapes)."""
+    N, Cin, H, W, Cout, s = shape
+    g = torch.Generator(device="cuda").manual_seed(3 + sum(shape))
+    x = torch.randn(N, Cin, H, W, device="cuda", generator=g) * 2
+    w = torch.randn(Cout, Cin, device="cuda", generator=g) * Cin ** -0.5
+    wsb = nat.pack_sb_weight(w)
+    b = torch.randn(Cout, device="cuda", generator=g)
+    ho, wo = (H - 1) // s + 1, (W - 1) // s + 1
+    res = torch.randn(N, Cout, ho, wo, device="cuda", generator=g) * 3
+    m2 = torch.zeros(4, device="cuda")
+    v = nat.conv1x1_f32(x, wsb, b, s, max_dev=m2, row=1)
+    r2 = torch.empty_like(v)
+    sm = nat.add_absmax(v, res, m2, 3, relu_out=r2)
+    m1 = torch.zeros(4, device="cuda")
+    y, so, r1 = torch.empty_like(v), torch.empty_like(v), torch.empty_like(v)
+    nat.conv1x1_add_f32(x, wsb, b, s, res, m1, 1, 3, r1, out=y, sum_out=so)
+    assert torch.equal(m1, m2) and torch.equal(y, v) and torch.equal(so, sm) and torch.equal(r1, r2)
+    iv = torch.tensor([1.0, 0.004, 1.0, 0.0061], device="cuda")
+    h2 = torch.zeros(4, 2048, dtype=torch.int64, device="cuda")
+    h1 = h2.clone()
+    v = nat.conv1x1_f32(x, wsb, b, s, interval_dev=iv, hist_dev=h2, row=1)
+    nat.add_hist(v, res, iv, h2, 3, relu_out=r2)
+    nat.conv1x1_add_hist_f32(x, wsb, b, s, res, iv, h1, 1, 3, r1)
+    assert torch.equal(h1, h2) and torch.equal(r1, r2)
+
+
+def test_split_bf16_pack_and_argument_errors(nat):
+    L = nat.lib()
+    g = torch.Generator(device="cuda").manual_seed(31)
+    w = torch.randn(8, 16, device="cuda", generator=g)
+    p = nat.pack_sb_weight(w).view(torch.bfloat16)                              # [3, Cout, Cin]
+    assert torch.equal(p[0].float() + p[1].float() + p[2].float(), w)           # hi + mid + lo IS the weight
+    assert torch.equal(p[0], w.bfloat16())
+    assert L.fq_conv1x1_sb_supported(16, 8) == 1 and L.fq_conv1x1_sb_supported(24, 8) == 0 and L.fq_conv1x1_sb_supported(16, 6) == 0
+    x = torch.zeros(1, 24, 4, 4, device="cuda")
+    y = torch.zeros(1, 8, 4, 4, device="cuda")
+    assert L.fq_conv1x1_sb_f32(x.data_ptr(), p.data_ptr(), None, y.data_ptr(), None, 1, 24, 4, 4, 8, 1, None, None, None, None, 0, None) == -4
+    assert L.fq_conv1x1_sb_f32(x.data_ptr(), None, None, y.data_ptr(), None, 1, 16, 4, 4, 8, 1, None, None, None, None, 0, None) == -1
+    assert L.fq_conv1x1_sb_pack(None, p.data_ptr(), 16, 8, None) == -1
+
+
+def test_resnet50_tables_with_the_split_bf16_kernels(monkeypatch):
+    """The product with FQ_CONV_SPLIT_BF16=1: the fabu ResNet-50's feat.table is the one the fp32-MFMA kernels give."""
+    from common.quantity import merge_bn, _float_conv
+    from model.resnet.ResNet_fabu import ResNet50
+    from tools import Quantity
+    model = merge_bn(cases.seed_model(ResNet50(input_size=64)).eval()).cuda()
+    batches = cases.calib_batches(4, (4, 3, 64, 64), seed=58)
+    tables = []
+    for env in ("1", "0"):
+        monkeypatch.setenv("FQ_CONV_SPLIT_BF16", env)
+        _float_conv.forget()
+        with product_workdir(input_shape="1,3,64,64", device="gpu", max_cali_img_num=3) as tmp:
+            q = Quantity(model)
+            bits = q.activation_quantize(batches)
+            tables.append((dict(bits), open(tmp + "/test/workdir/feat.table").read()))
+    monkeypatch.undo()
+    _float_conv.forget()
+    assert tables[0] == tables[1]
