@@ -7,6 +7,8 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity"))
 from common.quantity import _native as nat
+if os.environ.get("FQ_SB_LIB"):                                # a debug build (timing only, wrong results)
+    nat.LIB_PATH = nat.LIB_PATH.replace("libfq_hip.so", "libfq_hip_%s.so" % os.environ["FQ_SB_LIB"])
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 MODE = sys.argv[2] if len(sys.argv) > 2 else "max"
 # cin, cout, hw, stride, count
