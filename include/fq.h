@@ -234,7 +234,8 @@ int fq_conv1x1_f32(const float* x, const float* wt, const float* bias, float* y,
  * (profiles/r04_bf16x3_probe.txt; tests/test_gpu_float_forward_kernels.py holds both to the same bound); integer-valued operands
  * below 2^8 are exact as before; a non-finite input gives NaN.  Same operands, epilogues, statistics, workspace / tail split and
  * error codes as the entry points they shadow, except:
- *   wsb: the weights packed by fq_conv1x1_sb_pack from fp32 [Cout][Cin] (NOT transposed) into three bf16 planes [3][Cout][Cin],
+ *   wsb: the weights packed by fq_conv1x1_sb_pack from fp32 [Cout][Cin] (NOT transposed) into bf16 [Cin / 16][plane: hi, mid, lo]
+ *        [k % 16 / 8][Cout][8] -- the order the kernel's lanes load their MFMA operands in, straight from global memory --
  *        fq_conv1x1_sb_packed_bytes(Cin, Cout) bytes, 16-byte aligned;  Cin % 16 == 0, Cout % 4 == 0 (fq_conv1x1_sb_supported). */
 size_t fq_conv1x1_sb_packed_bytes(int Cin, int Cout);
 int fq_conv1x1_sb_supported(int Cin, int Cout);

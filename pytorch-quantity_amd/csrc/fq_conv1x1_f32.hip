@@ -531,6 +531,10 @@ __device__ __forceinline__ void conv1x1_tiles(const C1Args& a, Stat& stat, float
 // 16-byte pieces.  LDS per stage: [plane 3][k / 8: 2][row or column][8 bf16] for both operands -- every fragment read is one
 // conflict-free ds_read_b128.  Same three-stage pipeline with one barrier in the middle of a step, same accumulator layout,
 // hence the same epilogues, statistics and tail split as the fp32 kernel.
+#ifndef FQ_SB_ABLATE
+#define FQ_SB_ABLATE 0      // debug builds only (scripts/_dbg/build_sb_variants.sh): 1 no x loads after the first two K steps, 2 no W loads, 4 no split, 8 no LDS stores -- wrong results, timing only
+#endif
+#define FQ_SB_OFF(bit) ((FQ_SB_ABLATE) & (bit))
 constexpr int kSbBK = 16;
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef __bf16 bf2v __attribute__((ext_vector_type(2)));
@@ -540,8 +544,7 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 template <int WM, int WN>
 struct ShapeSb {
     static constexpr int BM = 64 * WM, BN = 64 * WN;
-    static constexpr int kABytes = 3 * 2 * BM * 16, kBBytes = 3 * 2 * BN * 16, kStage = kABytes + kBBytes;
-    static constexpr int kWVecs = (3 * 2 * BM + kT - 1) / kT;          // 16-byte pieces of the W tile per thread and K step
+    static constexpr int kStage = 3 * 2 * BN * 16;                     // the x tile of one K step: three planes, 12 KB
     static constexpr int kBytes = 3 * kStage + BM * 4;                 // three stages + the bias slice
     static_assert(BN == 128, "the x tile is staged by 128 columns x 2 halves of the K step = 256 threads");
 };
@@ -560,6 +563,11 @@ __device__ __forceinline__ void split3(float v, unsigned& hi, unsigned& mid, uns
     lo = bf16_bits(r2);
 }
 
+// Where the time of the first form went (profiles/r04_conv1x1_split_bf16_ablation.txt): not into the split (compiled out: -2 %) but
+// into LDS -- a bf16 MFMA eats its operands 12 x faster per matrix cycle than the fp32 one, and with both operands staged the LDS ran at
+// ~ 90 of its 128 bytes per cycle and CU.  So the WEIGHTS do not go through LDS at all: the pack is laid out [k / 16][plane][k % 16 / 8]
+// [Cout][8] and a lane's fragment is ONE 16-byte global load (coalesced: consecutive rows are consecutive pieces; L2-resident, the
+// second wave with the same rows hits L1), issued a whole K step ahead into the second of two fragment sets.  Only the x tile is staged.
 template <int WM, int WN, typename Stat>
 __device__ __forceinline__ void conv1x1_tiles_sb(const C1Args& a, Stat& stat, char* smem) {
     typedef ShapeSb<WM, WN> S;
@@ -574,9 +582,9 @@ __device__ __forceinline__ void conv1x1_tiles_sb(const C1Args& a, Stat& stat, ch
     const unsigned nk = a.Cin / kSbBK;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.wsb), 0, a.w_bytes, 0x00020000);
-    // fragment reads: A + ((plane * 2 + h) * BM + m0 + 32 mi + r) * 16, B + ((plane * 2 + h) * BN + n0 + 32 ni + r) * 16
-    const unsigned ard = (h * BM + m0 + r) * 16u, brd = S::kABytes + (h * BN + n0 + r) * 16u;
-    const unsigned bwr = S::kABytes + (xh * BN + xc) * 16u;       // x tile stores: + stage + plane * 2 * BN * 16
+    const unsigned brd = (h * BN + n0 + r) * 16u;                 // B fragment reads: + stage + (plane * 2 * BN + 32 ni) * 16
+    const unsigned bwr = (xh * BN + xc) * 16u;                    // x tile stores:    + stage + plane * 2 * BN * 16
+    const unsigned wplane = 2u * a.Cout * 16u, wstep = 3u * wplane;   // bytes of one plane / of one K step of the pack
 
     for (unsigned wi = v0; wi < a.work; wi += G) {
         unsigned t = wi, ks_begin = 0, ks_end = nk, slice = 0;
@@ -602,38 +610,26 @@ __device__ __forceinline__ void conv1x1_tiles_sb(const C1Args& a, Stat& stat, ch
             }
             xo = (n * a.Cin * a.HWin + pin + 8u * xh * a.HWin) * 4u;
         }
-        // W: 16-byte piece v of a K step = (plane, row, half): v = tid + kT i; rows past Cout re-read the last row (never stored)
-        unsigned wo[S::kWVecs], wl[S::kWVecs];
+        // W fragments: this lane's row of each 32-row block (rows past Cout re-read the last row: those accumulators are never stored)
+        unsigned wfo[WM];
 #pragma unroll
-        for (int i = 0; i < S::kWVecs; ++i) {
-            const unsigned v = tid + (unsigned)kT * i, plane = v / (2u * BM), rem = v - plane * (2u * BM), row = rem >> 1, half = rem & 1u;
-            const unsigned grow = min(mbase + row, a.Cout - 1u);
-            wo[i] = ((plane * a.Cout + grow) * a.Cin + 8u * half) * 2u;
-            wl[i] = ((plane * 2u + half) * BM + row) * 16u;
-        }
-        float xr[8];
-        u4v wreg[S::kWVecs];
-        auto gload = [&](unsigned ks) {                        // ks is uniform: the K advance is scalar arithmetic
-            const unsigned xs = ks * kSbBK * a.HWin * 4u, ws = ks * kSbBK * 2u;
+        for (int mi = 0; mi < WM; ++mi) wfo[mi] = (h * a.Cout + min(mbase + m0 + 32u * mi + r, a.Cout - 1u)) * 16u;
+        // the x values of step k wait in register set k % 2 (relative to ks_begin): they are loaded TWO steps before they are split
+        // and stored (one step was not enough latency cover: the staging waited for them)
+        float xr[2][8];
+        auto gload = [&](int set, unsigned ks) {               // ks is uniform: the K advance is scalar arithmetic
+            const unsigned xs = ks * kSbBK * a.HWin * 4u;
 #pragma unroll
             for (int i = 0; i < 8; ++i)
-                xr[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)xo, (int)(xs + (unsigned)i * a.HWin * 4u), 0));
-#pragma unroll
-            for (int i = 0; i < S::kWVecs; ++i)
-                if (S::kWVecs * kT == 3 * 2 * BM || tid + (unsigned)kT * i < 3u * 2u * BM)
-                    wreg[i] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)wo[i], (int)ws, 0));
+                xr[set][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (int)xo, (int)(xs + (unsigned)i * a.HWin * 4u), 0));
         };
-        auto lstore = [&](unsigned stage_off) {
-#pragma unroll
-            for (int i = 0; i < S::kWVecs; ++i)
-                if (S::kWVecs * kT == 3 * 2 * BM || tid + (unsigned)kT * i < 3u * 2u * BM)
-                    *reinterpret_cast<u4v*>(smem + stage_off + wl[i]) = wreg[i];
+        auto lstore = [&](int set, unsigned stage_off) {
             // two values at a time: v_cvt_pk_bf16_f32 (round to nearest even), the two halves widened again by a shift and a mask,
             // one packed subtraction for the residuals -- 4.5 vector instructions per value
             u4v ph, pm, pl;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const f2v v = {xr[2 * i], xr[2 * i + 1]};
+                const f2v v = {xr[set][2 * i], xr[set][2 * i + 1]};
                 const unsigned hb = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2v));
                 const f2v r1 = v - f2v{__builtin_bit_cast(float, hb << 16), __builtin_bit_cast(float, hb & 0xffff0000u)};
                 const unsigned mb = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf2v));
@@ -652,41 +648,49 @@ __device__ __forceinline__ void conv1x1_tiles_sb(const C1Args& a, Stat& stat, ch
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[mi][ni][e] = 0.0f;
 
-        gload(ks_begin);
-        if (tid < (unsigned)BM) s_bias[tid] = (a.bias && mbase + tid < a.Cout) ? a.bias[mbase + tid] : 0.0f;
-        lstore(0u);
-        if (ks_begin + 1 < ks_end) gload(ks_begin + 1);
-        __syncthreads();
-        // Two sets of operand fragments: a step multiplies out of one while the other is filled, behind the step's barrier, with
-        // the fragments of the following step -- their LDS latency falls under the second half of this step's MFMAs (with one
-        // set every step began with twelve reads and an MFMA waiting for each).
+        // Two sets of operand fragments: a step multiplies out of one while the other is filled with the fragments of the following
+        // step -- the weights' from global memory at the start of the step, the activations' from LDS behind the step's barrier.
         bf8v fa[2][WM][3], fb[2][WN][3];
-        auto frags = [&](int set, unsigned stage_off) {
+        auto wfrags = [&](int set, unsigned ks) {
+            const unsigned ws = ks * wstep;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
+            for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int mi = 0; mi < WM; ++mi)
-                    fa[set][mi][pl] = *reinterpret_cast<const bf8v*>(smem + stage_off + ard + (unsigned)(pl * 2 * BM + 32 * mi) * 16u);
+                    fa[set][mi][pl] = __builtin_bit_cast(bf8v, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)wfo[mi], (int)(ws + (unsigned)pl * wplane), 0));
+        };
+        auto xfrags = [&](int set, unsigned stage_off) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni)
                     fb[set][ni][pl] = *reinterpret_cast<const bf8v*>(smem + stage_off + brd + (unsigned)(pl * 2 * BN + 32 * ni) * 16u);
-            }
         };
+        // (x first, then W: the order the loop leaves the loads in -- the wait counts in the loop are the minimum over both ways into it)
+        gload(0, ks_begin);
+        wfrags(0, ks_begin);
+        if (tid < (unsigned)BM) s_bias[tid] = (a.bias && mbase + tid < a.Cout) ? a.bias[mbase + tid] : 0.0f;
+        if (ks_begin + 1 < ks_end) gload(1, ks_begin + 1);
+        lstore(0, 0u);
+        if (ks_begin + 2 < ks_end) gload(0, ks_begin + 2);
+        __syncthreads();
+        xfrags(0, 0u);
         unsigned cur = 0;
         auto kstep = [&](auto set_c, unsigned ks) {
             constexpr int set = decltype(set_c)::value;
             const unsigned nxt = cur == 2u * S::kStage ? 0u : cur + (unsigned)S::kStage;
+            if (ks + 1 < ks_end) wfrags(set ^ 1, ks + 1);
             // smallest products first: (hi, lo), (lo, hi), (mid, mid), (hi, mid), (mid, hi), (hi, hi)
             constexpr int kA[6] = {0, 2, 1, 0, 1, 0}, kB[6] = {2, 0, 1, 1, 0, 0};
 #pragma unroll
             for (int q = 0; q < 6; ++q) {
-                if (q == 3) {                                   // the middle of the step: the operands of step ks + 1 go to their stage,
-                    if (ks + 1 < ks_end) {                      // the loads of step ks + 2 are issued, one barrier, then its fragments
-                        lstore(nxt);
-                        if (ks + 2 < ks_end) gload(ks + 2);
+                if (q == 3) {                                   // the middle of the step: the x tile of step ks + 1 goes to its stage,
+                    if (ks + 1 < ks_end) {                      // the loads of step ks + 3 are issued, one barrier, then its fragments
+                        lstore(set ^ 1, nxt);
+                        if (ks + 3 < ks_end) gload(set ^ 1, ks + 3);
                     }
                     __syncthreads();
-                    if (ks + 1 < ks_end) frags(set ^ 1, nxt);
+                    if (ks + 1 < ks_end) xfrags(set ^ 1, nxt);
                 }
 #pragma unroll
                 for (int mi = 0; mi < WM; ++mi)
@@ -696,7 +700,6 @@ __device__ __forceinline__ void conv1x1_tiles_sb(const C1Args& a, Stat& stat, ch
             }
             cur = nxt;
         };
-        frags(0, 0u);
         for (unsigned ks = ks_begin;;) {
             kstep(Stage<0>{}, ks);
             if (++ks >= ks_end) break;
@@ -782,13 +785,16 @@ __global__ __launch_bounds__(kT) __attribute__((amdgpu_waves_per_eu(2))) void co
     hist_flush<kT>(s_bins[1], hist_sum);
 }
 
-// fp32 [Cout][Cin] -> three bf16 planes [3][Cout][Cin]: hi, mid, lo of every weight
-__global__ __launch_bounds__(256) void conv1x1_sb_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, unsigned n) {
+// fp32 [Cout][Cin] -> the pack the kernel's A fragments are loaded from: [Cin / 16][plane: hi, mid, lo][k % 16 / 8][Cout][8] bf16
+__global__ __launch_bounds__(256) void conv1x1_sb_pack_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, unsigned Cin,
+                                                              unsigned Cout) {
     const unsigned i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    unsigned hi, mid, lo;
-    split3(w[i], hi, mid, lo);
-    out[i] = (unsigned short)hi; out[(size_t)n + i] = (unsigned short)mid; out[2 * (size_t)n + i] = (unsigned short)lo;
+    if (i >= Cin * Cout) return;
+    const unsigned co = i / Cin, k = i - co * Cin;
+    unsigned p[3];
+    split3(w[i], p[0], p[1], p[2]);
+    for (unsigned pl = 0; pl < 3; ++pl)
+        out[((((size_t)(k >> 4) * 3u + pl) * 2u + ((k >> 3) & 1u)) * Cout + co) * 8u + (k & 7u)] = (unsigned short)p[pl];
 }
 
 // (4 waves per SIMD = four workgroups per CU: <= 128 registers with the 64 accumulators; the K-tail form -- Cin not a multiple
@@ -1211,7 +1217,8 @@ extern "C" int fq_conv1x1_sb_pack(const float* w_kc, void* wsb, int Cin, int Cou
     if (!w_kc || !wsb || Cin <= 0 || Cout <= 0) return FQ_ERR_INVALID_ARG;
     if ((size_t)Cin * Cout >= (1ULL << 30)) return FQ_ERR_UNSUPPORTED;
     const unsigned n = (unsigned)Cin * (unsigned)Cout;
-    hipLaunchKernelGGL(conv1x1_sb_pack_kernel, dim3((n + 255u) / 256u), dim3(256), 0, as_stream(stream), w_kc, static_cast<unsigned short*>(wsb), n);
+    hipLaunchKernelGGL(conv1x1_sb_pack_kernel, dim3((n + 255u) / 256u), dim3(256), 0, as_stream(stream), w_kc, static_cast<unsigned short*>(wsb),
+                       (unsigned)Cin, (unsigned)Cout);
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }

@@ -425,8 +425,9 @@ def conv_sb_supported(cin, cout):
 
 
 def pack_sb_weight(weight):
-    """[Cout, Cin(, 1, 1)] fp32 -> int16 [3, Cout, Cin]: the hi / mid / lo bf16 planes the split-bf16 1x1 kernels read
-    (fq_conv1x1_sb_pack).  conv1x1_f32 / conv1x1_add_f32 / conv1x1_add_hist_f32 take it in place of the transposed weights."""
+    """[Cout, Cin(, 1, 1)] fp32 -> the pack the split-bf16 1x1 kernels read (fq_conv1x1_sb_pack): 3 * Cout * Cin bf16 bit patterns,
+    the hi / mid / lo piece of every weight in the kernel's fragment order; handed around as an int16 tensor of SHAPE [3, Cout, Cin]
+    (the shape tells conv1x1_f32 / conv1x1_add_f32 / conv1x1_add_hist_f32 what it is; the memory order is the pack's)."""
     _need_cuda(weight, torch.float32, "fq_conv1x1_sb_pack")
     cout, cin = int(weight.shape[0]), int(weight.shape[1])
     w = weight.detach().reshape(cout, cin).contiguous()

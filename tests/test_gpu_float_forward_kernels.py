@@ -832,9 +832,12 @@ def test_split_bf16_pack_and_argument_errors(nat):
     L = nat.lib()
     g = torch.Generator(device="cuda").manual_seed(31)
     w = torch.randn(8, 16, device="cuda", generator=g)
-    p = nat.pack_sb_weight(w).view(torch.bfloat16)                              # [3, Cout, Cin]
+    raw = nat.pack_sb_weight(w)
+    # the pack: [Cin / 16][plane][k % 16 / 8][Cout][8] bf16 -> [plane][Cout][Cin]
+    p = raw.view(torch.bfloat16).reshape(1, 3, 2, 8, 8).permute(1, 3, 0, 2, 4).reshape(3, 8, 16)
     assert torch.equal(p[0].float() + p[1].float() + p[2].float(), w)           # hi + mid + lo IS the weight
     assert torch.equal(p[0], w.bfloat16())
+    p = raw
     assert L.fq_conv1x1_sb_supported(16, 8) == 1 and L.fq_conv1x1_sb_supported(24, 8) == 0 and L.fq_conv1x1_sb_supported(16, 6) == 0
     x = torch.zeros(1, 24, 4, 4, device="cuda")
     y = torch.zeros(1, 8, 4, 4, device="cuda")
