@@ -86,7 +86,8 @@ def weight(m, k):
     by_kind = state(m).setdefault("wt", {})
     cached = by_kind.get(k)
     if cached is None or cached[0] != tag:
-        sb = k == "c1" and _native.conv_sb_enabled() and _native.conv_sb_supported(w.shape[1], w.shape[0])
+        # (opt-in; from 128 input channels on: with 64 the four K steps of a tile do not pay for the split's prologue, 0.95 x)
+        sb = k == "c1" and _native.conv_sb_enabled() and w.shape[1] >= 128 and _native.conv_sb_supported(w.shape[1], w.shape[0])
         packed = (_native.pack_sb_weight(w) if sb                # (opt-in: the split-bf16 form of the 1x1 kernels takes this pack)
                   else w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1"
                   else _native.pack_kxk_weight(w) if k == "kxk"
