@@ -440,86 +440,198 @@ __device__ __forceinline__ double screen_log(double x) {
 }
 
 // S(t) for all 1920 candidates of one row: the row's P, prefix sums and prefix counts staged in LDS once, one wave per
-// candidate (no workgroup barrier inside the loop), two quantised bins per lane.
-__global__ __launch_bounds__(kKlBlock) void kl_screen_kernel(const double* __restrict__ Pw, const double* __restrict__ tailw,
-                                                             const double* __restrict__ SPw, const double* __restrict__ ALw,
-                                                             const unsigned short* __restrict__ NZw, double* __restrict__ klw) {
+// candidate (no workgroup barrier inside the loop), two quantised bins per lane.  Every lane's terms are those of the first
+// form of this kernel bit for bit (same expressions, same order); the 64 lanes' sums now meet in a different order (and the
+// 1e-12 correction in fp32), which moves S(t) by parts in 1e16.  What changed in round 4 is what a candidate costs -- 520
+// vector instructions (205 of them fp64) with 39 waits became ~320:
+//   * bin edges in integers: start = i t / 128, so ceil(start) = (i t + 127) >> 7, floor(end) = ((i + 1) t) >> 7 and the two
+//     fractional weights are (128 - (i t & 127)) / 128 and (((i + 1) t) & 127) / 128 -- exact, no fp64 ceil / floor / compare;
+//   * the prefix sums as (hi, lo) pairs: one 16-byte LDS read per index; one mass per quantised bin (the interior of bin 127
+//     stops at t - 1: its pair is read by every lane from the uniform address and selected);
+//   * the four logarithms of a lane (two interiors, two fractional edges) are computed unconditionally, side by side, with the
+//     table in LDS, and selected afterwards -- no divergent branch per term; an argument the fast path does not take (never for
+//     these strictly positive sums) sends the wave through the library logarithm for exactly those lanes;
+//   * the neighbour's expanded value and the wave's sums by DPP (wave_rol:1; row_shr / row_bcast) instead of 30 ds_bpermute;
+//   * the closing step of a candidate (the folded last bin: two more logarithms, three global loads) ran in ONE lane per
+//     candidate; now lane j keeps the reduced sums of the j-th candidate of a batch of 64 and the 64 closing steps run as one.
+constexpr int kScreenBlock = 512;                 // 8 waves, 240 candidates each; 56 KB of LDS: two workgroups per CU
+struct alignas(16) ScreenLogRow { double invc, logc_hi, logc_lo, pad; };
+struct alignas(16) DdPair { double hi, lo; };
+
+__device__ __forceinline__ double lane_plus_one(double v) {           // v of lane (lane + 1) & 63
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xf, 0xf, false);  // wave_rol:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int kCtrl, int kRowMask, int kBankMask>
+__device__ __forceinline__ double dpp_or_zero(double v) {             // the DPP source lane's v; 0 where there is none / masked
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, kRowMask, kBankMask, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, kRowMask, kBankMask, true);
+    return __hiloint2double(hi, lo);
+}
+template <int kCtrl, int kRowMask, int kBankMask>
+__device__ __forceinline__ float dpp_or_zero_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, kRowMask, kBankMask, true));
+}
+__device__ __forceinline__ double wave_sum_to_last(double v) {        // lane 63: the sum over the wave
+    double s = v + dpp_or_zero<0x111, 0xf, 0xf>(v);                    // row_shr:1
+    s += dpp_or_zero<0x112, 0xf, 0xf>(v);                             // row_shr:2
+    s += dpp_or_zero<0x113, 0xf, 0xf>(v);                             // row_shr:3   lane i: v[i-3 .. i] of its row
+    s += dpp_or_zero<0x114, 0xf, 0xe>(s);                             // row_shr:4, lanes 4..15 of a row
+    s += dpp_or_zero<0x118, 0xf, 0xc>(s);                             // row_shr:8, lanes 8..15: lane 15 = the row
+    s += dpp_or_zero<0x142, 0xa, 0xf>(s);                             // row_bcast:15 into rows 1 and 3
+    s += dpp_or_zero<0x143, 0xc, 0xf>(s);                             // row_bcast:31 into rows 2 and 3
+    return s;
+}
+__device__ __forceinline__ float wave_sum_to_last_f(float v) {
+    float s = v + dpp_or_zero_f<0x111, 0xf, 0xf>(v);
+    s += dpp_or_zero_f<0x112, 0xf, 0xf>(v);
+    s += dpp_or_zero_f<0x113, 0xf, 0xf>(v);
+    s += dpp_or_zero_f<0x114, 0xf, 0xe>(s);
+    s += dpp_or_zero_f<0x118, 0xf, 0xc>(s);
+    s += dpp_or_zero_f<0x142, 0xa, 0xf>(s);
+    s += dpp_or_zero_f<0x143, 0xc, 0xf>(s);
+    return s;
+}
+__device__ __forceinline__ double lane63(double v) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), kWave - 1), __builtin_amdgcn_readlane(__double2loint(v), kWave - 1));
+}
+__device__ __forceinline__ float lane63f(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), kWave - 1)); }
+// screen_log's test for "not a positive normal number" and its fast path, on the high word (every constant involved has a
+// zero low word)
+__device__ __forceinline__ bool screen_log_odd(double x) {
+    return (unsigned)__double2hiint(x) - 0x00100000u >= 0x7fe00000u;
+}
+__device__ __forceinline__ double screen_log_core(double x, const ScreenLogRow* __restrict__ tab) {
+    const unsigned hx = (unsigned)__double2hiint(x);
+    const unsigned tmp = hx - 0x3fe60000u;
+    const int i = (int)((tmp >> 13) & 127u);
+    const int k = (int)tmp >> 20;
+    const double z = __hiloint2double((int)(hx - (tmp & 0xfff00000u)), __double2loint(x));
+    const double invc = tab[i].invc, lch = tab[i].logc_hi, lcl = tab[i].logc_lo;
+    const double r = __builtin_fma(z, invc, -1.0);
+    double c = 1.0 / 7.0;
+    c = __builtin_fma(c, r, -1.0 / 6.0);
+    c = __builtin_fma(c, r, 1.0 / 5.0);
+    c = __builtin_fma(c, r, -1.0 / 4.0);
+    c = __builtin_fma(c, r, 1.0 / 3.0);
+    c = __builtin_fma(c, r, -0.5);
+    const double dk = (double)k;
+    const double hi = __builtin_fma(dk, 0x1.62e42fefa38p-1, lch);
+    const double lo = __builtin_fma(dk, 0x1.ef35793c7673p-45, lcl);
+    return hi + (r + __builtin_fma(r * r, c, lo));
+}
+
+__global__ __launch_bounds__(kScreenBlock) void kl_screen_kernel(const double* __restrict__ Pw, const double* __restrict__ tailw,
+                                                                 const double* __restrict__ SPw, const double* __restrict__ ALw,
+                                                                 const unsigned short* __restrict__ NZw, double* __restrict__ klw) {
     __shared__ double sP[FQ_BINS];
-    __shared__ double sSPh[FQ_BINS + 1], sSPl[FQ_BINS + 1];
+    __shared__ DdPair sSP[FQ_BINS + 1];
     __shared__ unsigned short sNZ[kNzStride];
+    __shared__ ScreenLogRow sLog[128];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-    for (int j = tid; j < FQ_BINS; j += kKlBlock) sP[j] = Pw[(size_t)row * FQ_BINS + j];
-    for (int j = tid; j <= FQ_BINS; j += kKlBlock) {
-        sSPh[j] = SPw[((size_t)row * (FQ_BINS + 1) + j) * 2];
-        sSPl[j] = SPw[((size_t)row * (FQ_BINS + 1) + j) * 2 + 1];
+    for (int j = tid; j < FQ_BINS; j += kScreenBlock) sP[j] = Pw[(size_t)row * FQ_BINS + j];
+    for (int j = tid; j <= FQ_BINS; j += kScreenBlock) {
+        sSP[j] = reinterpret_cast<const DdPair*>(SPw)[(size_t)row * (FQ_BINS + 1) + j];
         sNZ[j] = NZw[(size_t)row * kNzStride + j];
     }
+    if (tid < 128) { sLog[tid].invc = fq_log_table[tid].invc; sLog[tid].logc_hi = fq_log_table[tid].logc_hi; sLog[tid].logc_lo = fq_log_table[tid].logc_lo; }
     __syncthreads();
     const double* tail = tailw + (size_t)row * FQ_BINS;
     const double* AL = ALw + (size_t)row * 2 * (FQ_BINS + 1);
-    auto mass = [&](int lo, int hi) { return (sSPh[hi] - sSPh[lo]) + (sSPl[hi] - sSPl[lo]); };   // sum of P[lo..hi)
-    for (int c = wave; c < kCand; c += kKlBlock / kWave) {
+
+    // what lane j keeps of the j-th candidate of the running batch of 64
+    double cap_part = 0.0, cap_corr = 0.0, cap_ev = 0.0;
+    int cap_c = -1;
+    auto close_batch = [&]() {
+        if (cap_c >= 0) {
+            const int t = kTarget + cap_c;
+            const double plast = sP[t - 1];
+            const double a_last = plast + tail[t];
+            double s = (AL[2 * (t - 1)] - cap_part) + AL[2 * (t - 1) + 1];
+            double corr = cap_corr;
+            if (a_last != 0.0) {                                      // negative (rounding of the tail chain): NaN, kept
+                const double e_last = (plast != 0.0 ? 1e-9 + cap_ev : 1e-9) + 1e-12;
+                s += a_last * screen_log(a_last) - a_last * screen_log(e_last);
+                corr += e_last;
+            }
+            klw[(size_t)row * kCand + cap_c] = s + 1e-12 * corr;
+        }
+        cap_c = -1;
+    };
+
+    constexpr int kWaves = kScreenBlock / kWave;
+    for (int it = 0, c = wave; c < kCand; ++it, c += kWaves) {
         const int t = kTarget + c;
-        const double npb = (double)t / (double)kTarget;              // exact dyadic
-        double ev[2], part = 0.0, corr = 0.0;
-        int rl_[2]; double rs_[2]; bool redge[2];
+        const DdPair sp_t1 = sSP[t - 1];                              // uniform: the end of bin 127's interior
+        const int nz_t1 = (int)sNZ[t - 1];
+        double ev[2], mint[2], rs_[2], pr_[2];
+        int nint[2], rl_[2];
+        bool has_r[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int i = lane + h * kWave;
-            const double start = (double)i * npb, end = start + npb;
-            const int lu = (int)ceil(start), rl = (int)floor(end);
-            const bool has_l = (double)lu > start, has_r = (double)rl < end;
-            const double ls = has_l ? (double)lu - start : 0.0, rs = has_r ? end - (double)rl : 0.0;
-            const double pl = has_l ? sP[lu - 1] : 0.0, pr = has_r ? sP[rl] : 0.0;
-            const double q = ls * pl + rs * pr + mass(lu, rl);
-            double count = 1e-12 + (double)((int)sNZ[rl] - (int)sNZ[lu]);
+            const int a0 = i * t, a1 = a0 + t;
+            const int lu = (a0 + (kTarget - 1)) >> 7, rl = a1 >> 7;
+            const int fl = a0 & (kTarget - 1), fr = a1 & (kTarget - 1);
+            const double ls = (double)(fl ? kTarget - fl : 0) * (1.0 / kTarget);      // ceil(start) - start, exact
+            const double rs = (double)fr * (1.0 / kTarget);                           // end - floor(end), exact
+            const double pl_raw = sP[lu > 0 ? lu - 1 : 0], pr_raw = sP[rl < FQ_BINS ? rl : FQ_BINS - 1];
+            const double pl = fl ? pl_raw : 0.0, pr = fr ? pr_raw : 0.0;
+            const DdPair sa = sSP[lu], sb = sSP[rl];
+            const int nza = (int)sNZ[lu], nzb = (int)sNZ[rl];
+            const double m = (sb.hi - sa.hi) + (sb.lo - sa.lo);                       // sum of P[lu .. rl)
+            const double q = ls * pl + rs * pr + m;
+            double count = 1e-12 + (double)(nzb - nza);
             if (pl != 0.0) count += ls;
             if (pr != 0.0) count += rs;
             ev[h] = q / count;
             // interior of this quantised bin; the folded last bin t-1 (always interior of bin 127) is handled apart
-            const int hi = (i == kTarget - 1) ? t - 1 : rl;
-            const int nint = (int)sNZ[hi] - (int)sNZ[lu];
-            if (nint > 0) {
-                const double e = (1e-9 + ev[h]) + 1e-12;
-                part += mass(lu, hi) * screen_log(e);
-                corr += (double)nint * e;
-            }
-            rl_[h] = rl; rs_[h] = rs; redge[h] = has_r && pr != 0.0;
+            const bool last = h == 1 && lane == kWave - 1;
+            const double eh = last ? sp_t1.hi : sb.hi, el = last ? sp_t1.lo : sb.lo;
+            mint[h] = last ? (eh - sa.hi) + (el - sa.lo) : m;
+            nint[h] = (last ? nz_t1 : nzb) - nza;
+            rl_[h] = rl; rs_[h] = rs; pr_[h] = pr_raw; has_r[h] = fr != 0 && pr_raw != 0.0;
         }
         // fractional right edges: bin rl belongs to quantised bins i (weight rs) and i + 1 (weight 1 - rs).
         // bin i = lane      -> neighbour i + 1 is lane + 1's first bin, or (lane 63) bin 64 = lane 0's SECOND bin
         // bin i = lane + 64 -> neighbour is lane + 1's second bin; bin 127 has no right edge (end == t is an integer)
-        const double nxt0 = __shfl(ev[0], (lane + 1) & (kWave - 1), kWave);
-        const double nxt1 = __shfl(ev[1], (lane + 1) & (kWave - 1), kWave);
-        const double b64 = __shfl(ev[1], 0, kWave);
-        const double evn0 = (lane == kWave - 1) ? b64 : nxt0;
-        if (redge[0]) {
-            const double e = ((1e-9 + ev[0] * rs_[0]) + evn0 * (1.0 - rs_[0])) + 1e-12;
-            part += sP[rl_[0]] * screen_log(e);
-            corr += e;
-        }
-        if (redge[1] && lane != kWave - 1) {
-            const double e = ((1e-9 + ev[1] * rs_[1]) + nxt1 * (1.0 - rs_[1])) + 1e-12;
-            part += sP[rl_[1]] * screen_log(e);
-            corr += e;
-        }
+        const double nxt0 = lane_plus_one(ev[0]);
+        const double nxt1 = lane_plus_one(ev[1]);                     // in lane 63: lane 0's second bin = bin 64
+        const double evn0 = (lane == kWave - 1) ? nxt1 : nxt0;
+        const bool use[4] = {nint[0] > 0, nint[1] > 0, has_r[0], has_r[1] && lane != kWave - 1};
+        double e[4];
+        e[0] = (1e-9 + ev[0]) + 1e-12;
+        e[1] = (1e-9 + ev[1]) + 1e-12;
+        e[2] = ((1e-9 + ev[0] * rs_[0]) + evn0 * (1.0 - rs_[0])) + 1e-12;
+        e[3] = ((1e-9 + ev[1] * rs_[1]) + nxt1 * (1.0 - rs_[1])) + 1e-12;
+        double lg[4];
+        bool odd = false;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            part += __shfl_xor(part, off, kWave);
-            corr += __shfl_xor(corr, off, kWave);
+        for (int k = 0; k < 4; ++k) {
+            lg[k] = screen_log_core(e[k], sLog);
+            odd |= use[k] && screen_log_odd(e[k]);
         }
-        if (lane == kWave - 1) {
-            const double plast = sP[t - 1];
-            const double a_last = plast + tail[t];
-            double s = (AL[2 * (t - 1)] - part) + AL[2 * (t - 1) + 1];
-            if (a_last != 0.0) {                                      // negative (rounding of the tail chain): NaN, kept
-                const double e_last = (plast != 0.0 ? 1e-9 + ev[1] : 1e-9) + 1e-12;
-                s += a_last * screen_log(a_last) - a_last * screen_log(e_last);
-                corr += e_last;
-            }
-            klw[(size_t)row * kCand + c] = s + 1e-12 * corr;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(odd) != 0, 0)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (use[k] && screen_log_odd(e[k])) lg[k] = log(e[k]);
         }
+        double part = 0.0, corr = 0.0;
+        part += use[0] ? mint[0] * lg[0] : 0.0;  corr += use[0] ? (double)nint[0] * e[0] : 0.0;
+        part += use[1] ? mint[1] * lg[1] : 0.0;  corr += use[1] ? (double)nint[1] * e[1] : 0.0;
+        part += use[2] ? pr_[0] * lg[2] : 0.0;   corr += use[2] ? e[2] : 0.0;
+        part += use[3] ? pr_[1] * lg[3] : 0.0;   corr += use[3] ? e[3] : 0.0;
+        // the wave's sums, in lane 63 (row_shr 1, 2, 3, 4, 8, row_bcast 15, 31: no LDS, no wait); corr only ever enters as
+        // 1e-12 * corr, so it is added up in fp32 (6e-8 of 1e-12 of a sum of order one)
+        const double part_sum = lane63(wave_sum_to_last(part));
+        const double corr_sum = (double)lane63f(wave_sum_to_last_f((float)corr));
+        const double ev_last = lane63(ev[1]);
+        if ((it & (kWave - 1)) == lane) { cap_part = part_sum; cap_corr = corr_sum; cap_ev = ev_last; cap_c = c; }
+        if ((it & (kWave - 1)) == kWave - 1) close_batch();
     }
+    close_batch();
 }
 
 // survivors of one row -> work list (or the row -> exhaustive list when there are too many)
@@ -681,7 +793,7 @@ extern "C" int fq_kl_threshold_ex(const int64_t* hist, int rows, int32_t* thr_ou
         } else {
             hipLaunchKernelGGL(kl_prefix_kernel, dim3(nr), dim3(kKlBlock), 0, st, Pw, SPw, ALw, NZw, counters);
             FQ_LAUNCH_CHECK();
-            hipLaunchKernelGGL(kl_screen_kernel, dim3(nr), dim3(kKlBlock), 0, st, Pw, tailw, SPw, ALw, NZw, klw);
+            hipLaunchKernelGGL(kl_screen_kernel, dim3(nr), dim3(kScreenBlock), 0, st, Pw, tailw, SPw, ALw, NZw, klw);
             FQ_LAUNCH_CHECK();
             hipLaunchKernelGGL(kl_select_kernel, dim3(nr), dim3(kKlBlock), 0, st, klw, list, full_rows, counters,
                                nr * kListPerRow);
