@@ -17,8 +17,8 @@ import torch
 
 from . import _native
 
-__all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "call_qd", "state", "is_verified", "is_off", "forget",
-           "TOL"]
+__all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "call_qd", "call_linear_qd", "state", "is_verified",
+           "is_off", "forget", "TOL"]
 
 TOL = 1e-5                                      # |own - torch| <= TOL * (|W| * |x| + |b|): summation order only
 # module -> {"verified": the own kernel agreed with torch here, "off": it disagreed (the module keeps torch's convolution),
@@ -203,3 +203,32 @@ def call_qd(m, x, bit, bitwidth):
     if not is_verified(m) and verified(m, run, x) is not None:
         return None                                             # the module just failed its check: two passes, torch's convolution
     return run(qd=(int(bit), 8 if bitwidth == 8 else 16))
+
+
+def call_linear_qd(m, x, bit, bitwidth):
+    """QuanDequan(m(x), bit) for an nn.Linear in ONE kernel (reference new_quantity_op.py:248-256 = TestLinear.forward: the
+    linear layer, then output_qdp): a linear layer over a batch is the 1x1 convolution of a 1 x 1 plane, so it runs on
+    fq_conv1x1_qd_f32 with x seen as [N, in_features, 1, 1] and the weight matrix transposed once per module (cached like the
+    convolutions' weights).  None when the call does not qualify (the caller then runs the two passes): not a 2-D contiguous
+    fp32 CUDA batch, no bias, out_features % 4, somebody hooks the nn.Linear (a hook must see the un-quantised output), or
+    the module failed its once-per-process check against torch.addmm (same bound as the convolutions: summation order only)."""
+    if (not enabled() or torch.is_grad_enabled() or "forward" in m.__dict__ or _hooked(m) or is_off(m) or type(m) is not torch.nn.Linear
+            or not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or not x.is_contiguous()
+            or m.bias is None or m.weight.dtype != torch.float32 or m.out_features % 4 or x.shape[0] == 0
+            or x.numel() >= 2 ** 30 or x.shape[0] * m.out_features >= 2 ** 30):
+        return None
+    w = m.weight
+    tag = (w._version, w.data_ptr(), w.device)
+    cached = state(m).get("wt_linear")
+    if cached is None or cached[0] != tag:
+        cached = state(m)["wt_linear"] = (tag, w.detach().t().contiguous())
+    x4 = x.view(x.shape[0], x.shape[1], 1, 1)
+    if not is_verified(m):
+        own = _native.conv1x1_f32(x4, cached[1], m.bias, 1).view(x.shape[0], -1)
+        ref = torch.addmm(m.bias, x, w.t())
+        bound = torch.addmm(m.bias.abs(), x.abs(), w.abs().t())
+        if not bool(((own - ref).abs() <= TOL * bound).all()):
+            state(m)["off"] = True
+            return None
+        state(m)["verified"] = True
+    return _native.conv1x1_f32(x4, cached[1], m.bias, 1, qd=(int(bit), 8 if bitwidth == 8 else 16)).view(x.shape[0], -1)

@@ -728,6 +728,51 @@ def test_testconv_runs_as_one_kernel_unless_its_convolution_is_hooked():
             assert not any(k.startswith("_fq") for k in layer.Conv.__dict__)
 
 
+def test_testlinear_runs_as_one_kernel_unless_its_linear_layer_is_hooked():
+    """TestLinear.forward (reference new_quantity_op.py:248-256): one kernel -- the linear layer as the 1x1 convolution of a 1 x 1
+    plane with QuanDequan in its epilogue -- when nobody hooks the inner nn.Linear or output_qdp; with a hook the reference's two
+    calls run.  The fused result is QuanDequan of the own kernel's plain output bit for bit, and within one quantisation step of
+    the two-pass form (torch's GEMM sums in another order)."""
+    from torch import nn
+    from common.quantity import TestLinear, _float_conv, _native
+    with product_workdir(device="gpu") as tmp:
+        for i, (cin, cout, n) in enumerate(((2048, 1000, 256), (64, 12, 3), (500, 10, 1), (33, 7, 5))):
+            lin = nn.Linear(cin, cout).cuda().eval()
+            layer = TestLinear("fc%d" % i, lin, {"weight_bit": 6, "bias_bit": 5, "input_bit": 4, "output_bit": 4},
+                               tmp + "/test/workdir/rl%d.pth" % i)
+            x = torch.randn(n, cin, device="cuda")
+            calls, real = {"n": 0}, _native.quandequan
+
+            def counted(*a, **k):
+                calls["n"] += 1
+                return real(*a, **k)
+            _native.quandequan = counted
+            try:
+                with torch.no_grad():
+                    fused = layer(x)
+                    takes = cout % 4 == 0
+                    assert calls["n"] == (0 if takes else 1) and _float_conv.is_verified(layer.linear) == takes
+                    seen = []
+                    h = layer.linear.register_forward_hook(lambda m, inp, o: seen.append(o.clone()))
+                    two_pass = layer(x)
+                    h.remove()
+                    assert len(seen) == 1 and calls["n"] == (1 if takes else 2)
+                    h = layer.output_qdp.register_forward_hook(lambda m, inp, o: seen.append(o.clone()))
+                    assert torch.equal(layer(x), two_pass) and len(seen) == 2       # a hook on output_qdp fires
+                    h.remove()
+            finally:
+                _native.quandequan = real
+            assert fused.shape == (n, cout) and torch.equal(two_pass, _native.quandequan(seen[0], 4))
+            if takes:
+                wt = layer.linear.weight.detach().t().contiguous()
+                plain = _native.conv1x1_f32(x.view(n, cin, 1, 1), wt, layer.linear.bias, 1).view(n, cout)
+                assert torch.equal(fused, _native.quandequan(plain, 4))
+                assert float((fused - two_pass).abs().max()) <= 2.0 ** -4
+            else:
+                assert torch.equal(fused, two_pass)
+            assert "wt_linear" not in layer.linear.__dict__ and "forward" not in layer.linear.__dict__
+
+
 def test_pool_modules_are_served_and_tables_do_not_change():
     from torch import nn
     from common.quantity import View

@@ -196,7 +196,8 @@ def test_config5_recontest_r101_at_512_every_layer_output_equals_the_oracle(orac
     reference capture at this size (the reference's Python histogram loop needs minutes per image), so the check is per
     layer and exact: for each of the 105 TestConv / TestLinear modules the output the model hands on must be the CPU
     oracle's QuanDequan of the float convolution's own result (the same kernel run without the epilogue on the same
-    input) -- i.e. the QuanDequan epilogue of fq_conv1x1_qd_f32 / fq_conv_kxk_qd_f32 / fq_conv_stem_qd_f32 on every real
+    input; the classifier as the 1x1 convolution of a 1 x 1 plane) -- i.e. the QuanDequan epilogue of fq_conv1x1_qd_f32 /
+    fq_conv_kxk_qd_f32 / fq_conv_stem_qd_f32 on every real
     activation of the model, from 16 M-element planes down to 16 x 16 -- and the fake-quantised parameters must be the
     oracle's QuanDequan of the folded ones."""
     from common.quantity import merge_bn
@@ -231,8 +232,10 @@ def test_config5_recontest_r101_at_512_every_layer_output_equals_the_oracle(orac
                     assert k is not None, name                 # every convolution of the model is this library's
                     raw = _float_conv.plain(inner, k, x, check=False)
                     checked["fused"] += 1
-                else:
-                    raw = inner(x)
+                else:                                          # the classifier: the 1x1 convolution of a 1 x 1 plane
+                    wt = inner.weight.detach().t().contiguous()
+                    raw = _native.conv1x1_f32(x.view(x.shape[0], -1, 1, 1), wt, inner.bias, 1).view(x.shape[0], -1)
+                    checked["fused"] += 1
                 want = oracle.quandequan(raw.cpu().numpy(), bit)
                 assert np.array_equal(out.detach().cpu().numpy(), want), name
                 checked["n"] += 1
@@ -254,8 +257,8 @@ def test_config5_recontest_r101_at_512_every_layer_output_equals_the_oracle(orac
         finally:
             _native.quandequan = real_qd
         assert checked["n"] == 105 and checked["elems"] > 60_000_000, checked
-        # the 104 convolutions ran as ONE kernel each (QuanDequan in the epilogue): the standalone pass is left to the classifier
-        assert checked["fused"] == 104 and calls["qd"] == 1, (checked, calls)
+        # the 104 convolutions and the classifier ran as ONE kernel each (QuanDequan in the epilogue): no standalone pass
+        assert checked["fused"] == 105 and calls["qd"] == 0, (checked, calls)
         assert torch.isfinite(logits).all()
 
 
