@@ -32,7 +32,8 @@ The JSON line also carries
   roofline_conv1x1_add_f32 / roofline_conv1x1_add_hist_f32 : the last 1x1 convolution of a residual block + Eltwise + ReLU
                  in one kernel (pass 1 / pass 2): matrix work and algorithmic bytes (x, Wt, the shortcut, the ReLU output and
                  whichever of the two intermediate tensors is kept), frac_of_bound against max(matrix, bytes) per launch;
-  file_input   : the same images as .npy files through PRE_PROCESS.IMG = 2 (--input-mode npy|both), beside `value`, never it;
+  file_input   : the same images as .npy files through PRE_PROCESS.IMG = 2 (--input-mode npy|both), beside `value`, never it
+                 (the process's second such calibration, like `value`; first_run_images_per_s: the first, which page-locks its staging ring);
   roofline_conv_stem_f32 / roofline_conv_kxk_f32 : the same for the 7x7 stride-2 stem (fq_conv_stem_f32) and the stride-2 3x3
                  layers (fq_conv_kxk_f32); roofline_conv_wino_f32: the stride-1 3x3 layers (fq_conv3x3_wino_f32, Winograd);
   roofline_conv1x1_f32 : the float forward's 1x1 convolutions on the fp32 matrix cores (fq_conv1x1_f32, statistic in the
@@ -1141,18 +1142,25 @@ def main():
             ucfg["PRE_PROCESS"]["IMG"] = 2
             with open(ucfg_path, "w") as fh:
                 yaml.safe_dump(ucfg, fh)
-            fq = Quantity(model)
-            fq.file_batch = B
-            fq.profile_phases = True
-            barrier()
-            t0 = time.perf_counter()
-            fq.activation_quantize(paths)
-            barrier()
-            dt = time.perf_counter() - t0
+            # two runs, as for `value` (whose clock starts in a process that has calibrated before): the first one page-locks
+            # its staging ring (6 x 154 MB, 10-20 ms each) inside its clock and is reported as first_run_images_per_s
+            first_dt = None
+            for _rep in range(2):
+                fq = Quantity(model)
+                fq.file_batch = B
+                fq.profile_phases = True
+                barrier()
+                t0 = time.perf_counter()
+                fq.activation_quantize(paths)
+                barrier()
+                dt = time.perf_counter() - t0
+                if first_dt is None:
+                    first_dt = dt
             same = open("./workdir/feat.table").read() == feat_table
             result["file_input"] = {"mode": "npy (PRE_PROCESS.IMG = 2)", "files": len(paths), "file_bytes": int(os.path.getsize(paths[0])),
                                     "files_per_forward": B, "decode_threads": fq.decode_workers, "seconds": round(dt, 3),
                                     "images_per_s": round(len(paths) / dt, 1), "ratio_to_tensor_inputs": round(len(paths) / dt / value, 3),
+                                    "first_run_images_per_s": round(len(paths) / first_dt, 1),
                                     "same_table_as_tensor_inputs": bool(same), "write_files_s_outside_clock": round(write_s, 2),
                                     "pass1_s": round(fq.timings.get("pass1_s", 0.0), 4), "pass2_s": round(fq.timings.get("pass2_s", 0.0), 4),
                                     "host_wait_s": {k: round(v, 4) for k, v in getattr(fq, "input_wait_s", {}).items()}}
