@@ -102,6 +102,6 @@ class ChannelCollector(StatCollectives):
         bits = {}
         for n in self._names:
             lo, hi = self.row_range(n)
-            bits[n] = [int(b) for b in all_bits[lo:hi]]
+            bits[n] = all_bits[lo:hi].tolist()                    # (Python ints; a comprehension over 42 667 NumPy scalars took 2 ms)
         self.threshold_bins = thr
         return bits

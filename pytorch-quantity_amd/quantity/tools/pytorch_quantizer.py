@@ -772,7 +772,7 @@ class Quantity(_FusedForward, _FileInputs):
             path = table_file or os.path.join(self.config["OUTPUT"]["WORK_DIR"], "feat_channel.table")
             with open(path, "w") as fh:
                 for module, b in by_module.items():
-                    fh.write(module + " " + " ".join(str(v) for v in b) + "\n")
+                    fh.write(module + " " + " ".join(map(str, b)) + "\n")
         self._channel_collector = collector
         return by_module
 
