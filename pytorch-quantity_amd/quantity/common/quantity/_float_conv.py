@@ -150,7 +150,8 @@ def verified(m, run, x):
     scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
     own = run(max_dev=scratch, row=0)
     cmp = own[:head] if pick is None else own.index_select(0, pick)
-    if not (bool(((cmp - ref).abs() <= TOL * bound).all()) and float(scratch[0]) == float(own.abs().max())):
+    # (one device-side verdict, one host synchronisation: the first forward of a process checks 53 modules)
+    if not bool(((cmp - ref).abs() <= TOL * bound).all() & (scratch[0] == own.abs().max())):
         state(m)["off"] = True
         return torch.nn.Conv2d.forward(m, x)
     state(m)["verified"] = True
