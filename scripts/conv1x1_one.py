@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU: fq_conv1x1_f32 (FQ_ONE_KIND=kxk: fq_conv_kxk_f32 3x3 padding 1; =stem: fq_conv_stem_f32 7x7 stride 2 on 3 channels) on
+"""GPU: fq_conv1x1_f32 (FQ_ONE_KIND=kxk: fq_conv_kxk_f32 3x3 padding 1; =stem: fq_conv_stem_f32 7x7 stride 2 on 3 channels; =wino:
+fq_conv3x3_wino_f32; =sb: fq_conv1x1_sb_f32) on
 one layer shape, for rocprofv3.  usage: conv1x1_one.py Cin Cout H stride batch [max|hist|none|add|addhist|addkeep] [reps]
 (add / addhist: fq_conv1x1_add_f32 / fq_conv1x1_add_hist_f32, the residual tail in one kernel, nothing kept; addkeep: both tensors kept)"""
 import os, sys
@@ -17,8 +18,12 @@ if kind == "kxk":
     wt = _native.pack_kxk_weight(torch.randn(cout, cin, 3, 3, device="cuda") * (9 * cin) ** -0.5)
 elif kind == "stem":
     wt = _native.pack_stem_weight(torch.randn(cout, 3, 7, 7, device="cuda") * 147 ** -0.5)
+elif kind == "wino":                                      # fq_conv3x3_wino_f32 (3x3, stride 1, padding 1)
+    wt = _native.pack_wino_weight(torch.randn(cout, cin, 3, 3, device="cuda") * (9 * cin) ** -0.5)
+elif kind == "sb":                                        # fq_conv1x1_sb_f32: the split-bf16 form of the 1x1 kernel
+    wt = _native.pack_sb_weight((torch.randn(cout, cin, 1, 1, device="cuda") * cin ** -0.5))
 bias = torch.randn(cout, device="cuda")
-ho = (h - 1) // s + 1 if kind == "c1" else ((h + 2 - 3) // s + 1 if kind == "kxk" else (h + 6 - 7) // 2 + 1)
+ho = (h - 1) // s + 1 if kind in ("c1", "sb") else (h if kind == "wino" else ((h + 2 - 3) // s + 1 if kind == "kxk" else (h + 6 - 7) // 2 + 1))
 
 
 def conv(**kw):
@@ -26,6 +31,8 @@ def conv(**kw):
         return _native.conv_kxk_f32(x, wt, bias, (3, 3), s, 1, **kw)
     if kind == "stem":
         return _native.conv_stem_f32(x, wt, bias, cout, (7, 7), 2, 3, **kw)
+    if kind == "wino":
+        return _native.conv_wino_f32(x, wt, bias, cout, **kw)
     return _native.conv1x1_f32(x, wt, bias, s, **kw)
 
 

@@ -21,7 +21,7 @@ out = sys.argv[1]
 tot = collections.defaultdict(float); n = collections.defaultdict(int)
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv1x1_f32" not in r["Kernel_Name"] and "conv_stem_f32" not in r["Kernel_Name"]: continue
+        if not any(k in r["Kernel_Name"] for k in ("conv1x1_f32", "conv_stem_f32", "wino_f32", "conv1x1_sb")): continue
         tot[r["Counter_Name"]] += float(r["Counter_Value"]); n[r["Counter_Name"]] += 1
 for k in sorted(tot): print("%-28s %16.0f per launch (%d launches)" % (k, tot[k] / n[k], n[k]))
 PY
