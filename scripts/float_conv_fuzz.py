@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU fuzz: fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32 on random shapes with integer-valued data (every partial sum
+"""GPU fuzz: fq_conv1x1_f32 / fq_conv_kxk_f32 / fq_conv_stem_f32 / fq_conv3x3_wino_f32 / fq_conv1x1_sb_f32 on random shapes with integer-valued data (every partial sum
 exact in fp32, so any indexing mistake is a wrong bit) against a float64 convolution, with the abs-max / histogram / ReLU copy
 checked on the same output.  usage: float_conv_fuzz.py [cases=300] [seed=0]"""
 import os, sys
@@ -14,13 +14,22 @@ def run(cases, seed, verbose=True):
     """Returns the list of failing configurations."""
     rng = np.random.default_rng(seed)
     failures = []
+    counts = {}
     for it in range(cases):
-        kind = rng.choice(["c1", "kxk", "stem"], p=[0.4, 0.45, 0.15])
+        kind = rng.choice(["c1", "kxk", "stem", "wino", "sb"], p=[0.25, 0.25, 0.1, 0.25, 0.15])
         N = int(rng.integers(1, 9))
         if kind == "stem":
             cin, R, S, st = 3, 7, 7, 2
             cout = int(rng.integers(1, 65)); pad = int(rng.integers(0, 4))
             H, W = int(rng.integers(7, 80)), int(rng.integers(7, 80))
+        elif kind == "wino":                                  # Winograd F(2x2, 3x3): U = G g Gt has quarters, every sum stays exact
+            cin = 8 * int(rng.integers(1, 33)); cout = 64 * int(rng.integers(1, 5)); R = S = 3; st = 1; pad = 1
+            H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        elif kind == "sb":                                    # split-bf16 1x1: small integers are their own bf16 "hi" piece
+            cin = 16 * int(rng.integers(1, 33)); cout = 4 * int(rng.integers(1, 80)); R = S = 1; pad = 0; st = int(rng.choice([1, 1, 2]))
+            H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+            if not nat.conv_sb_supported(cin, cout):
+                kind = "c1"
         elif kind == "c1":
             cin = int(rng.integers(1, 200)); cout = 4 * int(rng.integers(1, 80)); R = S = 1; pad = 0
             st = int(rng.choice([1, 1, 2, 3])); H, W = int(rng.integers(1, 40)), int(rng.integers(1, 40))
@@ -37,6 +46,8 @@ def run(cases, seed, verbose=True):
             N = int(rng.integers(16, 80))
             if kind == "c1":
                 cin = 16 * int(rng.integers(8, 64))
+            if kind == "wino" and not nat.conv_wino_supported(N, cin, H, W, cout):
+                N = int(rng.integers(1, 9))
         g = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
         x = torch.randint(-8, 9, (N, cin, H, W), device="cuda", generator=g).float()
         w = torch.randint(-8, 9, (cout, cin, R, S), device="cuda", generator=g).float()
@@ -44,12 +55,21 @@ def run(cases, seed, verbose=True):
         ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), stride=st, padding=pad)
         mx = torch.zeros(1, device="cuda")
         r = torch.empty(ref.shape, device="cuda")
+        if kind == "wino" and not nat.conv_wino_supported(N, cin, H, W, cout):
+            kind = "kxk"
         if kind == "c1":
             run_k = lambda **kw: nat.conv1x1_f32(x, w.view(cout, cin).t().contiguous(), b, st, **kw)
+        elif kind == "sb":
+            wsb = nat.pack_sb_weight(w)
+            run_k = lambda **kw: nat.conv1x1_f32(x, wsb, b, st, **kw)
+        elif kind == "wino":
+            wu = nat.pack_wino_weight(w)
+            run_k = lambda **kw: nat.conv_wino_f32(x, wu, b, cout, **kw)
         elif kind == "kxk":
             run_k = lambda **kw: nat.conv_kxk_f32(x, nat.pack_kxk_weight(w), b, (R, S), st, pad, **kw)
         else:
             run_k = lambda **kw: nat.conv_stem_f32(x, nat.pack_stem_weight(w), b, cout, (7, 7), 2, pad, **kw)
+        counts[kind] = counts.get(kind, 0) + 1
         y = run_k(max_dev=mx, row=0, relu_out=r)
         iv = torch.tensor([float(mx[0]) / 2048 + 1e-12], device="cuda")
         hist = torch.zeros(1, 2048, dtype=torch.int64, device="cuda")
@@ -66,6 +86,8 @@ def run(cases, seed, verbose=True):
             failures.append(cfg)
             if verbose:
                 print("MISMATCH", cfg, flush=True)
+    if verbose:
+        print("kernels exercised:", ", ".join("%s %d" % kv for kv in sorted(counts.items())), flush=True)
     return failures
 
 
