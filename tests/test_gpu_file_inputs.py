@@ -178,3 +178,32 @@ def test_grouping_on_launches_of_more_than_256_tiles_with_the_tail_split_on_and_
     mass = h1.sum(axis=1).astype(np.float64)
     dist = np.abs(g64.astype(np.int64) - h1.astype(np.int64)).sum(axis=1)
     assert np.array_equal(g64.sum(axis=1), h1.sum(axis=1)) and float((dist / np.maximum(mass, 1)).max()) <= 1e-4
+
+
+def test_the_upload_of_the_next_host_batch_is_issued_before_this_one_is_handed_out():
+    """_device_items (round 4): a host batch's copy rides a side stream, and the copy of batch i + 1 is ISSUED before batch i is
+    handed to the caller (whose kernels it then runs beside) -- one item of look-ahead, never more.  A loader that refills its own
+    pinned buffer is not pulled ahead: its copy must be done before the loader is asked again, and waiting for that in front of
+    the current batch's launches would stall the host.  The batches arrive unchanged and in order either way."""
+    from tools import Quantity
+    with product_workdir(device="gpu", max_cali_img_num=100):
+        q = Quantity(_r18())
+        for pinned, want in ((False, ["pull0", "pull1", "got0", "pull2", "got1", "pull3", "got2", "got3"]),
+                             (True, ["pull0", "got0", "pull1", "got1", "pull2", "got2", "pull3", "got3"])):
+            log = []
+            host = [torch.full((2, 3, 32, 32), float(k)) for k in range(4)]
+            if pinned:
+                host = [h.pin_memory() for h in host]
+
+            def loader():
+                for k, h in enumerate(host):
+                    log.append("pull%d" % k)
+                    yield (h, 0)
+            got = []
+            for i, x in q._device_items(loader()):
+                log.append("got%d" % i)
+                assert x.is_cuda
+                got.append(x)
+            torch.cuda.synchronize()
+            assert log == want, (pinned, log)
+            assert all(torch.equal(g.cpu(), h) for g, h in zip(got, host))
