@@ -272,8 +272,9 @@ int fq_conv_kxk_f32(const float* x, const float* wt, const float* bias, float* y
  * u: the weights transformed and packed by fq_conv3x3_wino_f32_pack -- fq_conv3x3_wino_f32_packed_floats(Cin, Cout) floats,
  *   16-byte aligned, U = G g Gt computed in fp64 and rounded once, laid out [ci / 8][position 0..15][ci % 2][co][ci % 8 / 2];
  *   w_kcrs: fp32 [Cout][Cin][3][3] on the device.
- * x: fp32 [N][Cin][H][W], y / relu_out: fp32 [N][Cout][H][W]; Cin % 8 == 0, Cout % 64 == 0, x and y below 2^31 BYTES
- *   (fq_conv3x3_wino_f32_supported; FQ_ERR_UNSUPPORTED otherwise: callers keep fq_conv_kxk_f32 there).
+ * x: fp32 [N][Cin][H][W], y / relu_out: fp32 [N][Cout][H][W]; Cin % 8 == 0, Cout % 64 == 0, H * W >= 4, x and y below 2^31
+ *   BYTES (fq_conv3x3_wino_f32_supported; FQ_ERR_UNSUPPORTED otherwise: callers keep fq_conv_kxk_f32 there).  bias: 16-byte
+ *   aligned or FQ_ERR_UNSUPPORTED.  No byte outside [x, x + 4 N Cin H W) is read: x needs no slack behind it.
  * Numerics: per output an fmaf chain over ci = 0 .. Cin-1 for each of the 16 positions, the fixed additions of the output
  *   transform, then the bias: deterministic, independent of N (no tail split, no workspace), NOT the direct sum -- it differs
  *   from fq_conv_kxk_f32 by a few units in the last place of the LARGEST term (tests/test_gpu_conv_wino.py states the bound). */

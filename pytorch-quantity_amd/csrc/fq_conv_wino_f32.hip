@@ -184,10 +184,15 @@ __device__ __forceinline__ void wino_epilogue(const f16v (&acc)[8], unsigned ph,
 // four input rows in channel 0 of its image (a whole row is one 16-byte load; "row outside the image" = an out-of-range
 // offset, answered with zeros) and which columns exist.  Column -1 of a tile at the left edge is the pixel in front of the
 // row: it is loaded and dropped -- except in front of the tensor's very first pixel, where that row is loaded from column 0
-// and shifted.
+// and shifted.  The other end needs the same care: the 16 bytes of the last tile of a row end one pixel (even W) or two (odd W)
+// behind the row, and behind the LAST row of the LAST image that is the pixel behind the plane -- inside the tensor for every
+// channel but the last, whose load would read 4 or 8 bytes past x (the channel rides in the scalar offset, which the address
+// unit's range check does not see, so it would really be issued).  Those rows (`endrow`: at most one per tile) are loaded from
+// the plane's last four pixels instead and shifted the other way; nothing is ever read outside [x, x + x_bytes).
 struct TileIn {
     unsigned xo[4];
     bool c0ok, c2ok, c3ok, shift1;
+    int endrow;               // the row of this tile that is (last image, row H - 1, last tile of the row), or -1
 };
 
 template <int WT>
@@ -201,13 +206,17 @@ __device__ __forceinline__ TileIn tile_in(const WArgs& a, unsigned tb, unsigned 
     const unsigned nb = n * a.Cin * a.HW;
     t.c0ok = tx != 0u; t.c2ok = 2u * tx + 1u < a.W; t.c3ok = 2u * tx + 2u < a.W;
     t.shift1 = tile_ok && tc == 0u;
+    const bool last_col = tile_ok && tc + a.tiles_img >= a.tiles && tx + 1u == a.TW;        // last image, last tile of a row
+    t.endrow = -1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int iy = iy0 + i;
         const bool ok = tile_ok && (unsigned)iy < a.H;
-        t.xo[i] = ok ? (nb + (unsigned)iy * a.W + 2u * tx - 1u) * 4u : kOob;
+        const bool end = last_col && (unsigned)iy + 1u == a.H;
+        t.xo[i] = ok ? (end ? nb + a.HW - 4u : nb + (unsigned)iy * a.W + 2u * tx - 1u) * 4u : kOob;      // (HW >= 4: host check)
+        t.endrow = end ? i : t.endrow;
     }
-    if (t.shift1) t.xo[1] = 0u;
+    if (t.shift1) t.xo[1] = 0u;                               // (H = W = 2: tile 0 is also the last; its rows 1 and 2 are the two cases)
     const unsigned second = WT == 1 ? (lane >> 5) * a.HW * 4u : 0u;   // (an out-of-range offset stays out of range: x is below 2^31 bytes)
 #pragma unroll
     for (int i = 0; i < 4; ++i) t.xo[i] += second;
@@ -240,6 +249,8 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
     for (unsigned wi = v0; wi < a.work; wi += G) {
         const unsigned kb = wi / a.tiles_t, tb = wi - kb * a.tiles_t;
         const TileIn ti = tile_in<WT>(a, tb, lane);
+        // (odd H: row H - 1 is in the last tile row and in the one above it, TW tiles earlier)
+        const bool ends = (tb + 1u) * kBT + a.TW >= a.tiles;
         f4v d[4];                                             // this thread's input tile of the step being loaded, row by row
         auto xload = [&](unsigned s) {
             const int so = (int)((s * kCS + tch) * a.HW * 4u);
@@ -249,6 +260,13 @@ __device__ __forceinline__ void wino_tiles(const WArgs& a, Stat& stat, char* sme
         // Bt d B,  Bt = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: rows first, then columns
         auto transform_store = [&](unsigned stage_off) {
             if (tb == 0u) d[1] = ti.shift1 ? f4v{0.0f, d[1][0], d[1][1], d[1][2]} : d[1];     // (uniform: the block that holds tile 0)
+            if (ends) {                                       // (uniform: the blocks that hold a tile with an `endrow`)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f4v sh = kOddW ? f4v{d[i][2], d[i][3], 0.0f, 0.0f} : f4v{d[i][1], d[i][2], d[i][3], 0.0f};
+                    d[i] = ti.endrow == i ? sh : d[i];
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 d[i][0] = ti.c0ok ? d[i][0] : 0.0f;
@@ -422,6 +440,7 @@ __global__ __launch_bounds__(256) void wino_pack_kernel(const float* __restrict_
 bool wino_shape_ok(int N, int Cin, int Hin, int Win, int Cout) {
     if (N < 0 || Cin <= 0 || Hin <= 0 || Win <= 0 || Cout <= 0) return false;
     if ((Cin % (int)kCS) != 0 || (Cout % (int)kBK) != 0) return false;
+    if ((size_t)Hin * Win < 4) return false;                  // (the end-of-tensor row is loaded from the plane's last four pixels)
     const size_t in_bytes = (size_t)N * Cin * Hin * Win * 4, out_bytes = (size_t)N * Cout * Hin * Win * 4;
     const size_t tiles = (size_t)N * ((Hin + 1) / 2) * ((Win + 1) / 2);
     const size_t work = ((tiles + 31) / 32) * (size_t)(Cout / (int)kBK);                        // (32-bit work item numbers)

@@ -18,11 +18,11 @@ import torch
 from . import _native
 
 __all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "call_qd", "call_linear_qd", "state", "is_verified",
-           "is_off", "forget", "TOL"]
+           "is_off", "forget", "kernel_key", "TOL"]
 
 TOL = 1e-5                                      # |own - torch| <= TOL * (|W| * |x| + |b|): summation order only
-# module -> {"verified": the own kernel agreed with torch here, "off": it disagreed (the module keeps torch's convolution),
-#            "wt": (tag of the parameter, weights in the kernel's layout)}
+# module -> {"verified": the set of kernels (kernel_key) that agreed with torch on this module, "off": one disagreed (the module
+#            keeps torch's convolution), "wt": {kind: (tag of the parameter, weights in the kernel's layout)}}
 _STATE = weakref.WeakKeyDictionary()
 
 
@@ -33,8 +33,24 @@ def state(m):
     return st
 
 
-def is_verified(m):
-    return bool(_STATE.get(m, {}).get("verified"))
+def _uses_sb(m, k):
+    """Does kind k of this module run on the split-bf16 form of the 1x1 kernels?  (opt-in; from 128 input channels on: with
+    64 the four K steps of a tile do not pay for the split's prologue, 0.95 x)"""
+    w = m.weight
+    return k == "c1" and _native.conv_sb_enabled() and w.shape[1] >= 128 and _native.conv_sb_supported(w.shape[1], w.shape[0])
+
+
+def kernel_key(m, k):
+    """What the once-per-process check is keyed by: a module can run on several kernels in one process (the direct or the
+    Winograd kernel depending on the input's shape and FQ_CONV_WINO, the fp32 or the split-bf16 1x1 kernel depending on
+    FQ_CONV_SPLIT_BF16), and each of them is checked the first time the module runs on it."""
+    return (k, _uses_sb(m, k))
+
+
+def is_verified(m, k=None):
+    """Has the module passed its check on the kernel kind k runs on now (None: on any kernel)?"""
+    done = _STATE.get(m, {}).get("verified")
+    return bool(done) if k is None else bool(done) and kernel_key(m, k) in done
 
 
 def is_off(m):
@@ -71,7 +87,10 @@ def kind(m, x, wino=True):
     if (m.kernel_size != (1, 1) and m.in_channels % 16 == 0 and m.out_channels % 4 == 0
             and x.shape[2] + 2 * m.padding[0] >= m.kernel_size[0] and x.shape[3] + 2 * m.padding[1] >= m.kernel_size[1]
             and m.kernel_size[0] * m.kernel_size[1] * m.in_channels * m.out_channels < 2 ** 30):
+        # (the Winograd epilogue reads the bias 16 bytes at a time: a bias that is a view into a flat parameter buffer at an
+        #  odd offset keeps the layer on the direct kernel, whose bias reads are scalar)
         if (wino and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1) and _native.conv_wino_enabled()
+                and m.bias.data_ptr() % 16 == 0
                 and _native.conv_wino_supported(x.shape[0], m.in_channels, x.shape[2], x.shape[3], m.out_channels)):
             return "wino"
         return "kxk"
@@ -86,8 +105,7 @@ def weight(m, k):
     by_kind = state(m).setdefault("wt", {})
     cached = by_kind.get(k)
     if cached is None or cached[0] != tag:
-        # (opt-in; from 128 input channels on: with 64 the four K steps of a tile do not pay for the split's prologue, 0.95 x)
-        sb = k == "c1" and _native.conv_sb_enabled() and w.shape[1] >= 128 and _native.conv_sb_supported(w.shape[1], w.shape[0])
+        sb = _uses_sb(m, k)
         packed = (_native.pack_sb_weight(w) if sb                # (opt-in: the split-bf16 form of the 1x1 kernels takes this pack)
                   else w.detach().view(w.shape[0], w.shape[1]).t().contiguous() if k == "c1"
                   else _native.pack_kxk_weight(w) if k == "kxk"
@@ -109,10 +127,11 @@ def runner(m, k, x):
     return lambda **kw: _native.conv_stem_f32(x, wq, m.bias, m.out_channels, m.kernel_size, s, m.padding[0], **kw)
 
 
-def verified(m, run, x):
-    """Once per process and module: the own kernel against torch on this very input.  Returns torch's result when the
-    module fails (and marks it: it keeps the library convolution from now on), None when it passes."""
-    if is_verified(m):
+def verified(m, run, x, k=None):
+    """Once per process, module and kernel (kernel_key(m, k); k = None: once per module, whatever kernel `run` is): the own
+    kernel against torch on this very input.  Returns torch's result when the module fails (and marks it: it keeps the library
+    convolution from now on), None when it passes."""
+    if is_verified(m, k):
         return None
     # The reference result comes from an independent implementation of the same fp32 mathematics that is NOT the convolution
     # library: asking that library for a layer it will never run again would put its first-use solver search (tens of
@@ -154,7 +173,7 @@ def verified(m, run, x):
     if not bool(((cmp - ref).abs() <= TOL * bound).all() & (scratch[0] == own.abs().max())):
         state(m)["off"] = True
         return torch.nn.Conv2d.forward(m, x)
-    state(m)["verified"] = True
+    state(m).setdefault("verified", set()).add(kernel_key(m, k))
     return None
 
 
@@ -164,7 +183,7 @@ def plain(m, k, x, check=True):
     run = runner(m, k, x)
     if not check:
         return run()
-    ref = verified(m, run, x)
+    ref = verified(m, run, x, k)
     return ref if ref is not None else run()
 
 
@@ -201,7 +220,7 @@ def call_qd(m, x, bit, bitwidth):
     if k is None:
         return None
     run = runner(m, k, x)
-    if not is_verified(m) and verified(m, run, x) is not None:
+    if not is_verified(m, k) and verified(m, run, x, k) is not None:
         return None                                             # the module just failed its check: two passes, torch's convolution
     return run(qd=(int(bit), 8 if bitwidth == 8 else 16))
 
@@ -216,7 +235,8 @@ def call_linear_qd(m, x, bit, bitwidth):
     if (not enabled() or torch.is_grad_enabled() or "forward" in m.__dict__ or _hooked(m) or is_off(m) or type(m) is not torch.nn.Linear
             or not torch.is_tensor(x) or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2 or not x.is_contiguous()
             or m.bias is None or m.weight.dtype != torch.float32 or m.out_features % 4 or x.shape[0] == 0
-            or x.numel() >= 2 ** 30 or x.shape[0] * m.out_features >= 2 ** 30):
+            or x.numel() >= 2 ** 30 or x.shape[0] * m.out_features >= 2 ** 30 or m.in_features * m.out_features >= 2 ** 30
+            or x.shape[1] != m.in_features):
         return None
     w = m.weight
     tag = (w._version, w.data_ptr(), w.device)
@@ -224,12 +244,16 @@ def call_linear_qd(m, x, bit, bitwidth):
     if cached is None or cached[0] != tag:
         cached = state(m)["wt_linear"] = (tag, w.detach().t().contiguous())
     x4 = x.view(x.shape[0], x.shape[1], 1, 1)
-    if not is_verified(m):
-        own = _native.conv1x1_f32(x4, cached[1], m.bias, 1).view(x.shape[0], -1)
+    if not is_verified(m, "linear"):
+        try:
+            own = _native.conv1x1_f32(x4, cached[1], m.bias, 1).view(x.shape[0], -1)
+        except _native.FqError:                                 # a limit of the kernel this guard does not know: the two passes
+            state(m)["off"] = True
+            return None
         ref = torch.addmm(m.bias, x, w.t())
         bound = torch.addmm(m.bias.abs(), x.abs(), w.abs().t())
         if not bool(((own - ref).abs() <= TOL * bound).all()):
             state(m)["off"] = True
             return None
-        state(m)["verified"] = True
+        state(m).setdefault("verified", set()).add(kernel_key(m, "linear"))
     return _native.conv1x1_f32(x4, cached[1], m.bias, 1, qd=(int(bit), 8 if bitwidth == 8 else 16)).view(x.shape[0], -1)

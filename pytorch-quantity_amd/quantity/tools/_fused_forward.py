@@ -202,7 +202,7 @@ class _FusedForward(object):
                                                             relu_out=r, out=o), key)
             ctl.hist_fused += 1
             return True
-        ref = _float_conv.verified(m, run, x)                  # first use: against torch, once per process
+        ref = _float_conv.verified(m, run, x, kind)            # first use of this kernel: against torch, once per process
         if ref is not None:
             output.copy_(ref)                                  # this module keeps the library convolution from now on
             return False

@@ -21,15 +21,23 @@ SHAPES = [
     (5, 256, 256, 14, 14),        # layer3: 7x7 tiles per image, 245 tiles = 3.8 blocks
     (4, 512, 512, 7, 7),          # layer4: odd plane, 4x4 tiles with a missing row and column; 64 tiles = one block
     (3, 8, 64, 5, 9),             # one step; odd both ways
-    (70, 16, 128, 1, 1),          # 1x1 planes: one tile per image, three of its four pixels missing, eight taps padding
+    (70, 16, 128, 1, 4),          # one-row planes: two tiles per image, half of their pixels missing, six taps padding
     (1, 8, 64, 2, 3),             # a single partial block
     (7, 24, 64, 13, 6),           # three steps, odd height
     (33, 16, 192, 10, 10),        # 825 tiles = 12.9 blocks x 3 k-blocks: more work items than one round of a persistent grid
     (2, 40, 64, 6, 20),           # wide plane
     # (Cin >= 128: the half-size work item -- 64 channels x 32 tiles, two workgroups per CU, two channels per transform wave)
     (3, 128, 64, 5, 9),           # odd both ways, 45 tiles = 1.4 blocks
-    (70, 128, 128, 1, 1),         # 1x1 planes
+    (70, 128, 128, 2, 2),         # one tile per image
     (1, 136, 64, 2, 3),           # a single partial block, 17 steps
+    # the end of the tensor: the last tile's row H - 1 is loaded from the plane's last four pixels and shifted (tile_in)
+    (1, 8, 64, 2, 2),             # tile 0 is also the last tile: both shifts in one tile
+    (1, 8, 64, 1, 4),
+    (2, 16, 64, 4, 1),            # W = 1: every tile is the last of its row
+    (1, 8, 64, 3, 3),             # odd H: row H - 1 is in two tile rows
+    (2, 8, 64, 7, 2),
+    (3, 128, 64, 3, 5),           # the half-size work item
+    (40, 8, 64, 7, 9),            # odd H, the two tile rows with row H - 1 in different tile blocks
 ]
 
 
@@ -118,6 +126,45 @@ def test_quandequan_epilogue_equals_the_two_pass_form(nat, bit, bitwidth):
     assert nat.lib().fq_conv3x3_wino_qd_f32(x.data_ptr(), u.data_ptr(), None, plain.data_ptr(), 4, 24, 7, 7, 128, 3, 12, None) == -1
 
 
+def test_x_may_end_where_its_allocation_ends():
+    """The kernel reads nothing outside [x, x + x_bytes): x is put at the very end of an allocation of its own (hipMalloc, not
+    the caching allocator, whose blocks have neighbours), for an even and an odd W -- the 16-byte row load of the last tile
+    used to end 4 / 8 bytes behind the tensor for the last input channel (the channel rides in the scalar offset, which the
+    address unit's range check does not see).  In a child process: a fault would end the process, not the test run."""
+    import os, subprocess, sys
+    code = r'''
+import ctypes, sys, torch
+sys.path.insert(0, sys.argv[1])
+from common.quantity import _native as nat
+hip = ctypes.CDLL("libamdhip64.so")
+hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+L = nat.lib()
+for (N, cin, cout, H, W) in ((2, 64, 64, 32, 32), (2, 64, 64, 8, 31), (1, 128, 64, 32, 32), (1, 128, 64, 31, 8)):
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randint(-8, 9, (N, cin, H, W), device="cuda", generator=g).float()
+    w = torch.randint(-8, 9, (cout, cin, 3, 3), device="cuda", generator=g).float()
+    u = nat.pack_wino_weight(w)
+    nbytes = x.numel() * 4
+    total = (nbytes + (2 << 20) - 1) // (2 << 20) * (2 << 20)
+    base = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(base), total) == 0
+    xp = base.value + total - nbytes                      # x ends where the allocation ends
+    torch.cuda.synchronize()
+    assert hip.hipMemcpy(xp, x.data_ptr(), nbytes, 3) == 0
+    y = torch.empty(N, cout, H, W, device="cuda")
+    rc = L.fq_conv3x3_wino_f32(xp, u.data_ptr(), None, y.data_ptr(), None, N, cin, H, W, cout, None, None, None, None)
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None, padding=1)
+    assert torch.equal(y.double(), ref), (N, cin, cout, H, W)
+print("ok")
+'''
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pytorch-quantity_amd", "quantity")
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_an_image_computes_the_same_bits_in_any_batch(nat):
     """No K split, no workspace: what a pixel is does not depend on how many images ride in the launch or where in it the
     image sits (the direct kernel's tail split does make the last bit depend on the tile count -- include/fq.h)."""
@@ -181,6 +228,8 @@ def test_argument_errors(nat):
     assert L.fq_conv3x3_wino_f32_pack(None, P(u), 8, 64, None) == -1
     assert L.fq_conv3x3_wino_f32_pack(P(x), P(u), 4, 64, None) == -4
     assert L.fq_conv3x3_wino_f32_supported(4, 12, 8, 8, 64) == 0 and L.fq_conv3x3_wino_f32_supported(4, 8, 8, 8, 64) == 1
+    # planes of fewer than four pixels stay on the direct kernel (the end-of-tensor row is loaded from a plane's last four)
+    assert L.fq_conv3x3_wino_f32_supported(4, 8, 1, 3, 64) == 0 and L.fq_conv3x3_wino_f32_supported(4, 8, 1, 4, 64) == 1
 
 
 def test_resnet50_tables_do_not_depend_on_the_3x3_kernel(monkeypatch):

@@ -909,3 +909,86 @@ def test_resnet50_tables_with_the_split_bf16_kernels(monkeypatch):
     monkeypatch.undo()
     _float_conv.forget()
     assert tables[0] == tables[1]
+
+
+def test_every_kernel_a_module_runs_on_is_checked_once(monkeypatch):
+    """The once-per-process check is keyed by the KERNEL (`_float_conv.kernel_key`), not by the module alone: a 1x1 layer first
+    seen on the fp32-MFMA kernel is checked again the first time it runs on the split-bf16 kernel (FQ_CONV_SPLIT_BF16 flipped
+    in the process, as bench.py does), a 3x3 layer first seen at a shape the Winograd kernel refuses is checked again when a
+    shape it takes arrives -- and each only once."""
+    from torch import nn
+    from common.quantity import _float_conv
+    checks = []
+    real = _float_conv.verified
+
+    def counting(m, run, x, k=None):
+        before = set(_float_conv.state(m).get("verified", ()))
+        out = real(m, run, x, k)
+        if set(_float_conv.state(m).get("verified", ())) != before:
+            checks.append(_float_conv.kernel_key(m, k))
+        return out
+    monkeypatch.setattr(_float_conv, "verified", counting)
+    c1 = nn.Conv2d(128, 64, 1).cuda().eval()
+    c3 = nn.Conv2d(16, 64, 3, padding=1).cuda().eval()
+    x1 = torch.randn(2, 128, 6, 6, device="cuda")
+    with torch.no_grad():
+        monkeypatch.delenv("FQ_CONV_SPLIT_BF16", raising=False)
+        a = _float_conv.call(c1, x1)
+        _float_conv.call(c1, x1)
+        assert checks == [("c1", False)] and _float_conv.is_verified(c1, "c1")
+        monkeypatch.setenv("FQ_CONV_SPLIT_BF16", "1")
+        assert not _float_conv.is_verified(c1, "c1") and _float_conv.is_verified(c1)
+        b = _float_conv.call(c1, x1)
+        _float_conv.call(c1, x1)
+        assert checks == [("c1", False), ("c1", True)]
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max())
+        monkeypatch.delenv("FQ_CONV_SPLIT_BF16")
+        _float_conv.call(c1, x1)
+        assert len(checks) == 2                                                     # both kernels stay verified
+        del checks[:]
+        small, big = torch.randn(3, 16, 1, 3, device="cuda"), torch.randn(3, 16, 8, 8, device="cuda")
+        assert _float_conv.kind(c3, small) == "kxk" and _float_conv.kind(c3, big) == "wino"
+        for x in (small, big, small, big):
+            y = _float_conv.call(c3, x)
+            ref = torch.nn.functional.conv2d(x.double(), c3.weight.double(), c3.bias.double(), padding=1)
+            assert float((y.double() - ref).abs().max()) < 1e-5
+        assert checks == [("kxk", False), ("wino", False)]
+
+
+def test_a_bias_at_an_odd_offset_keeps_a_3x3_layer_on_the_direct_kernel():
+    """The Winograd epilogue reads the bias 16 bytes at a time and refuses a bias that is not 16-byte aligned
+    (FQ_ERR_UNSUPPORTED); kind() sees that before the call, so a bias that is a view into a flat parameter buffer at an odd
+    offset runs on fq_conv_kxk_f32 (scalar bias reads) instead of raising from inside the model's forward."""
+    from torch import nn
+    from common.quantity import _float_conv, _native
+    conv = nn.Conv2d(16, 64, 3, padding=1).cuda().eval()
+    flat = torch.randn(65, device="cuda")
+    conv.bias = nn.Parameter(flat[1:])                          # 4 bytes past a 16-byte boundary
+    assert conv.bias.data_ptr() % 16 == 4
+    x = torch.randn(2, 16, 8, 8, device="cuda")
+    with pytest.raises(_native.FqError):
+        _native.conv_wino_f32(x, _native.pack_wino_weight(conv.weight), conv.bias, 64)
+    with torch.no_grad():
+        assert _float_conv.kind(conv, x) == "kxk"
+        y = _float_conv.call(conv, x)
+    ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), conv.bias.double(), padding=1)
+    assert _float_conv.is_verified(conv, "kxk") and float((y.double() - ref).abs().max()) < 1e-5
+
+
+def test_testlinear_keeps_the_two_calls_when_the_kernel_refuses_the_layer(monkeypatch):
+    """call_linear_qd returns None -- the caller then runs the reference's two calls -- for anything the 1x1 kernel refuses,
+    instead of raising FqError from inside TestLinear.forward: the guard knows the weight-matrix limit, and a refusal it does
+    not know about (here: forced) turns the module off."""
+    from torch import nn
+    from common.quantity import _float_conv, _native
+    lin = nn.Linear(64, 12).cuda().eval()
+    x = torch.randn(3, 64, device="cuda")
+
+    def refuse(*a, **k):
+        raise _native.FqError("fq_conv1x1_f32: FQ_ERR_UNSUPPORTED")
+    with torch.no_grad():
+        monkeypatch.setattr(_native, "conv1x1_f32", refuse)
+        assert _float_conv.call_linear_qd(lin, x, 4, 8) is None and _float_conv.is_off(lin)
+        monkeypatch.undo()
+        assert _float_conv.call_linear_qd(lin, x, 4, 8) is None                    # stays off
+        assert _float_conv.call_linear_qd(nn.Linear(64, 12).cuda().eval(), x[:, :32].contiguous(), 4, 8) is None   # wrong width
