@@ -220,6 +220,7 @@ struct ChanTable {
     uint32_t groups[kChanChunk], nb[kChanChunk];          // image groups, images per group
     uint32_t cb[kChanChunk];                              // channels per workgroup: 1 (big planes) or kChanBlock
     uint32_t vec[kChanChunk];                             // 16-byte loads possible
+    uint32_t own[kChanChunk];                             // 8-channel blocks: every row of this tensor belongs to ONE workgroup of this call
     int32_t row0[kChanChunk];
     uint32_t wg_begin[kChanChunk + 1];
     int32_t nseg;
@@ -229,7 +230,7 @@ struct ChanView {
     const float* base;          // first element of (image n0, channel c0)
     size_t img_stride;          // C * HW
     uint32_t HW, run;           // run = cb * HW contiguous floats per image
-    uint32_t nimg, cb, vec;
+    uint32_t nimg, cb, vec, own;
     int row;                    // row of channel c0
 };
 
@@ -254,6 +255,7 @@ __device__ __forceinline__ ChanView chan_of(const ChanTable& t) {
     v.base = t.ptr[lo] + (size_t)n0 * v.img_stride + (size_t)c0 * v.HW;
     v.row = t.row0[lo] + (int)c0;
     v.vec = t.vec[lo] && ((v.run & 3u) == 0);
+    v.own = t.own[lo];
     return v;
 }
 
@@ -352,6 +354,19 @@ __global__ __launch_bounds__(kBlock) void absmax_chan_kernel(const ChanTable tab
     if (threadIdx.x < cv.cb) atomicMax(reinterpret_cast<unsigned int*>(max_inout + cv.row + threadIdx.x), s_m[threadIdx.x]);
 }
 
+// The flush of a row that ONE workgroup owns for the whole call (every image of the batch in one group, no other segment on the
+// row; the host decides: ChanTable::own): four 64-bit counters per lane read, added to and written back as two 16-byte accesses
+// each way instead of up to four 64-bit atomics.  A 14x14 plane gives a row 50 K elements per 256 images, a 7x7 plane 12.5 K --
+// against up to 2 048 bins to publish: with atomics (memory-side, 8 bytes each) the flush of the 34 000 small-plane rows of
+// ResNet-50 was a third of the kernel.  Launches on one stream are ordered, so the previous batch's sums are visible.
+__device__ __forceinline__ void own_add4(unsigned long long* __restrict__ d, unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3) {
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    u64x2* const p = reinterpret_cast<u64x2*>(d);
+    u64x2 a = p[0], b = p[1];
+    a.x += c0; a.y += c1; b.x += c2; b.y += c3;
+    p[0] = a; p[1] = b;
+}
+
 __global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTable tab, const float* __restrict__ interval,
                                                                unsigned long long* __restrict__ hist, const int allow_fast) {
     // big planes: s_bins[0 .. 2047] 32-bit bins of one row (+ 64 parking slots)
@@ -396,6 +411,13 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTab
     if (fast) for_each_in_block<kHistBlock, true>(cv, [&](float v, uint32_t ch) { add(v, ch, std::true_type{}); });
     else for_each_in_block<kHistBlock, true>(cv, [&](float v, uint32_t ch) { add(v, ch, std::false_type{}); });
     __syncthreads();
+    if (cv.own) {                                             // four consecutive bins (two packed dwords) per lane and step
+        for (uint32_t q = threadIdx.x; q < cv.cb * (FQ_BINS / 4); q += kHistBlock) {
+            const uint2 c = reinterpret_cast<const uint2*>(s_bins)[q];
+            if (c.x | c.y) own_add4(dst + 4u * (size_t)q, c.x & 0xffffu, c.x >> 16, c.y & 0xffffu, c.y >> 16);
+        }
+        return;
+    }
     for (uint32_t w = threadIdx.x; w < cv.cb * (FQ_BINS / 2); w += kHistBlock) {
         const unsigned int c = s_bins[w];
         if (c) {
@@ -408,7 +430,7 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_chan_kernel(const ChanTab
 }
 
 template <typename Launch>
-static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launch) {
+static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launch, bool may_own = false) {
     if (nseg < 0 || nseg > FQ_MAX_SEGS || (nseg > 0 && segs == nullptr)) return FQ_ERR_INVALID_ARG;
     for (int i = 0; i < nseg; ++i) {
         const fq_chan_seg& s = segs[i];
@@ -450,10 +472,20 @@ static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launc
             }
             if (nb > (uint32_t)s.N) nb = (uint32_t)s.N;
             const uint32_t groups = ((uint32_t)s.N + nb - 1) / nb;
+            // a row is one workgroup's own when the batch is a single image group and no other segment of the call feeds the row.
+            // Used for the 8-channel blocks only (measured at 256 images, steady state, scripts/chan_hist_probe.py: 7x7 planes
+            // 2.5 -> 3.1 TB/s -- 8 x 2 048 counters to publish per 100 K elements; one-channel workgroups on 14x14 / 28x28
+            // planes 5.2 -> 4.65 / 5.9 -> 5.5: their atomics are fire-and-forget, the read-add-write is a round trip at the end
+            // of a workgroup that has nothing left to overlap it with)
+            bool own = may_own && groups == 1 && cb != 1;
+            for (int j = 0; own && j < nseg; ++j) {
+                const fq_chan_seg& o = segs[j];
+                if (&o != &s && o.N != 0 && (int64_t)o.row0 < (int64_t)s.row0 + s.C && (int64_t)s.row0 < (int64_t)o.row0 + o.C) own = false;
+            }
             const uint64_t n_wg = (uint64_t)groups * (((uint64_t)s.C + cb - 1) / cb);
             if (wgs + n_wg > 0x7fffffffULL) { --i; break; }
             tab.ptr[k] = s.ptr; tab.N[k] = (uint32_t)s.N; tab.C[k] = (uint32_t)s.C; tab.HW[k] = (uint32_t)s.HW;
-            tab.groups[k] = groups; tab.nb[k] = nb; tab.cb[k] = cb; tab.vec[k] = vec; tab.row0[k] = s.row0;
+            tab.groups[k] = groups; tab.nb[k] = nb; tab.cb[k] = cb; tab.vec[k] = vec; tab.row0[k] = s.row0; tab.own[k] = own ? 1u : 0u;
             tab.wg_begin[k] = (uint32_t)wgs;
             wgs += n_wg;
             ++k;
@@ -466,7 +498,7 @@ static int for_each_chan_chunk(const fq_chan_seg* segs, int nseg, Launch&& launc
         for (int j = k; j <= kChanChunk; ++j) tab.wg_begin[j] = (uint32_t)wgs;
         for (int j = k; j < kChanChunk; ++j) {
             tab.ptr[j] = nullptr; tab.N[j] = 0; tab.C[j] = 1; tab.HW[j] = 1; tab.groups[j] = 1; tab.nb[j] = 1; tab.cb[j] = 1;
-            tab.vec[j] = 0; tab.row0[j] = 0;
+            tab.vec[j] = 0; tab.row0[j] = 0; tab.own[j] = 0;
         }
         const int rc = launch(tab, (uint32_t)wgs);
         if (rc != FQ_OK) return rc;
@@ -603,10 +635,13 @@ extern "C" int fq_hist2048_chan(const fq_chan_seg* segs, int nseg, const float* 
     if (nseg == 0) return FQ_OK;
     if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
     hipStream_t st = as_stream(stream);
+    // FQ_CHAN_OWN_FLUSH=0: every flush with atomics (A/B timing)
+    const char* const own_env = getenv("FQ_CHAN_OWN_FLUSH");
+    const bool own_ok = !(own_env && own_env[0] == '0');
     return for_each_chan_chunk(segs, nseg, [&](const ChanTable& tab, uint32_t wgs) -> int {
         hipLaunchKernelGGL(hist2048_chan_kernel, dim3(wgs), dim3(kHistBlock), 0, st, tab, interval,
                            reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
         FQ_LAUNCH_CHECK();
         return FQ_OK;
-    });
+    }, own_ok && (reinterpret_cast<uintptr_t>(hist) & 15u) == 0);
 }

@@ -83,6 +83,57 @@ def test_channel_kernels_large_and_ragged_planes(oracle, shape):
     assert not hh[:row0].any() and not hh[row0 + C:].any()
 
 
+def test_channel_histogram_owned_rows_and_shared_rows(oracle, monkeypatch):
+    """A row that one workgroup owns for the whole call (all images in one group, no other segment on the row) is flushed with
+    plain 16-byte read-add-write instead of 64-bit atomics.  Same counts either way (FQ_CHAN_OWN_FLUSH=0: atomics everywhere);
+    two tensors that feed the SAME rows in one call are seen on the host and keep the atomics (their sum is exact); a histogram
+    buffer that is only 8-byte aligned keeps the atomics; rows next to the touched ones stay untouched."""
+    from common.quantity import _native as nat
+    rng = np.random.default_rng(77)
+    shapes = [(64, 24, 14, 14), (64, 20, 7, 7), (16, 5, 28, 28)]       # one-channel form, 8-channel blocks (ragged), several per CU
+    xs = [torch.from_numpy((rng.standard_normal(s, dtype=np.float32) * np.float32(1.5))).cuda() for s in shapes]
+    row0s = [2, 2 + 24 + 1, 2 + 24 + 1 + 20 + 3]
+    rows = row0s[-1] + 5 + 2
+    iv = torch.from_numpy(rng.uniform(0.002, 0.004, rows).astype(np.float32)).cuda()
+
+    def ref_rows(x, r0, acc):
+        xh = x.cpu().numpy()
+        for c in range(xh.shape[1]):
+            acc[r0 + c] += oracle.hist2048(np.ascontiguousarray(xh[:, c]).ravel(), np.float32(iv[r0 + c].item()))
+    want = np.zeros((rows, 2048), dtype=np.int64)
+    for x, r0 in zip(xs, row0s):
+        ref_rows(x, r0, want)
+    got = {}
+    for env in ("1", "0"):
+        monkeypatch.setenv("FQ_CHAN_OWN_FLUSH", env)
+        hist = torch.full((rows, 2048), 5, dtype=torch.int64, device="cuda")      # earlier batches' counts stay
+        nat.hist2048_chan(xs, row0s, iv, hist)
+        nat.hist2048_chan(xs, row0s, iv, hist)
+        got[env] = hist.cpu().numpy()
+        np.testing.assert_array_equal(got[env], 2 * want + 5)
+    # the same rows fed by two segments of one call: no owner, exact sum
+    monkeypatch.setenv("FQ_CHAN_OWN_FLUSH", "1")
+    a, b = xs[1], torch.flip(xs[1], dims=(0,)) * 0.5
+    both = np.zeros((rows, 2048), dtype=np.int64)
+    ref_rows(a, 4, both); ref_rows(b, 4, both)
+    hist = torch.zeros(rows, 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_chan([a, b], [4, 4], iv, hist)
+    np.testing.assert_array_equal(hist.cpu().numpy(), both)
+    # partly overlapping row ranges
+    both = np.zeros((rows, 2048), dtype=np.int64)
+    ref_rows(a, 4, both); ref_rows(xs[0], 10, both)
+    hist = torch.zeros(rows, 2048, dtype=torch.int64, device="cuda")
+    nat.hist2048_chan([a, xs[0]], [4, 10], iv, hist)
+    np.testing.assert_array_equal(hist.cpu().numpy(), both)
+    # a histogram buffer 8 bytes off a 16-byte boundary
+    flat = torch.zeros(rows * 2048 + 1, dtype=torch.int64, device="cuda")
+    off = flat[1:].view(rows, 2048)
+    assert off.data_ptr() % 16 == 8
+    nat.hist2048_chan(xs, row0s, iv, off)
+    np.testing.assert_array_equal(off.cpu().numpy(), want)
+    assert int(flat[0]) == 0
+
+
 def test_channel_histogram_packed_bins_do_not_carry(oracle):
     """Small planes count in 16-bit halves of a dword: a workgroup hands one row at most 32 768 elements, so even when
     they all fall into ONE bin (a constant tensor: every element lands in bin 2047) nothing carries into the
