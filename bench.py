@@ -365,7 +365,7 @@ def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
         float_model(batch)
     for h in hooks:
         h.remove()
-    names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8", "block_tail_i8")
+    names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8", "block_tail_i8", "block_tail_proj_i8")
     events, saved = [], {n: getattr(_native, n) for n in names}
     bytes_of, macs_of = [], []
 
@@ -384,11 +384,16 @@ def int8_conv_roofline(float_model, int8_net, batch, forwards=3):
             res = a[8] if name == "conv2d_i8_add_resident" else (a[5] if name == "block_tail_i8" else None)
             # fq_block_tail_i8 also runs the next block's 1x1 reduction: its weights, its matrix work, its int8 output
             w_next = (a[12] if len(a) > 12 else k.get("w1q")) if name == "block_tail_i8" else None
-            bytes_of.append(nbytes(a[0], a[1], res, w_next, *outs))
+            w_proj = None
+            if name == "block_tail_proj_i8":                      # ... and the projection shortcut: its input, weights, matrix work
+                res, w_proj = a[5], a[6]                           # (xp is what is read in place of the shortcut tensor)
+                w_next = a[16] if len(a) > 16 else k.get("w1q")
+            bytes_of.append(nbytes(a[0], a[1], res, w_next, w_proj, *outs))
             first = next(t for t in outs if isinstance(t, torch.Tensor))
             pixels = first.numel() // first.shape[1 if first.dtype == torch.float32 else -1]
             wq = a[1]                                              # [K][R][S][Cpad] (stem: [R][64][32])
-            macs_of.append(pixels * (int(wq.numel()) + (int(w_next.numel()) if w_next is not None else 0)))
+            macs_of.append(pixels * (int(wq.numel()) + (int(w_next.numel()) if w_next is not None else 0)
+                                     + (int(w_proj.numel()) if w_proj is not None else 0)))
             return r
         return wrapper
     try:

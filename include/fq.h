@@ -59,7 +59,8 @@ int fq_last_hip_error(void);      /* thread-local hipError_t of the last FQ_ERR_
 /* Diagnostic, thread-local like the error code: which kernel the last fq_conv2d_i8 / _resident / _add_resident / _stem call of
  * this thread launched -- low byte: 1 conv3x3_i8_c64 (stationary 64-channel 3x3), 2 conv1x1_i8_stream, 3 conv3x3_i8_halo8
  * (256-pixel tiles, eight waves), 4 conv3x3_i8_halo, 5 / 6 conv2d_i8_dma with a ring of 2 / 3, 7 / 8 / 9 conv2d_i8_kernel
- * (C % 128 / C = 64 / general path), 10 stem_conv_i8, 11 block_tail_i8 (fq_block_tail_i8), 0 nothing launched; bits 8-15: output-channel
+ * (C % 128 / C = 64 / general path), 10 stem_conv_i8, 11 block_tail_i8 (fq_block_tail_i8), 12 the same with the projection
+ * shortcut computed in the kernel (fq_block_tail_proj_i8), 0 nothing launched; bits 8-15: output-channel
  * tile (64 / 128).  Lets a test assert that the dispatch it checked against a golden is the dispatch a benchmark timed. */
 int fq_conv2d_i8_last_variant(void);
 
@@ -432,6 +433,23 @@ int fq_block_tail_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, const float* q
                      int res_bytes, int g_res, int16_t* wide, int g_wide, int8_t* narrow, int ib, int relu,
                      const int8_t* w1_krsc, const float* qbias1, int rs1, int relu1, int8_t* q1_nhwc, long M, int C, int K3,
                      int C2, fq_stream_t stream);
+
+/* fq_block_tail_i8 for the FIRST block of a stage (round 5), whose shortcut is not a tensor but a projection: a 1x1
+ * NewConv2d.forward (new_quantity_op.py:124-133; stride 1 or 2, no padding, no ReLU) of the block's input.  As its own launch
+ * that convolution writes K3 bytes per pixel which the tail reads straight back; here the workgroup computes its 128 pixels of
+ * the projection -- contraction, RightShift(rsp) + BiasAdd + Sp, int8 on the grid obp -- slice by slice in front of conv3's slice:
+ * the same integers as fq_conv2d_i8_resident followed by fq_block_tail_i8 with res = its output (res_bytes 1, g_res = obp),
+ * bit for bit (tests/test_gpu_block_tail.py), CP bytes per pixel read instead of K3, nothing written.
+ * xp_nhwc int8 [N][Hp][Wp][CP]: the projection's input; wp_krsc int8 [K3][CP]; qbiasp fp32 [K3] integer valued; stride_p in
+ *   {1, 2} with H = (Hp - 1) / stride_p + 1, W likewise; every other argument as in fq_block_tail_i8 with M = N * H * W.
+ * fq_block_tail_proj_i8_supported: today C = CP = 64, C2 in {0, 64} (ResNet's first stage), K3 and the shifts as above;
+ * FQ_ERR_UNSUPPORTED otherwise and callers keep the projection as its own launch.  fq_conv2d_i8_last_variant: 12. */
+int fq_block_tail_proj_i8_supported(int C, int K3, int C2, int CP, int rs3, int rs1, int rsp, int stride_p);
+int fq_block_tail_proj_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, const float* qbias3, int rs3, int ob3,
+                          const int8_t* xp_nhwc, const int8_t* wp_krsc, const float* qbiasp, int rsp, int obp, int stride_p,
+                          int Hp, int Wp, int16_t* wide, int g_wide, int8_t* narrow, int ib, int relu, const int8_t* w1_krsc,
+                          const float* qbias1, int rs1, int relu1, int8_t* q1_nhwc, int N, int H, int W, int C, int K3, int C2,
+                          int CP, fq_stream_t stream);
 
 /* NewAdd.forward (new_quantity_op.py:171-174) on resident operands, with the nn.ReLU and the Quantity of
  * the consumers fused.  x, y: int8 (x_bytes = 1) or int16 (x_bytes = 2) arrays of n elements in the same

@@ -46,6 +46,13 @@ struct BtParams {
     int16_t* wide;                       // exact sum (may be null)
     int8_t* narrow;                      // its re-quantisation (may be null: nobody but the fused conv1 reads it)
     AddResParams ap;
+    // the projection shortcut computed in the kernel (CP > 0): res = Sp(RightShift(conv1x1(xp, wp)) + bias), int8 on grid g_res
+    const int8_t* xp;                    // [Mp][CP] int8 NHWC: the block's input
+    const int8_t* wp;                    // [K3][CP]
+    const float* qbiasp;                 // [K3], integer valued
+    TailParams tp;
+    unsigned xp_bytes;
+    int sp, Ho, Wo, Hp, Wp;              // stride of the projection; output plane; the plane of xp
 };
 
 // LDS rows of RB bytes hold RB / 16 chunks of 16 bytes; position c of row r holds chunk c ^ swz_of(r), chosen so that the 16 lanes
@@ -60,7 +67,13 @@ template <int RB> __device__ __forceinline__ int swz_of(int row) {
 #ifndef FQ_BT_WAVES
 #define FQ_BT_WAVES 2
 #endif
-template <int C, int C2, bool kRes16>
+// CP: input channels of a projection shortcut that is computed HERE instead of being read (0: the shortcut is a tensor).  The first
+// block of a stage adds conv3's output to a 1x1 convolution of the block's input; as its own launch that convolution writes K3
+// bytes per pixel which this kernel reads straight back (at 256 images and 56 x 56: 205 MB each way, 75 us for the launch).  Here the
+// workgroup multiplies its 128 pixels of the block input with the slice's 128 rows of wp right before conv3's slice, runs the
+// projection's own integer tail, and passes the bytes through the wave's rows of the LDS tile into the registers the shortcut would
+// have been loaded into: same integers, CP instead of K3 bytes per pixel read, nothing written.
+template <int C, int C2, bool kRes16, int CP = 0>
 __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_BT_WAVES))) void block_tail_i8_kernel(
     const int8_t* __restrict__ x, const int8_t* __restrict__ w3, const float* __restrict__ qbias3,
     const int8_t* __restrict__ w1, const float* __restrict__ qbias1, int8_t* __restrict__ q1, const BtParams p) {
@@ -69,6 +82,12 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
     constexpr int MT1 = C2 / 32;                         // accumulator tiles of the next conv1 per wave
     constexpr int W1_LOADS = C2 ? (C2 * 8) / kConvBlock : 1;
     constexpr bool kNext = C2 != 0;
+    constexpr bool kProj = CP != 0;
+    static_assert(!(kProj && kRes16), "a projection shortcut is int8");
+    constexpr int KSP = kProj ? CP / 32 : 1;             // MFMA sub-steps of the projection
+    constexpr int WP_LOADS = kProj ? (128 * (CP / 16)) / kConvBlock : 1;
+    __shared__ __attribute__((aligned(16))) int8_t sWP[kProj ? 128 * CP : 16];
+    __shared__ int sBiasP[kProj ? 1024 : 1];
     __shared__ __attribute__((aligned(16))) int8_t sW3[128 * C];
     __shared__ __attribute__((aligned(16))) int8_t sW1[kNext ? C2 * 128 : 16];
     __shared__ __attribute__((aligned(16))) int8_t sN[kTP * 128];
@@ -82,6 +101,9 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
     const int KT = p.K3 >> 7;
 
     for (int i = tid; i < p.K3; i += kConvBlock) sBias3[i] = (int)qbias3[i];          // integer valued by contract
+    if constexpr (kProj) {
+        for (int i = tid; i < p.K3; i += kConvBlock) sBiasP[i] = (int)p.qbiasp[i];
+    }
     if (kNext && tid < C2) sBias1[tid] = (int)qbias1[tid];
 
     // ---- x: this lane's pixel, 16 bytes per sub-step, for the whole tile's life
@@ -94,14 +116,41 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
         for (int ks = 0; ks < KS3; ++ks) fb[ks] = load_act(xr, off + (unsigned)(ks * 32));
     }
 
+    // ---- the projection's operand: the same lane's pixel of the block input (at the projection's stride)
+    v4i fp[KSP];
+    if constexpr (kProj) {
+        const __amdgpu_buffer_rsrc_t xpr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.xp), 0, p.xp_bytes, 0x00020000);
+        const int m = m0 + prow;
+        unsigned off = kOutOfRange;
+        if (m < p.M) {
+            unsigned mp = (unsigned)m;
+            if (p.sp != 1 || p.Hp != p.Ho || p.Wp != p.Wo) {
+                const unsigned hw = (unsigned)(p.Ho * p.Wo), n = (unsigned)m / hw, r = (unsigned)m - n * hw;
+                const unsigned oh = r / (unsigned)p.Wo, ow = r - oh * (unsigned)p.Wo;
+                mp = (n * (unsigned)p.Hp + oh * (unsigned)p.sp) * (unsigned)p.Wp + ow * (unsigned)p.sp;
+            }
+            off = mp * (unsigned)CP + (unsigned)(half * 16);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) fp[ks] = load_act(xpr, off + (unsigned)(ks * 32));
+    }
+
     // ---- weight slices: global -> registers (one slice ahead) -> LDS
     // (everything below addresses memory through buffer descriptors: a 32-bit per-lane offset that is fixed for the tile's life plus
     //  a scalar slice offset -- 64-bit per-lane pointers for three output streams, the shortcut and two weight matrices were 40
     //  registers of loop invariants, and with the next conv1's 64 accumulators alive that meant spills)
     const __amdgpu_buffer_rsrc_t w3r = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(w3), 0, (unsigned)(p.K3 * C), 0x00020000);
     const __amdgpu_buffer_rsrc_t w1r = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(w1), 0, (unsigned)(C2 * p.K3), 0x00020000);
-    v4i r3[W3_LOADS], r1[W1_LOADS];
+    const __amdgpu_buffer_rsrc_t wpr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(p.wp), 0, kProj ? (unsigned)(p.K3 * CP) : 0u, 0x00020000);
+    v4i r3[W3_LOADS], r1[W1_LOADS], rp[WP_LOADS];
     auto fetch = [&](int kt) {
+        if constexpr (kProj) {
+#pragma unroll
+            for (int j = 0; j < WP_LOADS; ++j) {
+                const int i = tid + kConvBlock * j, row = i / (CP / 16), c = i % (CP / 16);
+                rp[j] = load_act(wpr, (unsigned)(row * CP + c * 16) + (unsigned)(kt * 128 * CP));
+            }
+        }
 #pragma unroll
         for (int j = 0; j < W3_LOADS; ++j) {
             const int i = tid + kConvBlock * j, row = i / (C / 16), c = i % (C / 16);
@@ -116,6 +165,13 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
         }
     };
     auto stage = [&]() {
+        if constexpr (kProj) {
+#pragma unroll
+            for (int j = 0; j < WP_LOADS; ++j) {
+                const int i = tid + kConvBlock * j, row = i / (CP / 16), c = i % (CP / 16);
+                *reinterpret_cast<v4i*>(&sWP[row * CP + ((c ^ swz_of<CP ? CP : 64>(row)) * 16)]) = rp[j];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < W3_LOADS; ++j) {
             const int i = tid + kConvBlock * j, row = i / (C / 16), c = i % (C / 16);
@@ -134,9 +190,11 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
     __syncthreads();
 
     // operand-fragment offsets: row (lane & 31) of a 32-row block, chunk 2 ks + half, swizzled by the row
-    int a3_off[KS3], a1_off[4];
+    int a3_off[KS3], a1_off[4], ap_off[KSP];
 #pragma unroll
     for (int ks = 0; ks < KS3; ++ks) a3_off[ks] = (lane & 31) * C + (((2 * ks + half) ^ swz_of<C>(lane & 31)) * 16);
+#pragma unroll
+    for (int ks = 0; ks < KSP; ++ks) ap_off[ks] = kProj ? (lane & 31) * CP + (((2 * ks + half) ^ swz_of<CP ? CP : 64>(lane & 31)) * 16) : 0;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) a1_off[ks] = (lane & 31) * 128 + (((2 * ks + half) ^ swz_of<128>(lane & 31)) * 16);
     int8_t* const my_row = sN + prow * 128;
@@ -176,13 +234,54 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
 #pragma unroll 1
     for (int kt = 0; kt < KT; ++kt) {
         const int k0 = kt * 128;
+        if constexpr (kProj) {
+            // the shortcut of this slice = the projection of this wave's 32 pixels: 128 channels, 64 at a time, tail, int8 through
+            // the wave's own rows of the tile and back as 16 channels x 4 pixels per lane (LDS instructions of one wave run in order)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if constexpr (kRes16) {
-                res.lo[j] = (v4i_r)load_act(resr, 2u * o_el[j] + (unsigned)(2 * k0));
-                res.hi[j] = (v4i_r)load_act(resr, 2u * o_el[j] + (unsigned)(2 * k0 + 16));
-            } else {
-                res.lo[j] = (v4i_r)load_act(resr, o_el[j] + (unsigned)k0);
+            for (int hs = 0; hs < 2; ++hs) {
+                v16i acc[2];
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[a][r] = 0;
+#pragma unroll
+                for (int ks = 0; ks < KSP; ++ks) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        const v4i fa = *reinterpret_cast<const v4i*>(&sWP[(2 * hs + a) * 32 * CP + ap_off[ks]]);
+                        acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fp[ks], acc[a], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        int v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int kl = (2 * hs + a) * 32 + e + 8 * g + 4 * half;
+                            v[e] = conv_tail_i(acc[a][4 * g + e], sBiasP[k0 + kl], p.tp);
+                        }
+                        const int byte = (2 * hs + a) * 32 + 8 * g + 4 * half;
+                        *reinterpret_cast<unsigned*>(my_row + (((byte >> 4) ^ my_swz) * 16) + (byte & 15)) = pack4(v[0], v[1], v[2], v[3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int pix = s_pix + 8 * j;
+                res.lo[j] = *reinterpret_cast<const v4i_r*>(sN + pix * 128 + ((s_ch ^ swz_of<128>(pix)) * 16));
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if constexpr (kRes16) {
+                    res.lo[j] = (v4i_r)load_act(resr, 2u * o_el[j] + (unsigned)(2 * k0));
+                    res.hi[j] = (v4i_r)load_act(resr, 2u * o_el[j] + (unsigned)(2 * k0 + 16));
+                } else {
+                    res.lo[j] = (v4i_r)load_act(resr, o_el[j] + (unsigned)k0);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -317,6 +416,12 @@ void launch_bt(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w3, con
         hipLaunchKernelGGL((block_tail_i8_kernel<C, C2, false>), grid, dim3(kConvBlock), 0, st, x, w3, qb3, w1, qb1, q1, p);
 }
 
+template <int C, int C2, int CP>
+void launch_bt_proj(dim3 grid, hipStream_t st, const int8_t* x, const int8_t* w3, const float* qb3, const int8_t* w1, const float* qb1,
+                    int8_t* q1, const BtParams& p) {
+    hipLaunchKernelGGL((block_tail_i8_kernel<C, C2, false, CP>), grid, dim3(kConvBlock), 0, st, x, w3, qb3, w1, qb1, q1, p);
+}
+
 }  // namespace
 }  // namespace fq
 
@@ -348,6 +453,7 @@ extern "C" int fq_block_tail_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, con
     p.t3 = tail_params(rs3, 0);
     p.t1 = tail_params(C2 ? rs1 : 1, relu1);
     p.res = res; p.res_bytes = res_bytes; p.wide = wide; p.narrow = narrow;
+    p.xp = nullptr; p.wp = nullptr; p.qbiasp = nullptr; p.tp = tail_params(1, 0); p.xp_bytes = 0; p.sp = 1; p.Ho = p.Wo = p.Hp = p.Wp = 1;
     const int rc = make_add_params(ob3, g_res, g_wide, wide != nullptr, ib, relu, &p.ap);
     if (rc != FQ_OK) return rc;
     // the integer tail of conv3 is only the reference's fp32 chain while |acc| + 2^15 < 2^31: C * 127 * 128 is far below
@@ -365,6 +471,51 @@ extern "C" int fq_block_tail_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, con
         launch_bt<256, 0>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
     }
     note_conv_variant(11, 128);
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+// The first block of a stage: conv3 + NewAdd + (the next block's conv1) with the PROJECTION shortcut -- a 1x1 convolution of the
+// block's input, stride 1 or 2, its own RightShift + BiasAdd + Sp, no ReLU -- computed in the same kernel instead of being read.
+extern "C" int fq_block_tail_proj_i8_supported(int C, int K3, int C2, int CP, int rs3, int rs1, int rsp, int stride_p) {
+    if (!(C == 64 && CP == 64 && (C2 == 64 || C2 == 0))) return 0;
+    if (K3 < 128 || K3 > 1024 || (K3 & 127)) return 0;
+    if (rs3 < 1 || rs3 > 16 || rsp < 1 || rsp > 16 || (C2 && (rs1 < 1 || rs1 > 16))) return 0;
+    return (stride_p == 1 || stride_p == 2) ? 1 : 0;
+}
+
+extern "C" int fq_block_tail_proj_i8(const int8_t* x_nhwc, const int8_t* w3_krsc, const float* qbias3, int rs3, int ob3,
+                                     const int8_t* xp_nhwc, const int8_t* wp_krsc, const float* qbiasp, int rsp, int obp, int stride_p,
+                                     int Hp, int Wp, int16_t* wide, int g_wide, int8_t* narrow, int ib, int relu,
+                                     const int8_t* w1_krsc, const float* qbias1, int rs1, int relu1, int8_t* q1_nhwc, int N, int H,
+                                     int W, int C, int K3, int C2, int CP, fq_stream_t stream) {
+    if (N < 0 || H <= 0 || W <= 0 || Hp <= 0 || Wp <= 0) return FQ_ERR_INVALID_ARG;
+    if (!fq_block_tail_proj_i8_supported(C, K3, C2, CP, rs3, rs1, rsp, stride_p)) return FQ_ERR_UNSUPPORTED;
+    if ((Hp - 1) / stride_p + 1 != H || (Wp - 1) / stride_p + 1 != W) return FQ_ERR_INVALID_ARG;   // a 1x1 convolution without padding
+    const long M = (long)N * H * W, Mp = (long)N * Hp * Wp;
+    if (M == 0) return FQ_OK;
+    if (!x_nhwc || !w3_krsc || !qbias3 || !xp_nhwc || !wp_krsc || !qbiasp || (C2 && (!w1_krsc || !qbias1 || !q1_nhwc)) ||
+        (!C2 && !wide && !narrow))
+        return FQ_ERR_INVALID_ARG;
+    if ((reinterpret_cast<uintptr_t>(x_nhwc) | reinterpret_cast<uintptr_t>(w3_krsc) | reinterpret_cast<uintptr_t>(xp_nhwc) |
+         reinterpret_cast<uintptr_t>(wp_krsc) | reinterpret_cast<uintptr_t>(wide) | reinterpret_cast<uintptr_t>(narrow) |
+         reinterpret_cast<uintptr_t>(w1_krsc) | reinterpret_cast<uintptr_t>(q1_nhwc)) & 15u)
+        return FQ_ERR_INVALID_ARG;
+    if (M * (long)K3 >= 0x3fffffffL || M * (long)C >= 0x7fffffffL || Mp * (long)CP >= 0x7fffffffL) return FQ_ERR_UNSUPPORTED;
+    BtParams p;
+    p.M = (int)M; p.K3 = K3; p.x_bytes = (unsigned)(M * C);
+    p.t3 = tail_params(rs3, 0);
+    p.t1 = tail_params(C2 ? rs1 : 1, relu1);
+    p.res = nullptr; p.res_bytes = 1; p.wide = wide; p.narrow = narrow;
+    p.xp = xp_nhwc; p.wp = wp_krsc; p.qbiasp = qbiasp; p.tp = tail_params(rsp, 0); p.xp_bytes = (unsigned)(Mp * CP);
+    p.sp = stride_p; p.Ho = H; p.Wo = W; p.Hp = Hp; p.Wp = Wp;
+    const int rc = make_add_params(ob3, obp, g_wide, wide != nullptr, ib, relu, &p.ap);
+    if (rc != FQ_OK) return rc;
+    const dim3 grid((unsigned)((M + kTP - 1) / kTP));
+    hipStream_t st = as_stream(stream);
+    if (C2 == 64) launch_bt_proj<64, 64, 64>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+    else launch_bt_proj<64, 0, 64>(grid, st, x_nhwc, w3_krsc, qbias3, w1_krsc, qbias1, q1_nhwc, p);
+    note_conv_variant(12, 128);
     FQ_LAUNCH_CHECK();
     return FQ_OK;
 }

@@ -153,7 +153,10 @@ def verified(m, run, x, k=None):
         ref = (torch.matmul(w2, xs) + m.bias.view(1, -1, 1)).view(shape)
         bound = (torch.matmul(w2.abs(), xs.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
     else:                                                       # R x S (the stem included): im2col (unfold) + GEMM on the first and last images
-        head = max(1, min(x.shape[0], (1 << 28) // max(x[0].numel() * m.kernel_size[0] * m.kernel_size[1], 1)))
+        # (at most 16 images -- the first and the last 8, the policy of the 1x1 branch: every tile shape, image boundary and the
+        #  tiles of a launch's last round occur there; the unfolded copy of 149 images of a 56 x 56 layer was 1 GB and, with its two
+        #  GEMMs, most of what a process's first calibration paid for these checks)
+        head = max(1, min(x.shape[0], 16, (1 << 28) // max(x[0].numel() * m.kernel_size[0] * m.kernel_size[1], 1)))
         n_all = int(x.shape[0])
         pick = None
         if head < n_all and head >= 2:

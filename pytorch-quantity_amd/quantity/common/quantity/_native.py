@@ -156,6 +156,10 @@ def lib():
     L.fq_block_tail_i8_supported.argtypes = [ci] * 9
     L.fq_block_tail_i8.restype = ci
     L.fq_block_tail_i8.argtypes = [vp, vp, vp, ci, ci, vp, ci, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp, ctypes.c_long, ci, ci, ci, vp]
+    L.fq_block_tail_proj_i8_supported.restype = ci
+    L.fq_block_tail_proj_i8_supported.argtypes = [ci] * 8
+    L.fq_block_tail_proj_i8.restype = ci
+    L.fq_block_tail_proj_i8.argtypes = [vp, vp, vp, ci, ci, vp, vp, vp, ci, ci, ci, ci, ci, vp, ci, vp, ci, ci, vp, vp, ci, ci, vp] + [ci] * 7 + [vp]
     L.fq_add_resident.restype = ci
     L.fq_add_resident.argtypes = [vp, ci, ci, vp, ci, ci, vp, ci, vp, ci, ci, sz, vp]
     L.fq_dequant_nhwc_to_nchw.restype = ci
@@ -847,7 +851,7 @@ def pack_weight_krsc(w, cpad=None):
 # Which integer-convolution kernels ran (fq_conv2d_i8_last_variant): set conv_variant_log = {} and every call below counts its
 # kernel there by name -- tests and bench.py assert with it that the dispatch they checked is the dispatch they time.
 CONV_VARIANTS = {0: "none", 1: "c64_halo", 2: "stream", 3: "halo8", 4: "halo", 5: "dma2", 6: "dma3", 7: "tile_c128", 8: "tile_c64",
-                 9: "tile_general", 10: "stem", 11: "block_tail"}
+                 9: "tile_general", 10: "stem", 11: "block_tail", 12: "block_tail_proj"}
 conv_variant_log = None
 
 
@@ -1006,6 +1010,47 @@ def block_tail_i8(xq, w3q, qbias3, rs3, ob3, res, g_res, want_wide, g_wide, want
                                   w1q.data_ptr() if C2 else None, qbias1.contiguous().data_ptr() if C2 else None, int(rs1),
                                   1 if relu1 else 0, q1.data_ptr() if C2 else None, N * H * W, C, K3, C2, _stream(xq)),
            "fq_block_tail_i8")
+    _note_variant()
+    return wide, narrow, q1
+
+
+def block_tail_proj_supported(C, K3, C2, CP, rs3, rs1, rsp, stride_p):
+    """Does fq_block_tail_proj_i8 take this chain (the tail of a stage's first block with its projection shortcut computed in the
+    kernel)?"""
+    return bool(lib().fq_block_tail_proj_i8_supported(int(C), int(K3), int(C2), int(CP), int(rs3), int(rs1), int(rsp), int(stride_p)))
+
+
+def block_tail_proj_i8(xq, w3q, qbias3, rs3, ob3, xpq, wpq, qbiasp, rsp, obp, stride_p, want_wide, g_wide, want_narrow, ib, relu,
+                       w1q=None, qbias1=None, rs1=0, relu1=False):
+    """fq_block_tail_proj_i8: fq_block_tail_i8 whose shortcut is the 1x1 projection convolution of xpq (int8 [N,Hp,Wp,CP], weights
+    wpq int8 [K3,1,1,CP], stride stride_p), computed inside the kernel.  Returns (wide, narrow, q1) as block_tail_i8."""
+    for t in (xq, w3q, xpq, wpq):
+        _need_cuda(t, torch.int8, "fq_block_tail_proj_i8")
+    for t in (qbias3, qbiasp):
+        _need_cuda(t, torch.float32, "fq_block_tail_proj_i8")
+    N, H, W, C = xq.shape
+    Np, Hp, Wp, CP = xpq.shape
+    K3 = int(w3q.shape[0])
+    assert tuple(w3q.shape[1:]) == (1, 1, C) and tuple(wpq.shape) == (K3, 1, 1, CP) and Np == N
+    assert xq.is_contiguous() and w3q.is_contiguous() and xpq.is_contiguous() and wpq.is_contiguous()
+    assert qbias3.numel() == K3 and qbiasp.numel() == K3
+    C2 = 0
+    if w1q is not None:
+        _need_cuda(w1q, torch.int8, "fq_block_tail_proj_i8")
+        _need_cuda(qbias1, torch.float32, "fq_block_tail_proj_i8")
+        C2 = int(w1q.shape[0])
+        assert tuple(w1q.shape[1:]) == (1, 1, K3) and w1q.is_contiguous() and qbias1.numel() == C2
+    assert C2 or want_wide or want_narrow
+    wide = torch.empty(N, H, W, K3, dtype=torch.int16, device=xq.device) if want_wide else None
+    narrow = torch.empty(N, H, W, K3, dtype=torch.int8, device=xq.device) if want_narrow else None
+    q1 = torch.empty(N, H, W, C2, dtype=torch.int8, device=xq.device) if C2 else None
+    _check(lib().fq_block_tail_proj_i8(xq.data_ptr(), w3q.data_ptr(), qbias3.contiguous().data_ptr(), int(rs3), int(ob3),
+                                       xpq.data_ptr(), wpq.data_ptr(), qbiasp.contiguous().data_ptr(), int(rsp), int(obp),
+                                       int(stride_p), Hp, Wp, wide.data_ptr() if want_wide else None, int(g_wide),
+                                       narrow.data_ptr() if want_narrow else None, int(ib), 1 if relu else 0,
+                                       w1q.data_ptr() if C2 else None, qbias1.contiguous().data_ptr() if C2 else None, int(rs1),
+                                       1 if relu1 else 0, q1.data_ptr() if C2 else None, N, H, W, C, K3, C2, CP, _stream(xq)),
+           "fq_block_tail_proj_i8")
     _note_variant()
     return wide, narrow, q1
 

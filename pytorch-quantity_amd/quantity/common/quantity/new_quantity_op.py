@@ -364,6 +364,15 @@ def _block_tail_on():
 
 def _newadd_fused_conv_add(self, plan, x, y):
     """conv -> add in one kernel when one operand is a DeferredConv and the other a resident activation."""
+    if type(x) is DeferredConv and type(y) is DeferredConv:
+        fused = _newadd_fused_conv_proj_add(self, plan, x, y)
+        if fused is not None:
+            return fused
+        # (not taken after all: the projection runs as its own launch and the add sees its handle)
+        if plan.fuse_arg == 0:
+            y = y.materialise()
+        else:
+            x = x.materialise()
     d, other = (x, y) if type(x) is DeferredConv else ((y, x) if type(y) is DeferredConv else (None, None))
     if d is None or type(other) is DeferredConv or d._handle is not None:
         return None
@@ -409,6 +418,52 @@ def _newadd_fused_conv_add(self, plan, x, y):
     wide, narrow = _native.conv2d_i8_add_resident(d.xq, d.wq, L.quantized_bias, d.geom[0], d.geom[1], d.geom[2], L.rs_bit,
                                                   L.output_bit, h.exact, h.grid, want_wide, plan.grid, want_narrow,
                                                   plan.narrow_bit if want_narrow else 0, plan.relu)
+    ref = wide if wide is not None else narrow
+    return QHandle((ref.shape[0], L.Conv.out_channels, ref.shape[1], ref.shape[2]), wide, plan.grid, narrow, plan.narrow_bit,
+                   plan.relu)
+
+
+def _newadd_fused_conv_proj_add(self, plan, x, y):
+    """The first block of a stage: conv3 -> add <- projection, (-> the next block's conv1), in ONE kernel (fq_block_tail_proj_i8)
+    when both operands arrive as DeferredConvs and the plan says so; None otherwise."""
+    if not plan.fuse_proj or plan.fuse_arg is None or plan.emit_f32 or not _block_tail_on():
+        return None
+    d, dp = (x, y) if plan.fuse_arg == 0 else (y, x)
+    if d._handle is not None or dp._handle is not None:
+        return None
+    L, P = d.layer, dp.layer
+    one = lambda dd: tuple(tuple(int(v) for v in g) for g in dd.geom[1:]) == ((0, 0), (1, 1)) and tuple(dd.wq.shape[1:3]) == (1, 1)
+    sp = tuple(int(v) for v in dp.geom[0])
+    if (not one(d) or not one(dp) or tuple(int(v) for v in d.geom[0]) != (1, 1) or sp[0] != sp[1]
+            or max(0, L.output_bit, P.output_bit) != plan.grid or d.xq.shape[0] != dp.xq.shape[0]
+            or (dp.xq.shape[1] - 1) // sp[0] + 1 != d.xq.shape[1] or (dp.xq.shape[2] - 1) // sp[0] + 1 != d.xq.shape[2]
+            or L.Conv.out_channels != d.wq.shape[0] or P.Conv.out_channels != dp.wq.shape[0] or d.wq.shape[0] != dp.wq.shape[0]):
+        return None
+    want_narrow = plan.emit_int and plan.narrow_bit is not None
+    want_wide = plan.want_wide or not want_narrow
+    nxt = plan.fuse_next
+    np_ = nxt.__dict__.get("_resident") if nxt is not None else None
+    if nxt is not None and (np_ is None or not want_narrow or not want_wide):
+        return None
+    w1 = nxt._packed_weight(nxt.Conv) if nxt is not None else None
+    if w1 is not None and w1.shape[-1] != L.Conv.out_channels:
+        return None
+    if not _native.block_tail_proj_supported(d.xq.shape[-1], L.Conv.out_channels, nxt.Conv.out_channels if nxt is not None else 0,
+                                             dp.xq.shape[-1], L.rs_bit, nxt.rs_bit if nxt is not None else 0, P.rs_bit, sp[0]):
+        return None
+    if nxt is not None:
+        wide, narrow, q1 = _native.block_tail_proj_i8(d.xq, d.wq, L.quantized_bias, L.rs_bit, L.output_bit, dp.xq, dp.wq,
+                                                      P.quantized_bias, P.rs_bit, P.output_bit, sp[0], True, plan.grid,
+                                                      plan.narrow_to_hbm, plan.narrow_bit, plan.relu, w1, nxt.quantized_bias,
+                                                      nxt.rs_bit, np_.relu)
+        out = QHandle((wide.shape[0], L.Conv.out_channels, wide.shape[1], wide.shape[2]), wide, plan.grid, narrow, plan.narrow_bit,
+                      plan.relu)
+        out.next_out = (nxt, QHandle((q1.shape[0], nxt.Conv.out_channels, q1.shape[1], q1.shape[2]), q1, nxt.output_bit, q1,
+                                     nxt.output_bit, np_.relu))
+        return out
+    wide, narrow, _ = _native.block_tail_proj_i8(d.xq, d.wq, L.quantized_bias, L.rs_bit, L.output_bit, dp.xq, dp.wq, P.quantized_bias,
+                                                 P.rs_bit, P.output_bit, sp[0], want_wide, plan.grid, want_narrow,
+                                                 plan.narrow_bit if want_narrow else 0, plan.relu)
     ref = wide if wide is not None else narrow
     return QHandle((ref.shape[0], L.Conv.out_channels, ref.shape[1], ref.shape[2]), wide, plan.grid, narrow, plan.narrow_bit,
                    plan.relu)

@@ -86,6 +86,12 @@ def block_tail_enabled():
     return os.environ.get("FQ_BLOCK_TAIL", "1") != "0"
 
 
+def block_tail_proj_enabled():
+    """FQ_BLOCK_TAIL_PROJ=0: a stage's first block keeps its projection shortcut as a launch of its own (A/B timing)."""
+    import os
+    return os.environ.get("FQ_BLOCK_TAIL_PROJ", "1") != "0"
+
+
 def resident_of(x):
     """The integer form of an activation, if it has one (a handle, or an fp32 tensor carrying one)."""
     if type(x) is QHandle:
@@ -102,7 +108,7 @@ def as_f32(x):
 class Plan(object):
     """What one producer emits.  Plain data (pickles with the module)."""
     __slots__ = ("relu", "emit_f32", "emit_int", "narrow_bit", "want_wide", "grid", "resident_add", "defer", "fuse_arg",
-                 "fuse_next", "narrow_to_hbm")
+                 "fuse_next", "narrow_to_hbm", "fuse_proj")
 
     def __init__(self):
         self.relu = False            # the nn.ReLU that consumes this output is fused
@@ -116,6 +122,7 @@ class Plan(object):
         self.fuse_arg = None         # NewAdd: operand position (0 / 1) that arrives as a DeferredConv
         self.fuse_next = None        # NewAdd: the 1x1 NewConv2d consuming this sum that runs inside the add's kernel too
         self.narrow_to_hbm = True    # NewAdd with fuse_next: somebody besides that convolution reads the int8 re-quantisation
+        self.fuse_proj = False       # NewAdd with fuse_arg: the OTHER operand is a deferred 1x1 projection that the kernel computes too
 
     def __getstate__(self):
         return {k: getattr(self, k) for k in self.__slots__}
@@ -500,6 +507,33 @@ def enable(model, example_input, verify=True):
             plan.fuse_next = nxt
             plan.narrow_to_hbm = len(readers) > 1
             summary["fused_block_tails"] += 1
+    # ... and when the OTHER operand of such an add is a 1x1 projection of the block's input that nobody else reads (the first
+    # block of a stage), the kernel computes that convolution as well (fq_block_tail_proj_i8): its K3 bytes per pixel are neither
+    # written nor read back
+    summary["fused_projections"] = 0
+    for add_mod in add_resident:
+        plan = add_mod.__dict__.get("_resident")
+        if plan is None or plan.fuse_arg is None or plan.emit_f32 or not block_tail_enabled() or not block_tail_proj_enabled():
+            continue
+        ops = operands[add_mod]
+        v3, vp = ops[plan.fuse_arg], ops[1 - plan.fuse_arg]
+        conv3, proj = v3.producer, vp.producer
+        pp = proj.__dict__.get("_resident") if isinstance(proj, NewConv2d) else None
+        if (vp.kind != "contraction" or pp is None or pp.relu or pp.emit_f32 or pp.defer or vp.foreign
+                or vp.consumers != [(add_mod, 1 - plan.fuse_arg)] or not conv_can_read(proj) or tracer.calls.get(proj, 0) != 1):
+            continue
+        k3, kp = conv3.Conv, proj.Conv
+        nxt = plan.fuse_next
+        if (tuple(kp.kernel_size) != (1, 1) or tuple(kp.padding) != (0, 0) or kp.stride[0] != kp.stride[1]
+                or tuple(k3.kernel_size) != (1, 1) or tuple(k3.stride) != (1, 1) or tuple(k3.padding) != (0, 0)
+                or kp.out_channels != k3.out_channels or (kp.out_channels % 16) or (kp.in_channels % 16)
+                or not _native.block_tail_proj_supported(k3.in_channels, k3.out_channels, nxt.Conv.out_channels if nxt is not None else 0,
+                                                         kp.in_channels, conv3.rs_bit, nxt.rs_bit if nxt is not None else 0,
+                                                         proj.rs_bit, kp.stride[0])):
+            continue
+        pp.defer = True
+        plan.fuse_proj = True
+        summary["fused_projections"] += 1
     for m in tracer.avgpool_shapes:
         if avg_can_read(m):
             m.__dict__["forward"] = _AvgPoolResident(m)

@@ -25,7 +25,7 @@ sys.stdout = out
 x = data[0][0]
 resident.enable(net, x)
 
-names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8", "block_tail_i8")
+names = ("conv2d_i8_resident", "conv2d_i8_add_resident", "conv2d_i8_stem", "conv2d_i8", "block_tail_i8", "block_tail_proj_i8")
 saved = {n: getattr(_native, n) for n in names}
 rows, events = [], []
 
@@ -44,11 +44,17 @@ def timed(fn, name):
         pixels = first.numel() // first.shape[1 if first.dtype == torch.float32 else -1]
         wq = a[1]
         w_next = (a[12] if len(a) > 12 else k.get("w1q")) if name == "block_tail_i8" else None      # the fused next conv1
+        w_proj = None
+        if name == "block_tail_proj_i8":                      # the projection shortcut computed in the kernel: its input and weights
+            res, w_proj = a[5], a[6]
+            w_next = a[16] if len(a) > 16 else k.get("w1q")
         events.append((e0, e1))
-        label = name.replace("conv2d_i8_", "") if name != "block_tail_i8" else ("tail+conv1" if w_next is not None else "block_tail")
+        label = (name.replace("conv2d_i8_", "") if not name.startswith("block_tail")
+                 else ("proj+" if w_proj is not None else "") + ("tail+conv1" if w_next is not None else "block_tail"))
         wshape = tuple(wq.shape) if w_next is None else tuple(wq.shape[:1]) + (int(w_next.shape[0]),) + tuple(wq.shape[3:])
-        rows.append((label, tuple(a[0].shape), wshape, pixels, pixels * (int(wq.numel()) + (int(w_next.numel()) if w_next is not None else 0)),
-                     nbytes(a[0], a[1], res, w_next, *outs)))
+        rows.append((label, tuple(a[0].shape), wshape, pixels,
+                     pixels * (int(wq.numel()) + (int(w_next.numel()) if w_next is not None else 0) + (int(w_proj.numel()) if w_proj is not None else 0)),
+                     nbytes(a[0], a[1], res, w_next, w_proj, *outs)))
         return r
     return wrapper
 
@@ -65,13 +71,13 @@ for n in names:
     setattr(_native, n, saved[n])
 per = [a.elapsed_time(b) * 1e3 for a, b in events]
 L = len(rows) // FWD
-print("%-3s %-13s %-22s %-20s %9s %8s %8s %8s %8s" % ("#", "call", "x", "w", "us", "TOP/s", "GB/s", "mfma us", "hbm us"))
+print("%-3s %-15s %-22s %-20s %9s %8s %8s %8s %8s" % ("#", "call", "x", "w", "us", "TOP/s", "GB/s", "mfma us", "hbm us"))
 tot = tb = 0.0
 for i in range(L):
     name, xs, ws, pixels, macs, nb = rows[i]
     us = statistics.median(per[i + f * L] for f in range(FWD))
     t_m, t_h = 2.0 * macs / 5.0e15 * 1e6, nb / 8.0e12 * 1e6
     tot += us; tb += max(t_m, t_h)
-    print("%-3d %-13s %-22s %-20s %9.1f %8.1f %8.0f %8.1f %8.1f" % (i, name, "x".join(map(str, xs)), "x".join(map(str, ws)), us,
+    print("%-3d %-15s %-22s %-20s %9.1f %8.1f %8.0f %8.1f %8.1f" % (i, name, "x".join(map(str, xs)), "x".join(map(str, ws)), us,
                                                                    2.0 * macs / us / 1e6, nb / us / 1e3, t_m, t_h))
 print("one forward of %d images: %d launches, %.3f ms; semantic bound %.3f ms; fraction %.3f" % (B, L, tot / 1e3, tb / 1e3, tb / tot))

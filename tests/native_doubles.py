@@ -140,6 +140,13 @@ def block_tail_i8(xq, w3q, qbias3, rs3, ob3, res, g_res, want_wide, g_wide, want
     return wide, (narrow if want_narrow else None), q1
 
 
+def block_tail_proj_i8(xq, w3q, qbias3, rs3, ob3, xpq, wpq, qbiasp, rsp, obp, stride_p, want_wide, g_wide, want_narrow, ib, relu,
+                       w1q=None, qbias1=None, rs1=0, relu1=False):
+    """The tail of a stage's first block: the projection shortcut as its own convolution, then block_tail_i8 on its output."""
+    _, res = conv2d_i8_resident(xpq, wpq, qbiasp, (stride_p, stride_p), (0, 0), (1, 1), rsp, obp, False, True, False)
+    return block_tail_i8(xq, w3q, qbias3, rs3, ob3, res, obp, want_wide, g_wide, want_narrow, ib, relu, w1q, qbias1, rs1, relu1)
+
+
 def dequant_nhwc_to_nchw(q, g, channels):
     return torch.from_numpy(np.ascontiguousarray(np.moveaxis(_deq(q, g, channels), -1, 1)))
 
@@ -166,6 +173,7 @@ def quantity(x, ib, bitwidth=8, out=None):
 _DOUBLES = dict(quantize_i8_nhwc=quantize_i8_nhwc, quantize_i8_unfold_w=quantize_i8_unfold_w, conv2d_i8=conv2d_i8,
                 conv2d_i8_resident=conv2d_i8_resident, conv2d_i8_stem=conv2d_i8_stem,
                 conv2d_i8_add_resident=conv2d_i8_add_resident, add_resident=add_resident, block_tail_i8=block_tail_i8,
+                block_tail_proj_i8=block_tail_proj_i8,
                 dequant_nhwc_to_nchw=dequant_nhwc_to_nchw, maxpool_i8_nhwc=maxpool_i8_nhwc, avgpool_global_nhwc=avgpool_global_nhwc,
                 add_sat=add_sat, quantity=quantity)
 

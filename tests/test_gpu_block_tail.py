@@ -93,6 +93,67 @@ def test_block_tail_equals_the_two_launches_it_replaces(nat, case):
         assert int((got[2] != 0).sum()) > 0                       # (not a vacuous comparison)
 
 
+PROJ_CASES = [
+    # N, H, W (of the block's output), stride of the projection, K3, C2, (ob3, obp, ib), rs3, rsp, rs1, relu, want_wide, want_narrow
+    (2, 12, 12, 1, 256, 64, (4, 4, 4), 9, 8, 10, True, True, False),       # ResNet-50 stage 1, block 0
+    (3, 9, 7, 1, 256, 64, (4, 5, 3), 9, 9, 10, True, True, True),          # 189 pixels: a ragged tile; different grids
+    (2, 7, 5, 2, 256, 64, (3, 5, 4), 8, 10, 9, True, True, True),          # stride 2: the shortcut reads every other pixel of a 13 x 9 plane
+    (1, 6, 6, 2, 384, 0, (5, 5, 5), 9, 9, 0, False, True, True),           # no next conv1, no ReLU, 32-bit form of the add, 12 x 11 plane
+    (2, 10, 10, 1, 128, 0, (4, 5, 4), 9, 9, 0, True, False, True),         # one slice, narrow only
+    (9, 56, 56, 1, 256, 64, (4, 4, 4), 9, 9, 10, True, True, False),       # 221 tiles
+    (1, 1, 1, 1, 128, 64, (4, 5, 4), 9, 10, 10, True, True, True),         # one pixel
+]
+
+
+@pytest.mark.parametrize("case", PROJ_CASES, ids=lambda c: "%dx%dx%d_s%d_to%dto%d" % (c[0], c[1], c[2], c[3], c[4], c[5]))
+def test_block_tail_with_the_projection_inside_equals_the_launches_it_replaces(nat, case):
+    """fq_block_tail_proj_i8 (the tail of a stage's FIRST block: conv3 + NewAdd + ReLU + the next conv1, with the projection
+    shortcut -- a 1x1 NewConv2d of the block's input, stride 1 or 2 -- computed in the kernel) against fq_conv2d_i8_resident for
+    the projection followed by fq_block_tail_i8 on its output, and against the general kernels' chain: every output bit for bit."""
+    N, H, W, sp, K3, C2, (ob3, obp, ib), rs3, rsp, rs1, relu, want_wide, want_narrow = case
+    C = CP = 64
+    x, w3, b3, _res, w1, b1 = _operands(nat, N, H, W, C, K3, C2, torch.int8, seed=N * 100 + K3 + C2 + sp)
+    g = torch.Generator(device="cuda").manual_seed(N * 7 + K3 + sp)
+    Hp, Wp = (H - 1) * sp + 1 + (sp - 1) * (N % 2), (W - 1) * sp + 1                 # (an even plane too: its last row is never read)
+    xp = torch.randint(-128, 128, (N, Hp, Wp, CP), dtype=torch.int8, device="cuda", generator=g)
+    wp = nat.pack_weight_krsc(torch.randint(-127, 128, (K3, CP, 1, 1), device="cuda", generator=g).float())
+    bp = torch.randint(-100, 101, (K3,), device="cuda", generator=g).float()
+    g_wide = max(0, ob3, obp)
+    assert nat.block_tail_proj_supported(C, K3, C2, CP, rs3, rs1, rsp, sp)
+    _, res = nat.conv2d_i8_resident(xp, wp, bp, (sp, sp), (0, 0), (1, 1), rsp, obp, False, True, False)
+    assert tuple(res.shape) == (N, H, W, K3)
+    ref = nat.block_tail_i8(x, w3, b3, rs3, ob3, res, obp, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1, True)
+    ref2 = _two_launches(nat, x, w3, b3, rs3, ob3, res, obp, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1, True)
+    nat.conv_variant_log = log = {}
+    try:
+        got = nat.block_tail_proj_i8(x, w3, b3, rs3, ob3, xp, wp, bp, rsp, obp, sp, want_wide, g_wide, want_narrow, ib, relu, w1, b1, rs1,
+                                     True)
+    finally:
+        nat.conv_variant_log = None
+    assert log == {"block_tail_proj/128": 1}
+    for name, a, b, c in zip(("wide", "narrow", "q1"), got, ref, ref2):
+        assert (a is None) == (b is None), name
+        if a is not None:
+            assert torch.equal(a, b) and torch.equal(a, c), "%s differs in %d of %d" % (name, int((a != b).sum()), a.numel())
+    assert int((res != 0).sum()) > res.numel() // 2                              # (the shortcut is not vacuous)
+
+
+def test_block_tail_proj_argument_errors(nat):
+    L = nat.lib()
+    assert L.fq_block_tail_proj_i8_supported(64, 256, 64, 64, 9, 10, 9, 1) == 1 and L.fq_block_tail_proj_i8_supported(64, 256, 0, 64, 9, 0, 9, 2) == 1
+    assert L.fq_block_tail_proj_i8_supported(128, 512, 128, 256, 9, 10, 9, 2) == 0       # deeper stages keep the projection's own launch
+    assert L.fq_block_tail_proj_i8_supported(64, 256, 64, 64, 9, 10, 0, 1) == 0          # no integer tail for the projection
+    assert L.fq_block_tail_proj_i8_supported(64, 256, 64, 64, 9, 10, 9, 3) == 0
+    x = torch.zeros(4096, dtype=torch.int8, device="cuda")
+    P = x.data_ptr()
+    call = lambda *a: L.fq_block_tail_proj_i8(*a)
+    # plane sizes that are not the 1x1 convolution's: (Hp - 1) / stride + 1 != H
+    assert call(P, P, P, 9, 4, P, P, P, 9, 4, 2, 9, 9, P, 4, None, 4, 1, None, None, 0, 0, None, 1, 4, 4, 64, 256, 0, 64, None) == -1
+    assert call(P, P, P, 9, 4, None, P, P, 9, 4, 1, 4, 4, P, 4, None, 4, 1, None, None, 0, 0, None, 1, 4, 4, 64, 256, 0, 64, None) == -1
+    assert call(P, P, P, 9, 4, P, P, P, 9, 4, 1, 4, 4, P, 4, None, 4, 1, None, None, 0, 0, None, 1, 4, 4, 128, 512, 0, 256, None) == -4
+    assert call(P, P, P, 9, 4, P, P, P, 9, 4, 1, 4, 4, P, 4, None, 4, 1, None, None, 0, 0, None, 0, 4, 4, 64, 256, 0, 64, None) == 0   # no images
+
+
 def test_block_tail_against_the_oracle_chain(nat, oracle):
     """The same chain through the CPU oracle's element-wise ops on the exact integer convolution (no GPU kernel involved in the
     expected values): conv -> RightShift -> + bias -> Sp -> DeQuantity | add | clamp | ReLU | Quantity -> conv -> tail -> ReLU."""

@@ -73,7 +73,7 @@ def test_plan_of_a_mini_resnet_and_bit_identical_outputs():
             plain = net(x)
         summary = resident.enable(net, x)                      # verify=True: compares with the traced forward itself
         assert summary == {"resident_convs": 8, "resident_adds": 2, "resident_pools": 2, "fused_relus": 7, "fp32_outputs": 0,
-                           "int_only_outputs": 11, "fused_conv_adds": 2, "fused_block_tails": 0}, summary   # (16 / 32 channels: too thin)
+                           "int_only_outputs": 11, "fused_conv_adds": 2, "fused_block_tails": 0, "fused_projections": 0}, summary   # (16 / 32 channels: too thin)
         plans = resident.describe(net)
         assert plans["conv1"].relu and plans["conv1"].emit_int and not plans["conv1"].emit_f32          # stem -> int8 max-pool
         assert plans["maxpool"].emit_int and not plans["maxpool"].emit_f32 and plans["maxpool"].narrow_bit == 4
@@ -125,15 +125,17 @@ def test_block_tail_plan_runs_the_next_conv1_inside_the_add():
     """Two bottlenecks at ResNet-50's first-stage widths (64 -> 256): block 1's conv3 is deferred into its NewAdd, and that add's
     re-quantised sum feeds block 2's conv1 and nothing else -- so the add also runs THAT convolution (fq_block_tail_i8,
     Plan.fuse_next) and the int8 sum is not written; block 1's own conv1 / projection read the stem's int8 output (two readers:
-    no fusion there).  Same outputs, bit for bit; the plan survives pickling; FQ_BLOCK_TAIL=0 keeps the two launches."""
+    no fusion there).  Block 1's shortcut is a 1x1 projection of the block's input that only the add reads: it is deferred as well
+    and the same kernel computes it (fq_block_tail_proj_i8, Plan.fuse_proj) -- no launch, no tensor.  Same outputs, bit for bit;
+    the plan survives pickling; FQ_BLOCK_TAIL=0 keeps the two launches, FQ_BLOCK_TAIL_PROJ=0 the projection's own."""
     from common.quantity import resident
     with native_doubles.installed() as nat:
         net = _WideNet().eval()
         x = torch.randn(1, 3, 4, 4)
         with torch.no_grad():
             plain = net(x)
-        calls = {"bt": 0, "add": 0}
-        real_bt, real_add = nat.block_tail_i8, nat.conv2d_i8_add_resident
+        calls = {"bt": 0, "add": 0, "proj": 0, "conv": 0}
+        real_bt, real_add, real_proj, real_conv = nat.block_tail_i8, nat.conv2d_i8_add_resident, nat.block_tail_proj_i8, nat.conv2d_i8_resident
 
         def bt(*a, **k):
             calls["bt"] += 1
@@ -142,19 +144,31 @@ def test_block_tail_plan_runs_the_next_conv1_inside_the_add():
         def add(*a, **k):
             calls["add"] += 1
             return real_add(*a, **k)
-        nat.block_tail_i8, nat.conv2d_i8_add_resident = bt, add
+
+        def proj(*a, **k):
+            calls["proj"] += 1
+            return real_proj(*a, **k)
+
+        def conv(*a, **k):
+            calls["conv"] += 1
+            return real_conv(*a, **k)
+        nat.block_tail_i8, nat.conv2d_i8_add_resident, nat.block_tail_proj_i8, nat.conv2d_i8_resident = bt, add, proj, conv
         try:
             summary = resident.enable(net, x)
-            assert summary["fused_conv_adds"] == 3 and summary["fused_block_tails"] == 2, summary
+            assert summary["fused_conv_adds"] == 3 and summary["fused_block_tails"] == 2 and summary["fused_projections"] == 1, summary
             plans = resident.describe(net)
             assert plans["block1.Eltwise"].fuse_next is net.block2.conv1 and not plans["block1.Eltwise"].narrow_to_hbm
-            assert plans["block2.Eltwise"].fuse_next is net.block3.conv1
+            assert plans["block1.Eltwise"].fuse_proj and plans["block1.downsample.0"].defer and plans["block1.conv3"].defer
+            assert plans["block2.Eltwise"].fuse_next is net.block3.conv1 and not plans["block2.Eltwise"].fuse_proj
             assert plans["block3.Eltwise"].fuse_next is None                 # its sum goes to the average pool
-            calls["bt"] = calls["add"] = 0
+            for k in calls:
+                calls[k] = 0
             with torch.no_grad():
                 assert torch.equal(net(x), plain)
-            # blocks 1 and 2 run their tails AND the next conv1 through fq_block_tail_i8, block 3 its tail alone (same kernel)
-            assert calls["bt"] == 3 and calls["add"] == 0
+            # block 1: tail + projection + the next conv1 in one launch; block 2: tail + the next conv1; block 3: its tail alone.
+            # Launches of their own: the stem's ... no: conv1 (folded stem) is not conv2d_i8_resident; block 1's conv1 and conv2,
+            # conv2 of blocks 2 and 3 -- four; neither projection nor conv3 nor a fused conv1 among them
+            assert calls == {"bt": 2, "add": 0, "proj": 1, "conv": 4}, calls
             with torch.no_grad():
                 mid = net.block1(net.relu(net.conv1(x)))
             assert type(mid).__name__ == "QHandle" and mid.narrow is None and mid.next_out[0] is net.block2.conv1
@@ -162,7 +176,7 @@ def test_block_tail_plan_runs_the_next_conv1_inside_the_add():
             with torch.no_grad():
                 assert torch.equal(again(x), plain)
         finally:
-            nat.block_tail_i8, nat.conv2d_i8_add_resident = real_bt, real_add
+            nat.block_tail_i8, nat.conv2d_i8_add_resident, nat.block_tail_proj_i8, nat.conv2d_i8_resident = real_bt, real_add, real_proj, real_conv
 
 
 def test_block_tail_can_be_switched_off(monkeypatch):
@@ -171,6 +185,24 @@ def test_block_tail_can_be_switched_off(monkeypatch):
     with native_doubles.installed():
         net = _mini_resnet()
         assert resident.enable(net, torch.randn(1, 3, 8, 8))["fused_block_tails"] == 0
+        wide = _WideNet().eval()
+        summary = resident.enable(wide, torch.randn(1, 3, 4, 4))
+        assert summary["fused_block_tails"] == 0 and summary["fused_projections"] == 0
+
+
+def test_projection_fusion_can_be_switched_off(monkeypatch):
+    from common.quantity import resident
+    monkeypatch.setenv("FQ_BLOCK_TAIL_PROJ", "0")
+    with native_doubles.installed():
+        net = _WideNet().eval()
+        x = torch.randn(1, 3, 4, 4)
+        with torch.no_grad():
+            plain = net(x)
+        summary = resident.enable(net, x)
+        assert summary["fused_block_tails"] == 2 and summary["fused_projections"] == 0
+        assert not resident.describe(net)["block1.downsample.0"].defer
+        with torch.no_grad():
+            assert torch.equal(net(x), plain)
 
 
 def test_values_with_foreign_consumers_keep_their_fp32_form():
