@@ -62,6 +62,29 @@ template <int RB> __device__ __forceinline__ int swz_of(int row) {
     return RB == 256 ? row & 15 : (RB == 128 ? (row >> 1) & 7 : (row >> 2) & 3);
 }
 
+// The four-instruction tail (fq_int_tail.h) of four consecutive channels: their constants are three 16-byte LDS reads (G = 4), or
+// two rounds of three 8-byte reads (G = 2) where twelve constant registers at a time are more than the kernel has left
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+template <int G, int N>
+__device__ __forceinline__ void tail4(int (&v)[4], int a0, int a1, int a2, int a3, const int (&t)[3][N], int ch, int rs) {
+    const int acc[4] = {a0, a1, a2, a3};
+    if constexpr (G == 4) {
+        const v4i cB = *reinterpret_cast<const v4i*>(&t[0][ch]), cL = *reinterpret_cast<const v4i*>(&t[1][ch]),
+                  cH = *reinterpret_cast<const v4i*>(&t[2][ch]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = conv_tail_k(acc[e], cB[e], cL[e], cH[e], rs);
+    } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const v2i_t cB = *reinterpret_cast<const v2i_t*>(&t[0][ch + 2 * h]), cL = *reinterpret_cast<const v2i_t*>(&t[1][ch + 2 * h]),
+                        cH = *reinterpret_cast<const v2i_t*>(&t[2][ch + 2 * h]);
+            v[2 * h] = conv_tail_k(acc[2 * h], cB[0], cL[0], cH[0], rs);
+            v[2 * h + 1] = conv_tail_k(acc[2 * h + 1], cB[1], cL[1], cH[1], rs);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // C: conv3's input channels (64 / 128).  C2: the fused next conv1's output channels (64 / 128; 0: no next conv -- the kernel is
 // then conv3 + NewAdd alone, in the barrier-free form).  kRes16: the shortcut is int16 (a previous sum) or int8 (a projection).
 #ifndef FQ_BT_WAVES
@@ -83,16 +106,19 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
     constexpr int W1_LOADS = C2 ? (C2 * 8) / kConvBlock : 1;
     constexpr bool kNext = C2 != 0;
     constexpr bool kProj = CP != 0;
+    constexpr int TG = (C == 128 && C2 == 128 && kRes16) ? 2 : 4;      // (the one variant without twelve registers to spare)
     static_assert(!(kProj && kRes16), "a projection shortcut is int8");
     constexpr int KSP = kProj ? CP / 32 : 1;             // MFMA sub-steps of the projection
     constexpr int WP_LOADS = kProj ? (128 * (CP / 16)) / kConvBlock : 1;
     __shared__ __attribute__((aligned(16))) int8_t sWP[kProj ? 128 * CP : 16];
-    __shared__ int sBiasP[kProj ? 1024 : 1];
+    // per-channel constants of the integer tails (fq_int_tail.h, tail_consts): [0] rounding constant with the bias in it, [1] / [2]
+    // the merged clamp's bounds -- four consecutive channels of one kind are one 16-byte read
+    __shared__ __attribute__((aligned(16))) int sTP[kProj ? 3 : 1][kProj ? 1024 : 4];
     __shared__ __attribute__((aligned(16))) int8_t sW3[128 * C];
     __shared__ __attribute__((aligned(16))) int8_t sW1[kNext ? C2 * 128 : 16];
     __shared__ __attribute__((aligned(16))) int8_t sN[kTP * 128];
-    __shared__ int sBias3[1024];
-    __shared__ int sBias1[kNext ? C2 : 1];
+    __shared__ __attribute__((aligned(16))) int sT3[3][1024];
+    __shared__ __attribute__((aligned(16))) int sT1[3][kNext ? C2 : 4];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -100,11 +126,20 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
     const int m0 = blockIdx.x * kTP;
     const int KT = p.K3 >> 7;
 
-    for (int i = tid; i < p.K3; i += kConvBlock) sBias3[i] = (int)qbias3[i];          // integer valued by contract
-    if constexpr (kProj) {
-        for (int i = tid; i < p.K3; i += kConvBlock) sBiasP[i] = (int)p.qbiasp[i];
+    for (int i = tid; i < p.K3; i += kConvBlock) {
+        const TailK k = tail_consts((int)qbias3[i], p.t3);                           // (biases are integer valued by contract)
+        sT3[0][i] = k.B; sT3[1][i] = k.lo; sT3[2][i] = k.hi;
     }
-    if (kNext && tid < C2) sBias1[tid] = (int)qbias1[tid];
+    if constexpr (kProj) {
+        for (int i = tid; i < p.K3; i += kConvBlock) {
+            const TailK k = tail_consts((int)p.qbiasp[i], p.tp);
+            sTP[0][i] = k.B; sTP[1][i] = k.lo; sTP[2][i] = k.hi;
+        }
+    }
+    if (kNext && tid < C2) {
+        const TailK k = tail_consts((int)qbias1[tid], p.t1);
+        sT1[0][tid] = k.B; sT1[1][tid] = k.lo; sT1[2][tid] = k.hi;
+    }
 
     // ---- x: this lane's pixel, 16 bytes per sub-step, for the whole tile's life
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(x), 0, p.x_bytes, 0x00020000);
@@ -257,12 +292,8 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         int v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int kl = (2 * hs + a) * 32 + e + 8 * g + 4 * half;
-                            v[e] = conv_tail_i(acc[a][4 * g + e], sBiasP[k0 + kl], p.tp);
-                        }
-                        const int byte = (2 * hs + a) * 32 + 8 * g + 4 * half;
+                        const int byte = (2 * hs + a) * 32 + 8 * g + 4 * half;          // first of this lane's four channels
+                        tail4<TG>(v, acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3], sTP, k0 + byte, p.tp.rs);
                         *reinterpret_cast<unsigned*>(my_row + (((byte >> 4) ^ my_swz) * 16) + (byte & 15)) = pack4(v[0], v[1], v[2], v[3]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -310,12 +341,8 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     int v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int kl = (PT * hs + a) * 32 + e + 8 * g + 4 * half;
-                        v[e] = conv_tail_i(acc[a][4 * g + e], sBias3[k0 + kl], p.t3);
-                    }
                     const int byte = (PT * hs + a) * 32 + 8 * g + 4 * half;          // channel of v[0] inside the slice
+                    tail4<TG>(v, acc[a][4 * g], acc[a][4 * g + 1], acc[a][4 * g + 2], acc[a][4 * g + 3], sT3, k0 + byte, p.t3.rs);
                     *reinterpret_cast<unsigned*>(my_row + (((byte >> 4) ^ my_swz) * 16) + (byte & 15)) = pack4(v[0], v[1], v[2], v[3]);
                     __builtin_amdgcn_sched_barrier(0);        // four values at a time: left alone the scheduler runs all 32 tails abreast
                 }
@@ -378,12 +405,8 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(FQ_B
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 int v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kl = a * 32 + e + 8 * g + 4 * half;
-                    v[e] = conv_tail_i(acc1[a][4 * g + e], sBias1[kl], p.t1);
-                }
                 const int byte = a * 32 + 8 * g + 4 * half;
+                tail4<4>(v, acc1[a][4 * g], acc1[a][4 * g + 1], acc1[a][4 * g + 2], acc1[a][4 * g + 3], sT1, byte, p.t1.rs);
                 *reinterpret_cast<unsigned*>(my_row + (((byte >> 4) ^ my_swz) * 16) + (byte & 15)) = pack4(v[0], v[1], v[2], v[3]);
             }
         }

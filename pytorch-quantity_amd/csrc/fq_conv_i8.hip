@@ -135,7 +135,8 @@ __device__ __forceinline__ void load_residual(ResRegs<TK>& r, const ConvParams& 
 
 template <int TK, int kOut, bool kIntTail, bool kStageAliased = true>
 __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvParams& p, float* __restrict__ y,
-                                              int8_t* __restrict__ q, int8_t* sO, const float* sBias, const int* sBiasI, int m0,
+                                              int8_t* __restrict__ q, int8_t* sO, const float* sBias, const int* sBiasI,
+                                              const int (&sLH)[2][TK], int m0,
                                               int k0, int n_img, int pq, bool m_ok, ResRegs<TK>& res, int tid_base = 0) {
     constexpr int MT = TK / 32;
     // (tid_base: a 512-thread workgroup runs this once per 256-thread half, each on its own 128-pixel tile and its own sO)
@@ -153,7 +154,8 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
             for (int r = 0; r < 16; ++r) {
                 const int kl = a * 32 + (r & 3) + 8 * (r >> 2);          // compile-time constant
                 if (kl < kmax)
-                    out[(unsigned)(kl * PQ)] = kIntTail ? (float)conv_tail_i(acc[a][r], sBiasI[kl + 4 * half], p) * p.inv_ob
+                    out[(unsigned)(kl * PQ)] = kIntTail ? (float)conv_tail_k(acc[a][r], sBiasI[kl + 4 * half], sLH[0][kl + 4 * half],
+                                                                             sLH[1][kl + 4 * half], p.rs) * p.inv_ob
                                                         : conv_tail(acc[a][r], sBias[kl + 4 * half], p);
             }
         }
@@ -185,11 +187,17 @@ __device__ __forceinline__ void conv_epilogue(v16i (&acc)[TK / 32], const ConvPa
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 int v[4];
+                if constexpr (kIntTail) {
+                    // the four-instruction tail (fq_int_tail.h): rounding constant with the bias in it + the merged clamp's bounds of
+                    // this lane's four consecutive channels, three 16-byte LDS reads
+                    const int kl = a * 32 + 8 * g + 4 * half;
+                    const v4i cB = *reinterpret_cast<const v4i*>(&sBiasI[kl]), cL = *reinterpret_cast<const v4i*>(&sLH[0][kl]),
+                              cH = *reinterpret_cast<const v4i*>(&sLH[1][kl]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int kl = a * 32 + e + 8 * g + 4 * half;
-                    v[e] = kIntTail ? conv_tail_i(acc[a][4 * g + e], sBiasI[kl], p)
-                                    : (int)conv_tail_int(acc[a][4 * g + e], sBias[kl], p);
+                    for (int e = 0; e < 4; ++e) v[e] = conv_tail_k(acc[a][4 * g + e], cB[e], cL[e], cH[e], p.rs);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = (int)conv_tail_int(acc[a][4 * g + e], sBias[a * 32 + e + 8 * g + 4 * half], p);
                 }
                 *reinterpret_cast<unsigned*>(&sO[prow + a * 32 + 8 * g]) = pack4(v[0], v[1], v[2], v[3]);
                 if (kOut & kOutAdd) __builtin_amdgcn_sched_barrier(0);   // four tails at a time beside the residual registers (fq_block_tail_i8.hip)
@@ -265,7 +273,8 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
     constexpr int A_LOADS = TK / 32;      // 16-byte chunks per thread per K-step for the weight tile
     __shared__ __attribute__((aligned(16))) int8_t sA[2][TK * BKB];
     __shared__ float sBias[TK];
-    __shared__ int sBiasI[TK];
+    __shared__ __attribute__((aligned(16))) int sBiasI[TK];     // (integer tail: the rounding constant with the bias in it, tail_consts)
+    __shared__ __attribute__((aligned(16))) int sLH[2][TK];     //  ... and the merged clamp's bounds
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5;
@@ -277,7 +286,8 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
     if (tid < TK) {                                       // visible after the first barrier
         const float b = (k0 + tid < p.K) ? qbias[k0 + tid] : 0.0f;
         sBias[tid] = b;
-        sBiasI[tid] = (int)b;                             // integer valued by contract
+        const TailK tk = tail_consts((int)b, p);           // (integer valued by contract)
+        sBiasI[tid] = tk.B; sLH[0][tid] = tk.lo; sLH[1][tid] = tk.hi;
     }
 
     // this lane's output pixel
@@ -448,8 +458,8 @@ __global__ __launch_bounds__(kConvBlock) __attribute__((amdgpu_waves_per_eu(TK =
     }
 
     static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the int8 output tile is staged in the weight buffers");
-    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, res);
-    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, res);
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, sLH, m0, k0, n_img, pq, m_ok, res);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, sLH, m0, k0, n_img, pq, m_ok, res);
 }
 
 // ---- C % 128 == 0, K % TK == 0: both operands by LDS-DMA ----------------------------------------------
@@ -490,7 +500,8 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     __shared__ __attribute__((aligned(16))) int8_t sA[STAGES][TK * BKB];
     __shared__ __attribute__((aligned(16))) int8_t sB[STAGES][kTP * BKB];
     __shared__ float sBias[TK];
-    __shared__ int sBiasI[TK];
+    __shared__ __attribute__((aligned(16))) int sBiasI[TK];     // (integer tail: the rounding constant with the bias in it, tail_consts)
+    __shared__ __attribute__((aligned(16))) int sLH[2][TK];     //  ... and the merged clamp's bounds
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: LDS-DMA bases live in SGPRs (M0)
@@ -508,7 +519,8 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
     if (tid < TK) {                                       // visible after the first barrier
         const float b = qbias[k0 + tid];
         sBias[tid] = b;
-        sBiasI[tid] = (int)b;
+        const TailK tk = tail_consts((int)b, p);
+        sBiasI[tid] = tk.B; sLH[0][tid] = tk.lo; sLH[1][tid] = tk.hi;
     }
 
     // output pixel of this lane in MFMA layout (used by the fp32 epilogue)
@@ -672,8 +684,8 @@ __global__ __launch_bounds__(kConvBlock) void conv2d_i8_dma_kernel(const int8_t*
 
     static_assert(kTP * (TK + 16) <= STAGES * TK * BKB, "the int8 output tile is staged in the weight buffers");
     ResRegs<TK> res;
-    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, res);
-    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, m0, k0, n_img, pq, m_ok, res);
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, &sA[0][0], sBias, sBiasI, sLH, m0, k0, n_img, pq, m_ok, res);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, &sA[0][0], sBias, sBiasI, sLH, m0, k0, n_img, pq, m_ok, res);
     TR(4);
 }
 
@@ -713,6 +725,7 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_halo_kernel(const int8_
     int8_t* const sA = smem;
     float* const sBias = reinterpret_cast<float*>(smem + ST * TK * BKB);
     int* const sBiasI = reinterpret_cast<int*>(smem + ST * TK * BKB + TK * 4);
+    __shared__ __attribute__((aligned(16))) int sLH[2][TK];     // the merged clamp's bounds of the integer tail (tail_consts)
     int8_t* const sZero = smem + ST * TK * BKB + TK * 8;
     int8_t* const sSlab = sZero + BKB;
 
@@ -727,7 +740,8 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_halo_kernel(const int8_
     if (tid < TK) {
         const float b = qbias[k0 + tid];
         sBias[tid] = b;
-        sBiasI[tid] = (int)b;
+        const TailK tk = tail_consts((int)b, p);
+        sBiasI[tid] = tk.B; sLH[0][tid] = tk.lo; sLH[1][tid] = tk.hi;
     }
     if (tid < BKB / 4) reinterpret_cast<int*>(sZero)[tid] = 0;
 
@@ -869,8 +883,8 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_halo_kernel(const int8_
     for (int u = 0; u < NP; ++u) {
         if (u) __syncthreads();                               // the epilogue stages its int8 tile in sA: one half after the other
         ResRegs<TK> res;
-        if (p.rs) conv_epilogue<TK, kOut, true>(acc[u], p, y, q, sA, sBias, sBiasI, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u], res);
-        else conv_epilogue<TK, kOut, false>(acc[u], p, y, q, sA, sBias, sBiasI, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u], res);
+        if (p.rs) conv_epilogue<TK, kOut, true>(acc[u], p, y, q, sA, sBias, sBiasI, sLH, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u], res);
+        else conv_epilogue<TK, kOut, false>(acc[u], p, y, q, sA, sBias, sBiasI, sLH, m0 + kTP * u, k0, n_img[u], pq[u], m_ok[u], res);
     }
 }
 
@@ -896,6 +910,7 @@ __global__ __launch_bounds__(2 * kConvBlock) void conv3x3_i8_halo8_kernel(const 
     int8_t* const sA = smem;
     float* const sBias = reinterpret_cast<float*>(smem + ST * TK * BKB);
     int* const sBiasI = reinterpret_cast<int*>(smem + ST * TK * BKB + TK * 4);
+    __shared__ __attribute__((aligned(16))) int sLH[2][TK];     // the merged clamp's bounds of the integer tail (tail_consts)
     int8_t* const sZero = smem + ST * TK * BKB + TK * 8;
     int8_t* const sSlab = sZero + BKB;
 
@@ -911,7 +926,8 @@ __global__ __launch_bounds__(2 * kConvBlock) void conv3x3_i8_halo8_kernel(const 
     if (tid < TK) {
         const float b = qbias[k0 + tid];
         sBias[tid] = b;
-        sBiasI[tid] = (int)b;
+        const TailK tk = tail_consts((int)b, p);
+        sBiasI[tid] = tk.B; sLH[0][tid] = tk.lo; sLH[1][tid] = tk.hi;
     }
     if (tid < BKB / 4) reinterpret_cast<int*>(sZero)[tid] = 0;
 
@@ -1036,8 +1052,8 @@ __global__ __launch_bounds__(2 * kConvBlock) void conv3x3_i8_halo8_kernel(const 
     static_assert(kTP * (TK + 16) <= 2 * TK * BKB, "the first half's int8 tile is staged in the weight buffers");
     int8_t* const sO = u ? sSlab : sA;
     ResRegs<TK> res;
-    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, m0 + kTP * u, k0, n_img, pq, m_ok, res, u * kConvBlock);
-    else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, m0 + kTP * u, k0, n_img, pq, m_ok, res, u * kConvBlock);
+    if (p.rs) conv_epilogue<TK, kOut, true>(acc, p, y, q, sO, sBias, sBiasI, sLH, m0 + kTP * u, k0, n_img, pq, m_ok, res, u * kConvBlock);
+    else conv_epilogue<TK, kOut, false>(acc, p, y, q, sO, sBias, sBiasI, sLH, m0 + kTP * u, k0, n_img, pq, m_ok, res, u * kConvBlock);
 }
 
 // ---- 3 x 3, stride 1, padding 1, C == 64, K <= 64 (the first stage of a ResNet): weights stationary, persistent -------
@@ -1062,6 +1078,7 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
     int8_t* const sW = smem;
     float* const sBias = reinterpret_cast<float*>(smem + 9 * TK * RB);
     int* const sBiasI = reinterpret_cast<int*>(smem + 9 * TK * RB + TK * 4);
+    __shared__ __attribute__((aligned(16))) int sLH[2][TK];     // the merged clamp's bounds of the integer tail (tail_consts)
     int8_t* const sZero = smem + 9 * TK * RB + TK * 8;
     int8_t* const sO = sZero + RB;
     int8_t* const sSlab = sO + kTP * (TK + 16);
@@ -1074,7 +1091,8 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
     if (tid < TK) {
         const float b = tid < p.K ? qbias[tid] : 0.0f;
         sBias[tid] = b;
-        sBiasI[tid] = (int)b;
+        const TailK tk = tail_consts((int)b, p);
+        sBiasI[tid] = tk.B; sLH[0][tid] = tk.lo; sLH[1][tid] = tk.hi;
     }
     if (tid < RB / 4) reinterpret_cast<int*>(sZero)[tid] = 0;
 
@@ -1143,8 +1161,8 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
             }
         }
         ResRegs<TK> res;
-        if (p.rs) conv_epilogue<TK, kOut, true, false>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok, res);
-        else conv_epilogue<TK, kOut, false, false>(acc, p, y, q, sO, sBias, sBiasI, m0, 0, n_img, pq, m_ok, res);
+        if (p.rs) conv_epilogue<TK, kOut, true, false>(acc, p, y, q, sO, sBias, sBiasI, sLH, m0, 0, n_img, pq, m_ok, res);
+        else conv_epilogue<TK, kOut, false, false>(acc, p, y, q, sO, sBias, sBiasI, sLH, m0, 0, n_img, pq, m_ok, res);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the next slab has landed (mine) ...
         __syncthreads();                                      // ... and everybody's; everybody is done with this tile's slab and staging
         buf ^= 1;

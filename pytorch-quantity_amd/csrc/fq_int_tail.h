@@ -37,6 +37,28 @@ __device__ __forceinline__ int conv_tail_i(int acc, int qb, const P& p) {
     return med3_i32(med3_i32(r, p.ilo, p.ihi) + qb, p.slo, p.shi);
 }
 
+// The same tail in FOUR vector instructions, from three per-channel constants instead of one (tail_consts below):
+//   * floor commutes with adding a multiple of 2^rs:  ((acc + half + sign) >> rs) + qb = (acc + half + (qb << rs) + sign) >> rs,
+//     so the bias rides in the rounding constant  B = half_rs + (qb << rs)   (|qb| <= 2^15, rs <= 16: inside int32 with the host's
+//     bound on |acc|);
+//   * a clamp of a clamp is a clamp:  med3(med3(r, ilo, ihi) + qb, slo, shi) = med3(r + qb, lo, hi)  with
+//     lo = med3(ilo + qb, slo, shi), hi = med3(ihi + qb, slo, shi)  (a bias beyond the output range makes lo = hi).
+// Same integer for every acc the six-instruction form is valid for.  Where the tail is what a kernel's vector pipe is busy with
+// (fq_block_tail_i8: two or three tails per output value) the two instructions are time; in the stem they were not.
+struct TailK { int B, lo, hi; };
+template <typename P>
+__device__ __forceinline__ TailK tail_consts(int qb, const P& p) {
+    TailK k;
+    k.B = p.half_rs + (qb << p.rs);
+    const int a = p.ilo + qb, b = p.ihi + qb;
+    k.lo = a < p.slo ? p.slo : (a > p.shi ? p.shi : a);
+    k.hi = b < p.slo ? p.slo : (b > p.shi ? p.shi : b);
+    return k;
+}
+__device__ __forceinline__ int conv_tail_k(int acc, int B, int lo, int hi, int rs) {
+    return med3_i32((acc + B + (acc >> 31)) >> rs, lo, hi);
+}
+
 // bytes 0 of four registers -> one dword
 __device__ __forceinline__ unsigned pack4(int b0, int b1, int b2, int b3) {
     const unsigned p01 = __builtin_amdgcn_perm((unsigned)b1, (unsigned)b0, 0x0c0c0400u);
