@@ -181,6 +181,67 @@ __global__ __launch_bounds__(kResBlock) void maxpool_i8_nhwc_kernel(const int8_t
     }
 }
 
+// The 3x3 / stride 2 / padding 1 pooling of a ResNet stem in its own form (round 5): the generic kernel above makes nine 16-byte
+// loads per output and puts neighbouring output rows on different workgroups, i.e. XCDs with L2s of their own -- every input row
+// that two output rows share came from memory twice (257 MB moved for 256 x 112 x 112 x 64 in 74 us: 3.4 TB/s).  Here a workgroup
+// owns a band of kBand output rows of one image and a thread one (output column, 16-channel group) of it, walking down the band:
+// the horizontal maximum of input row 2p + 1 is kept for output row p + 1, so an output costs six loads, every input row is
+// read by ONE workgroup (the band's first row excepted), and the row loop is unrolled so that a thread has twelve loads in flight.
+// Edges: a window position outside the plane re-reads the nearest row / column inside it (max is idempotent).
+constexpr int kPoolBand = 8;
+
+__device__ __forceinline__ void pool_split(const v4i_r v, unsigned (&ev)[4], unsigned (&od)[4]) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const unsigned u = (unsigned)v[d];
+        ev[d] = (u << 8) & 0xff00ff00u;                   // bytes 0, 2 as the high bytes of two int16
+        od[d] = u & 0xff00ff00u;                          // bytes 1, 3
+    }
+}
+
+// horizontal maximum of the three window columns of one input row, as (even, odd) int16 pairs
+__device__ __forceinline__ void pool_hmax(const int8_t* __restrict__ row, int c0, int c1, int c2, unsigned (&ev)[4], unsigned (&od)[4]) {
+    const v4i_r a = *reinterpret_cast<const v4i_r*>(row + c0), b = *reinterpret_cast<const v4i_r*>(row + c1),
+                c = *reinterpret_cast<const v4i_r*>(row + c2);
+    unsigned e1[4], o1[4], e2[4], o2[4];
+    pool_split(a, ev, od); pool_split(b, e1, o1); pool_split(c, e2, o2);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        ev[d] = pk_max_i16(pk_max_i16(ev[d], e1[d]), e2[d]);
+        od[d] = pk_max_i16(pk_max_i16(od[d], o1[d]), o2[d]);
+    }
+}
+
+__global__ __launch_bounds__(kResBlock) void maxpool3x3s2_i8_nhwc_kernel(const int8_t* __restrict__ x, int8_t* __restrict__ y, int H, int W,
+                                                                         int C16, int P, int Q, int bands) {
+    const int n = blockIdx.x / bands, band = blockIdx.x - n * bands;
+    const int t = threadIdx.x;
+    if (t >= Q * C16) return;
+    const int oq = t / C16, c16 = t - oq * C16;
+    const int rowb = W * C16 * 16;                        // bytes of one input row
+    const int8_t* __restrict__ img = x + (size_t)n * H * rowb + c16 * 16;
+    int8_t* __restrict__ out = y + ((size_t)n * P * Q + oq) * C16 * 16 + c16 * 16;
+    const int iw = 2 * oq - 1;
+    const int c0 = max(iw, 0) * C16 * 16, c1 = (iw + 1) * C16 * 16, c2 = min(iw + 2, W - 1) * C16 * 16;
+    const int p0 = band * kPoolBand, p1 = min(p0 + kPoolBand, P);
+    unsigned pe[4], po[4];                                // horizontal maximum of input row 2 p - 1
+    pool_hmax(img + (size_t)max(2 * p0 - 1, 0) * rowb, c0, c1, c2, pe, po);
+#pragma unroll 2
+    for (int p = p0; p < p1; ++p) {
+        unsigned ae[4], ao[4], be[4], bo[4];
+        pool_hmax(img + (size_t)(2 * p) * rowb, c0, c1, c2, ae, ao);
+        pool_hmax(img + (size_t)min(2 * p + 1, H - 1) * rowb, c0, c1, c2, be, bo);
+        v4i_r o;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const unsigned e = pk_max_i16(pk_max_i16(pe[d], ae[d]), be[d]), od = pk_max_i16(pk_max_i16(po[d], ao[d]), bo[d]);
+            o[d] = (int)(((e >> 8) & 0x00ff00ffu) | (od & 0xff00ff00u));
+            pe[d] = be[d]; po[d] = bo[d];
+        }
+        *reinterpret_cast<v4i_r*>(out + (size_t)p * Q * C16 * 16) = o;
+    }
+}
+
 // Global average pooling (nn.AvgPool2d whose kernel covers the whole plane) on a resident activation:
 //   y[n][c] = (sum_hw q[n][hw][c]) * 2^-g / HW.
 // torch accumulates the window in fp32 and divides once; every partial sum here is an integer multiple of
@@ -215,6 +276,16 @@ extern "C" int fq_maxpool_i8_nhwc(const int8_t* x, int8_t* y, int N, int H, int 
     if (N == 0) return FQ_OK;
     if (!x || !y || ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15u)) return FQ_ERR_INVALID_ARG;
     const size_t total = (size_t)N * P * Q * (Cpad / 16);
+    // FQ_POOL_GENERIC=1: always the generic kernel (A/B timing)
+    static const bool generic = [] { const char* e = getenv("FQ_POOL_GENERIC"); return e && e[0] && e[0] != '0'; }();
+    const long bands = (P + kPoolBand - 1) / kPoolBand;
+    if (!generic && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 && Q * (Cpad / 16) <= kResBlock && H >= 2 && W >= 2 &&
+        (long)N * bands <= 0x7fffffffL && 2 * (P - 1) < H && 2 * (Q - 1) < W) {
+        hipLaunchKernelGGL(maxpool3x3s2_i8_nhwc_kernel, dim3((unsigned)(N * bands)), dim3(kResBlock), 0, as_stream(stream), x, y, H, W,
+                           Cpad / 16, P, Q, (int)bands);
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    }
     hipLaunchKernelGGL(maxpool_i8_nhwc_kernel, dim3(res_grid(total)), dim3(kResBlock), 0, as_stream(stream), x, y, H, W, Cpad / 16, P,
                        Q, kh, kw, sh, sw, ph, pw, total);
     FQ_LAUNCH_CHECK();

@@ -224,7 +224,12 @@ def test_dequant_nhwc_to_nchw(nat, oracle, dtype, g, N, C, H, W):
     np.testing.assert_array_equal(y, ref)
 
 
-@pytest.mark.parametrize("N,C,H,W,k,st,pd", [(2, 64, 17, 17, 3, 2, 1), (1, 20, 9, 12, 2, 2, 0), (3, 16, 8, 8, 3, 1, 1), (2, 48, 7, 7, 5, 3, 2)])
+@pytest.mark.parametrize("N,C,H,W,k,st,pd", [(2, 64, 17, 17, 3, 2, 1), (1, 20, 9, 12, 2, 2, 0), (3, 16, 8, 8, 3, 1, 1), (2, 48, 7, 7, 5, 3, 2),
+                                             # the banded 3x3 / 2 / 1 kernel (one workgroup per 8 output rows of an image): ResNet's
+                                             # stem plane, odd and even planes, a partial last band, one-row and two-pixel planes, a
+                                             # plane too wide for one workgroup (generic kernel)
+                                             (3, 64, 112, 112, 3, 2, 1), (2, 32, 35, 20, 3, 2, 1), (1, 16, 2, 2, 3, 2, 1),
+                                             (2, 48, 3, 9, 3, 2, 1), (1, 256, 40, 40, 3, 2, 1), (1, 64, 30, 200, 3, 2, 1)])
 def test_maxpool_i8_equals_torch_on_the_values(nat, N, C, H, W, k, st, pd):
     """Pooling the integers == quantising torch's max-pool of the de-quantised tensor."""
     rng = np.random.default_rng(C * H)
