@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define FQ_VERSION 102            /* 0.1.2: Winograd and split-bf16 forms of the float convolutions */
+#define FQ_VERSION 103            /* 0.1.3: fq_block_tail_proj_i8; owner flush of per-channel histogram rows */
 #define FQ_BINS 2048              /* INTERVAL_NUM, tools/configs.yml:24 */
 #define FQ_KL_TARGET_BINS 128     /* quantizer.py:98 target_bin */
 #define FQ_KL_CANDIDATES 1920     /* thresholds 128..2047, quantizer.py:103 */

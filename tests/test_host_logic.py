@@ -32,7 +32,7 @@ def test_c_abi_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libfq_hip.so does not export %s" % n
     lib.fq_version.restype = ctypes.c_int
-    assert lib.fq_version() == 102
+    assert lib.fq_version() == 103
 
 
 def test_host_bits_helpers_match_python(oracle):
