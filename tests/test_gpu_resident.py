@@ -244,7 +244,9 @@ def test_maxpool_i8_equals_torch_on_the_values(nat, N, C, H, W, k, st, pd):
     np.testing.assert_array_equal(got.cpu().numpy()[..., :C].astype(np.float32) / 2 ** g, ref.permute(0, 2, 3, 1).cpu().numpy())
 
 
-@pytest.mark.parametrize("dtype,g,N,C,H", [(np.int16, 6, 4, 2048, 7), (np.int8, 3, 2, 100, 4), (np.int16, 0, 3, 64, 16), (np.int16, 8, 2, 48, 13)])
+@pytest.mark.parametrize("dtype,g,N,C,H", [(np.int16, 6, 4, 2048, 7), (np.int8, 3, 2, 100, 4), (np.int16, 0, 3, 64, 16), (np.int16, 8, 2, 48, 13),
+                                           # one phase, 256 groups of 8 channels; more groups than threads (two sweeps); a single group
+                                           (np.int16, 5, 300, 2048, 7), (np.int16, 2, 2, 4000, 3), (np.int8, 4, 3, 8200, 2), (np.int8, 1, 5, 10, 5)])
 def test_avgpool_global_equals_torch_avg_pool2d(nat, dtype, g, N, C, H):
     """Bit-identical to torch's AvgPool2d(H) on the de-quantised fp32 tensor (exact partial sums, one division)."""
     rng = np.random.default_rng(C + H)
