@@ -60,7 +60,8 @@ int fq_last_hip_error(void);      /* thread-local hipError_t of the last FQ_ERR_
  * this thread launched -- low byte: 1 conv3x3_i8_c64 (stationary 64-channel 3x3), 2 conv1x1_i8_stream, 3 conv3x3_i8_halo8
  * (256-pixel tiles, eight waves), 4 conv3x3_i8_halo, 5 / 6 conv2d_i8_dma with a ring of 2 / 3, 7 / 8 / 9 conv2d_i8_kernel
  * (C % 128 / C = 64 / general path), 10 stem_conv_i8, 11 block_tail_i8 (fq_block_tail_i8), 12 the same with the projection
- * shortcut computed in the kernel (fq_block_tail_proj_i8), 0 nothing launched; bits 8-15: output-channel
+ * shortcut computed in the kernel (fq_block_tail_proj_i8), 13 linear_i8_wave (a linear layer, one wave per 32 x 32 tile), 0 nothing
+ * launched; bits 8-15: output-channel
  * tile (64 / 128).  Lets a test assert that the dispatch it checked against a golden is the dispatch a benchmark timed. */
 int fq_conv2d_i8_last_variant(void);
 

@@ -14,7 +14,7 @@ extern thread_local int g_last_hip_error;
 // "the kernels the bench times were the ones the golden check ran" is an assertion and not a belief.
 extern thread_local int g_last_conv_variant;
 enum ConvVariant { kVarNone = 0, kVarC64Halo = 1, kVarStream = 2, kVarHalo8 = 3, kVarHalo = 4, kVarDma2 = 5, kVarDma3 = 6,
-                   kVarTileC128 = 7, kVarTileC64 = 8, kVarTileGeneral = 9, kVarStem = 10 };
+                   kVarTileC128 = 7, kVarTileC64 = 8, kVarTileGeneral = 9, kVarStem = 10, kVarLinearWave = 13 };
 inline void note_conv_variant(int variant, int tk) { g_last_conv_variant = variant | (tk << 8); }
 
 inline int hip_fail(hipError_t e) {

@@ -1573,6 +1573,63 @@ struct FusedAdd {                        // residual operand and outputs of a fu
     AddResParams ap = {};
 };
 
+// A linear layer (NewLinear: N x C activations, K x C weights, fp32 [N][K] out) as one small workgroup per 32 x 32 output tile
+// (round 5).  The tiled kernels give a 256 x 1000 classifier 32 workgroups that each walk the whole reduction through LDS and
+// barriers: 24 us for 0.5 GMAC.  Here both operand fragments come straight from L2 into the MFMA's registers (a row of either
+// matrix is one lane's 16 bytes per sub-step), eight sub-steps of loads in flight per wave, and the four waves of the workgroup
+// take every fourth group of eight sub-steps; their int32 partial tiles meet in LDS (exact: integer sums in any order).
+constexpr int kLinWaves = 4;
+__global__ __launch_bounds__(64 * kLinWaves) void linear_i8_wave_kernel(const int8_t* __restrict__ x, const int8_t* __restrict__ w,
+                                                                        const float* __restrict__ qbias, float* __restrict__ y,
+                                                                        const ConvParams p) {
+    __shared__ int part[kLinWaves - 1][16][64];
+    const int lane = threadIdx.x & 63, r = lane & 31, half = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int k0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<int8_t*>(w), 0, p.w_bytes, 0x00020000);
+    const unsigned a0 = k0 + r < p.K ? (unsigned)(k0 + r) * (unsigned)p.C + (unsigned)(16 * half) : kOutOfRange;
+    const unsigned b0 = m0 + r < p.M ? (unsigned)(m0 + r) * (unsigned)p.C + (unsigned)(16 * half) : kOutOfRange;
+    const int steps = (p.C + 31) / 32;
+    // (C % 32 == 16: the upper half of the last sub-step lies behind the row -- in the next row, not out of range: request nothing)
+    const bool odd = (p.C & 31) != 0;
+    v16i acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0;
+    for (int g0 = 8 * wave; g0 < steps; g0 += 8 * kLinWaves) {       // groups of eight sub-steps, round robin over the waves
+        v4i fa[8], fb[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int ks = g0 + u;
+            const bool dead = ks >= steps || (odd && ks == steps - 1 && half == 1);
+            fa[u] = load_act(wr, dead ? kOutOfRange : a0 + (unsigned)(ks * 32));
+            fb[u] = load_act(xr, dead ? kOutOfRange : b0 + (unsigned)(ks * 32));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[u], fb[u], acc, 0, 0, 0);
+    }
+    if (wave != 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) part[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int v = 0; v < kLinWaves - 1; ++v)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += part[v][i][lane];
+    const int n = m0 + r;
+    if (n >= p.M) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = k0 + (i & 3) + 8 * (i >> 2) + 4 * half;
+        if (k < p.K) {
+            const float b = qbias[k];
+            y[(size_t)n * p.K + k] = p.rs ? (float)conv_tail_i(acc[i], (int)b, p) * p.inv_ob : conv_tail(acc[i], b, p);
+        }
+    }
+}
+
 static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw, int8_t* q_nhwc,
                               int Kpad, int relu, const FusedAdd& fa, int N, int H, int W, int C, int K, int R, int S, int stride_h, int stride_w,
                               int pad_h, int pad_w, int dil_h, int dil_w, int rs, int ob, int bitwidth, fq_stream_t stream) {
@@ -1624,6 +1681,15 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     // 1x1 layers with an int8 output: the streaming kernel with stationary weights (fq_conv1x1_i8.hip) where it applies
     if (launch_conv1x1_stream(st, x_nhwc, w_krsc, qbias, y_nchw, q_nhwc, p)) {
         note_conv_variant(kVarStream, 0);
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    }
+    // a linear layer with an fp32 output: one wave per 32 x 32 tile, operands straight from L2 (FQ_LINEAR_WAVE=0: the tiled kernels)
+    static const bool thin = [] { const char* e = getenv("FQ_LINEAR_WAVE"); return !(e && e[0] == '0'); }();
+    if (thin && H == 1 && W == 1 && R == 1 && S == 1 && P == 1 && Q == 1 && y_nchw && !q_nhwc && !fa.res && (M + 31) / 32 <= 65535) {
+        hipLaunchKernelGGL(linear_i8_wave_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((M + 31) / 32)), dim3(64 * kLinWaves), 0, st, x_nhwc, w_krsc,
+                           qbias, y_nchw, p);
+        note_conv_variant(kVarLinearWave, 32);
         FQ_LAUNCH_CHECK();
         return FQ_OK;
     }

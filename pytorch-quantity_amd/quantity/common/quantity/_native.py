@@ -851,7 +851,7 @@ def pack_weight_krsc(w, cpad=None):
 # Which integer-convolution kernels ran (fq_conv2d_i8_last_variant): set conv_variant_log = {} and every call below counts its
 # kernel there by name -- tests and bench.py assert with it that the dispatch they checked is the dispatch they time.
 CONV_VARIANTS = {0: "none", 1: "c64_halo", 2: "stream", 3: "halo8", 4: "halo", 5: "dma2", 6: "dma3", 7: "tile_c128", 8: "tile_c64",
-                 9: "tile_general", 10: "stem", 11: "block_tail", 12: "block_tail_proj"}
+                 9: "tile_general", 10: "stem", 11: "block_tail", 12: "block_tail_proj", 13: "linear_wave"}
 conv_variant_log = None
 
 

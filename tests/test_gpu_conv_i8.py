@@ -68,7 +68,9 @@ def test_conv2d_i8_vs_integer_oracle(nat, oracle, case):
 
 def test_linear_i8_vs_oracle(nat, oracle):
     rng = np.random.default_rng(9)
-    for N, F, K in ((4, 512, 10), (64, 2048, 1000), (3, 400, 120), (1, 84, 10)):
+    # (a linear layer runs as one wave per 32 x 32 output tile, operands straight from L2 -- linear_i8_wave_kernel; 400 and 84
+    #  input features: a last sub-step of 16 bytes; 300 rows, 37 columns: partial tiles both ways)
+    for N, F, K in ((4, 512, 10), (64, 2048, 1000), (3, 400, 120), (1, 84, 10), (300, 272, 37), (256, 2048, 1000)):
         xq = rng.integers(-128, 128, size=(N, F)).astype(np.int32)
         wq = rng.integers(-128, 128, size=(K, F)).astype(np.int32)
         qb = rng.integers(-128, 128, size=K).astype(np.float32)
@@ -77,9 +79,15 @@ def test_linear_i8_vs_oracle(nat, oracle):
         xp = np.zeros((N, fpad), dtype=np.int8)
         xp[:, :F] = xq
         w_dev = nat.pack_weight_krsc(_dev(wq.astype(np.float32)))
-        got = nat.conv2d_i8(_dev(xp), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), 9, 2).cpu().numpy()
-        ref = oracle.recon_epilogue(acc.astype(np.float32), qb, 9, 2)
-        np.testing.assert_array_equal(got, ref)
+        for rs, ob in ((9, 2), (0, 0), (13, -1), (20, 3)):                         # (0 and 20: the fp32 tail)
+            nat.conv_variant_log = log = {}
+            try:
+                got = nat.conv2d_i8(_dev(xp), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), rs, ob).cpu().numpy()
+            finally:
+                nat.conv_variant_log = None
+            assert log == {"linear_wave/32": 1}, log
+            ref = oracle.recon_epilogue(acc.astype(np.float32), qb, rs, ob)
+            np.testing.assert_array_equal(got, ref, err_msg="N=%d F=%d K=%d rs=%d ob=%d" % (N, F, K, rs, ob))
 
 
 def test_newconv2d_int8_path_equals_float_path(nat):
