@@ -236,6 +236,80 @@ def fixed_input(shape, seed=99):
     return torch.from_numpy(np.random.default_rng(seed).standard_normal(tuple(shape), dtype=np.float32))
 
 
+def tiny_vgg_net():
+    """A plain stack -- 3x3 convolutions, max-pools, a two-layer classifier, no residual -- at widths the own float kernels take
+    (16 / 64 channels: the direct R x S kernel and, for 64 -> 64 and 64 -> 128, the Winograd one)."""
+    import torch.nn as nn
+    from common.quantity import View
+
+    class TinyVgg(nn.Module):
+        def __init__(self):
+            super(TinyVgg, self).__init__()
+            self.c1 = nn.Conv2d(3, 16, 3, padding=1)
+            self.r1 = nn.ReLU(False)
+            self.c2 = nn.Conv2d(16, 64, 3, padding=1)
+            self.r2 = nn.ReLU(False)
+            self.p1 = nn.MaxPool2d(2, 2)
+            self.c3 = nn.Conv2d(64, 64, 3, padding=1)
+            self.r3 = nn.ReLU(False)
+            self.c4 = nn.Conv2d(64, 128, 3, padding=1)
+            self.r4 = nn.ReLU(False)
+            self.p2 = nn.MaxPool2d(2, 2)
+            self.c5 = nn.Conv2d(128, 32, 1)
+            self.r5 = nn.ReLU(False)
+            self.view = View()
+            self.f1 = nn.Linear(32 * 4 * 4, 24)
+            self.r6 = nn.ReLU(False)
+            self.f2 = nn.Linear(24, 10)
+
+        def forward(self, x):
+            x = self.p1(self.r2(self.c2(self.r1(self.c1(x)))))
+            x = self.p2(self.r4(self.c4(self.r3(self.c3(x)))))
+            x = self.view(self.r5(self.c5(x)))
+            return self.f2(self.r6(self.f1(x)))
+
+    return TinyVgg()
+
+
+def tiny_separable_net():
+    """Depthwise-separable blocks (a grouped 3x3 convolution the own kernels do not take, then a 1x1 one they do), a stride-2
+    depthwise layer, an identity shortcut, a global average pool: what a MobileNet is made of."""
+    import torch.nn as nn
+    from common.quantity import Eltwise, View
+
+    class TinySeparable(nn.Module):
+        def __init__(self):
+            super(TinySeparable, self).__init__()
+            self.stem = nn.Conv2d(3, 16, 3, stride=2, padding=1)
+            self.r0 = nn.ReLU(False)
+            self.dw1 = nn.Conv2d(16, 16, 3, padding=1, groups=16)
+            self.r1 = nn.ReLU(False)
+            self.pw1 = nn.Conv2d(16, 32, 1)
+            self.r2 = nn.ReLU(False)
+            self.dw2 = nn.Conv2d(32, 32, 3, stride=2, padding=1, groups=32)
+            self.r3 = nn.ReLU(False)
+            self.pw2 = nn.Conv2d(32, 64, 1)
+            self.r4 = nn.ReLU(False)
+            self.dw3 = nn.Conv2d(64, 64, 3, padding=1, groups=64)
+            self.r5 = nn.ReLU(False)
+            self.pw3 = nn.Conv2d(64, 64, 1)
+            self.Eltwise = Eltwise()
+            self.r6 = nn.ReLU(False)
+            self.pool = nn.AvgPool2d(4)
+            self.view = View()
+            self.fc = nn.Linear(64, 7)
+
+        def forward(self, x):
+            x = self.r0(self.stem(x))
+            x = self.r2(self.pw1(self.r1(self.dw1(x))))
+            x = self.r4(self.pw2(self.r3(self.dw2(x))))
+            y = self.pw3(self.r5(self.dw3(x)))
+            x = self.r6(self.Eltwise(y, x))
+            return self.fc(self.view(self.pool(x)))
+
+    return TinySeparable()
+
+
 def tiny_concat_net():
     """Small net with a Concat fed by two convolutions and an Eltwise fed by a Concat consumer and a
     convolution: covers the Concat merge group (shared interval, pooled histogram)."""

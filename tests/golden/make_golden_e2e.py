@@ -174,13 +174,15 @@ def capture_dkl(cq, tl):
 
 
 def capture_small(cq, tl):
-    """End-to-end tables for two small nets: the LeNet fixture (biased convs, MaxPool, Linear chain)
-    and a net with a Concat merge group."""
+    """End-to-end tables for four small nets: the LeNet fixture (biased convs, MaxPool, Linear chain), a net with a Concat merge
+    group, a plain VGG-like stack and a depthwise-separable one (grouped convolutions)."""
     import torch
     from model.lenet.lenet import Cnn                      # the reference's model file
     out = {}
     specs = (("lenet", lambda: Cnn(1, 10), "1,1,28,28", (4, 1, 28, 28)),
-             ("concat", cases.tiny_concat_net, "1,3,8,8", (4, 3, 8, 8)))
+             ("concat", cases.tiny_concat_net, "1,3,8,8", (4, 3, 8, 8)),
+             ("vgg", cases.tiny_vgg_net, "1,3,16,16", (4, 3, 16, 16)),
+             ("separable", cases.tiny_separable_net, "1,3,16,16", (4, 3, 16, 16)))
     for tag, ctor, shape_str, bshape in specs:
         with _refenv.reference_workdir(input_shape=shape_str, max_cali_img_num=2) as tmp:
             model = cases.seed_model(ctor(), base_seed=7).eval()

@@ -1,5 +1,5 @@
-"""Small end-to-end fixtures captured from the imported reference (golden G9): the LeNet fixture and a
-net with a Concat merge group.  CPU: orchestrator + oracle-backed engine, byte-identical tables and
+"""Small end-to-end fixtures captured from the imported reference (golden G9): the LeNet fixture, a
+net with a Concat merge group, a VGG-like stack and a depthwise-separable net.  CPU: orchestrator + oracle-backed engine, byte-identical tables and
 JSON.  GPU (-m gpu): the same through the HIP engine."""
 import hashlib
 import json
@@ -13,6 +13,10 @@ from workdir_util import product_workdir
 SPECS = {
     "lenet": (lambda: __import__("model.lenet.lenet", fromlist=["Cnn"]).Cnn(1, 10), "1,1,28,28", (4, 1, 28, 28)),
     "concat": (cases.tiny_concat_net, "1,3,8,8", (4, 3, 8, 8)),
+    # (round 5) models that are not ResNets: a plain 3x3 stack with max-pools and a two-layer classifier -- the direct and the
+    # Winograd float kernels without a residual anywhere -- and depthwise-separable blocks, whose grouped convolutions stay on torch
+    "vgg": (cases.tiny_vgg_net, "1,3,16,16", (4, 3, 16, 16)),
+    "separable": (cases.tiny_separable_net, "1,3,16,16", (4, 3, 16, 16)),
 }
 
 
@@ -52,7 +56,7 @@ def g9(golden_dir):
         return json.load(fh)
 
 
-@pytest.mark.parametrize("tag", ["lenet", "concat"])
+@pytest.mark.parametrize("tag", ["lenet", "concat", "vgg", "separable"])
 def test_small_net_cpu_matches_reference(g9, oracle, tag):
     from engine_doubles import OracleCollector, OracleQuantizer
     from tools import Quantity
@@ -65,7 +69,7 @@ def test_small_net_cpu_matches_reference(g9, oracle, tag):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag", ["lenet", "concat"])
+@pytest.mark.parametrize("tag", ["lenet", "concat", "vgg", "separable"])
 def test_small_net_gpu_matches_reference(g9, tag):
     from tools import Quantity
     _check(_run(tag, Quantity, "gpu"), g9[tag])
