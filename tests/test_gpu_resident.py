@@ -419,14 +419,18 @@ def test_foreign_consumers_and_shared_relu():
         assert torch.equal(net(x[:1]), plain[:1])
 
 
-@pytest.mark.parametrize("tag", ["concat", "lenet"])
+@pytest.mark.parametrize("tag", ["concat", "lenet", "vgg", "separable"])
 def test_small_nets_with_concat_and_pool_only_topologies(tag, monkeypatch):
     """Nets whose integer layers feed things the plan does not own (a Concat marker layer, View, Linear
-    chains): whatever goes resident, the logits must not change, and Concat operands must stay fp32."""
+    chains), a plain VGG-like stack (2x2 max-pools between integer layers) and depthwise-separable blocks (grouped convolutions
+    keep the reference's fp32 form): whatever goes resident, the logits must not change, and Concat operands must stay fp32."""
     from common.quantity import resident
     if tag == "concat":
         fn, shape, image, ch = cases.tiny_concat_net, "1,3,8,8", 8, 3
         monkeypatch.setattr(torch, "save", lambda *a, **k: None)       # the fixture net is a local class: not picklable
+    elif tag in ("vgg", "separable"):
+        fn, shape, image, ch = (cases.tiny_vgg_net if tag == "vgg" else cases.tiny_separable_net), "1,3,16,16", 16, 3
+        monkeypatch.setattr(torch, "save", lambda *a, **k: None)
     else:
         fn, shape, image, ch = (lambda: __import__("model.lenet.lenet", fromlist=["Cnn"]).Cnn(1, 10)), "1,1,28,28", 28, 1
     with product_workdir(input_shape=shape, device="gpu"):
@@ -438,6 +442,10 @@ def test_small_nets_with_concat_and_pool_only_topologies(tag, monkeypatch):
         if tag == "concat":
             assert plans["branch_a"].emit_f32 and plans["branch_b"].emit_f32, plans          # Concat is foreign code
             assert plans["stem"].relu and plans["Eltwise"].resident_add, plans
+        if tag == "vgg":
+            assert plans["p1"].emit_int and plans["p2"].emit_int and summary["resident_pools"] >= 2, plans     # int8 max-pools
+        if tag == "separable":
+            assert "dw1" not in plans or plans["dw1"].emit_f32, plans                     # a grouped convolution is not an integer layer
         assert summary["resident_convs"] >= 2
         with torch.no_grad():
             assert torch.equal(net(x), plain)
