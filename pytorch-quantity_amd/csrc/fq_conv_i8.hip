@@ -1143,8 +1143,16 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
         for (int a = 0; a < MT; ++a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][r] = 0;
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
+        // The operands of a tap -- two 16-byte reads of this lane's input pixel, four of the weights -- are requested kAhead taps
+        // before the tap's four MFMAs (round 5).  Left to the compiler the loop was "read, s_waitcnt lgkmcnt(0), MFMA" 18 times per
+        // tile on 90 registers: it schedules for an occupancy this kernel's 80 KB of LDS never reaches (two workgroups per CU), and
+        // every wait exposed the LDS latency -- 47 waits for 36 MFMAs.  The fences keep the order written here; the waits the
+        // compiler derives from it are counted ones that leave the younger taps' reads in flight.  144 registers; 41.5 -> 39.6 us
+        // per launch at 256 images (51.4 -> 47.1 stand-alone): the latency was a part of the tile's time, not most of it.
+        constexpr int kAhead = 2;
+        struct TapOps { v4i fb[2]; v4i fa[2][MT]; };
+        TapOps ops[kAhead + 1];
+        auto load_tap = [&](int tap, TapOps& o) {
             const int r = tap / 3, s_ = tap - 3 * r;          // compile-time after unrolling
             const int j = p_row + r * p.W + s_;
             const bool ok = m_ok && (unsigned)(oh + r - 1) < (unsigned)p.H && (unsigned)(ow + s_ - 1) < (unsigned)p.W;
@@ -1152,13 +1160,23 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
             const int sw = ok ? swz64(j) : 0;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const v4i fb = *reinterpret_cast<const v4i*>(smem + rowb + (unsigned)((((ks * 2 + half) ^ sw)) * 16));
+                o.fb[ks] = *reinterpret_cast<const v4i*>(smem + rowb + (unsigned)((((ks * 2 + half) ^ sw)) * 16));
 #pragma unroll
-                for (int a = 0; a < MT; ++a) {
-                    const v4i fa = *reinterpret_cast<const v4i*>(sW + tap * TK * RB + a_off[a] + swz_a[ks]);
-                    acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, acc[a], 0, 0, 0);
-                }
+                for (int a = 0; a < MT; ++a) o.fa[ks][a] = *reinterpret_cast<const v4i*>(sW + tap * TK * RB + a_off[a] + swz_a[ks]);
             }
+        };
+#pragma unroll
+        for (int t = 0; t < kAhead; ++t) load_tap(t, ops[t]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + kAhead < 9) load_tap(tap + kAhead, ops[(tap + kAhead) % (kAhead + 1)]);
+            __builtin_amdgcn_sched_barrier(0);
+            const TapOps& o = ops[tap % (kAhead + 1)];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int a = 0; a < MT; ++a) acc[a] = __builtin_amdgcn_mfma_i32_32x32x32_i8(o.fa[ks][a], o.fb[ks], acc[a], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         ResRegs<TK> res;
         if (p.rs) conv_epilogue<TK, kOut, true, false>(acc, p, y, q, sO, sBias, sBiasI, sLH, m0, 0, n_img, pq, m_ok, res);
