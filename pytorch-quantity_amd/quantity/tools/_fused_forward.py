@@ -480,6 +480,9 @@ class _FusedForward(object):
                     or not (self._only_our_hook(conv) and self._only_our_hook(relu))):
                 continue
             probe.relu_only[conv] = relu
+        # (the loop variable outlives the loop: it held the LAST convolution's output, whose reference count then exceeded the
+        #  control's by one -- a suspect in every calibration, i.e. a heap pass of 11-16 ms that found nothing; round 5)
+        _y = None
         # keepers (code that stores one of these tensors and reads it after the forward: invisible to the poison): whoever still
         # refers to a convolution's output or to a sum now that the learning forward has returned, and is not this calibration
         # (cheap first: a tensor nobody else holds has exactly the reference count of a CONTROL tensor put into the same containers

@@ -255,6 +255,23 @@ def test_readers_the_poison_cannot_see_are_found_and_their_chain_is_not_deferred
     assert torch.equal(kept, ref_model.b2.feat)
 
 
+def test_a_clean_model_needs_no_heap_pass(monkeypatch):
+    """The keeper scan's heap pass (gc.get_referrers over every tracked object: 11-16 ms on a ResNet-50 process) is only for
+    tensors whose reference count exceeds a control tensor's.  In a model nobody keeps anything of, no tensor does -- a loop
+    variable of the proof itself used to hold the last convolution's output and made it a suspect in EVERY calibration."""
+    from tools import _hook_state
+    calls = []
+    real = _hook_state._DeferralProbe.holders
+    monkeypatch.setattr(_hook_state._DeferralProbe, "holders", staticmethod(lambda tensors, ours: (calls.append(len(tensors)), real(tensors, ours))[1]))
+    model = cases.seed_model(_block_net(), base_seed=8).eval().cuda()
+    got = _calibrate(model, True)
+    assert got[4]["conv_add_chains_proven"] == 2 and calls == [], calls
+    # ... and a keeper still is one
+    model = cases.seed_model(_keeper_net("stash"), base_seed=8).eval().cuda()
+    got = _calibrate(model, True)
+    assert got[4]["conv_add_chains_proven"] == 1 and len(calls) >= 1 and all(n >= 1 for n in calls), calls
+
+
 def test_a_list_collector_hooked_on_the_parent_block_sees_what_the_unfused_run_shows_it():
     """register_forward_hook on the BLOCK (not on a module of the chain): it receives the block's input and its result -- the
     ReLU's output, which the one-kernel tail does write -- and keeps them in a list.  The chain stays fused (nothing it keeps is
