@@ -376,7 +376,8 @@ int fq_conv2d_i8_stem(const float* x_nchw, const int8_t* w_stem, const float* qb
  *   y = clamp( RightShift(acc, rs) + qbias[k] ) / 2^ob                                    (fp32 NCHW)
  * implicit GEMM on v_mfma_i32_32x32x32_i8.  x: int8 NHWC [N][H][W][C], w: int8 [K][R][S][C], both
  * 16-byte aligned, C % 16 == 0 (zero-pad channels; FQ_ERR_UNSUPPORTED otherwise), groups == 1.
- * qbias: fp32[K] integer valued.  y: fp32 [N][K][P][Q].  A Linear layer is H = W = R = S = 1.
+ * qbias: fp32[K] integer valued, of ANY magnitude (a bias beyond the output range saturates the output exactly as the reference's
+ *   fp32 BiasAdd + Sp does; tests/test_gpu_conv_i8.py).  y: fp32 [N][K][P][Q].  A Linear layer is H = W = R = S = 1.
  * The reference computes acc with an fp32 convolution, exact while |partial sums| < 2^24; in that
  * regime the results are identical, beyond it this kernel stays exact. */
 int fq_conv2d_i8(const int8_t* x_nhwc, const int8_t* w_krsc, const float* qbias, float* y_nchw,

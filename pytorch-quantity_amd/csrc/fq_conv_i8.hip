@@ -1680,7 +1680,9 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     else { p.lo = -32768.0f; p.hi = 32767.0f; p.ilo = -32768; p.ihi = 32767; }
     if (relu) p.lo = 0.0f;                                // ReLU commutes with the positive scale 2^-ob
     // integer tail where it is provably the same function (see conv_tail_i)
-    const bool int_tail = rs >= 1 && rs <= 16 && (long)R * S * C * 16384 + 65536 < 0x7fffffffL;
+    // (... and with the bias folded into the rounding constant -- tail_consts: |qb| <= shi - ilo after its clamp, shifted by rs)
+    const long qmax = bitwidth == 8 ? 255 : 65535;
+    const bool int_tail = rs >= 1 && rs <= 16 && (long)R * S * C * 16384 + 65536 + (qmax << rs) < 0x7fffffffL;
     p.rs = int_tail ? rs : 0;
     p.half_rs = int_tail ? 1 << (rs - 1) : 0;
     p.slo = (int)p.lo; p.shi = (int)p.hi;

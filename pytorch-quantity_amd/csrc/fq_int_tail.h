@@ -39,16 +39,22 @@ __device__ __forceinline__ int conv_tail_i(int acc, int qb, const P& p) {
 
 // The same tail in FOUR vector instructions, from three per-channel constants instead of one (tail_consts below):
 //   * floor commutes with adding a multiple of 2^rs:  ((acc + half + sign) >> rs) + qb = (acc + half + (qb << rs) + sign) >> rs,
-//     so the bias rides in the rounding constant  B = half_rs + (qb << rs)   (|qb| <= 2^15, rs <= 16: inside int32 with the host's
-//     bound on |acc|);
+//     so the bias rides in the rounding constant  B = half_rs + (qb << rs)   (qb clamped as described below: inside int32 with the
+//     host's bound on |acc|);
 //   * a clamp of a clamp is a clamp:  med3(med3(r, ilo, ihi) + qb, slo, shi) = med3(r + qb, lo, hi)  with
 //     lo = med3(ilo + qb, slo, shi), hi = med3(ihi + qb, slo, shi)  (a bias beyond the output range makes lo = hi).
 // Same integer for every acc the six-instruction form is valid for.  Where the tail is what a kernel's vector pipe is busy with
 // (fq_block_tail_i8: two or three tails per output value) the two instructions are time; in the stem they were not.
+// The bias is only "integer valued" by contract, not bounded: it is first brought into [slo - ihi, shi - ilo] -- beyond that range
+// the output is slo or shi whatever the accumulator holds (the smallest r + qb is already above shi, or the largest below slo), so
+// the clamped bias gives the same integer -- and then |qb| << rs stays below 2^(bits + 1 + rs), which the host adds to its bound
+// on |acc| (fq_conv_i8.hip, int_tail).
 struct TailK { int B, lo, hi; };
 template <typename P>
 __device__ __forceinline__ TailK tail_consts(int qb, const P& p) {
     TailK k;
+    const int qlo = p.slo - p.ihi, qhi = p.shi - p.ilo;
+    qb = qb < qlo ? qlo : (qb > qhi ? qhi : qb);
     k.B = p.half_rs + (qb << p.rs);
     const int a = p.ilo + qb, b = p.ihi + qb;
     k.lo = a < p.slo ? p.slo : (a > p.shi ? p.shi : a);

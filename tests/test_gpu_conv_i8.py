@@ -66,6 +66,49 @@ def test_conv2d_i8_vs_integer_oracle(nat, oracle, case):
         np.testing.assert_array_equal(got, ref, err_msg="rs=%d ob=%d" % (rs, ob))
 
 
+def test_a_bias_far_outside_the_output_range_saturates_like_the_reference(nat, oracle):
+    """The quantised bias is "integer valued" by contract, not bounded.  The four-instruction tail folds it into the rounding constant
+    (qb << rs): a bias of 10^5 or 3 x 10^9 would leave int32 there -- tail_consts first clamps it to the range beyond which the output
+    is the Sp bound whatever the accumulator holds.  fp32 output, int8 output (+ ReLU) and the residual-add epilogue, 8- and 16-bit."""
+    rng = np.random.default_rng(404)
+    N, C, H, W, K = 2, 64, 9, 9, 128
+    xq = rng.integers(-128, 128, size=(N, C, H, W)).astype(np.int32)
+    wq = rng.integers(-128, 128, size=(K, C, 1, 1)).astype(np.int32)
+    qb = rng.integers(-128, 128, size=K).astype(np.float32)
+    qb[::7] = [(-1) ** i * v for i, v in enumerate(np.resize([300.0, 1e5, 3e9, 40000.0, 255.0, 256.0], len(qb[::7])))]
+    acc = oracle.conv2d_int(xq, wq, (1, 1), (0, 0), (1, 1))
+    x_nhwc = np.ascontiguousarray(xq.transpose(0, 2, 3, 1)).astype(np.int8)
+    w_dev = nat.pack_weight_krsc(_dev(wq.astype(np.float32)))
+    for rs, ob, bw in ((8, 3, 8), (16, 2, 8), (12, 4, 16), (16, 0, 16)):
+        got = nat.conv2d_i8(_dev(x_nhwc), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), rs, ob, bw).cpu().numpy()
+        np.testing.assert_array_equal(got, oracle.recon_epilogue(acc.astype(np.float32), qb, rs, ob, bw), err_msg="rs=%d bits=%d" % (rs, bw))
+    for relu in (False, True):
+        _, q = nat.conv2d_i8_resident(_dev(x_nhwc), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), 9, 3, False, True, relu)
+        ref = oracle.recon_epilogue(acc.astype(np.float32), qb, 9, 0, 8)
+        ref = np.maximum(ref, 0) if relu else ref
+        np.testing.assert_array_equal(q.cpu().numpy().astype(np.float32), ref.transpose(0, 2, 3, 1))
+    # the block-tail kernel's three tails (conv3, the projection, the next conv1)
+    C2 = 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randint(-128, 128, (2, 6, 6, 64), dtype=torch.int8, device="cuda", generator=g)
+    xp = torch.randint(-128, 128, (2, 6, 6, 64), dtype=torch.int8, device="cuda", generator=g)
+    w3 = nat.pack_weight_krsc(torch.randint(-127, 128, (256, 64, 1, 1), device="cuda", generator=g).float())
+    wp = nat.pack_weight_krsc(torch.randint(-127, 128, (256, 64, 1, 1), device="cuda", generator=g).float())
+    w1 = nat.pack_weight_krsc(torch.randint(-127, 128, (C2, 256, 1, 1), device="cuda", generator=g).float())
+    big = lambda n: torch.from_numpy(np.resize(np.array([7.0, -1e5, 3e9, -300.0, 90.0, 1e4], dtype=np.float32), n)).cuda()
+    b3, bp, b1 = big(256), big(256).flip(0), big(C2)
+    _, res = nat.conv2d_i8_resident(xp, wp, bp, (1, 1), (0, 0), (1, 1), 9, 4, False, True, False)
+    wide, narrow = nat.conv2d_i8_add_resident(x, w3, b3, (1, 1), (0, 0), (1, 1), 9, 4, res, 4, True, 4, True, 4, True)
+    _, q1 = nat.conv2d_i8_resident(narrow, w1, b1, (1, 1), (0, 0), (1, 1), 10, 4, False, True, True)
+    got = nat.block_tail_proj_i8(x, w3, b3, 9, 4, xp, wp, bp, 9, 4, 1, True, 4, True, 4, True, w1, b1, 10, True)
+    for a, b_ in zip(got, (wide, narrow, q1)):
+        assert torch.equal(a, b_)
+    # ... and the general kernels' own results against the oracle's chain for the projection (the other two follow from it above)
+    accp = oracle.conv2d_int(xp.cpu().numpy().astype(np.int32).transpose(0, 3, 1, 2), wp.cpu().numpy().astype(np.int32).reshape(256, 64, 1, 1))
+    np.testing.assert_array_equal(res.cpu().numpy().astype(np.float32),
+                                  oracle.recon_epilogue(accp.astype(np.float32), bp.cpu().numpy(), 9, 0, 8).transpose(0, 2, 3, 1))
+
+
 def test_linear_i8_vs_oracle(nat, oracle):
     rng = np.random.default_rng(9)
     # (a linear layer runs as one wave per 32 x 32 output tile, operands straight from L2 -- linear_i8_wave_kernel; 400 and 84
