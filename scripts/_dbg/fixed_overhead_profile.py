@@ -18,4 +18,4 @@ q.activation_quantize(data)
 torch.cuda.synchronize(); pr.disable(); dt = time.perf_counter() - t0
 sys.stdout = out
 print("one batch: %.4f s" % dt, {k: round(v, 4) for k, v in q.timings.items() if k.endswith("_s")})
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45); print(s.getvalue()[:9000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40); print(s.getvalue()[:9000])
