@@ -137,43 +137,37 @@ def verified(m, run, x, k=None):
     # library: asking that library for a layer it will never run again would put its first-use solver search (tens of
     # milliseconds to seconds per configuration; 0.4 s for the 7x7 stem alone, scripts/_dbg/one_shot_probe.py) into a one-shot
     # calibration for nothing.
-    # (compared on `head` images; the abs-max is checked on the whole output)
-    pick = None
-    if m.kernel_size == (1, 1):                                 # 1x1: a GEMM (rocBLAS through torch.matmul) on the first 32 images
-        s = m.stride[0]
-        # (the first and the last 16: every tile shape and image boundary occurs there, and the tiles of the last, K-sliced
-        #  round of a launch are the last ones)
-        n_all = int(x.shape[0])
-        pick = None if n_all <= 32 else torch.cat([torch.arange(16, device=x.device), torch.arange(n_all - 16, n_all, device=x.device)])
-        head = min(n_all, 32)
-        xh = x if pick is None else x.index_select(0, pick)
-        xs = (xh if s == 1 else xh[:, :, ::s, ::s]).reshape(head, x.shape[1], -1)
-        w2 = m.weight.view(m.out_channels, -1)
-        shape = (head, m.out_channels, (x.shape[2] - 1) // s + 1, (x.shape[3] - 1) // s + 1)
-        ref = (torch.matmul(w2, xs) + m.bias.view(1, -1, 1)).view(shape)
-        bound = (torch.matmul(w2.abs(), xs.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
-    else:                                                       # R x S (the stem included): im2col (unfold) + GEMM on the first and last images
-        # (at most 16 images -- the first and the last 8, the policy of the 1x1 branch: every tile shape, image boundary and the
-        #  tiles of a launch's last round occur there; the unfolded copy of 149 images of a 56 x 56 layer was 1 GB and, with its two
-        #  GEMMs, most of what a process's first calibration paid for these checks)
-        head = max(1, min(x.shape[0], 16, (1 << 28) // max(x[0].numel() * m.kernel_size[0] * m.kernel_size[1], 1)))
-        n_all = int(x.shape[0])
-        pick = None
-        if head < n_all and head >= 2:
-            pick = torch.cat([torch.arange(head // 2, device=x.device), torch.arange(n_all - (head - head // 2), n_all, device=x.device)])
-        xh = x[:head] if pick is None else x.index_select(0, pick)
-        cols = torch.nn.functional.unfold(xh, m.kernel_size, padding=m.padding, stride=m.stride)
-        w2 = m.weight.view(m.out_channels, -1)
-        ho = (x.shape[2] + 2 * m.padding[0] - m.kernel_size[0]) // m.stride[0] + 1
-        shape = (head, m.out_channels, ho, cols.shape[2] // ho)
-        ref = (torch.matmul(w2, cols) + m.bias.view(1, -1, 1)).view(shape)
-        bound = (torch.matmul(w2.abs(), cols.abs()) + m.bias.abs().view(1, -1, 1)).view(shape)
-        del cols
+    # (compared on the first and the last images -- every tile shape and image boundary occurs there, and the tiles of the last,
+    #  K-sliced round of a launch are the last ones; the abs-max is checked on the whole output.  The two groups are VIEWS of x and
+    #  of the kernel's output, compared one after the other: the gathered copies this used to make -- up to 100 MB each -- and the
+    #  full-size temporary of `own.abs().max()` were allocator growth in a fresh process, most of the 0.16 s these checks cost a
+    #  one-shot calibration of ResNet-50; round 5)
+    n_all = int(x.shape[0])
+    if m.kernel_size == (1, 1):                                 # 1x1: a GEMM (rocBLAS through torch.matmul), 16 + 16 images
+        per = 16
+    else:                                                       # R x S (the stem included): im2col (unfold) + GEMM, 8 + 8 images
+        per = max(1, min(8, (1 << 27) // max(x[0].numel() * m.kernel_size[0] * m.kernel_size[1], 1)))
+    groups = [(0, n_all)] if n_all <= 2 * per else [(0, per), (n_all - per, n_all)]
+    w2 = m.weight.view(m.out_channels, -1)
     scratch = torch.zeros(1, dtype=torch.float32, device=x.device)
     own = run(max_dev=scratch, row=0)
-    cmp = own[:head] if pick is None else own.index_select(0, pick)
+    # (vector_norm(inf) = max |.| in one pass, no temporary; NaN propagates as in abs().max())
+    ok = scratch[0] == torch.linalg.vector_norm(own.reshape(-1), float("inf"))
+    for lo, hi in groups:
+        xh = x[lo:hi]
+        if m.kernel_size == (1, 1):
+            s = m.stride[0]
+            cols = (xh if s == 1 else xh[:, :, ::s, ::s]).reshape(hi - lo, x.shape[1], -1)
+        else:
+            cols = torch.nn.functional.unfold(xh, m.kernel_size, padding=m.padding, stride=m.stride)
+        ref = torch.matmul(w2, cols) + m.bias.view(1, -1, 1)
+        bound = torch.matmul(w2.abs(), cols.abs()) + m.bias.abs().view(1, -1, 1)
+        del cols
+        cmp = own[lo:hi].reshape(hi - lo, m.out_channels, -1)
+        ok = ok & ((cmp - ref).abs() <= TOL * bound).all()
+        del ref, bound
     # (one device-side verdict, one host synchronisation: the first forward of a process checks 53 modules)
-    if not bool(((cmp - ref).abs() <= TOL * bound).all() & (scratch[0] == own.abs().max())):
+    if not bool(ok):
         state(m)["off"] = True
         return torch.nn.Conv2d.forward(m, x)
     state(m).setdefault("verified", set()).add(kernel_key(m, k))

@@ -18,4 +18,4 @@ torch.cuda.synchronize(); pr.disable(); dt = time.perf_counter() - t0
 t1 = time.perf_counter(); q.activation_quantize(data); torch.cuda.synchronize(); dt2 = time.perf_counter() - t1
 sys.stdout = out
 print("first calibration %.3f s, second %.3f s" % (dt, dt2), {k: v for k, v in q.timings.items() if k.endswith("_s")})
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(40); print(s.getvalue()[:8000])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:8000])
