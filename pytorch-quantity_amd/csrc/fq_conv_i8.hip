@@ -1066,6 +1066,7 @@ struct C64Params {
     int slab_rows;                         // 130 + 2 W rounded up to 16
     int total_pixels;                      // N * H * W
     int tiles;                             // 128-pixel tiles
+    int xcd_chunk;                         // tiles per XCD (ceil(tiles / 8)); 0: tiles dealt round robin (FQ_C64_XCD=0)
 };
 
 template <int kOut>
@@ -1107,9 +1108,21 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
     }
     const rsrc_words xr = make_rsrc_words(x, p.x_bytes);
     const int n_slab_dma = cp.slab_rows >> 4;
+    // which tiles this workgroup takes: an XCD (workgroup g runs on XCD g % 8: observed placement, for speed only) owns a contiguous
+    // eighth of the tile sequence, so that the rows a tile's slab shares with its neighbours' -- 130 + 2 W rows for 128 fresh ones --
+    // are hits in that XCD's L2 (dealt g, g + grid, ... the neighbours ran on other XCDs: 104 MB fetched for a 51 MB tensor; round 5)
+    int tile, tile_end, tile_step;
+    if (cp.xcd_chunk != 0 && (gridDim.x & 7u) == 0) {
+        const int xcd = (int)(blockIdx.x & 7u), local = (int)(blockIdx.x >> 3);
+        tile = xcd * cp.xcd_chunk + local;
+        tile_end = min((xcd + 1) * cp.xcd_chunk, cp.tiles);
+        tile_step = (int)(gridDim.x >> 3);
+    } else {
+        tile = (int)blockIdx.x; tile_end = cp.tiles; tile_step = (int)gridDim.x;
+    }
     auto slab_dma = [&](int tile, int buf) {                  // 16 slab rows per instruction
         const int m0 = tile * kTP;
-        const bool live = tile < cp.tiles;
+        const bool live = tile < tile_end;
         for (int i = wave; i < n_slab_dma; i += 4) {
             const int row = 16 * i + (lane >> 2);
             const int g = m0 - p.W - 1 + row;
@@ -1126,12 +1139,12 @@ __global__ __launch_bounds__(kConvBlock) void conv3x3_i8_c64_kernel(const int8_t
     const int p_row = wave * 32 + (lane & 31);
     const unsigned zero_off = (unsigned)(sZero - smem), slab_off0 = (unsigned)(sSlab - smem);
 
-    int tile = blockIdx.x, buf = 0;
+    int buf = 0;
     slab_dma(tile, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    for (; tile < cp.tiles; tile += gridDim.x) {
-        slab_dma(tile + gridDim.x, buf ^ 1);                  // the next tile's slab flies under this tile's arithmetic
+    for (; tile < tile_end; tile += tile_step) {
+        slab_dma(tile + tile_step, buf ^ 1);                  // the next tile's slab flies under this tile's arithmetic
         const int m0 = tile * kTP;
         const int m = m0 + p_row;
         const bool m_ok = m < p.M;
@@ -1562,6 +1575,8 @@ static bool launch_conv_c64(hipStream_t st, const int8_t* x, const int8_t* w, co
     cp.slab_rows = (130 + 2 * p0.W + 15) & ~15;
     cp.total_pixels = p0.N * p0.H * p0.W;
     cp.tiles = (p0.M + kTP - 1) / kTP;
+    static const bool xcd_order = [] { const char* e = getenv("FQ_C64_XCD"); return !(e && e[0] == '0'); }();
+    cp.xcd_chunk = xcd_order ? (cp.tiles + 7) / 8 : 0;
     const size_t lds = (size_t)9 * 64 * 64 + 64 * 8 + 64 + (size_t)kTP * 80 + (size_t)2 * cp.slab_rows * 64;
     if (lds > 80 * 1024 - 64) return false;               // two workgroups per CU
     ConvParams p = p0;

@@ -38,6 +38,7 @@ struct StemParams {
     int PR, PC, PCS;         // patch rows, patch columns, LDS row stride in pixels (>= (TW-1)*sw + 8)
     int tiles_x, tiles_y;
     unsigned ntiles;
+    unsigned xcd_chunk;      // tiles per XCD (ceil(ntiles / 8)), 0: tiles dealt round robin (FQ_STEM_XCD=0)
     float scale;             // 2^ib
     int rs, half_rs, ilo, ihi, slo, shi;
 };
@@ -105,10 +106,24 @@ __global__ __launch_bounds__(kStemBlock) __attribute__((amdgpu_waves_per_eu(4)))
     const int frag0 = oy_l * p.sh * p.PCS + ox_l * p.sw + 4 * half;        // word index for filter row 0
     const int wfrag0 = (lane & 31) * 32 + 16 * half;                       // byte offset inside one [64][32] weight row block
 
-    unsigned tile = blockIdx.x;
-    if (tile < p.ntiles) fetch(tile);
+    // Which tiles this workgroup takes.  Workgroup g runs on XCD g % 8 (observed placement: for speed only), and each XCD has an L2
+    // of its own: with tiles dealt g, g + grid, ... the neighbours of a tile -- whose input patches overlap its own by half (a 21 x 37
+    // patch for 16 x 32 fresh pixels) -- ran on the other seven XCDs and every patch came over the fabric whole: 472 MB fetched for a
+    // 154 MB image (rocprofv3 FETCH_SIZE, round 5).  Here an XCD owns a contiguous eighth of the tile sequence (x fastest, then y,
+    // then the image) and its resident workgroups walk it side by side, so a patch's overlap with its neighbours' is an L2 hit.
+    const unsigned G = gridDim.x;
+    unsigned tile, tile_end, tile_step;
+    if (p.xcd_chunk != 0 && (G & 7u) == 0) {
+        const unsigned xcd = blockIdx.x & 7u, local = blockIdx.x >> 3;
+        tile = xcd * p.xcd_chunk + local;
+        tile_end = min((xcd + 1u) * p.xcd_chunk, p.ntiles);
+        tile_step = G >> 3;
+    } else {
+        tile = blockIdx.x; tile_end = p.ntiles; tile_step = G;
+    }
+    if (tile < tile_end) fetch(tile);
     __syncthreads();
-    for (; tile < p.ntiles; tile += gridDim.x) {
+    for (; tile < tile_end; tile += tile_step) {
         const int tx = nx_tx, ty = nx_ty;               // of `tile` (set when it was fetched)
         const long n = nx_n;
         // a. quantise the fetched patch into LDS
@@ -121,8 +136,8 @@ __global__ __launch_bounds__(kStemBlock) __attribute__((amdgpu_waves_per_eu(4)))
         }
         __syncthreads();
         // b. the next tile's loads fly under the matrix work (the last tile fetches itself again: no branch)
-        const unsigned next = tile + gridDim.x;
-        fetch(next < p.ntiles ? next : tile);
+        const unsigned next = tile + tile_step;
+        fetch(next < tile_end ? next : tile);
 
         // c. contraction: one MFMA per filter row and 32-channel block
         v16i acc[2];
@@ -209,6 +224,8 @@ extern "C" int fq_conv2d_i8_stem(const float* x_nchw, const int8_t* w_stem, cons
     const long ntiles = (long)N * p.tiles_x * p.tiles_y;
     if (ntiles > 0x7fffffffL) return FQ_ERR_INVALID_ARG;
     p.ntiles = (unsigned)ntiles;
+    static const bool xcd_order = [] { const char* e = getenv("FQ_STEM_XCD"); return !(e && e[0] == '0'); }();
+    p.xcd_chunk = xcd_order ? (unsigned)((ntiles + 7) / 8) : 0u;
     p.scale = ldexpf(1.0f, ib);
     p.rs = rs; p.half_rs = 1 << (rs - 1);
     p.ilo = -128; p.ihi = 127;
