@@ -18,7 +18,7 @@ import torch
 from . import _native
 
 __all__ = ["enabled", "kind", "weight", "runner", "verified", "plain", "call", "call_qd", "call_linear_qd", "state", "is_verified",
-           "is_off", "forget", "kernel_key", "TOL"]
+           "is_off", "forget", "kernel_key", "own_convs", "TOL"]
 
 TOL = 1e-5                                      # |own - torch| <= TOL * (|W| * |x| + |b|): summation order only
 # module -> {"verified": the set of kernels (kernel_key) that agreed with torch on this module, "off": one disagreed (the module
@@ -195,6 +195,37 @@ def call(m, x):
         return m(x)
     finally:
         del m.forward
+
+
+class own_convs(object):
+    """Context manager: inside it every nn.Conv2d of `model` that the own kernels take runs on them WITHOUT the once-per-module
+    check -- for forwards whose values nobody uses (Quantity's build_net_structure trace: only which tensor OBJECT reaches which
+    module matters there).  A fresh process then does not enter the convolution library for the trace either: its first-use solver
+    search was 0.27 s of a one-shot script's 0.29 s in Quantity(model) (scripts/_dbg/ctor_probe.py).  Forward hooks still fire
+    (the patched forward is an instance attribute, Module.__call__ runs it); nothing stays on the modules."""
+
+    def __init__(self, model):
+        self.model, self.patched = model, []
+
+    def __enter__(self):
+        if not (enabled() and torch.cuda.is_available()):
+            return self
+        for m in self.model.modules():
+            if type(m) is not torch.nn.Conv2d or m.bias is None or "forward" in m.__dict__:
+                continue
+
+            def forward(x, m=m):
+                k = kind(m, x) if not torch.is_grad_enabled() else None
+                return plain(m, k, x, check=False) if k is not None else torch.nn.Conv2d.forward(m, x)
+            m.forward = forward
+            self.patched.append(m)
+        return self
+
+    def __exit__(self, *exc):
+        for m in self.patched:
+            m.__dict__.pop("forward", None)
+        self.patched = []
+        return False
 
 
 def _hooked(m):

@@ -158,6 +158,9 @@ class Quantity(_FusedForward, _FileInputs):
         through single-input chains.  Returns OrderedDict name -> {'inputs': [...], 'type': str}.
         """
         assert device.lower() in ("gpu", "cpu"), "Input device is not valid, please specify 'gpu' or 'cpu'"
+        dev = self._model_device(model)
+        shapes = [input_size] if isinstance(input_size, tuple) else list(input_size)
+        x = [torch.rand(*s, device=dev) for s in shapes]
         trace = []            # (name, type, [input tensors], output tensor), execution order
         handles = []
 
@@ -168,24 +171,37 @@ class Quantity(_FusedForward, _FileInputs):
         for m in model.modules():
             if type(m).__name__ in self._all_op_type:
                 handles.append(m.register_forward_hook(on_forward))
-        dev = self._model_device(model)
-        shapes = [input_size] if isinstance(input_size, tuple) else list(input_size)
-        x = [torch.rand(*s, device=dev) for s in shapes]
-        with torch.no_grad():
-            model(*x)
-        for h in handles:
-            h.remove()
+        # (only which tensor OBJECT reaches which module is taken from this forward: on the GPU its convolutions run on the own
+        #  kernels, unchecked, so that a fresh process does not pay the convolution library's first-use search for a trace.
+        #  Shape-only "meta" stand-ins would launch nothing at all, but their first use costs a fresh process more than this
+        #  forward does -- 0.47 s against 0.22 s -- and the libraries' start-up then lands in the first calibration.)
+        try:
+            with torch.no_grad(), _float_conv.own_convs(model):
+                model(*x)
+        finally:
+            for h in handles:
+                h.remove()
         self.layers_num = len(trace)
 
         producer = {}          # id(tensor) -> node name; tensors are kept alive by `trace`
-        fingerprint = {}       # tid -> node name, fallback when a tensor object was re-wrapped
+        fingerprint = {}       # tid -> node name, fallback when a tensor object was re-wrapped; filled when first asked for
+        fingerprinted = [0]
+
+        def by_fingerprint(t, upto):
+            for j in range(fingerprinted[0], upto):            # the outputs of the nodes before this one, first producer wins
+                o = trace[j][3]
+                if torch.is_tensor(o) and o.numel():
+                    fingerprint.setdefault(tid(o), trace[j][0])
+            fingerprinted[0] = max(fingerprinted[0], upto)
+            return fingerprint.get(tid(t))
+
         net = OrderedDict()
         for i, (name, kind, ins, out) in enumerate(trace):
             inputs = []
             for t in ins:
                 src = producer.get(id(t))
                 if src is None:
-                    src = fingerprint.get(tid(t)) if t.numel() else None
+                    src = by_fingerprint(t, i) if (i and t.numel()) else None     # (nothing was produced before node 0)
                 if src is not None:
                     inputs.append(src)
                 elif i != 0:
@@ -196,8 +212,6 @@ class Quantity(_FusedForward, _FileInputs):
                         raise ValueError("Same input and output id, the op {} is useful?".format(name))
                     raise AssertionError("Some layers returned same tensor.")
                 producer[id(out)] = name           # a pass-through op becomes the newest producer
-                if out.numel():
-                    fingerprint.setdefault(tid(out), name)
             net[name] = {"inputs": inputs, "type": kind}
         keep = [n for n, info in net.items() if info["type"] in self._cared_op_type]
         return self.prune_net_info(net, keep)

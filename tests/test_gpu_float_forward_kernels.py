@@ -992,3 +992,36 @@ def test_testlinear_keeps_the_two_calls_when_the_kernel_refuses_the_layer(monkey
         monkeypatch.undo()
         assert _float_conv.call_linear_qd(lin, x, 4, 8) is None                    # stays off
         assert _float_conv.call_linear_qd(nn.Linear(64, 12).cuda().eval(), x[:, :32].contiguous(), 4, 8) is None   # wrong width
+
+
+def test_graph_discovery_on_the_gpu_runs_on_the_own_kernels_and_finds_the_reference_graph(golden_dir, monkeypatch):
+    """Quantity(model) traces one forward for the graph (build_net_structure): on the GPU its convolutions run on this library's
+    kernels (unchecked: only tensor identities are used), so a fresh process does not enter the convolution library there either;
+    the graph is the reference's (golden G7), the same as with the library convolutions, no value fingerprint is computed (no
+    host read of a device value), and nothing stays on the modules."""
+    import json
+    import os
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_fabu import ResNet50
+    from tools import Quantity, pytorch_quantizer
+    with open(os.path.join(golden_dir, "g7_netinfo.json")) as fh:
+        ref = json.load(fh)["r50"]
+    model = merge_bn(cases.seed_model(ResNet50(), gamma_scale=0.5).eval()).cuda()
+    real, calls, tids = torch.nn.functional.conv2d, [], []
+    real_tid = pytorch_quantizer.tid
+
+    def counting(*a, **k):
+        calls[-1] += 1
+        return real(*a, **k)
+    for own in ("1", "0"):
+        monkeypatch.setenv("FQ_OWN_CONV1X1", own)
+        monkeypatch.setattr(torch.nn.functional, "conv2d", counting)
+        monkeypatch.setattr(pytorch_quantizer, "tid", lambda t: (tids.append(1), real_tid(t))[1])
+        calls.append(0)
+        with product_workdir(input_shape="1,3,224,224", device="gpu"):
+            q = Quantity(model)
+        monkeypatch.undo()
+        assert dict(q.net_info) == ref["net_info"] and list(q.net_info.keys()) == ref["net_info_order"]
+        assert q.cared_op_layer_names == ref["cared_op_layer_names"] and q.layers_num == ref["layers_num"]
+        assert not any("forward" in m.__dict__ or m._forward_hooks for m in model.modules())
+    assert calls == [0, 53] and tids == []

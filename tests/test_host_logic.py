@@ -361,3 +361,30 @@ def test_deferral_probe_finds_keepers_of_a_tensor_in_one_heap_pass():
     for t in many[:8]:
         _DeferralProbe.holders([t], [many])
     assert one_pass < (time.perf_counter() - t0) * 2                     # 64 tensors in one pass: cheaper than 16 single scans
+
+
+def test_graph_discovery_reads_values_only_for_an_edge_identity_does_not_show(monkeypatch):
+    """The value fingerprint (tid: four reductions and four host reads per tensor) is the fallback matcher: a net whose
+    edges all show as tensor identity never computes one -- on the GPU that was 123 x 4 synchronisations per Quantity(model) --
+    and a tensor that was re-wrapped between two modules (here: multiplied by one) is still found through it."""
+    from torch import nn
+    from tools import Quantity, pytorch_quantizer
+    calls = []
+    real = pytorch_quantizer.tid
+    monkeypatch.setattr(pytorch_quantizer, "tid", lambda t: (calls.append(1), real(t))[1])
+    got = _discover(cases.tiny_concat_net, "1,3,8,8")
+    assert calls == [] and len(got["net_info_order"]) > 5
+
+    class Scaled(nn.Module):
+        def __init__(self):
+            super(Scaled, self).__init__()
+            self.conv = nn.Conv2d(3, 4, 1)
+            self.relu = nn.ReLU()
+            self.conv2 = nn.Conv2d(4, 4, 1)
+
+        def forward(self, x):
+            return self.conv2(self.relu(self.conv(x) * torch.ones(4, 1, 1)))
+    with product_workdir(input_shape="1,3,8,8", device="cpu"):
+        q = Quantity(Scaled().eval())
+    assert q.layers_num == 3 and q.net_info["Conv2d_3"]["inputs"] == ["Conv2d_1"]        # (through ReLU_2, which is pruned)
+    assert len(calls) == 2                                   # the one output before ReLU_2, and its input
