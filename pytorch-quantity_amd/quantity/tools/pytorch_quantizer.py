@@ -67,6 +67,7 @@ class Quantity(_FusedForward, _FileInputs):
     # the statistics engine; tests substitute oracle-backed doubles to exercise the host logic on CPU
     collector_cls = DistributionCollector
     quantizer_cls = Quantizer
+    channel_collector_cls = None    # None: common.quantity.channel_collector.ChannelCollector (activation_quantize_per_channel)
     profile_phases = False      # synchronise at phase boundaries so that .timings are device times
     # statistics kernels on a side stream under the next forward: measured on MI355X (ResNet-50, batch
     # 128) +0.8 % images/s, while the histogram kernel drops from 5.2 to 3.5 TB/s under contention and
@@ -722,7 +723,9 @@ class Quantity(_FusedForward, _FileInputs):
         (cared tensor, channel) instead of one per tensor.  Returns {module name: [bit per channel]} and
         writes "<module name> b0 b1 ... b(C-1)" lines to ./workdir/feat_channel.table.  No merge-group
         pooling is applied (the reference defines it for per-tensor scales only); 'image' is included."""
-        from common.quantity.channel_collector import ChannelCollector
+        ChannelCollector = self.channel_collector_cls
+        if ChannelCollector is None:
+            from common.quantity.channel_collector import ChannelCollector
         rank, _world = _dist_state()
         names = ["image"] + list(self.net_info.keys())
         named_feats, hooks = self.regist_hook_outfeature(self.model)

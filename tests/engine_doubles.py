@@ -120,3 +120,68 @@ class OracleQuantizer(object):
             self._threshold_bin[n] = t
             self._threshold_value[n] = tb
             self._bits[n] = int(8 - 1 - math.ceil(math.log(tb, 2)))
+
+
+class OracleChannelCollector(StatCollectives):
+    """Stand-in for common.quantity.channel_collector.ChannelCollector (one row per (tensor, channel)): same methods, the
+    oracle's abs-max / histogram / KL on the channel slices.  Like the per-tensor double it only SAYS where its state is;
+    the all-reduces are the product's."""
+
+    def __init__(self, channels, statistic=1, device=None):
+        self._names = list(channels.keys())
+        self._channels = dict(channels)
+        self._first, row = {}, 0
+        for n in self._names:
+            self._first[n] = row
+            row += int(channels[n])
+        self._rows = row
+        self._statistic = statistic
+        self._max = np.zeros(row, dtype=np.float32)
+        self._hist = np.zeros((row, BINS), dtype=np.int64)
+        self._interval = None
+
+    @property
+    def rows(self):
+        return self._rows
+
+    def row_range(self, name):
+        return self._first[name], self._first[name] + self._channels[name]
+
+    def _slices(self, tensors):
+        for n in self._names:
+            if n not in tensors:
+                continue
+            t = tensors[n].detach().cpu().numpy().astype(np.float32, copy=False)
+            assert t.shape[1] == self._channels[n]
+            for c in range(t.shape[1]):
+                yield self._first[n] + c, np.ascontiguousarray(t[:, c]).ravel()
+
+    def refresh_max_val(self, tensors):
+        for row, x in self._slices(tensors):
+            self._max[row] = orc.absmax(x, self._max[row])
+
+    def intervals(self):
+        self._interval = (self._statistic * self._max / BINS + 1e-12).astype(np.float32, copy=False)
+        return self._interval
+
+    def add_to_distributions(self, tensors):
+        if self._interval is None:
+            self.intervals()
+        for row, x in self._slices(tensors):
+            orc.hist2048(x, np.float32(self._interval[row]), self._hist[row])
+
+    def _stat_tensors(self):
+        return torch.from_numpy(self._max), torch.from_numpy(self._hist)
+
+    def quantize(self):
+        bits = {}
+        self.threshold_bins = np.zeros(self._rows, dtype=np.int32)
+        for n in self._names:
+            lo, hi = self.row_range(n)
+            bits[n] = []
+            for row in range(lo, hi):
+                t = orc.kl_threshold(orc.normalize(self._hist[row]))
+                self.threshold_bins[row] = t
+                tb = (t + 0.5) * self._interval[row]
+                bits[n].append(int(8 - 1 - math.ceil(math.log(tb, 2))))
+        return bits

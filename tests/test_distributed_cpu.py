@@ -112,3 +112,74 @@ def test_four_and_eight_rank_gloo_calibration_equals_the_single_process_table(tm
     assert one["hist_sums"]["image"] == 10 * 2 * 3 * 32 * 32
     for r in range(1, world):
         assert json.load(open(str(tmp_path / "wn.json") + ".files.rank%d" % r)) == []
+
+
+# ---------------------------------------------------------------- the per-channel rows (BASELINE config 4's exchange)
+CHANNEL_WORKER = textwrap.dedent('''
+    import os, sys, json
+    sys.path[:0] = [r"{root}", r"{root}/pytorch-quantity_amd/quantity", r"{root}/tests", r"{root}/tests/golden"]
+    import numpy as np, torch, torch.distributed as dist
+    import cases
+    from engine_doubles import OracleChannelCollector
+    from workdir_util import product_workdir
+    from common.quantity import merge_bn
+    from tools import Quantity
+
+    class CpuQuantity(Quantity):
+        channel_collector_cls = OracleChannelCollector
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    rank = dist.get_rank() if world > 1 else 0
+    torch.set_num_threads(2)
+    with product_workdir(input_shape="1,3,16,16", device="cpu", max_cali_img_num=int(os.environ.get("FQ_TEST_MAX_CALI", "4"))) as tmp:
+        model = merge_bn(cases.seed_model(cases.tiny_vgg_net()).eval())
+        q = CpuQuantity(model)
+        bits = q.activation_quantize_per_channel(cases.calib_batches(int(os.environ.get("FQ_TEST_BATCHES", "5")), (2, 3, 16, 16)))
+        wd = os.path.join(tmp, "test", "workdir")
+        listing = sorted(os.path.relpath(os.path.join(d, f), wd) for d, _s, fs in os.walk(wd) for f in fs)
+        json.dump(listing, open(r"{out}" + ".files.rank%d" % rank, "w"))
+        c = q._channel_collector
+        mx, hist = c._stat_tensors()
+        json.dump({{"bits": bits, "rows": c.rows, "max": mx.tolist(), "hist_row_sums": hist.sum(1).tolist(),
+                   "hist_digest": int((hist * (1 + torch.arange(hist.shape[1]))).sum()),
+                   "table": open(os.path.join(wd, "feat_channel.table")).read() if rank == 0 else None}},
+                  open(r"{out}" + ".rank%d" % rank, "w"))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+''')
+
+
+def _run_channels(world, out, max_cali=4, batches=5, port=29671):
+    script = os.path.join(tempfile.mkdtemp(prefix="fq_dist_ch_"), "worker.py")
+    with open(script, "w") as fh:
+        fh.write(CHANNEL_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, OMP_NUM_THREADS="2", FQ_TEST_MAX_CALI=str(max_cali), FQ_TEST_BATCHES=str(batches))
+    if world == 1:
+        cmd = [sys.executable, script]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), script]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return [json.load(open(out + ".rank%d" % k)) for k in range(world)]
+
+
+@pytest.mark.timeout(1800)
+@pytest.mark.parametrize("world,max_cali", [(2, 4), (3, 0)])
+def test_per_channel_rows_are_shard_count_invariant(tmp_path, world, max_cali):
+    """BASELINE config 4's exchange -- one MAX all-reduce of the per-(tensor, channel) maxima, one SUM all-reduce of the
+    per-channel histograms -- on gloo ranks (the product's lines, `_collectives.py`, under `activation_quantize_per_channel`;
+    the rows themselves come from the oracle): every rank ends with the single-process maxima, histograms and bits, also a rank
+    that owned no batch (three ranks, one batch), and only rank 0 writes feat_channel.table."""
+    one = _run_channels(1, str(tmp_path / "c1.json"), max_cali=max_cali)[0]
+    many = _run_channels(world, str(tmp_path / "cn.json"), max_cali=max_cali, port=29671 + world)
+    assert one["rows"] > 3 and sum(one["hist_row_sums"][:3]) == (max_cali + 1) * 2 * 3 * 16 * 16        # the image's three channels
+    for r in many:
+        for key in ("bits", "rows", "max", "hist_row_sums", "hist_digest"):
+            assert r[key] == one[key], key
+    assert many[0]["table"] == one["table"] and one["table"].startswith("image ")
+    files = [json.load(open(str(tmp_path / "cn.json") + ".files.rank%d" % k)) for k in range(world)]
+    assert "feat_channel.table" in files[0] and all(f == [] for f in files[1:])
