@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.join(ROOT, "pytorch-quantity_amd", "quantity"))
 from common.quantity import _native as nat
 nat.LIB_PATH = nat.LIB_PATH.replace("libfq_hip.so", "libfq_hip_trace.so")
 C, H, K, R, st, pd = [int(v) for v in sys.argv[1:7]]
-B = 128
+B = int(os.environ.get("FQ_CONV_ONE_BATCH", "128"))
 x = torch.randn(B, C, H, H, device="cuda") * 2
 w = torch.randint(-127, 128, (K, C, R, R), device="cuda").float()
 qb = torch.randint(-100, 100, (K,), device="cuda").float()
