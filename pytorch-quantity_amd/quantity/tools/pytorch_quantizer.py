@@ -634,6 +634,13 @@ class Quantity(_FusedForward, _FileInputs):
                 and inplace is False and hasattr(collector, "prepare_distributions")):
             collector.prepare_distributions()
             ctl.fuse_collector, ctl.fuse_stat = collector, "hist"
+        elif eager_ok and self.fuse_bias_absmax and self.own_conv1x1 and not ctl.fuse_off and ctl.fuse_verified:
+            # Pass 2 without the producers' histograms (a later module overwrites hooked tensors in place, or fuse_hist is off):
+            # the convolutions stay on the own kernels all the same (their plain form; the statistics come from the hooks), so that
+            # pass 2 histograms the very values pass 1 took the maxima of.  They used to fall back to the convolution library here,
+            # whose kernels do not give the same bits from call to call: the histograms of such a model differed by a handful of
+            # elements from one calibration to the next (scripts/model_fuzz.py, round 5).
+            ctl.own_plain = True
         if plan is not None and plan["kind"] == "B":
             ctl.stop_after = plan["stop_after"] if plan["stop_after"] else None
             try:
@@ -656,7 +663,7 @@ class Quantity(_FusedForward, _FileInputs):
                 self._forward_with_stats(item, collector.add_to_distributions, named_feats)
         self._join_stat_stream()
         del cached
-        ctl.fuse_collector, ctl.fuse_stat = None, "max"
+        ctl.fuse_collector, ctl.fuse_stat, ctl.own_plain = None, "max", False
         if _dist_on():
             collector.all_reduce_hist()
         if self.profile_phases:
