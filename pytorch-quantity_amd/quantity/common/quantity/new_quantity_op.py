@@ -21,7 +21,7 @@ import torch
 from torch import nn
 
 from . import _native, _float_conv
-from .resident import QHandle, DeferredConv, resident_of, as_f32
+from .resident import QHandle, DeferredConv, resident_of, as_f32, carry
 
 QUANTIZE_BIT = 8
 
@@ -279,7 +279,7 @@ class NewConv2d(_IntegerSimLayer):
             if y is None:
                 return handle
             if handle is not None:
-                y._fq_resident = handle
+                carry(y, handle)
             if plan.relu:
                 y._fq_relu_done = True
             return y
@@ -344,7 +344,7 @@ class NewAdd(nn.Module):
                     return handle
                 out = handle.to_f32()
                 if plan.emit_int:
-                    out._fq_resident = handle
+                    carry(out, handle)
                 if plan.relu:
                     out._fq_relu_done = True
                 return out

@@ -92,13 +92,26 @@ def block_tail_proj_enabled():
     return os.environ.get("FQ_BLOCK_TAIL_PROJ", "1") != "0"
 
 
+def carry(t, handle):
+    """Attach the integer form `handle` to the fp32 tensor t that stands for the same values (a producer that serves both kinds of
+    consumers).  The attachment holds for the tensor AS WRITTEN BY ITS PRODUCER: its version counter is remembered, and a tensor
+    that was written to since -- an in-place nn.ReLU between two consumers is legal PyTorch -- no longer has an integer form
+    (resident_of).  Found by scripts/recon_fuzz.py: the consumer behind such a ReLU read the integers from before it."""
+    t._fq_resident = handle
+    t._fq_resident_version = t._version
+    return t
+
+
 def resident_of(x):
-    """The integer form of an activation, if it has one (a handle, or an fp32 tensor carrying one)."""
+    """The integer form of an activation, if it has one (a handle, or an fp32 tensor carrying one that is still current)."""
     if type(x) is QHandle:
         return x
     if type(x) is DeferredConv:
         return x.materialise()
-    return getattr(x, "_fq_resident", None)
+    h = getattr(x, "_fq_resident", None)
+    if h is not None and getattr(x, "_fq_resident_version", None) != x._version:
+        return None                                          # written to since its producer attached the integers
+    return h
 
 
 def as_f32(x):
@@ -191,7 +204,7 @@ class _MaxPoolResident(object):
             return out
         t = out.to_f32()
         if plan.emit_int:
-            t._fq_resident = out
+            carry(t, out)
         return t
 
 

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""GPU fuzz of the integer-simulation model with RESIDENT integer activations on random model topologies (the generator of
+scripts/model_fuzz.py): calibrate, rewrite, rebuild as ReconModel, then the logits with fp32 module boundaries (the reference's
+form) against the logits of the resident plan (int8 / int16 hand-offs, fused ReLUs, conv + NewAdd in one kernel, block tails, pools
+on integers), eagerly and as one HIP graph: bit for bit.  The planner decides per edge who may hand over integers; a wrong decision
+on a graph nobody wrote a test for shows here.
+usage: recon_fuzz.py [models=40] [seed=1]"""
+import importlib.util, os, random, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("model_fuzz", os.path.join(ROOT, "scripts", "model_fuzz.py"))
+mf = importlib.util.module_from_spec(spec)
+sys.modules["model_fuzz"] = mf                        # (the reference's flow pickles whole models: the class must be importable)
+spec.loader.exec_module(mf)
+from common.quantity import resident
+from tools import Quantity, Reconstruction
+from workdir_util import product_workdir
+
+
+def build(i, seed):
+    rng = random.Random(seed * 100003 + i)
+    size = rng.choice([16, 24, 32])
+    torch.manual_seed(seed * 7919 + i)
+    model = mf.Net(rng, size).eval().cuda()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.5)
+    return model, size, rng
+
+
+def recon_of(model, twin, data):
+    """Calibrate `model` on `data`, quantise and rewrite its weights, and rebuild `twin` (the same weights, as the reference's flow
+    loads them) as the integer-simulation model.  Call inside product_workdir()."""
+    out = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        q = Quantity(model)
+        q.activation_quantize(data)
+        q.weight_quantize()
+        q.rewrite_weight()
+        rec = Reconstruction(twin)
+        return rec.ReconModel(rec.get_quantity_information(), "./workdir/recon.pth")
+    finally:
+        sys.stdout = out
+
+
+def run(n, seed, log=print):
+    bad, seen = 0, {}
+    for i in range(n):
+        model, size, rng = build(i, seed)
+        bs = rng.choice([4, 8])
+        data = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
+        out = sys.stdout
+        try:
+            with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=1):
+                net = recon_of(model, build(i, seed)[0], data)
+                x = data[0][0]
+                with torch.no_grad():
+                    plain = net(x)
+                    summary = resident.enable(net, x)
+                    got = net(x)
+                    x2 = torch.flip(x, dims=[0]) * 0.5
+                    got2 = net(x2)
+                    graphed = resident.capture(net, x)
+                    g1, g2 = graphed(x).clone(), graphed(x2).clone()
+                    resident.disable(net)
+                    want2 = net(x2)
+        except Exception as e:
+            sys.stdout = out
+            bad += 1
+            log("model %d (seed %d): %s: %s" % (i, seed, type(e).__name__, str(e)[:300]))
+            continue
+        for k, v in summary.items():
+            if isinstance(v, int):
+                seen[k] = seen.get(k, 0) + v
+        problems = []
+        if not torch.equal(got, plain) or not torch.equal(got2, want2):
+            problems.append("resident logits differ (max %.3g)" % float((got - plain).abs().max()))
+        if not torch.equal(g1, plain) or not torch.equal(g2, want2):
+            problems.append("graphed logits differ")
+        if problems:
+            bad += 1
+            log("model %d (seed %d, %d modules): %s; plan %s" % (i, seed, model.n, "; ".join(problems), {k: v for k, v in summary.items() if isinstance(v, int)}))
+    return bad, seen
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad, seen = run(n, seed)
+    print("recon_fuzz: %d random models (seed %d), %d with a finding; plans in all: %s" % (n, seed, bad, seen))

@@ -7,9 +7,30 @@ import importlib.util
 import os
 
 import pytest
+import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class SharedSum(torch.nn.Module):
+    def __init__(self):
+        super(SharedSum, self).__init__()
+        from common.quantity import Eltwise, Concat, View
+        self.stem = torch.nn.Conv2d(3, 16, 3, padding=1); self.r0 = torch.nn.ReLU()
+        self.c1 = torch.nn.Conv2d(16, 16, 1); self.add = Eltwise()
+        self.raw = torch.nn.Conv2d(16, 8, 1)                    # reads the sum as the Eltwise wrote it
+        self.r1 = torch.nn.ReLU(inplace=True)                   # ... which this ReLU then overwrites
+        self.act = torch.nn.Conv2d(16, 8, 3, padding=1)         # reads the rectified sum
+        self.cat = Concat(); self.r2 = torch.nn.ReLU()
+        self.view = View(); self.fc = torch.nn.Linear(16 * 16 * 16, 10)
+
+    def forward(self, x):
+        x = self.r0(self.stem(x))
+        s = self.add(self.c1(x), x)
+        a = self.raw(s)
+        b = self.act(self.r1(s))
+        return self.fc(self.view(self.r2(self.cat(a, b))))
 
 
 def test_random_topologies_give_the_unfused_tables():
@@ -56,3 +77,47 @@ def test_a_model_with_in_place_relus_calibrates_to_the_same_bits_every_time(monk
         assert torch.equal(r[2], first[2]) and r[1] == first[1] and r[3] == first[3]
     # the one layer the own kernels do not take (3x3 on 8 channels) is the only one that ever reaches the library, in either pass
     assert calls and all(shape[1] == 8 for shape in calls), calls
+
+
+def test_resident_integer_plans_of_random_topologies_give_the_boundary_logits():
+    """scripts/recon_fuzz.py: the same random graphs calibrated, rewritten and rebuilt as ReconModel -- the logits of the resident plan
+    (integer hand-offs, fused ReLUs, conv + NewAdd, block tails with and without a projection, pools on integers), eager and as one
+    HIP graph, on two inputs, equal the logits with fp32 module boundaries bit for bit."""
+    import sys
+    spec = importlib.util.spec_from_file_location("recon_fuzz", os.path.join(ROOT, "scripts", "recon_fuzz.py"))
+    rf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rf)
+    found = []
+    bad, seen = rf.run(40, 3, log=found.append)
+    assert bad == 0, found
+    assert seen["resident_convs"] > 300 and seen["fused_conv_adds"] > 40 and seen["fused_relus"] > 200, seen
+    assert seen["fused_block_tails"] > 5 and seen["fused_projections"] > 0 and seen["resident_pools"] > 5, seen
+
+
+def test_an_in_place_relu_between_two_consumers_of_a_sum_invalidates_its_integer_form():
+    """A NewAdd whose sum is read RAW by one convolution, then overwritten by an in-place nn.ReLU, then read by another: legal
+    PyTorch (the first reader ran before the ReLU).  The producer serves both kinds of consumers with an fp32 tensor that carries
+    its integer form; the in-place ReLU writes the fp32 values only, so the integers are stale from then on and the second
+    convolution must not read them (resident.carry remembers the tensor's version counter).  Before that, resident.enable()
+    refused such a model ("does not reproduce the fp32-boundary forward"; scripts/recon_fuzz.py, 14 of 900 random models)."""
+    import sys
+    spec = importlib.util.spec_from_file_location("recon_fuzz", os.path.join(ROOT, "scripts", "recon_fuzz.py"))
+    rf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(rf)
+    from common.quantity import resident
+    from workdir_util import product_workdir
+
+    def make():
+        torch.manual_seed(3)
+        return SharedSum().eval().cuda()
+    data = [(torch.randn(8, 3, 16, 16, device="cuda"), torch.zeros(8, dtype=torch.long)) for _ in range(2)]
+    sys.modules.setdefault("test_gpu_model_fuzz", sys.modules[__name__])
+    with product_workdir(input_shape="1,3,16,16", device="gpu", max_cali_img_num=1):
+        net = rf.recon_of(make(), make(), data)
+        x = data[0][0]
+        with torch.no_grad():
+            plain = net(x)
+            summary = resident.enable(net, x)                 # (verifies the plan on x: raised before the fix)
+            assert torch.equal(net(x), plain)
+            assert torch.equal(net(torch.flip(x, dims=[0])), torch.flip(plain, dims=[0]))
+        assert summary["resident_adds"] == 1 and summary["resident_convs"] >= 3, summary
