@@ -7,7 +7,9 @@ i, seed = int(sys.argv[1]), int(sys.argv[2])
 rng = random.Random(seed * 100003 + i)
 size = rng.choice([16, 24, 32])
 torch.manual_seed(seed * 7919 + i)
-model = mf.Net(rng, size).eval().cuda()
+odd = "odd" in sys.argv[3:]
+torch.backends.cudnn.deterministic = odd
+model = mf.Net(rng, size, odd).eval().cuda()
 with torch.no_grad():
     for p in model.parameters():
         p.mul_(1.5)
@@ -18,10 +20,10 @@ for step in model.plan:
     m = getattr(model, step[1])
     print("  %-4s %-50s %s -> %s" % (step[1], str(m)[:50], step[2], step[3]))
 a = mf.calibrate(model, size, batches)
-off = tuple(sys.argv[3].split(",")) if len(sys.argv) > 3 else mf.SWITCHES
+off = tuple(sys.argv[4].split(",")) if len(sys.argv) > 4 else mf.SWITCHES
 b = mf.calibrate(model, size, batches, off=off)
 print("second calibration without", off)
-names = list(a[0].keys())
+names = a[5]
 for r, k in enumerate(names):
     ha, hb = a[2][r].double(), b[2][r].double()
     flag = ("" if a[0][k] == b[0][k] else "   <-- bits differ") + ("" if torch.equal(ha, hb) and a[1][k] == b[1][k] else "  *")

@@ -17,11 +17,11 @@ from tools import Quantity, Reconstruction
 from workdir_util import product_workdir
 
 
-def build(i, seed):
+def build(i, seed, odd=False):
     rng = random.Random(seed * 100003 + i)
     size = rng.choice([16, 24, 32])
     torch.manual_seed(seed * 7919 + i)
-    model = mf.Net(rng, size).eval().cuda()
+    model = mf.Net(rng, size, odd).eval().cuda()
     with torch.no_grad():
         for p in model.parameters():
             p.mul_(1.5)
@@ -44,16 +44,16 @@ def recon_of(model, twin, data):
         sys.stdout = out
 
 
-def run(n, seed, log=print):
+def run(n, seed, log=print, odd=False):
     bad, seen = 0, {}
     for i in range(n):
-        model, size, rng = build(i, seed)
+        model, size, rng = build(i, seed, odd)
         bs = rng.choice([4, 8])
         data = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
         out = sys.stdout
         try:
             with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=1):
-                net = recon_of(model, build(i, seed)[0], data)
+                net = recon_of(model, build(i, seed, odd)[0], data)
                 x = data[0][0]
                 with torch.no_grad():
                     plain = net(x)
@@ -87,5 +87,6 @@ def run(n, seed, log=print):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    bad, seen = run(n, seed)
-    print("recon_fuzz: %d random models (seed %d), %d with a finding; plans in all: %s" % (n, seed, bad, seen))
+    odd = len(sys.argv) > 3 and sys.argv[3] == "odd"
+    bad, seen = run(n, seed, odd=odd)
+    print("recon_fuzz%s: %d random models (seed %d), %d with a finding; plans in all: %s" % (" odd" if odd else "", n, seed, bad, seen))

@@ -121,3 +121,23 @@ def test_an_in_place_relu_between_two_consumers_of_a_sum_invalidates_its_integer
             assert torch.equal(net(x), plain)
             assert torch.equal(net(torch.flip(x, dims=[0])), torch.flip(plain, dims=[0]))
         assert summary["resident_adds"] == 1 and summary["resident_convs"] >= 3, summary
+
+
+def test_random_topologies_with_layers_the_library_keeps_and_the_per_channel_rows():
+    """The same generator with depthwise and dilated convolutions and nearest-neighbour upsampling here and there (layers that stay
+    on the convolution library in the middle of a fused forward; its deterministic mode makes 'bit for bit' meaningful), and the
+    per-(tensor, channel) calibration of random models: equal bit for bit when repeated, and consistent with the per-tensor one (a
+    tensor's maximum is its largest channel maximum, its histogram holds as many elements as its channels' histograms together)."""
+    spec = importlib.util.spec_from_file_location("model_fuzz", os.path.join(ROOT, "scripts", "model_fuzz.py"))
+    mf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mf)
+    was = torch.backends.cudnn.deterministic
+    try:
+        found = []
+        bad, _seen = mf.run(30, 12, log=found.append, odd=True)
+        assert bad == 0, [m for m in found if not m.startswith("  (")]
+        found = []
+        assert mf.run_channels(20, 13, log=found.append) == 0, found
+        assert mf.run_channels(12, 14, log=found.append, odd=True) == 0, found
+    finally:
+        torch.backends.cudnn.deterministic = was
