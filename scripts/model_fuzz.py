@@ -178,7 +178,26 @@ class Net(nn.Module):
         return t["y"]
 
 
-def calibrate(model, size, batches, off=()):
+def calibrate(model, size, batches, off=(), cache_gb=None, plan=None):
+    """One calibration.  cache_gb: what pass 1 may keep for pass 2 (FQ_ACT_CACHE_GB; None: the engine's own rule -- nothing in a
+    process without a warm pool); plan: "A" / "B" forces the cache plan (FQ_CACHE_PLAN)."""
+    saved = {k: os.environ.get(k) for k in ("FQ_ACT_CACHE_GB", "FQ_CACHE_PLAN")}
+    for k, v in (("FQ_ACT_CACHE_GB", cache_gb), ("FQ_CACHE_PLAN", plan)):
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = str(v)
+    try:
+        return _calibrate(model, size, batches, off)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _calibrate(model, size, batches, off=()):
     with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=len(batches) - 1) as tmp:
         q = Quantity(model)
         for s in off:
@@ -244,6 +263,42 @@ def run_channels(n, seed, log=print, odd=False):
             bad += 1
             log("model %d (seed %d, %d modules): %s" % (i, seed, model.n, "; ".join(problems[:4])))
     return bad
+
+
+def run_cache(n, seed, log=print, odd=False):
+    """The activation cache on n random models: nothing kept / a few MB (the deepest tensors of every batch: plan B, pass 2 re-runs
+    a prefix of the network and stops) / more (whole batches: plan A) / everything, each plan also forced -- all must give the
+    statistics of the calibration without a cache bit for bit (the kept tensors ARE the ones pass 1 took the maxima of)."""
+    torch.backends.cudnn.deterministic = bool(odd)
+    bad, plans = 0, {}
+    for i in range(n):
+        rng = random.Random(seed * 100003 + i)
+        size = rng.choice([16, 24, 32])
+        torch.manual_seed(seed * 7919 + i)
+        model = Net(rng, size, odd).eval().cuda()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.5)
+        bs = rng.choice([4, 8])
+        batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(4)]
+        try:
+            base = calibrate(model, size, batches, cache_gb=0)
+            problems = []
+            for gb, plan in ((0.002, None), (0.002, "B"), (0.01, None), (0.01, "A"), (0.03, "B"), (4, None)):
+                c = calibrate(model, size, batches, cache_gb=gb, plan=plan)
+                kind = (c[4].get("cache_plan") or {}).get("kind")
+                plans[(kind, c[4].get("cache_bytes", 0) > 0)] = plans.get((kind, c[4].get("cache_bytes", 0) > 0), 0) + 1
+                if c[3] != base[3] or c[1] != base[1] or not torch.equal(c[2], base[2]):
+                    rows = [k for r, k in enumerate(base[5]) if not torch.equal(c[2][r], base[2][r]) or c[1][k] != base[1][k]]
+                    problems.append("cache %s GB plan %s (%s, %d bytes kept): rows %s differ" % (gb, plan, c[4].get("cache_plan"), c[4].get("cache_bytes", 0), rows[:5]))
+        except Exception as e:
+            bad += 1
+            log("model %d (seed %d): %s: %s" % (i, seed, type(e).__name__, str(e)[:300]))
+            continue
+        if problems:
+            bad += 1
+            log("model %d (seed %d, %d modules): %s" % (i, seed, model.n, "; ".join(problems[:3])))
+    return bad, plans
 
 
 def run(n, seed, log=print, odd=False):
@@ -315,6 +370,10 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     odd = "odd" in sys.argv[3:]
+    if "cache" in sys.argv[3:]:
+        bad, plans = run_cache(n, seed, odd=odd)
+        print("model_fuzz cache%s: %d random models (seed %d), %d with a finding; (plan, something kept) -> calibrations: %s" % (" odd" if odd else "", n, seed, bad, plans))
+        return
     if "channels" in sys.argv[3:]:
         print("model_fuzz channels%s: %d random models (seed %d), %d with a finding" % (" odd" if odd else "", n, seed, run_channels(n, seed, odd=odd)))
         return

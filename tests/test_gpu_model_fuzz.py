@@ -139,5 +139,10 @@ def test_random_topologies_with_layers_the_library_keeps_and_the_per_channel_row
         found = []
         assert mf.run_channels(20, 13, log=found.append) == 0, found
         assert mf.run_channels(12, 14, log=found.append, odd=True) == 0, found
+        # ... and the activation cache: nothing kept / the deepest tensors of every batch (plan B: pass 2 re-runs a prefix and stops)
+        # / whole batches (plan A) / everything -- the statistics of the calibration without a cache, bit for bit
+        bad, plans = mf.run_cache(16, 15, log=found.append)
+        assert bad == 0, found
+        assert plans.get(("B", True), 0) > 10 and plans.get(("A", True), 0) > 10, plans
     finally:
         torch.backends.cudnn.deterministic = was
