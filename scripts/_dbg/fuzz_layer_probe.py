@@ -8,14 +8,8 @@ from common.quantity import _float_conv
 i, seed, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
 odd = "odd" in sys.argv[4:]
 torch.backends.cudnn.deterministic = odd
-rng = random.Random(seed * 100003 + i)
-size = rng.choice([16, 24, 32])
-torch.manual_seed(seed * 7919 + i)
-model = mf.Net(rng, size, odd).eval().cuda()
-with torch.no_grad():
-    for p in model.parameters():
-        p.mul_(1.5)
-bs = rng.choice([4, 8])
+odd = False
+model, size, bs, rng = mf.random_net(i, seed, odd, "cuda")
 x = torch.randn(bs, 3, size, size, device="cuda")
 m = getattr(model, name)
 print(m)

@@ -4,16 +4,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 spec = importlib.util.spec_from_file_location("model_fuzz", os.path.join(ROOT, "scripts", "model_fuzz.py"))
 mf = importlib.util.module_from_spec(spec); spec.loader.exec_module(mf)
 i, seed = int(sys.argv[1]), int(sys.argv[2])
-rng = random.Random(seed * 100003 + i)
-size = rng.choice([16, 24, 32])
-torch.manual_seed(seed * 7919 + i)
 odd = "odd" in sys.argv[3:]
 torch.backends.cudnn.deterministic = odd
-model = mf.Net(rng, size, odd).eval().cuda()
-with torch.no_grad():
-    for p in model.parameters():
-        p.mul_(1.5)
-bs = rng.choice([4, 8])
+model, size, bs, rng = mf.random_net(i, seed, odd, "cuda")
 batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
 print("size", size, "batch", bs)
 for step in model.plan:

@@ -9,8 +9,7 @@ from common.quantity import resident, _native
 from tools import Quantity, Reconstruction
 from workdir_util import product_workdir
 i, seed = int(sys.argv[1]), int(sys.argv[2])
-model, size, rng = rf.build(i, seed)
-bs = rng.choice([4, 8])
+model, size, bs = rf.build(i, seed)
 data = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
 print("size", size, "batch", bs)
 for step in model.plan:

@@ -18,14 +18,8 @@ from workdir_util import product_workdir
 
 
 def build(i, seed, odd=False):
-    rng = random.Random(seed * 100003 + i)
-    size = rng.choice([16, 24, 32])
-    torch.manual_seed(seed * 7919 + i)
-    model = mf.Net(rng, size, odd).eval().cuda()
-    with torch.no_grad():
-        for p in model.parameters():
-            p.mul_(1.5)
-    return model, size, rng
+    model, size, bs, _rng = mf.random_net(i, seed, odd, "cuda")
+    return model, size, bs
 
 
 def recon_of(model, twin, data):
@@ -47,8 +41,7 @@ def recon_of(model, twin, data):
 def run(n, seed, log=print, odd=False):
     bad, seen = 0, {}
     for i in range(n):
-        model, size, rng = build(i, seed, odd)
-        bs = rng.choice([4, 8])
+        model, size, bs, rng = mf.random_net(i, seed, odd, "cuda")
         data = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
         out = sys.stdout
         try:

@@ -340,3 +340,177 @@ def tiny_concat_net():
             return self.fc(self.view(self.pool(y)))
 
     return TinyConcatNet()
+
+
+# ---------------------------------------------------------------- random topologies (scripts/model_fuzz.py, golden G11)
+import torch.nn as nn  # noqa: E402
+
+
+class RandomNet(nn.Module):
+    """A random graph: `plan` is a list of steps over a dictionary of live tensors; modules are attributes m0, m1, ..."""
+
+    def __init__(self, rng, size, odd=False):
+        super(RandomNet, self).__init__()
+        from common.quantity import Eltwise, Concat, View      # (the product's, or the reference's when a golden is captured)
+        self.plan, self.n = [], 0
+        ch = {"x": 3}
+        hw = {"x": size}
+        cur = "x"
+
+        def add(module):
+            name = "m%d" % self.n
+            self.n += 1
+            setattr(self, name, module)
+            return name
+
+        def conv(src, cout, k=None, s=1):
+            k = k if k is not None else rng.choice([1, 1, 3, 3, 5])
+            if hw[src] // s < 2:
+                s = 1
+            # (odd: now and then a layer the own kernels do not take -- depthwise, dilated -- which stays on the library in the
+            #  middle of a fused forward)
+            kw, pad = {}, k // 2
+            if odd and k == 3 and rng.random() < 0.25:
+                if rng.random() < 0.5 and cout == ch[src]:
+                    kw["groups"] = cout
+                elif hw[src] >= 8:
+                    kw["dilation"], pad = 2, 2
+            m = add(nn.Conv2d(ch[src], cout, k, stride=s, padding=pad, **kw))
+            out = "t%d" % self.n
+            self.plan.append(("call", m, [src], out))
+            ch[out], hw[out] = cout, (hw[src] + 2 * pad - (kw.get("dilation", 1) * (k - 1) + 1)) // s + 1
+            return out
+
+        inplace_p = 0.3 if rng.random() < 0.2 else 0.0      # one model in five has in-place ReLUs (everything then runs per tensor)
+
+        def relu(src):
+            m = add(nn.ReLU(rng.random() < inplace_p))
+            out = "t%d" % self.n
+            self.plan.append(("call", m, [src], out))
+            ch[out], hw[out] = ch[src], hw[src]
+            return out
+
+        widths = [8, 16, 64, 128, 128, 256]                 # (fq_conv1x1_add_f32 takes Cin % 16 == 0, Cout % 128 == 0)
+        cur = relu(conv("x", rng.choice([8, 16, 64]), k=rng.choice([3, 5, 7]), s=rng.choice([1, 2])))
+        for _ in range(rng.randint(2, 5)):
+            kind = rng.choice(["plain", "res", "res", "resproj", "concat", "pool", "twice", "shared", "bneck2", "projhead"])
+            c = ch[cur]
+
+            def bottleneck(src, mid, cout, project):
+                y = relu(conv(src, mid, k=1))
+                y = relu(conv(y, mid, k=3))
+                y = conv(y, cout, k=1)
+                short = conv(src, cout, k=1) if project else src
+                m = add(Eltwise())
+                out = "t%d" % self.n
+                self.plan.append(("call", m, [y, short], out))
+                ch[out], hw[out] = cout, hw[y]
+                return relu(out)
+            if kind == "bneck2":
+                # ResNet's shape: two or three bottlenecks of 4 C channels in a row (the integer model fuses conv3 + NewAdd + ReLU + the
+                # next conv1 into one kernel there; the float forward conv3 + Eltwise + ReLU)
+                C = rng.choice([64, 64, 128])
+                if c != 4 * C:
+                    cur = relu(conv(cur, 4 * C, k=1))
+                for _ in range(rng.randint(2, 3)):
+                    cur = bottleneck(cur, C, 4 * C, False)
+                continue
+            if kind == "projhead":
+                # a stage's first block: 64 -> 256 with a projection shortcut, then an identity block
+                if c != 64:
+                    cur = relu(conv(cur, 64, k=1))
+                cur = bottleneck(cur, 64, 256, True)
+                cur = bottleneck(cur, 64, 256, False)
+                continue
+            if kind == "plain":
+                cur = relu(conv(cur, rng.choice(widths), s=rng.choice([1, 1, 2])))
+            elif kind in ("res", "resproj"):
+                mid = rng.choice([8, 16, 16, 64])
+                cout = c if kind == "res" else rng.choice(widths)
+                s = rng.choice([1, 2]) if kind == "resproj" and hw[cur] >= 8 else 1
+                y = relu(conv(cur, mid, k=1))
+                y = relu(conv(y, mid, k=3, s=s))
+                y = conv(y, cout, k=1)
+                short = cur if kind == "res" else conv(cur, cout, k=1, s=s)
+                m = add(Eltwise())
+                out = "t%d" % self.n
+                self.plan.append(("call", m, [y, short] if rng.random() < 0.7 else [short, y], out))
+                ch[out], hw[out] = cout, hw[y]
+                cur = relu(out) if rng.random() < 0.85 else out
+            elif kind == "concat":
+                a, b = conv(cur, rng.choice([8, 16]), k=3), conv(cur, rng.choice([8, 16]), k=1)
+                m = add(Concat())
+                out = "t%d" % self.n
+                self.plan.append(("call", m, [a, b], out))
+                ch[out], hw[out] = ch[a] + ch[b], hw[a]
+                cur = relu(out)
+            elif kind == "pool" and odd and hw[cur] <= 8 and rng.random() < 0.5:
+                m = add(nn.UpsamplingNearest2d(scale_factor=2))
+                out = "t%d" % self.n
+                self.plan.append(("call", m, [cur], out))
+                ch[out], hw[out] = c, 2 * hw[cur]
+                cur = relu(conv(out, c, k=3))
+            elif kind == "pool" and hw[cur] >= 6:
+                k, s, p = rng.choice([(3, 2, 1), (2, 2, 0), (3, 1, 1)])
+                m = add(nn.MaxPool2d(k, s, p))
+                out = "t%d" % self.n
+                self.plan.append(("call", m, [cur], out))
+                ch[out], hw[out] = c, (hw[cur] + 2 * p - k) // s + 1
+                cur = out
+            elif kind == "twice":
+                # one convolution output read by TWO consumers: its ReLU and, raw, an Eltwise further down
+                y = conv(cur, c, k=1)
+                r = relu(y)
+                z = conv(r, c, k=3)
+                m = add(Eltwise())
+                out = "t%d" % self.n
+                self.plan.append(("call", m, [z, y], out))
+                ch[out], hw[out] = c, hw[z]
+                cur = relu(out)
+            elif kind == "shared":
+                # the sum of a residual block read by two branches
+                y = conv(cur, c, k=1)
+                m = add(Eltwise())
+                s_ = "t%d" % self.n
+                self.plan.append(("call", m, [y, cur], s_))
+                ch[s_], hw[s_] = c, hw[y]
+                a, b = conv(s_, 8, k=1), relu(s_)
+                b = conv(b, 8, k=3)
+                m = add(Concat())
+                out = "t%d" % self.n
+                self.plan.append(("call", m, [a, b], out))
+                ch[out], hw[out] = 16, hw[a]
+                cur = relu(out)
+        if rng.random() < 0.5 and hw[cur] > 1:
+            m = add(nn.AvgPool2d(hw[cur]))
+            out = "t%d" % self.n
+            self.plan.append(("call", m, [cur], out))
+            ch[out], hw[out] = ch[cur], 1
+            cur = out
+        m = add(View())
+        out = "t%d" % self.n
+        self.plan.append(("call", m, [cur], out))
+        feat = ch[cur] * hw[cur] * hw[cur]
+        m2 = add(nn.Linear(feat, 10))
+        self.plan.append(("call", m2, [out], "y"))
+
+    def forward(self, x):
+        t = {"x": x}
+        for _op, m, ins, out in self.plan:
+            t[out] = getattr(self, m)(*[t[i] for i in ins])
+        return t["y"]
+
+
+def random_net(index, seed, odd=False, device="cpu"):
+    """Model `index` of the seeded family: (model in eval mode, image size, batch size, the generator's rng after the draw)."""
+    import random
+    import torch
+    rng = random.Random(seed * 100003 + index)
+    size = rng.choice([16, 24, 32])
+    torch.manual_seed(seed * 7919 + index)
+    model = RandomNet(rng, size, odd).eval()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.5)
+    bs = rng.choice([4, 8])
+    return model.to(device), size, bs, rng

@@ -2,7 +2,7 @@
 """Capture end-to-end golden fixtures (G3, G4, G6, G7 of SURVEY.md section 8c) by running the imported
 reference in the build container:
 
-    python tests/golden/make_golden_e2e.py [r18] [g6] [g7]
+    python tests/golden/make_golden_e2e.py [r18] [g6] [g7] [dkl] [small] [random]
 
 Writes tests/golden/g3_r18_e2e.json (+ g4_r18_recon.npz), g6_rewriter.json, g7_netinfo.json.
 Fixtures hold inputs' recipes and the reference's outputs only.
@@ -203,6 +203,42 @@ def capture_small(cq, tl):
         json.dump(out, fh, indent=1, sort_keys=True)
 
 
+RANDOM_GRAPHS = [(i, 101, False) for i in range(20)] + [(i, 102, True) for i in range(10)]      # (index, seed, odd): golden G11
+
+
+def capture_random(cq, tl):
+    """G11: thirty random topologies (cases.random_net: residual blocks with and without projection, two consumers of one tensor,
+    concatenations, pools, in-place ReLUs; ten of them with depthwise / dilated convolutions and upsampling) through the REFERENCE:
+    graph discovery, merge groups, the calibration's maxima and feat.table, weight.table.  A graph the reference itself rejects (its
+    value fingerprints collide, or it finds an in-place module "useless") is recorded with the exception's type."""
+    import torch
+    out = {}
+    for (index, seed, odd) in RANDOM_GRAPHS:
+        tag = "%d/%d%s" % (index, seed, "/odd" if odd else "")
+        model, size, bs, _rng = cases.random_net(index, seed, odd)
+        rec = {"size": size, "batch": bs}
+        try:
+            with _refenv.reference_workdir(input_shape="1,3,%d,%d" % (size, size), max_cali_img_num=2) as tmp:
+                torch.manual_seed(0)
+                q = tl.Quantity(model)
+                rec.update({"net_info": {k: v for k, v in q.net_info.items()}, "net_info_order": list(q.net_info.keys()),
+                            "cared_op_layer_names": q.cared_op_layer_names, "merge_groups": q.get_merge_groups(q.net_info),
+                            "layers_num": q.layers_num})
+                q.activation_quantize(cases.calib_batches(3, (bs, 3, size, size), seed=9000 + index))
+                wd = os.path.join(tmp, "test", "workdir")
+                rec["feat_table"] = _read(os.path.join(wd, "feat.table"))
+                q.weight_quantize()
+                rec["weight_table"] = _read(os.path.join(wd, "weight.table"))
+        except Exception as e:                               # what the reference does with this graph is part of the golden
+            rec = {"size": size, "batch": bs, "reference_error": type(e).__name__, "message": str(e)[:60]}
+            print("random", tag, "reference raises", type(e).__name__, str(e)[:80])
+        out[tag] = rec
+        if "feat_table" in rec:
+            print("random", tag, "nodes", len(rec["net_info"]), "feat.table:", rec["feat_table"].replace("\n", " | ")[:100])
+    with open(os.path.join(HERE, "g11_random_graphs.json"), "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+
+
 def capture_g6(cq, tl):
     """BiasReWriter on a crafted directory: int8 wrap, negative bits, MAX_SHIFT capping."""
     import tempfile
@@ -291,6 +327,8 @@ def main():
         capture_dkl(cq, tl)
     if "small" in which:
         capture_small(cq, tl)
+    if "random" in which:
+        capture_random(cq, tl)
 
 
 if __name__ == "__main__":

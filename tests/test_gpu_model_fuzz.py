@@ -13,6 +13,34 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+class InPlaceRelus(torch.nn.Module):
+    """The shape scripts/model_fuzz.py found (model 138 of seed 6 at the time): 3x3 stride-2 convolutions followed by in-place ReLUs,
+    and one layer the own kernels do not take (3x3 on 8 channels)."""
+
+    def __init__(self):
+        super(InPlaceRelus, self).__init__()
+        from common.quantity import Eltwise, View
+        nn = torch.nn
+        self.stem = nn.Conv2d(3, 64, 7, stride=2, padding=3); self.r0 = nn.ReLU()
+        self.c1 = nn.Conv2d(64, 256, 3, padding=1); self.r1 = nn.ReLU()
+        self.c2 = nn.Conv2d(256, 8, 1); self.r2 = nn.ReLU(inplace=True)
+        self.c3 = nn.Conv2d(8, 8, 3, padding=1); self.r3 = nn.ReLU()
+        self.c4 = nn.Conv2d(8, 256, 1); self.add = Eltwise(); self.r4 = nn.ReLU()
+        self.c5 = nn.Conv2d(256, 128, 3, stride=2, padding=1); self.r5 = nn.ReLU(inplace=True)
+        self.c6 = nn.Conv2d(128, 128, 1); self.r6 = nn.ReLU(inplace=True)
+        self.c7 = nn.Conv2d(128, 128, 3, padding=1); self.add2 = Eltwise(); self.r7 = nn.ReLU(inplace=True)
+        self.view = View(); self.fc = nn.Linear(128 * 8 * 8, 10)
+
+    def forward(self, x):
+        x = self.r1(self.c1(self.r0(self.stem(x))))
+        y = self.c4(self.r3(self.c3(self.r2(self.c2(x)))))
+        x = self.r4(self.add(x, y))
+        x = self.r5(self.c5(x))
+        z = self.r6(self.c6(x))
+        x = self.r7(self.add2(self.c7(z), z))
+        return self.fc(self.view(x))
+
+
 class SharedSum(torch.nn.Module):
     def __init__(self):
         super(SharedSum, self).__init__()
@@ -49,20 +77,13 @@ def test_a_model_with_in_place_relus_calibrates_to_the_same_bits_every_time(monk
     """When a later module overwrites hooked tensors in place, pass 2 takes its histograms from inside the hooks -- and its
     convolutions must still run on the own kernels: on the convolution library (whose kernels do not give the same bits from call
     to call) the histograms of such a model differed by a handful of elements from one calibration to the next, and pass 2 binned
-    values that were not the ones pass 1 had taken the maxima of (found by scripts/model_fuzz.py, model 138 of seed 6)."""
-    import random
-    import torch
+    values that were not the ones pass 1 had taken the maxima of (found by scripts/model_fuzz.py)."""
     spec = importlib.util.spec_from_file_location("model_fuzz", os.path.join(ROOT, "scripts", "model_fuzz.py"))
     mf = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mf)
-    i, seed = 138, 6
-    rng = random.Random(seed * 100003 + i)
-    size = rng.choice([16, 24, 32])
-    torch.manual_seed(seed * 7919 + i)
-    model = mf.Net(rng, size).eval().cuda()
-    assert any(isinstance(m, torch.nn.ReLU) and m.inplace for m in model.modules())
-    bs = rng.choice([4, 8])
-    batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
+    torch.manual_seed(5)
+    model, size = InPlaceRelus().eval().cuda(), 32
+    batches = [(torch.randn(8, 3, size, size, device="cuda"), torch.zeros(8, dtype=torch.long)) for _ in range(3)]
     real, calls = torch.nn.functional.conv2d, []
 
     def counting(x, *a, **k):
