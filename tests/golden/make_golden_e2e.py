@@ -212,7 +212,7 @@ def capture_random(cq, tl):
     graph discovery, merge groups, the calibration's maxima and feat.table, weight.table.  A graph the reference itself rejects (its
     value fingerprints collide, or it finds an in-place module "useless") is recorded with the exception's type."""
     import torch
-    out = {}
+    out, logits = {}, {}
     for (index, seed, odd) in RANDOM_GRAPHS:
         tag = "%d/%d%s" % (index, seed, "/odd" if odd else "")
         model, size, bs, _rng = cases.random_net(index, seed, odd)
@@ -229,6 +229,18 @@ def capture_random(cq, tl):
                 rec["feat_table"] = _read(os.path.join(wd, "feat.table"))
                 q.weight_quantize()
                 rec["weight_table"] = _read(os.path.join(wd, "weight.table"))
+                # the integer-simulation model of the same graph, as the reference's flow builds it (tables as left above), on a
+                # fixed input: logits of ReconModel (G4's check on graphs that are not ResNets)
+                q.rewrite_weight()
+                rec["weight_table_rewritten"] = _read(os.path.join(wd, "weight.table"))
+                twin = cases.random_net(index, seed, odd)[0]
+                r = tl.Reconstruction(twin)
+                info = r.get_quantity_information()
+                recon = r.ReconModel(info, os.path.join(wd, "recon.pth"))
+                x = cases.fixed_input((4, 3, size, size), seed=77 + index)
+                with torch.no_grad():
+                    logits[tag] = recon(x).numpy()
+                rec["recon_layers"] = sorted(k for k in info.keys())
         except Exception as e:                               # what the reference does with this graph is part of the golden
             rec = {"size": size, "batch": bs, "reference_error": type(e).__name__, "message": str(e)[:60]}
             print("random", tag, "reference raises", type(e).__name__, str(e)[:80])
@@ -237,6 +249,8 @@ def capture_random(cq, tl):
             print("random", tag, "nodes", len(rec["net_info"]), "feat.table:", rec["feat_table"].replace("\n", " | ")[:100])
     with open(os.path.join(HERE, "g11_random_graphs.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
+    np.savez_compressed(os.path.join(HERE, "g11_random_recon.npz"), **{k.replace("/", "_"): v for k, v in logits.items()})
+    print("G11:", len(out), "graphs,", len(logits), "with ReconModel logits")
 
 
 def capture_g6(cq, tl):

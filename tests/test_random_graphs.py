@@ -94,3 +94,49 @@ def test_random_graphs_gpu_match_reference(g11):
             lines += 1
             apart += int(a[k] != b[k])
     assert lines > 300 and apart <= 0.03 * lines, (lines, apart)
+
+
+@pytest.mark.gpu
+def test_random_graphs_reconmodel_logits_equal_the_reference(g11, oracle, golden_dir):
+    """G4's check on graphs that are not ResNets: the reference's ReconModel logits (CPU, fixed input) of every graph it accepts,
+    against the integer-simulation model on the HIP kernels -- with fp32 module boundaries and with the resident integer plan --
+    bit for bit.  The tables the models are built from come from the oracle-backed CPU calibration, which the CPU test above pins to
+    the reference's byte for byte."""
+    import numpy as np
+    import torch
+    from engine_doubles import OracleCollector, OracleQuantizer
+    from common.quantity import resident
+    from tools import Quantity, Reconstruction
+
+    class CpuQuantity(Quantity):
+        collector_cls = OracleCollector
+        quantizer_cls = OracleQuantizer
+
+    logits = np.load(os.path.join(golden_dir, "g11_random_recon.npz"))
+    checked = planned = 0
+    for tag in _tags():
+        ref = g11[tag]
+        if "reference_error" in ref:
+            continue
+        index, seed, odd = int(tag.split("/")[0]), int(tag.split("/")[1]), tag.endswith("/odd")
+        model, size, bs, _rng = cases.random_net(index, seed, odd)
+        with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="cpu", max_cali_img_num=2) as tmp:
+            q = CpuQuantity(model)
+            q.activation_quantize(cases.calib_batches(3, (bs, 3, size, size), seed=9000 + index))
+            q.weight_quantize()
+            q.rewrite_weight()
+            wd = os.path.join(tmp, "test", "workdir")
+            assert open(os.path.join(wd, "weight.table")).read() == ref["weight_table_rewritten"], tag
+            rec = Reconstruction(cases.random_net(index, seed, odd)[0])
+            info = rec.get_quantity_information()
+            assert sorted(info.keys()) == ref["recon_layers"], tag
+            net = rec.ReconModel(info, os.path.join(wd, "recon.pth")).cuda()
+            x = cases.fixed_input((4, 3, size, size), seed=77 + index).cuda()
+            want = logits[tag.replace("/", "_")]
+            with torch.no_grad():
+                np.testing.assert_array_equal(net(x).cpu().numpy(), want, err_msg=tag)
+                summary = resident.enable(net, x)
+                np.testing.assert_array_equal(net(x).cpu().numpy(), want, err_msg=tag + " (resident)")
+            checked += 1
+            planned += summary["resident_convs"]
+    assert checked >= 20 and planned > 150, (checked, planned)
