@@ -75,13 +75,13 @@ def calibrate_channels(model, size, batches):
         return mx.clone(), hist.clone(), {n: c.row_range(n) for n in names}, open(os.path.join(tmp, "test", "workdir", "feat_channel.table")).read()
 
 
-def run_channels(n, seed, log=print, odd=False):
+def run_channels(n, seed, log=print, odd=False, share=False):
     """The per-channel calibration of n random models: twice (equal bit for bit), and against the per-tensor calibration of the same
     model -- a tensor's maximum is the largest of its channels' maxima, its histogram holds as many elements as theirs together."""
     torch.backends.cudnn.deterministic = bool(odd)
     bad = 0
     for i in range(n):
-        model, size, bs, rng = random_net(i, seed, odd, "cuda")
+        model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
         batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
         try:
             t = calibrate(model, size, batches)
@@ -106,14 +106,14 @@ def run_channels(n, seed, log=print, odd=False):
     return bad
 
 
-def run_cache(n, seed, log=print, odd=False):
+def run_cache(n, seed, log=print, odd=False, share=False):
     """The activation cache on n random models: nothing kept / a few MB (the deepest tensors of every batch: plan B, pass 2 re-runs
     a prefix of the network and stops) / more (whole batches: plan A) / everything, each plan also forced -- all must give the
     statistics of the calibration without a cache bit for bit (the kept tensors ARE the ones pass 1 took the maxima of)."""
     torch.backends.cudnn.deterministic = bool(odd)
     bad, plans = 0, {}
     for i in range(n):
-        model, size, bs, rng = random_net(i, seed, odd, "cuda")
+        model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
         batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(4)]
         try:
             base = calibrate(model, size, batches, cache_gb=0)
@@ -135,7 +135,7 @@ def run_cache(n, seed, log=print, odd=False):
     return bad, plans
 
 
-def run(n, seed, log=print, odd=False):
+def run(n, seed, log=print, odd=False, share=False):
     """n random models; returns (models with a finding, what the fused forwards launched in all).  odd: with depthwise / dilated
     convolutions and nearest-neighbour upsampling here and there."""
     # (layers the own kernels do not take run on the convolution library, whose default kernels do not give the same bits from call
@@ -144,7 +144,7 @@ def run(n, seed, log=print, odd=False):
     bad, seen = 0, {"conv_add_launches": 0, "conv_add_hist_launches": 0, "conv_add_chains_proven": 0, "relu_only_chains_proven": 0,
                     "launches_without_own_output": 0, "own_conv1x1_launches": 0, "fused_hist_launches": 0, "refused": 0}
     for i in range(n):
-        model, size, bs, rng = random_net(i, seed, odd, "cuda")
+        model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
         batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]   # (data, label)
         try:
             a = calibrate(model, size, batches)
@@ -196,16 +196,16 @@ def run(n, seed, log=print, odd=False):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    odd = "odd" in sys.argv[3:]
+    odd, share = "odd" in sys.argv[3:], "share" in sys.argv[3:]         # share: nn.ReLU modules that serve several places of the graph
     if "cache" in sys.argv[3:]:
-        bad, plans = run_cache(n, seed, odd=odd)
+        bad, plans = run_cache(n, seed, odd=odd, share=share)
         print("model_fuzz cache%s: %d random models (seed %d), %d with a finding; (plan, something kept) -> calibrations: %s" % (" odd" if odd else "", n, seed, bad, plans))
         return
     if "channels" in sys.argv[3:]:
-        print("model_fuzz channels%s: %d random models (seed %d), %d with a finding" % (" odd" if odd else "", n, seed, run_channels(n, seed, odd=odd)))
+        print("model_fuzz channels%s: %d random models (seed %d), %d with a finding" % (" odd" if odd else "", n, seed, run_channels(n, seed, odd=odd, share=share)))
         return
-    bad, seen = run(n, seed, odd=odd)
-    print("model_fuzz%s: %d random models (seed %d), %d with a finding; fused launches seen: %s" % (" odd" if odd else "", n, seed, bad, seen))
+    bad, seen = run(n, seed, odd=odd, share=share)
+    print("model_fuzz%s: %d random models (seed %d), %d with a finding; fused launches seen: %s" % ((" odd" if odd else "") + (" share" if share else ""), n, seed, bad, seen))
 
 
 if __name__ == "__main__":

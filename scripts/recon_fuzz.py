@@ -17,8 +17,8 @@ from tools import Quantity, Reconstruction
 from workdir_util import product_workdir
 
 
-def build(i, seed, odd=False):
-    model, size, bs, _rng = mf.random_net(i, seed, odd, "cuda")
+def build(i, seed, odd=False, share=False):
+    model, size, bs, _rng = mf.random_net(i, seed, odd, "cuda", share)
     return model, size, bs
 
 
@@ -38,15 +38,15 @@ def recon_of(model, twin, data):
         sys.stdout = out
 
 
-def run(n, seed, log=print, odd=False):
+def run(n, seed, log=print, odd=False, share=False):
     bad, seen = 0, {}
     for i in range(n):
-        model, size, bs, rng = mf.random_net(i, seed, odd, "cuda")
+        model, size, bs, rng = mf.random_net(i, seed, odd, "cuda", share)
         data = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
         out = sys.stdout
         try:
             with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=1):
-                net = recon_of(model, build(i, seed, odd)[0], data)
+                net = recon_of(model, build(i, seed, odd, share)[0], data)
                 x = data[0][0]
                 with torch.no_grad():
                     plain = net(x)
@@ -80,6 +80,6 @@ def run(n, seed, log=print, odd=False):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    odd = len(sys.argv) > 3 and sys.argv[3] == "odd"
-    bad, seen = run(n, seed, odd=odd)
-    print("recon_fuzz%s: %d random models (seed %d), %d with a finding; plans in all: %s" % (" odd" if odd else "", n, seed, bad, seen))
+    odd, share = "odd" in sys.argv[3:], "share" in sys.argv[3:]
+    bad, seen = run(n, seed, odd=odd, share=share)
+    print("recon_fuzz%s: %d random models (seed %d), %d with a finding; plans in all: %s" % ((" odd" if odd else "") + (" share" if share else ""), n, seed, bad, seen))

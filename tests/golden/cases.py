@@ -349,7 +349,7 @@ import torch.nn as nn  # noqa: E402
 class RandomNet(nn.Module):
     """A random graph: `plan` is a list of steps over a dictionary of live tensors; modules are attributes m0, m1, ..."""
 
-    def __init__(self, rng, size, odd=False):
+    def __init__(self, rng, size, odd=False, share=False):
         super(RandomNet, self).__init__()
         from common.quantity import Eltwise, Concat, View      # (the product's, or the reference's when a golden is captured)
         self.plan, self.n = [], 0
@@ -383,8 +383,19 @@ class RandomNet(nn.Module):
 
         inplace_p = 0.3 if rng.random() < 0.2 else 0.0      # one model in five has in-place ReLUs (everything then runs per tensor)
 
+        # share: ONE nn.ReLU module serves several places of the graph, as torchvision's blocks write it (`self.relu` three times
+        # in a Bottleneck): a second generator decides, so that the graphs drawn without it stay what they were
+        import random as _random
+        rng_share = _random.Random(rng.random()) if share else None
+        shared = []
+
         def relu(src):
-            m = add(nn.ReLU(rng.random() < inplace_p))
+            if rng_share is not None and shared and rng_share.random() < 0.6:
+                m = rng_share.choice(shared[-2:])
+                self.n += 1                                   # (keeps the tensor names unique)
+            else:
+                m = add(nn.ReLU(rng.random() < inplace_p))
+                shared.append(m)
             out = "t%d" % self.n
             self.plan.append(("call", m, [src], out))
             ch[out], hw[out] = ch[src], hw[src]
@@ -501,14 +512,14 @@ class RandomNet(nn.Module):
         return t["y"]
 
 
-def random_net(index, seed, odd=False, device="cpu"):
+def random_net(index, seed, odd=False, device="cpu", share=False):
     """Model `index` of the seeded family: (model in eval mode, image size, batch size, the generator's rng after the draw)."""
     import random
     import torch
     rng = random.Random(seed * 100003 + index)
     size = rng.choice([16, 24, 32])
     torch.manual_seed(seed * 7919 + index)
-    model = RandomNet(rng, size, odd).eval()
+    model = RandomNet(rng, size, odd, share).eval()
     with torch.no_grad():
         for p in model.parameters():
             p.mul_(1.5)

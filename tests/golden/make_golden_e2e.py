@@ -203,19 +203,20 @@ def capture_small(cq, tl):
         json.dump(out, fh, indent=1, sort_keys=True)
 
 
-RANDOM_GRAPHS = [(i, 101, False) for i in range(20)] + [(i, 102, True) for i in range(10)]      # (index, seed, odd): golden G11
+# (index, seed, odd, share): golden G11 -- share: nn.ReLU modules that serve several places of the graph (torchvision's style)
+RANDOM_GRAPHS = [(i, 101, False, False) for i in range(20)] + [(i, 102, True, False) for i in range(10)] + [(i, 103, False, True) for i in range(8)]
 
 
 def capture_random(cq, tl):
-    """G11: thirty random topologies (cases.random_net: residual blocks with and without projection, two consumers of one tensor,
+    """G11: thirty-eight random topologies (cases.random_net: residual blocks with and without projection, two consumers of one tensor,
     concatenations, pools, in-place ReLUs; ten of them with depthwise / dilated convolutions and upsampling) through the REFERENCE:
     graph discovery, merge groups, the calibration's maxima and feat.table, weight.table.  A graph the reference itself rejects (its
     value fingerprints collide, or it finds an in-place module "useless") is recorded with the exception's type."""
     import torch
     out, logits = {}, {}
-    for (index, seed, odd) in RANDOM_GRAPHS:
-        tag = "%d/%d%s" % (index, seed, "/odd" if odd else "")
-        model, size, bs, _rng = cases.random_net(index, seed, odd)
+    for (index, seed, odd, share) in RANDOM_GRAPHS:
+        tag = "%d/%d%s%s" % (index, seed, "/odd" if odd else "", "/share" if share else "")
+        model, size, bs, _rng = cases.random_net(index, seed, odd, share=share)
         rec = {"size": size, "batch": bs}
         try:
             with _refenv.reference_workdir(input_shape="1,3,%d,%d" % (size, size), max_cali_img_num=2) as tmp:
@@ -233,7 +234,7 @@ def capture_random(cq, tl):
                 # fixed input: logits of ReconModel (G4's check on graphs that are not ResNets)
                 q.rewrite_weight()
                 rec["weight_table_rewritten"] = _read(os.path.join(wd, "weight.table"))
-                twin = cases.random_net(index, seed, odd)[0]
+                twin = cases.random_net(index, seed, odd, share=share)[0]
                 r = tl.Reconstruction(twin)
                 info = r.get_quantity_information()
                 recon = r.ReconModel(info, os.path.join(wd, "recon.pth"))

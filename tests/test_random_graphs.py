@@ -1,5 +1,5 @@
-"""Golden G11: thirty RANDOM model topologies (cases.random_net -- residual blocks with and without projection, a tensor with two
-consumers, concatenations, pools, in-place ReLUs; ten with depthwise / dilated convolutions and upsampling) taken through the imported
+"""Golden G11: thirty-eight RANDOM model topologies (cases.random_net -- residual blocks with and without projection, a tensor with two
+consumers, concatenations, pools, in-place ReLUs; ten with depthwise / dilated convolutions and upsampling, eight with nn.ReLU modules that serve several places) taken through the imported
 REFERENCE in the build container (tests/golden/make_golden_e2e.py random): graph discovery, merge groups, feat.table, weight.table.
 CPU: the drop-in's orchestrator with the oracle-backed engine gives the reference's graph and byte-identical tables on every graph the
 reference accepts; the seven it rejects (its value fingerprints do not survive an in-place ReLU: "Can't find the input tensor") the
@@ -26,7 +26,7 @@ def _tags():
 
 def _model(tag):
     parts = tag.split("/")
-    return cases.random_net(int(parts[0]), int(parts[1]), len(parts) > 2)
+    return cases.random_net(int(parts[0]), int(parts[1]), "odd" in parts[2:], share="share" in parts[2:])
 
 
 def _run(tag, quantity_cls, device, tables=True):
@@ -118,8 +118,8 @@ def test_random_graphs_reconmodel_logits_equal_the_reference(g11, oracle, golden
         ref = g11[tag]
         if "reference_error" in ref:
             continue
-        index, seed, odd = int(tag.split("/")[0]), int(tag.split("/")[1]), tag.endswith("/odd")
-        model, size, bs, _rng = cases.random_net(index, seed, odd)
+        index = int(tag.split("/")[0])
+        model, size, bs, _rng = _model(tag)
         with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="cpu", max_cali_img_num=2) as tmp:
             q = CpuQuantity(model)
             q.activation_quantize(cases.calib_batches(3, (bs, 3, size, size), seed=9000 + index))
@@ -127,7 +127,7 @@ def test_random_graphs_reconmodel_logits_equal_the_reference(g11, oracle, golden
             q.rewrite_weight()
             wd = os.path.join(tmp, "test", "workdir")
             assert open(os.path.join(wd, "weight.table")).read() == ref["weight_table_rewritten"], tag
-            rec = Reconstruction(cases.random_net(index, seed, odd)[0])
+            rec = Reconstruction(_model(tag)[0])
             info = rec.get_quantity_information()
             assert sorted(info.keys()) == ref["recon_layers"], tag
             net = rec.ReconModel(info, os.path.join(wd, "recon.pth")).cuda()
