@@ -146,6 +146,8 @@ def run(n, seed, log=print, odd=False, share=False):
     for i in range(n):
         model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
         batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]   # (data, label)
+        if odd and rng.random() < 0.5:                           # a ragged last batch
+            batches[-1] = (batches[-1][0][:3].contiguous(), batches[-1][1][:3])
         try:
             a = calibrate(model, size, batches)
             b = calibrate(model, size, batches, off=("fuse_conv_add", "skip_unread_outputs"))

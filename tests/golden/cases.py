@@ -402,7 +402,9 @@ class RandomNet(nn.Module):
             return out
 
         widths = [8, 16, 64, 128, 128, 256]                 # (fq_conv1x1_add_f32 takes Cin % 16 == 0, Cout % 128 == 0)
-        cur = relu(conv("x", rng.choice([8, 16, 64]), k=rng.choice([3, 5, 7]), s=rng.choice([1, 2])))
+        if odd:                                             # ... and widths that are no multiple of 8 or 16: partial tiles, padded channels
+            widths = [8, 12, 20, 36, 64, 100, 128, 256]
+        cur = relu(conv("x", rng.choice([8, 16, 64] if not odd else [8, 12, 20, 64]), k=rng.choice([3, 5, 7]), s=rng.choice([1, 2])))
         for _ in range(rng.randint(2, 5)):
             kind = rng.choice(["plain", "res", "res", "resproj", "concat", "pool", "twice", "shared", "bneck2", "projhead"])
             c = ch[cur]
@@ -436,7 +438,7 @@ class RandomNet(nn.Module):
             if kind == "plain":
                 cur = relu(conv(cur, rng.choice(widths), s=rng.choice([1, 1, 2])))
             elif kind in ("res", "resproj"):
-                mid = rng.choice([8, 16, 16, 64])
+                mid = rng.choice([8, 16, 16, 64] if not odd else [8, 12, 20, 64])
                 cout = c if kind == "res" else rng.choice(widths)
                 s = rng.choice([1, 2]) if kind == "resproj" and hw[cur] >= 8 else 1
                 y = relu(conv(cur, mid, k=1))
@@ -449,7 +451,7 @@ class RandomNet(nn.Module):
                 ch[out], hw[out] = cout, hw[y]
                 cur = relu(out) if rng.random() < 0.85 else out
             elif kind == "concat":
-                a, b = conv(cur, rng.choice([8, 16]), k=3), conv(cur, rng.choice([8, 16]), k=1)
+                a, b = conv(cur, rng.choice([8, 16] if not odd else [8, 12, 20]), k=3), conv(cur, rng.choice([8, 16] if not odd else [4, 12, 16]), k=1)
                 m = add(Concat())
                 out = "t%d" % self.n
                 self.plan.append(("call", m, [a, b], out))
