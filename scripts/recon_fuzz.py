@@ -56,8 +56,16 @@ def run(n, seed, log=print, odd=False, share=False):
                     got2 = net(x2)
                     graphed = resident.capture(net, x)
                     g1, g2 = graphed(x).clone(), graphed(x2).clone()
+                    # two graphs of half the batch on two streams; another batch size than the plan was made on; the plan pickled
+                    dual = resident.capture(net, x, streams=2)
+                    d1, d2 = dual(x).clone(), dual(x2).clone()
+                    got3 = net(x[:3])
+                    torch.save(net, "./workdir/recon_resident.pth")
+                    again = torch.load("./workdir/recon_resident.pth", weights_only=False)
+                    got4 = again(x2)
                     resident.disable(net)
                     want2 = net(x2)
+                    want3 = net(x[:3])
         except Exception as e:
             sys.stdout = out
             bad += 1
@@ -71,6 +79,12 @@ def run(n, seed, log=print, odd=False, share=False):
             problems.append("resident logits differ (max %.3g)" % float((got - plain).abs().max()))
         if not torch.equal(g1, plain) or not torch.equal(g2, want2):
             problems.append("graphed logits differ")
+        if not torch.equal(d1, plain) or not torch.equal(d2, want2):
+            problems.append("logits of the two half-batch graphs differ")
+        if not torch.equal(got3, want3):
+            problems.append("resident logits differ at another batch size")
+        if not torch.equal(got4, want2):
+            problems.append("logits of the pickled resident model differ")
         if problems:
             bad += 1
             log("model %d (seed %d, %d modules): %s; plan %s" % (i, seed, model.n, "; ".join(problems), {k: v for k, v in summary.items() if isinstance(v, int)}))
