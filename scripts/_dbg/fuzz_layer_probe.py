@@ -10,7 +10,7 @@ odd = "odd" in sys.argv[4:]
 torch.backends.cudnn.deterministic = odd
 odd = False
 model, size, bs, rng = mf.random_net(i, seed, odd, "cuda")
-x = torch.randn(bs, 3, size, size, device="cuda")
+x = torch.randn(bs, model.cin, size, size, device="cuda")
 m = getattr(model, name)
 print(m)
 grabbed = {}

@@ -7,7 +7,7 @@ i, seed = int(sys.argv[1]), int(sys.argv[2])
 odd = "odd" in sys.argv[3:]
 torch.backends.cudnn.deterministic = odd
 model, size, bs, rng = mf.random_net(i, seed, odd, "cuda")
-batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
+batches = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
 print("size", size, "batch", bs)
 for step in model.plan:
     m = getattr(model, step[1])

@@ -6,7 +6,7 @@ mf = importlib.util.module_from_spec(spec); spec.loader.exec_module(mf)
 i, seed = int(sys.argv[1]), int(sys.argv[2])
 odd = False
 model, size, bs, rng = mf.random_net(i, seed, odd, "cuda")
-batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
+batches = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
 off = tuple(v for v in (sys.argv[3].split(",") if len(sys.argv) > 3 else []) if v)
 print("switched off:", off)
 for step in model.plan:

@@ -10,12 +10,12 @@ from tools import Quantity, Reconstruction
 from workdir_util import product_workdir
 i, seed = int(sys.argv[1]), int(sys.argv[2])
 model, size, bs = rf.build(i, seed)
-data = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
+data = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
 print("size", size, "batch", bs)
 for step in model.plan:
     print("  %-4s %-66s %s -> %s" % (step[1], str(getattr(model, step[1]))[:66], step[2], step[3]))
 out = sys.stdout
-with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=1):
+with product_workdir(input_shape="1,%d,%d,%d" % (model.cin, size, size), device="gpu", max_cali_img_num=1):
     sys.stdout = open(os.devnull, "w")
     q = Quantity(model); q.activation_quantize(data); q.weight_quantize(); q.rewrite_weight()
     twin, _s, _r = rf.build(i, seed)

@@ -46,7 +46,7 @@ def calibrate(model, size, batches, off=(), cache_gb=None, plan=None):
 
 
 def _calibrate(model, size, batches, off=()):
-    with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=len(batches) - 1) as tmp:
+    with product_workdir(input_shape="1,%d,%d,%d" % (getattr(model, "cin", 3), size, size), device="gpu", max_cali_img_num=len(batches) - 1) as tmp:
         q = Quantity(model)
         for s in off:
             setattr(q, s, False)
@@ -62,7 +62,7 @@ def _calibrate(model, size, batches, off=()):
 
 def calibrate_channels(model, size, batches):
     """The per-(tensor, channel) extension on the same model: (maxima [rows], histograms [rows, 2048], row ranges, table text)."""
-    with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=len(batches) - 1) as tmp:
+    with product_workdir(input_shape="1,%d,%d,%d" % (getattr(model, "cin", 3), size, size), device="gpu", max_cali_img_num=len(batches) - 1) as tmp:
         q = Quantity(model)
         out = sys.stdout; sys.stdout = open(os.devnull, "w")
         try:
@@ -82,7 +82,7 @@ def run_channels(n, seed, log=print, odd=False, share=False):
     bad = 0
     for i in range(n):
         model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
-        batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
+        batches = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
         try:
             t = calibrate(model, size, batches)
             c1 = calibrate_channels(model, size, batches)
@@ -114,7 +114,7 @@ def run_cache(n, seed, log=print, odd=False, share=False):
     bad, plans = 0, {}
     for i in range(n):
         model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
-        batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(4)]
+        batches = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(4)]
         try:
             base = calibrate(model, size, batches, cache_gb=0)
             problems = []
@@ -145,7 +145,7 @@ def run(n, seed, log=print, odd=False, share=False):
                     "launches_without_own_output": 0, "own_conv1x1_launches": 0, "fused_hist_launches": 0, "refused": 0}
     for i in range(n):
         model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
-        batches = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]   # (data, label)
+        batches = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]   # (data, label)
         if odd and rng.random() < 0.5:                           # a ragged last batch
             batches[-1] = (batches[-1][0][:3].contiguous(), batches[-1][1][:3])
         try:

@@ -42,10 +42,10 @@ def run(n, seed, log=print, odd=False, share=False):
     bad, seen = 0, {}
     for i in range(n):
         model, size, bs, rng = mf.random_net(i, seed, odd, "cuda", share)
-        data = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
+        data = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
         out = sys.stdout
         try:
-            with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=1):
+            with product_workdir(input_shape="1,%d,%d,%d" % (model.cin, size, size), device="gpu", max_cali_img_num=1):
                 net = recon_of(model, build(i, seed, odd, share)[0], data)
                 x = data[0][0]
                 with torch.no_grad():

@@ -353,7 +353,8 @@ class RandomNet(nn.Module):
         super(RandomNet, self).__init__()
         from common.quantity import Eltwise, Concat, View      # (the product's, or the reference's when a golden is captured)
         self.plan, self.n = [], 0
-        ch = {"x": 3}
+        self.cin = rng.choice([1, 3, 3, 4]) if odd else 3       # (odd: grey-scale and four-channel images too)
+        ch = {"x": self.cin}
         hw = {"x": size}
         cur = "x"
 

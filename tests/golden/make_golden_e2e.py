@@ -219,13 +219,13 @@ def capture_random(cq, tl):
         model, size, bs, _rng = cases.random_net(index, seed, odd, share=share)
         rec = {"size": size, "batch": bs}
         try:
-            with _refenv.reference_workdir(input_shape="1,3,%d,%d" % (size, size), max_cali_img_num=2) as tmp:
+            with _refenv.reference_workdir(input_shape="1,%d,%d,%d" % (model.cin, size, size), max_cali_img_num=2) as tmp:
                 torch.manual_seed(0)
                 q = tl.Quantity(model)
                 rec.update({"net_info": {k: v for k, v in q.net_info.items()}, "net_info_order": list(q.net_info.keys()),
                             "cared_op_layer_names": q.cared_op_layer_names, "merge_groups": q.get_merge_groups(q.net_info),
                             "layers_num": q.layers_num})
-                q.activation_quantize(cases.calib_batches(3, (bs, 3, size, size), seed=9000 + index))
+                q.activation_quantize(cases.calib_batches(3, (bs, model.cin, size, size), seed=9000 + index))
                 wd = os.path.join(tmp, "test", "workdir")
                 rec["feat_table"] = _read(os.path.join(wd, "feat.table"))
                 q.weight_quantize()
@@ -238,7 +238,7 @@ def capture_random(cq, tl):
                 r = tl.Reconstruction(twin)
                 info = r.get_quantity_information()
                 recon = r.ReconModel(info, os.path.join(wd, "recon.pth"))
-                x = cases.fixed_input((4, 3, size, size), seed=77 + index)
+                x = cases.fixed_input((4, model.cin, size, size), seed=77 + index)
                 with torch.no_grad():
                     logits[tag] = recon(x).numpy()
                 rec["recon_layers"] = sorted(k for k in info.keys())

@@ -32,7 +32,7 @@ def _model(tag):
 def _run(tag, quantity_cls, device, tables=True):
     model, size, bs, _rng = _model(tag)
     out = {}
-    with product_workdir(input_shape="1,3,%d,%d" % (size, size), device=device, max_cali_img_num=2) as tmp:
+    with product_workdir(input_shape="1,%d,%d,%d" % (model.cin, size, size), device=device, max_cali_img_num=2) as tmp:
         if device == "gpu":
             model = model.cuda()
         q = quantity_cls(model)
@@ -40,7 +40,7 @@ def _run(tag, quantity_cls, device, tables=True):
                     "merge_groups": q.get_merge_groups(q.net_info), "layers_num": q.layers_num})
         if tables:
             index = int(tag.split("/")[0])
-            q.activation_quantize(cases.calib_batches(3, (bs, 3, size, size), seed=9000 + index))
+            q.activation_quantize(cases.calib_batches(3, (bs, model.cin, size, size), seed=9000 + index))
             wd = os.path.join(tmp, "test", "workdir")
             out["feat_table"] = open(os.path.join(wd, "feat.table")).read()
             q.weight_quantize()
@@ -120,9 +120,9 @@ def test_random_graphs_reconmodel_logits_equal_the_reference(g11, oracle, golden
             continue
         index = int(tag.split("/")[0])
         model, size, bs, _rng = _model(tag)
-        with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="cpu", max_cali_img_num=2) as tmp:
+        with product_workdir(input_shape="1,%d,%d,%d" % (model.cin, size, size), device="cpu", max_cali_img_num=2) as tmp:
             q = CpuQuantity(model)
-            q.activation_quantize(cases.calib_batches(3, (bs, 3, size, size), seed=9000 + index))
+            q.activation_quantize(cases.calib_batches(3, (bs, model.cin, size, size), seed=9000 + index))
             q.weight_quantize()
             q.rewrite_weight()
             wd = os.path.join(tmp, "test", "workdir")
@@ -131,7 +131,7 @@ def test_random_graphs_reconmodel_logits_equal_the_reference(g11, oracle, golden
             info = rec.get_quantity_information()
             assert sorted(info.keys()) == ref["recon_layers"], tag
             net = rec.ReconModel(info, os.path.join(wd, "recon.pth")).cuda()
-            x = cases.fixed_input((4, 3, size, size), seed=77 + index).cuda()
+            x = cases.fixed_input((4, model.cin, size, size), seed=77 + index).cuda()
             want = logits[tag.replace("/", "_")]
             with torch.no_grad():
                 np.testing.assert_array_equal(net(x).cpu().numpy(), want, err_msg=tag)
