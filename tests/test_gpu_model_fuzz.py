@@ -167,3 +167,59 @@ def test_random_topologies_with_layers_the_library_keeps_and_the_per_channel_row
         assert plans.get(("B", True), 0) > 10 and plans.get(("A", True), 0) > 10, plans
     finally:
         torch.backends.cudnn.deterministic = was
+
+
+def test_a_calibration_leaves_the_model_as_it_found_it_also_when_it_fails_half_way():
+    """The fused forward works by instance-level `forward` attributes and hooks on the user's modules.  After a calibration -- and
+    after one that dies in the middle (here: the loader raises on its third batch) -- nothing of that is left: no hook, no patched
+    forward, the model computes what it computed before; and the same Quantity object calibrates again to the same table."""
+    spec = importlib.util.spec_from_file_location("model_fuzz", os.path.join(ROOT, "scripts", "model_fuzz.py"))
+    mf = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mf)
+    from tools import Quantity
+    from workdir_util import product_workdir
+    model, size, bs, _rng = mf.random_net(7, 3, False, "cuda")
+    x = torch.randn(bs, 3, size, size, device="cuda")
+    with torch.no_grad():
+        before = model(x).clone()
+
+    def same(y):                                             # (the library's convolutions need not give the same bits twice)
+        return torch.allclose(y, before, rtol=1e-4, atol=1e-5)
+
+    def clean():
+        return not any(m._forward_hooks or m._forward_pre_hooks or "forward" in m.__dict__ for m in model.modules())
+
+    class Dies(object):
+        def __init__(self, n):
+            self.items = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(n)]
+
+        def __len__(self):
+            return len(self.items)
+
+        def __getitem__(self, i):
+            if i == 2:
+                raise OSError("the loader lost a file")
+            return self.items[i]
+
+        def __iter__(self):
+            return (self[i] for i in range(len(self)))
+    with product_workdir(input_shape="1,3,%d,%d" % (size, size), device="gpu", max_cali_img_num=3) as tmp:
+        q = Quantity(model)
+        assert clean()
+        with pytest.raises(OSError):
+            q.activation_quantize(Dies(4))
+        assert clean()
+        with torch.no_grad():
+            assert same(model(x))
+        good = [(torch.randn(bs, 3, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(4)]
+        q.activation_quantize(good)
+        first = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
+        assert clean()
+        q.activation_quantize(good)                          # the same object once more
+        assert open(os.path.join(tmp, "test", "workdir", "feat.table")).read() == first and clean()
+        with torch.no_grad():
+            assert same(model(x))
+        by_channel = q.activation_quantize_per_channel(good)
+        assert clean() and len(by_channel["image"]) == 3
+        with torch.no_grad():
+            assert same(model(x))
