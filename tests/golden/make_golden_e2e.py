@@ -207,14 +207,14 @@ def capture_small(cq, tl):
 RANDOM_GRAPHS = [(i, 101, False, False) for i in range(20)] + [(i, 102, True, False) for i in range(10)] + [(i, 103, False, True) for i in range(8)]
 
 
-def capture_random(cq, tl):
+def capture_random(cq, tl, graphs=None, out_dir=None):
     """G11: thirty-eight random topologies (cases.random_net: residual blocks with and without projection, two consumers of one tensor,
     concatenations, pools, in-place ReLUs; ten of them with depthwise / dilated convolutions and upsampling) through the REFERENCE:
     graph discovery, merge groups, the calibration's maxima and feat.table, weight.table.  A graph the reference itself rejects (its
     value fingerprints collide, or it finds an in-place module "useless") is recorded with the exception's type."""
     import torch
     out, logits = {}, {}
-    for (index, seed, odd, share) in RANDOM_GRAPHS:
+    for (index, seed, odd, share) in (graphs or RANDOM_GRAPHS):
         tag = "%d/%d%s%s" % (index, seed, "/odd" if odd else "", "/share" if share else "")
         model, size, bs, _rng = cases.random_net(index, seed, odd, share=share)
         rec = {"size": size, "batch": bs}
@@ -248,9 +248,9 @@ def capture_random(cq, tl):
         out[tag] = rec
         if "feat_table" in rec:
             print("random", tag, "nodes", len(rec["net_info"]), "feat.table:", rec["feat_table"].replace("\n", " | ")[:100])
-    with open(os.path.join(HERE, "g11_random_graphs.json"), "w") as fh:
+    with open(os.path.join(out_dir or HERE, "g11_random_graphs.json"), "w") as fh:
         json.dump(out, fh, indent=1, sort_keys=True)
-    np.savez_compressed(os.path.join(HERE, "g11_random_recon.npz"), **{k.replace("/", "_"): v for k, v in logits.items()})
+    np.savez_compressed(os.path.join(out_dir or HERE, "g11_random_recon.npz"), **{k.replace("/", "_"): v for k, v in logits.items()})
     print("G11:", len(out), "graphs,", len(logits), "with ReconModel logits")
 
 
@@ -344,6 +344,12 @@ def main():
         capture_small(cq, tl)
     if "random" in which:
         capture_random(cq, tl)
+    if "random_sweep" in which:
+        # not a golden: a larger family written to FQ_G11_SWEEP_DIR for a one-off comparison in the build container
+        # (FQ_G11_DIR=<that directory> python -m pytest tests/test_random_graphs.py -m "not gpu")
+        n, seed = int(os.environ.get("FQ_G11_SWEEP_N", "100")), int(os.environ.get("FQ_G11_SWEEP_SEED", "201"))
+        graphs = [(i, seed, i % 3 == 1, i % 3 == 2) for i in range(n)]
+        capture_random(cq, tl, graphs, os.environ["FQ_G11_SWEEP_DIR"])
 
 
 if __name__ == "__main__":
