@@ -26,6 +26,19 @@ SWITCHES = ("fuse_bias_absmax", "fuse_relu", "fuse_hist", "own_pools", "fuse_con
 from cases import RandomNet as Net, random_net      # (tests/golden/cases.py: the generator is shared with golden G11)
 
 
+def fold(drawn):
+    """random_net()'s tuple with the model's BatchNorm2d layers folded into their convolutions (the flow's first step), if it has any."""
+    from common.quantity import merge_bn
+    model = drawn[0]
+    if getattr(model, "has_bn", False):
+        out = sys.stdout; sys.stdout = open(os.devnull, "w")
+        try:
+            model = merge_bn(model)
+        finally:
+            sys.stdout = out
+    return (model,) + tuple(drawn[1:])
+
+
 def calibrate(model, size, batches, off=(), cache_gb=None, plan=None):
     """One calibration.  cache_gb: what pass 1 may keep for pass 2 (FQ_ACT_CACHE_GB; None: the engine's own rule -- nothing in a
     process without a warm pool); plan: "A" / "B" forces the cache plan (FQ_CACHE_PLAN)."""
@@ -75,13 +88,13 @@ def calibrate_channels(model, size, batches):
         return mx.clone(), hist.clone(), {n: c.row_range(n) for n in names}, open(os.path.join(tmp, "test", "workdir", "feat_channel.table")).read()
 
 
-def run_channels(n, seed, log=print, odd=False, share=False):
+def run_channels(n, seed, log=print, odd=False, share=False, bn=False):
     """The per-channel calibration of n random models: twice (equal bit for bit), and against the per-tensor calibration of the same
     model -- a tensor's maximum is the largest of its channels' maxima, its histogram holds as many elements as theirs together."""
     torch.backends.cudnn.deterministic = bool(odd)
     bad = 0
     for i in range(n):
-        model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
+        model, size, bs, rng = fold(random_net(i, seed, odd, "cuda", share, bn))
         batches = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]
         try:
             t = calibrate(model, size, batches)
@@ -106,14 +119,14 @@ def run_channels(n, seed, log=print, odd=False, share=False):
     return bad
 
 
-def run_cache(n, seed, log=print, odd=False, share=False):
+def run_cache(n, seed, log=print, odd=False, share=False, bn=False):
     """The activation cache on n random models: nothing kept / a few MB (the deepest tensors of every batch: plan B, pass 2 re-runs
     a prefix of the network and stops) / more (whole batches: plan A) / everything, each plan also forced -- all must give the
     statistics of the calibration without a cache bit for bit (the kept tensors ARE the ones pass 1 took the maxima of)."""
     torch.backends.cudnn.deterministic = bool(odd)
     bad, plans = 0, {}
     for i in range(n):
-        model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
+        model, size, bs, rng = fold(random_net(i, seed, odd, "cuda", share, bn))
         batches = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(4)]
         try:
             base = calibrate(model, size, batches, cache_gb=0)
@@ -135,7 +148,7 @@ def run_cache(n, seed, log=print, odd=False, share=False):
     return bad, plans
 
 
-def run(n, seed, log=print, odd=False, share=False):
+def run(n, seed, log=print, odd=False, share=False, bn=False):
     """n random models; returns (models with a finding, what the fused forwards launched in all).  odd: with depthwise / dilated
     convolutions and nearest-neighbour upsampling here and there."""
     # (layers the own kernels do not take run on the convolution library, whose default kernels do not give the same bits from call
@@ -144,7 +157,7 @@ def run(n, seed, log=print, odd=False, share=False):
     bad, seen = 0, {"conv_add_launches": 0, "conv_add_hist_launches": 0, "conv_add_chains_proven": 0, "relu_only_chains_proven": 0,
                     "launches_without_own_output": 0, "own_conv1x1_launches": 0, "fused_hist_launches": 0, "refused": 0}
     for i in range(n):
-        model, size, bs, rng = random_net(i, seed, odd, "cuda", share)
+        model, size, bs, rng = fold(random_net(i, seed, odd, "cuda", share, bn))
         batches = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(3)]   # (data, label)
         if odd and rng.random() < 0.5:                           # a ragged last batch
             batches[-1] = (batches[-1][0][:3].contiguous(), batches[-1][1][:3])
@@ -199,15 +212,16 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     odd, share = "odd" in sys.argv[3:], "share" in sys.argv[3:]         # share: nn.ReLU modules that serve several places of the graph
+    bn = "bn" in sys.argv[3:]                                            # bn: BatchNorm2d behind half of the convolutions, folded by merge_bn first
     if "cache" in sys.argv[3:]:
-        bad, plans = run_cache(n, seed, odd=odd, share=share)
+        bad, plans = run_cache(n, seed, odd=odd, share=share, bn=bn)
         print("model_fuzz cache%s: %d random models (seed %d), %d with a finding; (plan, something kept) -> calibrations: %s" % (" odd" if odd else "", n, seed, bad, plans))
         return
     if "channels" in sys.argv[3:]:
-        print("model_fuzz channels%s: %d random models (seed %d), %d with a finding" % (" odd" if odd else "", n, seed, run_channels(n, seed, odd=odd, share=share)))
+        print("model_fuzz channels%s: %d random models (seed %d), %d with a finding" % (" odd" if odd else "", n, seed, run_channels(n, seed, odd=odd, share=share, bn=bn)))
         return
-    bad, seen = run(n, seed, odd=odd, share=share)
-    print("model_fuzz%s: %d random models (seed %d), %d with a finding; fused launches seen: %s" % ((" odd" if odd else "") + (" share" if share else ""), n, seed, bad, seen))
+    bad, seen = run(n, seed, odd=odd, share=share, bn=bn)
+    print("model_fuzz%s: %d random models (seed %d), %d with a finding; fused launches seen: %s" % ((" odd" if odd else "") + (" share" if share else "") + (" bn" if bn else ""), n, seed, bad, seen))
 
 
 if __name__ == "__main__":

@@ -17,8 +17,8 @@ from tools import Quantity, Reconstruction
 from workdir_util import product_workdir
 
 
-def build(i, seed, odd=False, share=False):
-    model, size, bs, _rng = mf.random_net(i, seed, odd, "cuda", share)
+def build(i, seed, odd=False, share=False, bn=False):
+    model, size, bs, _rng = mf.fold(mf.random_net(i, seed, odd, "cuda", share, bn))
     return model, size, bs
 
 
@@ -38,15 +38,15 @@ def recon_of(model, twin, data):
         sys.stdout = out
 
 
-def run(n, seed, log=print, odd=False, share=False):
+def run(n, seed, log=print, odd=False, share=False, bn=False):
     bad, seen = 0, {}
     for i in range(n):
-        model, size, bs, rng = mf.random_net(i, seed, odd, "cuda", share)
+        model, size, bs, rng = mf.fold(mf.random_net(i, seed, odd, "cuda", share, bn))
         data = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
         out = sys.stdout
         try:
             with product_workdir(input_shape="1,%d,%d,%d" % (model.cin, size, size), device="gpu", max_cali_img_num=1):
-                net = recon_of(model, build(i, seed, odd, share)[0], data)
+                net = recon_of(model, build(i, seed, odd, share, bn)[0], data)
                 x = data[0][0]
                 with torch.no_grad():
                     plain = net(x)
@@ -94,6 +94,6 @@ def run(n, seed, log=print, odd=False, share=False):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    odd, share = "odd" in sys.argv[3:], "share" in sys.argv[3:]
-    bad, seen = run(n, seed, odd=odd, share=share)
-    print("recon_fuzz%s: %d random models (seed %d), %d with a finding; plans in all: %s" % ((" odd" if odd else "") + (" share" if share else ""), n, seed, bad, seen))
+    odd, share, bn = "odd" in sys.argv[3:], "share" in sys.argv[3:], "bn" in sys.argv[3:]
+    bad, seen = run(n, seed, odd=odd, share=share, bn=bn)
+    print("recon_fuzz%s: %d random models (seed %d), %d with a finding; plans in all: %s" % ((" odd" if odd else "") + (" share" if share else "") + (" bn" if bn else ""), n, seed, bad, seen))

@@ -349,7 +349,7 @@ import torch.nn as nn  # noqa: E402
 class RandomNet(nn.Module):
     """A random graph: `plan` is a list of steps over a dictionary of live tensors; modules are attributes m0, m1, ..."""
 
-    def __init__(self, rng, size, odd=False, share=False):
+    def __init__(self, rng, size, odd=False, share=False, bn=False):
         super(RandomNet, self).__init__()
         from common.quantity import Eltwise, Concat, View      # (the product's, or the reference's when a golden is captured)
         self.plan, self.n = [], 0
@@ -357,6 +357,10 @@ class RandomNet(nn.Module):
         ch = {"x": self.cin}
         hw = {"x": size}
         cur = "x"
+
+        import random as _random
+        rng_bn = _random.Random(rng.random() + 1.0) if bn else None
+        self.has_bn = bool(bn)
 
         def add(module):
             name = "m%d" % self.n
@@ -376,10 +380,21 @@ class RandomNet(nn.Module):
                     kw["groups"] = cout
                 elif hw[src] >= 8:
                     kw["dilation"], pad = 2, 2
+            # bn: a BatchNorm2d behind about half of the convolutions (registered right after its convolution, as merge_bn pairs
+            # them), some of those convolutions without a bias; its own generator, so that the other graphs stay what they were
+            with_bn = rng_bn is not None and rng_bn.random() < 0.5
+            if with_bn and rng_bn.random() < 0.5:
+                kw["bias"] = False
             m = add(nn.Conv2d(ch[src], cout, k, stride=s, padding=pad, **kw))
             out = "t%d" % self.n
             self.plan.append(("call", m, [src], out))
             ch[out], hw[out] = cout, (hw[src] + 2 * pad - (kw.get("dilation", 1) * (k - 1) + 1)) // s + 1
+            if with_bn:
+                b = add(nn.BatchNorm2d(cout))
+                o2 = "t%d" % self.n
+                self.plan.append(("call", b, [out], o2))
+                ch[o2], hw[o2] = ch[out], hw[out]
+                out = o2
             return out
 
         inplace_p = 0.3 if rng.random() < 0.2 else 0.0      # one model in five has in-place ReLUs (everything then runs per tensor)
@@ -515,16 +530,22 @@ class RandomNet(nn.Module):
         return t["y"]
 
 
-def random_net(index, seed, odd=False, device="cpu", share=False):
+def random_net(index, seed, odd=False, device="cpu", share=False, bn=False):
     """Model `index` of the seeded family: (model in eval mode, image size, batch size, the generator's rng after the draw)."""
     import random
     import torch
     rng = random.Random(seed * 100003 + index)
     size = rng.choice([16, 24, 32])
     torch.manual_seed(seed * 7919 + index)
-    model = RandomNet(rng, size, odd, share).eval()
+    model = RandomNet(rng, size, odd, share, bn).eval()
     with torch.no_grad():
         for p in model.parameters():
             p.mul_(1.5)
+        for m in model.modules():                             # (bn: statistics and affine terms that are not the identity)
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0.0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.6, 1.4)
+                m.bias.normal_(0.0, 0.2)
     bs = rng.choice([4, 8])
     return model.to(device), size, bs, rng

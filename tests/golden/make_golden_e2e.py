@@ -203,20 +203,23 @@ def capture_small(cq, tl):
         json.dump(out, fh, indent=1, sort_keys=True)
 
 
-# (index, seed, odd, share): golden G11 -- share: nn.ReLU modules that serve several places of the graph (torchvision's style)
-RANDOM_GRAPHS = [(i, 101, False, False) for i in range(20)] + [(i, 102, True, False) for i in range(10)] + [(i, 103, False, True) for i in range(8)]
+# (index, seed, odd, share, bn): golden G11 -- share: nn.ReLU modules that serve several places of the graph (torchvision's style)
+RANDOM_GRAPHS = ([(i, 101, False, False, False) for i in range(20)] + [(i, 102, True, False, False) for i in range(10)] +
+                 [(i, 103, False, True, False) for i in range(8)] + [(i, 104, False, False, True) for i in range(8)])      # (.., bn)
 
 
 def capture_random(cq, tl, graphs=None, out_dir=None):
-    """G11: thirty-eight random topologies (cases.random_net: residual blocks with and without projection, two consumers of one tensor,
+    """G11: forty-six random topologies (cases.random_net: residual blocks with and without projection, two consumers of one tensor,
     concatenations, pools, in-place ReLUs; ten of them with depthwise / dilated convolutions and upsampling) through the REFERENCE:
     graph discovery, merge groups, the calibration's maxima and feat.table, weight.table.  A graph the reference itself rejects (its
     value fingerprints collide, or it finds an in-place module "useless") is recorded with the exception's type."""
     import torch
     out, logits = {}, {}
-    for (index, seed, odd, share) in (graphs or RANDOM_GRAPHS):
-        tag = "%d/%d%s%s" % (index, seed, "/odd" if odd else "", "/share" if share else "")
-        model, size, bs, _rng = cases.random_net(index, seed, odd, share=share)
+    for (index, seed, odd, share, bn) in (graphs or RANDOM_GRAPHS):
+        tag = "%d/%d%s%s%s" % (index, seed, "/odd" if odd else "", "/share" if share else "", "/bn" if bn else "")
+        model, size, bs, _rng = cases.random_net(index, seed, odd, share=share, bn=bn)
+        if bn:
+            model = cq.merge_bn(model, "cpu")                # (bn: BatchNorm2d behind half of the convolutions, folded first -- the reference's flow)
         rec = {"size": size, "batch": bs}
         try:
             with _refenv.reference_workdir(input_shape="1,%d,%d,%d" % (model.cin, size, size), max_cali_img_num=2) as tmp:
@@ -234,8 +237,10 @@ def capture_random(cq, tl, graphs=None, out_dir=None):
                 # fixed input: logits of ReconModel (G4's check on graphs that are not ResNets)
                 q.rewrite_weight()
                 rec["weight_table_rewritten"] = _read(os.path.join(wd, "weight.table"))
-                twin = cases.random_net(index, seed, odd, share=share)[0]
+                twin = cases.random_net(index, seed, odd, share=share, bn=bn)[0]
                 r = tl.Reconstruction(twin)
+                if bn:
+                    r.merge_bn()
                 info = r.get_quantity_information()
                 recon = r.ReconModel(info, os.path.join(wd, "recon.pth"))
                 x = cases.fixed_input((4, model.cin, size, size), seed=77 + index)
@@ -348,7 +353,7 @@ def main():
         # not a golden: a larger family written to FQ_G11_SWEEP_DIR for a one-off comparison in the build container
         # (FQ_G11_DIR=<that directory> python -m pytest tests/test_random_graphs.py -m "not gpu")
         n, seed = int(os.environ.get("FQ_G11_SWEEP_N", "100")), int(os.environ.get("FQ_G11_SWEEP_SEED", "201"))
-        graphs = [(i, seed, i % 3 == 1, i % 3 == 2) for i in range(n)]
+        graphs = [(i, seed, i % 4 == 1, i % 4 == 2, i % 4 == 3) for i in range(n)]
         capture_random(cq, tl, graphs, os.environ["FQ_G11_SWEEP_DIR"])
 
 

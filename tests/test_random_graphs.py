@@ -1,5 +1,5 @@
-"""Golden G11: thirty-eight RANDOM model topologies (cases.random_net -- residual blocks with and without projection, a tensor with two
-consumers, concatenations, pools, in-place ReLUs; ten with depthwise / dilated convolutions and upsampling, eight with nn.ReLU modules that serve several places) taken through the imported
+"""Golden G11: forty-six RANDOM model topologies (cases.random_net -- residual blocks with and without projection, a tensor with two
+consumers, concatenations, pools, in-place ReLUs; ten with depthwise / dilated convolutions and upsampling, eight with nn.ReLU modules that serve several places, eight with BatchNorm2d layers that merge_bn folds first) taken through the imported
 REFERENCE in the build container (tests/golden/make_golden_e2e.py random): graph discovery, merge groups, feat.table, weight.table.
 CPU: the drop-in's orchestrator with the oracle-backed engine gives the reference's graph and byte-identical tables on every graph the
 reference accepts; the seven it rejects (its value fingerprints do not survive an in-place ReLU: "Can't find the input tensor") the
@@ -29,8 +29,11 @@ def _tags():
 
 
 def _model(tag):
+    """(model with its BatchNorms folded, if it has any -- the flow's first step --, image size, batch size, rng)"""
+    from common.quantity import merge_bn
     parts = tag.split("/")
-    return cases.random_net(int(parts[0]), int(parts[1]), "odd" in parts[2:], share="share" in parts[2:])
+    model, size, bs, rng = cases.random_net(int(parts[0]), int(parts[1]), "odd" in parts[2:], share="share" in parts[2:], bn="bn" in parts[2:])
+    return (merge_bn(model) if model.has_bn else model), size, bs, rng
 
 
 def _run(tag, quantity_cls, device, tables=True):
