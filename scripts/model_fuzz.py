@@ -5,6 +5,7 @@
   B  the same without the two fusions that rest on a PROOF about the model's dataflow (fuse_conv_add, skip_unread_outputs): the same
      kernels compute the same sums in the same order, so maxima, histograms and table must equal A's BIT FOR BIT -- a chain wrongly
      taken hands somebody a tensor nobody wrote, and that shows here;
+  D  the same as A without the producers' histograms in pass 2 (fuse_hist): the plain own kernels + one statistic launch, = A bit for bit;
   C  every switch off (library convolutions, one streaming statistic launch per tensor): another summation order, so the maxima
      agree to that bound and a histogram differs by the few elements the bound moves across a bin edge; a table line may then differ
      where the KL search has a near tie (seen: 1 model in 300, one line, one bit) -- reported as a note, not as a finding.
@@ -165,6 +166,7 @@ def run(n, seed, log=print, odd=False, share=False, bn=False):
             a = calibrate(model, size, batches)
             b = calibrate(model, size, batches, off=("fuse_conv_add", "skip_unread_outputs"))
             c = calibrate(model, size, batches, off=SWITCHES)
+            d = calibrate(model, size, batches, off=("fuse_hist",))     # pass 2 on the plain own kernels, statistics from the hooks
         except Exception as e:                                   # a crash is a finding too
             bad += 1
             log("model %d (seed %d): %s: %s" % (i, seed, type(e).__name__, str(e)[:300]))
@@ -177,6 +179,9 @@ def run(n, seed, log=print, odd=False, share=False, bn=False):
         if a[3] != b[3] or a[1] != b[1] or not torch.equal(a[2], b[2]):
             rows = [k for r, k in enumerate(a[5]) if not torch.equal(a[2][r], b[2][r]) or a[1][k] != b[1][k]]
             problems.append("with / without the proven chains: rows %s differ" % rows[:6])
+        if a[3] != d[3] or a[1] != d[1] or not torch.equal(a[2], d[2]):
+            rows = [k for r, k in enumerate(a[5]) if not torch.equal(a[2][r], d[2][r]) or a[1][k] != d[1][k]]
+            problems.append("with / without the producers' histograms: rows %s differ" % rows[:6])
         # A against C: to the summation-order bound
         for k, v in a[1].items():
             if abs(v - c[1][k]) > 2e-5 * max(abs(v), abs(c[1][k]), 1e-6):
