@@ -12,7 +12,7 @@ spec = importlib.util.spec_from_file_location("model_fuzz", os.path.join(ROOT, "
 mf = importlib.util.module_from_spec(spec)
 sys.modules["model_fuzz"] = mf                        # (the reference's flow pickles whole models: the class must be importable)
 spec.loader.exec_module(mf)
-from common.quantity import resident
+from common.quantity import resident, _native
 from tools import Quantity, Reconstruction
 from workdir_util import product_workdir
 
@@ -38,8 +38,9 @@ def recon_of(model, twin, data):
         sys.stdout = out
 
 
-def run(n, seed, log=print, odd=False, share=False, bn=False):
+def run(n, seed, log=print, odd=False, share=False, bn=False, big=False, variants=None):
     bad, seen = 0, {}
+    variants = variants if variants is not None else {}
     for i in range(n):
         model, size, bs, rng = mf.fold(mf.random_net(i, seed, odd, "cuda", share, bn))
         data = [(torch.randn(bs, model.cin, size, size, device="cuda"), torch.zeros(bs, dtype=torch.long)) for _ in range(2)]
@@ -63,9 +64,19 @@ def run(n, seed, log=print, odd=False, share=False, bn=False):
                     torch.save(net, "./workdir/recon_resident.pth")
                     again = torch.load("./workdir/recon_resident.pth", weights_only=False)
                     got4 = again(x2)
+                    got5 = want5 = None
+                    if big:                                   # a batch at which the launches take their many-workgroup forms
+                        xb = torch.randn(256, model.cin, size, size, device="cuda")
+                        _native.conv_variant_log = {}
+                        got5 = net(xb)
+                        for k, v in _native.conv_variant_log.items():
+                            variants[k] = variants.get(k, 0) + v
+                        _native.conv_variant_log = None
                     resident.disable(net)
                     want2 = net(x2)
                     want3 = net(x[:3])
+                    if big:
+                        want5 = net(xb)
         except Exception as e:
             sys.stdout = out
             bad += 1
@@ -85,6 +96,8 @@ def run(n, seed, log=print, odd=False, share=False, bn=False):
             problems.append("resident logits differ at another batch size")
         if not torch.equal(got4, want2):
             problems.append("logits of the pickled resident model differ")
+        if big and not torch.equal(got5, want5):
+            problems.append("resident logits differ at 256 images")
         if problems:
             bad += 1
             log("model %d (seed %d, %d modules): %s; plan %s" % (i, seed, model.n, "; ".join(problems), {k: v for k, v in summary.items() if isinstance(v, int)}))
@@ -94,6 +107,9 @@ def run(n, seed, log=print, odd=False, share=False, bn=False):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    odd, share, bn = "odd" in sys.argv[3:], "share" in sys.argv[3:], "bn" in sys.argv[3:]
-    bad, seen = run(n, seed, odd=odd, share=share, bn=bn)
+    odd, share, bn, big = "odd" in sys.argv[3:], "share" in sys.argv[3:], "bn" in sys.argv[3:], "big" in sys.argv[3:]
+    variants = {}
+    bad, seen = run(n, seed, odd=odd, share=share, bn=bn, big=big, variants=variants)
+    if big:
+        print("integer kernels at 256 images:", dict(sorted(variants.items())))
     print("recon_fuzz%s: %d random models (seed %d), %d with a finding; plans in all: %s" % ((" odd" if odd else "") + (" share" if share else "") + (" bn" if bn else ""), n, seed, bad, seen))
