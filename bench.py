@@ -12,8 +12,11 @@ is re-exec'ed).  The line says what the collectives saw: `ranks_seen` (dist.get_
 
 WORKLOAD.  `--images` (default 5120 = BASELINE configs[1]'s "5k") calibration images PER GPU; --steps only decides how
 they are cut into batches (batch = images / steps: 256 at the driver's 20 steps, 128 at 40), never how many there are.
-`--total-images T` instead fixes the WHOLE job (strong scaling: T / N images per GPU, "scaling": "strong";
-`--gpus 8 --total-images 50000` is BASELINE configs[3] verbatim).
+`--total-images T` instead fixes the WHOLE job (strong scaling, "scaling": "strong"; `--gpus 8 --total-images 50000` is
+BASELINE configs[3] verbatim): ceil(T / 256) batches of 256 images (--batch to change it) dealt round-robin to the ranks, the
+SAME batch at every N -- so that the N = 1 and the N = 8 point of the curve time the same kernels -- and --steps is derived
+(the batches of the busiest rank).  Every line carries expected_own_conv_launches / own_conv_launches: pass 1 must have run
+every convolution of every owned batch on the own kernels; a rank that fell back to the library makes the bench exit 3.
 A "step" is one calibration batch taken through the whole hot path: forward -> abs-max (pass 1), forward -> 2048-bin
 histograms (pass 2); the timed region is ONE complete Quantity.activation_quantize() over the K batches of every GPU:
 both passes, the MAX / SUM all-reduces, the KL threshold sweep of all 71 rows and the feat.table write.  Inputs are
@@ -529,6 +532,8 @@ def parse_args():
     ap.add_argument("--int8-batch", type=int, default=256,
                     help="images per forward of the int8-sim / fake-quant throughput section")
     ap.add_argument("--no-per-channel", action="store_true")
+    ap.add_argument("--allow-library-convs", action="store_true",
+                    help="do not fail when convolutions of the timed region ran on the library instead of the own kernels")
     ap.add_argument("--input-mode", default="both", choices=["tensor", "npy", "both"],
                     help="tensor: device-resident batches only (the headline); npy / both: also the same images as one .npy file "
                          "each through PRE_PROCESS.IMG = 2 (reported as file_input, never the headline)")
@@ -538,11 +543,21 @@ def parse_args():
                          "ranks_seen / devices / the workload split -- what tests/test_bench_launch_cpu.py runs")
     args = ap.parse_args()
     world = max(args.gpus, 1)
-    per_gpu = args.images if not args.total_images else -(-args.total_images // world)
-    if args.batch <= 0:
-        args.batch = max(1, -(-per_gpu // max(args.steps, 1)))
+    if args.total_images:
+        # STRONG scaling (BASELINE configs[3]): the whole job is fixed and so is the batch -- 256 images per forward at EVERY N, so that
+        # t_1 and t_N time the same kernels on the same launch shapes (a batch derived from images / steps would run 2 500 images
+        # per forward at N = 1, past the own convolutions' 2^30-element limit and onto the library).  The job is
+        # ceil(total / batch) batches dealt round-robin; --steps is DERIVED: the batches the busiest rank owns.
+        if args.batch <= 0:
+            args.batch = 256
+        args.total_batches = -(-args.total_images // args.batch)
+        args.steps = -(-args.total_batches // world)
+    else:
+        if args.batch <= 0:
+            args.batch = max(1, -(-args.images // max(args.steps, 1)))
+        args.total_batches = args.steps * world
     args.scaling = "strong" if args.total_images else "weak"
-    args.images_per_gpu = args.batch * args.steps            # what is actually run (== per_gpu when steps divides it)
+    args.images_per_gpu = args.batch * args.steps            # the busiest rank's share (== --images when steps divides it)
     return args
 
 
@@ -655,7 +670,8 @@ def dry_launch(args):
                           "ranks_seen": world, "backend": "gloo", "devices": [list(d) for d in devices], "steps": args.steps,
                           "warmup": args.warmup, "scaling": args.scaling,
                           "config": {"batch": args.batch, "images_per_gpu": args.images_per_gpu,
-                                     "images_total": args.images_per_gpu * world, "parallelism": "dp%d" % world}}), flush=True)
+                                     "images_total": args.total_batches * args.batch, "batches_total": args.total_batches,
+                                     "parallelism": "dp%d" % world}}), flush=True)
     if "RANK" in os.environ:
         dist.barrier()
         dist.destroy_process_group()
@@ -731,6 +747,8 @@ def main():
     _native.lib()
 
     K, W, B, HW = args.steps, args.warmup, args.batch, args.image
+    TB = args.total_batches                                # batches of the WHOLE job (weak: K per rank; strong: fixed, dealt i % world)
+    n_owned = len(range(rank, TB, world))                  # ... of which this rank runs these (K on the busiest rank)
     shape = "1,3,%d,%d" % (HW, HW)
     devnull = open(os.devnull, "w")
     real_stdout = sys.stdout
@@ -761,8 +779,8 @@ def main():
     barrier()
 
     # ---- timed: K batches per GPU
-    make_workdir(K * world - 1, shape, dev_index)
-    data = DeviceBatches(K * world, B, HW, rank, world, device, on_host=args.host_inputs)
+    make_workdir(TB - 1, shape, dev_index)
+    data = DeviceBatches(TB, B, HW, rank, world, device, on_host=args.host_inputs)
     q = Quantity(model)
     q.profile_phases = True
     cache_budget = q._activation_cache_budget()            # per rank: every rank budgets its own GPU's pool
@@ -777,7 +795,7 @@ def main():
     if distributed:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    images = K * world * B
+    images = TB * B
     value = images / elapsed
     hist_s = kt_hist.summary()
     timings = dict(q.timings)
@@ -785,11 +803,21 @@ def main():
     timings["cache_budget_bytes_this_rank"] = int(cache_budget)
     feat_table = open("./workdir/feat.table").read() if rank == 0 else ""
     rows = len(q.net_info) + 1
+    # Did the timed region stay on the own kernels?  Pass 1 runs every nn.Conv2d of every owned batch exactly once, either as its
+    # own launch (own_conv1x1_launches) or inside its Eltwise's launch (conv_add_launches); a convolution that fell back to the
+    # library (a tensor past the kernels' 2^30-element limit, a module that failed its check) is missing from that sum, and a
+    # line with such a fallback inside is not comparable with one without -- every rank checks its own count, the ranks agree
+    # (one MIN all-reduce), and the process exits non-zero.
+    n_convs = sum(1 for m in model.modules() if type(m) is torch.nn.Conv2d)
+    expected_own = n_convs * n_owned
+    got_own = int(timings.get("own_conv1x1_launches", 0)) + int(timings.get("conv_add_launches", 0))
+    own_everywhere = all_ok(got_own >= expected_own or args.allow_library_convs, device)
 
     result = {
         "metric": BASELINE_METRIC,
-        "metric_note": "value = calibration images/s (both passes + KL sweep + feat.table, end to end) in a process that holds a "
-                       "warm allocator pool; value_cold = the same workload in a fresh process (allocation inside the clock); "
+        "metric_note": "value = calibration images/s (both passes + KL sweep + feat.table, end to end) in SERVICE MODE: a process that "
+                       "has calibrated before and holds a warm allocator pool of 80 % of HBM (230 GB), which pass 1's activations are kept "
+                       "in for pass 2; value_cold = the same workload in a fresh process (allocation inside the clock); "
                        "int8-sim images/s is reported beside it as int8_sim_images_per_s (resident integer activations, logits "
                        "bit-identical to int8_sim_fp32_boundary_images_per_s, the reference's module-boundary form)",
         "value": round(value, 2), "unit": "images/s", "n_gpus": world, "ranks_seen": ranks_seen,
@@ -800,7 +828,8 @@ def main():
         "config": {"workload": "fabu ResNet-%s per-tensor KL calibration, %d synthetic 3x%dx%d images per GPU "
                                "(batch %d x %d steps), %d images in the whole job, %d histogram rows x 2048 bins" %
                                ("50" if args.model == "r50" else "101", K * B, HW, HW, B, K, images, rows),
-                   "batch": B, "images_per_gpu": K * B, "images_total": images, "parallelism": "dp%d" % world,
+                   "batch": B, "images_per_gpu": K * B, "images_total": images, "batches_total": TB,
+                   "images_requested": args.total_images or args.images * world, "parallelism": "dp%d" % world,
                    "sharding": "batch i -> rank i %% %d; one MAX all-reduce of fp32[%d] after pass 1, one SUM all-reduce of "
                                "int64[%d] after pass 2 (RCCL); KL replicated; rank 0 writes feat.table" % (world, rows, rows * 2048),
                    "activation_cache": "pass-1 activations kept in a warm allocator pool (80 % of HBM, grown during warm-up); "
@@ -808,7 +837,14 @@ def main():
                                        "bytes used: phases_s.cache_bytes",
                    "int8_sim_images_per_forward": args.int8_batch},
         "phases_s": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
+        "expected_own_conv_launches": expected_own, "own_conv_launches": got_own,
+        "own_conv_launches_note": "rank 0, pass 1: %d nn.Conv2d x %d owned batches must all have run on the own fp32-MFMA kernels "
+                                  "(phases_s.own_conv1x1_launches + phases_s.conv_add_launches); every rank checks its own count and "
+                                  "the bench exits 3 when any rank falls short" % (n_convs, n_owned),
     }
+    if not own_everywhere:
+        result["error"] = ("a rank's timed region left the own convolution kernels (expected %d launches on rank 0, saw %d): the line "
+                           "is not comparable with the other points of the curve" % (expected_own, got_own))
     if cold is not None:
         if "cold" in cold:
             result["value_cold"] = cold["cold"]["images_per_s"]
@@ -854,7 +890,7 @@ def main():
                 make_workdir(2 - 1, shape, dev_index)
                 # packs the weights and runs every module's once-per-kernel check on the split-bf16 kernels, untimed
                 Quantity(model).activation_quantize(DeviceBatches(2, B, HW, rank, world, device))
-                make_workdir(K * world - 1, shape, dev_index)
+                make_workdir(TB - 1, shape, dev_index)
                 sq = Quantity(model)
                 sq.profile_phases = True
                 torch.cuda.synchronize(device)
@@ -873,7 +909,7 @@ def main():
             finally:
                 os.environ.pop("FQ_CONV_SPLIT_BF16", None)
                 # what reads ./workdir next finds the headline run's table, not this section's
-                make_workdir(K * world - 1, shape, dev_index)
+                make_workdir(TB - 1, shape, dev_index)
                 os.makedirs("./workdir", exist_ok=True)
                 with open("./workdir/feat.table", "w") as fh:
                     fh.write(feat_table)
@@ -1006,6 +1042,8 @@ def main():
         barrier()
         share_tables("./workdir")                                         # ... and every rank gets the two tables
         batches = [b.to(device) for b in data.owned()[:min(K, 8)]]
+        if not batches:                                    # strong scaling with fewer batches than ranks: this rank owns none
+            batches = [torch.randn(B, 3, HW, HW, generator=torch.Generator(device=device).manual_seed(99 + rank), device=device)]
         if args.int8_batch > B:                            # larger forwards: concatenated calibration batches
             per = (args.int8_batch + B - 1) // B
             src = batches if len(batches) >= per else batches * per
@@ -1135,7 +1173,10 @@ def main():
     # calibration item): the SAME images as the timed region, written as .npy files outside the clock, calibrated through
     # the drop-in's file mode (Quantity.file_batch files per forward, decoded by a thread pool into pinned staging, H2D on a
     # side stream).  Never the headline: reported beside it with its ratio to the tensor-input rate.
-    if world == 1 and args.input_mode in ("npy", "both") and not args.no_file_input:
+    if world == 1 and args.input_mode in ("npy", "both") and not args.no_file_input and images > 16384:
+        result["file_input"] = {"skipped": "%d images as one .npy file each is %.0f GB of scratch files; measured at the 5 120-image "
+                                           "configuration" % (images, images * 3 * HW * HW * 4 / 1e9)}
+    elif world == 1 and args.input_mode in ("npy", "both") and not args.no_file_input:
         try:
             import shutil
             import yaml
@@ -1217,6 +1258,7 @@ def main():
     if distributed:
         barrier()
         dist.destroy_process_group()
+    return 0 if own_everywhere else 3
 
 
 if __name__ == "__main__":

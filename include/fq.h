@@ -148,6 +148,12 @@ typedef struct fq_chan_seg {
     int32_t reserved;      /* must be 0 */
 } fq_chan_seg;
 int fq_absmax_chan(const fq_chan_seg* segs, int nseg, float* max_inout, fq_stream_t stream);
+/* ORDERING CONTRACT of fq_hist2048_chan: a workgroup that is the only one of its launch to feed a group of rows adds its
+ * counts to them with plain 16-byte read-add-writes, not atomics (the "owner flush": 7x7 planes 2.0 -> 3.05 TB/s).  Every
+ * writer of `hist` rows [row0, row0 + C) of the segments of one call must therefore be ORDERED with that call -- same
+ * stream, or an event between them.  A launch on another stream that adds to the same rows at the same time (a statistics
+ * side stream, an atomic producer) loses counts.  Within one call the library checks that no two segments share rows
+ * and falls back to atomics for the call when they do.  FQ_CHAN_OWN_FLUSH=0 in the environment: atomics everywhere. */
 int fq_hist2048_chan(const fq_chan_seg* segs, int nseg, const float* interval, int64_t* hist,
                      fq_stream_t stream);
 

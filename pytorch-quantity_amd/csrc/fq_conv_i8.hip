@@ -1493,6 +1493,12 @@ static void launch_conv_tile(dim3 grid, hipStream_t st, const int8_t* x, const i
         hipLaunchKernelGGL((conv2d_i8_kernel<TK, kPath, kOutF32>), grid, dim3(kConvBlock), 0, st, x, w, qbias, y, q, p);
 }
 
+// Dynamic LDS a kernel of the halo family may ask for and still run two workgroups per CU (160 KB): half the CU's LDS minus what
+// the kernel declares STATICALLY beside its dynamic carve-out -- sLH[2][TK] ints, the merged clamp bounds of the integer tail --
+// and the allocation granule.  (The budget used to ignore the static part; no shape fell into the gap, but one layout change
+// could have halved the occupancy silently.)
+static constexpr size_t two_per_cu_lds(int tk) { return (size_t)80 * 1024 - 64 - (size_t)8 * tk; }
+
 // the halo form of the 3 x 3 layers; false when the layer is not of that shape
 template <int TK>
 static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, const float* qbias, float* y, int8_t* q,
@@ -1512,7 +1518,7 @@ static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, c
         const size_t fixed8 = (size_t)TK * 8 + 128 + (size_t)hp8.slab_rows * 128;
         const int stages8 = st_env ? st_env : 2;
         const size_t lds8 = (size_t)stages8 * TK * 128 + fixed8;
-        if (lds8 <= 80 * 1024 - 64 && (stages8 == 2 || stages8 == 3)) {
+        if (lds8 <= two_per_cu_lds(TK) && (stages8 == 2 || stages8 == 3)) {
             dim3 grid8((unsigned)(((long)p0.M + 255) / 256), (unsigned)(p0.K / TK));
             const ConvParams p8 = xcd_order(grid8, p0);
 #define FQ_HALO8_K(OUT, STG)                                                                                             \
@@ -1539,9 +1545,9 @@ static bool launch_conv_halo(hipStream_t st, const int8_t* x, const int8_t* w, c
     hp.slab_rows = (128 * np + 2 + 2 * p0.W + 7) & ~7;
     hp.total_pixels = p0.N * p0.H * p0.W;
     const size_t fixed = (size_t)TK * 8 + 128 + (size_t)hp.slab_rows * 128;
-    const int stages = st_env ? st_env : ((size_t)3 * TK * 128 + fixed <= 80 * 1024 - 64 ? 3 : 2);
+    const int stages = st_env ? st_env : ((size_t)3 * TK * 128 + fixed <= two_per_cu_lds(TK) ? 3 : 2);
     const size_t lds = (size_t)stages * TK * 128 + fixed;
-    if (lds > 80 * 1024 - 64 || (stages != 2 && stages != 3) || (np != 1 && np != 2)) return false;   // two workgroups per CU
+    if (lds > two_per_cu_lds(TK) || (stages != 2 && stages != 3) || (np != 1 && np != 2)) return false;   // two workgroups per CU
     dim3 grid((unsigned)(((long)p0.M + 128 * np - 1) / (128 * np)), (unsigned)(p0.K / TK));
     const ConvParams p = xcd_order(grid, p0);
 #define FQ_HALO_K(OUT, STG, NPX)                                                                                         \
@@ -1578,7 +1584,7 @@ static bool launch_conv_c64(hipStream_t st, const int8_t* x, const int8_t* w, co
     static const bool xcd_order = [] { const char* e = getenv("FQ_C64_XCD"); return !(e && e[0] == '0'); }();
     cp.xcd_chunk = xcd_order ? (cp.tiles + 7) / 8 : 0;
     const size_t lds = (size_t)9 * 64 * 64 + 64 * 8 + 64 + (size_t)kTP * 80 + (size_t)2 * cp.slab_rows * 64;
-    if (lds > 80 * 1024 - 64) return false;               // two workgroups per CU
+    if (lds > two_per_cu_lds(64)) return false;            // two workgroups per CU
     ConvParams p = p0;
     p.xcd_kt = 0; p.tiles_m = cp.tiles;
     static const int per_cu = [] { const char* e = getenv("FQ_C64_WG_PER_CU"); return e ? atoi(e) : 2; }();
@@ -1658,7 +1664,16 @@ __global__ __launch_bounds__(64 * kLinWaves) void linear_i8_wave_kernel(const in
         const int k = k0 + (i & 3) + 8 * (i >> 2) + 4 * half;
         if (k < p.K) {
             const float b = qbias[k];
-            y[(size_t)n * p.K + k] = p.rs ? (float)conv_tail_i(acc[i], (int)b, p) * p.inv_ob : conv_tail(acc[i], b, p);
+            // (a bias of ANY magnitude, as fq.h promises: tail_consts brings it into the range beyond which the output is a bound
+            //  whatever the accumulator holds; the unclamped six-instruction form would wrap on a bias near INT_MAX)
+            float out;
+            if (p.rs) {
+                const TailK tk = tail_consts((int)b, p);               // (v_cvt_i32_f32 saturates)
+                out = (float)conv_tail_k(acc[i], tk.B, tk.lo, tk.hi, p.rs) * p.inv_ob;
+            } else {
+                out = conv_tail(acc[i], b, p);
+            }
+            y[(size_t)n * p.K + k] = out;
         }
     }
 }
@@ -1721,7 +1736,8 @@ static int conv2d_i8_dispatch(const int8_t* x_nhwc, const int8_t* w_krsc, const 
     }
     // a linear layer with an fp32 output: one wave per 32 x 32 tile, operands straight from L2 (FQ_LINEAR_WAVE=0: the tiled kernels)
     static const bool thin = [] { const char* e = getenv("FQ_LINEAR_WAVE"); return !(e && e[0] == '0'); }();
-    if (thin && H == 1 && W == 1 && R == 1 && S == 1 && P == 1 && Q == 1 && y_nchw && !q_nhwc && !fa.res && (M + 31) / 32 <= 65535) {
+    // (pad 0, dilation 1: with padding and a stride >= 3 the one output pixel would sample the zero border, not x)
+    if (thin && H == 1 && W == 1 && R == 1 && S == 1 && P == 1 && Q == 1 && pad_h == 0 && pad_w == 0 && dil_h == 1 && dil_w == 1 && y_nchw && !q_nhwc && !fa.res && (M + 31) / 32 <= 65535) {
         hipLaunchKernelGGL(linear_i8_wave_kernel, dim3((unsigned)((K + 31) / 32), (unsigned)((M + 31) / 32)), dim3(64 * kLinWaves), 0, st, x_nhwc, w_krsc,
                            qbias, y_nchw, p);
         note_conv_variant(kVarLinearWave, 32);

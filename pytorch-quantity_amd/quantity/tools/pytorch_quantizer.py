@@ -513,6 +513,10 @@ class Quantity(_FusedForward, _FileInputs):
             return self._calibrate(images_files, collector, quantizer, named_feats, merge_groups, top_feat_names,
                                    table_file)
         finally:
+            # (an exception in pass 2 -- a data-loader error, an FqError -- must not leave the pass's modes set on the controller)
+            ctl = self._hook_ctl
+            ctl.fuse_collector, ctl.fuse_stat, ctl.own_plain, ctl.stop_after, ctl.eager = None, "max", False, None, None
+            ctl.deferred = {}
             for m in patched:
                 del m.forward
             for h in hooks:                 # (the reference never removes its hooks)

@@ -16,6 +16,9 @@
           build container (torch.sqrt on CPU is machine dependent in the last bit; see cases.fold_bn_with_scales).
   h6      G10 (g10_dilation.npz): Quantity.dilation_to_zero_padding (quantity/tools/pytorch_quantizer.py:679-693)
           on seeded kernels.
+  (time18 and time101 also KEEP what those runs computed -- G12 g12_r18_config1.json + g12_r18_config1_stats.npz: feat.table,
+          weight.table, the JSON files' sha256, and what the KL search was handed, for config 1 at its stated 256 images; G13
+          g13_r101_512_stats.npz: the same statistics + feat.table + the BatchNorm fold factors for ResNet-101 @512^2, one image)
   time18  wall time of the reference's Python path on BASELINE config 1 (ResNet-18, 256 synthetic 3x32x32 images:
           2 batches of 128 with MAX_CALI_IMG_NUM = 1, WORKER_NUM 4 as shipped) -> tests/golden/ref_timing_r18.json
           (recorded in BASELINE.md; a measurement, not a parity fixture).
@@ -219,6 +222,36 @@ def capture_h6(cq, tl):
     print("G10 written:", {k: v.shape for k, v in arrays.items()})
 
 
+class _kl_spy(object):
+    """What the reference's calibration hands to its KL search (Quantizer.quantize, called at pytorch_quantizer.py:447 with
+    the merged intervals and histograms) and the bits it finds, captured in passing."""
+
+    def __init__(self, tl):
+        self.qmod, self.seen = sys.modules[tl.Quantity.__module__], {}
+
+    def __enter__(self):
+        seen, real = self.seen, self.qmod.Quantizer.quantize
+        self.real = real
+
+        def spy(q, distributions, distribution_intervals):
+            seen["names"] = list(distributions.keys())
+            seen["hist"] = np.stack([np.asarray(distributions[k], dtype=np.int64) for k in seen["names"]])
+            seen["interval"] = np.array([distribution_intervals[k] for k in seen["names"]], dtype=np.float64)
+            real(q, distributions, distribution_intervals)
+            seen["bits"] = np.array([q.bits[k] for k in seen["names"]], dtype=np.int64)
+        self.qmod.Quantizer.quantize = spy
+        return seen
+
+    def __exit__(self, *exc):
+        self.qmod.Quantizer.quantize = self.real
+        return False
+
+
+def _save_stats(path, seen, feat, extra=None):
+    np.savez_compressed(path, names=np.array(seen["names"]), hist=seen["hist"], interval=seen["interval"], bits=seen["bits"],
+                        feat_table=np.array(feat), **(extra or {}))
+
+
 def time_r18(cq, tl):
     import torch
     from model.resnet.ResNet_18_fabu import ResNet18          # the REFERENCE's model file
@@ -227,19 +260,30 @@ def time_r18(cq, tl):
                      "(MAX_CALI_IMG_NUM 1 -> batches 0..1), WORKER_NUM 4, INTERVAL_NUM 2048, CPU",
            "host": {"cpus": os.cpu_count(), "python": sys.version.split()[0], "numpy": np.__version__,
                     "torch": torch.__version__}}
-    with _refenv.reference_workdir(input_shape="1,3,32,32", max_cali_img_num=1):
+    with _refenv.reference_workdir(input_shape="1,3,32,32", max_cali_img_num=1) as tmp:
         model = cq.merge_bn(cases.seed_model(ResNet18()).eval(), "cpu")
         t0 = time.perf_counter()
         q = tl.Quantity(model)
         rec["graph_discovery_s"] = round(time.perf_counter() - t0, 3)
         batches = cases.calib_batches(2, (128, 3, 32, 32))
         t0 = time.perf_counter()
-        q.activation_quantize(batches)
+        with _kl_spy(tl) as seen:                 # G12: the tables of this very run are kept, not only its wall time
+            q.activation_quantize(batches)
         rec["activation_quantize_s"] = round(time.perf_counter() - t0, 3)
+        feat = _read(os.path.join(tmp, "test", "workdir", "feat.table"))
         t0 = time.perf_counter()
         q.weight_quantize()
         rec["weight_quantize_and_rewrite_s"] = round(time.perf_counter() - t0, 3)
+        wd = os.path.join(tmp, "test", "workdir")
+        g12 = {"recipe": {"model": "ResNet_18_fabu (cases.seed_model, merge_bn)", "n_batches": 2, "shape": [128, 3, 32, 32], "seed": 0,
+                          "max_cali_img_num": 1},
+               "feat_table": feat, "weight_table": _read(os.path.join(wd, "weight.table")),
+               "files": {d: _dir_state(os.path.join(wd, d)) for d in ("weight", "bias", "new_weight", "new_bias")}}
     rec["calibration_images_per_s"] = round(256 / rec["activation_quantize_s"], 3)
+    _save_stats(os.path.join(HERE, "g12_r18_config1_stats.npz"), seen, feat)
+    with open(os.path.join(HERE, "g12_r18_config1.json"), "w") as fh:
+        json.dump(g12, fh, indent=1, sort_keys=True)
+    print("G12 written: config 1 at its stated size,", seen["hist"].shape, "rows x bins,", int(seen["hist"][0].sum()), "image elements")
     with open(os.path.join(HERE, "ref_timing_r18.json"), "w") as fh:
         json.dump(rec, fh, indent=1, sort_keys=True)
     print(json.dumps(rec, indent=1))
@@ -253,15 +297,23 @@ def time_r101_512(cq, tl):
     rec = {"config": "BASELINE configs[4] shape: fabu ResNet-101 @3x512x512, ONE synthetic image (MAX_CALI_IMG_NUM 0), WORKER_NUM 4, "
                      "INTERVAL_NUM 2048, CPU; 139 histogram rows, 132.25 M cared elements",
            "host": {"cpus": os.cpu_count(), "python": sys.version.split()[0], "numpy": np.__version__, "torch": torch.__version__}}
-    with _refenv.reference_workdir(input_shape="1,3,512,512", max_cali_img_num=0):
+    with _refenv.reference_workdir(input_shape="1,3,512,512", max_cali_img_num=0) as tmp:
         model = cq.merge_bn(cases.seed_model(ResNet101(input_size=512), gamma_scale=0.5).eval(), "cpu")
         t0 = time.perf_counter()
         q = tl.Quantity(model)
         rec["graph_discovery_s"] = round(time.perf_counter() - t0, 3)
         t0 = time.perf_counter()
-        q.activation_quantize(cases.calib_batches(1, (1, 3, 512, 512), seed=512))
+        with _kl_spy(tl) as seen:                 # G13: the tables of this very run are kept, not only its wall time
+            q.activation_quantize(cases.calib_batches(1, (1, 3, 512, 512), seed=512))
         rec["activation_quantize_s"] = round(time.perf_counter() - t0, 3)
+        feat = _read(os.path.join(tmp, "test", "workdir", "feat.table"))
+        # the BatchNorm fold factors as THIS machine's torch.sqrt evaluates them (cases.fold_bn_with_scales, see capture_scales)
+        raw = cases.seed_model(ResNet101(input_size=512), gamma_scale=0.5).eval()
+        scales = {"scale__" + name: (layer.weight.data / torch.sqrt(layer.running_var + 1e-5)).numpy().copy()
+                  for name, layer in raw.named_modules() if type(layer).__name__ == "BatchNorm2d"}
     rec["calibration_images_per_s"] = round(1.0 / rec["activation_quantize_s"], 5)
+    _save_stats(os.path.join(HERE, "g13_r101_512_stats.npz"), seen, feat, scales)
+    print("G13 written: ResNet-101 @512^2, one image,", seen["hist"].shape, "rows x bins")
     with open(os.path.join(HERE, "ref_timing_r101_512.json"), "w") as fh:
         json.dump(rec, fh, indent=1, sort_keys=True)
     print(json.dumps(rec, indent=1))

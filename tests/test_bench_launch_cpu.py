@@ -31,9 +31,30 @@ def test_bare_multi_gpu_command_starts_its_own_ranks(n):
     d = json.loads(lines[0])
     assert d["dry_launch"] is True and d["n_gpus"] == n and d["ranks_seen"] == n and d["scaling"] == "strong"
     assert sorted(x[0] for x in d["devices"]) == list(range(n))
-    per_gpu = -(-50000 // n)
-    assert d["config"]["batch"] == -(-per_gpu // 20) and d["config"]["parallelism"] == "dp%d" % n
+    # strong scaling keeps the forward's shape: 256 images per batch at EVERY N (so that t_1 and t_N time the same kernels), the
+    # job is ceil(50000 / 256) = 196 batches dealt round-robin, and --steps is derived: the batches of the busiest rank
+    assert d["config"]["batch"] == 256 and d["config"]["batches_total"] == 196 and d["config"]["images_total"] == 196 * 256
+    assert d["steps"] == -(-196 // n) and d["config"]["images_per_gpu"] == 256 * -(-196 // n)
+    assert d["config"]["parallelism"] == "dp%d" % n
     assert "torch.distributed.run" in r.stderr             # the parent said what it started
+
+
+@pytest.mark.timeout(300)
+def test_strong_scaling_at_one_gpu_runs_the_same_batch_as_at_eight():
+    """The N = 1 leg of BASELINE config 4's curve: same 196 batches of 256 images, all on the one rank (no launcher, no group)."""
+    r = _bare(["--gpus", "1", "--total-images", "50000", "--steps", "20", "--warmup", "5", "--dry-launch"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][-1])
+    assert d["scaling"] == "strong" and d["config"]["batch"] == 256 and d["steps"] == 196
+    assert d["config"]["batches_total"] == 196 and d["config"]["images_per_gpu"] == 196 * 256
+
+
+@pytest.mark.timeout(300)
+def test_weak_scaling_default_is_the_drivers_configuration():
+    r = _bare(["--gpus", "1", "--steps", "20", "--warmup", "5", "--dry-launch"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][-1])
+    assert d["scaling"] == "weak" and d["config"]["batch"] == 256 and d["steps"] == 20 and d["config"]["images_total"] == 5120
 
 
 @pytest.mark.timeout(300)

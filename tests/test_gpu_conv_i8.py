@@ -82,6 +82,24 @@ def test_a_bias_far_outside_the_output_range_saturates_like_the_reference(nat, o
     for rs, ob, bw in ((8, 3, 8), (16, 2, 8), (12, 4, 16), (16, 0, 16)):
         got = nat.conv2d_i8(_dev(x_nhwc), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), rs, ob, bw).cpu().numpy()
         np.testing.assert_array_equal(got, oracle.recon_epilogue(acc.astype(np.float32), qb, rs, ob, bw), err_msg="rs=%d bits=%d" % (rs, bw))
+    # ... and on a 1 x 1 plane, where the call runs on the linear layer's kernel (linear_i8_wave_kernel: its own copy of the tail)
+    x1 = rng.integers(-128, 128, size=(37, C, 1, 1)).astype(np.int32)
+    acc1 = oracle.conv2d_int(x1, wq, (1, 1), (0, 0), (1, 1))
+    x1_nhwc = np.ascontiguousarray(x1.transpose(0, 2, 3, 1)).astype(np.int8)
+    for rs, ob, bw in ((8, 3, 8), (16, 2, 8), (12, 4, 16), (16, 0, 16)):
+        nat.conv_variant_log = seen = {}
+        try:
+            got = nat.conv2d_i8(_dev(x1_nhwc), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), rs, ob, bw).cpu().numpy()
+        finally:
+            nat.conv_variant_log = None
+        assert any(k.startswith("linear_wave") for k in seen), seen
+        np.testing.assert_array_equal(got, oracle.recon_epilogue(acc1.astype(np.float32), qb, rs, ob, bw), err_msg="1x1 plane rs=%d bits=%d" % (rs, bw))
+    # a 1 x 1 plane with padding 1 and stride 3 still has ONE output pixel, but it samples the zero border: bias only.  That call must
+    # not take the linear kernel (which ignores the geometry)
+    got = nat.conv2d_i8(_dev(x1_nhwc), w_dev, _dev(qb), (3, 3), (1, 1), (1, 1), 8, 3, 8).cpu().numpy()
+    accz = oracle.conv2d_int(x1, wq, (3, 3), (1, 1), (1, 1))
+    assert accz.shape[2:] == (1, 1) and not accz.any()
+    np.testing.assert_array_equal(got, oracle.recon_epilogue(accz.astype(np.float32), qb, 8, 3, 8))
     for relu in (False, True):
         _, q = nat.conv2d_i8_resident(_dev(x_nhwc), w_dev, _dev(qb), (1, 1), (0, 0), (1, 1), 9, 3, False, True, relu)
         ref = oracle.recon_epilogue(acc.astype(np.float32), qb, 9, 0, 8)

@@ -79,6 +79,7 @@ def test_bench_runs_under_the_distributed_launcher_with_rccl():
     line = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["value"] > 0 and d["config"]["images_total"] == 256
+    assert d["own_conv_launches"] == d["expected_own_conv_launches"] == 53 * 2 and "error" not in d
     assert d["ranks_seen"] == 1 and d["backend"].startswith("nccl") and d["devices"][0][:2] == [0, 0]
     assert d["int8_sim_resident"]["bit_identical_logits"] is True and d["int8_sim_images_per_s"] > 0
     assert "recon_errors" not in d and "recon_error" not in d
@@ -94,8 +95,8 @@ def test_bench_eight_rank_flow_runs_to_its_json_line_on_one_gpu():
     and no error key -- so that the first real 8-GPU run cannot die on plumbing."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", FQ_BENCH_BACKEND="gloo", FQ_BENCH_POOL_FRAC="0.05", OMP_NUM_THREADS="2")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-images", "1024", "--steps", "2",
-                        "--warmup", "1", "--int8-batch", "32", "--no-cold", "--no-cpu-baseline", "--no-per-channel"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--total-images", "1024", "--batch", "64",
+                        "--steps", "2", "--warmup", "1", "--int8-batch", "32", "--no-cold", "--no-cpu-baseline", "--no-per-channel"],
                        env=env, capture_output=True, text=True, timeout=1400)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.strip().split("\n") if ln.startswith("{")]
@@ -104,4 +105,7 @@ def test_bench_eight_rank_flow_runs_to_its_json_line_on_one_gpu():
     assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
     assert d["ranks_seen"] == 8 and sorted(x[0] for x in d["devices"]) == list(range(8)) and d["backend"].startswith("gloo")
     assert d["config"]["images_total"] == 1024 and d["config"]["images_per_gpu"] == 128 and d["config"]["parallelism"] == "dp8"
+    assert d["config"]["batch"] == 64 and d["config"]["batches_total"] == 16 and d["steps"] == 2
+    # every rank's timed region stayed on the own convolution kernels (the bench would have exited 3 otherwise)
+    assert d["own_conv_launches"] == d["expected_own_conv_launches"] == 53 * 2 and "error" not in d
     assert "recon_errors" not in d and "recon_error" not in d
