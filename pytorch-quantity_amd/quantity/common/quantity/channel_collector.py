@@ -34,8 +34,11 @@ class ChannelCollector(StatCollectives):
         self._statistic = statistic
         self._device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._max = torch.zeros(row, dtype=torch.float32, device=self._device)
-        self._hist = torch.zeros(row, _native.BINS, dtype=torch.int64, device=self._device)
+        # (W equal row blocks when distributed -- what the reduce-scatter after pass 2 takes; the kernels only see the real rows)
+        self._hist_padded = torch.zeros(self.padded_rows(row), _native.BINS, dtype=torch.int64, device=self._device)
+        self._hist = self._hist_padded[:row]
         self._interval = None
+        self._own_block = None           # (first row, [S][2048]) after reduce_scatter_hist(): this rank's rows, summed over ranks
 
     @property
     def rows(self):
@@ -78,8 +81,8 @@ class ChannelCollector(StatCollectives):
         for i in range(0, len(ts), _MAX_SEGS):
             _native.hist2048_chan(ts[i:i + _MAX_SEGS], row0s[i:i + _MAX_SEGS], self._interval, self._hist)
 
-    def _stat_tensors(self):             # all_reduce_max() / all_reduce_hist(): StatCollectives
-        return self._max, self._hist
+    def _stat_tensors(self):             # all_reduce_max() / reduce_scatter_hist(): StatCollectives
+        return self._max, self._hist_padded
 
     @property
     def max_device(self):
@@ -90,15 +93,29 @@ class ChannelCollector(StatCollectives):
         return self._hist
 
     def quantize(self):
-        """-> {tensor name: [bits per channel]} via the KL sweep (quantizer.py:86-90 per row)."""
+        """-> {tensor name: [bits per channel]} via the KL sweep (quantizer.py:86-90 per row).  After reduce_scatter_hist() the
+        sweep runs on this rank's row block only and the ranks exchange (threshold bin, bits) with one all-gather."""
         import time
         iv = self._interval.cpu().numpy()
         torch.cuda.synchronize(self._device)
         t0 = time.perf_counter()
-        thr = _native.kl_threshold(self._hist).cpu().numpy()
-        self.kl_seconds = round(time.perf_counter() - t0, 4)      # the sweep of all rows (device time: .cpu() waits)
-        # quantizer.py:86-90 per row through the C helper (the host libm call CPython's math.log(x, 2) makes), all rows at once
-        all_bits, _thr_val = _native.bits_from_threshold(thr, iv)
+        if self._own_block is None:
+            thr = _native.kl_threshold(self._hist).cpu().numpy()
+            self.kl_seconds = round(time.perf_counter() - t0, 4)      # the sweep of all rows (device time: .cpu() waits)
+            # quantizer.py:86-90 per row through the C helper (the host libm call CPython's math.log(x, 2) makes), all rows at once
+            all_bits, _thr_val = _native.bits_from_threshold(thr, iv)
+        else:
+            lo, block = self._own_block
+            per = int(block.shape[0])
+            thr_own = _native.kl_threshold(block).cpu().numpy()
+            self.kl_seconds = round(time.perf_counter() - t0, 4)      # the sweep of this rank's rows
+            iv_own = np.ones(per, dtype=np.float32)                   # (padding rows: any positive width; their result is dropped)
+            n_real = max(0, min(lo + per, self._rows) - lo)
+            iv_own[:n_real] = iv[lo:lo + n_real]
+            bits_own, _thr_val = _native.bits_from_threshold(thr_own, iv_own)
+            local = torch.from_numpy(np.stack([np.asarray(thr_own, dtype=np.int32), np.asarray(bits_own, dtype=np.int32)])).to(self._device)
+            both = self.all_gather_rows(local).cpu().numpy()
+            thr, all_bits = both[0, :self._rows], both[1, :self._rows]
         bits = {}
         for n in self._names:
             lo, hi = self.row_range(n)

@@ -780,7 +780,9 @@ class Quantity(_FusedForward, _FileInputs):
                             cached[i] = dict(named_feats)
                             used += need
                 if _dist_on():
-                    collector.all_reduce_max() if _pass == 1 else collector.all_reduce_hist()
+                    # pass 1: one MAX all-reduce of fp32[rows]; pass 2: one reduce-scatter -- every rank gets the global histograms of
+                    # ITS row block only, sweeps those, and the bits are all-gathered (collector.quantize; _collectives.py)
+                    collector.all_reduce_max() if _pass == 1 else collector.reduce_scatter_hist()
                 if _pass == 1:
                     collector.intervals()
             bits = collector.quantize()

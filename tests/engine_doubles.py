@@ -137,8 +137,11 @@ class OracleChannelCollector(StatCollectives):
         self._rows = row
         self._statistic = statistic
         self._max = np.zeros(row, dtype=np.float32)
-        self._hist = np.zeros((row, BINS), dtype=np.int64)
+        # (W equal row blocks when distributed: what the product's reduce-scatter takes, StatCollectives.padded_rows)
+        self._hist_padded = np.zeros((self.padded_rows(row), BINS), dtype=np.int64)
+        self._hist = self._hist_padded[:row]
         self._interval = None
+        self._own_block = None
 
     @property
     def rows(self):
@@ -171,17 +174,31 @@ class OracleChannelCollector(StatCollectives):
             orc.hist2048(x, np.float32(self._interval[row]), self._hist[row])
 
     def _stat_tensors(self):
-        return torch.from_numpy(self._max), torch.from_numpy(self._hist)
+        return torch.from_numpy(self._max), torch.from_numpy(self._hist_padded)
+
+    def _row_result(self, hist_row, interval):
+        t = orc.kl_threshold(orc.normalize(hist_row))
+        tb = (t + 0.5) * interval
+        return t, int(8 - 1 - math.ceil(math.log(tb, 2)))
 
     def quantize(self):
+        """Same protocol as the product's ChannelCollector.quantize: all rows here when not distributed; after
+        reduce_scatter_hist() (the product's line) this rank's block only, then the product's all-gather of (threshold, bits)."""
+        if self._own_block is None:
+            res = [self._row_result(self._hist[r], self._interval[r]) for r in range(self._rows)]
+            thr, all_bits = [a for a, _b in res], [b for _a, b in res]
+        else:
+            lo, block = self._own_block
+            block = block.numpy()
+            local = np.zeros((2, block.shape[0]), dtype=np.int32)
+            for j in range(block.shape[0]):
+                if lo + j < self._rows:
+                    local[0, j], local[1, j] = self._row_result(block[j], self._interval[lo + j])
+            both = self.all_gather_rows(torch.from_numpy(local)).numpy()
+            thr, all_bits = both[0, :self._rows].tolist(), both[1, :self._rows].tolist()
+        self.threshold_bins = np.asarray(thr, dtype=np.int32)
         bits = {}
-        self.threshold_bins = np.zeros(self._rows, dtype=np.int32)
         for n in self._names:
             lo, hi = self.row_range(n)
-            bits[n] = []
-            for row in range(lo, hi):
-                t = orc.kl_threshold(orc.normalize(self._hist[row]))
-                self.threshold_bins[row] = t
-                tb = (t + 0.5) * self._interval[row]
-                bits[n].append(int(8 - 1 - math.ceil(math.log(tb, 2))))
+            bits[n] = [int(b) for b in all_bits[lo:hi]]
         return bits

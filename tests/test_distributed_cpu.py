@@ -133,6 +133,14 @@ CHANNEL_WORKER = textwrap.dedent('''
         dist.init_process_group("gloo")
     rank = dist.get_rank() if world > 1 else 0
     torch.set_num_threads(2)
+    # every collective this process issues: (name, dtype, elements)
+    calls = []
+    for name in ("all_reduce", "reduce_scatter_tensor", "all_gather_into_tensor"):
+        def spy(*a, _real=getattr(dist, name), _name=name, **k):
+            t = a[1] if _name == "reduce_scatter_tensor" else a[0]
+            calls.append([_name, str(t.dtype), int(t.numel())])
+            return _real(*a, **k)
+        setattr(dist, name, spy)
     with product_workdir(input_shape="1,3,16,16", device="cpu", max_cali_img_num=int(os.environ.get("FQ_TEST_MAX_CALI", "4"))) as tmp:
         model = merge_bn(cases.seed_model(cases.tiny_vgg_net()).eval())
         q = CpuQuantity(model)
@@ -142,8 +150,14 @@ CHANNEL_WORKER = textwrap.dedent('''
         json.dump(listing, open(r"{out}" + ".files.rank%d" % rank, "w"))
         c = q._channel_collector
         mx, hist = c._stat_tensors()
-        json.dump({{"bits": bits, "rows": c.rows, "max": mx.tolist(), "hist_row_sums": hist.sum(1).tolist(),
-                   "hist_digest": int((hist * (1 + torch.arange(hist.shape[1]))).sum()),
+        weights = 1 + torch.arange(hist.shape[1])
+        if c._own_block is None:                      # one process: every row is this rank's
+            lo, block = 0, hist[:c.rows]
+        else:
+            lo, block = c._own_block
+        json.dump({{"bits": bits, "rows": c.rows, "max": mx.tolist(), "calls": calls,
+                   "own_lo": int(lo), "own_row_sums": block.sum(1).tolist(), "own_row_digests": (block * weights).sum(1).tolist(),
+                   "thr": [int(t) for t in c.threshold_bins],
                    "table": open(os.path.join(wd, "feat_channel.table")).read() if rank == 0 else None}},
                   open(r"{out}" + ".rank%d" % rank, "w"))
     if world > 1:
@@ -168,18 +182,36 @@ def _run_channels(world, out, max_cali=4, batches=5, port=29671):
 
 
 @pytest.mark.timeout(1800)
-@pytest.mark.parametrize("world,max_cali", [(2, 4), (3, 0)])
+@pytest.mark.parametrize("world,max_cali", [(2, 4), (3, 0), (3, 4)])
 def test_per_channel_rows_are_shard_count_invariant(tmp_path, world, max_cali):
-    """BASELINE config 4's exchange -- one MAX all-reduce of the per-(tensor, channel) maxima, one SUM all-reduce of the
-    per-channel histograms -- on gloo ranks (the product's lines, `_collectives.py`, under `activation_quantize_per_channel`;
-    the rows themselves come from the oracle): every rank ends with the single-process maxima, histograms and bits, also a rank
-    that owned no batch (three ranks, one batch), and only rank 0 writes feat_channel.table."""
+    """BASELINE config 4's exchange on gloo ranks -- the product's lines (`_collectives.py`, under
+    `activation_quantize_per_channel`; the rows themselves come from the oracle): one MAX all-reduce of the per-(tensor, channel)
+    maxima, ONE reduce-scatter of the per-channel histograms (rank r receives the global rows of its block [r*S, (r+1)*S) and
+    nothing else), the KL sweep of that block on its owner, ONE all-gather of (threshold bin, bits).  No rank all-reduces the
+    histogram buffer.  Every rank ends with the single-process maxima, thresholds and bits -- also a rank that owned no batch
+    (three ranks, one batch) -- each rank's block equals the single-process histograms of those rows, and only rank 0 writes
+    feat_channel.table, byte-identical for W = 1 / 2 / 3."""
     one = _run_channels(1, str(tmp_path / "c1.json"), max_cali=max_cali)[0]
-    many = _run_channels(world, str(tmp_path / "cn.json"), max_cali=max_cali, port=29671 + world)
-    assert one["rows"] > 3 and sum(one["hist_row_sums"][:3]) == (max_cali + 1) * 2 * 3 * 16 * 16        # the image's three channels
-    for r in many:
-        for key in ("bits", "rows", "max", "hist_row_sums", "hist_digest"):
+    many = _run_channels(world, str(tmp_path / "cn.json"), max_cali=max_cali, port=29671 + world + 3 * max_cali)
+    rows = one["rows"]
+    assert rows > 3 and sum(one["own_row_sums"][:3]) == (max_cali + 1) * 2 * 3 * 16 * 16        # the image's three channels
+    assert one["calls"] == []                                                                  # one process: no collective at all
+    per = -(-rows // world)
+    for k, r in enumerate(many):
+        for key in ("bits", "rows", "max", "thr"):
             assert r[key] == one[key], key
+        # this rank's block: the single-process histograms of rows [k * per, (k + 1) * per), zero rows behind the last real one
+        lo = k * per
+        assert r["own_lo"] == lo and len(r["own_row_sums"]) == per
+        want_sums = (one["own_row_sums"][lo:lo + per] + [0] * per)[:per]
+        want_dig = (one["own_row_digests"][lo:lo + per] + [0] * per)[:per]
+        assert r["own_row_sums"] == want_sums and r["own_row_digests"] == want_dig
+        # the exchange itself: MAX over fp32[rows]; one reduce-scatter whose INPUT is the padded buffer; one all-gather of
+        # int32[2][per]; and no all-reduce of anything histogram sized
+        assert ["all_reduce", "torch.float32", rows] in r["calls"]
+        assert r["calls"].count(["reduce_scatter_tensor", "torch.int64", world * per * 2048]) == 1
+        assert r["calls"].count(["all_gather_into_tensor", "torch.int32", world * 2 * per]) == 1
+        assert not [c for c in r["calls"] if c[0] == "all_reduce" and c[2] >= 2048]
     assert many[0]["table"] == one["table"] and one["table"].startswith("image ")
     files = [json.load(open(str(tmp_path / "cn.json") + ".files.rank%d" % k)) for k in range(world)]
     assert "feat_channel.table" in files[0] and all(f == [] for f in files[1:])

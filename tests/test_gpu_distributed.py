@@ -25,12 +25,24 @@ WORKER = textwrap.dedent('''
     from model.resnet.ResNet_18_fabu import ResNet18
     from tools import Quantity
     torch.cuda.set_device(0)
+    with product_workdir(device="gpu", max_cali_img_num=1) as tmp:          # no process group yet: the single-process per-channel rows
+        q0 = Quantity(merge_bn(cases.seed_model(ResNet18()).eval()).cuda())
+        single = q0.activation_quantize_per_channel(cases.calib_batches(3, (4, 3, 32, 32)))
+        single_rows = int(q0._channel_collector.rows)
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
     calls, real = [], dist.all_reduce
     def counted(t, op=dist.ReduceOp.SUM, **kw):
         calls.append([str(op).split(".")[-1], str(t.dtype), t.device.type, t.numel()])
         return real(t, op=op, **kw)
     dist.all_reduce = counted
+    real_rs, real_ag = dist.reduce_scatter_tensor, dist.all_gather_into_tensor
+    def counted_rs(out, inp, op=dist.ReduceOp.SUM, **kw):
+        calls.append(["REDUCE_SCATTER", str(inp.dtype), inp.device.type, inp.numel()])
+        return real_rs(out, inp, op=op, **kw)
+    def counted_ag(out, inp, **kw):
+        calls.append(["ALL_GATHER", str(inp.dtype), inp.device.type, inp.numel()])
+        return real_ag(out, inp, **kw)
+    dist.reduce_scatter_tensor, dist.all_gather_into_tensor = counted_rs, counted_ag
     with product_workdir(device="gpu", max_cali_img_num=1) as tmp:
         q = Quantity(merge_bn(cases.seed_model(ResNet18()).eval()).cuda())
         q.activation_quantize(cases.calib_batches(3, (4, 3, 32, 32)))
@@ -38,6 +50,8 @@ WORKER = textwrap.dedent('''
                "calls": list(calls)}}
         by_module = q.activation_quantize_per_channel(cases.calib_batches(3, (4, 3, 32, 32)))
         out["per_channel"] = {{k: [int(b) for b in v] for k, v in by_module.items()}}
+        out["per_channel_single"] = {{k: [int(b) for b in v] for k, v in single.items()}}
+        out["rows"], out["calls_all"] = single_rows, list(calls)
     dist.barrier()
     json.dump(out, open(r"{out}", "w"))
     dist.destroy_process_group()
@@ -67,6 +81,14 @@ def test_single_rank_rccl_calibration_gives_the_reference_tables(tmp_path, golde
     assert ["MAX", "torch.float32", "cuda", 30] in got["calls"]
     assert ["SUM", "torch.int64", "cuda", 30 * 2048] in got["calls"]
     assert len(got["per_channel"]) == 30 and len(got["per_channel"]["image"]) == 3
+    # the per-channel exchange through RCCL on the device buffers: MAX of fp32[rows], ONE reduce-scatter of the histogram rows, ONE
+    # all-gather of int32 (threshold bin, bits) -- and the same bits as the process computed before it joined a group
+    rows = got["rows"]
+    assert got["per_channel"] == got["per_channel_single"]
+    assert ["MAX", "torch.float32", "cuda", rows] in got["calls_all"]
+    assert got["calls_all"].count(["REDUCE_SCATTER", "torch.int64", "cuda", rows * 2048]) == 1
+    assert got["calls_all"].count(["ALL_GATHER", "torch.int32", "cuda", 2 * rows]) == 1
+    assert not [c for c in got["calls_all"] if c[0] == "SUM" and c[3] == rows * 2048]
 
 
 @pytest.mark.timeout(1200)
