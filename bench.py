@@ -745,6 +745,15 @@ def main():
     from common.quantity import _native
     from tools import Quantity, Reconstruction
     _native.lib()
+    # every call of the segmented histogram since the process started, so that a kernel trace of this command can be cut to the
+    # timed region's launches by position (roofline.trace_slice; scripts/summarize_profile.py writes them out one per row)
+    hist_calls = [0]
+    _hist_entry = _native.hist2048_seg
+
+    def _counted_hist(*a, **k):
+        hist_calls[0] += -(-len(a[0]) // 96)          # dispatches: fq_hist2048_seg takes 96 segments per launch (kSegChunk)
+        return _hist_entry(*a, **k)
+    _native.hist2048_seg = _counted_hist
 
     K, W, B, HW = args.steps, args.warmup, args.batch, args.image
     TB = args.total_batches                                # batches of the WHOLE job (weak: K per rank; strong: fixed, dealt i % world)
@@ -768,13 +777,8 @@ def main():
         # one-shot process gets (no cache: the engine never grows its pool for one; allocation inside the clock) is
         # `value_cold`.
         if "FQ_ACT_CACHE_GB" not in os.environ:
-            free_b, total_b = torch.cuda.mem_get_info()
-            pooled_b = torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
             frac = float(os.environ.get("FQ_BENCH_POOL_FRAC", "%.4f" % (0.80 / sharing if sharing == 1 else 0.40 / sharing)))
-            grow = min(int(total_b * frac) - torch.cuda.memory_allocated(), free_b + pooled_b - (8 << 30))
-            if grow > 0:
-                pool = torch.empty(grow, dtype=torch.uint8, device=device)
-                del pool
+            Quantity.reserve_pool(frac, device)           # the product's service-mode switch (tools.Quantity.reserve_pool)
         del wq
     barrier()
 
@@ -784,6 +788,7 @@ def main():
     q = Quantity(model)
     q.profile_phases = True
     cache_budget = q._activation_cache_budget()            # per rank: every rank budgets its own GPU's pool
+    hist_calls_before = hist_calls[0]
     with CallTimer(_native, "hist2048_seg", _seg_bytes) as kt_hist:
         kt_hist.enabled = True
         barrier()
@@ -875,6 +880,10 @@ def main():
         pass
     if hist_s:
         result["roofline"] = hbm_roofline("hist2048_seg_kernel", hist_s, {"traffic": traffic, "traffic_source": traffic_src})
+        # where the timed launches sit in a kernel trace of this command: dispatches [first, first + count) of hist2048_seg_kernel in
+        # start order (a call is one dispatch per 96 segments; ResNet-50 has 71)
+        result["roofline"]["trace_slice"] = {"kernel": "hist2048_seg_kernel", "first": hist_calls_before,
+                                             "count": hist_calls[0] - hist_calls_before}
 
     # ---- the same calibration with the float 1x1 layers on the split-bf16 kernels (FQ_CONV_SPLIT_BF16=1: every fp32 operand as three
     # bf16 pieces, six of the nine products on the bf16 matrix cores, fp32 accumulation -- as accurate as the fp32 fma chain, DESIGN.md
@@ -1015,24 +1024,64 @@ def main():
         if world == 1:
             result["roofline_bias_add_absmax"] = {"error": repr(e)}
 
-    # ---- the fused fake-quant kernel on its own (north_star: >= 60 % of the HBM roofline)
+    # ---- the fused fake-quant kernel on its own (north_star: >= 60 % of the HBM roofline).  EIGHT input / output pairs of 411 MB
+    # each (6.6 GB) are walked round robin, so that no launch finds any of its bytes in the 256 MB Infinity Cache (one pair
+    # replayed 20 times did: 822 MB is only 3.2 x the cache, and the fabric counters count its hits as traffic)
     try:
-        xq = torch.empty(802816 * 128, device=device)                    # the largest ResNet-50 activation at batch 128
-        xq.normal_()
-        yq = torch.empty_like(xq)
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(20)]
-        _native.quandequan(xq, 4, 8, out=yq)
-        for a, b in evs:
-            a.record()
+        n_el, pairs, reps = 802816 * 128, 8, 3                           # the largest ResNet-50 activation at batch 128
+        xs = [torch.empty(n_el, device=device).normal_() for _ in range(pairs)]
+        ys = [torch.empty(n_el, device=device) for _ in range(pairs)]
+        for xq, yq in zip(xs, ys):
             _native.quandequan(xq, 4, 8, out=yq)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(pairs * reps)]
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            _native.quandequan(xs[i % pairs], 4, 8, out=ys[i % pairs])
             b.record()
         torch.cuda.synchronize()
         ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         result["roofline_fakequant"] = hbm_roofline("unary_vec_kernel<QuanDequanOp>",
-                                                    {"launches": 20, "mean_ms": ms, "bytes_per_launch": xq.numel() * 8.0})
-        del xq, yq
+                                                    {"launches": len(evs), "mean_ms": ms, "bytes_per_launch": n_el * 8.0},
+                                                    {"working_set_gb": round(pairs * n_el * 8.0 / 1e9, 2),
+                                                     "note": "%d input/output pairs walked round robin (%.1f GB, 26 x the Infinity Cache): every "
+                                                             "byte comes from / goes to HBM" % (pairs, pairs * n_el * 8.0 / 1e9)})
+        del xs, ys
     except Exception as e:
         result["roofline_fakequant"] = {"error": repr(e)}
+    # ... and the form ReconTest actually runs (TestConv.forward = convolution, then QuanDequan of its output, reference
+    # new_quantity_op.py:283-292): the QuanDequan EPILOGUE of the own convolution kernels (conv1x1_f32_qd_kernel).  Measured on the
+    # layer where the output stream dominates -- 64 -> 256 channels @56x56, 256 images: 205 MB read, 822 MB written, 26.3 GFLOP, so the
+    # matrix pipe (0.167 ms at the fp32 MFMA peak) and HBM (0.128 ms at 8 TB/s) bound it about equally -- four operand sets round robin
+    try:
+        sets = 4
+        xs = [torch.empty(256, 64, 56, 56, device=device).normal_() for _ in range(sets)]
+        ys = [torch.empty(256, 256, 56, 56, device=device) for _ in range(sets)]
+        wt = torch.empty(64, 256, device=device).normal_(0, 0.1)
+        bq = torch.empty(256, device=device).normal_(0, 0.1)
+        for xq, yq in zip(xs, ys):
+            _native.conv1x1_f32(xq, wt, bq, 1, qd=(4, 8), out=yq)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(sets * 3)]
+        for i, (a, b) in enumerate(evs):
+            a.record()
+            _native.conv1x1_f32(xs[i % sets], wt, bq, 1, qd=(4, 8), out=ys[i % sets])
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        by = 4.0 * (xs[0].numel() + wt.numel() + ys[0].numel())
+        fl = 2.0 * 256 * 56 * 56 * 64 * 256
+        t_hbm, t_mfma = by / (HBM_PEAK_GBS * 1e9) * 1e3, fl / (F32_MFMA_PEAK_TFLOPS * 1e12) * 1e3
+        result["roofline_fakequant_fused"] = {
+            "bound": "mfma" if t_mfma >= t_hbm else "hbm", "kernel": "conv1x1_f32_qd_kernel (QuanDequan in the convolution's epilogue)",
+            "layer": "64 -> 256 channels @56x56, 256 images", "launches": len(evs), "mean_launch_ms": round(ms, 4),
+            "algorithmic_bytes_per_launch": by, "algorithmic_flops_per_launch": fl,
+            "hbm_gbs": round(by / (ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(by / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "tflops": round(fl / (ms * 1e-3) / 1e12, 1), "frac_of_mfma_peak": round(fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+            "bound_ms_per_launch": round(max(t_hbm, t_mfma), 4), "frac_of_bound": round(max(t_hbm, t_mfma) / ms, 4),
+            "working_set_gb": round(sets * by / 1e9, 2),
+            "note": "what ReconTest runs: no standalone QuanDequan pass at all (4 B/element saved against convolution + fq_quandequan_f32)"}
+        del xs, ys
+    except Exception as e:
+        result["roofline_fakequant_fused"] = {"error": repr(e)}
 
     # ---- int8-sim / fake-quant forward throughput (BASELINE config[2]); replicas only, no data-path collective.
     # Collectives in this section (barriers, the MAX of the elapsed times) are never inside a try: local work is

@@ -318,6 +318,26 @@ class Quantity(_FusedForward, _FileInputs):
                 groups.append(bottoms)
         return groups
 
+    @staticmethod
+    def reserve_pool(fraction=0.80, device=None, keep_free=8 << 30):
+        """EXTENSION (no reference counterpart): grow the caching allocator's pool of `device` to `fraction` of its HBM, once, OUTSIDE
+        any calibration -- the service-mode switch.  A calibration never grows its pool for the activation cache (28 ms per GB of
+        fresh hipMalloc costs more than a cached GB saves, see _activation_cache_budget), so a fresh process runs pass 2 on second
+        forwards; a process that calibrates repeatedly (or one big job) calls this first and every later
+        activation_quantize() keeps pass 1's activations in the pool instead.  Returns the bytes the pool holds afterwards
+        (torch.cuda.memory_reserved()); a no-op on a host without a GPU.  Never takes the last `keep_free` bytes of the device."""
+        if not torch.cuda.is_available():
+            return 0
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        pooled_b = torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)
+        # one block of everything still missing: the allocator keeps it whole and carves the cache's tensors out of it
+        grow = min(int(total_b * float(fraction)) - torch.cuda.memory_reserved(dev), free_b - int(keep_free))
+        if grow > (64 << 20):
+            block = torch.empty(grow, dtype=torch.uint8, device=dev)
+            del block
+        return int(torch.cuda.memory_reserved(dev))
+
     def _activation_cache_budget(self):
         """Bytes of HBM that pass 1 may keep alive for pass 2 (0 disables the cache)."""
         if self.device != "gpu" or not torch.cuda.is_available():

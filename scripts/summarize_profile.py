@@ -16,6 +16,51 @@ def rows(pattern):
                 yield r
 
 
+# ---- the timed region's histogram launches, one per row (profiles/rNN_hist_timed_launches.csv): bench.py's line says which
+# dispatches of hist2048_seg_kernel they are (roofline.trace_slice), the kernel trace holds each dispatch's start / end
+def timed_hist_launches():
+    import json
+    line = None
+    for name in ("bench_line.json",):
+        path = os.path.join(out, name)
+        if os.path.isfile(path):
+            cand = [ln for ln in open(path).read().split("\n") if ln.startswith("{")]
+            line = json.loads(cand[-1]) if cand else None
+    if not line or "trace_slice" not in line.get("roofline", {}):
+        print("== no roofline.trace_slice in bench_line.json: timed launches not isolated ==")
+        return
+    sl, roof = line["roofline"]["trace_slice"], line["roofline"]
+    disp = [r for r in rows("trace/**/*kernel_trace.csv") if sl["kernel"] in r.get("Kernel_Name", "")]
+    disp.sort(key=lambda r: int(r["Start_Timestamp"]))
+    picked = disp[sl["first"]:sl["first"] + sl["count"]]
+    if len(picked) != sl["count"]:
+        print("== kernel trace holds %d dispatches of %s, the slice wants [%d, %d) ==" % (len(disp), sl["kernel"], sl["first"],
+                                                                                        sl["first"] + sl["count"]))
+        return
+    path = os.path.join(out, "hist_timed_launches.csv")
+    durs = []
+    with open(path, "w", newline="") as fh:
+        w = csv.writer(fh)
+        w.writerow(["dispatch_index_of_this_kernel", "start_ns", "end_ns", "duration_us", "grid_size", "workgroup_size",
+                    "algorithmic_bytes", "GB_per_s", "frac_of_8000_GB_per_s"])
+        for i, r in enumerate(picked):
+            d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+            durs.append(d)
+            gbs = roof["algorithmic_bytes_per_launch"] / (d * 1e-6) / 1e9
+            w.writerow([sl["first"] + i, r["Start_Timestamp"], r["End_Timestamp"], "%.3f" % d, r.get("Grid_Size", ""),
+                        r.get("Workgroup_Size", ""), int(roof["algorithmic_bytes_per_launch"]), "%.1f" % gbs, "%.4f" % (gbs / 8000.0)])
+    mean = sum(durs) / len(durs)
+    print("== the %d timed launches of %s (dispatches %d..%d of the trace) -> %s ==" % (len(durs), sl["kernel"], sl["first"],
+                                                                                      sl["first"] + len(durs) - 1, path))
+    print("   mean %.1f us (min %.1f, max %.1f); %.0f algorithmic bytes per launch -> %.1f GB/s = %.4f of 8000; bench.py's HIP events in "
+          "the same run: mean %.1f us -> frac %.4f" % (mean, min(durs), max(durs), roof["algorithmic_bytes_per_launch"],
+                                                       roof["algorithmic_bytes_per_launch"] / (mean * 1e-6) / 1e9,
+                                                       roof["algorithmic_bytes_per_launch"] / (mean * 1e-6) / 1e9 / 8000.0,
+                                                       roof["mean_launch_ms"] * 1e3, roof["frac"]))
+
+
+timed_hist_launches()
+
 print("== kernel stats (fq:: kernels and top 8 overall) ==")
 stats = list(rows("trace/**/*kernel_stats.csv"))
 for i, r in enumerate(stats):

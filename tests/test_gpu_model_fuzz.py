@@ -66,7 +66,9 @@ def test_random_topologies_give_the_unfused_tables():
     mf = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mf)
     found = []
-    bad, seen = mf.run(48, 11, log=found.append)
+    # evidence size inside the suite (300 models, ~2 minutes; FQ_FUZZ_MODELS shrinks it for a quick local run): round 5's two real
+    # dataflow bugs were found by exactly this fuzzer at a few hundred models, not at 48
+    bad, seen = mf.run(int(os.environ.get("FQ_FUZZ_MODELS", "300")), 11, log=found.append)
     assert bad == 0, [m for m in found if not m.startswith("  (")]
     # ... and the fused paths really ran on these graphs
     assert seen["conv_add_chains_proven"] > 0 and seen["conv_add_launches"] > 0 and seen["conv_add_hist_launches"] > 0
@@ -109,7 +111,7 @@ def test_resident_integer_plans_of_random_topologies_give_the_boundary_logits():
     rf = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(rf)
     found = []
-    bad, seen = rf.run(40, 3, log=found.append)
+    bad, seen = rf.run(int(os.environ.get("FQ_FUZZ_MODELS", "300")), 3, log=found.append)
     assert bad == 0, found
     assert seen["resident_convs"] > 300 and seen["fused_conv_adds"] > 40 and seen["fused_relus"] > 200, seen
     assert seen["fused_block_tails"] > 5 and seen["fused_projections"] > 0 and seen["resident_pools"] > 5, seen
