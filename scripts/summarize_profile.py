@@ -47,8 +47,8 @@ def timed_hist_launches():
             d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             durs.append(d)
             gbs = roof["algorithmic_bytes_per_launch"] / (d * 1e-6) / 1e9
-            w.writerow([sl["first"] + i, r["Start_Timestamp"], r["End_Timestamp"], "%.3f" % d, r.get("Grid_Size", ""),
-                        r.get("Workgroup_Size", ""), int(roof["algorithmic_bytes_per_launch"]), "%.1f" % gbs, "%.4f" % (gbs / 8000.0)])
+            w.writerow([sl["first"] + i, r["Start_Timestamp"], r["End_Timestamp"], "%.3f" % d, r.get("Grid_Size", r.get("Grid_Size_X", "")),
+                        r.get("Workgroup_Size", r.get("Workgroup_Size_X", "")), int(roof["algorithmic_bytes_per_launch"]), "%.1f" % gbs, "%.4f" % (gbs / 8000.0)])
     mean = sum(durs) / len(durs)
     print("== the %d timed launches of %s (dispatches %d..%d of the trace) -> %s ==" % (len(durs), sl["kernel"], sl["first"],
                                                                                       sl["first"] + len(durs) - 1, path))
