@@ -136,6 +136,21 @@ int fq_bits_from_threshold(const int32_t* thr, const float* interval, int rows,
 /* HOST helper: pytorch_quantizer.py:651-653  bits = 7 - ceil(log(absmax)/log(2)). absmax > 0. */
 int fq_bits_from_absmax(const float* absmax, int n, int32_t* bits_out);
 
+/* A tensor and a sum in one pass (pass 2 of a calibration whose pass 1 did not write a residual block's Eltwise output because
+ * both of its operands are kept anyway): for every pair, a[i] is counted into row_a (skipped when row_a = -1) and
+ * fl32(a[i] + b[i]) -- the fp32 addition fabu_layer.py:5-11 performs -- into row_sum, exactly as fq_hist2048_seg would count
+ * the stored tensors (distribution_collector.py:127-135).  a and b are device pointers to n floats each, 16-byte aligned
+ * (FQ_ERR_UNSUPPORTED otherwise: the caller then materialises the sum); row_a != row_sum. */
+typedef struct fq_pair_seg {
+    const float* a;
+    const float* b;
+    size_t n;
+    int32_t row_a;
+    int32_t row_sum;
+} fq_pair_seg;
+int fq_hist2048_pair_seg(const fq_pair_seg* segs, int nseg, const float* interval, int64_t* hist,
+                         fq_stream_t stream);
+
 /* ---- per-channel rows (extension: the reference calibrates per tensor, distribution_collector.py:40-42) ---- */
 /* One histogram row per (tensor, channel): tensor [N][C][HW] (dense NCHW; HW = 1 for [N][F]) feeds rows
  * row0 .. row0 + C - 1, channel c being the N planes at (n*C + c)*HW.  Same arithmetic per row as the

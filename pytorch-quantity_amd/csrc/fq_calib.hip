@@ -195,6 +195,117 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable
 }
 
 // ---------------------------------------------------------------------------------------------
+// pairs: the histogram of a tensor a AND of the sum a + b in one pass over both (fq_hist2048_pair_seg)
+// ---------------------------------------------------------------------------------------------
+// A residual block's Eltwise output is conv3's output + the shortcut.  When pass 1 keeps conv3's output for pass 2 anyway and
+// the shortcut (the previous block's ReLU output) exists anyway, the sum need not be written at all: pass 2 reads the two
+// operands once and bins a into row_a and fl32(a + b) -- the very addition the Eltwise performs -- into row_sum.  Same bytes
+// as reading a and a stored sum; pass 1 writes 4 B per element less.  Both pointers 16-byte aligned (host check).
+constexpr int kPairChunk = 64;         // pairs per launch (kernarg block 2.4 KB)
+struct PairTable {
+    const float* a[kPairChunk];
+    const float* b[kPairChunk];
+    uint64_t n[kPairChunk];
+    uint32_t chunk_begin[kPairChunk + 1];
+    int32_t row_a[kPairChunk];            // -1: a is not histogrammed (only the sum)
+    int32_t row_s[kPairChunk];
+    uint32_t chunks_per_wg;
+    uint32_t total_chunks;
+    int32_t nseg;
+};
+
+// chunks [c0, c1) of one pair: 16-byte vectors, two of each operand in flight per lane; the last n % 4 elements are scalar
+template <int kThreads, typename F>
+__device__ __forceinline__ void for_each_pair_in_chunks(const float* pa, const float* pb, uint64_t cnt, uint32_t c0, uint32_t c1, F&& f) {
+    const int tid = threadIdx.x;
+    const f4v* __restrict__ va = reinterpret_cast<const f4v*>(pa);
+    const f4v* __restrict__ vb = reinterpret_cast<const f4v*>(pb);
+    const uint64_t nvec = cnt >> 2;
+    uint64_t base = (uint64_t)c0 * kChunkVec;
+    const uint64_t end = (uint64_t)c1 * kChunkVec < nvec ? (uint64_t)c1 * kChunkVec : nvec;
+    for (; base + 2 * kThreads <= end; base += 2 * kThreads) {
+        const uint64_t i = base + tid;
+        const f4v a0 = stream_load(&va[i]);
+        const f4v a1 = stream_load(&va[i + kThreads]);
+        const f4v b0 = stream_load(&vb[i]);
+        const f4v b1 = stream_load(&vb[i + kThreads]);
+        __builtin_amdgcn_sched_barrier(0);            // the four loads in flight together (see for_each_in_chunks)
+        f(a0.x, b0.x); f(a0.y, b0.y); f(a0.z, b0.z); f(a0.w, b0.w);
+        f(a1.x, b1.x); f(a1.y, b1.y); f(a1.z, b1.z); f(a1.w, b1.w);
+    }
+    for (uint64_t i = base + tid; i < end; i += kThreads) {
+        const f4v a0 = stream_load(&va[i]);
+        const f4v b0 = stream_load(&vb[i]);
+        f(a0.x, b0.x); f(a0.y, b0.y); f(a0.z, b0.z); f(a0.w, b0.w);
+    }
+    const uint32_t tail = (uint32_t)(cnt & 3u);
+    if (c0 == 0 && (uint32_t)tid < tail) f(pa[(nvec << 2) + tid], pb[(nvec << 2) + tid]);
+}
+
+template <bool kFastA, bool kFastS>
+__device__ __forceinline__ void pair_piece(const float* pa, const float* pb, uint64_t n, uint32_t c0, uint32_t c1, float iva, float ivs,
+                                           bool want_a, unsigned int* bins_a, unsigned int* bins_s) {
+    const float ya = 1.0f / iva, ys = 1.0f / ivs;
+    unsigned int* park = bins_s + FQ_BINS + (threadIdx.x & (kWave - 1));
+    if (want_a) {
+        for_each_pair_in_chunks<kHistBlock>(pa, pb, n, c0, c1, [&](float a, float b) {
+            const float s = a + b;                    // (-ffp-contract=off: one rounded fp32 addition, the Eltwise's)
+            atomicAdd((a != 0.0f) ? (bins_a + bin_of<kFastA>(a, iva, ya)) : park, 1u);
+            atomicAdd((s != 0.0f) ? (bins_s + bin_of<kFastS>(s, ivs, ys)) : park, 1u);
+        });
+    } else {
+        for_each_pair_in_chunks<kHistBlock>(pa, pb, n, c0, c1, [&](float a, float b) {
+            const float s = a + b;
+            atomicAdd((s != 0.0f) ? (bins_s + bin_of<kFastS>(s, ivs, ys)) : park, 1u);
+        });
+    }
+}
+
+__global__ __launch_bounds__(kHistBlock) void hist2048_pair_seg_kernel(const PairTable tab, const float* __restrict__ interval,
+                                                                   unsigned long long* __restrict__ hist, const int allow_fast) {
+    __shared__ unsigned int s_a[FQ_BINS];
+    __shared__ unsigned int s_s[FQ_BINS + kWave];
+    for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) s_a[b] = 0u;
+    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kHistBlock) s_s[b] = 0u;
+    __syncthreads();
+    uint32_t c = blockIdx.x * tab.chunks_per_wg;
+    const uint32_t c_end = c + tab.chunks_per_wg < tab.total_chunks ? c + tab.chunks_per_wg : tab.total_chunks;
+    int s = 0;
+    {
+        int lo = 0, hi = tab.nseg - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (tab.chunk_begin[mid] <= c) lo = mid; else hi = mid - 1;
+        }
+        s = lo;
+    }
+    while (c < c_end) {
+        const uint32_t seg_end = tab.chunk_begin[s + 1];
+        const uint32_t stop = seg_end < c_end ? seg_end : c_end;
+        const uint32_t c0 = c - tab.chunk_begin[s], c1 = stop - tab.chunk_begin[s];
+        const int ra = tab.row_a[s], rs = tab.row_s[s];
+        const float ivs = interval[rs], iva = ra >= 0 ? interval[ra] : 1.0f;
+        const bool fa = allow_fast && fast_quotient_ok(iva), fs = allow_fast && fast_quotient_ok(ivs);      // uniform per workgroup
+        if (fa && fs) pair_piece<true, true>(tab.a[s], tab.b[s], tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);
+        else if (fa) pair_piece<true, false>(tab.a[s], tab.b[s], tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);
+        else if (fs) pair_piece<false, true>(tab.a[s], tab.b[s], tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);
+        else pair_piece<false, false>(tab.a[s], tab.b[s], tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);
+        __syncthreads();
+        unsigned long long* __restrict__ ds = hist + (size_t)rs * FQ_BINS;
+        unsigned long long* __restrict__ da = hist + (size_t)(ra >= 0 ? ra : rs) * FQ_BINS;
+        for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) {
+            const unsigned int cs = s_s[b];
+            if (cs) { atomicAdd(ds + b, (unsigned long long)cs); s_s[b] = 0u; }
+            const unsigned int ca = s_a[b];
+            if (ca) { atomicAdd(da + b, (unsigned long long)ca); s_a[b] = 0u; }
+        }
+        __syncthreads();
+        c = stop;
+        ++s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-channel rows: one histogram row per (tensor, channel) of an NCHW activation
 // ---------------------------------------------------------------------------------------------
 // A row is no longer one contiguous run: channel c of tensor [N][C][HW] is the N planes at (n*C + c)*HW.  The tensor is
@@ -616,6 +727,55 @@ extern "C" int fq_hist2048_seg(const fq_seg* segs, int nseg, const float* interv
         FQ_LAUNCH_CHECK();
         return FQ_OK;
     });
+}
+
+extern "C" int fq_hist2048_pair_seg(const fq_pair_seg* segs, int nseg, const float* interval, int64_t* hist, fq_stream_t stream) {
+    using namespace fq;
+    if (nseg < 0 || nseg > FQ_MAX_SEGS || (nseg > 0 && segs == nullptr)) return FQ_ERR_INVALID_ARG;
+    for (int i = 0; i < nseg; ++i) {
+        const fq_pair_seg& p = segs[i];
+        if (p.row_sum < 0 || p.row_a < -1 || p.row_a == p.row_sum) return FQ_ERR_INVALID_ARG;
+        if (p.n != 0 && (p.a == nullptr || p.b == nullptr)) return FQ_ERR_INVALID_ARG;
+        if ((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b)) & 3u) return FQ_ERR_INVALID_ARG;
+        if (p.n != 0 && ((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b)) & 15u)) return FQ_ERR_UNSUPPORTED;
+    }
+    if (nseg == 0) return FQ_OK;
+    if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    int i = 0;
+    while (i < nseg) {
+        PairTable tab;
+        int k = 0;
+        uint64_t chunks = 0;
+        while (i < nseg && k < kPairChunk) {
+            const fq_pair_seg& p = segs[i++];
+            if (p.n == 0) continue;
+            const uint64_t nvec = p.n >> 2;
+            uint64_t nc = (nvec + kChunkVec - 1) / kChunkVec;
+            if (nc == 0) nc = 1;                                     // fewer than four elements: the scalar tail of chunk 0
+            if (chunks + nc > 0x7fffffffULL) { --i; break; }
+            tab.a[k] = p.a; tab.b[k] = p.b; tab.n[k] = p.n; tab.row_a[k] = p.row_a; tab.row_s[k] = p.row_sum;
+            tab.chunk_begin[k] = (uint32_t)chunks;
+            chunks += nc;
+            ++k;
+        }
+        if (k == 0) {
+            if (i < nseg && segs[i].n != 0) return FQ_ERR_INVALID_ARG;
+            continue;
+        }
+        tab.nseg = k;
+        for (int j = k; j <= kPairChunk; ++j) tab.chunk_begin[j] = (uint32_t)chunks;
+        for (int j = k; j < kPairChunk; ++j) { tab.a[j] = tab.b[j] = nullptr; tab.n[j] = 0; tab.row_a[j] = -1; tab.row_s[j] = 0; }
+        const uint64_t slots = (uint64_t)kCUs * wg_per_cu(kWgPerCUHist);
+        uint64_t per_wg = (chunks + slots - 1) / slots;
+        if (per_wg < kMinChunksPerWg) per_wg = kMinChunksPerWg;
+        tab.chunks_per_wg = (uint32_t)per_wg;
+        tab.total_chunks = (uint32_t)chunks;
+        hipLaunchKernelGGL(hist2048_pair_seg_kernel, dim3((uint32_t)((chunks + per_wg - 1) / per_wg)), dim3(kHistBlock), 0, st, tab, interval,
+                           reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
+        FQ_LAUNCH_CHECK();
+    }
+    return FQ_OK;
 }
 
 extern "C" int fq_absmax_chan(const fq_chan_seg* segs, int nseg, float* max_inout, fq_stream_t stream) {

@@ -26,6 +26,10 @@ class _Seg(ctypes.Structure):
                 ("reserved", ctypes.c_int32)]
 
 
+class _PairSeg(ctypes.Structure):
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("n", ctypes.c_size_t), ("row_a", ctypes.c_int32), ("row_sum", ctypes.c_int32)]
+
+
 class _ChanSeg(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("HW", ctypes.c_int64),
                 ("row0", ctypes.c_int32), ("reserved", ctypes.c_int32)]
@@ -55,6 +59,8 @@ def lib():
     L.fq_absmax_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp]
     L.fq_hist2048_seg.restype = ci
     L.fq_hist2048_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp, vp]
+    L.fq_hist2048_pair_seg.restype = ci
+    L.fq_hist2048_pair_seg.argtypes = [ctypes.POINTER(_PairSeg), ci, vp, vp, vp]
     L.fq_absmax_chan.restype = ci
     L.fq_absmax_chan.argtypes = [ctypes.POINTER(_ChanSeg), ci, vp, vp]
     L.fq_hist2048_chan.restype = ci
@@ -285,6 +291,31 @@ def hist2048_seg(tensors, rows, interval, hist):
     arr, keep = _seg_array(tensors, rows)
     _check(lib().fq_hist2048_seg(arr, len(tensors), interval.data_ptr(), hist.data_ptr(), _stream(hist)),
            "fq_hist2048_seg")
+    return keep
+
+
+def hist2048_pair_seg(a_tensors, b_tensors, rows_a, rows_sum, interval, hist):
+    """fq_hist2048_pair_seg: for every pair, a counted into hist[row_a] (row_a None / -1: not counted) and a + b (the fp32 addition
+    of an Eltwise) into hist[row_sum], one pass over both.  Dense fp32 CUDA tensors of equal size, 16-byte aligned."""
+    if not a_tensors:
+        return
+    _need_cuda(interval, torch.float32, "interval")
+    _need_cuda(hist, torch.int64, "hist")
+    assert hist.is_contiguous() and hist.shape[-1] == BINS and len(a_tensors) == len(b_tensors) == len(rows_a) == len(rows_sum)
+    arr = (_PairSeg * len(a_tensors))()
+    keep = []
+    for i, (a, b, ra, rs) in enumerate(zip(a_tensors, b_tensors, rows_a, rows_sum)):
+        _need_cuda(a, torch.float32, "pair %d a" % i)
+        _need_cuda(b, torch.float32, "pair %d b" % i)
+        assert a.shape == b.shape, "the operands of a pair have different shapes"
+        da, db = dense_view(a), dense_view(b)
+        if da.stride() != db.stride():                         # element i of one must be element i of the other in storage order
+            da, db = a.contiguous(), b.contiguous()
+        keep += [da, db]
+        arr[i].a, arr[i].b, arr[i].n = da.data_ptr(), db.data_ptr(), da.numel()
+        arr[i].row_a, arr[i].row_sum = (-1 if ra is None else int(ra)), int(rs)
+        assert arr[i].row_sum < hist.numel() // BINS and arr[i].row_a < hist.numel() // BINS
+    _check(lib().fq_hist2048_pair_seg(arr, len(a_tensors), interval.data_ptr(), hist.data_ptr(), _stream(hist)), "fq_hist2048_pair_seg")
     return keep
 
 

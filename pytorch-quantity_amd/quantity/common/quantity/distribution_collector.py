@@ -122,6 +122,24 @@ class DistributionCollector(StatCollectives):
         self._keepalive = _native.hist2048_seg(segs, rows, self._interval_dev, self._hist_dev)
 
     # ------------------------------------------------------------------ beyond the reference API
+    supports_pairs = True       # add_pairs_to_distributions(): a tensor and a sum of two tensors in one pass
+
+    def add_pairs_to_distributions(self, pairs):
+        """pairs: [(a, b, name of a's row or None, name of the sum's row)].  a is counted into its row and a + b -- the fp32
+        addition an Eltwise performs (fabu_layer.py:5-11) -- into the sum's row, exactly as add_to_distributions() would count
+        the two stored tensors; the sum itself is never written (fq_hist2048_pair_seg)."""
+        if not pairs:
+            return
+        self._added_to_distributions_flag = True
+        if not hasattr(self, "_distribution_intervals"):
+            self.distribution_intervals
+        self._sync_intervals()
+        a = [_as_device_f32(p[0], self._device) for p in pairs]
+        b = [_as_device_f32(p[1], self._device) for p in pairs]
+        rows_a = [None if p[2] is None else self.row_of(p[2]) for p in pairs]
+        rows_s = [self.row_of(p[3]) for p in pairs]
+        self._keepalive_pairs = _native.hist2048_pair_seg(a, b, rows_a, rows_s, self._interval_dev, self._hist_dev)
+
     supports_partial = True     # refresh_max_val / add_to_distributions accept a dict holding only SOME of the tensors
 
     def row_of(self, name):

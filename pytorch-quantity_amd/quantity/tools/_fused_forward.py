@@ -267,6 +267,15 @@ class _FusedForward(object):
         relu = ctl.relu_after.get(m) if self.fuse_relu else None
         keep = lambda name: self.materialize_all or (ctl.keep_feats and (ctl.keep_names is None or name in ctl.keep_names))
         keep_y, keep_s = keep(conv_key), keep(key) if key is not None else True
+        # Both wanted by pass 2's cache: the sum is conv3's output + the shortcut, and the shortcut exists anyway -- so the sum is
+        # NOT written (4 B per element less, and small planes keep the one-kernel form); the cache keeps the shortcut in its place
+        # and pass 2 histograms the pair (fq_hist2048_pair_seg).  Only for an Eltwise whose shortcut the probe forward has seen
+        # unmodified until the end of the forward (ctl.pair_ok), and never when somebody wants every tensor materialised.
+        pair = (keep_y and keep_s and key is not None and self.pair_hist and not self.materialize_all and m in ctl.pair_ok
+                and ctl.fuse_stat != "hist" and ctl.eager is not None and getattr(coll, "supports_pairs", False)
+                and other.dtype == torch.float32 and other.data_ptr() % 16 == 0 and t3.data_ptr() % 16 == 0)
+        if pair:
+            keep_s = False
         # (small planes with BOTH tensors kept: three store streams of partial lines make the one kernel slower than the two,
         #  scripts/conv_add_bench.py: 356 vs 340 us at 14 x 14, 283 vs 276 at 7 x 7)
         small = t3.shape[2] * t3.shape[3] < 28 * 28
@@ -291,6 +300,9 @@ class _FusedForward(object):
         coll.note_max_refreshed()
         if keep_y and ctl.eager is not None:
             ctl.eager.note(conv_key, t3)                        # (what its own hook left out: the tensor exists only now)
+        if pair:
+            ctl.pairs[key] = (conv_key, other, other._version)
+            ctl.pair_sums += 1
         ctl.fuse_verified.add(m)
         ctl.relu_ready = (output, r, relu, output._version)
         ctl.fused_relus.add(relu)
@@ -543,4 +555,8 @@ class _FusedForward(object):
         self._probe_out = None
         if not ok:
             return {}, set()
+        # ... and the Eltwises whose shortcut operand was still as the add saw it when the learning forward ended: pass 2 may read it
+        # in place of a stored sum (Quantity.pair_hist).  (Both probe forwards ran the same code on the same input.)
+        ctl.pair_ok = set(elt for elt, (o, v) in probe.others.items() if torch.is_tensor(o) and o._version == v)
+        probe.others = {}
         return {conv: pair[0] for conv, pair in probe.candidates.items()}, set(probe.relu_only)

@@ -90,6 +90,7 @@ class _DeferralProbe(object):
         self.candidates = {}        # conv module -> (Eltwise module, nn.ReLU module)
         self.relu_only = {}         # conv module -> the nn.ReLU that is the only reader of its output (skip_unread_outputs)
         self.private = {}           # poison: id(poisoned tensor) -> (poisoned tensor, real tensor, the one module that may read it)
+        self.others = {}            # learn: Eltwise module -> (its OTHER operand -- the shortcut --, that tensor's version at the add)
 
     def conv_done(self, m, y):
         if self.mode == "learn":
@@ -114,6 +115,9 @@ class _DeferralProbe(object):
                 e = self.conv_out.get(id(t)) if torch.is_tensor(t) else None
                 if e is not None and e[0] is t:
                     self.pairs.setdefault(m, e[1])
+                    other = y if t is x else x
+                    if torch.is_tensor(other) and other is not t:
+                        self.others.setdefault(m, (other, other._version))
                     break
             return None
         rx, ry = self.real(x, m), self.real(y, m)
@@ -188,7 +192,8 @@ class _HookState(object):
     The rest are counters for Quantity.timings."""
     __slots__ = ("stop_after", "events", "eager", "fuse_bias", "fuse_collector", "fuse_off", "fuse_verified", "fuse_warm",
                  "relu_after", "relu_ready", "last_out", "fused_relus", "fuse_stat", "hist_fused", "keep_feats", "keep_names",
-                 "own_plain", "own_conv1x1", "deferred", "defer_ok", "deferred_adds", "deferred_hists", "poison", "relu_only_ok", "skipped_outputs")
+                 "own_plain", "own_conv1x1", "deferred", "defer_ok", "deferred_adds", "deferred_hists", "poison", "relu_only_ok", "skipped_outputs",
+                 "pair_ok", "pairs", "pair_sums")
 
     def __init__(self):
         self.stop_after = None          # ordinal of the last module pass 2 needs (the hook raises _StopForward there)
@@ -217,3 +222,7 @@ class _HookState(object):
         self.poison = None              # the _DeferralProbe of a running probe forward
         self.relu_only_ok = set()       # convolutions whose output only their nn.ReLU reads (same proof)
         self.skipped_outputs = 0        # launches that did not write the convolution's own output
+        self.pair_ok = set()            # Eltwise modules whose shortcut operand nobody writes to after the add (probe forward)
+        self.pairs = {}                 # THIS forward: key of a sum that was not written -> (key of conv3's output, the shortcut
+        #                                 tensor, its version): pass 2 histograms the pair (fq_hist2048_pair_seg)
+        self.pair_sums = 0              # sums pass 1 did not write because pass 2 histograms (conv3 output, shortcut) instead

@@ -114,6 +114,10 @@ class Quantity(_FusedForward, _FileInputs):
     # tape the hooked tensors: the oracle-replay tests)
     materialize_all = False
     own_conv1x1 = _float_conv.enabled()                              # FQ_OWN_CONV1X1=0: A/B against the library convolutions
+    # A residual sum both of whose operands pass 2's cache keeps anyway (conv3's output; the shortcut = the previous block's ReLU
+    # output or the projection) is not written by pass 1: the cache keeps the shortcut in the sum's place and pass 2 histograms
+    # (conv3 output, conv3 output + shortcut) in one pass over the pair (fq_hist2048_pair_seg).  Same integers.
+    pair_hist = os.environ.get("FQ_PAIR_HIST", "1") != "0"
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -359,6 +363,57 @@ class Quantity(_FusedForward, _FileInputs):
         warm = pooled - (total >> 4)
         return max(warm, 0)
 
+    def _cache_entry(self, named_feats, keep):
+        """What pass 1 keeps of the forward that just ran: the hooked tensors named in `keep` (None: all) -- with every sum that
+        was not written replaced by its pair, ("pair", sum key) -> (key of conv3's output, that tensor, the shortcut tensor, the
+        shortcut's version, whether conv3's output is itself among the kept tensors).  Returns (entry, bytes it holds on to)."""
+        pairs = self._hook_ctl.pairs
+        entry, held, nbytes = {}, set(), 0
+
+        def hold(t):
+            if id(t) not in held:
+                held.add(id(t))
+                return t.numel() * t.element_size()
+            return 0
+        for n, t in named_feats.items():
+            if keep is not None and n not in keep:
+                continue
+            p = pairs.get(n)
+            if p is None:
+                entry[n] = t
+                nbytes += hold(t)
+                continue
+            conv_key, other, version = p
+            # (the forward that ran before the plan existed may have left a sum to its pair whose conv3 output the plan does not
+            #  keep: that one batch then holds the tensor privately, and pass 2 counts it where the prefix forward re-makes it)
+            y_kept = keep is None or conv_key in keep
+            entry[("pair", n)] = (conv_key, named_feats[conv_key], other, version, y_kept)
+            nbytes += hold(other) + hold(named_feats[conv_key])
+        return entry, nbytes
+
+    def _add_with_pairs(self, collector):
+        """collector.add_to_distributions for dicts that may hold pairs (see _cache_entry): the pairs go through
+        add_pairs_to_distributions, which also counts conv3's output -- that tensor then leaves the plain list."""
+        def add(feats):
+            pairs = [(k[1], v) for k, v in feats.items() if isinstance(k, tuple)]
+            if not pairs:
+                return collector.add_to_distributions(feats)
+            plain = dict((k, v) for k, v in feats.items() if not isinstance(k, tuple))
+            jobs = []
+            for sum_key, (conv_key, y, other, version, y_kept) in pairs:
+                if other._version != version:
+                    raise RuntimeError("the shortcut of %s was written to after the add that pass 1 left to pass 2; set "
+                                       "Quantity.pair_hist = False (FQ_PAIR_HIST=0)" % sum_key)
+                if y_kept and plain.pop(conv_key, None) is None:
+                    raise RuntimeError("pass 2 holds the pair of %s without %s" % (sum_key, conv_key))
+                jobs.append((y, other, conv_key if y_kept else None, sum_key))
+            if plain:
+                collector.add_to_distributions(plain)
+            collector.add_pairs_to_distributions(jobs)
+        add.__name__ = "add_to_distributions"
+        add.__self__ = collector
+        return add
+
     def _forward_with_stats(self, item, fn, named_feats, extra=None):
         """One forward (possibly ended early by the cache plan) with fn applied to every hooked tensor it produced and
         to `extra` (tensors of the same batch kept from pass 1).  Returns the _EagerStats of that forward, or None
@@ -373,6 +428,7 @@ class Quantity(_FusedForward, _FileInputs):
         eager = _EagerStats(fn, limit)
         eager.retain = self._hook_ctl.keep_feats
         self._hook_ctl.eager = eager
+        self._hook_ctl.pairs = {}
         try:
             self.net_forward(self.model, item)
         finally:
@@ -626,13 +682,12 @@ class Quantity(_FusedForward, _FileInputs):
             need_all = sum(t.numel() * t.element_size() for t in named_feats.values())
             if plan["kind"] == "A":
                 if len(cached) < plan["whole_batches"] and used + need_all <= budget:
-                    cached[i] = dict(named_feats)
+                    cached[i], nbytes = self._cache_entry(named_feats, None)
                     cached_ids.add(i)
-                    used += need_all
+                    used += nbytes
             else:
-                kept = {n: t for n, t in named_feats.items() if n in plan["keep"]}
-                cached[i] = kept
-                used += sum(t.numel() * t.element_size() for t in kept.values())
+                cached[i], nbytes = self._cache_entry(named_feats, plan["keep"])
+                used += nbytes
         ctl.fuse_collector = None
         self._join_stat_stream()
         if _dist_on():                      # also at world size 1: same code path, trivial cost
@@ -665,26 +720,27 @@ class Quantity(_FusedForward, _FileInputs):
             # whose kernels do not give the same bits from call to call: the histograms of such a model differed by a handful of
             # elements from one calibration to the next (scripts/model_fuzz.py, round 5).
             ctl.own_plain = True
+        add = self._add_with_pairs(collector) if ctl.pair_sums else collector.add_to_distributions
         if plan is not None and plan["kind"] == "B":
             ctl.stop_after = plan["stop_after"] if plan["stop_after"] else None
             try:
                 for i, item in self._device_items(images_files):
                     if plan["stop_after"]:
                         # ends at the last tensor that was not kept; fresh and kept tensors go out in one launch
-                        self._forward_with_stats(item, collector.add_to_distributions, named_feats, extra=cached.pop(i))
+                        self._forward_with_stats(item, add, named_feats, extra=cached.pop(i))
                         continue
                     feats = {"image": self.preprocess(item) if not torch.is_tensor(item) else item}
                     if self.device == "gpu" and feats["image"].device.type != "cuda":
                         feats["image"] = feats["image"].cuda()
                     feats.update(cached.pop(i))
-                    self._on_stat_stream(collector.add_to_distributions, feats)
+                    self._on_stat_stream(add, feats)
             finally:
                 ctl.stop_after = None
         else:
             for i in sorted(cached):
-                self._on_stat_stream(collector.add_to_distributions, cached[i])
+                self._on_stat_stream(add, cached[i])
             for i, item in self._device_items(self._skip(images_files, cached_ids)):
-                self._forward_with_stats(item, collector.add_to_distributions, named_feats)
+                self._forward_with_stats(item, add, named_feats)
         self._join_stat_stream()
         del cached
         ctl.fuse_collector, ctl.fuse_stat, ctl.own_plain = None, "max", False
@@ -740,6 +796,7 @@ class Quantity(_FusedForward, _FileInputs):
                         "own_conv1x1_launches": ctl.own_conv1x1,
                         "conv_add_chains_proven": len(ctl.defer_ok), "conv_add_launches": ctl.deferred_adds,
                         "conv_add_hist_launches": ctl.deferred_hists,
+                        "sums_left_to_pass2_pairs": ctl.pair_sums,
                         "relu_only_chains_proven": len(ctl.relu_only_ok), "launches_without_own_output": ctl.skipped_outputs,
                         "chains_refused_for_keepers": dict(getattr(self, "deferral_refused", None) or {}),
                         "stats_group_bytes": self._stats_limit,

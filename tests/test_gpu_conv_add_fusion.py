@@ -52,7 +52,7 @@ def _block_net(variant="plain", hw=64):
     return Net()
 
 
-def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None, hw=64, skip=None):
+def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None, hw=64, skip=None, pair=None):
     from tools import Quantity
     if monkeypatch is not None and cache_gb is not None:
         monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
@@ -61,6 +61,8 @@ def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None,
         q = Quantity(model)
         q.fuse_conv_add = fuse
         q.skip_unread_outputs = fuse if skip is None else skip
+        if pair is not None:
+            q.pair_hist = pair
         bits = q.activation_quantize(cases.calib_batches(batches, (8, 3, hw, hw), seed=91))
         table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
         return dict(bits), table, dict(q._collector.max_vals), q._collector.hist_device.clone(), dict(q.timings)
@@ -111,18 +113,68 @@ def test_convolution_outputs_only_their_relu_reads_are_not_written(monkeypatch, 
         assert 0 < n < 4 * 5 + 4 * 5           # the early tensors are not kept, the deep ones are
 
 
-def test_small_planes_with_both_tensors_kept_stay_on_the_two_kernels(monkeypatch):
-    """8 x 8 planes and a cache that keeps everything: three store streams of partial lines make the one kernel slower than
-    the two (scripts/conv_add_bench.py), so the convolution is launched on its own after all -- same tables; without a cache
-    the same planes take the one kernel."""
+def test_small_planes_with_both_tensors_kept(monkeypatch):
+    """8 x 8 planes and a cache that keeps everything.  With the sum written (pair_hist off) three store streams of partial lines
+    make the one kernel slower than the two (scripts/conv_add_bench.py), so the convolution is launched on its own after all.
+    With pair_hist (the default) the sum is not written -- the cache keeps the shortcut in its place and pass 2 histograms the
+    pair -- so the same planes take the one kernel with its two store streams.  Same tables either way; without a cache the
+    planes take the one kernel too."""
     model = cases.seed_model(_block_net(hw=16), base_seed=8).eval().cuda()
     want = _calibrate(model, False, "1", "A", monkeypatch=monkeypatch, hw=16)
-    got = _calibrate(model, True, "1", "A", monkeypatch=monkeypatch, hw=16)
-    assert got[4]["conv_add_chains_proven"] == 2 and got[4]["conv_add_launches"] == 0
+    old = _calibrate(model, True, "1", "A", monkeypatch=monkeypatch, hw=16, pair=False)
+    assert old[4]["conv_add_chains_proven"] == 2 and old[4]["conv_add_launches"] == 0 and old[4]["sums_left_to_pass2_pairs"] == 0
+    assert old[1] == want[1] and old[2] == want[2] and torch.equal(old[3], want[3])
+    got = _calibrate(model, True, "1", "A", monkeypatch=monkeypatch, hw=16, pair=True)
+    assert got[4]["conv_add_launches"] in (2 * 4, 2 * 5) and got[4]["sums_left_to_pass2_pairs"] == got[4]["conv_add_launches"]
     assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
     cold = _calibrate(model, True, "0", "", monkeypatch=monkeypatch, hw=16)
-    assert cold[4]["conv_add_launches"] == 2 * 5 and cold[4]["conv_add_hist_launches"] == 2 * 5
+    assert cold[4]["conv_add_launches"] == 2 * 5 and cold[4]["conv_add_hist_launches"] == 2 * 5 and cold[4]["sums_left_to_pass2_pairs"] == 0
     assert cold[1] == want[1] and cold[2] == want[2] and torch.equal(cold[3], want[3])
+
+
+@pytest.mark.parametrize("cache_gb,plan", [("1", "A"), ("0.07", "A"), ("1", "B"), ("0.05", "B")])
+def test_a_sum_whose_operands_the_cache_keeps_is_left_to_pass_2(monkeypatch, cache_gb, plan):
+    """Quantity.pair_hist: a residual sum = conv3's output + the shortcut.  Where pass 2's cache keeps both tensors of a chain,
+    pass 1 does not write the sum; the cache holds the shortcut (block 1: the projection's output, a kept tensor anyway; block 2:
+    the previous block's ReLU output) and pass 2 counts conv3's output and the sum in one pass over the pair
+    (fq_hist2048_pair_seg).  Every maximum, every histogram and the table are those of the run that writes and re-reads the sums,
+    and of the unfused run; the cache holds no more bytes than before."""
+    model = cases.seed_model(_block_net(), base_seed=8).eval().cuda()
+    want = _calibrate(model, False, cache_gb, plan, monkeypatch=monkeypatch)
+    off = _calibrate(model, True, cache_gb, plan, monkeypatch=monkeypatch, pair=False)
+    on = _calibrate(model, True, cache_gb, plan, monkeypatch=monkeypatch, pair=True)
+    for got in (off, on):
+        assert got[1] == want[1] and got[0] == want[0] and got[2] == want[2] and torch.equal(got[3], want[3])
+    assert off[4]["sums_left_to_pass2_pairs"] == 0
+    n = on[4]["sums_left_to_pass2_pairs"]
+    if cache_gb == "1":
+        assert n == on[4]["conv_add_launches"] and n in (2 * 4, 2 * 5)            # every chain of every fused forward
+        assert on[4]["cache_bytes"] <= off[4]["cache_bytes"]
+    else:
+        assert 0 < n <= on[4]["conv_add_launches"]                                # the chains / batches the partial cache keeps
+
+
+def test_a_shortcut_written_in_place_after_the_add_keeps_its_sum_materialised(monkeypatch):
+    """The shortcut must still hold, in pass 2, what the add saw.  A model that writes to it after the add (here: the block's
+    input gets a constant added in place once the sum exists) is found by the probe forward's version counters: that Eltwise's
+    sums are written as before, the other block's are left to pass 2.  Same tables as the unfused run."""
+    from torch import nn
+    net = _block_net()
+
+    class Meddling(type(net.b2)):
+        def forward(self, x):
+            y = self.c3(self.r2(self.c2(self.r1(self.c1(x)))))
+            z = self.r3(self.add(y, x))
+            x.add_(1.0)                                            # after the add: the sum is right, the shortcut no longer is
+            return z
+    net.b2.__class__ = Meddling
+    model = cases.seed_model(net, base_seed=8).eval().cuda()
+    want = _calibrate(model, False, "1", "A", monkeypatch=monkeypatch)
+    got = _calibrate(model, True, "1", "A", monkeypatch=monkeypatch, pair=True)
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+    # block 2's shortcut is block 1's ReLU output -- not a hooked tensor, so the calibration itself does not mind the write;
+    # only block 1's chain (shortcut = the projection, untouched) may leave its sum to pass 2
+    assert 0 < got[4]["sums_left_to_pass2_pairs"] <= got[4]["conv_add_launches"] // 2 + 1
 
 
 def test_a_convolution_output_with_a_second_reader_is_not_deferred():

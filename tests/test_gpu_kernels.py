@@ -353,3 +353,44 @@ def test_hist_bin_edges_adversarial(nat, oracle):
     got = hist.cpu().numpy()
     for r, iv in enumerate(ivs):
         np.testing.assert_array_equal(got[r], oracle.hist2048(segs[r], iv), err_msg="iv=%r" % iv)
+
+
+def test_pair_histogram_counts_a_tensor_and_a_sum_like_the_two_stored_tensors(oracle):
+    """fq_hist2048_pair_seg: a into row_a, fl32(a + b) into row_sum in one pass -- against fq_hist2048_seg on a and on the stored
+    torch.add(a, b), and against the oracle; ragged sizes (n % 4, n < 4, a size that crosses workgroup shares), exact zeros in a
+    and in the sum (a = -b), values beyond the last bin, existing counts preserved, row_a = None, an interval outside the fast
+    quotient's range."""
+    from common.quantity import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(77)
+    sizes = [3, 4, 1001, 65536 + 7, 3 * 1048576 + 2, 802816 * 8]
+    a = [torch.randn(n, generator=g, device="cuda") * (1.0 + i) for i, n in enumerate(sizes)]
+    b = [torch.randn(n, generator=g, device="cuda") * 0.7 for n in sizes]
+    for x, y in zip(a, b):
+        x[::7] = 0.0
+        y[::11] = 0.0
+        if x.numel() > 100:
+            y[5:50] = -x[5:50]                                         # the sum is an exact zero where a is not
+            x[60] = 1e9                                                # beyond the last bin (and so is the sum)
+    rows = 2 * len(sizes) + 1
+    iv = torch.rand(rows, generator=g, device="cuda") * 0.01 + 0.002
+    iv[3] = 1e-30                                                      # outside the fast quotient's range: the IEEE divide
+    rows_a = [2 * i for i in range(len(sizes))]
+    rows_s = [2 * i + 1 for i in range(len(sizes))]
+    rows_a[1] = None                                                   # this pair: only the sum
+    hist = torch.zeros(rows, 2048, dtype=torch.int64, device="cuda")
+    hist[:, 5] = 3                                                     # accumulated INTO
+    want = hist.clone()
+    nat.hist2048_pair_seg(a, b, rows_a, rows_s, iv, hist)
+    sums = [torch.add(x, y) for x, y in zip(a, b)]
+    nat.hist2048_seg([x for x, r in zip(a, rows_a) if r is not None] + sums, [r for r in rows_a if r is not None] + rows_s, iv, want)
+    assert torch.equal(hist, want)
+    assert int(hist[rows - 1].sum()) == 3 and int(hist[2].sum()) == 3          # untouched rows (row 2 = the pair without row_a)
+    host_iv = iv.cpu().numpy()
+    for i in (0, 2, 3):
+        ref = np.zeros(2048, dtype=np.int64)
+        ref[5] = 3
+        oracle.hist2048(sums[i].cpu().numpy(), np.float32(host_iv[rows_s[i]]), ref)
+        assert np.array_equal(hist[rows_s[i]].cpu().numpy(), ref), i
+    # a misaligned operand is refused (the caller then materialises the sum)
+    with pytest.raises(nat.FqError):
+        nat.hist2048_pair_seg([a[2][1:]], [b[2][1:]], [0], [1], iv, hist)
