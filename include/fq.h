@@ -126,6 +126,17 @@ int fq_kl_threshold_ex(const int64_t* hist, int rows, int32_t* thr_out, double* 
                        double* runner_up_kl_out, double* kl_curve_out, int mode,
                        void* workspace, size_t workspace_bytes, fq_stream_t stream);
 
+/* INTERVAL_NUM other than 2048 (tools/configs.yml:24; distribution_collector.py:9-14 takes it as interval_num and
+ * quantizer.py:98-167 sweeps t = 128 .. distribution.size - 1, whatever the size): the segmented histogram and the exhaustive
+ * KL sweep for bins in {512, 1024, 2048, 4096} (FQ_ERR_UNSUPPORTED otherwise; 2048 is the entry points above).
+ *   fq_hist_seg_n         hist is int64[rows][bins]; bin = min((int)(|x| / interval[row]), bins - 1) for x != 0
+ *   fq_kl_threshold_n     hist int64[rows][bins] -> thr_out in [128, bins - 1]; kl_curve_out NULL or float64[rows][bins - 128]
+ * The producer-fused statistics, the per-channel rows and the screened search exist for 2048 only. */
+int fq_hist_seg_n(const fq_seg* segs, int nseg, const float* interval, int64_t* hist, int bins, fq_stream_t stream);
+size_t fq_kl_workspace_bytes_n(int rows, int bins);
+int fq_kl_threshold_n(const int64_t* hist, int rows, int bins, int32_t* thr_out, double* kl_curve_out,
+                      void* workspace, size_t workspace_bytes, fq_stream_t stream);
+
 /* HOST helper (no device work): quantizer.py:86-90
  *   thr_val = fl32((t + 0.5) * interval);  bits = 7 - ceil(log(thr_val) / log(2))
  * evaluated with the host libm in float64 exactly as CPython's math.log(x, 2) does.

@@ -28,6 +28,7 @@
 #include "../include/fq_log.h"
 
 #define BINS 2048
+#define BINS_MAX 4096               /* INTERVAL_NUM of the _n entry points: any value in (128, 4096] */
 #define TARGET 128
 
 /* ------------------------------------------------------------------------------------------
@@ -55,12 +56,13 @@ float orc_absmax(const float* x, uint64_t n, float running) {
  *     the Python int 0 and the reference yields the Python float 1e-12; its fp32 image is what any
  *     later fp32-array divide would use, and is what this returns.
  * ------------------------------------------------------------------------------------------ */
-float orc_interval(float max_val, int statistic) {
+float orc_interval_n(float max_val, int statistic, int bins) {       /* interval_num = bins (configs.yml:24; dc.py:9-14) */
     volatile float a = (float)statistic * max_val;
-    volatile float b = a / 2048.0f;
+    volatile float b = a / (float)bins;
     volatile float c = b + (float)1e-12;
     return c;
 }
+float orc_interval(float max_val, int statistic) { return orc_interval_n(max_val, statistic, BINS); }
 
 /* ------------------------------------------------------------------------------------------
  * A3  _add_to_distribution   distribution_collector.py:127-135, accumulated as :115-118
@@ -70,16 +72,18 @@ float orc_interval(float max_val, int statistic) {
  *     Quotients >= 2048, inf and nan go to bin 2047 (the product's documented behaviour; the
  *     reference raises for the last two).
  * ------------------------------------------------------------------------------------------ */
-void orc_hist2048(const float* x, uint64_t n, float interval, int64_t* hist) {
+void orc_hist_n(const float* x, uint64_t n, float interval, int64_t* hist, int bins) {   /* INTERVAL_NUM = bins (dc.py:131: interval_num - 1) */
+    const float limit = (float)bins;
     for (uint64_t i = 0; i < n; ++i) {
         float v = x[i];
         if (v != 0.0f) {
             volatile float q = fabsf(v) / interval;
-            int idx = (q < 2048.0f) ? (int)q : (BINS - 1);
+            int idx = (q < limit) ? (int)q : (bins - 1);
             hist[idx] += 1;
         }
     }
 }
+void orc_hist2048(const float* x, uint64_t n, float interval, int64_t* hist) { orc_hist_n(x, n, interval, hist, BINS); }
 
 /* ------------------------------------------------------------------------------------------
  * NumPy pairwise summation of a contiguous float64 vector (numpy/_core/src/umath/loops_utils.h.src,
@@ -115,17 +119,19 @@ double orc_np_sum(const double* a, int64_t n) { return np_pairwise_sum(a, n); }
  *     float64 sum of integers (exact below 2^53, so the order is immaterial).  fp32 array divided
  *     by a float64 scalar gives float64: (double)(float)h / denom.
  * ------------------------------------------------------------------------------------------ */
-void orc_normalize_i64(const int64_t* hist, double* p) {
+void orc_normalize_i64_n(const int64_t* hist, double* p, int bins) {
     int64_t total = 0;
-    for (int j = 0; j < BINS; ++j) total += hist[j];
+    for (int j = 0; j < bins; ++j) total += hist[j];
     double denom = (double)total + 1e-12;
-    for (int j = 0; j < BINS; ++j) p[j] = (double)(float)hist[j] / denom;
+    for (int j = 0; j < bins; ++j) p[j] = (double)(float)hist[j] / denom;
 }
+void orc_normalize_i64(const int64_t* hist, double* p) { orc_normalize_i64_n(hist, p, BINS); }
 
-void orc_normalize_f64(const double* hist, double* p) {
-    double denom = np_pairwise_sum(hist, BINS) + 1e-12;
-    for (int j = 0; j < BINS; ++j) p[j] = (double)(float)hist[j] / denom;
+void orc_normalize_f64_n(const double* hist, double* p, int bins) {
+    double denom = np_pairwise_sum(hist, bins) + 1e-12;
+    for (int j = 0; j < bins; ++j) p[j] = (double)(float)hist[j] / denom;
 }
+void orc_normalize_f64(const double* hist, double* p) { orc_normalize_f64_n(hist, p, BINS); }
 
 /* ------------------------------------------------------------------------------------------
  * A7  compute_kl_divergence   quantizer.py:169-174
@@ -149,13 +155,15 @@ static double kl_divergence(const double* a, const double* b, int n, int use_fq_
  *     p: float64[2048].  Returns the threshold in [128, 2047]; kl_curve (nullable) gets the 1920
  *     divergences.  Order of every floating-point operation follows the Python source.
  * ------------------------------------------------------------------------------------------ */
-int orc_kl_threshold(const double* p, double* kl_curve, int use_fq_log) {
+/* bins = distribution.size (quantizer.py:101,:103: the sweep runs to the histogram's length, whatever INTERVAL_NUM is); bins <= BINS_MAX */
+int orc_kl_threshold_n(const double* p, int bins, double* kl_curve, int use_fq_log) {
+    if (bins <= TARGET || bins > BINS_MAX) return -1;
     double min_kl = 66666.0;                                 /* :99 */
-    double threshold_sum = np_pairwise_sum(p + TARGET, BINS - TARGET);   /* :100 */
-    int target_threshold = BINS - 1;                         /* :101 */
-    double t_dist[BINS], q[TARGET], expand[BINS], scratch[BINS];
+    double threshold_sum = np_pairwise_sum(p + TARGET, bins - TARGET);   /* :100 */
+    int target_threshold = bins - 1;                         /* :101 */
+    double t_dist[BINS_MAX], q[TARGET], expand[BINS_MAX], scratch[BINS_MAX];
 
-    for (int threshold = TARGET; threshold < BINS; ++threshold) {        /* :103 */
+    for (int threshold = TARGET; threshold < bins; ++threshold) {        /* :103 */
         memcpy(t_dist, p, sizeof(double) * threshold);       /* :104 */
         t_dist[threshold - 1] += threshold_sum;              /* :105 */
         threshold_sum = threshold_sum - p[threshold];        /* :108 */
@@ -217,6 +225,7 @@ int orc_kl_threshold(const double* p, double* kl_curve, int use_fq_log) {
     }
     return target_threshold;
 }
+int orc_kl_threshold(const double* p, double* kl_curve, int use_fq_log) { return orc_kl_threshold_n(p, BINS, kl_curve, use_fq_log); }
 
 /* ------------------------------------------------------------------------------------------
  * A8  quantize_worker bits   quantizer.py:86-90

@@ -45,6 +45,16 @@ def lib():
         L.orc_interval.argtypes = [ctypes.c_float, ci]
         L.orc_hist2048.restype = None
         L.orc_hist2048.argtypes = [f32p, u64, ctypes.c_float, i64p]
+        L.orc_interval_n.restype = ctypes.c_float
+        L.orc_interval_n.argtypes = [ctypes.c_float, ci, ci]
+        L.orc_hist_n.restype = None
+        L.orc_hist_n.argtypes = [f32p, u64, ctypes.c_float, i64p, ci]
+        L.orc_normalize_i64_n.restype = None
+        L.orc_normalize_i64_n.argtypes = [i64p, f64p, ci]
+        L.orc_normalize_f64_n.restype = None
+        L.orc_normalize_f64_n.argtypes = [f64p, f64p, ci]
+        L.orc_kl_threshold_n.restype = ci
+        L.orc_kl_threshold_n.argtypes = [f64p, ci, f64p, ci]
         L.orc_np_sum.restype = ctypes.c_double
         L.orc_np_sum.argtypes = [f64p, ctypes.c_int64]
         L.orc_normalize_i64.restype = None
@@ -89,16 +99,17 @@ def absmax(x, running=0.0):
     return np.float32(lib().orc_absmax(_p(x, ctypes.c_float), x.size, np.float32(running)))
 
 
-def interval(max_val, statistic=1):
-    return np.float32(lib().orc_interval(np.float32(max_val), int(statistic)))
+def interval(max_val, statistic=1, bins=BINS):
+    return np.float32(lib().orc_interval_n(np.float32(max_val), int(statistic), int(bins)))
 
 
-def hist2048(x, iv, hist=None):
+def hist2048(x, iv, hist=None, bins=None):
+    """The |x| histogram with INTERVAL_NUM = bins (default 2048; with `hist` given: its length)."""
     x = _f32(x).ravel()
     if hist is None:
-        hist = np.zeros(BINS, dtype=np.int64)
-    assert hist.dtype == np.int64 and hist.flags.c_contiguous
-    lib().orc_hist2048(_p(x, ctypes.c_float), x.size, np.float32(iv), _p(hist, ctypes.c_int64))
+        hist = np.zeros(BINS if bins is None else int(bins), dtype=np.int64)
+    assert hist.dtype == np.int64 and hist.flags.c_contiguous and (bins is None or hist.size == bins)
+    lib().orc_hist_n(_p(x, ctypes.c_float), x.size, np.float32(iv), _p(hist, ctypes.c_int64), hist.size)
     return hist
 
 
@@ -108,22 +119,26 @@ def np_sum(a):
 
 
 def normalize(hist):
-    p = np.empty(BINS, dtype=np.float64)
+    """quantizer.py:95-96 for a histogram of any length (INTERVAL_NUM bins)."""
+    n = int(np.asarray(hist).size)
+    p = np.empty(n, dtype=np.float64)
     if np.asarray(hist).dtype == np.float64:
         h = np.ascontiguousarray(hist, dtype=np.float64)
-        lib().orc_normalize_f64(_p(h, ctypes.c_double), _p(p, ctypes.c_double))
+        lib().orc_normalize_f64_n(_p(h, ctypes.c_double), _p(p, ctypes.c_double), n)
     else:
         h = np.ascontiguousarray(hist, dtype=np.int64)
-        lib().orc_normalize_i64(_p(h, ctypes.c_int64), _p(p, ctypes.c_double))
+        lib().orc_normalize_i64_n(_p(h, ctypes.c_int64), _p(p, ctypes.c_double), n)
     return p
 
 
 def kl_threshold(p, want_curve=False, use_fq_log=False):
+    """quantizer.py:98-167 on a normalised distribution of any length in (128, 4096]: the sweep runs t = 128 .. len(p) - 1."""
     p = np.ascontiguousarray(p, dtype=np.float64)
-    curve = np.empty(KL_CANDIDATES, dtype=np.float64) if want_curve else None
-    t = lib().orc_kl_threshold(_p(p, ctypes.c_double),
-                               _p(curve, ctypes.c_double) if want_curve else None,
-                               1 if use_fq_log else 0)
+    curve = np.empty(p.size - 128, dtype=np.float64) if want_curve else None
+    t = lib().orc_kl_threshold_n(_p(p, ctypes.c_double), p.size,
+                                 _p(curve, ctypes.c_double) if want_curve else None,
+                                 1 if use_fq_log else 0)
+    assert t >= 0, "orc_kl_threshold_n: unsupported length %d" % p.size
     return (t, curve) if want_curve else t
 
 

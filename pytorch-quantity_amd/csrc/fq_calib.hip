@@ -149,23 +149,23 @@ __global__ __launch_bounds__(kBlock) void absmax_seg_kernel(const SegTable tab, 
 // ---------------------------------------------------------------------------------------------
 // 2048-bin histogram of |x|, x != 0  (distribution_collector.py:127-135)
 // ---------------------------------------------------------------------------------------------
-template <bool kFast>
+template <bool kFast, int kBins>
 __device__ __forceinline__ void hist_piece(const float* p, uint64_t n, uint32_t c0, uint32_t c1, float iv, unsigned int* s_bins) {
     const float y = 1.0f / iv;                        // IEEE, once per lane
-    // branch-free: lanes holding an exact zero add into a private scratch slot (2048 + lane)
-    unsigned int* park = s_bins + FQ_BINS + (threadIdx.x & (kWave - 1));
+    // branch-free: lanes holding an exact zero add into a private scratch slot (kBins + lane)
+    unsigned int* park = s_bins + kBins + (threadIdx.x & (kWave - 1));
     for_each_in_chunks<kHistBlock, true>(p, n, c0, c1, [&](float v) {
-        unsigned int* slot = (v != 0.0f) ? (s_bins + bin_of<kFast>(v, iv, y)) : park;
+        unsigned int* slot = (v != 0.0f) ? (s_bins + bin_of<kFast, kBins>(v, iv, y)) : park;
         atomicAdd(slot, 1u);                          // ds_add_u32
     });
 }
 
-__global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable tab,
-                                                              const float* __restrict__ interval,
-                                                              unsigned long long* __restrict__ hist,
-                                                              const int allow_fast) {
-    __shared__ unsigned int s_bins[FQ_BINS + kWave];
-    for (int b = threadIdx.x; b < FQ_BINS + kWave; b += kHistBlock) s_bins[b] = 0u;
+// kBins = INTERVAL_NUM (tools/configs.yml:24; distribution_collector.py:9-14 is generic in it): 2048 as shipped, the entry point
+// fq_hist_seg_n also instantiates 512 / 1024 / 4096
+template <int kBins>
+__device__ __forceinline__ void hist_seg_body(const SegTable& tab, const float* __restrict__ interval, unsigned long long* __restrict__ hist,
+                                              const int allow_fast, unsigned int* s_bins) {
+    for (int b = threadIdx.x; b < kBins + kWave; b += kHistBlock) s_bins[b] = 0u;
     __syncthreads();
     for_each_piece(tab, [&](int s, uint32_t c0, uint32_t c1) {
         const int row = tab.row[s];
@@ -178,12 +178,12 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable
         // workgroup.
         const unsigned int ivb = __float_as_uint(iv);
         const bool fast = allow_fast && ivb >= 0x21800000u && ivb <= 0x5d800000u;
-        if (fast) hist_piece<true>(tab.ptr[s], tab.n[s], c0, c1, iv, s_bins);
-        else hist_piece<false>(tab.ptr[s], tab.n[s], c0, c1, iv, s_bins);
+        if (fast) hist_piece<true, kBins>(tab.ptr[s], tab.n[s], c0, c1, iv, s_bins);
+        else hist_piece<false, kBins>(tab.ptr[s], tab.n[s], c0, c1, iv, s_bins);
         __syncthreads();
         // publish the non-zero bins of this row and clear them for the next piece
-        unsigned long long* __restrict__ dst = hist + (size_t)row * FQ_BINS;
-        for (int b = threadIdx.x; b < FQ_BINS; b += kHistBlock) {
+        unsigned long long* __restrict__ dst = hist + (size_t)row * kBins;
+        for (int b = threadIdx.x; b < kBins; b += kHistBlock) {
             const unsigned int c = s_bins[b];
             if (c) {
                 atomicAdd(dst + b, (unsigned long long)c);
@@ -192,6 +192,21 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable
         }
         __syncthreads();
     });
+}
+
+__global__ __launch_bounds__(kHistBlock) void hist2048_seg_kernel(const SegTable tab,
+                                                              const float* __restrict__ interval,
+                                                              unsigned long long* __restrict__ hist,
+                                                              const int allow_fast) {
+    __shared__ unsigned int s_bins[FQ_BINS + kWave];
+    hist_seg_body<FQ_BINS>(tab, interval, hist, allow_fast, s_bins);
+}
+
+template <int kBins>
+__global__ __launch_bounds__(kHistBlock) void hist_seg_n_kernel(const SegTable tab, const float* __restrict__ interval,
+                                                               unsigned long long* __restrict__ hist, const int allow_fast) {
+    __shared__ unsigned int s_bins[kBins + kWave];
+    hist_seg_body<kBins>(tab, interval, hist, allow_fast, s_bins);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -724,6 +739,25 @@ extern "C" int fq_hist2048_seg(const fq_seg* segs, int nseg, const float* interv
     return for_each_chunk(segs, nseg, kWgPerCUHist, [&](const SegTable& tab, uint32_t wgs) -> int {
         hipLaunchKernelGGL(hist2048_seg_kernel, dim3(wgs), dim3(kHistBlock), 0, st, tab, interval,
                            reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
+        FQ_LAUNCH_CHECK();
+        return FQ_OK;
+    });
+}
+
+extern "C" int fq_hist_seg_n(const fq_seg* segs, int nseg, const float* interval, int64_t* hist, int bins, fq_stream_t stream) {
+    using namespace fq;
+    if (bins == FQ_BINS) return fq_hist2048_seg(segs, nseg, interval, hist, stream);
+    if (bins != 512 && bins != 1024 && bins != 4096) return FQ_ERR_UNSUPPORTED;
+    int rc = validate(segs, nseg);
+    if (rc != FQ_OK) return rc;
+    if (nseg == 0) return FQ_OK;
+    if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    return for_each_chunk(segs, nseg, kWgPerCUHist, [&](const SegTable& tab, uint32_t wgs) -> int {
+        unsigned long long* h = reinterpret_cast<unsigned long long*>(hist);
+        if (bins == 512) hipLaunchKernelGGL(hist_seg_n_kernel<512>, dim3(wgs), dim3(kHistBlock), 0, st, tab, interval, h, hist_fast_quotient_enabled());
+        else if (bins == 1024) hipLaunchKernelGGL(hist_seg_n_kernel<1024>, dim3(wgs), dim3(kHistBlock), 0, st, tab, interval, h, hist_fast_quotient_enabled());
+        else hipLaunchKernelGGL(hist_seg_n_kernel<4096>, dim3(wgs), dim3(kHistBlock), 0, st, tab, interval, h, hist_fast_quotient_enabled());
         FQ_LAUNCH_CHECK();
         return FQ_OK;
     });

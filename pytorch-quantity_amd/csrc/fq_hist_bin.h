@@ -10,7 +10,7 @@ namespace fq {
 // correctly rounded a/iv for every fp32 significand pair (checked exhaustively on the GPU,
 // scripts/verify_fastdiv.hip, result under profiles/), and overflow / inf / nan fall through to the
 // same "last bin" as the IEEE path because  q < 2048  is false for inf and nan.
-template <bool kFast>
+template <bool kFast, int kBins = FQ_BINS>
 __device__ __forceinline__ int bin_of(float v, float iv, float y) {
     const float a = fabsf(v);
     float q;
@@ -21,7 +21,7 @@ __device__ __forceinline__ int bin_of(float v, float iv, float y) {
     } else {
         q = a / iv;                                   // v_div_scale / v_rcp / fma x4 / v_div_fmas / v_div_fixup
     }
-    return (q < 2048.0f) ? (int)q : (FQ_BINS - 1);   // >= 2048, inf, nan -> last bin
+    return (q < (float)kBins) ? (int)q : (kBins - 1);   // >= INTERVAL_NUM (2048), inf, nan -> last bin
 }
 
 // The exhaustive proof of the fast quotient covers every significand pair but assumes that no intermediate

@@ -80,6 +80,29 @@ __device__ __forceinline__ double pw_leaf_nz(const double* a, int n, unsigned* n
     return res;
 }
 
+// ... and for slices of up to 32 elements (INTERVAL_NUM 4096: 4096 / 128 bins per quantised bin)
+__device__ __forceinline__ double pw_leaf_nz32(const double* a, int n, unsigned* nz) {          // n <= 32
+    unsigned m = 0;
+    double res;
+    if (n < 8) {
+        res = 0.0;
+        for (int i = 0; i < n; ++i) { const double v = a[i]; res += v; m |= (v != 0.0 ? 1u : 0u) << i; }
+    } else {
+        double r[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { r[k] = a[k]; m |= (r[k] != 0.0 ? 1u : 0u) << k; }
+        const int lim = n - (n & 7);                      // 8, 16, 24 or 32
+        for (int i = 8; i < lim; i += 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const double v = a[i + k]; r[k] += v; m |= (v != 0.0 ? 1u : 0u) << (i + k); }
+        }
+        res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (int i = lim; i < n; ++i) { const double v = a[i]; res += v; m |= (v != 0.0 ? 1u : 0u) << i; }
+    }
+    *nz = m;
+    return res;
+}
+
 // Walks the recursion tree of pairwise_sum(n) in order; leaf(off, len) supplies each leaf's value.
 template <typename LeafFn>
 __device__ double pw_walk(int n, LeafFn&& leaf) {
@@ -118,14 +141,17 @@ __device__ double pw_sum_serial(const double* a, int n) {
 }
 
 // ---- prepare: normalise, tail chain -------------------------------------------------------------
+// B = INTERVAL_NUM = the histogram's length (quantizer.py:98-167 is generic in distribution.size): 2048 as shipped; 512 / 1024 / 4096
+// through fq_kl_threshold_n
+template <int B = FQ_BINS>
 __global__ __launch_bounds__(kKlBlock) void kl_prepare_kernel(const long long* __restrict__ hist, double* __restrict__ Pw,
                                                               double* __restrict__ tailw) {
-    __shared__ double sP[FQ_BINS];
+    __shared__ double sP[B];
     __shared__ long long s_part[kKlBlock / kWave];
     const int row = blockIdx.x, tid = threadIdx.x;
-    const long long* h = hist + (size_t)row * FQ_BINS;
+    const long long* h = hist + (size_t)row * B;
     long long part = 0;
-    for (int j = tid; j < FQ_BINS; j += kKlBlock) part += h[j];
+    for (int j = tid; j < B; j += kKlBlock) part += h[j];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, kWave);
     if ((tid & (kWave - 1)) == 0) s_part[tid / kWave] = part;
@@ -134,18 +160,18 @@ __global__ __launch_bounds__(kKlBlock) void kl_prepare_kernel(const long long* _
 #pragma unroll
     for (int w = 0; w < kKlBlock / kWave; ++w) total += s_part[w];
     const double denom = (double)total + 1e-12;                  // quantizer.py:96
-    for (int j = tid; j < FQ_BINS; j += kKlBlock) {
+    for (int j = tid; j < B; j += kKlBlock) {
         const double p = (double)(float)h[j] / denom;            // astype(float32) / float64 scalar
         sP[j] = p;
-        Pw[(size_t)row * FQ_BINS + j] = p;
+        Pw[(size_t)row * B + j] = p;
     }
     __syncthreads();
     if (tid == 0) {
-        double* tail = tailw + (size_t)row * FQ_BINS;
-        double ts = pw_sum_serial(sP + kTarget, FQ_BINS - kTarget);      // :100
+        double* tail = tailw + (size_t)row * B;
+        double ts = pw_sum_serial(sP + kTarget, B - kTarget);      // :100
         tail[kTarget] = ts;
 #pragma unroll 8
-        for (int t = kTarget; t < FQ_BINS - 1; ++t) {                    // :108
+        for (int t = kTarget; t < B - 1; ++t) {                    // :108
             ts = ts - sP[t];
             tail[t + 1] = ts;
         }
@@ -153,20 +179,25 @@ __global__ __launch_bounds__(kKlBlock) void kl_prepare_kernel(const long long* _
 }
 
 // ---- sweep: one workgroup per (threshold, row) --------------------------------------------------
-struct SweepSmem {
-    double sP[FQ_BINS];
-    double sE[FQ_BINS];            // expand_distribution, later reused for the compacted KL terms
+template <int B = FQ_BINS>
+struct SweepSmemT {
+    double sP[B];
+    double sE[B];            // expand_distribution, later reused for the compacted KL terms
     double s_leaf_val[kMaxLeaves];
     int s_leaf_off[kMaxLeaves];
     int s_leaf_len[kMaxLeaves];
     int s_wave_cnt[kKlBlock / kWave];
     int s_nleaf;
 };
+typedef SweepSmemT<FQ_BINS> SweepSmem;
 
 // KL(t) of one row, by the whole workgroup; lane 0 of wave 0 stores it to *out.  Exact: the reference's operations in
 // the reference's order.  (Every thread must call it; it ends without a barrier -- callers that reuse `sm` add one.)
-__device__ __forceinline__ void kl_exact_candidate(SweepSmem& sm, const double* __restrict__ P, const double tail, const int t,
+template <int B = FQ_BINS>
+__device__ __forceinline__ void kl_exact_candidate(SweepSmemT<B>& sm, const double* __restrict__ P, const double tail, const int t,
                                                    double* __restrict__ out) {
+    constexpr int KPL = B > 2048 ? 16 : 8;            // consecutive bins per lane in the KL-term phase (256 lanes cover B)
+    static_assert(KPL * kKlBlock >= B && B / kTarget <= 32, "INTERVAL_NUM beyond the kernel's lane mapping");
     double* sP = sm.sP;
     double* sE = sm.sE;
     double* s_leaf_val = sm.s_leaf_val;
@@ -198,7 +229,8 @@ __device__ __forceinline__ void kl_exact_candidate(SweepSmem& sm, const double* 
         if (has_l) { ls = (double)lu - start; q += ls * sP[lu - 1]; }
         if (has_r) { rs = end - (double)rl;   q += rs * sP[rl]; }
         unsigned nz = 0;
-        q += pw_leaf_nz(sP + lu, rl - lu, &nz);                           // slice .sum(), length <= 16
+        if constexpr (B > 2048) q += pw_leaf_nz32(sP + lu, rl - lu, &nz);  // slice .sum(), length <= B / 128
+        else q += pw_leaf_nz(sP + lu, rl - lu, &nz);                      // length <= 16
         double count = 1e-12;
         left_live = has_l && sP[lu - 1] != 0.0;
         const bool right_live = has_r && sP[rl] != 0.0;
@@ -216,12 +248,12 @@ __device__ __forceinline__ void kl_exact_candidate(SweepSmem& sm, const double* 
     if (left_live) sE[lu - 1] += ev * ls;
     __syncthreads();
 
-    // KL terms (quantizer.py:169-174) for 8 consecutive bins per lane, compacted over a != 0
-    double term[8];
+    // KL terms (quantizer.py:169-174) for 8 (16) consecutive bins per lane, compacted over a != 0
+    double term[KPL];
     unsigned nzmask = 0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int j = tid * 8 + k;
+    for (int k = 0; k < KPL; ++k) {
+        const int j = tid * KPL + k;
         term[k] = 0.0;
         if (j < t) {
             double a = sP[j];
@@ -252,7 +284,7 @@ __device__ __forceinline__ void kl_exact_candidate(SweepSmem& sm, const double* 
     double* sT = sE;
     int pos = base + incl - cnt;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < KPL; ++k)
         if (nzmask & (1u << k)) sT[pos++] = term[k];
     // Leaves of NumPy's pairwise recursion over the m compacted terms, without walking the tree serially (one
     // lane doing that took half of the kernel): the tree is at most 6 levels deep for m <= 2048, so lane c of
@@ -282,8 +314,10 @@ __device__ __forceinline__ void kl_exact_candidate(SweepSmem& sm, const double* 
     __syncthreads();
 
     // leaves in parallel: 8 lanes = NumPy's 8 strided accumulators
-    {
-        const int L = tid >> 3, k = tid & 7;
+    // (32 leaves per pass: a sum of up to 2048 terms has at most 17 leaves, of 4096 terms 33)
+#pragma unroll
+    for (int L0 = 0; L0 < (B > 2048 ? 64 : 32); L0 += 32) {
+        const int L = L0 + (tid >> 3), k = tid & 7;
         const bool live = L < s_nleaf;
         const int off = live ? s_leaf_off[L] : 0;
         const int len = live ? s_leaf_len[L] : 0;
@@ -332,7 +366,18 @@ __global__ __launch_bounds__(kKlBlock) void kl_sweep_kernel(const double* __rest
     __shared__ SweepSmem sm;
     const int t = kTarget + blockIdx.x;       // threshold
     const int row = blockIdx.y;
-    kl_exact_candidate(sm, Pw + (size_t)row * FQ_BINS, tailw[(size_t)row * FQ_BINS + t], t, klw + (size_t)row * kCand + blockIdx.x);
+    kl_exact_candidate<FQ_BINS>(sm, Pw + (size_t)row * FQ_BINS, tailw[(size_t)row * FQ_BINS + t], t, klw + (size_t)row * kCand + blockIdx.x);
+}
+
+// the same sweep for another INTERVAL_NUM: B - 128 candidates per row; the two B-sized LDS arrays are dynamic (64 KB at 4096)
+template <int B>
+__global__ __launch_bounds__(kKlBlock) void kl_sweep_n_kernel(const double* __restrict__ Pw, const double* __restrict__ tailw,
+                                                              double* __restrict__ klw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char kl_dyn_smem[];
+    SweepSmemT<B>& sm = *reinterpret_cast<SweepSmemT<B>*>(kl_dyn_smem);
+    const int t = kTarget + blockIdx.x;
+    const int row = blockIdx.y;
+    kl_exact_candidate<B>(sm, Pw + (size_t)row * B, tailw[(size_t)row * B + t], t, klw + (size_t)row * (B - kTarget) + blockIdx.x);
 }
 
 // ---- screened path ------------------------------------------------------------------------------
@@ -688,7 +733,7 @@ __global__ __launch_bounds__(kKlBlock) void kl_exact_list_kernel(const double* _
             row = full_rows[r / kCand]; c = (int)(r % kCand);
         }
         const int t = kTarget + c;
-        kl_exact_candidate(sm, Pw + (size_t)row * FQ_BINS, tailw[(size_t)row * FQ_BINS + t], t, klw + (size_t)row * kCand + c);
+        kl_exact_candidate<FQ_BINS>(sm, Pw + (size_t)row * FQ_BINS, tailw[(size_t)row * FQ_BINS + t], t, klw + (size_t)row * kCand + c);
         __syncthreads();                                               // sm is reused by the next item
     }
 }
@@ -697,15 +742,17 @@ __global__ __launch_bounds__(kKlBlock) void kl_exact_list_kernel(const double* _
 // Also reports how decisive the choice was: best = KL(t*), runner_up = the smallest KL of any OTHER candidate (+inf when
 // there is none): a runner-up within an ulp-sized distance of the best is a near-tie that a differently rounded
 // logarithm (np.log vs fq_log, DESIGN.md "The logarithm") could have decided the other way.
+template <int B = FQ_BINS>
 __global__ __launch_bounds__(kKlBlock) void kl_argmin_kernel(const double* __restrict__ klw, int* __restrict__ thr_out,
                                                              double* __restrict__ best_out, double* __restrict__ runner_out) {
     __shared__ double s_v[kKlBlock], s_w[kKlBlock];
     __shared__ int s_t[kKlBlock];
     const int row = blockIdx.x, tid = threadIdx.x;
-    const double* kl = klw + (size_t)row * kCand;
+    constexpr int kCandB = B - kTarget;
+    const double* kl = klw + (size_t)row * kCandB;
     double bv = 66666.0, second = __builtin_inf();
     int bt = 0x7fffffff;
-    for (int i = tid; i < kCand; i += kKlBlock) {
+    for (int i = tid; i < kCandB; i += kKlBlock) {
         const double v = kl[i];
         if (v < bv) { if (bt != 0x7fffffff) second = bv; bv = v; bt = kTarget + i; }   // NaN never wins
         else if (v < second) second = v;
@@ -730,7 +777,7 @@ __global__ __launch_bounds__(kKlBlock) void kl_argmin_kernel(const double* __res
     }
     if (tid == 0) {
         const bool none = s_t[0] == 0x7fffffff;
-        thr_out[row] = none ? (FQ_BINS - 1) : s_t[0];
+        thr_out[row] = none ? (B - 1) : s_t[0];
         if (best_out) best_out[row] = none ? __builtin_inf() : s_v[0];
         if (runner_out) runner_out[row] = s_w[0];
     }
@@ -784,7 +831,7 @@ extern "C" int fq_kl_threshold_ex(const int64_t* hist, int rows, int32_t* thr_ou
     for (int r0 = 0; r0 < rows; r0 += kRowChunk) {
         const int nr = rows - r0 < kRowChunk ? rows - r0 : kRowChunk;
         double* klw = kl_curve_out ? kl_curve_out + (size_t)r0 * kCand : kl_ws;
-        hipLaunchKernelGGL(kl_prepare_kernel, dim3(nr), dim3(kKlBlock), 0, st,
+        hipLaunchKernelGGL(kl_prepare_kernel<FQ_BINS>, dim3(nr), dim3(kKlBlock), 0, st,
                            reinterpret_cast<const long long*>(hist) + (size_t)r0 * FQ_BINS, Pw, tailw);
         FQ_LAUNCH_CHECK();
         if (!screened) {
@@ -803,11 +850,63 @@ extern "C" int fq_kl_threshold_ex(const int64_t* hist, int rows, int32_t* thr_ou
                                counters, nr * kListPerRow);
             FQ_LAUNCH_CHECK();
         }
-        hipLaunchKernelGGL(kl_argmin_kernel, dim3(nr), dim3(kKlBlock), 0, st, klw, thr_out + r0,
+        hipLaunchKernelGGL(kl_argmin_kernel<FQ_BINS>, dim3(nr), dim3(kKlBlock), 0, st, klw, thr_out + r0,
                            best_kl_out ? best_kl_out + r0 : nullptr, runner_up_kl_out ? runner_up_kl_out + r0 : nullptr);
         FQ_LAUNCH_CHECK();
     }
     return FQ_OK;
+}
+
+namespace fq {
+template <int B>
+static int kl_threshold_n(const int64_t* hist, int rows, int32_t* thr_out, double* kl_curve_out, void* workspace, size_t workspace_bytes,
+                          hipStream_t st) {
+    constexpr int kCandB = B - kTarget;
+    constexpr size_t per_row = (size_t)(2 * B + kCandB) * sizeof(double);
+    const size_t ch = rows < kRowChunk ? (size_t)rows : (size_t)kRowChunk;
+    if (workspace_bytes < ch * per_row) return FQ_ERR_WORKSPACE;
+    char* w = reinterpret_cast<char*>(workspace);
+    double* Pw = reinterpret_cast<double*>(w);            w += ch * B * sizeof(double);
+    double* tailw = reinterpret_cast<double*>(w);         w += ch * B * sizeof(double);
+    double* kl_ws = reinterpret_cast<double*>(w);
+    static bool lds_ok[kMaxDevices] = {};
+    if (sizeof(SweepSmemT<B>) > 48 * 1024 &&
+        !ensure_dynamic_lds(reinterpret_cast<const void*>(kl_sweep_n_kernel<B>), (int)sizeof(SweepSmemT<B>), lds_ok))
+        return FQ_ERR_UNSUPPORTED;
+    for (int r0 = 0; r0 < rows; r0 += kRowChunk) {
+        const int nr = rows - r0 < kRowChunk ? rows - r0 : kRowChunk;
+        double* klw = kl_curve_out ? kl_curve_out + (size_t)r0 * kCandB : kl_ws;
+        hipLaunchKernelGGL(kl_prepare_kernel<B>, dim3(nr), dim3(kKlBlock), 0, st, reinterpret_cast<const long long*>(hist) + (size_t)r0 * B,
+                           Pw, tailw);
+        FQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(kl_sweep_n_kernel<B>, dim3(kCandB, nr), dim3(kKlBlock), sizeof(SweepSmemT<B>), st, Pw, tailw, klw);
+        FQ_LAUNCH_CHECK();
+        hipLaunchKernelGGL(kl_argmin_kernel<B>, dim3(nr), dim3(kKlBlock), 0, st, klw, thr_out + r0, (double*)nullptr, (double*)nullptr);
+        FQ_LAUNCH_CHECK();
+    }
+    return FQ_OK;
+}
+}  // namespace fq
+
+extern "C" size_t fq_kl_workspace_bytes_n(int rows, int bins) {
+    if (rows <= 0 || bins <= FQ_KL_TARGET_BINS) return 0;
+    if (bins == FQ_BINS) return fq_kl_workspace_bytes(rows);
+    const size_t r = rows < fq::kRowChunk ? (size_t)rows : (size_t)fq::kRowChunk;
+    return r * (size_t)(3 * bins - FQ_KL_TARGET_BINS) * sizeof(double) + 64;
+}
+
+extern "C" int fq_kl_threshold_n(const int64_t* hist, int rows, int bins, int32_t* thr_out, double* kl_curve_out,
+                                 void* workspace, size_t workspace_bytes, fq_stream_t stream) {
+    using namespace fq;
+    if (bins == FQ_BINS) return fq_kl_threshold(hist, rows, thr_out, kl_curve_out, workspace, workspace_bytes, stream);
+    if (bins != 512 && bins != 1024 && bins != 4096) return FQ_ERR_UNSUPPORTED;
+    if (rows < 0) return FQ_ERR_INVALID_ARG;
+    if (rows == 0) return FQ_OK;
+    if (!hist || !thr_out || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 7u)) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    if (bins == 512) return kl_threshold_n<512>(hist, rows, thr_out, kl_curve_out, workspace, workspace_bytes, st);
+    if (bins == 1024) return kl_threshold_n<1024>(hist, rows, thr_out, kl_curve_out, workspace, workspace_bytes, st);
+    return kl_threshold_n<4096>(hist, rows, thr_out, kl_curve_out, workspace, workspace_bytes, st);
 }
 
 extern "C" int fq_kl_threshold(const int64_t* hist, int rows, int32_t* thr_out, double* kl_curve_out,

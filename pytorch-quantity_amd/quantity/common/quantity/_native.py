@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 BINS = 2048
+SUPPORTED_BINS = (512, 1024, 2048, 4096)      # INTERVAL_NUM the histogram / KL kernels are instantiated for (fq.h: fq_hist_seg_n)
 KL_CANDIDATES = 1920
 
 _PKG_ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..", ".."))
@@ -59,6 +60,12 @@ def lib():
     L.fq_absmax_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp]
     L.fq_hist2048_seg.restype = ci
     L.fq_hist2048_seg.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp, vp]
+    L.fq_hist_seg_n.restype = ci
+    L.fq_hist_seg_n.argtypes = [ctypes.POINTER(_Seg), ci, vp, vp, ci, vp]
+    L.fq_kl_workspace_bytes_n.restype = sz
+    L.fq_kl_workspace_bytes_n.argtypes = [ci, ci]
+    L.fq_kl_threshold_n.restype = ci
+    L.fq_kl_threshold_n.argtypes = [vp, ci, ci, vp, vp, vp, sz, vp]
     L.fq_hist2048_pair_seg.restype = ci
     L.fq_hist2048_pair_seg.argtypes = [ctypes.POINTER(_PairSeg), ci, vp, vp, vp]
     L.fq_absmax_chan.restype = ci
@@ -286,11 +293,14 @@ def hist2048_seg(tensors, rows, interval, hist):
         return
     _need_cuda(interval, torch.float32, "interval")
     _need_cuda(hist, torch.int64, "hist")
-    assert hist.is_contiguous() and hist.shape[-1] == BINS
-    assert max(int(r) for r in rows) < hist.numel() // BINS and interval.numel() >= hist.numel() // BINS
+    bins = int(hist.shape[-1])                    # INTERVAL_NUM: 2048 as shipped; 512 / 1024 / 4096 through fq_hist_seg_n
+    assert hist.is_contiguous() and bins in SUPPORTED_BINS
+    assert max(int(r) for r in rows) < hist.numel() // bins and interval.numel() >= hist.numel() // bins
     arr, keep = _seg_array(tensors, rows)
-    _check(lib().fq_hist2048_seg(arr, len(tensors), interval.data_ptr(), hist.data_ptr(), _stream(hist)),
-           "fq_hist2048_seg")
+    if bins == BINS:
+        _check(lib().fq_hist2048_seg(arr, len(tensors), interval.data_ptr(), hist.data_ptr(), _stream(hist)), "fq_hist2048_seg")
+    else:
+        _check(lib().fq_hist_seg_n(arr, len(tensors), interval.data_ptr(), hist.data_ptr(), bins, _stream(hist)), "fq_hist_seg_n")
     return keep
 
 
@@ -327,10 +337,25 @@ def kl_threshold(hist, want_curve=False, mode=KL_AUTO, want_evidence=False):
     (best KL, runner-up KL: float64 cuda tensors).  Returns thr, or (thr, curve), or (thr, best, runner_up), or
     (thr, curve, best, runner_up).  mode: fq.h FQ_KL_AUTO / FQ_KL_EXHAUSTIVE / FQ_KL_SCREENED."""
     _need_cuda(hist, torch.int64, "hist")
-    assert hist.is_contiguous() and hist.dim() == 2 and hist.shape[1] == BINS
+    assert hist.is_contiguous() and hist.dim() == 2 and hist.shape[1] in SUPPORTED_BINS
     rows = hist.shape[0]
     dev = hist.device
     thr = torch.empty(rows, dtype=torch.int32, device=dev)
+    if hist.shape[1] != BINS:
+        # INTERVAL_NUM 512 / 1024 / 4096: the exhaustive sweep only (fq_kl_threshold_n); the evidence comes from its curve
+        bins = int(hist.shape[1])
+        curve = torch.empty(rows, bins - 128, dtype=torch.float64, device=dev)
+        if rows:
+            wsb = lib().fq_kl_workspace_bytes_n(rows, bins)
+            ws = torch.empty((wsb + 7) // 8, dtype=torch.float64, device=dev)
+            _check(lib().fq_kl_threshold_n(hist.data_ptr(), rows, bins, thr.data_ptr(), curve.data_ptr(), ws.data_ptr(), wsb, _stream(hist)),
+                   "fq_kl_threshold_n")
+        out = (thr,) + ((curve,) if want_curve else ())
+        if want_evidence:
+            c = torch.where(torch.isnan(curve) | (curve >= 66666.0), torch.full_like(curve, float("inf")), curve)
+            two = torch.topk(c, 2, dim=1, largest=False).values if rows else c[:, :2]
+            out = out + (two[:, 0].contiguous(), two[:, 1].contiguous())
+        return out if len(out) > 1 else thr
     curve = torch.empty(rows, KL_CANDIDATES, dtype=torch.float64, device=dev) if want_curve else None
     best = torch.empty(rows, dtype=torch.float64, device=dev) if want_evidence else None
     runner = torch.empty(rows, dtype=torch.float64, device=dev) if want_evidence else None

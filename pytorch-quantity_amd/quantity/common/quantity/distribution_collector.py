@@ -36,8 +36,9 @@ def _as_device_f32(t, device):
 class DistributionCollector(StatCollectives):
 
     def __init__(self, tensor_list, interval_num=2048, statistic=1, worker_num=1, debug=False, device=None):
-        if interval_num != _native.BINS:
-            raise ValueError("the MI355X histogram kernel is built for INTERVAL_NUM = 2048, got %r" % interval_num)
+        if interval_num not in _native.SUPPORTED_BINS:
+            raise ValueError("the MI355X histogram / KL kernels are built for INTERVAL_NUM in %r, got %r"
+                             % (_native.SUPPORTED_BINS, interval_num))
         self._tensor_list = list(tensor_list)
         self._row = {name: i for i, name in enumerate(self._tensor_list)}
         self._interval_num = interval_num
@@ -122,7 +123,16 @@ class DistributionCollector(StatCollectives):
         self._keepalive = _native.hist2048_seg(segs, rows, self._interval_dev, self._hist_dev)
 
     # ------------------------------------------------------------------ beyond the reference API
-    supports_pairs = True       # add_pairs_to_distributions(): a tensor and a sum of two tensors in one pass
+    @property
+    def supports_pairs(self):
+        """add_pairs_to_distributions(): a tensor and a sum of two tensors in one pass (the 2048-bin kernel only)."""
+        return self._interval_num == _native.BINS
+
+    @property
+    def fused_hist_ok(self):
+        """May the producers histogram their own output (fq_*_hist_f32)?  Those epilogues exist for INTERVAL_NUM = 2048 only;
+        with another bin count pass 2 takes every histogram through fq_hist_seg_n."""
+        return self._interval_num == _native.BINS
 
     def add_pairs_to_distributions(self, pairs):
         """pairs: [(a, b, name of a's row or None, name of the sum's row)].  a is counted into its row and a + b -- the fp32

@@ -23,7 +23,8 @@ __all__ = ["Quantizer"]
 def _rows_to_device(distributions, names, device):
     """Stack per-tensor histograms (NumPy int32 / merged float64, or device int64) into int64[T,2048]."""
     if isinstance(distributions, torch.Tensor):
-        assert distributions.dtype == torch.int64 and distributions.shape == (len(names), _native.BINS)
+        assert (distributions.dtype == torch.int64 and distributions.dim() == 2 and distributions.shape[0] == len(names)
+                and distributions.shape[1] in _native.SUPPORTED_BINS)
         return distributions.contiguous()
     rows = []
     for n in names:

@@ -710,7 +710,7 @@ class Quantity(_FusedForward, _FileInputs):
         # pass 2: histograms with the final intervals
         print("Collect histograms of activations:")
         if (eager_ok and self.fuse_bias_absmax and self.fuse_hist and not ctl.fuse_off and ctl.fuse_verified
-                and inplace is False and hasattr(collector, "prepare_distributions")):
+                and inplace is False and hasattr(collector, "prepare_distributions") and getattr(collector, "fused_hist_ok", True)):
             collector.prepare_distributions()
             ctl.fuse_collector, ctl.fuse_stat = collector, "hist"
         elif eager_ok and self.fuse_bias_absmax and self.own_conv1x1 and not ctl.fuse_off and ctl.fuse_verified:

@@ -549,3 +549,39 @@ def random_net(index, seed, odd=False, device="cpu", share=False, bn=False):
                 m.bias.normal_(0.0, 0.2)
     bs = rng.choice([4, 8])
     return model.to(device), size, bs, rng
+
+
+# --------------------------------------------------------------------------------------------
+# G14: INTERVAL_NUM other than 2048 (configs.yml:24; distribution_collector.py:9-14 and quantizer.py:98-167 are generic in the
+# histogram's length).  Tensors for the collector and histograms of `bins` bins for the KL sweep.
+# --------------------------------------------------------------------------------------------
+G14_BINS = (512, 1024, 4096)
+
+
+def g14_tensor_cases():
+    c = g1_cases()
+    return {k: c[k] for k in ("normal_100352", "normal_3batch", "relu_sparse", "all_zero", "single_outlier", "tiny_values",
+                              "ragged_4099", "pass2_exceeds", "uniform")}
+
+
+def g14_hists(bins):
+    j = np.arange(bins, dtype=np.float64)
+    s = bins / 2048.0
+
+    def poisson(lam, seed):
+        return _rng(seed).poisson(lam).astype(np.int32)
+
+    h = {}
+    h["gauss"] = poisson(2e4 * np.exp(-0.5 * (j / (300.0 * s)) ** 2), 1401)
+    h["laplace"] = poisson(1e5 * np.exp(-j / (60.0 * s)), 1402)
+    h["heavy_tail"] = poisson(1e5 / (1.0 + (j / (20.0 * s)) ** 2), 1403)
+    h["relu_like"] = poisson(8e4 * np.exp(-j / (35.0 * s)) + 30.0 * np.exp(-0.5 * ((j - 900 * s) / (200.0 * s)) ** 2), 1404)
+    sp = np.zeros(bins, dtype=np.int32)
+    idx = _rng(1405).choice(bins, 90, replace=False)
+    sp[idx] = _rng(1406).integers(1, 50, 90)
+    h["sparse_random"] = sp
+    h["empty"] = np.zeros(bins, dtype=np.int32)
+    h["merged_f64"] = h["gauss"].astype(np.float64) + h["laplace"].astype(np.float64)
+    if bins > 2048:                      # the reference's interpreted sweep costs ~10 s per 4096-bin histogram
+        h = {k: h[k] for k in ("gauss", "relu_like", "sparse_random", "merged_f64")}
+    return h

@@ -4,7 +4,8 @@ reference.  Run in the build container only:
 
     python tests/golden/make_golden_kernels.py
 
-Writes tests/golden/g1_hist.npz, g2_kl.npz, g5_ops.npz, g8_merge_bn.npz.  The fixtures are data
+Writes tests/golden/g1_hist.npz, g2_kl.npz, g5_ops.npz, g8_merge_bn.npz; `... g14` writes g14_interval_num.npz (the collector
+and the KL search at INTERVAL_NUM 512 / 1024 / 4096).  The fixtures are data
 (inputs or their seeds+sha256, and the reference's outputs); no reference source is stored.
 """
 import json
@@ -84,6 +85,52 @@ def capture_g2(cq):
     np.savez_compressed(os.path.join(HERE, "g2_kl.npz"), **out)
 
 
+def capture_g14(cq):
+    """G14 (g14_interval_num.npz): the collector and the KL search of the reference at INTERVAL_NUM 512 / 1024 / 4096."""
+    out, meta = {}, {}
+    for bins in cases.G14_BINS:
+        for name, case in cases.g14_tensor_cases().items():
+            coll = cq.DistributionCollector([name], interval_num=bins, statistic=1, worker_num=1)
+            for b in case["p1"]:
+                coll.refresh_max_val({name: b})
+            mv = coll.max_vals[name]
+            iv = coll.distribution_intervals[name]
+            for b in case["p2"]:
+                coll.add_to_distributions({name: b})
+            hist = coll.distributions[name]
+            assert hist.shape == (bins,)
+            out["%d/t/%s/hist" % (bins, name)] = hist
+            out["%d/t/%s/max" % (bins, name)] = np.float64(mv)
+            out["%d/t/%s/interval" % (bins, name)] = np.float64(iv)
+            meta["%d/%s" % (bins, name)] = dict(interval_type=type(iv).__name__)
+        for name, h in cases.g14_hists(bins).items():
+            q = cq.Quantizer([name], worker_num=1)
+            curve = []
+            orig = q.compute_kl_divergence
+
+            def rec(a, b, _orig=orig, _curve=curve):
+                v = _orig(a, b)
+                _curve.append(float(v))
+                return v
+            q.compute_kl_divergence = rec
+            p = q.normalize_distribution(h)
+            thr = q.threshold_distribution(p)
+            n_curve = len(curve)
+            iv = np.float32(3.0 / bins)
+            _, bits, tv = q.quantize_worker([name], {name: h}, {name: iv})
+            assert n_curve == bins - 128
+            out["%d/k/%s/hist" % (bins, name)] = h
+            out["%d/k/%s/p" % (bins, name)] = np.asarray(p)
+            out["%d/k/%s/kl" % (bins, name)] = np.array(curve[:n_curve], dtype=np.float64)
+            out["%d/k/%s/thr" % (bins, name)] = np.int32(thr)
+            out["%d/k/%s/bits" % (bins, name)] = np.int32(bits[0])
+            out["%d/k/%s/thr_val" % (bins, name)] = np.float64(tv[0])
+            out["%d/k/%s/interval" % (bins, name)] = iv
+            print("G14", bins, name, "thr", thr, "bits", bits[0], flush=True)
+    out["meta"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(HERE, "g14_interval_num.npz"), **out)
+
+
 def capture_g5(cq):
     import torch
     x = torch.from_numpy(cases.g5_inputs())
@@ -147,6 +194,8 @@ def main():
         capture_g8(cq)
     if "g2" in which:
         capture_g2(cq)
+    if "g14" in which:
+        capture_g14(cq)
 
 
 if __name__ == "__main__":

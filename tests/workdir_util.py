@@ -12,13 +12,15 @@ PKG_QUANTITY = os.path.join(os.path.dirname(HERE), "pytorch-quantity_amd", "quan
 
 
 @contextlib.contextmanager
-def product_workdir(input_shape="1,3,32,32", device="cpu", max_cali_img_num=1, gpu=0, keep=None):
+def product_workdir(input_shape="1,3,32,32", device="cpu", max_cali_img_num=1, gpu=0, keep=None, interval_num=None):
     tmp = tempfile.mkdtemp(prefix="fq_wd_")
     os.makedirs(os.path.join(tmp, "tools"))
     os.makedirs(os.path.join(tmp, "test"))
     with open(os.path.join(PKG_QUANTITY, "tools", "configs.yml")) as fh:
         cfg = yaml.safe_load(fh)
     cfg["SETTINGS"]["MAX_CALI_IMG_NUM"] = max_cali_img_num
+    if interval_num is not None:
+        cfg["SETTINGS"]["INTERVAL_NUM"] = int(interval_num)
     with open(os.path.join(tmp, "tools", "configs.yml"), "w") as fh:
         yaml.safe_dump(cfg, fh)
     with open(os.path.join(PKG_QUANTITY, "test", "user_configs.yml")) as fh:
