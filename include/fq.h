@@ -155,6 +155,9 @@ int fq_bits_from_absmax(const float* absmax, int n, int32_t* bits_out);
 typedef struct fq_pair_seg {
     const float* a;
     const float* b;
+    float* relu_out;       /* NULL, or n floats (16-byte aligned, not aliasing a or b of ANY pair of the call) that receive
+                            * max(a + b, 0) as nn.ReLU computes it (NaN kept): the NEXT block's shortcut, re-made in pass 2
+                            * instead of kept from pass 1 */
     size_t n;
     int32_t row_a;
     int32_t row_sum;

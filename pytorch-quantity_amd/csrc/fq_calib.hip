@@ -19,6 +19,7 @@
 
 #include "fq_common.h"
 #include "fq_hist_bin.h"
+#include "fq_producer_stat.h"
 
 namespace fq {
 
@@ -216,10 +217,11 @@ __global__ __launch_bounds__(kHistBlock) void hist_seg_n_kernel(const SegTable t
 // the shortcut (the previous block's ReLU output) exists anyway, the sum need not be written at all: pass 2 reads the two
 // operands once and bins a into row_a and fl32(a + b) -- the very addition the Eltwise performs -- into row_sum.  Same bytes
 // as reading a and a stored sum; pass 1 writes 4 B per element less.  Both pointers 16-byte aligned (host check).
-constexpr int kPairChunk = 64;         // pairs per launch (kernarg block 2.4 KB)
+constexpr int kPairChunk = 48;         // pairs per launch (kernarg block 2.2 KB)
 struct PairTable {
     const float* a[kPairChunk];
     const float* b[kPairChunk];
+    float* r[kPairChunk];                 // nullable: receives relu(a + b) (the next block's shortcut, re-made instead of kept)
     uint64_t n[kPairChunk];
     uint32_t chunk_begin[kPairChunk + 1];
     int32_t row_a[kPairChunk];            // -1: a is not histogrammed (only the sum)
@@ -229,15 +231,23 @@ struct PairTable {
     int32_t nseg;
 };
 
-// chunks [c0, c1) of one pair: 16-byte vectors, two of each operand in flight per lane; the last n % 4 elements are scalar
-template <int kThreads, typename F>
-__device__ __forceinline__ void for_each_pair_in_chunks(const float* pa, const float* pb, uint64_t cnt, uint32_t c0, uint32_t c1, F&& f) {
+// chunks [c0, c1) of one pair: 16-byte vectors, two of each operand in flight per lane; the last n % 4 elements are scalar.
+// f(a, b) -> the value to store at the same index of r (when r is given)
+template <int kThreads, bool kStore, typename F>
+__device__ __forceinline__ void for_each_pair_in_chunks(const float* pa, const float* pb, float* pr, uint64_t cnt, uint32_t c0, uint32_t c1,
+                                                        F&& f) {
     const int tid = threadIdx.x;
     const f4v* __restrict__ va = reinterpret_cast<const f4v*>(pa);
     const f4v* __restrict__ vb = reinterpret_cast<const f4v*>(pb);
+    f4v* __restrict__ vr = reinterpret_cast<f4v*>(pr);
     const uint64_t nvec = cnt >> 2;
     uint64_t base = (uint64_t)c0 * kChunkVec;
     const uint64_t end = (uint64_t)c1 * kChunkVec < nvec ? (uint64_t)c1 * kChunkVec : nvec;
+    auto four = [&](const f4v a, const f4v b, uint64_t i) {
+        f4v o;
+        o.x = f(a.x, b.x); o.y = f(a.y, b.y); o.z = f(a.z, b.z); o.w = f(a.w, b.w);
+        if (kStore) vr[i] = o;
+    };
     for (; base + 2 * kThreads <= end; base += 2 * kThreads) {
         const uint64_t i = base + tid;
         const f4v a0 = stream_load(&va[i]);
@@ -245,33 +255,34 @@ __device__ __forceinline__ void for_each_pair_in_chunks(const float* pa, const f
         const f4v b0 = stream_load(&vb[i]);
         const f4v b1 = stream_load(&vb[i + kThreads]);
         __builtin_amdgcn_sched_barrier(0);            // the four loads in flight together (see for_each_in_chunks)
-        f(a0.x, b0.x); f(a0.y, b0.y); f(a0.z, b0.z); f(a0.w, b0.w);
-        f(a1.x, b1.x); f(a1.y, b1.y); f(a1.z, b1.z); f(a1.w, b1.w);
+        four(a0, b0, i);
+        four(a1, b1, i + kThreads);
     }
-    for (uint64_t i = base + tid; i < end; i += kThreads) {
-        const f4v a0 = stream_load(&va[i]);
-        const f4v b0 = stream_load(&vb[i]);
-        f(a0.x, b0.x); f(a0.y, b0.y); f(a0.z, b0.z); f(a0.w, b0.w);
-    }
+    for (uint64_t i = base + tid; i < end; i += kThreads) four(stream_load(&va[i]), stream_load(&vb[i]), i);
     const uint32_t tail = (uint32_t)(cnt & 3u);
-    if (c0 == 0 && (uint32_t)tid < tail) f(pa[(nvec << 2) + tid], pb[(nvec << 2) + tid]);
+    if (c0 == 0 && (uint32_t)tid < tail) {
+        const float o = f(pa[(nvec << 2) + tid], pb[(nvec << 2) + tid]);
+        if (kStore) pr[(nvec << 2) + tid] = o;
+    }
 }
 
-template <bool kFastA, bool kFastS>
-__device__ __forceinline__ void pair_piece(const float* pa, const float* pb, uint64_t n, uint32_t c0, uint32_t c1, float iva, float ivs,
-                                           bool want_a, unsigned int* bins_a, unsigned int* bins_s) {
+template <bool kFastA, bool kFastS, bool kStore>
+__device__ __forceinline__ void pair_piece(const float* pa, const float* pb, float* pr, uint64_t n, uint32_t c0, uint32_t c1, float iva,
+                                           float ivs, bool want_a, unsigned int* bins_a, unsigned int* bins_s) {
     const float ya = 1.0f / iva, ys = 1.0f / ivs;
     unsigned int* park = bins_s + FQ_BINS + (threadIdx.x & (kWave - 1));
     if (want_a) {
-        for_each_pair_in_chunks<kHistBlock>(pa, pb, n, c0, c1, [&](float a, float b) {
+        for_each_pair_in_chunks<kHistBlock, kStore>(pa, pb, pr, n, c0, c1, [&](float a, float b) {
             const float s = a + b;                    // (-ffp-contract=off: one rounded fp32 addition, the Eltwise's)
             atomicAdd((a != 0.0f) ? (bins_a + bin_of<kFastA>(a, iva, ya)) : park, 1u);
             atomicAdd((s != 0.0f) ? (bins_s + bin_of<kFastS>(s, ivs, ys)) : park, 1u);
+            return relu_like_torch(s);
         });
     } else {
-        for_each_pair_in_chunks<kHistBlock>(pa, pb, n, c0, c1, [&](float a, float b) {
+        for_each_pair_in_chunks<kHistBlock, kStore>(pa, pb, pr, n, c0, c1, [&](float a, float b) {
             const float s = a + b;
             atomicAdd((s != 0.0f) ? (bins_s + bin_of<kFastS>(s, ivs, ys)) : park, 1u);
+            return relu_like_torch(s);
         });
     }
 }
@@ -301,10 +312,17 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_pair_seg_kernel(const Pai
         const int ra = tab.row_a[s], rs = tab.row_s[s];
         const float ivs = interval[rs], iva = ra >= 0 ? interval[ra] : 1.0f;
         const bool fa = allow_fast && fast_quotient_ok(iva), fs = allow_fast && fast_quotient_ok(ivs);      // uniform per workgroup
-        if (fa && fs) pair_piece<true, true>(tab.a[s], tab.b[s], tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);
-        else if (fa) pair_piece<true, false>(tab.a[s], tab.b[s], tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);
-        else if (fs) pair_piece<false, true>(tab.a[s], tab.b[s], tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);
-        else pair_piece<false, false>(tab.a[s], tab.b[s], tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);
+        float* const pr = tab.r[s];
+#define FQ_PAIR_PIECE(FA, FS)                                                                                                 \
+    do {                                                                                                                      \
+        if (pr) pair_piece<FA, FS, true>(tab.a[s], tab.b[s], pr, tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);              \
+        else pair_piece<FA, FS, false>(tab.a[s], tab.b[s], pr, tab.n[s], c0, c1, iva, ivs, ra >= 0, s_a, s_s);                \
+    } while (0)
+        if (fa && fs) FQ_PAIR_PIECE(true, true);
+        else if (fa) FQ_PAIR_PIECE(true, false);
+        else if (fs) FQ_PAIR_PIECE(false, true);
+        else FQ_PAIR_PIECE(false, false);
+#undef FQ_PAIR_PIECE
         __syncthreads();
         unsigned long long* __restrict__ ds = hist + (size_t)rs * FQ_BINS;
         unsigned long long* __restrict__ da = hist + (size_t)(ra >= 0 ? ra : rs) * FQ_BINS;
@@ -771,7 +789,8 @@ extern "C" int fq_hist2048_pair_seg(const fq_pair_seg* segs, int nseg, const flo
         if (p.row_sum < 0 || p.row_a < -1 || p.row_a == p.row_sum) return FQ_ERR_INVALID_ARG;
         if (p.n != 0 && (p.a == nullptr || p.b == nullptr)) return FQ_ERR_INVALID_ARG;
         if ((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b)) & 3u) return FQ_ERR_INVALID_ARG;
-        if (p.n != 0 && ((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b)) & 15u)) return FQ_ERR_UNSUPPORTED;
+        if (p.n != 0 && ((reinterpret_cast<uintptr_t>(p.a) | reinterpret_cast<uintptr_t>(p.b) | reinterpret_cast<uintptr_t>(p.relu_out)) & 15u))
+            return FQ_ERR_UNSUPPORTED;
     }
     if (nseg == 0) return FQ_OK;
     if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
@@ -788,7 +807,7 @@ extern "C" int fq_hist2048_pair_seg(const fq_pair_seg* segs, int nseg, const flo
             uint64_t nc = (nvec + kChunkVec - 1) / kChunkVec;
             if (nc == 0) nc = 1;                                     // fewer than four elements: the scalar tail of chunk 0
             if (chunks + nc > 0x7fffffffULL) { --i; break; }
-            tab.a[k] = p.a; tab.b[k] = p.b; tab.n[k] = p.n; tab.row_a[k] = p.row_a; tab.row_s[k] = p.row_sum;
+            tab.a[k] = p.a; tab.b[k] = p.b; tab.r[k] = p.relu_out; tab.n[k] = p.n; tab.row_a[k] = p.row_a; tab.row_s[k] = p.row_sum;
             tab.chunk_begin[k] = (uint32_t)chunks;
             chunks += nc;
             ++k;
@@ -799,7 +818,7 @@ extern "C" int fq_hist2048_pair_seg(const fq_pair_seg* segs, int nseg, const flo
         }
         tab.nseg = k;
         for (int j = k; j <= kPairChunk; ++j) tab.chunk_begin[j] = (uint32_t)chunks;
-        for (int j = k; j < kPairChunk; ++j) { tab.a[j] = tab.b[j] = nullptr; tab.n[j] = 0; tab.row_a[j] = -1; tab.row_s[j] = 0; }
+        for (int j = k; j < kPairChunk; ++j) { tab.a[j] = tab.b[j] = nullptr; tab.r[j] = nullptr; tab.n[j] = 0; tab.row_a[j] = -1; tab.row_s[j] = 0; }
         const uint64_t slots = (uint64_t)kCUs * wg_per_cu(kWgPerCUHist);
         uint64_t per_wg = (chunks + slots - 1) / slots;
         if (per_wg < kMinChunksPerWg) per_wg = kMinChunksPerWg;

@@ -28,7 +28,8 @@ class _Seg(ctypes.Structure):
 
 
 class _PairSeg(ctypes.Structure):
-    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("n", ctypes.c_size_t), ("row_a", ctypes.c_int32), ("row_sum", ctypes.c_int32)]
+    _fields_ = [("a", ctypes.c_void_p), ("b", ctypes.c_void_p), ("relu_out", ctypes.c_void_p), ("n", ctypes.c_size_t),
+                ("row_a", ctypes.c_int32), ("row_sum", ctypes.c_int32)]
 
 
 class _ChanSeg(ctypes.Structure):
@@ -304,17 +305,19 @@ def hist2048_seg(tensors, rows, interval, hist):
     return keep
 
 
-def hist2048_pair_seg(a_tensors, b_tensors, rows_a, rows_sum, interval, hist):
+def hist2048_pair_seg(a_tensors, b_tensors, rows_a, rows_sum, interval, hist, relu_outs=None):
     """fq_hist2048_pair_seg: for every pair, a counted into hist[row_a] (row_a None / -1: not counted) and a + b (the fp32 addition
-    of an Eltwise) into hist[row_sum], one pass over both.  Dense fp32 CUDA tensors of equal size, 16-byte aligned."""
+    of an Eltwise) into hist[row_sum], one pass over both; relu_outs[i] (None or a dense tensor of a's size) receives max(a + b, 0)
+    as nn.ReLU computes it.  Dense fp32 CUDA tensors of equal size, 16-byte aligned."""
     if not a_tensors:
         return
     _need_cuda(interval, torch.float32, "interval")
     _need_cuda(hist, torch.int64, "hist")
     assert hist.is_contiguous() and hist.shape[-1] == BINS and len(a_tensors) == len(b_tensors) == len(rows_a) == len(rows_sum)
+    relu_outs = [None] * len(a_tensors) if relu_outs is None else list(relu_outs)
     arr = (_PairSeg * len(a_tensors))()
     keep = []
-    for i, (a, b, ra, rs) in enumerate(zip(a_tensors, b_tensors, rows_a, rows_sum)):
+    for i, (a, b, ra, rs, r) in enumerate(zip(a_tensors, b_tensors, rows_a, rows_sum, relu_outs)):
         _need_cuda(a, torch.float32, "pair %d a" % i)
         _need_cuda(b, torch.float32, "pair %d b" % i)
         assert a.shape == b.shape, "the operands of a pair have different shapes"
@@ -323,6 +326,11 @@ def hist2048_pair_seg(a_tensors, b_tensors, rows_a, rows_sum, interval, hist):
             da, db = a.contiguous(), b.contiguous()
         keep += [da, db]
         arr[i].a, arr[i].b, arr[i].n = da.data_ptr(), db.data_ptr(), da.numel()
+        arr[i].relu_out = None
+        if r is not None:
+            _need_cuda(r, torch.float32, "pair %d relu_out" % i)
+            assert r.shape == a.shape and r.stride() == da.stride() and r.data_ptr() not in (da.data_ptr(), db.data_ptr())
+            arr[i].relu_out = r.data_ptr()
         arr[i].row_a, arr[i].row_sum = (-1 if ra is None else int(ra)), int(rs)
         assert arr[i].row_sum < hist.numel() // BINS and arr[i].row_a < hist.numel() // BINS
     _check(lib().fq_hist2048_pair_seg(arr, len(a_tensors), interval.data_ptr(), hist.data_ptr(), _stream(hist)), "fq_hist2048_pair_seg")

@@ -135,9 +135,10 @@ class DistributionCollector(StatCollectives):
         return self._interval_num == _native.BINS
 
     def add_pairs_to_distributions(self, pairs):
-        """pairs: [(a, b, name of a's row or None, name of the sum's row)].  a is counted into its row and a + b -- the fp32
-        addition an Eltwise performs (fabu_layer.py:5-11) -- into the sum's row, exactly as add_to_distributions() would count
-        the two stored tensors; the sum itself is never written (fq_hist2048_pair_seg)."""
+        """pairs: [(a, b, name of a's row or None, name of the sum's row[, relu_out])].  a is counted into its row and a + b -- the
+        fp32 addition an Eltwise performs (fabu_layer.py:5-11) -- into the sum's row, exactly as add_to_distributions() would count
+        the two stored tensors; the sum itself is never written; relu_out (optional, a tensor like a) receives max(a + b, 0), the
+        next block's shortcut (fq_hist2048_pair_seg)."""
         if not pairs:
             return
         self._added_to_distributions_flag = True
@@ -148,7 +149,8 @@ class DistributionCollector(StatCollectives):
         b = [_as_device_f32(p[1], self._device) for p in pairs]
         rows_a = [None if p[2] is None else self.row_of(p[2]) for p in pairs]
         rows_s = [self.row_of(p[3]) for p in pairs]
-        self._keepalive_pairs = _native.hist2048_pair_seg(a, b, rows_a, rows_s, self._interval_dev, self._hist_dev)
+        relus = [p[4] if len(p) > 4 else None for p in pairs]
+        self._keepalive_pairs = _native.hist2048_pair_seg(a, b, rows_a, rows_s, self._interval_dev, self._hist_dev, relus)
 
     supports_partial = True     # refresh_max_val / add_to_distributions accept a dict holding only SOME of the tensors
 

@@ -18,6 +18,8 @@ same call fires -- and each fusion is a small state machine over them.  States l
 
 Every fusion falls back to the unfused form of the same arithmetic; none changes a table (tests/test_gpu_conv_add_fusion.py,
 tests/test_gpu_float_forward_kernels.py, tests/test_gpu_r50_tables.py)."""
+import weakref
+
 import torch
 
 from common.quantity import _native, _float_conv
@@ -301,8 +303,13 @@ class _FusedForward(object):
         if keep_y and ctl.eager is not None:
             ctl.eager.note(conv_key, t3)                        # (what its own hook left out: the tensor exists only now)
         if pair:
-            ctl.pairs[key] = (conv_key, other, other._version)
+            # (the shortcut is the ReLU output another tail of this forward wrote?  Then it is max(that sum, 0) and pass 2 can
+            #  re-make it from that sum's own pair instead of the cache keeping it: src = that sum's key)
+            src = ctl.sum_relu.get(id(other))
+            ctl.pairs[key] = (conv_key, other, other._version, src[1] if src is not None and src[0]() is other else None)
             ctl.pair_sums += 1
+        if key is not None:
+            ctl.sum_relu[id(r)] = (weakref.ref(r), key)
         ctl.fuse_verified.add(m)
         ctl.relu_ready = (output, r, relu, output._version)
         ctl.fused_relus.add(relu)

@@ -193,7 +193,7 @@ class _HookState(object):
     __slots__ = ("stop_after", "events", "eager", "fuse_bias", "fuse_collector", "fuse_off", "fuse_verified", "fuse_warm",
                  "relu_after", "relu_ready", "last_out", "fused_relus", "fuse_stat", "hist_fused", "keep_feats", "keep_names",
                  "own_plain", "own_conv1x1", "deferred", "defer_ok", "deferred_adds", "deferred_hists", "poison", "relu_only_ok", "skipped_outputs",
-                 "pair_ok", "pairs", "pair_sums")
+                 "pair_ok", "pairs", "pair_sums", "sum_relu")
 
     def __init__(self):
         self.stop_after = None          # ordinal of the last module pass 2 needs (the hook raises _StopForward there)
@@ -226,3 +226,5 @@ class _HookState(object):
         self.pairs = {}                 # THIS forward: key of a sum that was not written -> (key of conv3's output, the shortcut
         #                                 tensor, its version): pass 2 histograms the pair (fq_hist2048_pair_seg)
         self.pair_sums = 0              # sums pass 1 did not write because pass 2 histograms (conv3 output, shortcut) instead
+        self.sum_relu = {}              # THIS forward: id(r) -> (weak reference to r, key of the sum): the ReLU outputs the one-kernel
+        #                                 tails wrote -- a pair whose shortcut is one of them can re-make it in pass 2

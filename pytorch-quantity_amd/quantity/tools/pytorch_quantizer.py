@@ -118,6 +118,10 @@ class Quantity(_FusedForward, _FileInputs):
     # output or the projection) is not written by pass 1: the cache keeps the shortcut in the sum's place and pass 2 histograms
     # (conv3 output, conv3 output + shortcut) in one pass over the pair (fq_hist2048_pair_seg).  Same integers.
     pair_hist = os.environ.get("FQ_PAIR_HIST", "1") != "0"
+    # ... and a shortcut that is itself the ReLU output of an earlier such sum (every identity block) is not kept either: pass 2
+    # re-makes it, level by level, from that sum's pair (fq_hist2048_pair_seg's relu_out) -- the cache then holds conv3's outputs and
+    # one shortcut per stage, and what it no longer spends on sums it spends on earlier layers (a shorter second forward).
+    pair_chain = os.environ.get("FQ_PAIR_CHAIN", "1") != "0"
 
     def __init__(self, model):
         assert os.path.isfile("../tools/configs.yml"), "./configs.yml"
@@ -365,8 +369,11 @@ class Quantity(_FusedForward, _FileInputs):
 
     def _cache_entry(self, named_feats, keep):
         """What pass 1 keeps of the forward that just ran: the hooked tensors named in `keep` (None: all) -- with every sum that
-        was not written replaced by its pair, ("pair", sum key) -> (key of conv3's output, that tensor, the shortcut tensor, the
-        shortcut's version, whether conv3's output is itself among the kept tensors).  Returns (entry, bytes it holds on to)."""
+        was not written replaced by its pair, ("pair", sum key) -> (key of conv3's output, that tensor, the shortcut tensor or None,
+        the shortcut's version, whether conv3's output is itself among the kept tensors, src).  A shortcut that is the ReLU output
+        of an earlier sum of this very entry (src = that sum's key) is not kept at all: pass 2 re-makes it from that sum's pair
+        (fq_hist2048_pair_seg's relu_out), so a chain of identity blocks holds one shortcut, its head's.
+        Returns (entry, bytes it holds on to)."""
         pairs = self._hook_ctl.pairs
         entry, held, nbytes = {}, set(), 0
 
@@ -375,7 +382,7 @@ class Quantity(_FusedForward, _FileInputs):
                 held.add(id(t))
                 return t.numel() * t.element_size()
             return 0
-        for n, t in named_feats.items():
+        for n, t in named_feats.items():                   # (forward order: a sum's src comes before it)
             if keep is not None and n not in keep:
                 continue
             p = pairs.get(n)
@@ -383,33 +390,54 @@ class Quantity(_FusedForward, _FileInputs):
                 entry[n] = t
                 nbytes += hold(t)
                 continue
-            conv_key, other, version = p
+            conv_key, other, version, src = p
             # (the forward that ran before the plan existed may have left a sum to its pair whose conv3 output the plan does not
             #  keep: that one batch then holds the tensor privately, and pass 2 counts it where the prefix forward re-makes it)
             y_kept = keep is None or conv_key in keep
-            entry[("pair", n)] = (conv_key, named_feats[conv_key], other, version, y_kept)
-            nbytes += hold(other) + hold(named_feats[conv_key])
+            chained = src is not None and self.pair_chain and ("pair", src) in entry
+            entry[("pair", n)] = (conv_key, named_feats[conv_key], None if chained else other, version, y_kept, src if chained else None)
+            nbytes += hold(named_feats[conv_key]) + (0 if chained else hold(other))
         return entry, nbytes
 
     def _add_with_pairs(self, collector):
         """collector.add_to_distributions for dicts that may hold pairs (see _cache_entry): the pairs go through
-        add_pairs_to_distributions, which also counts conv3's output -- that tensor then leaves the plain list."""
+        add_pairs_to_distributions, which also counts conv3's output -- that tensor then leaves the plain list.  Chained pairs run
+        level by level: a level's launch writes the ReLU outputs the next level's pairs add as their shortcut."""
         def add(feats):
             pairs = [(k[1], v) for k, v in feats.items() if isinstance(k, tuple)]
             if not pairs:
                 return collector.add_to_distributions(feats)
             plain = dict((k, v) for k, v in feats.items() if not isinstance(k, tuple))
-            jobs = []
-            for sum_key, (conv_key, y, other, version, y_kept) in pairs:
-                if other._version != version:
-                    raise RuntimeError("the shortcut of %s was written to after the add that pass 1 left to pass 2; set "
-                                       "Quantity.pair_hist = False (FQ_PAIR_HIST=0)" % sum_key)
+            wanted = set(v[5] for _k, v in pairs if v[5] is not None)          # sums whose ReLU a later pair adds
+            depth, levels = {}, []
+            for sum_key, v in pairs:                                          # (forward order)
+                conv_key, y, other, version, y_kept, src = v
+                if src is None:
+                    if other._version != version:
+                        raise RuntimeError("the shortcut of %s was written to after the add that pass 1 left to pass 2; set "
+                                           "Quantity.pair_hist = False (FQ_PAIR_HIST=0)" % sum_key)
+                    depth[sum_key] = 0
+                else:
+                    if src not in depth:
+                        raise RuntimeError("pass 2 holds the pair of %s without the pair of %s it is chained to" % (sum_key, src))
+                    depth[sum_key] = depth[src] + 1
                 if y_kept and plain.pop(conv_key, None) is None:
                     raise RuntimeError("pass 2 holds the pair of %s without %s" % (sum_key, conv_key))
-                jobs.append((y, other, conv_key if y_kept else None, sum_key))
+                while len(levels) <= depth[sum_key]:
+                    levels.append([])
+                levels[depth[sum_key]].append((sum_key, v))
             if plain:
                 collector.add_to_distributions(plain)
-            collector.add_pairs_to_distributions(jobs)
+            made = {}
+            for jobs_of_level in levels:
+                jobs = []
+                for sum_key, (conv_key, y, other, _version, y_kept, src) in jobs_of_level:
+                    b = other if src is None else made.pop(src)
+                    r = torch.empty_like(y) if sum_key in wanted else None
+                    if r is not None:
+                        made[sum_key] = r
+                    jobs.append((y, b, conv_key if y_kept else None, sum_key, r))
+                collector.add_pairs_to_distributions(jobs)
         add.__name__ = "add_to_distributions"
         add.__self__ = collector
         return add
@@ -428,7 +456,7 @@ class Quantity(_FusedForward, _FileInputs):
         eager = _EagerStats(fn, limit)
         eager.retain = self._hook_ctl.keep_feats
         self._hook_ctl.eager = eager
-        self._hook_ctl.pairs = {}
+        self._hook_ctl.pairs, self._hook_ctl.sum_relu = {}, {}
         try:
             self.net_forward(self.model, item)
         finally:
@@ -495,11 +523,25 @@ class Quantity(_FusedForward, _FileInputs):
         cost_a = (n_owned - min(m, n_owned)) * t_full
         room = budget // n_owned
         keep, used = [], 0
+        # What keeping a tensor costs.  A sum that pass 1 leaves to its pair (Quantity.pair_hist) costs its SHORTCUT instead -- nothing
+        # when that is a hooked tensor kept in its own right (a projection's output); and when it is the ReLU output of an earlier
+        # such sum (pair_chain) the cost is given back as soon as that earlier block's conv3 output joins the suffix, because
+        # pass 2 then re-makes the shortcut instead of reading a kept one.
+        pair_info = dict(self._hook_ctl.pairs) if self.pair_hist else {}
+        hooked = set(id(t) for t in feats.values())
+        refund = {}                                              # conv3 key of the src pair -> bytes given back when it is kept
         for n, o, b in sorted(sizes, key=lambda e: -e[1]):       # deepest first
-            if n == "image" or used + b > room:
+            cost = b
+            p = pair_info.get(n)
+            if p is not None:
+                conv_key, other, _version, src = p
+                cost = 0 if id(other) in hooked else other.numel() * other.element_size()
+                if cost and src is not None and self.pair_chain and src in pair_info:
+                    refund[pair_info[src][0]] = refund.get(pair_info[src][0], 0) + cost
+            if n == "image" or used + cost > room:
                 break
             keep.append(n)
-            used += b
+            used += cost - refund.pop(n, 0)
         if not keep:
             return plan
         early = [o for n, o, _b in sizes if n not in keep and n != "image"]

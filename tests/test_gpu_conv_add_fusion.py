@@ -52,7 +52,7 @@ def _block_net(variant="plain", hw=64):
     return Net()
 
 
-def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None, hw=64, skip=None, pair=None):
+def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None, hw=64, skip=None, pair=None, chain=None):
     from tools import Quantity
     if monkeypatch is not None and cache_gb is not None:
         monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
@@ -63,6 +63,8 @@ def _calibrate(model, fuse, cache_gb=None, plan="", batches=5, monkeypatch=None,
         q.skip_unread_outputs = fuse if skip is None else skip
         if pair is not None:
             q.pair_hist = pair
+        if chain is not None:
+            q.pair_chain = chain
         bits = q.activation_quantize(cases.calib_batches(batches, (8, 3, hw, hw), seed=91))
         table = open(os.path.join(tmp, "test", "workdir", "feat.table")).read()
         return dict(bits), table, dict(q._collector.max_vals), q._collector.hist_device.clone(), dict(q.timings)
@@ -143,15 +145,22 @@ def test_a_sum_whose_operands_the_cache_keeps_is_left_to_pass_2(monkeypatch, cac
     want = _calibrate(model, False, cache_gb, plan, monkeypatch=monkeypatch)
     off = _calibrate(model, True, cache_gb, plan, monkeypatch=monkeypatch, pair=False)
     on = _calibrate(model, True, cache_gb, plan, monkeypatch=monkeypatch, pair=True)
-    for got in (off, on):
+    # pair_chain (the default): block 2's shortcut is block 1's ReLU output = max(block 1's sum, 0), so the cache does not keep it
+    # either -- pass 2 re-makes it while it counts block 1's pair (fq_hist2048_pair_seg's relu_out) and counts block 2's pair in a
+    # second launch.  Without the chain the shortcut is kept as a tensor.
+    flat = _calibrate(model, True, cache_gb, plan, monkeypatch=monkeypatch, pair=True, chain=False)
+    for got in (off, on, flat):
         assert got[1] == want[1] and got[0] == want[0] and got[2] == want[2] and torch.equal(got[3], want[3])
     assert off[4]["sums_left_to_pass2_pairs"] == 0
     n = on[4]["sums_left_to_pass2_pairs"]
     if cache_gb == "1":
         assert n == on[4]["conv_add_launches"] and n in (2 * 4, 2 * 5)            # every chain of every fused forward
-        assert on[4]["cache_bytes"] <= off[4]["cache_bytes"]
+        assert flat[4]["cache_bytes"] <= off[4]["cache_bytes"]
+        # one 8 x 128 x 32 x 32 fp32 tensor (4 MB) less per batch than the flat form: block 2's shortcut
+        assert flat[4]["cache_bytes"] - on[4]["cache_bytes"] >= 4 * 8 * 128 * 32 * 32 * 4
     else:
         assert 0 < n <= on[4]["conv_add_launches"]                                # the chains / batches the partial cache keeps
+        assert on[4]["cache_bytes"] <= flat[4]["cache_bytes"] + 1
 
 
 def test_a_shortcut_written_in_place_after_the_add_keeps_its_sum_materialised(monkeypatch):

@@ -391,6 +391,19 @@ def test_pair_histogram_counts_a_tensor_and_a_sum_like_the_two_stored_tensors(or
         ref[5] = 3
         oracle.hist2048(sums[i].cpu().numpy(), np.float32(host_iv[rows_s[i]]), ref)
         assert np.array_equal(hist[rows_s[i]].cpu().numpy(), ref), i
+    # relu_out: max(a + b, 0) as nn.ReLU computes it (NaN kept, -0.0 -> what torch gives), for some pairs and not for others
+    a[2][100], b[2][101] = float("nan"), float("nan")
+    a[2][102], b[2][102] = -0.0, 0.0
+    hist2, want2 = torch.zeros_like(hist), torch.zeros_like(hist)
+    relus = [torch.full_like(x, 123.0) if i % 2 == 0 else None for i, x in enumerate(a)]
+    nat.hist2048_pair_seg(a, b, rows_a, rows_s, iv, hist2, relus)
+    sums = [torch.add(x, y) for x, y in zip(a, b)]
+    nat.hist2048_seg([x for x, r in zip(a, rows_a) if r is not None] + sums, [r for r in rows_a if r is not None] + rows_s, iv, want2)
+    assert torch.equal(hist2, want2)
+    for i, r in enumerate(relus):
+        if r is not None:
+            ref = torch.relu(sums[i])
+            assert torch.equal(torch.isnan(r), torch.isnan(ref)) and torch.equal(torch.nan_to_num(r, nan=7.0), torch.nan_to_num(ref, nan=7.0)), i
     # a misaligned operand is refused (the caller then materialises the sum)
     with pytest.raises(nat.FqError):
         nat.hist2048_pair_seg([a[2][1:]], [b[2][1:]], [0], [1], iv, hist)
