@@ -126,6 +126,24 @@ int fq_kl_threshold_ex(const int64_t* hist, int rows, int32_t* thr_out, double* 
                        double* runner_up_kl_out, double* kl_curve_out, int mode,
                        void* workspace, size_t workspace_bytes, fq_stream_t stream);
 
+/* A whole stage of residual blocks in one pass.  The blocks of a stage chain on their shortcut: S_1 = y_1 + head and, for k > 1,
+ * S_k = y_k + max(S_(k-1), 0) -- an identity block's shortcut IS the previous block's nn.ReLU output.  For every chain, y_k[i] is
+ * counted into row_y[k] (skipped when -1) and S_k[i] into row_sum[k], k = 0 .. len - 1, each exactly as fq_hist2048_seg would count
+ * the stored tensor (every addition one rounded fp32 add as fabu_layer.py:5-11 performs it, every ReLU as torch computes it); no
+ * sum and no intermediate shortcut is read or written: (len + 1) x 4 bytes per position.  All pointers 16-byte aligned
+ * (FQ_ERR_UNSUPPORTED otherwise), n floats each.  One launch per chain. */
+#define FQ_CHAIN_MAX 6
+typedef struct fq_chain_seg {
+    const float* head;                 /* the first block's shortcut (a projection's output, or a kept ReLU output) */
+    const float* y[FQ_CHAIN_MAX];      /* conv3 outputs of the chain's blocks, in order */
+    size_t n;
+    int32_t len;                       /* 1 .. FQ_CHAIN_MAX */
+    int32_t row_y[FQ_CHAIN_MAX];
+    int32_t row_sum[FQ_CHAIN_MAX];
+} fq_chain_seg;
+int fq_hist2048_chain_seg(const fq_chain_seg* segs, int nseg, const float* interval, int64_t* hist,
+                          fq_stream_t stream);
+
 /* INTERVAL_NUM other than 2048 (tools/configs.yml:24; distribution_collector.py:9-14 takes it as interval_num and
  * quantizer.py:98-167 sweeps t = 128 .. distribution.size - 1, whatever the size): the segmented histogram and the exhaustive
  * KL sweep for bins in {512, 1024, 2048, 4096} (FQ_ERR_UNSUPPORTED otherwise; 2048 is the entry points above).

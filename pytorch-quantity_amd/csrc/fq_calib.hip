@@ -339,6 +339,133 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_pair_seg_kernel(const Pai
 }
 
 // ---------------------------------------------------------------------------------------------
+// chains: a whole stage of residual blocks in one pass (fq_hist2048_chain_seg)
+// ---------------------------------------------------------------------------------------------
+// The blocks of a stage chain on their shortcut: S_1 = y_1 + head, and for k > 1  S_k = y_k + max(S_{k-1}, 0) -- the shortcut of an
+// identity block IS the previous block's ReLU output.  So when pass 1 keeps the conv3 outputs y_1 .. y_L of a stage and the
+// stage's first shortcut (the projection's output), neither the sums nor the intermediate shortcuts need exist in HBM: a thread
+// reads head[i], y_1[i] .. y_L[i] once, walks the chain in registers and counts 2 L values.  (L + 1) x 4 bytes per position
+// instead of the 3 L x 4 of writing, keeping and re-reading every sum.  2 L histograms of 2048 32-bit bins in LDS (dynamic:
+// 16 KB per block of the chain), 512 threads, as many workgroups per CU as that leaves room for, each with an equal run of 16 KB
+// chunks; the 16-byte loads of all L + 1 streams of two vectors are in flight together.
+constexpr int kChainBlock = 512;
+template <int L>
+struct ChainArgs {
+    const float* head;
+    const float* y[L];
+    uint64_t n;
+    int32_t row_y[L];                     // -1: y_k is not histogrammed
+    int32_t row_s[L];
+    uint32_t chunks_per_wg, total_chunks;
+};
+
+template <int L, bool kFast>
+__device__ __forceinline__ void chain_body(const ChainArgs<L>& t, const float* __restrict__ interval, unsigned int* bins) {
+    // bins: [2 L][FQ_BINS] then kWave parking slots; histogram 2 k = y_k, 2 k + 1 = S_k
+    float ivy[L], ivs[L], ry[L], rs[L];
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        ivy[k] = t.row_y[k] >= 0 ? interval[t.row_y[k]] : 1.0f;
+        ivs[k] = interval[t.row_s[k]];
+        ry[k] = 1.0f / ivy[k];
+        rs[k] = 1.0f / ivs[k];
+    }
+    unsigned int* const park = bins + 2 * L * FQ_BINS + (threadIdx.x & (kWave - 1));
+    auto one = [&](float o, const float (&a)[L]) {
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            const float s = a[k] + o;                 // (-ffp-contract=off: the Eltwise's one rounded fp32 addition)
+            if (t.row_y[k] >= 0) atomicAdd((a[k] != 0.0f) ? (bins + (2 * k) * FQ_BINS + bin_of<kFast>(a[k], ivy[k], ry[k])) : park, 1u);
+            atomicAdd((s != 0.0f) ? (bins + (2 * k + 1) * FQ_BINS + bin_of<kFast>(s, ivs[k], rs[k])) : park, 1u);
+            o = relu_like_torch(s);                   // the next block's shortcut, as nn.ReLU computes it
+        }
+    };
+    const int tid = threadIdx.x;
+    const uint64_t nvec = t.n >> 2;
+    const uint32_t c0 = blockIdx.x * t.chunks_per_wg;
+    const uint32_t c1 = c0 + t.chunks_per_wg < t.total_chunks ? c0 + t.chunks_per_wg : t.total_chunks;
+    uint64_t base = (uint64_t)c0 * kChunkVec;
+    const uint64_t end = (uint64_t)c1 * kChunkVec < nvec ? (uint64_t)c1 * kChunkVec : nvec;
+    const f4v* __restrict__ vh = reinterpret_cast<const f4v*>(t.head);
+    for (; base + 2 * kChainBlock <= end; base += 2 * kChainBlock) {
+        const uint64_t i = base + tid;
+        const f4v h0 = stream_load(&vh[i]), h1 = stream_load(&vh[i + kChainBlock]);
+        f4v y0[L], y1[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) {
+            y0[k] = stream_load(reinterpret_cast<const f4v*>(t.y[k]) + i);
+            y1[k] = stream_load(reinterpret_cast<const f4v*>(t.y[k]) + i + kChainBlock);
+        }
+        __builtin_amdgcn_sched_barrier(0);            // all 2 (L + 1) loads in flight before the first LDS atomic
+        float a[L];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) a[k] = y0[k][e];
+            one(h0[e], a);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) a[k] = y1[k][e];
+            one(h1[e], a);
+        }
+    }
+    for (uint64_t i = base + tid; i < end; i += kChainBlock) {
+        const f4v h0 = stream_load(&vh[i]);
+        f4v y0[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) y0[k] = stream_load(reinterpret_cast<const f4v*>(t.y[k]) + i);
+        float a[L];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) a[k] = y0[k][e];
+            one(h0[e], a);
+        }
+    }
+    const uint32_t tail = (uint32_t)(t.n & 3u);
+    if (c0 == 0 && (uint32_t)tid < tail) {
+        float a[L];
+#pragma unroll
+        for (int k = 0; k < L; ++k) a[k] = t.y[k][(nvec << 2) + tid];
+        one(t.head[(nvec << 2) + tid], a);
+    }
+}
+
+template <int L>
+__global__ __launch_bounds__(kChainBlock) void hist2048_chain_kernel(const ChainArgs<L> t, const float* __restrict__ interval,
+                                                                  unsigned long long* __restrict__ hist, const int allow_fast) {
+    extern __shared__ __attribute__((aligned(16))) unsigned int chain_bins[];
+    for (int b = threadIdx.x; b < 2 * L * FQ_BINS + kWave; b += kChainBlock) chain_bins[b] = 0u;
+    __syncthreads();
+    bool fast = allow_fast != 0;                      // the 3-instruction quotient only when EVERY row's interval allows it (uniform)
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        if (t.row_y[k] >= 0) fast = fast && fast_quotient_ok(interval[t.row_y[k]]);
+        fast = fast && fast_quotient_ok(interval[t.row_s[k]]);
+    }
+    if (fast) chain_body<L, true>(t, interval, chain_bins);
+    else chain_body<L, false>(t, interval, chain_bins);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < L; ++k) {
+        if (t.row_y[k] >= 0) {
+            unsigned long long* __restrict__ d = hist + (size_t)t.row_y[k] * FQ_BINS;
+            for (int b = threadIdx.x; b < FQ_BINS; b += kChainBlock) {
+                const unsigned int c = chain_bins[(2 * k) * FQ_BINS + b];
+                if (c) atomicAdd(d + b, (unsigned long long)c);
+            }
+        }
+        unsigned long long* __restrict__ d = hist + (size_t)t.row_s[k] * FQ_BINS;
+        for (int b = threadIdx.x; b < FQ_BINS; b += kChainBlock) {
+            const unsigned int c = chain_bins[(2 * k + 1) * FQ_BINS + b];
+            if (c) atomicAdd(d + b, (unsigned long long)c);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // per-channel rows: one histogram row per (tensor, channel) of an NCHW activation
 // ---------------------------------------------------------------------------------------------
 // A row is no longer one contiguous run: channel c of tensor [N][C][HW] is the N planes at (n*C + c)*HW.  The tensor is
@@ -779,6 +906,72 @@ extern "C" int fq_hist_seg_n(const fq_seg* segs, int nseg, const float* interval
         FQ_LAUNCH_CHECK();
         return FQ_OK;
     });
+}
+
+namespace fq {
+template <int L>
+static int launch_chain(const fq_chain_seg& c, const float* interval, int64_t* hist, hipStream_t st) {
+    ChainArgs<L> a;
+    a.head = c.head;
+    a.n = c.n;
+    for (int k = 0; k < L; ++k) { a.y[k] = c.y[k]; a.row_y[k] = c.row_y[k]; a.row_s[k] = c.row_sum[k]; }
+    const uint64_t nvec = c.n >> 2;
+    uint64_t chunks = (nvec + kChunkVec - 1) / kChunkVec;
+    if (chunks == 0) chunks = 1;
+    if (chunks > 0x7fffffffULL) return FQ_ERR_UNSUPPORTED;
+    const size_t lds = (size_t)(2 * L * FQ_BINS + kWave) * sizeof(unsigned int);
+    int per_cu = (int)((size_t)150 * 1024 / lds);                 // 160 KB of LDS per CU, some of it the runtime's
+    if (per_cu > 3) per_cu = 3;
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t slots = (uint64_t)kCUs * per_cu;
+    uint64_t per_wg = (chunks + slots - 1) / slots;
+    if (per_wg < kMinChunksPerWg) per_wg = kMinChunksPerWg;
+    a.chunks_per_wg = (uint32_t)per_wg;
+    a.total_chunks = (uint32_t)chunks;
+    static bool lds_ok[kMaxDevices] = {};
+    if (lds > 64 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(hist2048_chain_kernel<L>), (int)lds, lds_ok)) return FQ_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(hist2048_chain_kernel<L>, dim3((uint32_t)((chunks + per_wg - 1) / per_wg)), dim3(kChainBlock), lds, st, a, interval,
+                       reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
+}  // namespace fq
+
+extern "C" int fq_hist2048_chain_seg(const fq_chain_seg* segs, int nseg, const float* interval, int64_t* hist, fq_stream_t stream) {
+    using namespace fq;
+    if (nseg < 0 || nseg > FQ_MAX_SEGS || (nseg > 0 && segs == nullptr)) return FQ_ERR_INVALID_ARG;
+    for (int i = 0; i < nseg; ++i) {
+        const fq_chain_seg& c = segs[i];
+        if (c.len < 1 || c.len > FQ_CHAIN_MAX) return FQ_ERR_INVALID_ARG;
+        uintptr_t bits = reinterpret_cast<uintptr_t>(c.head);
+        for (int k = 0; k < c.len; ++k) {
+            if (c.row_sum[k] < 0 || c.row_y[k] < -1 || c.row_y[k] == c.row_sum[k]) return FQ_ERR_INVALID_ARG;
+            if (c.n != 0 && c.y[k] == nullptr) return FQ_ERR_INVALID_ARG;
+            bits |= reinterpret_cast<uintptr_t>(c.y[k]);
+        }
+        if (c.n != 0 && c.head == nullptr) return FQ_ERR_INVALID_ARG;
+        if (bits & 3u) return FQ_ERR_INVALID_ARG;
+        if (c.n != 0 && (bits & 15u)) return FQ_ERR_UNSUPPORTED;
+    }
+    if (nseg == 0) return FQ_OK;
+    if (interval == nullptr || hist == nullptr) return FQ_ERR_INVALID_ARG;
+    hipStream_t st = as_stream(stream);
+    for (int i = 0; i < nseg; ++i) {                       // one launch per chain: the chains of a forward differ in length and size
+        const fq_chain_seg& c = segs[i];
+        if (c.n == 0) continue;
+        int rc;
+        switch (c.len) {
+            case 1: rc = launch_chain<1>(c, interval, hist, st); break;
+            case 2: rc = launch_chain<2>(c, interval, hist, st); break;
+            case 3: rc = launch_chain<3>(c, interval, hist, st); break;
+            case 4: rc = launch_chain<4>(c, interval, hist, st); break;
+            case 5: rc = launch_chain<5>(c, interval, hist, st); break;
+            default: rc = launch_chain<6>(c, interval, hist, st); break;
+        }
+        if (rc != FQ_OK) return rc;
+    }
+    return FQ_OK;
 }
 
 extern "C" int fq_hist2048_pair_seg(const fq_pair_seg* segs, int nseg, const float* interval, int64_t* hist, fq_stream_t stream) {

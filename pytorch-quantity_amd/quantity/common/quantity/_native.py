@@ -32,6 +32,14 @@ class _PairSeg(ctypes.Structure):
                 ("row_a", ctypes.c_int32), ("row_sum", ctypes.c_int32)]
 
 
+CHAIN_MAX = 6                # FQ_CHAIN_MAX
+
+
+class _ChainSeg(ctypes.Structure):
+    _fields_ = [("head", ctypes.c_void_p), ("y", ctypes.c_void_p * CHAIN_MAX), ("n", ctypes.c_size_t), ("len", ctypes.c_int32),
+                ("row_y", ctypes.c_int32 * CHAIN_MAX), ("row_sum", ctypes.c_int32 * CHAIN_MAX)]
+
+
 class _ChanSeg(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("HW", ctypes.c_int64),
                 ("row0", ctypes.c_int32), ("reserved", ctypes.c_int32)]
@@ -67,6 +75,8 @@ def lib():
     L.fq_kl_workspace_bytes_n.argtypes = [ci, ci]
     L.fq_kl_threshold_n.restype = ci
     L.fq_kl_threshold_n.argtypes = [vp, ci, ci, vp, vp, vp, sz, vp]
+    L.fq_hist2048_chain_seg.restype = ci
+    L.fq_hist2048_chain_seg.argtypes = [ctypes.POINTER(_ChainSeg), ci, vp, vp, vp]
     L.fq_hist2048_pair_seg.restype = ci
     L.fq_hist2048_pair_seg.argtypes = [ctypes.POINTER(_PairSeg), ci, vp, vp, vp]
     L.fq_absmax_chan.restype = ci
@@ -334,6 +344,38 @@ def hist2048_pair_seg(a_tensors, b_tensors, rows_a, rows_sum, interval, hist, re
         arr[i].row_a, arr[i].row_sum = (-1 if ra is None else int(ra)), int(rs)
         assert arr[i].row_sum < hist.numel() // BINS and arr[i].row_a < hist.numel() // BINS
     _check(lib().fq_hist2048_pair_seg(arr, len(a_tensors), interval.data_ptr(), hist.data_ptr(), _stream(hist)), "fq_hist2048_pair_seg")
+    return keep
+
+
+def hist2048_chain_seg(chains, interval, hist):
+    """fq_hist2048_chain_seg.  chains: [(head, [y_1 .. y_L], [row of y_k or None], [row of S_k])] with S_1 = y_1 + head and
+    S_k = y_k + relu(S_(k-1)): every y_k counted into its row and every S_k into its row, one pass over the L + 1 tensors, nothing
+    written.  Dense fp32 CUDA tensors of one size and layout, 16-byte aligned, L <= CHAIN_MAX."""
+    if not chains:
+        return
+    _need_cuda(interval, torch.float32, "interval")
+    _need_cuda(hist, torch.int64, "hist")
+    assert hist.is_contiguous() and hist.shape[-1] == BINS
+    rows = hist.numel() // BINS
+    arr = (_ChainSeg * len(chains))()
+    keep = []
+    for i, (head, ys, rows_y, rows_s) in enumerate(chains):
+        assert 1 <= len(ys) <= CHAIN_MAX and len(ys) == len(rows_y) == len(rows_s)
+        ts = [head] + list(ys)
+        for t in ts:
+            _need_cuda(t, torch.float32, "chain %d" % i)
+            assert t.shape == head.shape, "the tensors of a chain have different shapes"
+        dense = [dense_view(t) for t in ts]
+        if any(d.stride() != dense[0].stride() for d in dense):          # element i of one must be element i of the others
+            dense = [t.contiguous() for t in ts]
+        keep += dense
+        arr[i].head, arr[i].n, arr[i].len = dense[0].data_ptr(), dense[0].numel(), len(ys)
+        for k in range(len(ys)):
+            arr[i].y[k] = dense[1 + k].data_ptr()
+            arr[i].row_y[k] = -1 if rows_y[k] is None else int(rows_y[k])
+            arr[i].row_sum[k] = int(rows_s[k])
+            assert arr[i].row_sum[k] < rows and arr[i].row_y[k] < rows
+    _check(lib().fq_hist2048_chain_seg(arr, len(chains), interval.data_ptr(), hist.data_ptr(), _stream(hist)), "fq_hist2048_chain_seg")
     return keep
 
 

@@ -152,6 +152,22 @@ class DistributionCollector(StatCollectives):
         relus = [p[4] if len(p) > 4 else None for p in pairs]
         self._keepalive_pairs = _native.hist2048_pair_seg(a, b, rows_a, rows_s, self._interval_dev, self._hist_dev, relus)
 
+    def add_chains_to_distributions(self, chains):
+        """chains: [(head, [(y_k, name of y_k's row or None, name of S_k's row), ...])]: a stage of residual blocks whose sums pass
+        1 did not write -- S_1 = y_1 + head, S_k = y_k + relu(S_(k-1)) -- counted in one pass over the conv3 outputs and the one
+        shortcut (fq_hist2048_chain_seg); nothing is written."""
+        if not chains:
+            return
+        self._added_to_distributions_flag = True
+        if not hasattr(self, "_distribution_intervals"):
+            self.distribution_intervals
+        self._sync_intervals()
+        jobs = []
+        for head, blocks in chains:
+            jobs.append((_as_device_f32(head, self._device), [_as_device_f32(b[0], self._device) for b in blocks],
+                         [None if b[1] is None else self.row_of(b[1]) for b in blocks], [self.row_of(b[2]) for b in blocks]))
+        self._keepalive_chains = _native.hist2048_chain_seg(jobs, self._interval_dev, self._hist_dev)
+
     supports_partial = True     # refresh_max_val / add_to_distributions accept a dict holding only SOME of the tensors
 
     def row_of(self, name):

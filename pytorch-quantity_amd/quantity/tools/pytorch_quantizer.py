@@ -119,8 +119,8 @@ class Quantity(_FusedForward, _FileInputs):
     # (conv3 output, conv3 output + shortcut) in one pass over the pair (fq_hist2048_pair_seg).  Same integers.
     pair_hist = os.environ.get("FQ_PAIR_HIST", "1") != "0"
     # ... and a shortcut that is itself the ReLU output of an earlier such sum (every identity block) is not kept either: pass 2
-    # re-makes it, level by level, from that sum's pair (fq_hist2048_pair_seg's relu_out) -- the cache then holds conv3's outputs and
-    # one shortcut per stage, and what it no longer spends on sums it spends on earlier layers (a shorter second forward).
+    # walks the stage's chain in registers (fq_hist2048_chain_seg: S_k = y_k + relu(S_(k-1))) -- the cache then holds conv3's outputs
+    # and one shortcut per stage, and what it no longer spends on sums it spends on earlier layers (a shorter second forward).
     pair_chain = os.environ.get("FQ_PAIR_CHAIN", "1") != "0"
 
     def __init__(self, model):
@@ -371,11 +371,11 @@ class Quantity(_FusedForward, _FileInputs):
         """What pass 1 keeps of the forward that just ran: the hooked tensors named in `keep` (None: all) -- with every sum that
         was not written replaced by its pair, ("pair", sum key) -> (key of conv3's output, that tensor, the shortcut tensor or None,
         the shortcut's version, whether conv3's output is itself among the kept tensors, src).  A shortcut that is the ReLU output
-        of an earlier sum of this very entry (src = that sum's key) is not kept at all: pass 2 re-makes it from that sum's pair
-        (fq_hist2048_pair_seg's relu_out), so a chain of identity blocks holds one shortcut, its head's.
+        of an earlier sum of this very entry (src = that sum's key) is not kept at all: pass 2 walks the chain in registers
+        (fq_hist2048_chain_seg), so a stage of identity blocks holds one shortcut, its head's.
         Returns (entry, bytes it holds on to)."""
         pairs = self._hook_ctl.pairs
-        entry, held, nbytes = {}, set(), 0
+        entry, held, nbytes, chain_len = {}, set(), 0, {}
 
         def hold(t):
             if id(t) not in held:
@@ -394,50 +394,44 @@ class Quantity(_FusedForward, _FileInputs):
             # (the forward that ran before the plan existed may have left a sum to its pair whose conv3 output the plan does not
             #  keep: that one batch then holds the tensor privately, and pass 2 counts it where the prefix forward re-makes it)
             y_kept = keep is None or conv_key in keep
-            chained = src is not None and self.pair_chain and ("pair", src) in entry
+            chained = (src is not None and self.pair_chain and ("pair", src) in entry and chain_len.get(src, 0) < _native.CHAIN_MAX
+                       and other.shape == named_feats[conv_key].shape == entry[("pair", src)][1].shape)
+            chain_len[n] = chain_len[src] + 1 if chained else 1
             entry[("pair", n)] = (conv_key, named_feats[conv_key], None if chained else other, version, y_kept, src if chained else None)
             nbytes += hold(named_feats[conv_key]) + (0 if chained else hold(other))
         return entry, nbytes
 
     def _add_with_pairs(self, collector):
         """collector.add_to_distributions for dicts that may hold pairs (see _cache_entry): the pairs go through
-        add_pairs_to_distributions, which also counts conv3's output -- that tensor then leaves the plain list.  Chained pairs run
-        level by level: a level's launch writes the ReLU outputs the next level's pairs add as their shortcut."""
+        add_pairs_to_distributions, which also counts conv3's output -- that tensor then leaves the plain list; pairs chained on
+        each other's ReLU output (a stage of identity blocks) go through add_chains_to_distributions, one launch per chain."""
         def add(feats):
             pairs = [(k[1], v) for k, v in feats.items() if isinstance(k, tuple)]
             if not pairs:
                 return collector.add_to_distributions(feats)
             plain = dict((k, v) for k, v in feats.items() if not isinstance(k, tuple))
-            wanted = set(v[5] for _k, v in pairs if v[5] is not None)          # sums whose ReLU a later pair adds
-            depth, levels = {}, []
-            for sum_key, v in pairs:                                          # (forward order)
+            chains, chain_of = [], {}                                         # [(head, [(y, row of y, row of sum), ...])]
+            for sum_key, v in pairs:                                          # (forward order: a sum's src comes before it)
                 conv_key, y, other, version, y_kept, src = v
+                if y_kept and plain.pop(conv_key, None) is None:
+                    raise RuntimeError("pass 2 holds the pair of %s without %s" % (sum_key, conv_key))
+                block = (y, conv_key if y_kept else None, sum_key)
                 if src is None:
                     if other._version != version:
                         raise RuntimeError("the shortcut of %s was written to after the add that pass 1 left to pass 2; set "
                                            "Quantity.pair_hist = False (FQ_PAIR_HIST=0)" % sum_key)
-                    depth[sum_key] = 0
+                    chain_of[sum_key] = len(chains)
+                    chains.append((other, [block]))
                 else:
-                    if src not in depth:
+                    if src not in chain_of or chains[chain_of[src]][1][-1][2] != src:
                         raise RuntimeError("pass 2 holds the pair of %s without the pair of %s it is chained to" % (sum_key, src))
-                    depth[sum_key] = depth[src] + 1
-                if y_kept and plain.pop(conv_key, None) is None:
-                    raise RuntimeError("pass 2 holds the pair of %s without %s" % (sum_key, conv_key))
-                while len(levels) <= depth[sum_key]:
-                    levels.append([])
-                levels[depth[sum_key]].append((sum_key, v))
+                    chain_of[sum_key] = chain_of[src]
+                    chains[chain_of[src]][1].append(block)
             if plain:
                 collector.add_to_distributions(plain)
-            made = {}
-            for jobs_of_level in levels:
-                jobs = []
-                for sum_key, (conv_key, y, other, _version, y_kept, src) in jobs_of_level:
-                    b = other if src is None else made.pop(src)
-                    r = torch.empty_like(y) if sum_key in wanted else None
-                    if r is not None:
-                        made[sum_key] = r
-                    jobs.append((y, b, conv_key if y_kept else None, sum_key, r))
-                collector.add_pairs_to_distributions(jobs)
+            # single blocks go out together in one launch, a stage's chain in one launch of its own
+            collector.add_pairs_to_distributions([(b[0][0], head, b[0][1], b[0][2]) for head, b in chains if len(b) == 1])
+            collector.add_chains_to_distributions([c for c in chains if len(c[1]) > 1])
         add.__name__ = "add_to_distributions"
         add.__self__ = collector
         return add
@@ -530,13 +524,20 @@ class Quantity(_FusedForward, _FileInputs):
         pair_info = dict(self._hook_ctl.pairs) if self.pair_hist else {}
         hooked = set(id(t) for t in feats.values())
         refund = {}                                              # conv3 key of the src pair -> bytes given back when it is kept
+        depth = {}
+
+        def depth_of(n):                                         # position of a sum in its stage's chain (the kernel takes 6 blocks)
+            if n not in depth:
+                src = pair_info[n][3]
+                depth[n] = depth_of(src) + 1 if src is not None and src in pair_info else 0
+            return depth[n]
         for n, o, b in sorted(sizes, key=lambda e: -e[1]):       # deepest first
             cost = b
             p = pair_info.get(n)
             if p is not None:
                 conv_key, other, _version, src = p
                 cost = 0 if id(other) in hooked else other.numel() * other.element_size()
-                if cost and src is not None and self.pair_chain and src in pair_info:
+                if cost and src is not None and self.pair_chain and src in pair_info and depth_of(n) % _native.CHAIN_MAX:
                     refund[pair_info[src][0]] = refund.get(pair_info[src][0], 0) + cost
             if n == "image" or used + cost > room:
                 break

@@ -407,3 +407,55 @@ def test_pair_histogram_counts_a_tensor_and_a_sum_like_the_two_stored_tensors(or
     # a misaligned operand is refused (the caller then materialises the sum)
     with pytest.raises(nat.FqError):
         nat.hist2048_pair_seg([a[2][1:]], [b[2][1:]], [0], [1], iv, hist)
+
+
+def test_chain_histogram_walks_a_stage_of_residual_blocks_like_the_stored_tensors(oracle):
+    """fq_hist2048_chain_seg: S_1 = y_1 + head, S_k = y_k + relu(S_(k-1)); every y_k and every S_k counted exactly as fq_hist2048_seg
+    counts the stored tensors (the sums made by torch.add / torch.relu), chain lengths 1 .. 6, ragged sizes, exact zeros, NaN,
+    values beyond the last bin, a row of y not wanted, existing counts preserved, one interval outside the fast quotient's range
+    (the whole chain then takes the IEEE divide), and the first sum against the oracle."""
+    from common.quantity import _native as nat
+    g = torch.Generator(device="cuda").manual_seed(78)
+    rows = 40
+    iv = torch.rand(rows, generator=g, device="cuda") * 0.01 + 0.002
+    hist = torch.zeros(rows, 2048, dtype=torch.int64, device="cuda")
+    hist[:, 9] = 2
+    want = hist.clone()
+    chains, plain_t, plain_r, row = [], [], [], 0
+    for L, n in ((1, 1001), (2, 3), (3, 65536 + 5), (4, 2 * 1048576 + 3), (6, 802816 * 4), (5, 70001)):
+        head = torch.randn(n, generator=g, device="cuda")
+        ys = [torch.randn(n, generator=g, device="cuda") * (0.5 + 0.3 * k) for k in range(L)]
+        head[::13] = 0.0
+        for y in ys:
+            y[::7] = 0.0
+        if n > 100:
+            ys[0][5:40] = -head[5:40]                                  # S_1 exactly zero there
+            ys[-1][50] = 1e9
+            ys[0][60] = float("nan")
+        rows_y = [row + 2 * k for k in range(L)]
+        rows_s = [row + 2 * k + 1 for k in range(L)]
+        if L == 3:
+            rows_y[1] = None
+        row += 2 * L
+        chains.append((head, ys, rows_y, rows_s))
+        o = head
+        for k in range(L):
+            s_ = torch.add(ys[k], o)
+            if rows_y[k] is not None:
+                plain_t.append(ys[k])
+                plain_r.append(rows_y[k])
+            plain_t.append(s_)
+            plain_r.append(rows_s[k])
+            o = torch.relu(s_)
+    assert row <= rows
+    iv[chains[3][3][1]] = 1e-30                                        # chain of 4: outside the fast quotient's range
+    nat.hist2048_chain_seg(chains, iv, hist)
+    nat.hist2048_seg(plain_t, plain_r, iv, want)
+    assert torch.equal(hist, want)
+    head, ys, _ry, rs_ = chains[2]
+    ref = np.zeros(2048, dtype=np.int64)
+    ref[9] = 2
+    oracle.hist2048((ys[0] + head).cpu().numpy(), np.float32(iv[rs_[0]].item()), ref)
+    assert np.array_equal(hist[rs_[0]].cpu().numpy(), ref)
+    with pytest.raises(nat.FqError):                                   # misaligned: refused
+        nat.hist2048_chain_seg([(head[1:], [ys[0][1:]], [0], [1])], iv, hist)

@@ -100,23 +100,51 @@ def test_gpu_calibration_with_interval_num_1024_equals_the_oracle_engine_on_the_
     from model.resnet.ResNet_18_fabu import ResNet18
     from tools import Quantity
     from workdir_util import product_workdir
+    from common.quantity import Quantizer
     seen = {}
 
+    class SpyQuantizer(Quantizer):                       # what the KL search is handed (merge groups already pooled)
+        def quantize(self, distributions, distribution_intervals):
+            seen["hist"] = distributions.cpu().numpy().copy()
+            seen["iv"] = dict(distribution_intervals)
+            return super().quantize(distributions, distribution_intervals)
+
     class Spy(Quantity):
-        def _calibrate(self, *a, **k):
-            bits = super()._calibrate(*a, **k)
-            seen["hist"] = self._collector.hist_device.cpu().numpy().copy()
-            seen["iv"] = dict(self._collector._distribution_intervals)
-            return bits
+        quantizer_cls = SpyQuantizer
 
     with product_workdir(device="gpu", max_cali_img_num=1, interval_num=1024) as tmp:
         model = merge_bn(cases.seed_model(ResNet18()).eval()).cuda()
         q = Spy(model)
         bits = q.activation_quantize(cases.calib_batches(2, (4, 3, 32, 32)))
         assert seen["hist"].shape == (30, 1024) and q.timings["fused_hist_launches"] == 0
+        assert type(q._collector).__module__ == "common.quantity.distribution_collector" and q._collector.hist_device.shape == (30, 1024)
         names = ["image"] + list(q.net_info.keys())
         oq = OracleQuantizer(names, worker_num=1)
         oq.quantize({n: seen["hist"][i] for i, n in enumerate(names)}, seen["iv"])
-        # (bit tying of merge groups happens after the search: compare the raw thresholds)
+        # (bit tying of merge groups happens after the search: compare the raw thresholds and the bits the search itself found)
         assert {n: int(q._quantizer.threshold_bins[n]) for n in names} == {n: int(oq.threshold_bins[n]) for n in names}
         assert all(int(seen["hist"][i].sum()) > 0 for i in range(30)) and len(bits) == 30
+        # ... and every histogram row is the oracle's 1024-bin histogram of the very tensors: a second calibration of the same
+        # batches with every tensor materialised, taped and replayed through the oracle
+        taped = {}
+
+        class TapeCollector(DistributionCollector):
+            def add_to_distributions(self, tensors):
+                for k, v in tensors.items():
+                    taped.setdefault(k, []).append(v.detach().cpu().numpy().copy())
+                super().add_to_distributions(tensors)
+
+        class TapeQuantity(Quantity):
+            collector_cls = TapeCollector
+            fuse_bias_absmax = False
+            fuse_relu = False
+
+        q2 = TapeQuantity(model)
+        q2.activation_quantize(cases.calib_batches(2, (4, 3, 32, 32)))
+        got = q2._collector.hist_device.cpu().numpy()
+        ivs = q2._collector._distribution_intervals
+        for i, n in enumerate(names):
+            ref = np.zeros(1024, dtype=np.int64)
+            for x in taped[n]:
+                oracle.hist2048(x, np.float32(ivs[n]), ref)
+            np.testing.assert_array_equal(got[i], ref, err_msg=n)
