@@ -416,7 +416,7 @@ def test_chain_histogram_walks_a_stage_of_residual_blocks_like_the_stored_tensor
     (the whole chain then takes the IEEE divide), and the first sum against the oracle."""
     from common.quantity import _native as nat
     g = torch.Generator(device="cuda").manual_seed(78)
-    rows = 40
+    rows = 48
     iv = torch.rand(rows, generator=g, device="cuda") * 0.01 + 0.002
     hist = torch.zeros(rows, 2048, dtype=torch.int64, device="cuda")
     hist[:, 9] = 2
