@@ -136,6 +136,8 @@ def run_cache(n, seed, log=print, odd=False, share=False, bn=False):
                 c = calibrate(model, size, batches, cache_gb=gb, plan=plan)
                 kind = (c[4].get("cache_plan") or {}).get("kind")
                 plans[(kind, c[4].get("cache_bytes", 0) > 0)] = plans.get((kind, c[4].get("cache_bytes", 0) > 0), 0) + 1
+                # (sums pass 1 left to pass 2's pair / chain kernels -- Quantity.pair_hist, pair_chain: only a cache makes them)
+                plans["sums_left_to_pairs"] = plans.get("sums_left_to_pairs", 0) + int(c[4].get("sums_left_to_pass2_pairs", 0) or 0)
                 if c[3] != base[3] or c[1] != base[1] or not torch.equal(c[2], base[2]):
                     rows = [k for r, k in enumerate(base[5]) if not torch.equal(c[2][r], base[2][r]) or c[1][k] != base[1][k]]
                     problems.append("cache %s GB plan %s (%s, %d bytes kept): rows %s differ" % (gb, plan, c[4].get("cache_plan"), c[4].get("cache_bytes", 0), rows[:5]))
