@@ -73,8 +73,11 @@ def test_bench_recon_section_helpers_keep_two_ranks_in_step(tmp_path):
     (["--steps", "20", "--warmup", "5"], 5120, 256, "weak"),        # the driver's command: same 5 120 images
     (["--steps", "40"], 5120, 128, "weak"),                         # --steps only cuts the same images differently
     (["--steps", "10", "--images", "1000"], 1000, 100, "weak"),
-    (["--gpus", "8", "--total-images", "50000"], 6260, 313, "strong"),      # config 4: 50 000 / 8 = 6 250 -> 313 x 20
+    # config 4 (strong scaling): the batch stays 256 at every N; ceil(50 000 / 256) = 196 batches, the busiest of 8 ranks owns 25
+    (["--gpus", "8", "--total-images", "50000"], 6400, 256, "strong"),
+    (["--gpus", "1", "--total-images", "50000", "--steps", "20"], 50176, 256, "strong"),      # the N = 1 leg: --steps is derived
     (["--gpus", "2", "--total-images", "1024", "--steps", "2"], 512, 256, "strong"),
+    (["--gpus", "8", "--total-images", "1024", "--batch", "64"], 128, 64, "strong"),
     (["--batch", "64", "--steps", "4"], 256, 64, "weak"),
 ])
 def test_bench_workload_arithmetic(monkeypatch, argv, per_gpu, batch, scaling):
