@@ -232,6 +232,15 @@ def _seg_bytes(a, k):
     return 4.0 * sum(int(t.numel()) for t in a[0])
 
 
+def _chain_bytes(a, k):             # hist2048_chain_seg(chains, ...): every chain reads its head and its L conv3 outputs once
+    return 4.0 * sum(int(head.numel()) * (1 + len(ys)) for head, ys, _ry, _rs in a[0])
+
+
+def _pair_bytes(a, k):              # hist2048_pair_seg(a_tensors, b_tensors, ...): both operands once (+ the ReLU output when asked for)
+    relus = a[6] if len(a) > 6 else k.get("relu_outs")
+    return 4.0 * sum(int(t.numel()) * (2 + (1 if relus is not None and relus[i] is not None else 0)) for i, t in enumerate(a[0]))
+
+
 def _bias_add_bytes(a, k):          # y += bias[c] in place (4 B read + 4 B written) (+ 4 B for the fused ReLU's copy)
     relu = k.get("relu_out") if "relu_out" in k else (a[4] if len(a) > 4 else None)
     return (8.0 + (4.0 if relu is not None else 0.0)) * int(a[0].numel())
@@ -789,8 +798,9 @@ def main():
     q.profile_phases = True
     cache_budget = q._activation_cache_budget()            # per rank: every rank budgets its own GPU's pool
     hist_calls_before = hist_calls[0]
-    with CallTimer(_native, "hist2048_seg", _seg_bytes) as kt_hist:
-        kt_hist.enabled = True
+    with CallTimer(_native, "hist2048_seg", _seg_bytes) as kt_hist, CallTimer(_native, "hist2048_chain_seg", _chain_bytes) as kt_chain, \
+            CallTimer(_native, "hist2048_pair_seg", _pair_bytes) as kt_pair:
+        kt_hist.enabled = kt_chain.enabled = kt_pair.enabled = True
         barrier()
         t0 = time.perf_counter()
         q.activation_quantize(data)
@@ -884,6 +894,16 @@ def main():
         # start order (a call is one dispatch per 96 segments; ResNet-50 has 71)
         result["roofline"]["trace_slice"] = {"kernel": "hist2048_seg_kernel", "first": hist_calls_before,
                                              "count": hist_calls[0] - hist_calls_before}
+
+    # the residual stages' histograms of pass 2 (round 6): conv3 outputs and sums counted from (head, y_1 .. y_L) without any sum in HBM
+    for key, kt, kernel, note in (
+            ("roofline_hist_chain", kt_chain, "hist2048_chain_kernel<L>",
+             "pass 2, one call per batch = one launch per residual stage (L = 3 / 4 / 6 / 3 blocks for ResNet-50): reads the stage's first "
+             "shortcut and its L conv3 outputs once, counts 2 L rows, writes nothing; (L + 1) x 4 B per position"),
+            ("roofline_hist_pair", kt_pair, "hist2048_pair_seg_kernel", "pass 2: a conv3 output and its sum from the pair (single blocks)")):
+        sm = kt.summary()
+        if sm:
+            result[key] = hbm_roofline(kernel, sm, {"note": note, "launches_are": "calls of the entry point (a chain call launches one kernel per chain)"})
 
     # ---- the same calibration with the float 1x1 layers on the split-bf16 kernels (FQ_CONV_SPLIT_BF16=1: every fp32 operand as three
     # bf16 pieces, six of the nine products on the bf16 matrix cores, fp32 accumulation -- as accurate as the fp32 fma chain, DESIGN.md
