@@ -61,6 +61,37 @@ def timed_hist_launches():
 
 timed_hist_launches()
 
+
+# ---- HBM traffic of exactly those launches: the PMC passes' own bench line (bench_line_pmc.json) says which dispatches of the
+# kernel its timed region was; FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md), KB -> bytes
+def timed_hist_traffic():
+    import json
+    path = os.path.join(out, "bench_line_pmc.json")
+    if not os.path.isfile(path):
+        return
+    cand = [ln for ln in open(path).read().split("\n") if ln.startswith("{")]
+    line = json.loads(cand[-1]) if cand else None
+    if not line or "trace_slice" not in line.get("roofline", {}):
+        return
+    sl, alg = line["roofline"]["trace_slice"], line["roofline"]["algorithmic_bytes_per_launch"]
+    means = {}
+    for counter, tag in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+        per = {}
+        for r in rows(tag + "/**/*counter_collection.csv"):
+            if sl["kernel"] in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter:
+                per[int(r["Dispatch_Id"])] = per.get(int(r["Dispatch_Id"]), 0.0) + float(r["Counter_Value"])
+        ids = sorted(per)[sl["first"]:sl["first"] + sl["count"]]
+        if len(ids) != sl["count"]:
+            print("== %s: %d dispatches of %s in the counter pass, the slice wants %d ==" % (counter, len(per), sl["kernel"], sl["count"]))
+            return
+        means[counter] = sum(per[i] for i in ids) / len(ids)
+    hbm = means["FETCH_SIZE"] * 2 * 1024 + means["WRITE_SIZE"] * 1024
+    print("== HBM traffic of the %d timed launches of %s (separate --pmc passes): FETCH_SIZE %.1f KB x 2 + WRITE_SIZE %.1f KB = %.0f bytes "
+          "per launch against %.0f algorithmic: ratio %.4f ==" % (sl["count"], sl["kernel"], means["FETCH_SIZE"], means["WRITE_SIZE"], hbm, alg, hbm / alg))
+
+
+timed_hist_traffic()
+
 print("== kernel stats (fq:: kernels and top 8 overall) ==")
 stats = list(rows("trace/**/*kernel_stats.csv"))
 for i, r in enumerate(stats):

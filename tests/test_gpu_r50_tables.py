@@ -482,3 +482,38 @@ def test_r50_weight_tables_equal_the_reference(g4r50):
     assert got["weight_table"] == tables["weight_table"]
     for d in ("weight", "bias", "new_weight", "new_bias"):
         assert got[d] == tables["files"][d], d
+
+
+def test_r50_at_the_batch_the_bench_times_every_fusion_and_the_cache_change_no_histogram(monkeypatch):
+    """The configuration bench.py times -- ResNet-50, 256 images per batch, a cache that keeps the deep tensors of every batch, every
+    producer fusion, the residual sums left to pass 2's chain kernel -- against the plainest path the engine has on the same
+    batches: no cache (every image through the network twice), no proof-based fusion, no pair / chain histograms.  All 71 maxima
+    and all 71 x 2048 bins must be equal (the own convolutions are deterministic, so 'equal' means bit for bit), and so must
+    the table.  Three batches: the third runs pass 1 with every module checked and every fusion active."""
+    from tools import Quantity
+    from common.quantity import merge_bn
+    from model.resnet.ResNet_fabu import ResNet50
+    model = merge_bn(cases.seed_model(ResNet50(), gamma_scale=0.5).eval()).cuda()
+    g = torch.Generator(device="cuda").manual_seed(4321)
+    batches = [(torch.randn(256, 3, 224, 224, generator=g, device="cuda"), None) for _ in range(3)]
+
+    def run(cache_gb, plan, **switches):
+        monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
+        monkeypatch.setenv("FQ_CACHE_PLAN", plan)
+        with product_workdir(input_shape="1,3,224,224", device="gpu", max_cali_img_num=2) as tmp:
+            q = Quantity(model)
+            for k, v in switches.items():
+                setattr(q, k, v)
+            q.activation_quantize(batches)
+            return (open(os.path.join(tmp, "test", "workdir", "feat.table")).read(), q._collector.max_device.clone(),
+                    q._collector.hist_device.clone(), dict(q.timings))
+    plain = run("0", "", fuse_conv_add=False, skip_unread_outputs=False, pair_hist=False, fuse_hist=False)
+    fused = run("24", "B")                               # 8 GB per batch: the deep half of the network is kept, as in the bench
+    assert fused[3]["cache_plan"]["kind"] == "B" and fused[3]["cache_bytes"] > 10e9
+    assert fused[3]["sums_left_to_pass2_pairs"] >= 16 and fused[3]["conv_add_launches"] >= 16 * 2
+    assert plain[3]["cache_bytes"] == 0 and plain[3]["sums_left_to_pass2_pairs"] == 0 and plain[3]["conv_add_launches"] == 0
+    assert torch.equal(fused[1], plain[1])
+    assert torch.equal(fused[2], plain[2])
+    assert fused[0] == plain[0] and len(fused[0].strip().split("\n")) == 71
+    whole = run("60", "A")                               # whole batches kept: every sum of every batch goes through the chains
+    assert whole[3]["cache_plan"]["kind"] == "A" and torch.equal(whole[2], plain[2]) and torch.equal(whole[1], plain[1])
