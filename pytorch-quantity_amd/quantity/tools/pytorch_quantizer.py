@@ -484,9 +484,10 @@ class Quantity(_FusedForward, _FileInputs):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             fn(feats)
-        for t in feats.values():
-            if torch.is_tensor(t) and t.is_cuda:
-                t.record_stream(side)          # the allocator must not recycle it while the side stream reads
+        for v in feats.values():
+            for t in (v if isinstance(v, tuple) else (v,)):          # (a pair entry holds its tensors in a tuple)
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(side)      # the allocator must not recycle it while the side stream reads
 
     def _join_stat_stream(self):
         side = getattr(self, "_side_stream", None)
