@@ -853,6 +853,9 @@ def main():
                    "int8_sim_images_per_forward": args.int8_batch},
         "phases_s": {k: (round(v, 4) if isinstance(v, float) else v) for k, v in timings.items()},
         "expected_own_conv_launches": expected_own, "own_conv_launches": got_own,
+        # what the calibration wrote (rank 0): integer sums and maxima are order independent, so the SAME job run on any number of
+        # ranks must give the same digest -- bench.py --total-images T at N = 1 and N = 8 are comparable by this field
+        "feat_table_sha256": __import__("hashlib").sha256(feat_table.encode()).hexdigest() if rank == 0 else None,
         "own_conv_launches_note": "rank 0, pass 1: %d nn.Conv2d x %d owned batches must all have run on the own fp32-MFMA kernels "
                                   "(phases_s.own_conv1x1_launches + phases_s.conv_add_launches); every rank checks its own count and "
                                   "the bench exits 3 when any rank falls short" % (n_convs, n_owned),
