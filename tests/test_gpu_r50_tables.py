@@ -517,3 +517,47 @@ def test_r50_at_the_batch_the_bench_times_every_fusion_and_the_cache_change_no_h
     assert fused[0] == plain[0] and len(fused[0].strip().split("\n")) == 71
     whole = run("60", "A")                               # whole batches kept: every sum of every batch goes through the chains
     assert whole[3]["cache_plan"]["kind"] == "A" and torch.equal(whole[2], plain[2]) and torch.equal(whole[1], plain[1])
+
+
+def test_r101_chains_longer_than_the_kernel_takes_are_cut_and_change_no_histogram(monkeypatch):
+    """ResNet-101's third stage is 23 bottlenecks: 22 identity blocks chained on each other's ReLU output.  fq_hist2048_chain_seg
+    takes 6 blocks per launch, so the cache keeps a shortcut at every sixth block and pass 2 walks chains of 6, 6, 6, 5 (and the
+    cache plan counts exactly those shortcuts).  Every maximum, histogram and table line equals the plain path's."""
+    from tools import Quantity
+    from common.quantity import merge_bn, _native
+    from model.resnet.ResNet_fabu import ResNet101
+    model = merge_bn(cases.seed_model(ResNet101(), gamma_scale=0.5).eval()).cuda()
+    g = torch.Generator(device="cuda").manual_seed(101)
+    batches = [(torch.randn(32, 3, 224, 224, generator=g, device="cuda"), None) for _ in range(3)]
+    chains = []
+    real = _native.hist2048_chain_seg
+
+    def spy(chains_, *a, **k):
+        chains.extend(len(c[1]) for c in chains_)
+        return real(chains_, *a, **k)
+    monkeypatch.setattr(_native, "hist2048_chain_seg", spy)
+
+    def run(cache_gb, plan, **switches):
+        monkeypatch.setenv("FQ_ACT_CACHE_GB", cache_gb)
+        monkeypatch.setenv("FQ_CACHE_PLAN", plan)
+        with product_workdir(input_shape="1,3,224,224", device="gpu", max_cali_img_num=2) as tmp:
+            q = Quantity(model)
+            for k, v in switches.items():
+                setattr(q, k, v)
+            q.activation_quantize(batches)
+            return (open(os.path.join(tmp, "test", "workdir", "feat.table")).read(), q._collector.max_device.clone(),
+                    q._collector.hist_device.clone(), dict(q.timings))
+    plain = run("0", "", fuse_conv_add=False, skip_unread_outputs=False, pair_hist=False, fuse_hist=False)
+    assert not chains
+    whole = run("16", "A")                               # 3.2 GB per batch: every batch kept whole
+    assert whole[3]["cache_plan"]["kind"] == "A" and whole[3]["sums_left_to_pass2_pairs"] >= 33 * 2
+    assert torch.equal(whole[1], plain[1]) and torch.equal(whole[2], plain[2]) and whole[0] == plain[0]
+    assert len(whole[0].strip().split("\n")) == 139
+    # per batch: stage 1 (3 blocks), stage 2 (4), stage 3 (23 = 6 + 6 + 6 + 5), stage 4 (3)
+    per_batch = sorted(chains[:7])
+    assert per_batch == [3, 3, 4, 5, 6, 6, 6], chains[:14]
+    chains.clear()
+    part = run("4", "B")                                 # the deep suffix of every batch: the first chain starts mid-stage
+    assert part[3]["cache_plan"]["kind"] == "B" and part[3]["sums_left_to_pass2_pairs"] > 0 and chains
+    assert torch.equal(part[1], plain[1]) and torch.equal(part[2], plain[2]) and part[0] == plain[0]
+    assert part[3]["cache_bytes"] <= 4 * 2 ** 30 + 64 * 2 ** 20          # the plan's own account of the shortcuts it keeps holds
