@@ -1297,10 +1297,11 @@ def main():
 
     # ---- per-channel rows (extension; BASELINE configs[1] words the workload "per-channel"): same two passes with
     # one histogram row per (tensor, channel), read in place by fq_absmax_chan / fq_hist2048_chan, then the KL sweep of
-    # all 42 667 rows -- on 1 024 images (the sweep is a fixed cost per row set)
+    # all 42 667 rows -- on the WHOLE workload (config 2's 5 120 images; up to round 5: 1 024 of them, where the sweep's fixed 47 ms
+    # was a third of the time); strong-scaling jobs keep to 20 batches
     if world == 1 and not args.no_per_channel:
         try:
-            n_pc = max(1, min(K, 1024 // B if B <= 1024 else 1))
+            n_pc = max(1, min(K, 20))
             pc_data = [(b, 0) for b in data.owned()[:n_pc]]
             make_workdir(len(pc_data) - 1, shape, dev_index)
             pq = Quantity(model)
