@@ -377,9 +377,9 @@ class Quantity(_FusedForward, _FileInputs):
         pairs = self._hook_ctl.pairs
         entry, held, nbytes, chain_len = {}, set(), 0, {}
 
-        def hold(t):
-            if id(t) not in held:
-                held.add(id(t))
+        def hold(t):                                       # (by address: the hooks keep detach() aliases of the model's tensors)
+            if t.data_ptr() not in held:
+                held.add(t.data_ptr())
                 return t.numel() * t.element_size()
             return 0
         for n, t in named_feats.items():                   # (forward order: a sum's src comes before it)
@@ -523,7 +523,7 @@ class Quantity(_FusedForward, _FileInputs):
         # such sum (pair_chain) the cost is given back as soon as that earlier block's conv3 output joins the suffix, because
         # pass 2 then re-makes the shortcut instead of reading a kept one.
         pair_info = dict(self._hook_ctl.pairs) if self.pair_hist else {}
-        hooked = set(id(t) for t in feats.values())
+        hooked = set(t.data_ptr() for t in feats.values())       # (by address: feats holds detach() aliases of the model's tensors)
         refund = {}                                              # conv3 key of the src pair -> bytes given back when it is kept
         depth = {}
 
@@ -537,7 +537,7 @@ class Quantity(_FusedForward, _FileInputs):
             p = pair_info.get(n)
             if p is not None:
                 conv_key, other, _version, src = p
-                cost = 0 if id(other) in hooked else other.numel() * other.element_size()
+                cost = 0 if other.data_ptr() in hooked else other.numel() * other.element_size()
                 if cost and src is not None and self.pair_chain and src in pair_info and depth_of(n) % _native.CHAIN_MAX:
                     refund[pair_info[src][0]] = refund.get(pair_info[src][0], 0) + cost
             if n == "image" or used + cost > room:
