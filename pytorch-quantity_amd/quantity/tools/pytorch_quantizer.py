@@ -375,7 +375,7 @@ class Quantity(_FusedForward, _FileInputs):
         (fq_hist2048_chain_seg), so a stage of identity blocks holds one shortcut, its head's.
         Returns (entry, bytes it holds on to)."""
         pairs = self._hook_ctl.pairs
-        entry, held, nbytes, chain_len = {}, set(), 0, {}
+        entry, held, nbytes, chain_len, continued = {}, set(), 0, {}, set()
 
         def hold(t):                                       # (by address: the hooks keep detach() aliases of the model's tensors)
             if t.data_ptr() not in held:
@@ -394,9 +394,14 @@ class Quantity(_FusedForward, _FileInputs):
             # (the forward that ran before the plan existed may have left a sum to its pair whose conv3 output the plan does not
             #  keep: that one batch then holds the tensor privately, and pass 2 counts it where the prefix forward re-makes it)
             y_kept = keep is None or conv_key in keep
+            # (a chain is linear: when one sum's ReLU output is the shortcut of two later blocks, the first of them continues the
+            #  chain and the second keeps its shortcut as a tensor)
             chained = (src is not None and self.pair_chain and ("pair", src) in entry and chain_len.get(src, 0) < _native.CHAIN_MAX
+                       and src not in continued
                        and other.shape == named_feats[conv_key].shape == entry[("pair", src)][1].shape)
             chain_len[n] = chain_len[src] + 1 if chained else 1
+            if chained:
+                continued.add(src)
             entry[("pair", n)] = (conv_key, named_feats[conv_key], None if chained else other, version, y_kept, src if chained else None)
             nbytes += hold(named_feats[conv_key]) + (0 if chained else hold(other))
         return entry, nbytes

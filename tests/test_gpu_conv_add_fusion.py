@@ -384,3 +384,45 @@ def test_an_input_written_in_place_before_the_eltwise_is_refused():
                 q.activation_quantize(cases.calib_batches(3, (8, 3, 64, 64), seed=91))
         finally:
             del model.b1.forward
+
+
+def test_a_relu_output_that_is_the_shortcut_of_two_later_blocks(monkeypatch):
+    """A chain is linear.  Here block 1's ReLU output is the shortcut of block 2 AND of block 3 (a skip over two blocks): block 2
+    continues block 1's chain, block 3 keeps its shortcut as a tensor (a single pair) -- and every statistic equals the unfused
+    run's."""
+    from torch import nn
+    from common.quantity import Eltwise, View
+
+    class Body(nn.Module):
+        def __init__(self, cin, mid, cout):
+            super().__init__()
+            self.c1, self.r1 = nn.Conv2d(cin, mid, 1), nn.ReLU()
+            self.c2, self.r2 = nn.Conv2d(mid, mid, 3, padding=1), nn.ReLU()
+            self.c3 = nn.Conv2d(mid, cout, 1)
+            self.add, self.r3 = Eltwise(), nn.ReLU()
+
+        def forward(self, x, shortcut):
+            return self.r3(self.add(self.c3(self.r2(self.c2(self.r1(self.c1(x))))), shortcut))
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.stem, self.relu0 = nn.Conv2d(3, 32, 3, padding=1), nn.ReLU()
+            self.down = nn.Conv2d(32, 128, 1)
+            self.b1, self.b2, self.b3 = Body(32, 16, 128), Body(128, 32, 128), Body(128, 32, 128)
+            self.pool, self.view, self.fc = nn.AvgPool2d(32), View(), nn.Linear(128, 10)
+
+        def forward(self, x):
+            x0 = self.relu0(self.stem(x))
+            x1 = self.b1(x0, self.down(x0))
+            x2 = self.b2(x1, x1)
+            x3 = self.b3(x2, x1)                                   # the shortcut from two blocks back
+            return self.fc(self.view(self.pool(x3)))
+
+    model = cases.seed_model(Net(), base_seed=8).eval().cuda()
+    want = _calibrate(model, False, "1", "A", monkeypatch=monkeypatch, hw=32)
+    got = _calibrate(model, True, "1", "A", monkeypatch=monkeypatch, hw=32, pair=True, chain=True)
+    assert got[4]["conv_add_chains_proven"] == 3 and got[4]["sums_left_to_pass2_pairs"] >= 3 * 4
+    assert got[1] == want[1] and got[2] == want[2] and torch.equal(got[3], want[3])
+    part = _calibrate(model, True, "0.02", "B", monkeypatch=monkeypatch, hw=32, pair=True, chain=True)
+    assert part[1] == want[1] and part[2] == want[2] and torch.equal(part[3], want[3])
