@@ -856,6 +856,10 @@ def main():
         # what the calibration wrote (rank 0): integer sums and maxima are order independent, so the SAME job run on any number of
         # ranks must give the same digest -- bench.py --total-images T at N = 1 and N = 8 are comparable by this field
         "feat_table_sha256": __import__("hashlib").sha256(feat_table.encode()).hexdigest() if rank == 0 else None,
+        # ... and what the table was made from: the 71 maxima and the 71 x 2048 histogram counts every rank holds after the two
+        # all-reduces (the table's bits are a coarse function of them; this digest moves with a single count)
+        "statistics_sha256": __import__("hashlib").sha256(q._collector.max_device.cpu().numpy().tobytes()
+                                                          + q._collector.hist_device.cpu().numpy().tobytes()).hexdigest(),
         "own_conv_launches_note": "rank 0, pass 1: %d nn.Conv2d x %d owned batches must all have run on the own fp32-MFMA kernels "
                                   "(phases_s.own_conv1x1_launches + phases_s.conv_add_launches); every rank checks its own count and "
                                   "the bench exits 3 when any rank falls short" % (n_convs, n_owned),
