@@ -349,6 +349,7 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_pair_seg_kernel(const Pai
 // 16 KB per block of the chain), 512 threads, as many workgroups per CU as that leaves room for, each with an equal run of 16 KB
 // chunks; the 16-byte loads of all L + 1 streams of two vectors are in flight together.
 constexpr int kChainBlock = 512;
+constexpr int kChainMinChunks = 4;      // chunks (16 KB of every stream) per workgroup at least: amortises zeroing + flushing 2 L x 2048 bins
 template <int L>
 struct ChainArgs {
     const float* head;
@@ -923,9 +924,14 @@ static int launch_chain(const fq_chain_seg& c, const float* interval, int64_t* h
     int per_cu = (int)((size_t)150 * 1024 / lds);                 // 160 KB of LDS per CU, some of it the runtime's
     if (per_cu > 3) per_cu = 3;
     if (per_cu < 1) per_cu = 1;
+    // FQ_CHAIN_WG_PER_CU / FQ_CHAIN_MIN_CHUNKS: tuning knobs (scripts/chain_hist_probe.py)
+    static const int per_cu_env = [] { const char* e = getenv("FQ_CHAIN_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    static const int min_chunks_env = [] { const char* e = getenv("FQ_CHAIN_MIN_CHUNKS"); return e ? atoi(e) : 0; }();
+    if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
     const uint64_t slots = (uint64_t)kCUs * per_cu;
     uint64_t per_wg = (chunks + slots - 1) / slots;
-    if (per_wg < kMinChunksPerWg) per_wg = kMinChunksPerWg;
+    const uint64_t min_chunks = min_chunks_env > 0 ? (uint64_t)min_chunks_env : (uint64_t)kChainMinChunks;
+    if (per_wg < min_chunks) per_wg = min_chunks;
     a.chunks_per_wg = (uint32_t)per_wg;
     a.total_chunks = (uint32_t)chunks;
     static bool lds_ok[kMaxDevices] = {};
