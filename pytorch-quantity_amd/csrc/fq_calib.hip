@@ -348,7 +348,7 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_pair_seg_kernel(const Pai
 // instead of the 3 L x 4 of writing, keeping and re-reading every sum.  2 L histograms of 2048 32-bit bins in LDS (dynamic:
 // 16 KB per block of the chain), 512 threads, as many workgroups per CU as that leaves room for, each with an equal run of 16 KB
 // chunks; the 16-byte loads of all L + 1 streams of two vectors are in flight together.
-constexpr int kChainBlock = 512;
+constexpr int kChainThreadsOnePerCu = 512;   // (1024 measured: scripts/chain_hist_probe.py)
 constexpr int kChainMinChunks = 4;      // chunks (16 KB of every stream) per workgroup at least: amortises zeroing + flushing 2 L x 2048 bins
 template <int L>
 struct ChainArgs {
@@ -360,7 +360,7 @@ struct ChainArgs {
     uint32_t chunks_per_wg, total_chunks;
 };
 
-template <int L, bool kFast>
+template <int L, bool kFast, int kChainBlock>
 __device__ __forceinline__ void chain_body(const ChainArgs<L>& t, const float* __restrict__ interval, unsigned int* bins) {
     // bins: [2 L][FQ_BINS] then kWave parking slots; histogram 2 k = y_k, 2 k + 1 = S_k
     float ivy[L], ivs[L], ry[L], rs[L];
@@ -434,7 +434,7 @@ __device__ __forceinline__ void chain_body(const ChainArgs<L>& t, const float* _
     }
 }
 
-template <int L>
+template <int L, int kChainBlock>
 __global__ __launch_bounds__(kChainBlock) void hist2048_chain_kernel(const ChainArgs<L> t, const float* __restrict__ interval,
                                                                   unsigned long long* __restrict__ hist, const int allow_fast) {
     extern __shared__ __attribute__((aligned(16))) unsigned int chain_bins[];
@@ -446,8 +446,8 @@ __global__ __launch_bounds__(kChainBlock) void hist2048_chain_kernel(const Chain
         if (t.row_y[k] >= 0) fast = fast && fast_quotient_ok(interval[t.row_y[k]]);
         fast = fast && fast_quotient_ok(interval[t.row_s[k]]);
     }
-    if (fast) chain_body<L, true>(t, interval, chain_bins);
-    else chain_body<L, false>(t, interval, chain_bins);
+    if (fast) chain_body<L, true, kChainBlock>(t, interval, chain_bins);
+    else chain_body<L, false, kChainBlock>(t, interval, chain_bins);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < L; ++k) {
@@ -910,6 +910,16 @@ extern "C" int fq_hist_seg_n(const fq_seg* segs, int nseg, const float* interval
 }
 
 namespace fq {
+template <int L, int TB>
+static int launch_chain_tb(const ChainArgs<L>& a, uint64_t chunks, uint64_t per_wg, size_t lds, const float* interval, int64_t* hist, hipStream_t st) {
+    static bool lds_ok[kMaxDevices] = {};
+    if (lds > 64 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(hist2048_chain_kernel<L, TB>), (int)lds, lds_ok)) return FQ_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((hist2048_chain_kernel<L, TB>), dim3((uint32_t)((chunks + per_wg - 1) / per_wg)), dim3(TB), lds, st, a, interval,
+                       reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
+    FQ_LAUNCH_CHECK();
+    return FQ_OK;
+}
+
 template <int L>
 static int launch_chain(const fq_chain_seg& c, const float* interval, int64_t* hist, hipStream_t st) {
     ChainArgs<L> a;
@@ -924,9 +934,10 @@ static int launch_chain(const fq_chain_seg& c, const float* interval, int64_t* h
     int per_cu = (int)((size_t)150 * 1024 / lds);                 // 160 KB of LDS per CU, some of it the runtime's
     if (per_cu > 3) per_cu = 3;
     if (per_cu < 1) per_cu = 1;
-    // FQ_CHAIN_WG_PER_CU / FQ_CHAIN_MIN_CHUNKS: tuning knobs (scripts/chain_hist_probe.py)
+    // FQ_CHAIN_WG_PER_CU / FQ_CHAIN_MIN_CHUNKS / FQ_CHAIN_THREADS: tuning knobs (scripts/chain_hist_probe.py)
     static const int per_cu_env = [] { const char* e = getenv("FQ_CHAIN_WG_PER_CU"); return e ? atoi(e) : 0; }();
     static const int min_chunks_env = [] { const char* e = getenv("FQ_CHAIN_MIN_CHUNKS"); return e ? atoi(e) : 0; }();
+    static const int threads_env = [] { const char* e = getenv("FQ_CHAIN_THREADS"); return e ? atoi(e) : 0; }();
     if (per_cu_env > 0 && per_cu_env < per_cu) per_cu = per_cu_env;
     const uint64_t slots = (uint64_t)kCUs * per_cu;
     uint64_t per_wg = (chunks + slots - 1) / slots;
@@ -934,12 +945,10 @@ static int launch_chain(const fq_chain_seg& c, const float* interval, int64_t* h
     if (per_wg < min_chunks) per_wg = min_chunks;
     a.chunks_per_wg = (uint32_t)per_wg;
     a.total_chunks = (uint32_t)chunks;
-    static bool lds_ok[kMaxDevices] = {};
-    if (lds > 64 * 1024 && !ensure_dynamic_lds(reinterpret_cast<const void*>(hist2048_chain_kernel<L>), (int)lds, lds_ok)) return FQ_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(hist2048_chain_kernel<L>, dim3((uint32_t)((chunks + per_wg - 1) / per_wg)), dim3(kChainBlock), lds, st, a, interval,
-                       reinterpret_cast<unsigned long long*>(hist), hist_fast_quotient_enabled());
-    FQ_LAUNCH_CHECK();
-    return FQ_OK;
+    // a workgroup of 16 waves where the LDS leaves room for one workgroup only (L >= 5): as many waves per CU as two of 8
+    const int threads = threads_env == 512 || threads_env == 1024 ? threads_env : (per_cu == 1 ? kChainThreadsOnePerCu : 512);
+    if (threads == 1024) return launch_chain_tb<L, 1024>(a, chunks, per_wg, lds, interval, hist, st);
+    return launch_chain_tb<L, 512>(a, chunks, per_wg, lds, interval, hist, st);
 }
 
 }  // namespace fq
