@@ -348,8 +348,8 @@ __global__ __launch_bounds__(kHistBlock) void hist2048_pair_seg_kernel(const Pai
 // instead of the 3 L x 4 of writing, keeping and re-reading every sum.  2 L histograms of 2048 32-bit bins in LDS (dynamic:
 // 16 KB per block of the chain), 512 threads, as many workgroups per CU as that leaves room for, each with an equal run of 16 KB
 // chunks; the 16-byte loads of all L + 1 streams of two vectors are in flight together.
-constexpr int kChainThreadsOnePerCu = 512;   // (1024 measured: scripts/chain_hist_probe.py)
-constexpr int kChainMinChunks = 4;      // chunks (16 KB of every stream) per workgroup at least: amortises zeroing + flushing 2 L x 2048 bins
+constexpr int kChainThreadsOnePerCu = 1024;  // L >= 5 leaves LDS for ONE workgroup per CU: 16 waves instead of 8 (stage 3: 294 -> 261 us, profiles/r06_chain_hist_probe.txt)
+constexpr int kChainMinChunks = 16;     // chunks (16 KB of every stream) per workgroup at least: amortises zeroing + flushing 2 L x 2048 bins
 template <int L>
 struct ChainArgs {
     const float* head;
